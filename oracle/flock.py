@@ -1,0 +1,187 @@
+"""fp64 numpy restatement of the flocking simulation (TEST ORACLE) -- PARITY UNPINNED.
+
+The reference only *imports* the environment (third-party package `gym_flock`,
+github.com/katetolstaya/gym-flock, version unpinned: reference README.md:7, train.py:6);
+its source is not under /root/reference and is not installed here, so nothing in this
+file can be checked against the real environment.  It restates THIS repo's own written
+spec, "FLOCK-SPEC v1" (DESIGN.md), which was designed to satisfy the reference's
+call-site contract:
+
+  reset() -> (values (N,6) f64, network (N,N) f64 with zero diagonal)   state_with_delay.py:22-26
+  step(u (N,2)) -> ((values, network), reward, done, info)               gnn_dagger.py:163
+  controller(centralized=None) -> (N,2)                                  gnn_dagger.py:156, gnn_baseline.py:16
+  params_from_cfg(section): n_agents, comm_radius, v_max, dt             train.py:20-21, cfg/dagger.cfg:24-32
+
+Every constant is a named field of FlockParams.  All arithmetic is fp64 with the exact
+operation order written below (no fused multiply-add), so a device kernel using the
+same order reproduces the adjacency bit-for-bit and the sums to rounding.
+"""
+from dataclasses import dataclass, replace
+import numpy as np
+
+
+@dataclass(frozen=True)
+class FlockParams:
+    n_agents: int = 100
+    comm_radius: float = 1.0
+    v_max: float = 3.0
+    v_bias: float = 3.0          # common velocity offset range at reset (defaults to v_max)
+    dt: float = 0.01
+    max_rad_init: float = 2.0    # r_max = max_rad_init * sqrt(n_agents); positions in disc of radius sqrt(r_max)
+    action_gain: float = 10.0    # step applies u * action_gain
+    max_accel: float = 1.0       # |u| clipped to this before the gain
+    ctrl_gain: float = 0.1       # controller output = clip(raw, +-ctrl_clip) * ctrl_gain
+    ctrl_clip: float = 10.0
+    min_dist_thresh: float = 0.1 # reset rejection: minimum pairwise distance
+    min_degree: int = 2          # reset rejection: minimum node degree
+    reward_scale: float = 1.0
+    mean_pooling: bool = True    # network = adj / max(deg,1) ; else raw 0/1 adjacency
+    max_episode_steps: int = 500 # TimeLimit equivalent (`done` after this many steps)
+    # variant knobs (FLOCK-SPEC v1 variants, see multiagent_gnn_policies_amd/envs)
+    n_leaders: int = 0           # FlockingLeader: first n_leaders agents ignore u and keep their velocity
+    two_flocks: bool = False     # FlockingTwoFlocks: reset draws two groups with opposite bias
+
+    @property
+    def comm_radius2(self):
+        return self.comm_radius * self.comm_radius
+
+    @property
+    def r_max(self):
+        return self.max_rad_init * np.sqrt(self.n_agents)
+
+
+def params_from_cfg(section, base=None):
+    """Mirror of the env's params_from_cfg(args) call (train.py:20-21)."""
+    p = base or FlockParams()
+    kw = dict(n_agents=section.getint('n_agents'),
+              comm_radius=section.getfloat('comm_radius'),
+              v_max=section.getfloat('v_max'),
+              v_bias=section.getfloat('v_max'))
+    if section.get('dt') is not None:
+        kw['dt'] = section.getfloat('dt')
+    return replace(p, **kw)
+
+
+# --------------------------------------------------------------------------- dynamics
+def integrate(x, u, p):
+    """x (N,4) = (px,py,vx,vy) fp64; u (N,2).  Returns the new x.  Double integrator.
+
+    ue = clip(u, +-max_accel) * action_gain
+    p' = (p + v*dt) + ((ue*dt)*dt)*0.5 ;  v' = v + ue*dt
+    Leaders (first n_leaders rows) use ue = 0.
+    """
+    x = np.array(x, dtype=np.float64, copy=True)
+    ue = np.clip(np.asarray(u, dtype=np.float64), -p.max_accel, p.max_accel) * p.action_gain
+    if p.n_leaders > 0:
+        ue = ue.copy()
+        ue[:p.n_leaders] = 0.0
+    dt = np.float64(p.dt)
+    x[:, 0] = (x[:, 0] + x[:, 2] * dt) + ((ue[:, 0] * dt) * dt) * 0.5
+    x[:, 1] = (x[:, 1] + x[:, 3] * dt) + ((ue[:, 1] * dt) * dt) * 0.5
+    x[:, 2] = x[:, 2] + ue[:, 0] * dt
+    x[:, 3] = x[:, 3] + ue[:, 1] * dt
+    return x
+
+
+def helpers(x, p):
+    """Pairwise quantities.  Returns dict(diff (N,N,4), r2 (N,N) with +inf diagonal,
+    adj (N,N) 0/1 f64, deg (N,), network (N,N) f64, values (N,6) f64)."""
+    x = np.asarray(x, dtype=np.float64)
+    n = x.shape[0]
+    diff = x.reshape(n, 1, 4) - x.reshape(1, n, 4)          # diff[i,j] = x_i - x_j
+    r2 = diff[:, :, 0] * diff[:, :, 0] + diff[:, :, 1] * diff[:, :, 1]
+    np.fill_diagonal(r2, np.inf)
+    adj = (r2 < p.comm_radius2).astype(np.float64)
+    deg = adj.sum(axis=1)
+    degc = np.where(deg == 0, 1.0, deg)
+    network = adj / degc[:, None] if p.mean_pooling else adj.copy()
+    r4 = r2 * r2
+    feats = np.stack([diff[:, :, 2], diff[:, :, 0] / r4, diff[:, :, 0] / r2,
+                      diff[:, :, 3], diff[:, :, 1] / r4, diff[:, :, 1] / r2], axis=2)
+    values = np.zeros((n, 6), dtype=np.float64)
+    for j in range(n):                                       # sequential-j summation order
+        values += feats[:, j, :] * adj[:, j, None]
+    return dict(diff=diff, r2=r2, adj=adj, deg=deg, network=network, values=values)
+
+
+def reward(x, p):
+    """-(var(vx) + var(vy)) * reward_scale, population variance."""
+    v = np.asarray(x, dtype=np.float64)[:, 2:4]
+    return float(-1.0 * np.sum(np.var(v, axis=0)) * p.reward_scale)
+
+
+def potential_grad(d, r2, p):
+    """d/dx of 1/r^2 + log r^2 :  -2 d / r^4 + 2 d / r^2, zero beyond the comm radius."""
+    g = -2.0 * (d / (r2 * r2)) + 2.0 * (d / r2)
+    g = np.where(r2 > p.comm_radius2, 0.0, g)
+    return g
+
+
+def controller(x, p, centralized=False):
+    """Expert: u_i = -sum_j (v_i - v_j) - sum_j grad U(r_ij); neighbour-masked unless centralized.
+    Output clip(raw, +-ctrl_clip) * ctrl_gain, shape (N,2)."""
+    h = helpers(x, p)
+    diff, r2, adj = h['diff'], h['r2'], h['adj']
+    gx = potential_grad(diff[:, :, 0], r2, p)
+    gy = potential_grad(diff[:, :, 1], r2, p)
+    n = diff.shape[0]
+    terms = np.stack([diff[:, :, 2], diff[:, :, 3], gx, gy], axis=2)
+    if not centralized:
+        terms = terms * adj[:, :, None]
+    else:
+        eye = np.eye(n, dtype=bool)
+        terms = np.where(eye[:, :, None], 0.0, terms)
+    s = np.zeros((n, 4), dtype=np.float64)
+    for j in range(n):
+        s += terms[:, j, :]
+    raw = np.stack([-s[:, 2] - s[:, 0], -s[:, 1] - s[:, 3]], axis=1)
+    return np.clip(raw, -p.ctrl_clip, p.ctrl_clip) * p.ctrl_gain
+
+
+def step(x, u, p):
+    """One env step: integrate then recompute helpers.  Returns (x', values, network, reward)."""
+    x2 = integrate(x, u, p)
+    h = helpers(x2, p)
+    return x2, h['values'], h['network'], reward(x2, p)
+
+
+# --------------------------------------------------------------------------- reset
+def sample_candidate(rng, p):
+    """One draw of the reset distribution; RNG call ORDER is part of the spec:
+    length(N) ; angle(N) ; bias(2) ; vx(N) ; vy(N).  `rng` is numpy's global-RNG-like API."""
+    n = p.n_agents
+    x = np.zeros((n, 4), dtype=np.float64)
+    length = np.sqrt(rng.uniform(0, p.r_max, size=(n,)))
+    angle = np.pi * rng.uniform(0, 2, size=(n,))
+    x[:, 0] = length * np.cos(angle)
+    x[:, 1] = length * np.sin(angle)
+    bias = rng.uniform(low=-p.v_bias, high=p.v_bias, size=(2,))
+    x[:, 2] = rng.uniform(low=-p.v_max, high=p.v_max, size=(n,)) + bias[0]
+    x[:, 3] = rng.uniform(low=-p.v_max, high=p.v_max, size=(n,)) + bias[1]
+    if p.two_flocks:
+        half = n // 2
+        x[:half, 0] -= np.sqrt(p.r_max)
+        x[half:, 0] += np.sqrt(p.r_max)
+        x[:half, 2] = x[:half, 2] - bias[0] + abs(bias[0])
+        x[half:, 2] = x[half:, 2] - bias[0] - abs(bias[0])
+    return x
+
+
+def candidate_ok(x, p):
+    pos = x[:, 0:2]
+    d = pos[:, None, :] - pos[None, :, :]
+    r2 = d[:, :, 0] * d[:, :, 0] + d[:, :, 1] * d[:, :, 1]
+    np.fill_diagonal(r2, np.inf)
+    min_dist = np.sqrt(r2.min())
+    degree = (r2 < p.comm_radius2).sum(axis=1).min()
+    return degree >= p.min_degree and min_dist >= p.min_dist_thresh
+
+
+def reset(rng, p, max_tries=100000):
+    """Rejection-sample an initial configuration with min degree >= min_degree and
+    min pairwise distance >= min_dist_thresh."""
+    for _ in range(max_tries):
+        x = sample_candidate(rng, p)
+        if candidate_ok(x, p):
+            return x
+    raise RuntimeError("flock reset: no admissible configuration found")
