@@ -1,0 +1,177 @@
+/*
+ * mgp.h -- C ABI of libmgp.so: the MI355X (gfx950) hot path of the multi-agent GNN
+ * flocking policy.  Every entry point replaces a piece of arithmetic that the reference
+ * (katetolstaya/multiagent_gnn_policies) dispatches to stock ATen ops or to the external
+ * gym_flock package.  The reference has no FFI of its own; the interface each function
+ * stands in for is cited as reference file:line.  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer into caller-owned memory (e.g. torch tensors),
+ *     row-major, contiguous unless strides are passed; strides are in ELEMENTS;
+ *   - fp32 unless the name says f64; sizes are plain ints;
+ *   - work is ENQUEUED on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *     nothing synchronises, allocates or keeps state between calls -> re-entrant per stream,
+ *     HIP-graph capturable;
+ *   - return 0 on success or a negative MGP_E* code; never throws.  mgp_strerror() maps
+ *     codes to text.
+ */
+#ifndef MGP_H
+#define MGP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGP_VERSION 100            /* 0.1.0 */
+
+#define MGP_OK            0
+#define MGP_EINVAL       -1        /* bad size / null pointer / unsupported combination */
+#define MGP_EALIGN       -2        /* pointer not 4-byte aligned */
+#define MGP_ELAUNCH      -3        /* hipLaunchKernel reported an error */
+#define MGP_ENODEV       -4        /* no HIP device / wrong architecture */
+#define MGP_EUNSUPPORTED -5        /* valid request the fused kernel does not cover: use the composed ops */
+
+#define MGP_ACT_NONE 0
+#define MGP_ACT_TANH 1
+
+#define MGP_MAX_LAYERS 8
+
+int         mgp_version(void);
+const char* mgp_strerror(int code);
+/* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or a negative code. */
+int         mgp_device_info(char* name, int cap);
+
+/* ------------------------------------------------------------------------------------
+ * Graph-shift aggregation                        reference learner/actor.py:69-71
+ *   Y[b,k,c,n] = sum_m X[b,k,c,m] * G[b,k,m,n]        (torch.matmul(x, delay_gso))
+ * G is (B,K,N,N) contiguous.  X and Y are addressed through (b,k,c) strides with n
+ * contiguous, so both the input layout (B,K,C,N) and the reference's permuted layout
+ * (B,C,K,N) (actor.py:64,71) are served without a copy.
+ * ------------------------------------------------------------------------------------ */
+int mgp_agg_fwd(const float* X, const float* G, float* Y,
+                int B, int K, int C, int N,
+                long sxb, long sxk, long sxc,
+                long syb, long syk, long syc,
+                void* stream);
+
+/* Backward of the aggregation w.r.t. X           autograd of actor.py:70
+ *   dX[b,k,c,m] = sum_n dY[b,k,c,n] * G[b,k,m,n]                                   */
+int mgp_agg_bwd_x(const float* dY, const float* G, float* dX,
+                  int B, int K, int C, int N,
+                  long sgb, long sgk, long sgc,      /* dY strides */
+                  long sdb, long sdk, long sdc,      /* dX strides */
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Per-agent dense layer = the reference's Conv2d with kernel (step,1), stride (step,1)
+ *                                                 reference learner/actor.py:37-38,73-77
+ *   out[b,o,t,n] = act( bias[o] + sum_c W[o,c] * in[b,c,t,n] )
+ * `in` is addressed by (b,c,t) strides, n contiguous; `out` is (B,Cout,T,N) contiguous.
+ * The (k,1) feature filter at layer ind_agg is the case Cin = C*K, T = 1 with
+ * W (out, C, K, 1) viewed as (out, C*K).
+ * ------------------------------------------------------------------------------------ */
+int mgp_dense_fwd(const float* in, const float* W, const float* bias, float* out,
+                  int B, int Cin, int Cout, int T, int N,
+                  long sib, long sic, long sit,
+                  int act, void* stream);
+
+/* Backward of the dense layer                     autograd of actor.py:73-77
+ *   delta = dOut * act'(out) ; dW[o,c] = sum delta*in ; db[o] = sum delta ;
+ *   dIn[b,c,t,n] = sum_o W[o,c] * delta[b,o,t,n]   (dIn contiguous (B,Cin,T,N); may be NULL)
+ * `workspace` must hold mgp_dense_bwd_workspace(...) floats.  Deterministic (no atomics). */
+long mgp_dense_bwd_workspace(int B, int Cin, int Cout, int T, int N);
+int  mgp_dense_bwd(const float* dOut, const float* out, const float* in, const float* W,
+                   float* dW, float* db, float* dIn,
+                   int B, int Cin, int Cout, int T, int N,
+                   long sib, long sic, long sit,
+                   int act, float* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused Actor forward, aggregation before layer 0 (ind_agg == 0: the only configuration
+ * train.py reaches, gnn_dagger.py:43, gnn_cloning.py:41)
+ *                                                 reference learner/actor.py:45-86
+ *   out (B,1,nA,N) = MLP( X . G )   with X (B,K,F,N), G (B,K,N,N) contiguous.
+ * W[i] / b[i]: HOST arrays of n_layers device pointers, W[i] shaped (dims[i+1], dims[i]*(i==0?K:1)),
+ * dims = {F, h_1, ..., nA} (n_layers+1 ints).
+ * `saved` (may be NULL for inference) receives what mgp_actor_bwd needs:
+ *   [ Y (B, F*K, N) | Z_0 (B,h_1,N) | ... | Z_{L-2} (B,h_{L-1},N) ],  mgp_actor_saved_floats() floats.
+ * Returns MGP_EUNSUPPORTED for shapes the fused kernel does not cover (caller composes
+ * mgp_agg_fwd + mgp_dense_fwd instead).
+ * ------------------------------------------------------------------------------------ */
+long mgp_actor_saved_floats(const int* dims, int n_layers, int B, int K, int N);
+int  mgp_actor_fwd(const float* X, const float* G,
+                   const float* const* W, const float* const* b,
+                   const int* dims, int n_layers,
+                   float* out, float* saved,
+                   int B, int K, int N, void* stream);
+
+/* Backward of the fused Actor forward (parameters only; X and G are leaves without grad
+ * in DAGGER, gnn_dagger.py:83-92).  dW[i]/db[i]: HOST arrays of device pointers (overwritten). */
+long mgp_actor_bwd_workspace(const int* dims, int n_layers, int B, int K, int N);
+int  mgp_actor_bwd(const float* dOut, const float* saved,
+                   const float* const* W, const int* dims, int n_layers,
+                   float* const* dW, float* const* db,
+                   int B, int K, int N, float* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Delayed-GSO / delay-line update                 reference learner/state_with_delay.py:44-53
+ *   G_next[b,0] = I ; G_next[b,j] = A[b] @ G_prev[b,j-1] (j>=1; 0 if !has_prev)
+ *   Xd_next[b,0] = X_t[b] ; Xd_next[b,j] = Xd_prev[b,j-1]   (0 if !has_prev)
+ * A (B,N,N), G_* (B,K,N,N), X_t (B,F,N), Xd_* (B,K,F,N).  G_prev[b,0] is the identity by
+ * construction (state_with_delay.py:45) and is not read: G_next[b,1] = A[b] exactly.
+ * G_prev/Xd_prev may be NULL iff has_prev == 0.  next buffers must not alias prev.
+ * ------------------------------------------------------------------------------------ */
+int mgp_gso_update(const float* A, const float* G_prev, float* G_next,
+                   const float* X_t, const float* Xd_prev, float* Xd_next,
+                   int B, int K, int F, int N, int has_prev, void* stream);
+
+/* curr_gso: powers of the current adjacency      reference learner/state_with_delay.py:38-41
+ *   P[b,0] = I ; P[b,j] = A[b] @ P[b,j-1]                                            */
+int mgp_gso_powers(const float* A, float* P, int B, int K, int N, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Flocking simulation (gym_flock is NOT part of the reference tree: own spec FLOCK-SPEC v1,
+ * DESIGN.md).  Call sites replaced: env.step gnn_dagger.py:163, env.env.controller
+ * gnn_dagger.py:156 / gnn_baseline.py:16, observation tuple state_with_delay.py:22-26.
+ * State x is fp64 (B,N,4) = (px,py,vx,vy); all pairwise arithmetic is fp64.
+ * ------------------------------------------------------------------------------------ */
+typedef struct MgpFlockParams {
+    double comm_radius2;   /* squared communication radius                        */
+    double dt;             /* integration step                                    */
+    double action_gain;    /* step applies clip(u) * action_gain                  */
+    double max_accel;      /* |u| clip                                            */
+    double ctrl_gain;      /* controller output scale                             */
+    double ctrl_clip;      /* controller raw clip                                 */
+    double reward_scale;
+    int    mean_pooling;   /* network = adj / max(deg,1) if nonzero               */
+    int    n_leaders;      /* first n_leaders agents ignore u                     */
+} MgpFlockParams;
+
+/* x <- integrate(x, u) in place (u (B,N,2) fp32, may be NULL = zero action / refresh only), then
+ *   A    (B,N,N) fp32  network matrix           (may be NULL)
+ *   A64  (B,N,N) fp64  same, fp64               (may be NULL; gym facade)
+ *   feat (B,6,N) fp32  features TRANSPOSED to the (F,N) layout state_with_delay.py:29 builds (may be NULL)
+ *   feat64 (B,N,6) fp64 features in the env's own (N,6) layout (may be NULL; gym facade)
+ *   reward (B) fp64    -(var vx + var vy) * reward_scale  (may be NULL)                       */
+int mgp_flock_step(double* x, const float* u, float* A, double* A64, float* feat, double* feat64,
+                   double* reward, const MgpFlockParams* p, int B, int N, void* stream);
+
+/* Expert controller on the current x: u (B,N,2) fp32 and/or u64 (B,N,2) fp64 (either may be NULL). */
+int mgp_flock_controller(const double* x, float* u, double* u64, const MgpFlockParams* p,
+                         int centralized, int B, int N, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * DAGGER update helpers                            reference learner/gnn_dagger.py:91-93
+ *   mgp_mse_grad : loss[0] = mean((pred-target)^2) ; dPred = 2 (pred-target) / n
+ *   mgp_adam_step: torch.optim.Adam defaults on one flat fp32 buffer (step = 1-based count)
+ * ------------------------------------------------------------------------------------ */
+int mgp_mse_grad(const float* pred, const float* target, float* dPred, float* loss,
+                 long n, void* stream);
+int mgp_adam_step(float* param, const float* grad, float* m, float* v, long n,
+                  float lr, float beta1, float beta2, float eps, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGP_H */

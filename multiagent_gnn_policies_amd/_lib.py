@@ -1,0 +1,109 @@
+"""ctypes binding of libmgp.so (the C ABI declared in include/mgp.h).
+
+The product has NO CPU fallback: if the library cannot be loaded every op raises.  Loading the
+library itself needs no GPU (the CPU test-suite checks that it loads and exports every symbol).
+"""
+import ctypes
+import os
+import re
+import threading
+
+from . import build as _build
+
+_c_float_p = ctypes.POINTER(ctypes.c_float)
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_vp = ctypes.c_void_p
+_int = ctypes.c_int
+_long = ctypes.c_long
+_f32 = ctypes.c_float
+
+
+class MgpFlockParams(ctypes.Structure):
+    """Mirror of struct MgpFlockParams (include/mgp.h)."""
+    _fields_ = [('comm_radius2', ctypes.c_double), ('dt', ctypes.c_double), ('action_gain', ctypes.c_double),
+                ('max_accel', ctypes.c_double), ('ctrl_gain', ctypes.c_double), ('ctrl_clip', ctypes.c_double),
+                ('reward_scale', ctypes.c_double), ('mean_pooling', ctypes.c_int), ('n_leaders', ctypes.c_int)]
+
+
+# name -> (restype, argtypes).  Pointers are passed as raw integers (tensor.data_ptr()).
+SIGNATURES = {
+    'mgp_version': (_int, []),
+    'mgp_strerror': (ctypes.c_char_p, [_int]),
+    'mgp_device_info': (_int, [ctypes.c_char_p, _int]),
+    'mgp_agg_fwd': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _long, _long, _long, _long, _long, _long, _vp]),
+    'mgp_agg_bwd_x': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _long, _long, _long, _long, _long, _long, _vp]),
+    'mgp_dense_fwd': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _long, _long, _long, _int, _vp]),
+    'mgp_dense_bwd_workspace': (_long, [_int, _int, _int, _int, _int]),
+    'mgp_dense_bwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _long, _long, _long,
+                             _int, _vp, _vp]),
+    'mgp_actor_saved_floats': (_long, [ctypes.POINTER(_int), _int, _int, _int, _int]),
+    'mgp_actor_fwd': (_int, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_int), _int,
+                             _vp, _vp, _int, _int, _int, _vp]),
+    'mgp_actor_bwd_workspace': (_long, [ctypes.POINTER(_int), _int, _int, _int, _int]),
+    'mgp_actor_bwd': (_int, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_int), _int, ctypes.POINTER(_vp),
+                             ctypes.POINTER(_vp), _int, _int, _int, _vp, _vp]),
+    'mgp_gso_update': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
+    'mgp_gso_powers': (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    'mgp_flock_step': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(MgpFlockParams), _int, _int, _vp]),
+    'mgp_flock_controller': (_int, [_vp, _vp, _vp, ctypes.POINTER(MgpFlockParams), _int, _int, _int, _vp]),
+    'mgp_mse_grad': (_int, [_vp, _vp, _vp, _vp, _long, _vp]),
+    'mgp_adam_step': (_int, [_vp, _vp, _vp, _vp, _long, _f32, _f32, _f32, _f32, _int, _vp]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class MgpError(RuntimeError):
+    pass
+
+
+def header_symbols():
+    """Names of every function include/mgp.h declares (used by the CPU symbol test)."""
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'mgp.h')
+    with open(hdr) as f:
+        text = f.read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(mgp_[a-z0-9_]+)\s*\(', text)))
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Builds the library if it is missing and hipcc exists."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = _build.LIB_PATH
+        if not os.path.exists(path):
+            try:
+                _build.build(verbose=False)
+            except Exception as e:  # loud, never a silent fallback
+                raise MgpError("libmgp.so is missing and could not be built: %s" % e)
+        try:
+            handle = ctypes.CDLL(path)
+        except OSError as e:
+            raise MgpError("cannot load %s: %s" % (path, e))
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError:
+                raise MgpError("libmgp.so does not export %s (stale build? run python -m "
+                               "multiagent_gnn_policies_amd.build --force)" % name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.mgp_version() <= 0:
+            raise MgpError("libmgp.so reports an invalid version")
+        _lib = handle
+        return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().mgp_strerror(rc)
+        raise MgpError("%s failed: %s (code %d)" % (what, msg.decode() if msg else '?', rc))
+
+
+def strerror(rc):
+    return lib().mgp_strerror(rc).decode()

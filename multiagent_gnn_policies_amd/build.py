@@ -1,0 +1,93 @@
+"""Builds libmgp.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m multiagent_gnn_policies_amd.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU.  Objects go to csrc/build/ (git-ignored); the
+shared library lands next to this file so it travels with the repo snapshot to the GPU box.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, 'csrc')
+OBJ_DIR = os.path.join(CSRC, 'build')
+LIB_PATH = os.path.join(PKG_DIR, 'libmgp.so')
+STAMP = os.path.join(OBJ_DIR, 'libmgp.srchash')
+
+ARCH = 'gfx950'
+COMMON_FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+# flock.hip must reproduce numpy's op-by-op fp64 rounding: no fused multiply-add contraction
+PER_FILE_FLAGS = {'flock.hip': ['-ffp-contract=off']}
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def source_hash():
+    h = hashlib.sha256()
+    names = sources() + sorted(f for f in os.listdir(CSRC) if f.endswith('.h'))
+    names.append(os.path.join('..', '..', 'include', 'mgp.h'))
+    for n in names:
+        with open(os.path.join(CSRC, n), 'rb') as f:
+            h.update(n.encode())
+            h.update(f.read())
+    h.update(' '.join(COMMON_FLAGS).encode())
+    return h.hexdigest()
+
+
+def hipcc_path():
+    p = shutil.which('hipcc')
+    if p is None and os.path.exists('/opt/rocm/bin/hipcc'):
+        p = '/opt/rocm/bin/hipcc'
+    return p
+
+
+def is_current():
+    if not (os.path.exists(LIB_PATH) and os.path.exists(STAMP)):
+        return False
+    with open(STAMP) as f:
+        return f.read().strip() == source_hash()
+
+
+def build(force=False, verbose=True):
+    """Compile every .hip under csrc/ for gfx950 and link libmgp.so.  Returns the library path."""
+    if not force and is_current():
+        return LIB_PATH
+    hipcc = hipcc_path()
+    if hipcc is None:
+        raise RuntimeError("hipcc not found: cannot build libmgp.so (ROCm toolchain required)")
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    objs = []
+    procs = []
+    for src in sources():
+        obj = os.path.join(OBJ_DIR, src[:-4] + '.o')
+        cmd = [hipcc] + COMMON_FLAGS + PER_FILE_FLAGS.get(src, []) + ['-c', os.path.join(CSRC, src), '-o', obj]
+        if verbose:
+            print('[mgp build]', ' '.join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors='replace')))
+        if verbose and out.strip():
+            print(out.decode(errors='replace'))
+    tmp = LIB_PATH + '.tmp'
+    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', tmp] + objs
+    if verbose:
+        print('[mgp build]', ' '.join(cmd), flush=True)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s" % r.stdout.decode(errors='replace'))
+    os.replace(tmp, LIB_PATH)
+    with open(STAMP, 'w') as f:
+        f.write(source_hash())
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,272 @@
+// Graph-shift aggregation  Y[b,k,c,n] = sum_m X[b,k,c,m] * G[b,k,m,n]   (reference actor.py:69-71)
+// and its backward w.r.t. X  dX[b,k,c,m] = sum_n dY[b,k,c,n] * G[b,k,m,n].
+//
+// HBM-bound: 2*C flops per 4 bytes of G (C = 6 -> 3 flop/B, ridge is ~20 flop/B).  The design goal is
+// therefore to read every byte of the dense (B,K,N,N) operator exactly once, fully coalesced:
+//   * the contraction index m is the ROW index of G, so a workgroup that owns whole rows streams
+//     G[b,k] as one flat array of float4 (N <= 256), or as 1 KiB row segments (N > 256);
+//   * a thread owns V=4 adjacent output columns and CT channels (CT*V accumulators) and walks down
+//     the rows with stride R = 256/colgroups; the X[b,k] tile is staged TRANSPOSED in LDS ([m][c]) so the
+//     CT multipliers of one row come from one or two wide, mostly-broadcast ds_reads;
+//   * the R row-phases are combined through LDS in a fixed order (deterministic, no atomics).
+#include "mgp_common.h"
+
+namespace {
+
+constexpr int AGG_THREADS = 256;
+constexpr int AGG_UNROLL = 8;       // rows in flight per thread
+constexpr int AGG_RED_CH = 8;       // channels reduced per LDS pass
+
+template <int V> struct VecLoad;
+template <> struct VecLoad<4> {
+    static __device__ __forceinline__ void load(const float* p, float (&g)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
+    }
+};
+template <> struct VecLoad<1> {
+    static __device__ __forceinline__ void load(const float* p, float (&g)[1]) { g[0] = *p; }
+};
+
+// grid: x = column tile + ntiles * channel chunk, y = k, z = b
+template <int CT, int V>
+__global__ __launch_bounds__(AGG_THREADS)
+void agg_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G, float* __restrict__ Y,
+                    int K, int C, int N, int tw, int ntiles, int MC,
+                    long sxb, long sxk, long sxc, long syb, long syk, long syc)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tile = blockIdx.x % ntiles;
+    const int c0 = (blockIdx.x / ntiles) * CT;
+    const int k = blockIdx.y, b = blockIdx.z;
+    const int n0 = tile * tw;
+    const int cols = min(tw, N - n0);
+    const int cgt = (cols + V - 1) / V;          // column groups in this tile (<= 256)
+    const int R = AGG_THREADS / cgt;             // row phases
+    const int twp = cgt * V;
+    const int tid = threadIdx.x;
+    const int cg = tid % cgt, r = tid / cgt;
+    const bool active = r < R;
+
+    float* xs = smem;                            // [MC][CT]
+    float* red = smem + (size_t)MC * CT;         // [R][AGG_RED_CH][twp]
+
+    float acc[CT][V];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[c][v] = 0.f;
+
+    const float* Gbk = G + ((size_t)b * K + k) * (size_t)N * N + n0 + cg * V;
+    const float* Xbk = X + b * sxb + k * sxk;
+    // a V=1 tail lane past the tile edge only happens when V==1 (cols % 4 == 0 is required for V=4)
+    const bool col_ok = (cg * V) < cols;
+
+    for (int m0 = 0; m0 < N; m0 += MC) {
+        const int mc = min(MC, N - m0);
+        __syncthreads();
+        for (int i = tid; i < mc * CT; i += AGG_THREADS) {
+            const int c = i / mc, mm = i - c * mc;
+            xs[mm * CT + c] = (c0 + c < C) ? Xbk[(c0 + c) * sxc + m0 + mm] : 0.f;
+        }
+        __syncthreads();
+        if (active && col_ok) {
+            for (int mm = r; mm < mc; mm += R * AGG_UNROLL) {
+                float g[AGG_UNROLL][V];
+#pragma unroll
+                for (int u = 0; u < AGG_UNROLL; ++u) {
+                    const int row = mm + u * R;
+                    if (row < mc) {
+                        VecLoad<V>::load(Gbk + (size_t)(m0 + row) * N, g[u]);
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < V; ++v) g[u][v] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < AGG_UNROLL; ++u) {
+                    const int row = min(mm + u * R, mc - 1);     // g is zero past the end
+                    const float* xr = xs + row * CT;
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        const float x = xr[c];
+#pragma unroll
+                        for (int v = 0; v < V; ++v) acc[c][v] = fmaf(x, g[u][v], acc[c][v]);
+                    }
+                }
+            }
+        }
+    }
+
+    float* Ybk = Y + b * syb + k * syk;
+    if (R == 1) {
+        if (col_ok) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                if (c0 + c < C) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) Ybk[(c0 + c) * syc + n0 + cg * V + v] = acc[c][v];
+                }
+            }
+        }
+        return;
+    }
+    // combine the R row phases, AGG_RED_CH channels per pass, fixed order r = 0..R-1
+#pragma unroll
+    for (int cb = 0; cb < CT; cb += AGG_RED_CH) {
+        constexpr int CH = (CT < AGG_RED_CH) ? CT : AGG_RED_CH;
+        __syncthreads();
+        if (active && col_ok) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (cb + c < CT) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) red[((size_t)r * CH + c) * twp + cg * V + v] = acc[cb + c < CT ? cb + c : 0][v];
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < CH * cols; i += AGG_THREADS) {
+            const int c = i / cols, col = i - c * cols;
+            if (cb + c < CT && c0 + cb + c < C) {
+                float s = 0.f;
+                for (int rr = 0; rr < R; ++rr) s += red[((size_t)rr * CH + c) * twp + col];
+                Ybk[(c0 + cb + c) * syc + n0 + col] = s;
+            }
+        }
+    }
+}
+
+// dX[b,k,c,m] = sum_n dY[b,k,c,n] * G[b,k,m,n]: one wave per row m of G, lanes stride along n.
+// grid: x = row tile + nrt * channel chunk, y = k, z = b
+constexpr int BWX_ROWS = 32;         // rows of G per workgroup
+template <int CT>
+__global__ __launch_bounds__(AGG_THREADS)
+void agg_bwd_x_kernel(const float* __restrict__ dY, const float* __restrict__ G, float* __restrict__ dX,
+                      int K, int C, int N, int nrt, int NC,
+                      long sgb, long sgk, long sgc, long sdb, long sdk, long sdc)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // dys[CT][NC]
+    const int rt = blockIdx.x % nrt;
+    const int c0 = (blockIdx.x / nrt) * CT;
+    const int k = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m_begin = rt * BWX_ROWS;
+    const int m_end = min(N, m_begin + BWX_ROWS);
+    const float* Gbk = G + ((size_t)b * K + k) * (size_t)N * N;
+    const float* dYbk = dY + b * sgb + k * sgk;
+    float* dXbk = dX + b * sdb + k * sdk;
+
+    constexpr int RPW = BWX_ROWS / 4;      // rows per wave
+    float acc[RPW][CT];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[i][c] = 0.f;
+
+    for (int n0 = 0; n0 < N; n0 += NC) {
+        const int nc = min(NC, N - n0);
+        __syncthreads();
+        for (int i = tid; i < CT * nc; i += AGG_THREADS) {
+            const int c = i / nc, nn = i - c * nc;
+            smem[c * NC + nn] = (c0 + c < C) ? dYbk[(c0 + c) * sgc + n0 + nn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int m = m_begin + wave + 4 * i;
+            if (m < m_end) {
+                const float* grow = Gbk + (size_t)m * N + n0;
+                for (int nn = lane; nn < nc; nn += 64) {
+                    const float g = grow[nn];
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[i][c] = fmaf(smem[c * NC + nn], g, acc[i][c]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int m = m_begin + wave + 4 * i;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const float s = mgp_wave_sum(acc[i][c]);
+            if (lane == 0 && m < m_end && c0 + c < C) dXbk[(c0 + c) * sdc + m] = s;
+        }
+    }
+}
+
+template <int CT, int V>
+int launch_agg_fwd(const float* X, const float* G, float* Y, int B, int K, int C, int N,
+                   long sxb, long sxk, long sxc, long syb, long syk, long syc, hipStream_t st)
+{
+    const int tw = (N <= 256) ? N : 64 * V;
+    const int ntiles = mgp_ceil_div(N, tw);
+    const int nchunks = mgp_ceil_div(C, CT);
+    int MC = 8192 / CT;
+    if (MC > N) MC = N;
+    constexpr int CH = (CT < AGG_RED_CH) ? CT : AGG_RED_CH;
+    const size_t lds = ((size_t)MC * CT + (size_t)AGG_THREADS * V * CH) * sizeof(float);
+    dim3 grid(ntiles * nchunks, K, B);
+    hipLaunchKernelGGL((agg_fwd_kernel<CT, V>), grid, dim3(AGG_THREADS), lds, st,
+                       X, G, Y, K, C, N, tw, ntiles, MC, sxb, sxk, sxc, syb, syk, syc);
+    return mgp_launch_status();
+}
+
+template <int V>
+int dispatch_agg_fwd(const float* X, const float* G, float* Y, int B, int K, int C, int N,
+                     long sxb, long sxk, long sxc, long syb, long syk, long syc, hipStream_t st)
+{
+#define MGP_AGG_CASE(CT) return launch_agg_fwd<CT, V>(X, G, Y, B, K, C, N, sxb, sxk, sxc, syb, syk, syc, st)
+    if (C <= 4) MGP_AGG_CASE(4);
+    if (C <= 6) MGP_AGG_CASE(6);
+    if (C <= 8) MGP_AGG_CASE(8);
+    if (C <= 16) MGP_AGG_CASE(16);
+    MGP_AGG_CASE(32);
+#undef MGP_AGG_CASE
+}
+
+template <int CT>
+int launch_agg_bwd_x(const float* dY, const float* G, float* dX, int B, int K, int C, int N,
+                     long sgb, long sgk, long sgc, long sdb, long sdk, long sdc, hipStream_t st)
+{
+    const int nrt = mgp_ceil_div(N, BWX_ROWS);
+    const int nchunks = mgp_ceil_div(C, CT);
+    int NC = 8192 / CT;
+    if (NC > N) NC = N;
+    const size_t lds = (size_t)CT * NC * sizeof(float);
+    dim3 grid(nrt * nchunks, K, B);
+    hipLaunchKernelGGL((agg_bwd_x_kernel<CT>), grid, dim3(AGG_THREADS), lds, st,
+                       dY, G, dX, K, C, N, nrt, NC, sgb, sgk, sgc, sdb, sdk, sdc);
+    return mgp_launch_status();
+}
+
+}  // namespace
+
+extern "C" int mgp_agg_fwd(const float* X, const float* G, float* Y, int B, int K, int C, int N,
+                           long sxb, long sxk, long sxc, long syb, long syk, long syc, void* stream)
+{
+    if (B < 0 || K <= 0 || C <= 0 || N <= 0) return MGP_EINVAL;
+    if (B == 0) return MGP_OK;
+    MGP_CHECK_PTR(X); MGP_CHECK_PTR(G); MGP_CHECK_PTR(Y);
+    if (B > 65535 || K > 65535) return MGP_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    mgp_clear_error();
+    const bool vec = (N % 4 == 0) && mgp_aligned16(G);
+    if (vec) return dispatch_agg_fwd<4>(X, G, Y, B, K, C, N, sxb, sxk, sxc, syb, syk, syc, st);
+    return dispatch_agg_fwd<1>(X, G, Y, B, K, C, N, sxb, sxk, sxc, syb, syk, syc, st);
+}
+
+extern "C" int mgp_agg_bwd_x(const float* dY, const float* G, float* dX, int B, int K, int C, int N,
+                             long sgb, long sgk, long sgc, long sdb, long sdk, long sdc, void* stream)
+{
+    if (B < 0 || K <= 0 || C <= 0 || N <= 0) return MGP_EINVAL;
+    if (B == 0) return MGP_OK;
+    MGP_CHECK_PTR(dY); MGP_CHECK_PTR(G); MGP_CHECK_PTR(dX);
+    if (B > 65535 || K > 65535) return MGP_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    mgp_clear_error();
+    if (C <= 2) return launch_agg_bwd_x<2>(dY, G, dX, B, K, C, N, sgb, sgk, sgc, sdb, sdk, sdc, st);
+    if (C <= 4) return launch_agg_bwd_x<4>(dY, G, dX, B, K, C, N, sgb, sgk, sgc, sdb, sdk, sdc, st);
+    return launch_agg_bwd_x<8>(dY, G, dX, B, K, C, N, sgb, sgk, sgc, sdb, sdk, sdc, st);
+}

@@ -1,0 +1,31 @@
+// Library-level entry points of libmgp.so: version, error strings, device probe.
+#include <string.h>
+#include "mgp_common.h"
+
+extern "C" int mgp_version(void) { return MGP_VERSION; }
+
+extern "C" const char* mgp_strerror(int code)
+{
+    switch (code) {
+        case MGP_OK: return "ok";
+        case MGP_EINVAL: return "invalid argument (size, null pointer or unsupported combination)";
+        case MGP_EALIGN: return "pointer is not sufficiently aligned";
+        case MGP_ELAUNCH: return "HIP kernel launch failed";
+        case MGP_ENODEV: return "no HIP device available";
+        case MGP_EUNSUPPORTED: return "shape not covered by this kernel (use the composed ops)";
+        default: return "unknown mgp error code";
+    }
+}
+
+extern "C" int mgp_device_info(char* name, int cap)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return MGP_ENODEV;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return MGP_ENODEV;
+    if (name != nullptr && cap > 0) {
+        strncpy(name, prop.gcnArchName, (size_t)cap - 1);
+        name[cap - 1] = '\0';
+    }
+    return prop.multiProcessorCount;
+}

@@ -1,0 +1,76 @@
+// DAGGER update helpers (reference gnn_dagger.py:91-93): F.mse_loss + its gradient, and torch.optim.Adam
+// (defaults: no amsgrad, no weight decay) on one flat fp32 parameter buffer.
+#include <math.h>
+#include "mgp_common.h"
+
+namespace {
+
+constexpr int OP_THREADS = 1024;
+
+// single workgroup: deterministic fixed-order reduction (n is B*nA*N, a few thousand to ~1e5)
+__global__ __launch_bounds__(OP_THREADS)
+void mse_grad_kernel(const float* __restrict__ pred, const float* __restrict__ target, float* __restrict__ dPred,
+                     float* __restrict__ loss, long n)
+{
+    __shared__ double sh[OP_THREADS / 64];
+    const float scale = 2.0f / (float)n;
+    double s = 0.0;
+    for (long i = threadIdx.x; i < n; i += OP_THREADS) {
+        const float d = pred[i] - target[i];
+        if (dPred != nullptr) dPred[i] = scale * d;
+        s += (double)d * (double)d;
+    }
+    s = mgp_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss != nullptr) {
+        double t = 0.0;
+        for (int w = 0; w < OP_THREADS / 64; ++w) t += sh[w];
+        loss[0] = (float)(t / (double)n);
+    }
+}
+
+__global__ __launch_bounds__(256)
+void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                 long n, float one_m_b1, float b2, float one_m_b2, float step_size, float bc2_sqrt, float eps)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = m[i] + (gi - m[i]) * one_m_b1;          // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = v[i] * b2 + one_m_b2 * gi * gi;         // mul_(beta2).addcmul_(grad, grad, 1-beta2)
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);                  // addcdiv_(exp_avg, denom, -step_size)
+    m[i] = mi;
+    v[i] = vi;
+}
+
+}  // namespace
+
+extern "C" int mgp_mse_grad(const float* pred, const float* target, float* dPred, float* loss, long n, void* stream)
+{
+    if (n <= 0) return MGP_EINVAL;
+    MGP_CHECK_PTR(pred); MGP_CHECK_PTR(target);
+    if (dPred == nullptr && loss == nullptr) return MGP_EINVAL;
+    mgp_clear_error();
+    hipLaunchKernelGGL(mse_grad_kernel, dim3(1), dim3(OP_THREADS), 0, static_cast<hipStream_t>(stream),
+                       pred, target, dPred, loss, n);
+    return mgp_launch_status();
+}
+
+extern "C" int mgp_adam_step(float* param, const float* grad, float* m, float* v, long n,
+                             float lr, float beta1, float beta2, float eps, int step, void* stream)
+{
+    if (n <= 0 || step <= 0) return MGP_EINVAL;
+    MGP_CHECK_PTR(param); MGP_CHECK_PTR(grad); MGP_CHECK_PTR(m); MGP_CHECK_PTR(v);
+    mgp_clear_error();
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       param, grad, m, v, n, (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2),
+                       step_size, bc2_sqrt, eps);
+    return mgp_launch_status();
+}

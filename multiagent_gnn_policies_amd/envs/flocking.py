@@ -1,0 +1,307 @@
+"""Flocking environments with the call-site contract the reference expects from `gym_flock`
+(reference train.py:18-25, gnn_dagger.py:150-163, gnn_baseline.py:13-17, state_with_delay.py:22-26):
+
+    env = make('FlockingRelative-v0'); env.env.params_from_cfg(args); env.seed(s)
+    (values (N,6) f64, network (N,N) f64) = env.reset()
+    u = env.env.controller()                      # (N,2)
+    (values, network), reward, done, info = env.step(u)
+
+`gym` / `gym_flock` are not dependencies (neither is installable here); `make` and `TimeLimit` provide
+the two things the reference uses from gym: the id registry and the `.env` + step-limit wrapper.
+The dynamics follow this repo's FLOCK-SPEC v1 and run in HIP kernels (`mgp_flock_step`,
+`mgp_flock_controller`): `VecFlock` is the B-episode device-resident simulator, the gym-style classes
+are B = 1 facades over it that return numpy tuples.
+"""
+from dataclasses import dataclass, replace
+
+import numpy as np
+import torch
+
+from .. import ops
+from .._lib import MgpFlockParams
+
+
+@dataclass(frozen=True)
+class FlockParams:
+    n_agents: int = 100
+    comm_radius: float = 1.0
+    v_max: float = 3.0
+    v_bias: float = 3.0
+    dt: float = 0.01
+    max_rad_init: float = 1.0
+    action_gain: float = 10.0
+    max_accel: float = 1.0
+    ctrl_gain: float = 0.1
+    ctrl_clip: float = 10.0
+    min_dist_thresh: float = 0.1
+    min_degree: int = 2
+    reward_scale: float = 1.0
+    mean_pooling: bool = True
+    max_episode_steps: int = 500
+    n_leaders: int = 0
+    two_flocks: bool = False
+    init_mode: str = 'auto'
+    grid_spacing: float = 0.6
+    grid_jitter: float = 0.1
+
+    @property
+    def comm_radius2(self):
+        return self.comm_radius * self.comm_radius
+
+    @property
+    def r_max(self):
+        return self.max_rad_init * np.sqrt(self.n_agents)
+
+    def to_c(self):
+        return MgpFlockParams(self.comm_radius2, self.dt, self.action_gain, self.max_accel, self.ctrl_gain,
+                              self.ctrl_clip, self.reward_scale, 1 if self.mean_pooling else 0, self.n_leaders)
+
+
+# ----------------------------------------------------------------------------------- reset sampling
+def _sample_candidate(rng, p):
+    """One draw of the reset distribution (FLOCK-SPEC v1 section 3).  RNG call order is part of the spec."""
+    n = p.n_agents
+    x = np.zeros((n, 4), dtype=np.float64)
+    length = np.sqrt(rng.uniform(0, p.r_max, size=(n,)))
+    angle = np.pi * rng.uniform(0, 2, size=(n,))
+    x[:, 0] = length * np.cos(angle)
+    x[:, 1] = length * np.sin(angle)
+    bias = rng.uniform(low=-p.v_bias, high=p.v_bias, size=(2,))
+    x[:, 2] = rng.uniform(low=-p.v_max, high=p.v_max, size=(n,)) + bias[0]
+    x[:, 3] = rng.uniform(low=-p.v_max, high=p.v_max, size=(n,)) + bias[1]
+    if p.two_flocks:
+        half = n // 2
+        x[:half, 0] -= np.sqrt(p.r_max)
+        x[half:, 0] += np.sqrt(p.r_max)
+        x[:half, 2] = x[:half, 2] - bias[0] + abs(bias[0])
+        x[half:, 2] = x[half:, 2] - bias[0] - abs(bias[0])
+    return x
+
+
+def lattice_sites(n):
+    """First n integer lattice points ordered by (a^2+b^2, a, b): a disc-shaped patch of a square lattice."""
+    m = int(np.ceil(np.sqrt(n / np.pi))) + 2
+    a, b = np.meshgrid(np.arange(-m, m + 1), np.arange(-m, m + 1), indexing='ij')
+    a, b = a.ravel(), b.ravel()
+    order = np.lexsort((b, a, a * a + b * b))[:n]
+    return np.stack([a[order], b[order]], axis=1).astype(np.float64)
+
+
+def use_grid(p):
+    return p.init_mode == 'grid' or (p.init_mode == 'auto' and p.n_agents > 100)
+
+
+def _sample_candidate_grid(rng, p):
+    """Grid-mode draw (FLOCK-SPEC v1 section 3b): jittered square lattice, pitch grid_spacing*R, jitter
+    +-grid_jitter*R.  RNG call order: jitter_x(N) ; jitter_y(N) ; bias(2) ; vx(N) ; vy(N)."""
+    n = p.n_agents
+    x = np.zeros((n, 4), dtype=np.float64)
+    sites = lattice_sites(n)
+    s = p.grid_spacing * p.comm_radius
+    j = p.grid_jitter * p.comm_radius
+    x[:, 0] = sites[:, 0] * s + rng.uniform(-j, j, size=(n,))
+    x[:, 1] = sites[:, 1] * s + rng.uniform(-j, j, size=(n,))
+    bias = rng.uniform(low=-p.v_bias, high=p.v_bias, size=(2,))
+    x[:, 2] = rng.uniform(low=-p.v_max, high=p.v_max, size=(n,)) + bias[0]
+    x[:, 3] = rng.uniform(low=-p.v_max, high=p.v_max, size=(n,)) + bias[1]
+    return x
+
+
+def _candidate_ok(x, p):
+    pos = x[:, 0:2]
+    d = pos[:, None, :] - pos[None, :, :]
+    r2 = d[:, :, 0] * d[:, :, 0] + d[:, :, 1] * d[:, :, 1]
+    np.fill_diagonal(r2, np.inf)
+    return (r2 < p.comm_radius2).sum(axis=1).min() >= p.min_degree and np.sqrt(r2.min()) >= p.min_dist_thresh
+
+
+def sample_initial_state(rng, p, max_tries=100000):
+    """Rejection-sample x0 (N,4): min degree >= p.min_degree and min distance >= p.min_dist_thresh.
+    Host-side control logic, executed once per episode (the per-step arithmetic is on the device)."""
+    for _ in range(max_tries):
+        x = _sample_candidate_grid(rng, p) if use_grid(p) else _sample_candidate(rng, p)
+        if _candidate_ok(x, p):
+            return x
+    raise RuntimeError("flock reset: no admissible initial configuration found")
+
+
+# ----------------------------------------------------------------------------------- device simulator
+class VecFlock(object):
+    """B independent flocking episodes, state and observations resident on one MI355X.
+
+    Buffers (all preallocated, reused every step -> HIP-graph capturable):
+      x (B,N,4) f64 | network (B,N,N) f32 | features (B,6,N) f32 (already (F,N)) | reward (B) f64
+    """
+
+    def __init__(self, B, params, device='cuda', want_f64_obs=False):
+        self.B, self.p = B, params
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise ops.MgpError("VecFlock needs a HIP device (no CPU simulation path)")
+        N = params.n_agents
+        self.N = N
+        self._c = params.to_c()
+        self.x = torch.zeros((B, N, 4), device=self.device, dtype=torch.float64)
+        self.network = torch.zeros((B, N, N), device=self.device, dtype=torch.float32)
+        self.features = torch.zeros((B, 6, N), device=self.device, dtype=torch.float32)
+        self.reward = torch.zeros((B,), device=self.device, dtype=torch.float64)
+        self.expert = torch.zeros((B, N, 2), device=self.device, dtype=torch.float32)
+        self.network64 = torch.zeros((B, N, N), device=self.device, dtype=torch.float64) if want_f64_obs else None
+        self.features64 = torch.zeros((B, N, 6), device=self.device, dtype=torch.float64) if want_f64_obs else None
+        self.expert64 = torch.zeros((B, N, 2), device=self.device, dtype=torch.float64) if want_f64_obs else None
+
+    def set_state(self, x0):
+        """x0 (B,N,4) array-like fp64: install states and refresh observations."""
+        x0 = torch.as_tensor(np.asarray(x0, dtype=np.float64))
+        assert x0.shape == (self.B, self.N, 4)
+        self.x.copy_(x0)
+        self.refresh()
+
+    def reset(self, rng=None):
+        rng = rng if rng is not None else np.random
+        self.set_state(np.stack([sample_initial_state(rng, self.p) for _ in range(self.B)]))
+
+    def refresh(self):
+        """Recompute observations for the current x without integrating."""
+        ops.flock_step(self.x, None, self._c, A=self.network, A64=self.network64, feat=self.features,
+                       feat64=self.features64, reward=self.reward)
+
+    def step(self, u):
+        """u (B,N,2) fp32 on device.  Advances every episode one step (in place)."""
+        ops.flock_step(self.x, u, self._c, A=self.network, A64=self.network64, feat=self.features,
+                       feat64=self.features64, reward=self.reward)
+
+    def controller(self, centralized=False):
+        """Expert action for the current state -> (B,N,2) fp32 (buffer reused)."""
+        ops.flock_controller(self.x, self._c, centralized=bool(centralized), u=self.expert, u64=self.expert64)
+        return self.expert
+
+
+# ----------------------------------------------------------------------------------- gym-style facade
+class FlockingRelativeEnv(object):
+    """Single-episode environment with the raw-env interface the reference reaches through `env.env`."""
+
+    variant = {}
+
+    def __init__(self, device=None):
+        self.params = replace(FlockParams(), **self.variant)
+        self.device = device
+        self._sim = None
+        self._rng = np.random          # the reference seeds numpy's global RNG (train.py:27)
+        self.n_features = 6
+        self.nu = 2
+
+    # -- configuration -------------------------------------------------------------------------
+    def params_from_cfg(self, args):
+        kw = dict(n_agents=args.getint('n_agents'), comm_radius=args.getfloat('comm_radius'),
+                  v_max=args.getfloat('v_max'), v_bias=args.getfloat('v_max'))
+        if args.get('dt') is not None:
+            kw['dt'] = args.getfloat('dt')
+        self.params = replace(self.params, **kw)
+        self._sim = None
+
+    def seed(self, seed=None):
+        self._rng = np.random.RandomState(seed) if seed is not None else np.random
+        return [seed]
+
+    @property
+    def n_agents(self):
+        return self.params.n_agents
+
+    def _ensure(self):
+        if self._sim is None:
+            dev = self.device or ('cuda:0' if torch.cuda.is_available() else None)
+            if dev is None:
+                raise ops.MgpError("the flocking simulator needs a HIP device (no CPU simulation path)")
+            self._sim = VecFlock(1, self.params, dev, want_f64_obs=True)
+        return self._sim
+
+    def _obs(self):
+        s = self._sim
+        return s.features64[0].cpu().numpy(), s.network64[0].cpu().numpy()
+
+    # -- gym API -------------------------------------------------------------------------------
+    def reset(self):
+        s = self._ensure()
+        s.reset(self._rng)
+        return self._obs()
+
+    def step(self, u):
+        s = self._ensure()
+        u = np.asarray(u)
+        assert u.shape == (self.params.n_agents, self.nu)
+        ut = torch.from_numpy(np.ascontiguousarray(u, dtype=np.float32)).reshape(1, -1, 2).to(s.device)
+        s.step(ut)
+        return self._obs(), float(s.reward[0].item()), False, {}
+
+    def controller(self, centralized=None):
+        s = self._ensure()
+        s.controller(bool(centralized))
+        return s.expert64[0].cpu().numpy()
+
+    def render(self, mode='human'):
+        return None
+
+    def close(self):
+        self._sim = None
+
+
+class FlockingLeaderEnv(FlockingRelativeEnv):
+    """FLOCK-SPEC v1 variant: the first `n_leaders` agents keep their initial velocity (ignore u)."""
+    variant = dict(n_leaders=2)
+
+
+class FlockingTwoFlocksEnv(FlockingRelativeEnv):
+    """FLOCK-SPEC v1 variant: reset draws two groups displaced along x with opposite velocity bias."""
+    variant = dict(two_flocks=True)
+
+
+class TimeLimit(object):
+    """The part of gym.wrappers.TimeLimit the reference relies on: `.env`, and `done` after
+    `max_episode_steps` steps (reference gnn_dagger.py:154,163: `while not done`)."""
+
+    def __init__(self, env, max_episode_steps):
+        self.env = env
+        self._max_episode_steps = max_episode_steps
+        self._elapsed = 0
+
+    def seed(self, seed=None):
+        return self.env.seed(seed)
+
+    def reset(self):
+        self._elapsed = 0
+        return self.env.reset()
+
+    def step(self, action):
+        obs, reward, done, info = self.env.step(action)
+        self._elapsed += 1
+        if self._elapsed >= self._max_episode_steps:
+            done = True
+            info = dict(info)
+            info['TimeLimit.truncated'] = True
+        return obs, reward, done, info
+
+    def render(self, mode='human'):
+        return self.env.render(mode)
+
+    def close(self):
+        return self.env.close()
+
+
+_REGISTRY = {
+    'FlockingRelative-v0': FlockingRelativeEnv,
+    'FlockingLeader-v0': FlockingLeaderEnv,
+    'FlockingTwoFlocks-v0': FlockingTwoFlocksEnv,
+}
+
+
+def registered_ids():
+    return sorted(_REGISTRY)
+
+
+def make(name, device=None, max_episode_steps=None):
+    """`gym.make` stand-in for the ids the reference's cfg files name."""
+    if name not in _REGISTRY:
+        raise KeyError("unknown environment id %r (known: %s)" % (name, ', '.join(registered_ids())))
+    env = _REGISTRY[name](device=device)
+    return TimeLimit(env, max_episode_steps or env.params.max_episode_steps)

@@ -1,0 +1,78 @@
+"""Fused single-kernel Actor forward/backward (ind_agg == 0) on top of mgp_actor_fwd / mgp_actor_bwd."""
+import ctypes
+
+import torch
+
+from .. import _lib, ops
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+class _ActorFusedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, G, dims, K, *params):
+        L = _lib.lib()
+        n_layers = len(dims) - 1
+        B, _, F, N = X.shape
+        Ws = [p.contiguous() for p in params[0::2]]
+        bs = [p.contiguous() for p in params[1::2]]
+        cdims = (ctypes.c_int * len(dims))(*dims)
+        need_bwd = any(ctx.needs_input_grad[4:])
+        saved = None
+        if need_bwd:
+            n_saved = L.mgp_actor_saved_floats(cdims, n_layers, B, K, N)
+            saved = torch.empty((n_saved,), device=X.device, dtype=torch.float32)
+        out = torch.empty((B, 1, dims[-1], N), device=X.device, dtype=torch.float32)
+        rc = L.mgp_actor_fwd(ops._ptr(X), ops._ptr(G), _ptr_array(Ws), _ptr_array(bs), cdims, n_layers,
+                             ops._ptr(out), ops._ptr(saved), B, K, N, ops._stream())
+        if rc == -5:      # MGP_EUNSUPPORTED
+            return None
+        _lib.check(rc, 'mgp_actor_fwd')
+        ctx.dims, ctx.K, ctx.shape = dims, K, (B, F, N)
+        ctx.save_for_backward(saved, *Ws)
+        ctx.param_shapes = [p.shape for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            raise ops.MgpError("fused Actor backward provides parameter gradients only")
+        L = _lib.lib()
+        saved, *Ws = ctx.saved_tensors
+        dims, K = ctx.dims, ctx.K
+        B, F, N = ctx.shape
+        n_layers = len(dims) - 1
+        cdims = (ctypes.c_int * len(dims))(*dims)
+        dWs = [torch.empty_like(w) for w in Ws]
+        dbs = [torch.empty((dims[i + 1],), device=dOut.device, dtype=torch.float32) for i in range(n_layers)]
+        n_ws = L.mgp_actor_bwd_workspace(cdims, n_layers, B, K, N)
+        ws = torch.empty((max(1, n_ws),), device=dOut.device, dtype=torch.float32)
+        rc = L.mgp_actor_bwd(ops._ptr(dOut.contiguous()), ops._ptr(saved), _ptr_array(Ws), cdims, n_layers,
+                             _ptr_array(dWs), _ptr_array(dbs), B, K, N, ops._ptr(ws), ops._stream())
+        _lib.check(rc, 'mgp_actor_bwd')
+        grads = []
+        for i in range(n_layers):
+            grads += [dWs[i].view(ctx.param_shapes[2 * i]), dbs[i]]
+        return (None, None, None, None) + tuple(grads)
+
+
+def try_forward(actor, delay_state, delay_gso):
+    """Returns the (B,1,nA,N) output, or None when the fused kernel does not cover this shape
+    (the caller then composes the generic HIP ops)."""
+    if delay_state.requires_grad or delay_gso.requires_grad:
+        return None
+    if actor.n_layers > 8:
+        return None
+    ops._dev(delay_state, 'delay_state'); ops._dev(delay_gso, 'delay_gso')
+    X = delay_state.contiguous()
+    G = delay_gso.contiguous()
+    params = []
+    for conv in actor.conv_layers:
+        out_c = conv.weight.shape[0]
+        params += [conv.weight.view(out_c, -1), conv.bias]
+    return _ActorFusedFn.apply(X, G, tuple(actor.layers), actor.k, *params)

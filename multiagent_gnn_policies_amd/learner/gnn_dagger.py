@@ -1,0 +1,205 @@
+"""DAGGER learner and training loop -- drop-in for reference learner/gnn_dagger.py:18-243.
+
+`DAGGER(device, args, k=None)` exposes the same `select_action`, `gradient_step`, `save_model`,
+`load_model`; `train_dagger(env, args, device)` keeps the reference's schedule (beta decay per episode,
+expert labels, `updates_per_step` updates after each episode, periodic evaluation, final statistics).
+Arithmetic (Actor forward/backward, MSE, Adam) runs in the HIP kernels; parameters and gradients live in
+one flat fp32 buffer each, so a data-parallel run needs exactly one all-reduce of 6,920 bytes per update.
+"""
+import os
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..parallel import FlatGradSync
+from .actor import Actor
+from .replay_buffer import ReplayBuffer, Transition
+from .state_with_delay import MultiAgentStateWithDelay
+
+
+class FlatAdam(object):
+    """torch.optim.Adam(defaults) semantics on a single flat parameter buffer (kernel mgp_adam_step).
+
+    Re-homes every parameter of `module` as a view into one contiguous fp32 buffer (state_dict keys and
+    shapes are unchanged), keeps a matching flat gradient buffer, first/second-moment buffers and the
+    step count.
+    """
+
+    def __init__(self, module, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in module.parameters()]
+        self.lr, self.betas, self.eps = lr, betas, eps
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.empty((total,), device=dev, dtype=torch.float32)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                self.flat[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat[off:off + n].view(p.shape)
+                off += n
+        self.flat_grad = torch.zeros_like(self.flat)
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.step_count = 0
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def gather_grads(self):
+        """Pack p.grad into the flat gradient buffer (one device-side concat of 1,730 floats)."""
+        torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat_grad)
+        return self.flat_grad
+
+    def step(self):
+        self.step_count += 1
+        ops.adam_step(self.flat, self.flat_grad, self.m, self.v, self.lr, self.step_count,
+                      self.betas[0], self.betas[1], self.eps)
+
+
+class DAGGER(object):
+
+    def __init__(self, device, args, k=None):
+        n_s = args.getint('n_states')
+        n_a = args.getint('n_actions')
+        k = k or args.getint('k')
+        hidden_size = args.getint('hidden_size')
+        n_layers = args.getint('n_layers') or 2
+        self.gamma = args.getfloat('gamma')      # read for cfg compatibility; unused by DAGGER
+        self.tau = args.getfloat('tau')
+
+        self.n_agents = args.getint('n_agents')
+        self.n_states = n_s
+        self.n_actions = n_a
+        self.device = torch.device(device)
+
+        hidden_layers = [hidden_size] * n_layers
+        ind_agg = 0                               # reference gnn_dagger.py:43
+        self.actor = Actor(n_s, n_a, hidden_layers, k, ind_agg).to(self.device)
+        self.actor_optim = FlatAdam(self.actor, lr=args.getfloat('actor_lr'))
+        self.grad_sync = FlatGradSync()           # no-op unless torch.distributed is initialised
+        self.grad_sync.broadcast_(self.actor_optim.flat)
+
+    def select_action(self, state):
+        """(1,K,F,N),(1,K,N,N) -> action (N,nA) on the device (reference gnn_dagger.py:55-72)."""
+        self.actor.eval()
+        with torch.no_grad():
+            mu = self.actor(state.delay_state, state.delay_gso)
+        mu = mu.permute(0, 1, 3, 2).reshape((self.n_agents, self.n_actions))
+        self.actor.train()
+        return mu
+
+    def gradient_step(self, batch):
+        """One supervised update on a batch of transitions (reference gnn_dagger.py:76-96)."""
+        delay_gso_batch = torch.cat(tuple(s.delay_gso for s in batch.state)).to(self.device)
+        delay_state_batch = torch.cat(tuple(s.delay_state for s in batch.state)).to(self.device)
+        optimal_action_batch = torch.cat(batch.action).to(self.device)
+        return self.gradient_step_tensors(delay_state_batch, delay_gso_batch, optimal_action_batch)
+
+    def gradient_step_tensors(self, delay_state_batch, delay_gso_batch, optimal_action_batch):
+        self.actor_optim.zero_grad()
+        actor_batch = self.actor(delay_state_batch, delay_gso_batch)
+        policy_loss = ops.mse_loss(actor_batch, optimal_action_batch)
+        policy_loss.backward()
+        flat_grad = self.actor_optim.gather_grads()
+        self.grad_sync.all_reduce_mean_(flat_grad)
+        self.actor_optim.step()
+        return policy_loss.item()
+
+    def save_model(self, env_name, suffix="", actor_path=None):
+        if not os.path.exists('models/'):
+            os.makedirs('models/')
+        if actor_path is None:
+            actor_path = "models/actor_{}_{}".format(env_name, suffix)
+        print('Saving model to {}'.format(actor_path))
+        torch.save({k: v.detach().clone() for k, v in self.actor.state_dict().items()}, actor_path)
+
+    def load_model(self, actor_path, map_location):
+        if actor_path is not None:
+            sd = torch.load(actor_path, map_location)
+            with torch.no_grad():
+                own = self.actor.state_dict()
+                for k_, v in sd.items():
+                    own[k_].copy_(v)              # keeps the flat-buffer views intact
+            missing = set(own) ^ set(sd)
+            if missing:
+                raise KeyError("state_dict mismatch: %s" % sorted(missing))
+
+
+def _rollout_reward(env, learner, device, args):
+    ep_reward = 0
+    state = MultiAgentStateWithDelay(device, args, env.reset(), prev_state=None)
+    done = False
+    while not done:
+        action = learner.select_action(state)
+        next_state, reward, done, _ = env.step(action.cpu().numpy())
+        state = MultiAgentStateWithDelay(device, args, next_state, prev_state=state)
+        ep_reward += reward
+    return ep_reward
+
+
+def train_dagger(env, args, device):
+    debug = args.getboolean('debug')
+    memory = ReplayBuffer(max_size=args.getint('buffer_size'))
+    learner = DAGGER(device, args)
+
+    n_a = args.getint('n_actions')
+    n_agents = args.getint('n_agents')
+    batch_size = args.getint('batch_size')
+    n_train_episodes = args.getint('n_train_episodes')
+    beta_coeff = args.getfloat('beta_coeff')
+    test_interval = args.getint('test_interval')
+    n_test_episodes = args.getint('n_test_episodes')
+    updates_per_step = args.getint('updates_per_step')
+
+    total_numsteps = 0
+    updates = 0
+    beta = 1
+    stats = {'mean': -1.0 * np.inf, 'std': 0}
+
+    for i in range(n_train_episodes):
+        beta = max(beta * beta_coeff, 0.5)
+        state = MultiAgentStateWithDelay(device, args, env.reset(), prev_state=None)
+        done = False
+        policy_loss_sum = 0
+        while not done:
+            optimal_action = env.env.controller()
+            if np.random.binomial(1, beta) > 0:
+                action = optimal_action
+            else:
+                action = learner.select_action(state).cpu().numpy()
+            next_obs, reward, done, _ = env.step(action)
+            next_state = MultiAgentStateWithDelay(device, args, next_obs, prev_state=state)
+            total_numsteps += 1
+
+            notdone = torch.tensor([float(not done)], device=device)
+            reward_t = torch.tensor([float(reward)], device=device)
+            # expert label (N,nA) -> (1,1,nA,N)
+            label = torch.from_numpy(np.ascontiguousarray(np.asarray(optimal_action, dtype=np.float32).T))
+            label = label.reshape((1, 1, n_a, n_agents)).to(device)
+            memory.insert(Transition(state, label, notdone, next_state, reward_t))
+            state = next_state
+
+        if memory.curr_size > batch_size:
+            for _ in range(updates_per_step):
+                transitions = memory.sample(batch_size)
+                batch = Transition(*zip(*transitions))
+                policy_loss_sum += learner.gradient_step(batch)
+                updates += 1
+
+        if i % test_interval == 0 and debug:
+            test_rewards = [_rollout_reward(env, learner, device, args) for _ in range(n_test_episodes)]
+            print("Episode: {}, updates: {}, total numsteps: {}, reward: {}, policy loss: {}".format(
+                i, updates, total_numsteps, np.mean(test_rewards), policy_loss_sum))
+
+    test_rewards = [_rollout_reward(env, learner, device, args) for _ in range(n_test_episodes)]
+    stats['mean'] = np.mean(test_rewards)
+    stats['std'] = np.std(test_rewards)
+
+    if debug and args.get('fname'):
+        learner.save_model(args.get('env'), suffix=args.get('fname'))
+
+    env.close()
+    return stats

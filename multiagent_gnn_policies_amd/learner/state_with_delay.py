@@ -1,0 +1,87 @@
+"""`MultiAgentStateWithDelay` -- drop-in for reference learner/state_with_delay.py:4-53.
+
+Same constructor `(device, args, env_state, prev_state=None, k=None)` and attributes
+`values (1,1,F,N)`, `network (1,1,N,N)`, `delay_gso (1,K,N,N)`, `delay_state (1,K,F,N)`,
+`curr_gso (1,K,N,N)`.  The recursion `delay_gso[1:] = A_t @ prev.delay_gso[:-1]` and the delay line
+run in the HIP kernel `mgp_gso_update`.  `curr_gso` (powers of A_t) is only consumed by the reference's
+dead DDPG path, so it is computed lazily on first access (`mgp_gso_powers`).
+
+`BatchedDelayState` is the B-episode, allocation-free form used by the vectorised rollout.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+
+
+class MultiAgentStateWithDelay(object):
+
+    def __init__(self, device, args, env_state, prev_state=None, k=None):
+        n_states = args.getint('n_states')
+        n_agents = args.getint('n_agents')
+        k = k or args.getint('k')
+
+        state_value, state_network = env_state
+        # contract of reference state_with_delay.py:24-26
+        assert state_value.shape == (n_agents, n_states)
+        assert state_network.shape == (n_agents, n_agents)
+        assert np.sum(np.diag(state_network)) == 0  # no self loops
+
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise ops.MgpError("MultiAgentStateWithDelay needs a HIP device (got %s); this package has no CPU "
+                               "compute path" % device)
+        # fp64 -> fp32 on the host (what torch.Tensor(ndarray) does, state_with_delay.py:34-35), then H2D
+        v32 = np.ascontiguousarray(np.asarray(state_value).T, dtype=np.float32).reshape(1, 1, n_states, n_agents)
+        a32 = np.ascontiguousarray(np.asarray(state_network), dtype=np.float32).reshape(1, 1, n_agents, n_agents)
+        self.values = torch.from_numpy(v32).to(device)
+        self.network = torch.from_numpy(a32).to(device)
+        self._k = k
+
+        has_prev = prev_state is not None and k > 1
+        G_prev = prev_state.delay_gso if has_prev else None
+        Xd_prev = prev_state.delay_state if has_prev else None
+        self.delay_gso, self.delay_state = ops.gso_update(self.network[0], G_prev, self.values[0], Xd_prev, k)
+        self._curr_gso = None
+
+    @property
+    def curr_gso(self):
+        """I, A_t, A_t^2, ... (reference state_with_delay.py:38-41); lazily evaluated."""
+        if self._curr_gso is None:
+            self._curr_gso = ops.gso_powers(self.network[0], self._k)
+        return self._curr_gso
+
+
+class BatchedDelayState(object):
+    """Delay line + delayed GSO for B independent episodes, resident on the device.
+
+    Holds two (B,K,N,N) / (B,K,F,N) ping-pong buffer pairs; `push(A, X)` advances every episode by one
+    step with a single `mgp_gso_update` launch and no allocation (HIP-graph capturable).
+    """
+
+    def __init__(self, device, B, K, F, N):
+        self.B, self.K, self.F, self.N = B, K, F, N
+        kw = dict(device=device, dtype=torch.float32)
+        self._G = [torch.zeros((B, K, N, N), **kw), torch.zeros((B, K, N, N), **kw)]
+        self._X = [torch.zeros((B, K, F, N), **kw), torch.zeros((B, K, F, N), **kw)]
+        self._cur = 0
+        self._has_prev = False
+
+    def reset(self):
+        self._has_prev = False
+
+    def push(self, A, X_t):
+        """A (B,N,N) fp32, X_t (B,F,N) fp32 (both contiguous, on device)."""
+        nxt = 1 - self._cur
+        ops.gso_update_into(A, self._G[self._cur], self._G[nxt], X_t, self._X[self._cur], self._X[nxt],
+                            has_prev=self._has_prev)
+        self._cur = nxt
+        self._has_prev = True
+
+    @property
+    def delay_gso(self):
+        return self._G[self._cur]
+
+    @property
+    def delay_state(self):
+        return self._X[self._cur]

@@ -1,0 +1,255 @@
+"""torch-tensor front end of the C ABI (include/mgp.h): argument checking, raw pointers, the current
+HIP stream, and the autograd glue.  Every function here runs a hand-written HIP kernel from libmgp.so;
+nothing falls back to ATen math or to the CPU.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import MgpError, MgpFlockParams
+
+ACT_NONE, ACT_TANH = 0, 1
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise MgpError("%s is on %s: the MI355X kernels need tensors on a HIP device (there is no CPU "
+                       "fallback in this package)" % (name, t.device))
+    if t.dtype != dtype:
+        raise MgpError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _inner_contig(t, name):
+    if t.stride(-1) != 1 and t.shape[-1] != 1:
+        raise MgpError("%s must be contiguous along its last (agent) axis" % name)
+
+
+# ------------------------------------------------------------------------------------ aggregation
+def agg_fwd(T, G):
+    """T (B,C,K,N) (any b/c/k strides, agent axis contiguous), G (B,K,N,N) -> (B,C,K,N) contiguous.
+    out[b,c,k,n] = sum_m T[b,c,k,m] G[b,k,m,n]          (reference actor.py:69-71)"""
+    _dev(T, 'T'); _dev(G, 'G')
+    B, C, K, N = T.shape
+    assert G.shape == (B, K, N, N)
+    if not G.is_contiguous():
+        G = G.contiguous()
+    if T.stride(3) != 1:
+        T = T.contiguous()
+    Y = torch.empty((B, C, K, N), device=T.device, dtype=torch.float32)
+    rc = _lib.lib().mgp_agg_fwd(_ptr(T), _ptr(G), _ptr(Y), B, K, C, N,
+                                T.stride(0), T.stride(2), T.stride(1),
+                                Y.stride(0), Y.stride(2), Y.stride(1), _stream())
+    _lib.check(rc, 'mgp_agg_fwd')
+    return Y
+
+
+def agg_bwd_x(dY, G):
+    """dY (B,C,K,N), G (B,K,N,N) -> dT (B,C,K,N): dT[b,c,k,m] = sum_n dY[b,c,k,n] G[b,k,m,n]."""
+    _dev(dY, 'dY'); _dev(G, 'G')
+    B, C, K, N = dY.shape
+    if not G.is_contiguous():
+        G = G.contiguous()
+    if dY.stride(3) != 1:
+        dY = dY.contiguous()
+    dT = torch.empty((B, C, K, N), device=dY.device, dtype=torch.float32)
+    rc = _lib.lib().mgp_agg_bwd_x(_ptr(dY), _ptr(G), _ptr(dT), B, K, C, N,
+                                  dY.stride(0), dY.stride(2), dY.stride(1),
+                                  dT.stride(0), dT.stride(2), dT.stride(1), _stream())
+    _lib.check(rc, 'mgp_agg_bwd_x')
+    return dT
+
+
+class _AggFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, T, G):
+        ctx.save_for_backward(G)
+        return agg_fwd(T, G)
+
+    @staticmethod
+    def backward(ctx, dY):
+        (G,) = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            raise MgpError("gradient w.r.t. delay_gso is not supported (the reference never asks for it)")
+        dT = agg_bwd_x(dY.contiguous(), G) if ctx.needs_input_grad[0] else None
+        return dT, None
+
+
+def aggregate(T, G):
+    """Differentiable (w.r.t. T) graph-shift aggregation."""
+    return _AggFn.apply(T, G)
+
+
+# ------------------------------------------------------------------------------------ dense layer
+def dense_fwd(inp, W2, bias, act):
+    """inp (B,Cin,T,N) view, W2 (Cout,Cin), bias (Cout) -> (B,Cout,T,N) contiguous."""
+    _dev(inp, 'input'); _dev(W2, 'weight'); _dev(bias, 'bias')
+    B, Cin, T, N = inp.shape
+    Cout = W2.shape[0]
+    assert W2.shape == (Cout, Cin) and bias.shape == (Cout,)
+    if inp.stride(3) != 1:
+        inp = inp.contiguous()
+    W2 = W2.contiguous()
+    out = torch.empty((B, Cout, T, N), device=inp.device, dtype=torch.float32)
+    rc = _lib.lib().mgp_dense_fwd(_ptr(inp), _ptr(W2), _ptr(bias.contiguous()), _ptr(out), B, Cin, Cout, T, N,
+                                  inp.stride(0), inp.stride(1), inp.stride(2), act, _stream())
+    _lib.check(rc, 'mgp_dense_fwd')
+    return out
+
+
+def dense_bwd(dOut, out, inp, W2, act, need_dinp):
+    B, Cin, T, N = inp.shape
+    Cout = W2.shape[0]
+    if inp.stride(3) != 1:
+        inp = inp.contiguous()
+    W2 = W2.contiguous()
+    dOut = dOut.contiguous()
+    L = _lib.lib()
+    ws = torch.empty((max(1, L.mgp_dense_bwd_workspace(B, Cin, Cout, T, N)),), device=inp.device,
+                     dtype=torch.float32)
+    dW = torch.empty((Cout, Cin), device=inp.device, dtype=torch.float32)
+    db = torch.empty((Cout,), device=inp.device, dtype=torch.float32)
+    dIn = torch.empty((B, Cin, T, N), device=inp.device, dtype=torch.float32) if need_dinp else None
+    rc = L.mgp_dense_bwd(_ptr(dOut), _ptr(out), _ptr(inp), _ptr(W2), _ptr(dW), _ptr(db), _ptr(dIn),
+                         B, Cin, Cout, T, N, inp.stride(0), inp.stride(1), inp.stride(2), act, _ptr(ws), _stream())
+    _lib.check(rc, 'mgp_dense_bwd')
+    return dW, db, dIn
+
+
+class _DenseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, W2, bias, act):
+        out = dense_fwd(inp, W2, bias, act)
+        ctx.act = act
+        ctx.save_for_backward(inp, W2, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        inp, W2, out = ctx.saved_tensors
+        dW, db, dIn = dense_bwd(dOut, out, inp, W2, ctx.act, ctx.needs_input_grad[0])
+        return dIn, dW, db, None
+
+
+def dense(inp, W2, bias, act):
+    """Differentiable per-agent dense layer (the reference's (step,1) Conv2d + optional tanh)."""
+    return _DenseFn.apply(inp, W2, bias, act)
+
+
+# ------------------------------------------------------------------------------------ state update
+def gso_update(A, G_prev, X_t, Xd_prev, K):
+    """A (B,N,N), G_prev (B,K,N,N)|None, X_t (B,F,N), Xd_prev (B,K,F,N)|None -> (G_next, Xd_next).
+    Reference state_with_delay.py:44-53."""
+    _dev(A, 'A'); _dev(X_t, 'X_t')
+    B, N, _ = A.shape
+    F = X_t.shape[1]
+    has_prev = G_prev is not None
+    if has_prev:
+        _dev(G_prev, 'G_prev'); _dev(Xd_prev, 'Xd_prev')
+        assert G_prev.shape == (B, K, N, N) and Xd_prev.shape == (B, K, F, N)
+        G_prev = G_prev.contiguous(); Xd_prev = Xd_prev.contiguous()
+    A = A.contiguous(); X_t = X_t.contiguous()
+    G_next = torch.empty((B, K, N, N), device=A.device, dtype=torch.float32)
+    Xd_next = torch.empty((B, K, F, N), device=A.device, dtype=torch.float32)
+    rc = _lib.lib().mgp_gso_update(_ptr(A), _ptr(G_prev), _ptr(G_next), _ptr(X_t), _ptr(Xd_prev), _ptr(Xd_next),
+                                   B, K, F, N, 1 if has_prev else 0, _stream())
+    _lib.check(rc, 'mgp_gso_update')
+    return G_next, Xd_next
+
+
+def gso_update_into(A, G_prev, G_next, X_t, Xd_prev, Xd_next, has_prev=True):
+    """In-place variant on preallocated ping-pong buffers (no allocation: HIP-graph capturable)."""
+    B, K, N, _ = G_next.shape
+    F = X_t.shape[1]
+    rc = _lib.lib().mgp_gso_update(_ptr(A), _ptr(G_prev), _ptr(G_next), _ptr(X_t), _ptr(Xd_prev), _ptr(Xd_next),
+                                   B, K, F, N, 1 if has_prev else 0, _stream())
+    _lib.check(rc, 'mgp_gso_update')
+
+
+def gso_powers(A, K):
+    """A (B,N,N) -> (B,K,N,N): I, A, A@A, ...   (reference state_with_delay.py:38-41)."""
+    _dev(A, 'A')
+    B, N, _ = A.shape
+    A = A.contiguous()
+    P = torch.empty((B, K, N, N), device=A.device, dtype=torch.float32)
+    rc = _lib.lib().mgp_gso_powers(_ptr(A), _ptr(P), B, K, N, _stream())
+    _lib.check(rc, 'mgp_gso_powers')
+    return P
+
+
+# ------------------------------------------------------------------------------------ flocking sim
+def flock_step(x, u, params, A=None, A64=None, feat=None, feat64=None, reward=None):
+    """In-place sim step on x (B,N,4) fp64; any output may be None.  See include/mgp.h."""
+    _dev(x, 'x', torch.float64)
+    B, N, _ = x.shape
+    assert x.is_contiguous()
+    if u is not None:
+        _dev(u, 'u'); assert u.shape == (B, N, 2) and u.is_contiguous()
+    rc = _lib.lib().mgp_flock_step(_ptr(x), _ptr(u), _ptr(A), _ptr(A64), _ptr(feat), _ptr(feat64), _ptr(reward),
+                                   ctypes.byref(params), B, N, _stream())
+    _lib.check(rc, 'mgp_flock_step')
+
+
+def flock_controller(x, params, centralized=False, u=None, u64=None):
+    _dev(x, 'x', torch.float64)
+    B, N, _ = x.shape
+    rc = _lib.lib().mgp_flock_controller(_ptr(x), _ptr(u), _ptr(u64), ctypes.byref(params),
+                                         1 if centralized else 0, B, N, _stream())
+    _lib.check(rc, 'mgp_flock_controller')
+
+
+# ------------------------------------------------------------------------------------ DAGGER update
+def mse_grad(pred, target, want_grad=True):
+    """Returns (loss (1,) tensor, dPred or None):  F.mse_loss(pred, target) and its gradient."""
+    _dev(pred, 'pred'); _dev(target, 'target')
+    assert pred.shape == target.shape
+    pred = pred.contiguous(); target = target.contiguous()
+    loss = torch.empty((1,), device=pred.device, dtype=torch.float32)
+    dPred = torch.empty_like(pred) if want_grad else None
+    rc = _lib.lib().mgp_mse_grad(_ptr(pred), _ptr(target), _ptr(dPred), _ptr(loss), pred.numel(), _stream())
+    _lib.check(rc, 'mgp_mse_grad')
+    return loss, dPred
+
+
+class _MseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        loss, dPred = mse_grad(pred, target, True)
+        ctx.save_for_backward(dPred)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dPred,) = ctx.saved_tensors
+        return dPred * g, None
+
+
+def mse_loss(pred, target):
+    """Differentiable mean-squared error (reference gnn_dagger.py:91)."""
+    return _MseFn.apply(pred, target)
+
+
+def adam_step(param, grad, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+    """torch.optim.Adam defaults on one flat fp32 buffer, in place (reference gnn_dagger.py:49,93)."""
+    for t, n in ((param, 'param'), (grad, 'grad'), (m, 'm'), (v, 'v')):
+        _dev(t, n)
+        assert t.is_contiguous()
+    rc = _lib.lib().mgp_adam_step(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(),
+                                  lr, beta1, beta2, eps, step, _stream())
+    _lib.check(rc, 'mgp_adam_step')
+
+
+__all__ = ['MgpFlockParams', 'MgpError', 'aggregate', 'dense', 'agg_fwd', 'agg_bwd_x', 'dense_fwd', 'dense_bwd',
+           'gso_update', 'gso_update_into', 'gso_powers', 'flock_step', 'flock_controller', 'mse_grad', 'mse_loss',
+           'adam_step', 'ACT_NONE', 'ACT_TANH']

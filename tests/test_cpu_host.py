@@ -1,0 +1,190 @@
+"""CPU-only: host logic and the C-ABI library (loads, exports every declared symbol) -- no kernels run."""
+import configparser
+import ctypes
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, golden_weights, ACTOR_GOLDENS, DAGGER_GOLDENS
+
+
+def _args(**kw):
+    cp = configparser.ConfigParser()
+    base = dict(alg='dagger', batch_size='20', buffer_size='10000', updates_per_step='200', seed='11',
+                actor_lr='5e-5', n_train_episodes='400', beta_coeff='0.993', test_interval='40',
+                n_test_episodes='20', k='3', hidden_size='32', gamma='0.99', tau='0.5',
+                env='FlockingRelative-v0', v_max='3.0', comm_radius='1.0', n_agents='100',
+                n_actions='2', n_states='6', debug='False', dt='0.01')
+    base.update({k: str(v) for k, v in kw.items()})
+    cp['DEFAULT'] = base
+    cp['test'] = {}
+    return cp['test']
+
+
+def test_library_loads_and_exports_every_header_symbol():
+    from multiagent_gnn_policies_amd import _lib
+    handle = _lib.lib()
+    declared = _lib.header_symbols()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(handle, name), "libmgp.so does not export %s declared in include/mgp.h" % name
+    assert set(declared) == set(_lib.SIGNATURES), "ctypes signature table out of sync with include/mgp.h"
+    assert handle.mgp_version() == 100
+    assert _lib.strerror(0) == 'ok'
+    assert 'invalid' in _lib.strerror(-1)
+
+
+def test_library_is_in_tree_and_built_for_gfx950():
+    from multiagent_gnn_policies_amd import build
+    assert os.path.dirname(build.LIB_PATH) == os.path.join(ROOT, 'multiagent_gnn_policies_amd')
+    assert os.path.exists(build.LIB_PATH)
+    with open(build.LIB_PATH, 'rb') as f:
+        blob = f.read()
+    assert b'gfx950' in blob, "libmgp.so carries no gfx950 code object"
+
+
+def test_c_abi_argument_validation_without_gpu():
+    """Entry points validate sizes/pointers before touching the device."""
+    from multiagent_gnn_policies_amd import _lib
+    L = _lib.lib()
+    null = ctypes.c_void_p(0)
+    assert L.mgp_agg_fwd(null, null, null, 1, 3, 6, 100, 0, 0, 0, 0, 0, 0, null) == -1      # null pointers
+    assert L.mgp_agg_fwd(null, null, null, 1, 0, 6, 100, 0, 0, 0, 0, 0, 0, null) == -1      # K == 0
+    assert L.mgp_agg_fwd(null, null, null, 0, 3, 6, 100, 0, 0, 0, 0, 0, 0, null) == 0       # empty batch
+    assert L.mgp_dense_fwd(null, null, null, null, 1, 4, 4, 1, 8, 0, 0, 0, 7, null) == -1   # bad activation
+    assert L.mgp_gso_update(null, null, null, null, null, null, 1, 3, 6, 0, 0, null) == -1
+    assert L.mgp_adam_step(null, null, null, null, 10, 1e-3, 0.9, 0.999, 1e-8, 0, null) == -1
+    assert L.mgp_dense_bwd_workspace(20, 18, 32, 1, 100) == 20 * 2 * (32 * 18 + 32)
+    dims = (ctypes.c_int * 4)(6, 32, 32, 2)
+    assert L.mgp_actor_saved_floats(dims, 3, 20, 3, 100) == 20 * (18 + 32 + 32) * 100
+
+
+def test_actor_constructor_matches_reference_layout_and_init():
+    """Same attributes, state_dict keys/shapes, and identical default init under the same torch seed."""
+    from multiagent_gnn_policies_amd.learner import Actor
+    for name in ACTOR_GOLDENS:
+        if '_init_' not in name:
+            continue
+        g = load_golden(name)
+        B, K, F, N = [int(v) for v in g['shape']]
+        Ws, bs = golden_weights(g)
+        hidden = [int(h) for h in g['hidden']]
+        torch.manual_seed(int(g['seed']))
+        a = Actor(F, Ws[-1].shape[0], hidden, K, int(g['ind_agg']))
+        assert a.k == K and a.n_s == F and a.n_a == Ws[-1].shape[0]
+        assert a.layers == [F] + hidden + [a.n_a] and a.n_layers == len(Ws) and a.ind_agg == int(g['ind_agg'])
+        sd = a.state_dict()
+        assert list(sd.keys()) == [f'conv_layers.{i}.{p}' for i in range(len(Ws)) for p in ('weight', 'bias')]
+        for i in range(len(Ws)):
+            assert np.array_equal(sd[f'conv_layers.{i}.weight'].numpy(), Ws[i]), name
+            assert np.array_equal(sd[f'conv_layers.{i}.bias'].numpy(), bs[i]), name
+
+
+def test_actor_loads_shipped_checkpoint_layout():
+    from multiagent_gnn_policies_amd.learner import Actor
+    ck = load_golden('ckpt_dagger_k3')
+    sd = {k.replace('__', '.'): torch.from_numpy(v) for k, v in ck.items()}
+    a = Actor(6, 2, [32, 32], 3, 0)
+    a.load_state_dict(sd)                                   # strict: keys and shapes must match
+    assert sum(p.numel() for p in a.parameters()) == 1730
+
+
+def test_no_cpu_fallback():
+    """Product ops must refuse CPU tensors loudly instead of computing on the host."""
+    from multiagent_gnn_policies_amd import MgpError, ops
+    from multiagent_gnn_policies_amd.learner import Actor, MultiAgentStateWithDelay
+    a = Actor(6, 2, [32, 32], 3, 0)
+    with pytest.raises(MgpError):
+        a(torch.zeros(1, 3, 6, 10), torch.zeros(1, 3, 10, 10))
+    with pytest.raises(AssertionError):                      # shape contract is checked first
+        a(torch.zeros(1, 2, 6, 10), torch.zeros(1, 3, 10, 10))
+    with pytest.raises(MgpError):
+        ops.agg_fwd(torch.zeros(1, 6, 3, 10), torch.zeros(1, 3, 10, 10))
+    vals, net = np.zeros((10, 6)), np.zeros((10, 10))
+    with pytest.raises(MgpError):
+        MultiAgentStateWithDelay(torch.device('cpu'), _args(n_agents=10), (vals, net))
+    with pytest.raises(AssertionError):                      # zero-diagonal contract (state_with_delay.py:26)
+        MultiAgentStateWithDelay(torch.device('cpu'), _args(n_agents=10), (vals, np.eye(10)))
+
+
+def test_product_never_imports_oracle():
+    import re
+    pkg = os.path.join(ROOT, 'multiagent_gnn_policies_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                with open(os.path.join(dirpath, f)) as fh:
+                    assert not re.search(r'^\s*(from|import)\s+oracle\b', fh.read(), flags=re.M), f
+    with open(os.path.join(ROOT, 'train.py')) as fh:
+        assert 'oracle' not in fh.read()
+
+
+def test_replay_buffer_semantics():
+    from multiagent_gnn_policies_amd.learner import ReplayBuffer, Transition
+    rb = ReplayBuffer(max_size=3)
+    for i in range(5):
+        rb.insert(Transition(i, i, i, i, i))
+    assert rb.curr_size == 3 and rb.position == 2
+    assert sorted(t.state for t in rb.buffer) == [2, 3, 4]          # oldest overwritten
+    random.seed(0)
+    s = rb.sample(3)
+    assert sorted(t.state for t in s) == [2, 3, 4]                  # without replacement
+    with pytest.raises(ValueError):
+        rb.sample(4)
+    rb.clear()
+    assert rb.curr_size == 0 and rb.buffer == []
+
+
+def test_time_limit_and_registry():
+    from multiagent_gnn_policies_amd import envs
+
+    class Fake(object):
+        def __init__(self):
+            self.n = 0
+
+        def reset(self):
+            return 'obs'
+
+        def step(self, a):
+            self.n += 1
+            return 'obs', -1.0, False, {}
+
+    tl = envs.TimeLimit(Fake(), 3)
+    tl.reset()
+    dones = [tl.step(None)[2] for _ in range(3)]
+    assert dones == [False, False, True]
+    tl.reset()
+    assert tl.step(None)[2] is False
+    assert {'FlockingRelative-v0', 'FlockingLeader-v0', 'FlockingTwoFlocks-v0'} <= set(envs.registered_ids())
+    with pytest.raises(KeyError):
+        envs.make('NoSuchEnv-v0')
+    env = envs.make('FlockingRelative-v0')
+    assert isinstance(env.env, envs.FlockingRelativeEnv)
+    env.env.params_from_cfg(_args(n_agents=50, comm_radius=1.5, v_max=2.0, dt=0.02))
+    p = env.env.params
+    assert (p.n_agents, p.comm_radius, p.v_max, p.v_bias, p.dt) == (50, 1.5, 2.0, 2.0, 0.02)
+
+
+def test_reset_sampler_matches_oracle_spec():
+    from multiagent_gnn_policies_amd.envs import flocking
+    from oracle import flock as ofl
+    p = flocking.FlockParams(n_agents=40)
+    op = ofl.FlockParams(n_agents=40)
+    a = flocking.sample_initial_state(np.random.RandomState(5), p)
+    b = ofl.reset(np.random.RandomState(5), op)
+    assert np.array_equal(a, b)
+    h = ofl.helpers(a, op)
+    assert h['deg'].min() >= 2 and np.sqrt(h['r2'].min()) >= 0.1
+
+
+def test_shard_range_partitions_episodes():
+    from multiagent_gnn_policies_amd.parallel import shard_range
+    for n, w in [(256, 8), (10, 4), (3, 8), (64, 1)]:
+        got = [shard_range(n, r, w) for r in range(w)]
+        assert got[0][0] == 0 and got[-1][1] == n
+        assert all(got[i][1] == got[i + 1][0] for i in range(w - 1))
+        sizes = [hi - lo for lo, hi in got]
+        assert max(sizes) - min(sizes) <= 1
