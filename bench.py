@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""bench.py -- agent-steps/sec of the per-step hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" advances EVERY episode of the batch by one environment step through the whole path
+    sim step (mgp_flock_step)  ->  delayed-GSO / delay-line update (mgp_gso_update)
+    ->  Actor forward (aggregation X.G + filter GEMM + tanh MLP)  ->  action fed back to the sim,
+all inputs resident in HBM, no host round trip (steps are replayed from a captured HIP graph).
+Workload = BASELINE.json configs[1]: FlockingRelative-v0, N=100 agents, K=3 taps, 256 parallel episodes
+PER GPU (weak scaling: episodes are independent, ranks never communicate in the rollout).
+value = (episodes * agents * steps * ranks) / max-over-ranks wall time.
+
+Also reported on the same JSON line:
+  roofline      the graph-shift aggregation kernel (HBM-bound): algorithmic bytes (4KN^2 + 8KFN per
+                episode-step) / average launch duration measured with HIP events on the
+                launch stream, over rotating input sets larger than the 256 MiB Infinity Cache.
+  kernels       same measurement for the other kernels of the step.
+  cpu_baseline  the PyTorch-CPU port of the reference op sequence (oracle/torch_port.py, "kind": "port"),
+                reference-style B=1 loop, timed on this host for a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from multiagent_gnn_policies_amd import ops, parallel  # noqa: E402
+from multiagent_gnn_policies_amd.envs import FlockParams, VecFlock  # noqa: E402
+from multiagent_gnn_policies_amd.learner import Actor  # noqa: E402
+from multiagent_gnn_policies_amd.learner.state_with_delay import BatchedDelayState  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+F_FEAT, N_ACT = 6, 2
+
+
+def load_weights(actor):
+    """Shipped reference checkpoint (stored as plain arrays in tests/golden) when the shape matches,
+    else torch default init under seed 11 (cfg/dagger.cfg:9)."""
+    path = os.path.join(ROOT, 'tests', 'golden', 'ckpt_dagger_k3.npz')
+    if os.path.exists(path):
+        with np.load(path) as z:
+            sd = {k.replace('__', '.'): torch.from_numpy(z[k]) for k in z.files}
+        try:
+            actor.load_state_dict(sd)
+            return 'reference checkpoint actor_FlockingRelative-v0_dagger_k3'
+        except RuntimeError:
+            pass
+    return 'default init (seed 11)'
+
+
+class Rollout(object):
+    """Device-resident vectorised rollout; one `step()` = one env step for all B episodes."""
+
+    def __init__(self, device, B, N, K, hidden, seed):
+        self.B, self.N, self.K = B, N, K
+        self.params = FlockParams(n_agents=N, init_mode='grid')
+        self.sim = VecFlock(B, self.params, device)
+        torch.manual_seed(11)
+        self.actor = Actor(F_FEAT, N_ACT, hidden, K, 0).to(device)
+        self.weights = load_weights(self.actor)
+        self.actor.eval()
+        self.state = BatchedDelayState(device, B, K, F_FEAT, N)
+        self.sim.reset(np.random.RandomState(seed))
+        self.state.push(self.sim.network, self.sim.features)
+
+    def step(self):
+        with torch.no_grad():
+            out = self.actor(self.state.delay_state, self.state.delay_gso)      # (B,1,2,N)
+            self.sim.step(out)                                                   # consumes (B,1,2,N) directly
+            self.state.push(self.sim.network, self.sim.features)
+
+
+def time_kernel(fn, n_sets, iters):
+    """Average duration (ms) of one launch of fn(i), HIP events on the launch stream, back to back."""
+    for i in range(min(n_sets, 3)):
+        fn(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for it in range(iters):
+        fn(it % n_sets)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def kernel_rooflines(device, B, N, K, actor, flock_c):
+    """Per-kernel live measurements on rotating buffers (working set > 256 MiB Infinity Cache)."""
+    g_bytes = 4 * K * N * N * B
+    n_sets = max(2, int(np.ceil(320 * 2 ** 20 / g_bytes)))
+    n_sets = min(n_sets, 24)
+    gen = torch.Generator(device=device).manual_seed(1)
+    Gs = [torch.rand((B, K, N, N), device=device, generator=gen) for _ in range(n_sets)]
+    Xs = [torch.randn((B, K, F_FEAT, N), device=device, generator=gen) for _ in range(n_sets)]
+    res = {}
+    # --- aggregation (the roofline kernel)
+    iters = max(50, 4 * n_sets)
+    ms = time_kernel(lambda i: ops.agg_fwd(Xs[i].permute(0, 2, 1, 3), Gs[i]), n_sets, iters)
+    agg_bytes = (4 * K * N * N + 8 * K * F_FEAT * N) * B
+    res['agg_fwd'] = dict(ms=ms, bytes=agg_bytes, gbs=agg_bytes / ms / 1e6)
+    # --- whole Actor forward (aggregation + filter GEMM + MLP readout)
+    with torch.no_grad():
+        ms = time_kernel(lambda i: actor(Xs[i], Gs[i]), n_sets, iters)
+    act_bytes = (4 * K * N * N + 4 * K * F_FEAT * N + 4 * N_ACT * N) * B
+    res['actor_fwd'] = dict(ms=ms, bytes=act_bytes, gbs=act_bytes / ms / 1e6)
+    # --- delayed-GSO update: read A, G_prev[1..K-2]; write K slices
+    As = [torch.zeros((B, N, N), device=device) for _ in range(n_sets)]
+    for a in As:
+        mask = torch.rand((B, N, N), device=device, generator=gen) < (8.0 / N)
+        a.copy_(mask.float() / mask.float().sum(-1, keepdim=True).clamp(min=1))
+    Gn = [torch.empty((B, K, N, N), device=device) for _ in range(2)]
+    Xn = torch.empty((B, K, F_FEAT, N), device=device)
+    Xt = torch.randn((B, F_FEAT, N), device=device, generator=gen)
+    ms = time_kernel(lambda i: ops.gso_update_into(As[i], Gs[i], Gn[i % 2], Xt, Xs[i], Xn, True), n_sets, iters)
+    gso_bytes = 4 * (2 * K - 1) * N * N * B
+    res['gso_update'] = dict(ms=ms, bytes=gso_bytes, gbs=gso_bytes / ms / 1e6)
+    # --- sim step: writes the dense N x N network matrix
+    xs = torch.randn((B, N, 4), device=device, dtype=torch.float64, generator=gen) * 3.0
+    u = torch.zeros((B, N, 2), device=device)
+    feat = torch.empty((B, F_FEAT, N), device=device)
+    rew = torch.empty((B,), device=device, dtype=torch.float64)
+    ms = time_kernel(lambda i: ops.flock_step(xs, u, flock_c, A=As[i], feat=feat, reward=rew), n_sets, iters)
+    sim_bytes = (4 * N * N + 8 * 4 * N * 2 + 4 * (2 + 6) * N) * B
+    res['flock_step'] = dict(ms=ms, bytes=sim_bytes, gbs=sim_bytes / ms / 1e6)
+    del Gs, Xs, As
+    torch.cuda.empty_cache()
+    return res, n_sets
+
+
+def cpu_baseline(N, K, hidden, budget_s=12.0):
+    """Reference-style single-episode CPU loop (oracle/torch_port.py + numpy sim), bounded sample."""
+    from oracle import flock as ofl, torch_port
+    path = os.path.join(ROOT, 'tests', 'golden', 'ckpt_dagger_k3.npz')
+    torch.manual_seed(11)
+    if os.path.exists(path) and K == 3 and hidden == [32, 32]:
+        with np.load(path) as z:
+            Ws = [torch.from_numpy(z[f'conv_layers__{i}__weight']) for i in range(3)]
+            bs = [torch.from_numpy(z[f'conv_layers__{i}__bias']) for i in range(3)]
+    else:
+        dims = [F_FEAT] + hidden + [N_ACT]
+        Ws = [torch.randn(dims[i + 1], dims[i], K if i == 0 else 1, 1) * 0.1 for i in range(len(dims) - 1)]
+        bs = [torch.zeros(dims[i + 1]) for i in range(len(dims) - 1)]
+    p = ofl.FlockParams(n_agents=N, init_mode='grid')
+    x = ofl.reset(np.random.RandomState(0), p)
+    torch_port.rollout_steps(x, p, Ws, bs, K, 5)                     # warm-up
+    chunk, done = 50, 0
+    t0 = time.perf_counter()
+    while True:
+        _, x = torch_port.rollout_steps(x, p, Ws, bs, K, chunk)
+        done += chunk
+        el = time.perf_counter() - t0
+        if el >= budget_s or done >= 20000:
+            break
+    threads = torch.get_num_threads()
+    return dict(value=N * done / el, unit='agent-steps/s', cores=threads, kind='port',
+                sample='1 episode x %d steps (%.1f s), reference-style B=1 loop: numpy fp64 sim + torch-CPU '
+                       'state update (incl. curr_gso) + Actor forward; host has %d logical cores'
+                       % (done, el, os.cpu_count() or 0),
+                ms_per_env_step=1e3 * el / done)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--episodes', type=int, default=256, help='parallel episodes per GPU')
+    ap.add_argument('--agents', type=int, default=100)
+    ap.add_argument('--taps', type=int, default=3)
+    ap.add_argument('--hidden', type=int, default=32)
+    ap.add_argument('--layers', type=int, default=2)
+    ap.add_argument('--graph-steps', type=int, default=10, help='env steps captured per HIP graph (0 = eager)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    B, N, K = args.episodes, args.agents, args.taps
+    hidden = [args.hidden] * args.layers
+
+    ro = Rollout(device, B, N, K, hidden, seed=1000 + rank)
+
+    # ---- capture `gs` consecutive env steps into one HIP graph (even count: ping-pong buffers realign)
+    gs = args.graph_steps
+    if gs > 0:
+        gs = gs + (gs % 2)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                ro.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(gs):
+                ro.step()
+
+        def run(n_steps):
+            for _ in range(n_steps // gs):
+                graph.replay()
+            for _ in range(n_steps % gs):
+                ro.step()
+    else:
+        def run(n_steps):
+            for _ in range(n_steps):
+                ro.step()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    run(args.warmup)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        el = float(t.item())
+    finite = bool(torch.isfinite(ro.sim.x).all().item())
+
+    out = None
+    if rank == 0:
+        total_eps = B * world
+        value = total_eps * N * args.steps / el
+        out = {
+            "metric": "agent-steps/sec, FlockingRelative-v0 N=%d K=%d" % (N, K),
+            "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "FlockingRelative-v0 N=%d K=%d, %d parallel episodes per MI355X "
+                                   "(BASELINE.json configs[1]); per step: sim step -> delayed-GSO update -> "
+                                   "Actor forward (hidden %s) -> action" % (N, K, B, hidden),
+                       "episodes_per_gpu": B, "episodes_total": total_eps, "agents": N, "taps": K,
+                       "graph_steps": gs, "weights": ro.weights, "parallelism": "episodes sharded x%d, no "
+                       "data-path collective" % world, "state_finite": finite},
+        }
+    if rank == 0 and not args.no_roofline:
+        res, n_sets = kernel_rooflines(device, B, N, K, ro.actor, ro.sim._c)
+        agg = res['agg_fwd']
+        out["roofline"] = {"kernel": "agg_fwd_kernel (graph-shift aggregation X.G)", "bound": "hbm",
+                           "achieved": agg['gbs'], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": agg['gbs'] / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_launch": agg['bytes'], "avg_launch_ms": agg['ms'],
+                           "rotating_input_sets": n_sets}
+        out["kernels"] = {k: {"avg_launch_ms": v['ms'], "algorithmic_bytes": v['bytes'], "GBps": v['gbs']}
+                          for k, v in res.items()}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(N, K, hidden)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -39,6 +39,8 @@ extern "C" {
 
 int         mgp_version(void);
 const char* mgp_strerror(int code);
+/* Text of the HIP error behind the calling thread's most recent MGP_ELAUNCH. */
+const char* mgp_last_hip_error(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or a negative code. */
 int         mgp_device_info(char* name, int cap);
 
@@ -148,13 +150,16 @@ typedef struct MgpFlockParams {
     int    n_leaders;      /* first n_leaders agents ignore u                     */
 } MgpFlockParams;
 
-/* x <- integrate(x, u) in place (u (B,N,2) fp32, may be NULL = zero action / refresh only), then
+/* x <- integrate(x, u) in place, then observations.  u is fp32 with batch stride 2N and element (i,a) at
+ * i*su_agent + a*su_axis: (B,N,2) is (2,1); the Actor's output layout (B,1,2,N) is (1,N) -- no transpose
+ * kernel between policy and simulator.  u may be NULL (= refresh observations only).
  *   A    (B,N,N) fp32  network matrix           (may be NULL)
  *   A64  (B,N,N) fp64  same, fp64               (may be NULL; gym facade)
  *   feat (B,6,N) fp32  features TRANSPOSED to the (F,N) layout state_with_delay.py:29 builds (may be NULL)
  *   feat64 (B,N,6) fp64 features in the env's own (N,6) layout (may be NULL; gym facade)
  *   reward (B) fp64    -(var vx + var vy) * reward_scale  (may be NULL)                       */
-int mgp_flock_step(double* x, const float* u, float* A, double* A64, float* feat, double* feat64,
+int mgp_flock_step(double* x, const float* u, long su_agent, long su_axis,
+                   float* A, double* A64, float* feat, double* feat64,
                    double* reward, const MgpFlockParams* p, int B, int N, void* stream);
 
 /* Expert controller on the current x: u (B,N,2) fp32 and/or u64 (B,N,2) fp64 (either may be NULL). */

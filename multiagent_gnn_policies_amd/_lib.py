@@ -29,6 +29,7 @@ class MgpFlockParams(ctypes.Structure):
 SIGNATURES = {
     'mgp_version': (_int, []),
     'mgp_strerror': (ctypes.c_char_p, [_int]),
+    'mgp_last_hip_error': (ctypes.c_char_p, []),
     'mgp_device_info': (_int, [ctypes.c_char_p, _int]),
     'mgp_agg_fwd': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _long, _long, _long, _long, _long, _long, _vp]),
     'mgp_agg_bwd_x': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _long, _long, _long, _long, _long, _long, _vp]),
@@ -44,7 +45,8 @@ SIGNATURES = {
                              ctypes.POINTER(_vp), _int, _int, _int, _vp, _vp]),
     'mgp_gso_update': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     'mgp_gso_powers': (_int, [_vp, _vp, _int, _int, _int, _vp]),
-    'mgp_flock_step': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(MgpFlockParams), _int, _int, _vp]),
+    'mgp_flock_step': (_int, [_vp, _vp, _long, _long, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(MgpFlockParams), _int,
+                             _int, _vp]),
     'mgp_flock_controller': (_int, [_vp, _vp, _vp, ctypes.POINTER(MgpFlockParams), _int, _int, _int, _vp]),
     'mgp_mse_grad': (_int, [_vp, _vp, _vp, _vp, _long, _vp]),
     'mgp_adam_step': (_int, [_vp, _vp, _vp, _vp, _long, _f32, _f32, _f32, _f32, _int, _vp]),
@@ -75,6 +77,11 @@ def lib():
     with _lock:
         if _lib is not None:
             return _lib
+        # torch bundles its own HIP runtime (soname libamdhip64.so.7).  It must be mapped BEFORE libmgp.so so
+        # that our DT_NEEDED libamdhip64.so.7 binds to the very same runtime instance torch uses; loading
+        # libmgp first would pull /opt/rocm's copy and leave two runtimes in one process (kernels launched
+        # into a runtime that never saw torch's device context: "no ROCm-capable device").
+        import torch  # noqa: F401
         path = _build.LIB_PATH
         if not os.path.exists(path):
             try:
@@ -102,7 +109,11 @@ def lib():
 def check(rc, what):
     if rc != 0:
         msg = lib().mgp_strerror(rc)
-        raise MgpError("%s failed: %s (code %d)" % (what, msg.decode() if msg else '?', rc))
+        text = msg.decode() if msg else '?'
+        if rc == -3:
+            hip = lib().mgp_last_hip_error()
+            text += ' [HIP: %s]' % (hip.decode() if hip else '?')
+        raise MgpError("%s failed: %s (code %d)" % (what, text, rc))
 
 
 def strerror(rc):

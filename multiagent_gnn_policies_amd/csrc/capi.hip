@@ -2,7 +2,14 @@
 #include <string.h>
 #include "mgp_common.h"
 
+thread_local int mgp_tls_hip_error = 0;
+
 extern "C" int mgp_version(void) { return MGP_VERSION; }
+
+extern "C" const char* mgp_last_hip_error(void)
+{
+    return hipGetErrorString((hipError_t)mgp_tls_hip_error);
+}
 
 extern "C" const char* mgp_strerror(int code)
 {

@@ -33,8 +33,8 @@ __device__ __forceinline__ double block_sum(double v, double* sh /* [4] */)
 
 // grid: x = b
 __global__ __launch_bounds__(FL_THREADS)
-void flock_integrate_kernel(double* __restrict__ x, const float* __restrict__ u, double* __restrict__ reward,
-                            MgpFlockParams p, int N)
+void flock_integrate_kernel(double* __restrict__ x, const float* __restrict__ u, long su_agent, long su_axis,
+                            double* __restrict__ reward, MgpFlockParams p, int N)
 {
     __shared__ double sh[4];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -45,8 +45,9 @@ void flock_integrate_kernel(double* __restrict__ x, const float* __restrict__ u,
         if (u != nullptr) {
             double ux = 0.0, uy = 0.0;
             if (i >= p.n_leaders) {
-                ux = clipd((double)u[((size_t)b * N + i) * 2 + 0], -p.max_accel, p.max_accel) * p.action_gain;
-                uy = clipd((double)u[((size_t)b * N + i) * 2 + 1], -p.max_accel, p.max_accel) * p.action_gain;
+                const float* ub = u + (size_t)b * N * 2 + (size_t)i * su_agent;
+                ux = clipd((double)ub[0], -p.max_accel, p.max_accel) * p.action_gain;
+                uy = clipd((double)ub[su_axis], -p.max_accel, p.max_accel) * p.action_gain;
             }
             px = (px + vx * p.dt) + ((ux * p.dt) * p.dt) * 0.5;
             py = (py + vy * p.dt) + ((uy * p.dt) * p.dt) * 0.5;
@@ -184,7 +185,8 @@ int check_params(const MgpFlockParams* p)
 
 }  // namespace
 
-extern "C" int mgp_flock_step(double* x, const float* u, float* A, double* A64, float* feat, double* feat64,
+extern "C" int mgp_flock_step(double* x, const float* u, long su_agent, long su_axis,
+                              float* A, double* A64, float* feat, double* feat64,
                               double* reward, const MgpFlockParams* p, int B, int N, void* stream)
 {
     if (B < 0 || N <= 0) return MGP_EINVAL;
@@ -196,7 +198,8 @@ extern "C" int mgp_flock_step(double* x, const float* u, float* A, double* A64, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     mgp_clear_error();
     if (u != nullptr || reward != nullptr) {
-        hipLaunchKernelGGL(flock_integrate_kernel, dim3(B), dim3(FL_THREADS), 0, st, x, u, reward, *p, N);
+        hipLaunchKernelGGL(flock_integrate_kernel, dim3(B), dim3(FL_THREADS), 0, st, x, u, su_agent, su_axis,
+                           reward, *p, N);
         rc = mgp_launch_status();
         if (rc != MGP_OK) return rc;
     }

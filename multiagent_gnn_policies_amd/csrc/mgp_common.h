@@ -25,8 +25,13 @@
 // this call's launches.
 static inline void mgp_clear_error() { (void)hipGetLastError(); }
 
+extern thread_local int mgp_tls_hip_error;      // defined in capi.hip; read by mgp_last_hip_error()
+
 static inline int mgp_launch_status() {
-    return hipGetLastError() == hipSuccess ? MGP_OK : MGP_ELAUNCH;
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return MGP_OK;
+    mgp_tls_hip_error = (int)e;
+    return MGP_ELAUNCH;
 }
 
 static inline bool mgp_aligned16(const void* p) {

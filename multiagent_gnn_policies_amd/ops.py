@@ -190,14 +190,21 @@ def gso_powers(A, K):
 
 # ------------------------------------------------------------------------------------ flocking sim
 def flock_step(x, u, params, A=None, A64=None, feat=None, feat64=None, reward=None):
-    """In-place sim step on x (B,N,4) fp64; any output may be None.  See include/mgp.h."""
+    """In-place sim step on x (B,N,4) fp64; any output may be None.  See include/mgp.h.
+    u: (B,N,2) contiguous, or the Actor's output (B,1,2,N) contiguous (consumed without a transpose)."""
     _dev(x, 'x', torch.float64)
     B, N, _ = x.shape
     assert x.is_contiguous()
+    su_agent, su_axis = 2, 1
     if u is not None:
-        _dev(u, 'u'); assert u.shape == (B, N, 2) and u.is_contiguous()
-    rc = _lib.lib().mgp_flock_step(_ptr(x), _ptr(u), _ptr(A), _ptr(A64), _ptr(feat), _ptr(feat64), _ptr(reward),
-                                   ctypes.byref(params), B, N, _stream())
+        _dev(u, 'u')
+        assert u.is_contiguous()
+        if u.shape == (B, 1, 2, N) or u.shape == (B, 2, N):
+            su_agent, su_axis = 1, N
+        else:
+            assert u.shape == (B, N, 2), "u must be (B,N,2) or (B,1,2,N)"
+    rc = _lib.lib().mgp_flock_step(_ptr(x), _ptr(u), su_agent, su_axis, _ptr(A), _ptr(A64), _ptr(feat), _ptr(feat64),
+                                   _ptr(reward), ctypes.byref(params), B, N, _stream())
     _lib.check(rc, 'mgp_flock_step')
 
 

@@ -107,3 +107,28 @@ def test_label_action_roundtrip():
     lab = od.label_from_action(a)
     assert lab.shape == (1, 1, 2, 7)
     assert np.array_equal(od.action_from_output(lab), a)
+
+
+@pytest.mark.parametrize('name', [n for n in ACTOR_GOLDENS])
+def test_torch_port_matches_reference(name):
+    """The torch-CPU port timed as bench.py's cpu_baseline reproduces the reference outputs."""
+    import torch
+    from oracle import torch_port
+    g = load_golden(name)
+    X, G = golden_inputs(g)
+    Ws, bs = golden_weights(g)
+    out = torch_port.actor_forward(torch.from_numpy(X), torch.from_numpy(G), [torch.from_numpy(w) for w in Ws],
+                                   [torch.from_numpy(b) for b in bs], int(g['ind_agg']), int(g['shape'][1]))
+    assert close(out.numpy(), g['out'], 2e-6)
+
+
+def test_torch_port_state_matches_reference():
+    from oracle import torch_port
+    g = load_golden('state_N16_K3')
+    prev = None
+    for t in range(int(g['steps'])):
+        st = torch_port.PortState(g[f'values_{t}'], g[f'network_{t}'], 3, prev)
+        assert np.array_equal(st.delay_gso.numpy(), g[f'delay_gso_{t}'])
+        assert np.array_equal(st.delay_state.numpy(), g[f'delay_state_{t}'])
+        assert np.array_equal(st.curr_gso.numpy(), g[f'curr_gso_{t}'])
+        prev = st
