@@ -101,9 +101,9 @@ def helpers(x, p):
     r4 = r2 * r2
     feats = np.stack([diff[:, :, 2], diff[:, :, 0] / r4, diff[:, :, 0] / r2,
                       diff[:, :, 3], diff[:, :, 1] / r4, diff[:, :, 1] / r2], axis=2)
-    values = np.zeros((n, 6), dtype=np.float64)
-    for j in range(n):                                       # sequential-j summation order
-        values += feats[:, j, :] * adj[:, j, None]
+    # reduction over the middle axis adds the j-slices in ascending order (sequential-j summation;
+    # bit-identical to an explicit loop `for j: values += feats[:, j] * adj[:, j]`)
+    values = np.sum(feats * adj[:, :, None], axis=1)
     return dict(diff=diff, r2=r2, adj=adj, deg=deg, network=network, values=values)
 
 
@@ -134,9 +134,7 @@ def controller(x, p, centralized=False):
     else:
         eye = np.eye(n, dtype=bool)
         terms = np.where(eye[:, :, None], 0.0, terms)
-    s = np.zeros((n, 4), dtype=np.float64)
-    for j in range(n):
-        s += terms[:, j, :]
+    s = np.sum(terms, axis=1)                                # ascending-j summation order
     raw = np.stack([-s[:, 2] - s[:, 0], -s[:, 1] - s[:, 3]], axis=1)
     return np.clip(raw, -p.ctrl_clip, p.ctrl_clip) * p.ctrl_gain
 
