@@ -102,6 +102,8 @@ int  mgp_dense_bwd(const float* dOut, const float* out, const float* in, const f
  * mgp_agg_fwd + mgp_dense_fwd instead).
  * ------------------------------------------------------------------------------------ */
 long mgp_actor_saved_floats(const int* dims, int n_layers, int B, int K, int N);
+/* 1 if the fused kernel covers (dims, K, N): F <= 8, F*K <= 64, every layer width <= 64, LDS plan fits. */
+int  mgp_actor_supported(const int* dims, int n_layers, int K, int N);
 int  mgp_actor_fwd(const float* X, const float* G,
                    const float* const* W, const float* const* b,
                    const int* dims, int n_layers,
@@ -157,10 +159,12 @@ typedef struct MgpFlockParams {
  *   A64  (B,N,N) fp64  same, fp64               (may be NULL; gym facade)
  *   feat (B,6,N) fp32  features TRANSPOSED to the (F,N) layout state_with_delay.py:29 builds (may be NULL)
  *   feat64 (B,N,6) fp64 features in the env's own (N,6) layout (may be NULL; gym facade)
- *   reward (B) fp64    -(var vx + var vy) * reward_scale  (may be NULL)                       */
+ *   reward (B) fp64    -(var vx + var vy) * reward_scale  (may be NULL)
+ *   expert (B,N,2) fp32 decentralised expert action for the NEW state (may be NULL): a closed form of the
+ *                      features, so the DAGGER label costs no second pairwise pass                   */
 int mgp_flock_step(double* x, const float* u, long su_agent, long su_axis,
                    float* A, double* A64, float* feat, double* feat64,
-                   double* reward, const MgpFlockParams* p, int B, int N, void* stream);
+                   double* reward, float* expert, const MgpFlockParams* p, int B, int N, void* stream);
 
 /* Expert controller on the current x: u (B,N,2) fp32 and/or u64 (B,N,2) fp64 (either may be NULL). */
 int mgp_flock_controller(const double* x, float* u, double* u64, const MgpFlockParams* p,

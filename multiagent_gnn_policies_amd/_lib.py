@@ -38,6 +38,7 @@ SIGNATURES = {
     'mgp_dense_bwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _long, _long, _long,
                              _int, _vp, _vp]),
     'mgp_actor_saved_floats': (_long, [ctypes.POINTER(_int), _int, _int, _int, _int]),
+    'mgp_actor_supported': (_int, [ctypes.POINTER(_int), _int, _int, _int]),
     'mgp_actor_fwd': (_int, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_int), _int,
                              _vp, _vp, _int, _int, _int, _vp]),
     'mgp_actor_bwd_workspace': (_long, [ctypes.POINTER(_int), _int, _int, _int, _int]),
@@ -45,8 +46,8 @@ SIGNATURES = {
                              ctypes.POINTER(_vp), _int, _int, _int, _vp, _vp]),
     'mgp_gso_update': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     'mgp_gso_powers': (_int, [_vp, _vp, _int, _int, _int, _vp]),
-    'mgp_flock_step': (_int, [_vp, _vp, _long, _long, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(MgpFlockParams), _int,
-                             _int, _vp]),
+    'mgp_flock_step': (_int, [_vp, _vp, _long, _long, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(MgpFlockParams),
+                             _int, _int, _vp]),
     'mgp_flock_controller': (_int, [_vp, _vp, _vp, ctypes.POINTER(MgpFlockParams), _int, _int, _int, _vp]),
     'mgp_mse_grad': (_int, [_vp, _vp, _vp, _vp, _long, _vp]),
     'mgp_adam_step': (_int, [_vp, _vp, _vp, _vp, _long, _f32, _f32, _f32, _f32, _int, _vp]),

@@ -133,8 +133,9 @@ class VecFlock(object):
       x (B,N,4) f64 | network (B,N,N) f32 | features (B,6,N) f32 (already (F,N)) | reward (B) f64
     """
 
-    def __init__(self, B, params, device='cuda', want_f64_obs=False):
+    def __init__(self, B, params, device='cuda', want_f64_obs=False, with_expert=False):
         self.B, self.p = B, params
+        self.with_expert = with_expert
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise ops.MgpError("VecFlock needs a HIP device (no CPU simulation path)")
@@ -162,17 +163,20 @@ class VecFlock(object):
         self.set_state(np.stack([sample_initial_state(rng, self.p) for _ in range(self.B)]))
 
     def refresh(self):
-        """Recompute observations for the current x without integrating."""
+        """Recompute observations (and the decentralised expert action) for the current x without integrating."""
         ops.flock_step(self.x, None, self._c, A=self.network, A64=self.network64, feat=self.features,
-                       feat64=self.features64, reward=self.reward)
+                       feat64=self.features64, reward=self.reward, expert=self.expert if self.with_expert else None)
 
     def step(self, u):
-        """u (B,N,2) fp32 on device.  Advances every episode one step (in place)."""
+        """u (B,N,2) or the Actor output (B,1,2,N), fp32 on device.  Advances every episode one step in place;
+        with `with_expert` the decentralised expert action of the new state lands in `self.expert` for free."""
         ops.flock_step(self.x, u, self._c, A=self.network, A64=self.network64, feat=self.features,
-                       feat64=self.features64, reward=self.reward)
+                       feat64=self.features64, reward=self.reward, expert=self.expert if self.with_expert else None)
 
     def controller(self, centralized=False):
         """Expert action for the current state -> (B,N,2) fp32 (buffer reused)."""
+        if self.with_expert and not centralized and self.expert64 is None:
+            return self.expert                      # already produced by the last step()/refresh()
         ops.flock_controller(self.x, self._c, centralized=bool(centralized), u=self.expert, u64=self.expert64)
         return self.expert
 

@@ -30,8 +30,6 @@ class _ActorFusedFn(torch.autograd.Function):
         out = torch.empty((B, 1, dims[-1], N), device=X.device, dtype=torch.float32)
         rc = L.mgp_actor_fwd(ops._ptr(X), ops._ptr(G), _ptr_array(Ws), _ptr_array(bs), cdims, n_layers,
                              ops._ptr(out), ops._ptr(saved), B, K, N, ops._stream())
-        if rc == -5:      # MGP_EUNSUPPORTED
-            return None
         _lib.check(rc, 'mgp_actor_fwd')
         ctx.dims, ctx.K, ctx.shape = dims, K, (B, F, N)
         ctx.save_for_backward(saved, *Ws)
@@ -69,6 +67,10 @@ def try_forward(actor, delay_state, delay_gso):
     if actor.n_layers > 8:
         return None
     ops._dev(delay_state, 'delay_state'); ops._dev(delay_gso, 'delay_gso')
+    dims = tuple(actor.layers)
+    cdims = (ctypes.c_int * len(dims))(*dims)
+    if not _lib.lib().mgp_actor_supported(cdims, actor.n_layers, actor.k, delay_state.shape[3]):
+        return None
     X = delay_state.contiguous()
     G = delay_gso.contiguous()
     params = []

@@ -189,7 +189,7 @@ def gso_powers(A, K):
 
 
 # ------------------------------------------------------------------------------------ flocking sim
-def flock_step(x, u, params, A=None, A64=None, feat=None, feat64=None, reward=None):
+def flock_step(x, u, params, A=None, A64=None, feat=None, feat64=None, reward=None, expert=None):
     """In-place sim step on x (B,N,4) fp64; any output may be None.  See include/mgp.h.
     u: (B,N,2) contiguous, or the Actor's output (B,1,2,N) contiguous (consumed without a transpose)."""
     _dev(x, 'x', torch.float64)
@@ -204,7 +204,7 @@ def flock_step(x, u, params, A=None, A64=None, feat=None, feat64=None, reward=No
         else:
             assert u.shape == (B, N, 2), "u must be (B,N,2) or (B,1,2,N)"
     rc = _lib.lib().mgp_flock_step(_ptr(x), _ptr(u), su_agent, su_axis, _ptr(A), _ptr(A64), _ptr(feat), _ptr(feat64),
-                                   _ptr(reward), ctypes.byref(params), B, N, _stream())
+                                   _ptr(reward), _ptr(expert), ctypes.byref(params), B, N, _stream())
     _lib.check(rc, 'mgp_flock_step')
 
 

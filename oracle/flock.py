@@ -88,7 +88,9 @@ def integrate(x, u, p):
 
 def helpers(x, p):
     """Pairwise quantities.  Returns dict(diff (N,N,4), r2 (N,N) with +inf diagonal,
-    adj (N,N) 0/1 f64, deg (N,), network (N,N) f64, values (N,6) f64)."""
+    adj (N,N) 0/1 f64, deg (N,), network (N,N) f64, values (N,6) f64).
+
+    Features use ONE division per pair: q = 1/r2, then dx*(q*q) and dx*q (FLOCK-SPEC v1 section 2)."""
     x = np.asarray(x, dtype=np.float64)
     n = x.shape[0]
     diff = x.reshape(n, 1, 4) - x.reshape(1, n, 4)          # diff[i,j] = x_i - x_j
@@ -98,9 +100,10 @@ def helpers(x, p):
     deg = adj.sum(axis=1)
     degc = np.where(deg == 0, 1.0, deg)
     network = adj / degc[:, None] if p.mean_pooling else adj.copy()
-    r4 = r2 * r2
-    feats = np.stack([diff[:, :, 2], diff[:, :, 0] / r4, diff[:, :, 0] / r2,
-                      diff[:, :, 3], diff[:, :, 1] / r4, diff[:, :, 1] / r2], axis=2)
+    q = 1.0 / r2
+    qq = q * q
+    feats = np.stack([diff[:, :, 2], diff[:, :, 0] * qq, diff[:, :, 0] * q,
+                      diff[:, :, 3], diff[:, :, 1] * qq, diff[:, :, 1] * q], axis=2)
     # reduction over the middle axis adds the j-slices in ascending order (sequential-j summation;
     # bit-identical to an explicit loop `for j: values += feats[:, j] * adj[:, j]`)
     values = np.sum(feats * adj[:, :, None], axis=1)
@@ -113,29 +116,21 @@ def reward(x, p):
     return float(-1.0 * np.sum(np.var(v, axis=0)) * p.reward_scale)
 
 
-def potential_grad(d, r2, p):
-    """d/dx of 1/r^2 + log r^2 :  -2 d / r^4 + 2 d / r^2, zero beyond the comm radius."""
-    g = -2.0 * (d / (r2 * r2)) + 2.0 * (d / r2)
-    g = np.where(r2 > p.comm_radius2, 0.0, g)
-    return g
-
-
 def controller(x, p, centralized=False):
-    """Expert: u_i = -sum_j (v_i - v_j) - sum_j grad U(r_ij); neighbour-masked unless centralized.
-    Output clip(raw, +-ctrl_clip) * ctrl_gain, shape (N,2)."""
-    h = helpers(x, p)
-    diff, r2, adj = h['diff'], h['r2'], h['adj']
-    gx = potential_grad(diff[:, :, 0], r2, p)
-    gy = potential_grad(diff[:, :, 1], r2, p)
-    n = diff.shape[0]
-    terms = np.stack([diff[:, :, 2], diff[:, :, 3], gx, gy], axis=2)
-    if not centralized:
-        terms = terms * adj[:, :, None]
+    """Expert action (N,2), a closed form of the observation (FLOCK-SPEC v1 section 5):
+        potential term   gx = 2*f2 - 2*f1 , gy = 2*f5 - 2*f4     (gradient of 1/r^2 + log r^2 over neighbours)
+        velocity term    decentralised: f0, f3 (sum over neighbours of v_i - v_j)
+                         centralised:   N*v_i - sum_j v_j          (sum over all agents)
+        u = clip(-(velocity) - (potential), +-ctrl_clip) * ctrl_gain"""
+    x = np.asarray(x, dtype=np.float64)
+    f = helpers(x, p)['values']
+    n = x.shape[0]
+    if centralized:
+        vx = n * x[:, 2] - np.sum(x[:, 2])
+        vy = n * x[:, 3] - np.sum(x[:, 3])
     else:
-        eye = np.eye(n, dtype=bool)
-        terms = np.where(eye[:, :, None], 0.0, terms)
-    s = np.sum(terms, axis=1)                                # ascending-j summation order
-    raw = np.stack([-s[:, 2] - s[:, 0], -s[:, 1] - s[:, 3]], axis=1)
+        vx, vy = f[:, 0], f[:, 3]
+    raw = np.stack([-vx - (2.0 * f[:, 2] - 2.0 * f[:, 1]), -vy - (2.0 * f[:, 5] - 2.0 * f[:, 4])], axis=1)
     return np.clip(raw, -p.ctrl_clip, p.ctrl_clip) * p.ctrl_gain
 
 

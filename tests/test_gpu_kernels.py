@@ -164,7 +164,8 @@ def test_flock_step_and_controller(n, variant):
     rew = torch.empty((B,), device='cuda', dtype=torch.float64)
     cp = _c_params(p)
     for it in range(3):
-        ops.flock_step(x_d, dev(us), cp, A=A, A64=A64, feat=feat, feat64=feat64, reward=rew)
+        ex_d = torch.empty((B, n, 2), device='cuda')
+        ops.flock_step(x_d, dev(us), cp, A=A, A64=A64, feat=feat, feat64=feat64, reward=rew, expert=ex_d)
         u_d = torch.empty((B, n, 2), device='cuda'); u64_d = torch.empty((B, n, 2), device='cuda', dtype=torch.float64)
         ops.flock_controller(x_d, cp, centralized=False, u=u_d, u64=u64_d)
         uc_d = torch.empty((B, n, 2), device='cuda', dtype=torch.float64)
@@ -181,6 +182,7 @@ def test_flock_step_and_controller(n, variant):
             uo = ofl.controller(x2, p, centralized=False)
             assert relerr(u64_d[b].cpu().numpy(), uo) <= 1e-11
             assert relerr(u_d[b].cpu().numpy(), uo) <= 1e-6
+            assert np.array_equal(ex_d[b].cpu().numpy(), u_d[b].cpu().numpy())     # by-product == dedicated call
             assert relerr(uc_d[b].cpu().numpy(), ofl.controller(x2, p, centralized=True)) <= 1e-11
             xs[b] = x2
         us = rs.uniform(-1.0, 1.0, size=(B, n, 2)).astype(np.float32)
