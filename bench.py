@@ -196,8 +196,9 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
-    torch.cuda.set_device(local)
-    device = torch.device('cuda', local)
+    dev_index = parallel.local_device_index(local)
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     B, N, K = args.episodes, args.agents, args.taps
     hidden = [args.hidden] * args.layers
 

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from .. import parallel
 from ..parallel import FlatGradSync
 from .actor import Actor
 from .replay_buffer import ReplayBuffer, Transition
@@ -156,11 +157,19 @@ def train_dagger(env, args, device):
 
     total_numsteps = 0
     updates = 0
-    beta = 1
     stats = {'mean': -1.0 * np.inf, 'std': 0}
 
-    for i in range(n_train_episodes):
-        beta = max(beta * beta_coeff, 0.5)
+    # Data-parallel run (one process per GPU, torchrun): the n_train_episodes episodes are dealt round-robin to
+    # the ranks (global episode e = i * world + rank keeps the reference's beta schedule per episode), every
+    # rank performs the same number of updates and gradients are averaged by ONE flat all-reduce per update.
+    rank, world = parallel.rank(), parallel.world_size()
+    local_episodes = (n_train_episodes + world - 1) // world
+    lo_t, hi_t = parallel.shard_range(n_test_episodes)
+    n_test_local = max(1, hi_t - lo_t) if world > 1 else n_test_episodes
+
+    for i in range(local_episodes):
+        e = i * world + rank
+        beta = max(beta_coeff ** (e + 1), 0.5)          # == the reference's running product max(beta*coeff, 0.5)
         state = MultiAgentStateWithDelay(device, args, env.reset(), prev_state=None)
         done = False
         policy_loss_sum = 0
@@ -189,16 +198,19 @@ def train_dagger(env, args, device):
                 policy_loss_sum += learner.gradient_step(batch)
                 updates += 1
 
-        if i % test_interval == 0 and debug:
-            test_rewards = [_rollout_reward(env, learner, device, args) for _ in range(n_test_episodes)]
-            print("Episode: {}, updates: {}, total numsteps: {}, reward: {}, policy loss: {}".format(
-                i, updates, total_numsteps, np.mean(test_rewards), policy_loss_sum))
+        if (i * world) % test_interval < world and debug:
+            test_rewards = [_rollout_reward(env, learner, device, args) for _ in range(n_test_local)]
+            test_rewards = parallel.all_gather_floats(test_rewards)
+            if rank == 0:
+                print("Episode: {}, updates: {}, total numsteps: {}, reward: {}, policy loss: {}".format(
+                    i * world, updates, total_numsteps * world, np.mean(test_rewards), policy_loss_sum))
 
-    test_rewards = [_rollout_reward(env, learner, device, args) for _ in range(n_test_episodes)]
+    test_rewards = [_rollout_reward(env, learner, device, args) for _ in range(n_test_local)]
+    test_rewards = parallel.all_gather_floats(test_rewards)
     stats['mean'] = np.mean(test_rewards)
     stats['std'] = np.std(test_rewards)
 
-    if debug and args.get('fname'):
+    if debug and args.get('fname') and rank == 0:
         learner.save_model(args.get('env'), suffix=args.get('fname'))
 
     env.close()

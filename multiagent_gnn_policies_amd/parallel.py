@@ -33,11 +33,20 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
-            torch.cuda.set_device(local)
+            # MGP_DIST_BACKEND=gloo lets several ranks share ONE GPU (tests on a 1-GPU box); production = RCCL
+            backend = os.environ.get('MGP_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_device_index(local))
         dist.init_process_group(backend=backend, rank=rk, world_size=world)
     return rk, world, local
+
+
+def local_device_index(local_rank=None):
+    """GPU index of this rank: LOCAL_RANK, folded onto the visible devices (several ranks may share a GPU in tests)."""
+    if local_rank is None:
+        local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 1
+    return local_rank % max(1, n)
 
 
 def shard_range(n_items, rk=None, world=None):

@@ -107,3 +107,36 @@ def test_dagger_learning_reduces_loss():
         losses.append(learner.gradient_step_tensors(X[idx], G[idx], Y[idx]))
     assert np.isfinite(losses).all()
     assert np.mean(losses[-30:]) < 0.7 * np.mean(losses[:30])
+
+
+def _torchrun(script_args, timeout=900):
+    import socket
+    sock = socket.socket(); sock.bind(('127.0.0.1', 0)); port = sock.getsockname()[1]; sock.close()
+    env = dict(os.environ, PYTHONPATH=ROOT, MGP_DIST_BACKEND='gloo')        # two ranks share the one GPU of the box
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port)] + script_args
+    return subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                          timeout=timeout)
+
+
+def test_train_py_two_ranks_data_parallel():
+    """torchrun x2: episodes dealt to ranks, flat-gradient all-reduce per update, rank 0 prints the sweep table."""
+    r = _torchrun([os.path.join(ROOT, 'train.py'), 'cfg/smoke.cfg'])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.strip() and ',' in l]
+    assert lines[0] == 'alg, reward'
+    assert [l.split(',')[0] for l in lines[1:]] == ['dagger', 'cloning', 'baseline']      # printed once (rank 0)
+
+
+def test_bench_two_ranks_contract():
+    """bench.py under the driver's multi-GPU launch line (2 ranks): one JSON line, weak scaling, aggregate value."""
+    import json
+    r = _torchrun([os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '4', '--episodes', '32'])
+    assert r.returncode == 0, r.stderr[-3000:]
+    js = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(js) == 1
+    d = json.loads(js[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['steps'] == 20
+    assert d['config']['episodes_total'] == 64
+    assert abs(d['value'] - 64 * 100 * 20 / (d['ms_per_step'] * 20 / 1e3)) / d['value'] < 1e-6
+    assert 'cpu_baseline' not in d and 'roofline' in d

@@ -5,13 +5,14 @@ learner runs on the MI355X kernels.
 """
 from os import path
 import configparser
+import os
 import random
 import sys
 
 import numpy as np
 import torch
 
-from multiagent_gnn_policies_amd import envs
+from multiagent_gnn_policies_amd import envs, parallel
 from multiagent_gnn_policies_amd.learner.gnn_dagger import train_dagger
 from multiagent_gnn_policies_amd.learner.gnn_cloning import train_cloning
 from multiagent_gnn_policies_amd.learner.gnn_baseline import train_baseline
@@ -19,12 +20,14 @@ from multiagent_gnn_policies_amd.learner.gnn_baseline import train_baseline
 
 def run_experiment(args):
     env_name = args.get('env')
-    env = envs.make(env_name)
+    env = envs.make(env_name, device='cuda:%d' % parallel.local_device_index())
     if isinstance(env.env, envs.FlockingRelativeEnv):
         env.env.params_from_cfg(args)
 
-    # one seed for the four RNG streams, as in reference train.py:24-28
-    seed = args.getint('seed')
+    # one seed for the four RNG streams, as in reference train.py:24-28 (+ rank under torchrun, so every
+    # rank rolls out different episodes; weights are broadcast from rank 0 when the learner is built)
+    rank, world, local_rank = parallel.init_from_env()
+    seed = args.getint('seed') + rank
     env.seed(seed)
     random.seed(seed)
     np.random.seed(seed)
@@ -32,7 +35,8 @@ def run_experiment(args):
 
     if not torch.cuda.is_available():
         raise RuntimeError("train.py needs an MI355X (HIP device); this framework has no CPU compute path")
-    device = torch.device("cuda:0")
+    device = torch.device("cuda", parallel.local_device_index(local_rank))
+    torch.cuda.set_device(device)
 
     alg = args.get('alg').lower()
     if alg == 'dagger':
@@ -57,11 +61,12 @@ def main():
     printed_header = False
     if config.sections():
         for section_name in config.sections():
-            if not printed_header:
+            if not printed_header and int(os.environ.get('RANK', '0')) == 0:
                 print(config[section_name].get('header'))
                 printed_header = True
             stats = run_experiment(config[section_name])
-            print(section_name + ", " + str(stats['mean']) + ", " + str(stats['std']))
+            if parallel.rank() == 0:
+                print(section_name + ", " + str(stats['mean']) + ", " + str(stats['std']))
     else:
         val = run_experiment(config[config.default_section])
         print(val)
