@@ -32,23 +32,30 @@ __device__ __forceinline__ void row_axpy(float (&acc)[V], float w, const float* 
     }
 }
 
-// grid: x = row tile (then extra blocks for the delay line), y = b
+// grid: 1-D.  Workgroup id -> (episode b, slot) with b % 8 == id % 8: the dispatcher places workgroup id on XCD
+// id % 8 (observed, used for speed only), so every row tile of an episode shares ONE XCD's L2 and the source
+// rows of G_prev[b] (re-read deg times) are fetched from HBM once instead of once per XCD.
+// slot < nrt: row tile; slot >= nrt: delay-line copy duty.
 // Products are written for dst slices j in [j_lo, j_hi): dst[b,j] = A[b] @ src[b,j-1].
 // If write_base: dst[b,0] = I, dst[b,1] = (has_prev ? A[b] : 0), and slices >= 2 are zeroed when !has_prev.
 template <int V>
 __global__ __launch_bounds__(GSO_THREADS)
 void gso_rows_kernel(const float* __restrict__ A, const float* __restrict__ src, float* __restrict__ dst,
-                     int K, int N, int j_lo, int j_hi, int write_base, int has_prev, int nrt,
+                     int B, int K, int N, int j_lo, int j_hi, int write_base, int has_prev, int nrt, int nslots,
                      const float* __restrict__ X_t, const float* __restrict__ Xd_prev, float* __restrict__ Xd_next,
                      int F)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
+    // id = (b / 8) * (8 * slots) + slot * 8 + (b % 8)
+    const int slots = nslots;
+    const int grp = blockIdx.x / (8 * slots), rem8 = blockIdx.x - grp * (8 * slots);
+    const int slot = rem8 / 8, b = grp * 8 + (rem8 & 7);
+    if (b >= B) return;
 
-    if ((int)blockIdx.x >= nrt) {
+    if (slot >= nrt) {
         // delay line duty: copy (K,F,N) floats for episode b, spread over the extra blocks
-        const int nb = gridDim.x - nrt, bi = blockIdx.x - nrt;
+        const int nb = slots - nrt, bi = slot - nrt;
         const long per = (long)K * F * N;
         float* out = Xd_next + (long)b * per;
         for (long i = (long)bi * GSO_THREADS + tid; i < per; i += (long)nb * GSO_THREADS) {
@@ -69,7 +76,7 @@ void gso_rows_kernel(const float* __restrict__ A, const float* __restrict__ src,
     float* dstb = dst + (size_t)b * K * NN;
 
     for (int rr = wave; rr < GSO_ROWS; rr += GSO_WAVES) {
-        const int i = blockIdx.x * GSO_ROWS + rr;
+        const int i = slot * GSO_ROWS + rr;
         if (i >= N) break;                                            // wave-uniform
         const float* arow = Ab + (size_t)i * N;
         // ---- compact the non-zeros of A[b,i,:] (ascending m)
@@ -145,21 +152,22 @@ int launch_gso(const float* A, const float* src, float* dst, int B, int K, int N
     const size_t lds = (size_t)GSO_WAVES * 2 * N * sizeof(float);
     if (lds > 150 * 1024) return MGP_EUNSUPPORTED;
     const bool vec = (N % 4 == 0) && mgp_aligned16(dst) && (src == nullptr || mgp_aligned16(src));
-    dim3 grid(nrt + extra, B);
+    const int nslots = nrt + extra;
+    dim3 grid((unsigned)(((B + 7) / 8) * 8 * nslots));
     if (vec) {
         if (lds > 48 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(gso_rows_kernel<4>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MGP_ELAUNCH;
-        hipLaunchKernelGGL((gso_rows_kernel<4>), grid, dim3(GSO_THREADS), lds, st, A, src, dst, K, N, j_lo, j_hi,
-                           write_base, has_prev, nrt, X_t, Xd_prev, Xd_next, F);
+        hipLaunchKernelGGL((gso_rows_kernel<4>), grid, dim3(GSO_THREADS), lds, st, A, src, dst, B, K, N, j_lo, j_hi,
+                           write_base, has_prev, nrt, nslots, X_t, Xd_prev, Xd_next, F);
     } else {
         if (lds > 48 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(gso_rows_kernel<1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MGP_ELAUNCH;
-        hipLaunchKernelGGL((gso_rows_kernel<1>), grid, dim3(GSO_THREADS), lds, st, A, src, dst, K, N, j_lo, j_hi,
-                           write_base, has_prev, nrt, X_t, Xd_prev, Xd_next, F);
+        hipLaunchKernelGGL((gso_rows_kernel<1>), grid, dim3(GSO_THREADS), lds, st, A, src, dst, B, K, N, j_lo, j_hi,
+                           write_base, has_prev, nrt, nslots, X_t, Xd_prev, Xd_next, F);
     }
     return mgp_launch_status();
 }

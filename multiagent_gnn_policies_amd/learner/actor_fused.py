@@ -15,14 +15,14 @@ def _ptr_array(tensors):
 
 class _ActorFusedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, X, G, dims, K, *params):
+    def forward(ctx, X, G, dims, K, want_grad, *params):
         L = _lib.lib()
         n_layers = len(dims) - 1
         B, _, F, N = X.shape
         Ws = [p.contiguous() for p in params[0::2]]
         bs = [p.contiguous() for p in params[1::2]]
         cdims = (ctypes.c_int * len(dims))(*dims)
-        need_bwd = any(ctx.needs_input_grad[4:])
+        need_bwd = want_grad and any(ctx.needs_input_grad[5:])
         saved = None
         if need_bwd:
             n_saved = L.mgp_actor_saved_floats(cdims, n_layers, B, K, N)
@@ -56,7 +56,7 @@ class _ActorFusedFn(torch.autograd.Function):
         grads = []
         for i in range(n_layers):
             grads += [dWs[i].view(ctx.param_shapes[2 * i]), dbs[i]]
-        return (None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None) + tuple(grads)
 
 
 def try_forward(actor, delay_state, delay_gso):
@@ -77,4 +77,5 @@ def try_forward(actor, delay_state, delay_gso):
     for conv in actor.conv_layers:
         out_c = conv.weight.shape[0]
         params += [conv.weight.view(out_c, -1), conv.bias]
-    return _ActorFusedFn.apply(X, G, tuple(actor.layers), actor.k, *params)
+    # under torch.no_grad() (select_action / rollouts) nothing is saved for backward: Y and Z stay on chip
+    return _ActorFusedFn.apply(X, G, tuple(actor.layers), actor.k, torch.is_grad_enabled(), *params)

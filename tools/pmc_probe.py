@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Workload for rocprofv3 --pmc passes: every hot kernel of the step, 20 launches each, on rotating input sets
+larger than the Infinity Cache (same shapes as bench.py's roofline leg).  Usage on the GPU box:
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out -o pmc_fetch -- python tools/pmc_probe.py
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d out -o pmc_write -- python tools/pmc_probe.py
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from multiagent_gnn_policies_amd.envs import FlockParams  # noqa: E402
+from multiagent_gnn_policies_amd.learner import Actor  # noqa: E402
+
+
+def main():
+    B = int(os.environ.get('PROBE_B', '256'))
+    N = int(os.environ.get('PROBE_N', '100'))
+    K = 3
+    dev = torch.device('cuda:0')
+    actor = Actor(6, 2, [32, 32], K, 0).to(dev)
+    bench.load_weights(actor)
+    actor.eval()
+    res, n_sets = bench.kernel_rooflines(dev, B, N, K, actor, FlockParams(n_agents=N).to_c())
+    print({k: round(v['ms'] * 1e3, 2) for k, v in res.items()}, n_sets)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (rocpd .db) into per-kernel HBM traffic per launch.
+
+gfx950 corrections (MI355X_MICROARCH.md, section HBM): counter values are KiB; FETCH_SIZE reports exactly 1/2
+of the bytes of a wide coalesced streaming read -> doubled.  WRITE_SIZE is taken as is (checked here against the
+known output size of agg_fwd: 1.84 MB algorithmic vs 1.92 MB counted).
+
+    python tools/pmc_summary.py gpurun_out/pmc/fetch_results.db gpurun_out/pmc/write_results.db [out.json]
+"""
+import json
+import re
+import sqlite3
+import sys
+
+
+def per_kernel(path, counter):
+    db = sqlite3.connect(path)
+    rows = db.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? "
+                      "group by kernel_name", (counter,)).fetchall()
+    out = {}
+    for name, n, avg in rows:
+        m = re.search(r'(\w+_kernel)', name)
+        if m and 'at::native' not in name:
+            out[m.group(1)] = (n, avg)
+    return out
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], 'FETCH_SIZE')
+    write = per_kernel(sys.argv[2], 'WRITE_SIZE')
+    res = {}
+    print("# HBM traffic per launch from rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes)")
+    print("# read = 2 x FETCH_SIZE KiB (gfx950 half-count correction), write = WRITE_SIZE KiB")
+    print("%-28s %8s %14s %14s %14s" % ('kernel', 'launches', 'read_MB', 'write_MB', 'total_MB'))
+    for k in sorted(set(fetch) | set(write)):
+        rd = 2.0 * fetch.get(k, (0, 0.0))[1] * 1024.0
+        wr = write.get(k, (0, 0.0))[1] * 1024.0
+        res[k] = dict(read_bytes=rd, write_bytes=wr, total_bytes=rd + wr, launches=fetch.get(k, (0, 0))[0])
+        print("%-28s %8d %14.3f %14.3f %14.3f" % (k, res[k]['launches'], rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
+    if len(sys.argv) > 3:
+        with open(sys.argv[3], 'w') as f:
+            json.dump(res, f, indent=1)
+
+
+if __name__ == '__main__':
+    main()
