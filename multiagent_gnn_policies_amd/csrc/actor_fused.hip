@@ -61,13 +61,96 @@ template <> struct GLoad<1> {
     static __device__ __forceinline__ void ld(const float* p, float (&g)[1]) { g[0] = *p; }
 };
 
+constexpr int AF_CS = 68;                 // floats per agent column in the activation buffers (64 channels + pad:
+                                          // 68 = 4 mod 64 keeps a 16-lane ds_read_b128 group on disjoint banks)
+constexpr int AF_WFS = 20;                // floats per lane in a weight fragment block (16 k-steps + pad, same reason)
+
+// position of channel c inside an agent column of an activation buffer: MFMA B-fragment order, so that lane
+// (li, lq) of the wave finds its 16 k-step operands B[k = lq][j = li] contiguous (c = 4 s + lq  ->  lq*16 + s)
+__host__ __device__ inline int bpos(int c) { return (c & 3) * 16 + (c >> 2); }
+
+// Branch-free tanh (the eight evaluations of a tile epilogue interleave freely; libm's tanhf is a branchy call):
+//   |x| <  0.35 : odd Taylor polynomial through x^11 (truncation < 1e-8)
+//   |x| >= 0.35 : (1 - e) / (1 + e), e = exp(-2|x|)
+// Max error ~2 ulp of the result; well inside the 1e-5 parity budget.
+__device__ __forceinline__ float tanh_fast(float x)
+{
+    const float ax = fabsf(x);
+    const float x2 = x * x;
+    float p = fmaf(x2, -1382.f / 155925.f, 62.f / 2835.f);
+    p = fmaf(x2, p, -17.f / 315.f);
+    p = fmaf(x2, p, 2.f / 15.f);
+    p = fmaf(x2, p, -1.f / 3.f);
+    const float small = fmaf(x * x2, p, x);
+    const float e = __expf(-2.f * ax);
+    const float big = copysignf(__fdividef(1.f - e, 1.f + e), x);
+    return ax < 0.35f ? small : big;
+}
+
+struct MlpArgs {
+    const float* bin; float* bout; const float* wfrag; float* out; float* saved; size_t soff;
+    int ksteps, cout, cols, n0, N, b, nt, lane; bool last;
+};
+
+// One layer for the 16 agent columns of n-tile a.nt: D[mt] (16 x 16) = W[mt] (16 x cin) . Act (cin x 16), MT m-tiles
+// sharing the B fragment (MT independent accumulator chains), bias preloaded into the accumulators.
+template <int MT>
+__device__ __forceinline__ void mlp_layer(const MlpArgs& a)
+{
+    const int li = a.lane & 15, lq = a.lane >> 4;
+    const int col = a.nt * 16 + li;
+    float fb[16];
+    {
+        const float4* pb = reinterpret_cast<const float4*>(a.bin + col * AF_CS + lq * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float4 t = pb[i]; fb[4 * i] = t.x; fb[4 * i + 1] = t.y; fb[4 * i + 2] = t.z; fb[4 * i + 3] = t.w; }
+    }
+    float fa[MT][16];
+    f32x4 acc[MT];
+    const float* bias = a.wfrag + MT * 64 * AF_WFS;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const float4* pa = reinterpret_cast<const float4*>(a.wfrag + (mt * 64 + a.lane) * AF_WFS);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float4 t = pa[i]; fa[mt][4 * i] = t.x; fa[mt][4 * i + 1] = t.y; fa[mt][4 * i + 2] = t.z; fa[mt][4 * i + 3] = t.w; }
+        const float4 bv = *reinterpret_cast<const float4*>(bias + mt * 16 + lq * 4);
+        acc[mt][0] = bv.x; acc[mt][1] = bv.y; acc[mt][2] = bv.z; acc[mt][3] = bv.w;
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        if (s < a.ksteps) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][s], fb[s], acc[mt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int c = mt * 16 + lq * 4 + rr;               // output channel (rows >= cout carry exact zeros)
+            float v = acc[mt][rr];
+            if (a.last) {
+                if (c < a.cout && col < a.cols) a.out[((size_t)a.b * a.cout + c) * a.N + a.n0 + col] = v;
+            } else {
+#ifndef MGP_AF_NO_TANH
+                v = tanh_fast(v);
+#endif
+                a.bout[col * AF_CS + rr * 16 + mt * 4 + lq] = v;   // == bpos(c)
+                if (a.saved != nullptr && c < a.cout && col < a.cols)
+                    a.saved[a.soff + ((size_t)a.b * a.cout + c) * a.N + a.n0 + col] = v;
+            }
+        }
+    }
+}
+
 // LDS carve-up (floats).  `red` (aggregation partials) and the activation ping-pong buffers alias: the MLP
 // phase starts only after the combine.
 struct Carve {
     int xs;            // X tile, all taps: [K][MC][CT]
-    int ys;            // aggregated features  [pad16(F*K)][ncp]
-    int w;             // padded weights (+ bias in the spare column of each row)
-    int un;            // union: red [R][F*K][twp]  |  act0,act1 [pad16(maxw)][ncp] each
+    int ys;            // aggregated features = activation buffer A  [ncols16][AF_CS]
+    int w;             // per layer: weight fragments [MT][64][AF_WFS] + bias [MT*16]
+    int un;            // union: red [R][F*K][twp]  |  activation buffer B [ncols16][AF_CS]
     int act_stride;    // floats per activation buffer
     int wtot;          // floats in the padded weight image
     int total;
@@ -155,26 +238,29 @@ void actor_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G, 
                     xs[row * CT + c] = 0.f;
                 }
             }
-            // padded weight image: rows up to pad16(cout), columns up to pad4(cin), bias in column ws-1
+            // weights in MFMA A-fragment order: wfrag[mt][lane][AF_WFS] with lane = (c & 3) * 16 + (o & 15),
+            // slot s = c >> 2  (16x16x4: lane (li, lq) feeds A[i = li][k = lq] of k-step s), zero padded;
+            // followed by the bias of the layer's pad16(cout) rows.  A lane later fetches its 16 k-steps with
+            // four ds_read_b128.
             for (int l = 0; l < P.n_layers; ++l) {
                 const int cin = (l == 0) ? FK : P.dims[l];
                 const int cout = P.dims[l + 1];
-                const int ws = wstride(cin), tot = pad16(cout) * ws;
+                const int MT = pad16(cout) / 16;
+                const int tot = MT * 64 * AF_WFS;
                 float* dst = wl + P.woff[l];
                 const float* src = P.W[l];
                 const float* bsrc = P.b[l];
-                constexpr int WU = 5;
+                constexpr int WU = 6;
                 for (int base = 0; base < tot; base += AF_THREADS * WU) {
                     float wv[WU];
 #pragma unroll
                     for (int j = 0; j < WU; ++j) {
                         const int e = base + tid + AF_THREADS * j;
-                        const int o = e / ws, c = e - o * ws;
+                        const int mt = e / (64 * AF_WFS), r1 = e - mt * (64 * AF_WFS);
+                        const int ln = r1 / AF_WFS, sl = r1 - ln * AF_WFS;
+                        const int c = 4 * sl + (ln >> 4), o = mt * 16 + (ln & 15);
                         float v = 0.f;
-                        if (e < tot && o < cout) {
-                            if (c < cin) v = src[(size_t)o * cin + c];
-                            else if (c == ws - 1) v = bsrc[o];
-                        }
+                        if (e < tot && sl < 16 && o < cout && c < cin) v = src[(size_t)o * cin + c];
                         wv[j] = v;
                     }
 #pragma unroll
@@ -183,8 +269,8 @@ void actor_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G, 
                         if (e < tot) dst[e] = wv[j];
                     }
                 }
+                for (int o = tid; o < MT * 16; o += AF_THREADS) dst[tot + o] = (o < cout) ? bsrc[o] : 0.f;
             }
-            for (int i = tid; i < (pad16(FK) - FK) * ncp; i += AF_THREADS) ys[FK * ncp + i] = 0.f;
         }
         __syncthreads();
         AF_STAMP(1);
@@ -213,14 +299,17 @@ void actor_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G, 
         }
     }
     AF_STAMP(2);
-    // ---- combine the R row phases: red[r][c*K + k][col], fixed order r = 0..R-1 (deterministic)
+    // ---- combine the R row phases (fixed order r = 0..R-1: deterministic) into ys, which is kept in the MFMA
+    //      B-fragment order  ys[col][AF_CS]  with channel q = c*K + k at position (q & 3) * 16 + (q >> 2)
+    const int ncols16 = pad16(cols);
     if (R == 1) {
         if (active) {
 #pragma unroll
             for (int c = 0; c < CT; ++c)
                 if (c < F) {
+                    const int q = c * K + kk;
 #pragma unroll
-                    for (int v = 0; v < V; ++v) ys[(c * K + kk) * ncp + cg * V + v] = acc[c][v];
+                    for (int v = 0; v < V; ++v) ys[(cg * V + v) * AF_CS + bpos(q)] = acc[c][v];
                 }
         }
     } else {
@@ -228,118 +317,80 @@ void actor_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G, 
 #pragma unroll
             for (int c = 0; c < CT; ++c)
                 if (c < F) {
-#pragma unroll
-                    for (int v = 0; v < V; ++v) red[((size_t)r * FK + c * K + kk) * twp + cg * V + v] = acc[c][v];
+                    float* p = red + ((size_t)r * FK + c * K + kk) * twp + cg * V;
+                    if constexpr (V == 4) {
+                        *reinterpret_cast<float4*>(p) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+                    } else {
+                        p[0] = acc[c][0];
+                    }
                 }
         }
         __syncthreads();
         AF_STAMP(3);
         for (int i = tid; i < FK * cgt; i += AF_THREADS) {
             const int q = i / cgt, cgi = i - q * cgt;
-            float s[V];
+            float sum[V];
 #pragma unroll
-            for (int v = 0; v < V; ++v) s[v] = 0.f;
+            for (int v = 0; v < V; ++v) sum[v] = 0.f;
+            const float* p = red + (size_t)q * twp + cgi * V;
             for (int rr = 0; rr < R; ++rr) {
-                const float* p = red + ((size_t)rr * FK + q) * twp + cgi * V;
-#pragma unroll
-                for (int v = 0; v < V; ++v) s[v] += p[v];
+                if constexpr (V == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(p + (size_t)rr * FK * twp);
+                    sum[0] += t.x; sum[1] += t.y; sum[2] += t.z; sum[3] += t.w;
+                } else {
+                    sum[0] += p[(size_t)rr * FK * twp];
+                }
             }
 #pragma unroll
-            for (int v = 0; v < V; ++v) ys[q * ncp + cgi * V + v] = s[v];
+            for (int v = 0; v < V; ++v) ys[(cgi * V + v) * AF_CS + bpos(q)] = sum[v];
         }
+    }
+    // zero what the MFMA k-loop reads but nobody wrote: channels FK..pad4(FK)-1, and columns cols..ncols16-1
+    for (int i = tid; i < (pad4(FK) - FK) * ncols16; i += AF_THREADS) {
+        const int q = FK + i / ncols16, col = i % ncols16;
+        ys[col * AF_CS + bpos(q)] = 0.f;
+    }
+    for (int i = tid; i < FK * (ncols16 - cols); i += AF_THREADS) {
+        const int q = i / (ncols16 - cols), col = cols + i % (ncols16 - cols);
+        ys[col * AF_CS + bpos(q)] = 0.f;
     }
     __syncthreads();
     AF_STAMP(4);
-    // columns beyond `cols` inside the last 16-wide n-tile must be finite for the MFMA: zero them
-    const int ncols16 = pad16(cols);
-    for (int i = tid; i < FK * (ncols16 - cols); i += AF_THREADS) {
-        const int row = i / (ncols16 - cols), col = cols + i % (ncols16 - cols);
-        ys[row * ncp + col] = 0.f;
-    }
     if (saved != nullptr) {
         float* sy = saved + (size_t)b * FK * N;
         for (int i = tid; i < FK * cols; i += AF_THREADS) {
-            const int row = i / cols, col = i - row * cols;
-            sy[(size_t)row * N + n0 + col] = ys[row * ncp + col];
+            const int q = i / cols, col = i - q * cols;
+            sy[(size_t)q * N + n0 + col] = ys[col * AF_CS + bpos(q)];
         }
     }
-    __syncthreads();
     AF_STAMP(5);
 
-    // ---- phase 2: per-agent MLP on fp32 MFMA --------------------------------------------------------------
+    // ---- phase 2: per-agent MLP on fp32 MFMA.  Wave w owns the 16 agent columns of n-tile w through ALL layers
+    //      (its activations never leave its own LDS columns), so there is no workgroup barrier between layers.
     const int NT = ncols16 / 16;
-    const float* actin = ys;
-    float* act0 = smem + cv.un;
-    float* act1 = act0 + cv.act_stride;
-    size_t soff = (size_t)B * FK * N;                   // running offset into `saved`
-    const int li = lane & 15, lq = lane >> 4;
-    for (int l = 0; l < P.n_layers; ++l) {
-        const int cin = (l == 0) ? FK : P.dims[l];
-        const int cout = P.dims[l + 1];
-        const int ksteps = pad4(cin) / 4;
-        const int ws = wstride(cin);
-        const float* wb = wl + P.woff[l];
-        const bool last = (l == P.n_layers - 1);
-        float* actout = (l & 1) ? act1 : act0;
-        const int MT = pad16(cout) / 16;
-        // tile pairs (same m-tile, two n-tiles) share the A fragment and give two independent accumulators
-        const int NTP = (NT + 1) / 2;
-        for (int t = wave; t < MT * NTP; t += AF_WAVES) {
-            const int mt = t / NTP, ntp = t - mt * NTP;
-            const int nt0 = ntp * 2, nt1 = nt0 + 1;
-            const bool two = nt1 < NT;
-            // accumulators start at the bias of their rows (row = mt*16 + lq*4 + rr); padded rows hold 0
-            f32x4 acc0;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) acc0[rr] = wb[(mt * 16 + lq * 4 + rr) * ws + ws - 1];
-            f32x4 acc1 = acc0;
-            const float* ap = wb + (mt * 16 + li) * ws + lq;
-            const float* bp0 = actin + lq * ncp + nt0 * 16 + li;
-            const float* bp1 = actin + lq * ncp + (two ? nt1 : nt0) * 16 + li;
-            // fragments of up to 16 k-steps (cin <= 64) are fetched before the MFMA chain starts
-            constexpr int KS = AF_MAXW / 4;
-            float fa[KS], fb0[KS], fb1[KS];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int sc = min(s, ksteps - 1);
-                fa[s] = ap[4 * sc];
-                fb0[s] = bp0[(size_t)4 * sc * ncp];
-                fb1[s] = bp1[(size_t)4 * sc * ncp];
-            }
-            if (t == 0) AF_STAMP(10 + 4 * l);
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                if (s < ksteps) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s], fb0[s], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s], fb1[s], acc1, 0, 0, 0);
-                }
-            }
-            if (t == 0) { asm volatile("" :: "v"(acc0[0]), "v"(acc1[0])); AF_STAMP(11 + 4 * l); }
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                if (half == 1 && !two) break;
-                const f32x4 acc = half ? acc1 : acc0;
-                const int col = (half ? nt1 : nt0) * 16 + li;
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int row = mt * 16 + lq * 4 + rr;
-                    float v = acc[rr];                    // rows >= cout: zero weights and zero bias -> 0
-                    if (!last) v = tanhf(v);
-                    if (last) {
-                        if (row < cout && col < cols) out[((size_t)b * cout + row) * N + n0 + col] = v;
-                    } else {
-                        actout[row * ncp + col] = v;
-                        if (saved != nullptr && row < cout && col < cols)
-                            saved[soff + ((size_t)b * cout + row) * N + n0 + col] = v;
-                    }
-                }
-            }
+#ifdef MGP_AF_MLP_STAMPS
+    if (wave == 0) { AF_STAMP(30); }
+#endif
+    if (wave < NT) {
+        float* bufA = ys;                                   // layer 0 input; reused as the odd layers' output
+        float* bufB = smem + cv.un;                          // aliases `red` (dead after the barrier above)
+        size_t soff = (size_t)B * FK * N;                    // running offset into `saved`
+        for (int l = 0; l < P.n_layers; ++l) {
+            const int cin = (l == 0) ? FK : P.dims[l];
+            const int cout = P.dims[l + 1];
+            const float* bin = (l & 1) ? bufB : bufA;
+            float* bout = (l & 1) ? bufA : bufB;
+            const bool last = (l == P.n_layers - 1);
+            MlpArgs ma = {bin, bout, wl + P.woff[l], out, saved, soff, pad4(cin) / 4, cout, cols, n0, N, b, wave, lane,
+                          last};
+            const int MT = pad16(cout) / 16;
+            if (MT == 1) mlp_layer<1>(ma);
+            else if (MT == 2) mlp_layer<2>(ma);
+            else if (MT == 3) mlp_layer<3>(ma);
+            else mlp_layer<4>(ma);
+            soff += (size_t)B * cout * N;
+            AF_STAMP(6 + l);
         }
-        AF_STAMP(12 + 4 * l);
-        soff += (size_t)B * cout * N;
-        actin = actout;
-        __syncthreads();
-        AF_STAMP(6 + l);
     }
 }
 
@@ -467,28 +518,24 @@ bool make_plan(const int* dims, int n_layers, int K, int N, bool vec_ok, Plan* p
     pl->MC = 12288 / (K * pl->CT);
     if (pl->MC > N) pl->MC = N;
     if (pl->MC < 1) return false;
-    // ncp = 16 mod 32 keeps the two k-rows an MFMA B-read touches per half-wave on disjoint banks
-    int ncp = pad16(pl->tw);
-    if (ncp % 32 == 0) ncp += 16;
-    pl->ncp = ncp;
-    int maxw = 0, wtot = 0;
+    pl->ncp = AF_CS;
+    int wtot = 0;
     for (int l = 0; l < n_layers; ++l) {
-        const int cin = (l == 0) ? FK : dims[l];
+        const int MT = pad16(dims[l + 1]) / 16;
         pl->woff[l] = wtot;
-        wtot += pad16(dims[l + 1]) * wstride(cin);
-        if (l < n_layers - 1 && dims[l + 1] > maxw) maxw = dims[l + 1];
+        wtot += MT * 64 * AF_WFS + MT * 16;             // fragments + bias
     }
+    const int buf = pad16(pl->tw) * AF_CS;              // one activation buffer [ncols16][AF_CS]
     Carve& cv = pl->cv;
     int off = 0;
     cv.xs = off;  off += K * pl->MC * pl->CT; off = (off + 3) & ~3;
-    cv.ys = off;  off += pad16(FK) * ncp;
+    cv.ys = off;  off += buf;
     cv.w = off;   off += wtot; off = (off + 3) & ~3;
     cv.wtot = wtot;
     cv.un = off;
-    cv.act_stride = pad16(maxw > 0 ? maxw : 16) * ncp;
+    cv.act_stride = buf;
     const int red = (pl->R > 1) ? pl->R * FK * twp : 0;
-    const int act = 2 * cv.act_stride;
-    off += red > act ? red : act;
+    off += red > buf ? red : buf;
     cv.total = off;
     return (size_t)off * sizeof(float) <= AF_LDS_LIMIT;
 }
