@@ -74,8 +74,9 @@ class Rollout(object):
     def step(self):
         with torch.no_grad():
             out = self.actor(self.state.delay_state, self.state.delay_gso)      # (B,1,2,N)
-            self.sim.step(out)                                                   # consumes (B,1,2,N) directly
-            self.state.push(self.sim.network, self.sim.features)
+            A_dst, X_dst = self.state.next_slots()
+            self.sim.step(out, A_out=A_dst, feat_out=X_dst)     # action consumed as (B,1,2,N); A_t, X_t written in place
+            self.state.advance()                                 # G[:,j>=2] = A_t . G_prev[:,j-1], delay-line shift
 
 
 def time_kernel(fn, n_sets, iters):

@@ -130,6 +130,15 @@ int mgp_gso_update(const float* A, const float* G_prev, float* G_next,
                    const float* X_t, const float* Xd_prev, float* Xd_next,
                    int B, int K, int F, int N, int has_prev, void* stream);
 
+/* In-place form of mgp_gso_update for device-resident rollouts: the caller (mgp_flock_step with strided outputs)
+ * has ALREADY put A_t into G_next[:,1] and X_t into Xd_next[:,0], and G_next[:,0] holds I from allocation.
+ * Computes only G_next[b,j] = G_next[b,1] @ G_prev[b,j-1] for j >= 2 and Xd_next[b,j] = Xd_prev[b,j-1] for j >= 1;
+ * with has_prev == 0 (first step of an episode) slices j >= 1 are zeroed instead (state_with_delay.py:44-53 with
+ * prev_state=None).  Skips the A read-copy-write and the identity write of mgp_gso_update: 3 N^2 instead of
+ * (2K-1) N^2 floats of traffic per episode-step at K = 3. */
+int mgp_gso_advance(const float* G_prev, float* G_next, const float* Xd_prev, float* Xd_next,
+                    int B, int K, int F, int N, int has_prev, void* stream);
+
 /* curr_gso: powers of the current adjacency      reference learner/state_with_delay.py:38-41
  *   P[b,0] = I ; P[b,j] = A[b] @ P[b,j-1]                                            */
 int mgp_gso_powers(const float* A, float* P, int B, int K, int N, void* stream);
@@ -161,10 +170,14 @@ typedef struct MgpFlockParams {
  *   feat64 (B,N,6) fp64 features in the env's own (N,6) layout (may be NULL; gym facade)
  *   reward (B) fp64    -(var vx + var vy) * reward_scale  (may be NULL)
  *   expert (B,N,2) fp32 decentralised expert action for the NEW state (may be NULL): a closed form of the
- *                      features, so the DAGGER label costs no second pairwise pass                   */
+ *                      features, so the DAGGER label costs no second pairwise pass
+ *   sAb / sFb          batch strides (elements) of A / feat; 0 = dense (N*N / 6*N).  With sAb = K*N*N and
+ *                      A = delay_gso_next + N*N the simulator writes the network matrix straight into slice 1 of
+ *                      the next delayed-GSO buffer (feat likewise into delay_state_next[:,0]): see mgp_gso_advance */
 int mgp_flock_step(double* x, const float* u, long su_agent, long su_axis,
                    float* A, double* A64, float* feat, double* feat64,
-                   double* reward, float* expert, const MgpFlockParams* p, int B, int N, void* stream);
+                   double* reward, float* expert, long sAb, long sFb,
+                   const MgpFlockParams* p, int B, int N, void* stream);
 
 /* Expert controller on the current x: u (B,N,2) fp32 and/or u64 (B,N,2) fp64 (either may be NULL). */
 int mgp_flock_controller(const double* x, float* u, double* u64, const MgpFlockParams* p,

@@ -20,10 +20,12 @@
 
 namespace {
 
-constexpr int AF_THREADS = 512;
+constexpr int AF_THREADS = 512;           // 8 waves; one workgroup per episode at N <= 128 (a 2-per-CU column split
+                                          // ran in lockstep and measured 25% slower: both stream, then both compute)
 constexpr int AF_WAVES = AF_THREADS / 64;
-constexpr int AF_TILE = 128;              // max agent columns per workgroup
-constexpr int AF_U = 20;                  // G rows in flight per thread (one batch covers N = 100)
+constexpr int AF_TILE = 16 * AF_WAVES;    // max agent columns per workgroup: one 16-wide MFMA n-tile per wave
+constexpr int AF_U = 20;                  // G rows in flight per thread (one batch covers N = 100: 17 rows).
+                                          // NB: 18 makes hipcc spill 332 B/lane; 20 allocates 240 VGPRs, no scratch
 constexpr int AF_MAXW = 64;               // max layer width covered by the fused kernel
 constexpr int AF_LDS_LIMIT = 150 * 1024;
 
@@ -47,6 +49,9 @@ struct ActorParams {
 
 __host__ __device__ inline int pad4(int x) { return (x + 3) & ~3; }
 __host__ __device__ inline int pad16(int x) { return (x + 15) & ~15; }
+// m-tiles (16 output rows each) a layer of `cout` rows is run with: 1, 2 or 4 (3 is padded to 4 to limit the
+// number of MLP code instances: this kernel is latency bound and instruction-cache misses show)
+__host__ __device__ inline int mtiles(int cout) { const int m = pad16(cout) / 16; return m == 3 ? 4 : m; }
 // LDS row stride of a padded weight block with `cin` input channels (odd => spread over banks)
 __host__ __device__ inline int wstride(int cin) { return pad4(cin) + 1; }
 
@@ -69,22 +74,15 @@ constexpr int AF_WFS = 20;                // floats per lane in a weight fragmen
 // (li, lq) of the wave finds its 16 k-step operands B[k = lq][j = li] contiguous (c = 4 s + lq  ->  lq*16 + s)
 __host__ __device__ inline int bpos(int c) { return (c & 3) * 16 + (c >> 2); }
 
-// Branch-free tanh (the eight evaluations of a tile epilogue interleave freely; libm's tanhf is a branchy call):
-//   |x| <  0.35 : odd Taylor polynomial through x^11 (truncation < 1e-8)
-//   |x| >= 0.35 : (1 - e) / (1 + e), e = exp(-2|x|)
-// Max error ~2 ulp of the result; well inside the 1e-5 parity budget.
+// tanh(x) = 1 - 2 / (1 + exp(2x)): five instructions (v_mul, v_exp_f32, v_add, v_rcp_f32, v_fma), no branches, so
+// the evaluations of a tile epilogue pipeline back to back -- the epilogue is instruction-latency bound at 2 waves
+// per SIMD (libm's branchy tanhf measured 3x longer).  exp overflow -> rcp(inf) = 0 -> 1; underflow -> -1.
+// ABSOLUTE error <= ~2e-7 everywhere (1-ulp v_exp/v_rcp on values in [0,2]); the relative error near 0 is larger,
+// which is irrelevant against the 1e-5 absolute parity budget (measured on the goldens: worst 6e-7).
 __device__ __forceinline__ float tanh_fast(float x)
 {
-    const float ax = fabsf(x);
-    const float x2 = x * x;
-    float p = fmaf(x2, -1382.f / 155925.f, 62.f / 2835.f);
-    p = fmaf(x2, p, -17.f / 315.f);
-    p = fmaf(x2, p, 2.f / 15.f);
-    p = fmaf(x2, p, -1.f / 3.f);
-    const float small = fmaf(x * x2, p, x);
-    const float e = __expf(-2.f * ax);
-    const float big = copysignf(__fdividef(1.f - e, 1.f + e), x);
-    return ax < 0.35f ? small : big;
+    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);     // exp(2x) = 2^(2x log2 e)
+    return fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + e), 1.f);
 }
 
 struct MlpArgs {
@@ -116,14 +114,26 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a)
         const float4 bv = *reinterpret_cast<const float4*>(bias + mt * 16 + lq * 4);
         acc[mt][0] = bv.x; acc[mt][1] = bv.y; acc[mt][2] = bv.z; acc[mt][3] = bv.w;
     }
+#ifdef MGP_AF_MLP_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    AF_STAMP(40 + a.nt * 0 + (a.last ? 8 : 0));
+#endif
+    // k-steps run in groups of four (one uniform branch per group instead of per step); the activation buffers are
+    // zero-initialised and the weight fragments zero padded, so the surplus steps of a group add exact zeros
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        if (s < a.ksteps) {
+    for (int sg = 0; sg < 4; ++sg) {
+        if (4 * sg < a.ksteps) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][s], fb[s], acc[mt], 0, 0, 0);
+            for (int s = 4 * sg; s < 4 * sg + 4; ++s)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][s], fb[s], acc[mt], 0, 0, 0);
         }
     }
+#ifdef MGP_AF_MLP_STAMPS
+    asm volatile("" :: "v"(acc[0][0]));
+    AF_STAMP(41 + (a.last ? 8 : 0));
+#endif
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -142,6 +152,9 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a)
             }
         }
     }
+#ifdef MGP_AF_MLP_STAMPS
+    AF_STAMP(42 + (a.last ? 8 : 0));
+#endif
 }
 
 // LDS carve-up (floats).  `red` (aggregation partials) and the activation ping-pong buffers alias: the MLP
@@ -168,7 +181,11 @@ void actor_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G, 
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x % ntiles, b = blockIdx.x / ntiles;
+    // workgroup id -> (episode b, column tile) with b % 8 == id % 8: the tiles of an episode run on ONE XCD (observed
+    // id % 8 placement; speed only), so the 128-byte lines straddling two column tiles are fetched from HBM once
+    const int grp = blockIdx.x / (8 * ntiles), rem8 = blockIdx.x - grp * (8 * ntiles);
+    const int tile = rem8 / 8, b = grp * 8 + (rem8 & 7);
+    if (b >= B) return;
     const int F = P.dims[0];
     const int n0 = tile * tw;
     const int cols = min(tw, N - n0);
@@ -240,12 +257,13 @@ void actor_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G, 
             }
             // weights in MFMA A-fragment order: wfrag[mt][lane][AF_WFS] with lane = (c & 3) * 16 + (o & 15),
             // slot s = c >> 2  (16x16x4: lane (li, lq) feeds A[i = li][k = lq] of k-step s), zero padded;
-            // followed by the bias of the layer's pad16(cout) rows.  A lane later fetches its 16 k-steps with
-            // four ds_read_b128.
+            // followed by the bias of the layer's mtiles*16 rows.  A lane later fetches its 16 k-steps with
+            // four wide ds_reads.  (Loaded after the G batch: gathering them into registers first would let the
+            // staging finish while the batch is still in flight, but costs ~450 B/lane of scratch spills.)
             for (int l = 0; l < P.n_layers; ++l) {
                 const int cin = (l == 0) ? FK : P.dims[l];
                 const int cout = P.dims[l + 1];
-                const int MT = pad16(cout) / 16;
+                const int MT = mtiles(cout);
                 const int tot = MT * 64 * AF_WFS;
                 float* dst = wl + P.woff[l];
                 const float* src = P.W[l];
@@ -270,6 +288,10 @@ void actor_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G, 
                     }
                 }
                 for (int o = tid; o < MT * 16; o += AF_THREADS) dst[tot + o] = (o < cout) ? bsrc[o] : 0.f;
+            }
+            {   // activation buffer A (= ys): zero once; the combine later fills channels < F*K of columns < cols
+                float4* za = reinterpret_cast<float4*>(ys);
+                for (int i = tid; i < pad16(cols) * AF_CS / 4; i += AF_THREADS) za[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         __syncthreads();
@@ -345,14 +367,11 @@ void actor_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G, 
             for (int v = 0; v < V; ++v) ys[(cgi * V + v) * AF_CS + bpos(q)] = sum[v];
         }
     }
-    // zero what the MFMA k-loop reads but nobody wrote: channels FK..pad4(FK)-1, and columns cols..ncols16-1
-    for (int i = tid; i < (pad4(FK) - FK) * ncols16; i += AF_THREADS) {
-        const int q = FK + i / ncols16, col = i % ncols16;
-        ys[col * AF_CS + bpos(q)] = 0.f;
-    }
-    for (int i = tid; i < FK * (ncols16 - cols); i += AF_THREADS) {
-        const int q = i / (ncols16 - cols), col = cols + i % (ncols16 - cols);
-        ys[col * AF_CS + bpos(q)] = 0.f;
+    __syncthreads();
+    // buffer B (aliases `red`, dead now) must read as zeros wherever layer outputs never land (k-step padding)
+    {
+        float4* zb = reinterpret_cast<float4*>(smem + cv.un);
+        for (int i = tid; i < ncols16 * AF_CS / 4; i += AF_THREADS) zb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     AF_STAMP(4);
@@ -375,6 +394,9 @@ void actor_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G, 
         float* bufA = ys;                                   // layer 0 input; reused as the odd layers' output
         float* bufB = smem + cv.un;                          // aliases `red` (dead after the barrier above)
         size_t soff = (size_t)B * FK * N;                    // running offset into `saved`
+#ifdef MGP_AF_MLP_TWICE
+        for (int rep = 0; rep < 2; ++rep)
+#endif
         for (int l = 0; l < P.n_layers; ++l) {
             const int cin = (l == 0) ? FK : P.dims[l];
             const int cout = P.dims[l + 1];
@@ -383,13 +405,16 @@ void actor_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G, 
             const bool last = (l == P.n_layers - 1);
             MlpArgs ma = {bin, bout, wl + P.woff[l], out, saved, soff, pad4(cin) / 4, cout, cols, n0, N, b, wave, lane,
                           last};
-            const int MT = pad16(cout) / 16;
+            const int MT = mtiles(cout);
             if (MT == 1) mlp_layer<1>(ma);
             else if (MT == 2) mlp_layer<2>(ma);
-            else if (MT == 3) mlp_layer<3>(ma);
-            else mlp_layer<4>(ma);
+            else mlp_layer<4>(ma);                        // MT == 3 runs as 4 (the extra m-tile is all zeros)
             soff += (size_t)B * cout * N;
+#ifdef MGP_AF_MLP_TWICE
+            AF_STAMP(6 + l + 8 * rep);
+#else
             AF_STAMP(6 + l);
+#endif
         }
     }
 }
@@ -508,20 +533,23 @@ bool make_plan(const int* dims, int n_layers, int K, int N, bool vec_ok, Plan* p
     if (FK > AF_MAXW) return false;
     pl->V = (vec_ok && N % 4 == 0) ? 4 : 1;
     pl->CT = F <= 4 ? 4 : (F <= 6 ? 6 : 8);
-    pl->tw = N <= AF_TILE ? N : AF_TILE;
+    // balanced column tiles of <= AF_TILE columns (multiples of 4): N = 100 -> 52 + 48
+    pl->ntiles = (N + AF_TILE - 1) / AF_TILE;
+    pl->tw = (((N + pl->ntiles - 1) / pl->ntiles) + 3) & ~3;
+    if (pl->tw > AF_TILE) pl->tw = AF_TILE;
     pl->ntiles = (N + pl->tw - 1) / pl->tw;
     const int cgt = (pl->tw + pl->V - 1) / pl->V;
     if (K * cgt > AF_THREADS) return false;
     pl->R = AF_THREADS / (K * cgt);
     const int twp = cgt * pl->V;
-    // rows of X staged per chunk, all taps at once: K * MC * CT floats <= 12288 (48 KB)
-    pl->MC = 12288 / (K * pl->CT);
+    // rows of X staged per chunk, all taps at once: K * MC * CT floats <= 8192 (32 KB)
+    pl->MC = 8192 / (K * pl->CT);
     if (pl->MC > N) pl->MC = N;
     if (pl->MC < 1) return false;
     pl->ncp = AF_CS;
     int wtot = 0;
     for (int l = 0; l < n_layers; ++l) {
-        const int MT = pad16(dims[l + 1]) / 16;
+        const int MT = mtiles(dims[l + 1]);
         pl->woff[l] = wtot;
         wtot += MT * 64 * AF_WFS + MT * 16;             // fragments + bias
     }
@@ -549,7 +577,7 @@ int launch_fwd(const float* X, const float* G, float* out, float* saved, const A
         hipFuncSetAttribute(reinterpret_cast<const void*>(actor_fwd_kernel<CT, V>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return MGP_ELAUNCH;
-    hipLaunchKernelGGL((actor_fwd_kernel<CT, V>), dim3((unsigned)B * pl.ntiles), dim3(AF_THREADS), lds, st,
+    hipLaunchKernelGGL((actor_fwd_kernel<CT, V>), dim3((unsigned)(((B + 7) / 8) * 8 * pl.ntiles)), dim3(AF_THREADS), lds, st,
                        X, G, out, saved, P, pl.cv, B, K, N, pl.tw, pl.ntiles, pl.R, pl.MC, pl.ncp);
     return mgp_launch_status();
 }

@@ -41,6 +41,7 @@ __device__ __forceinline__ double block_sum(double v, double* sh /* [FL_WAVES] *
 struct FlockOut {
     float* A; double* A64; float* feat; double* feat64; double* reward;
     float* expert; double* expert64; int centralized;
+    long sAb, sFb;          // batch strides (elements) of A and feat: lets the sim write straight into delay_gso[:,1] / delay_state[:,0]
 };
 
 // integrate one agent in registers (spec section 1)
@@ -154,7 +155,7 @@ void flock_step_kernel(double* __restrict__ x, const float* __restrict__ u, long
         }
         wrow[rl] = p.mean_pooling ? 1.0 / (deg == 0.0 ? 1.0 : deg) : 1.0;
         if (o.feat != nullptr) {
-            float* fb = o.feat + (size_t)b * 6 * N + i;
+            float* fb = o.feat + (size_t)b * o.sFb + i;
             fb[0 * (size_t)N] = (float)f0; fb[1 * (size_t)N] = (float)f1; fb[2 * (size_t)N] = (float)f2;
             fb[3 * (size_t)N] = (float)f3; fb[4 * (size_t)N] = (float)f4; fb[5 * (size_t)N] = (float)f5;
         }
@@ -182,6 +183,7 @@ void flock_step_kernel(double* __restrict__ x, const float* __restrict__ u, long
     __syncthreads();
     // ---- network rows i0..i0+rows-1: one flat coalesced sweep, membership recomputed from LDS (same fp64 ops)
     const size_t base = ((size_t)b * N + i0) * N;
+    const size_t baseA = (size_t)b * o.sAb + (size_t)i0 * N;
     int ri = tid / N, j = tid - ri * N;                     // (row, col) of flat index tid
     const int dri = FL_THREADS / N, dj = FL_THREADS - dri * N;
     for (int idx = tid; idx < rows * N; idx += FL_THREADS) {
@@ -190,7 +192,7 @@ void flock_step_kernel(double* __restrict__ x, const float* __restrict__ u, long
         const double r2 = dx * dx + dy * dy;
         const bool nb = (j != gi) && (r2 < R2);
         const double w = nb ? wrow[ri] : 0.0;
-        if (o.A != nullptr) o.A[base + idx] = (float)w;
+        if (o.A != nullptr) o.A[baseA + idx] = (float)w;
         if (o.A64 != nullptr) o.A64[base + idx] = w;
         ri += dri; j += dj;
         if (j >= N) { j -= N; ri += 1; }
@@ -238,7 +240,8 @@ int launch_flock(double* x, const float* u, long su_agent, long su_axis, const F
 
 extern "C" int mgp_flock_step(double* x, const float* u, long su_agent, long su_axis,
                               float* A, double* A64, float* feat, double* feat64,
-                              double* reward, float* expert, const MgpFlockParams* p, int B, int N, void* stream)
+                              double* reward, float* expert, long sAb, long sFb,
+                              const MgpFlockParams* p, int B, int N, void* stream)
 {
     if (B < 0 || N <= 0) return MGP_EINVAL;
     int rc = check_params(p);
@@ -246,7 +249,8 @@ extern "C" int mgp_flock_step(double* x, const float* u, long su_agent, long su_
     if (B == 0) return MGP_OK;
     if (B > 65535 || N > 4096) return MGP_EUNSUPPORTED;
     MGP_CHECK_PTR8(x);
-    FlockOut o = {A, A64, feat, feat64, reward, expert, nullptr, 0};
+    if (sAb < 0 || sFb < 0) return MGP_EINVAL;
+    FlockOut o = {A, A64, feat, feat64, reward, expert, nullptr, 0, sAb ? sAb : (long)N * N, sFb ? sFb : 6L * N};
     return launch_flock(x, u, su_agent, su_axis, o, p, B, N, static_cast<hipStream_t>(stream));
 }
 
@@ -260,7 +264,7 @@ extern "C" int mgp_flock_controller(const double* x, float* u, double* u64, cons
     if (B > 65535 || N > 4096) return MGP_EUNSUPPORTED;
     MGP_CHECK_PTR8(x);
     if (u == nullptr && u64 == nullptr) return MGP_EINVAL;
-    FlockOut o = {nullptr, nullptr, nullptr, nullptr, nullptr, u, u64, centralized ? 1 : 0};
+    FlockOut o = {nullptr, nullptr, nullptr, nullptr, nullptr, u, u64, centralized ? 1 : 0, 0, 0};
     // no action => the state is only read
     return launch_flock(const_cast<double*>(x), nullptr, 2, 1, o, p, B, N, static_cast<hipStream_t>(stream));
 }

@@ -41,7 +41,8 @@ __device__ __forceinline__ void row_axpy(float (&acc)[V], float w, const float* 
 template <int V>
 __global__ __launch_bounds__(GSO_THREADS)
 void gso_rows_kernel(const float* __restrict__ A, const float* __restrict__ src, float* __restrict__ dst,
-                     int B, int K, int N, int j_lo, int j_hi, int write_base, int has_prev, int nrt, int nslots,
+                     long sAb, int mode, int B, int K, int N, int j_lo, int j_hi, int write_base, int has_prev, int nrt,
+                     int nslots,
                      const float* __restrict__ X_t, const float* __restrict__ Xd_prev, float* __restrict__ Xd_next,
                      int F)
 {
@@ -61,7 +62,7 @@ void gso_rows_kernel(const float* __restrict__ A, const float* __restrict__ src,
         for (long i = (long)bi * GSO_THREADS + tid; i < per; i += (long)nb * GSO_THREADS) {
             const long j = i / ((long)F * N);
             float v;
-            if (j == 0) v = X_t[(long)b * F * N + i];
+            if (j == 0) { if (mode == 1) continue; v = X_t[(long)b * F * N + i]; }
             else v = has_prev ? Xd_prev[(long)b * per + i - (long)F * N] : 0.f;
             out[i] = v;
         }
@@ -71,7 +72,7 @@ void gso_rows_kernel(const float* __restrict__ A, const float* __restrict__ src,
     int* idx = reinterpret_cast<int*>(smem) + (size_t)wave * 2 * N;      // per-wave [N] indices
     float* wgt = reinterpret_cast<float*>(idx + N);                       // per-wave [N] weights
     const size_t NN = (size_t)N * N;
-    const float* Ab = A + (size_t)b * NN;
+    const float* Ab = A + (size_t)b * sAb;
     const float* srcb = src ? src + (size_t)b * K * NN : nullptr;
     float* dstb = dst + (size_t)b * K * NN;
 
@@ -100,6 +101,10 @@ void gso_rows_kernel(const float* __restrict__ A, const float* __restrict__ src,
             }
         }
         // make this wave's LDS list visible to all its lanes (single wave: a wave barrier suffices)
+        if (mode == 1 && !has_prev && K > 1) {               // episode start: slice 1 (the sim's A_t) is zeroed too
+            float* r1 = dstb + NN + (size_t)i * N;
+            for (int n = lane; n < N; n += 64) r1[n] = 0.f;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -107,7 +112,7 @@ void gso_rows_kernel(const float* __restrict__ A, const float* __restrict__ src,
         for (int j = max(j_lo, 2); j < j_hi; ++j) {
             float* orow = dstb + (size_t)j * NN + (size_t)i * N;
             if (!has_prev) {
-                if (write_base) for (int n = lane; n < N; n += 64) orow[n] = 0.f;
+                if (write_base || mode == 1) for (int n = lane; n < N; n += 64) orow[n] = 0.f;
                 continue;
             }
             const float* sj = srcb + (size_t)(j - 1) * NN;
@@ -136,7 +141,7 @@ void gso_rows_kernel(const float* __restrict__ A, const float* __restrict__ src,
     }
 }
 
-int launch_gso(const float* A, const float* src, float* dst, int B, int K, int N, int j_lo, int j_hi,
+int launch_gso(const float* A, long sAb, int mode, const float* src, float* dst, int B, int K, int N, int j_lo, int j_hi,
                int write_base, int has_prev, const float* X_t, const float* Xd_prev, float* Xd_next, int F,
                hipStream_t st)
 {
@@ -159,15 +164,15 @@ int launch_gso(const float* A, const float* src, float* dst, int B, int K, int N
             hipFuncSetAttribute(reinterpret_cast<const void*>(gso_rows_kernel<4>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MGP_ELAUNCH;
-        hipLaunchKernelGGL((gso_rows_kernel<4>), grid, dim3(GSO_THREADS), lds, st, A, src, dst, B, K, N, j_lo, j_hi,
-                           write_base, has_prev, nrt, nslots, X_t, Xd_prev, Xd_next, F);
+        hipLaunchKernelGGL((gso_rows_kernel<4>), grid, dim3(GSO_THREADS), lds, st, A, src, dst, sAb, mode, B, K, N,
+                           j_lo, j_hi, write_base, has_prev, nrt, nslots, X_t, Xd_prev, Xd_next, F);
     } else {
         if (lds > 48 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(gso_rows_kernel<1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MGP_ELAUNCH;
-        hipLaunchKernelGGL((gso_rows_kernel<1>), grid, dim3(GSO_THREADS), lds, st, A, src, dst, B, K, N, j_lo, j_hi,
-                           write_base, has_prev, nrt, nslots, X_t, Xd_prev, Xd_next, F);
+        hipLaunchKernelGGL((gso_rows_kernel<1>), grid, dim3(GSO_THREADS), lds, st, A, src, dst, sAb, mode, B, K, N,
+                           j_lo, j_hi, write_base, has_prev, nrt, nslots, X_t, Xd_prev, Xd_next, F);
     }
     return mgp_launch_status();
 }
@@ -187,8 +192,24 @@ extern "C" int mgp_gso_update(const float* A, const float* G_prev, float* G_next
         if (K > 1) MGP_CHECK_PTR(Xd_prev);
         if (G_prev == G_next || Xd_prev == Xd_next) return MGP_EINVAL;
     }
-    return launch_gso(A, has_prev ? G_prev : nullptr, G_next, B, K, N, 2, K, 1, has_prev ? 1 : 0,
+    return launch_gso(A, (long)N * N, 0, has_prev ? G_prev : nullptr, G_next, B, K, N, 2, K, 1, has_prev ? 1 : 0,
                       X_t, has_prev ? Xd_prev : nullptr, Xd_next, F, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mgp_gso_advance(const float* G_prev, float* G_next, const float* Xd_prev, float* Xd_next,
+                               int B, int K, int F, int N, int has_prev, void* stream)
+{
+    if (B < 0 || K <= 0 || F <= 0 || N <= 0) return MGP_EINVAL;
+    if (B == 0 || K == 1) return MGP_OK;
+    if (B > 65535) return MGP_EINVAL;
+    MGP_CHECK_PTR(G_next); MGP_CHECK_PTR(Xd_next);
+    if (has_prev) {
+        MGP_CHECK_PTR(G_prev); MGP_CHECK_PTR(Xd_prev);
+        if (G_prev == G_next || Xd_prev == Xd_next) return MGP_EINVAL;
+    }
+    // A_t lives in slice 1 of G_next (batch stride K*N*N)
+    return launch_gso(G_next + (size_t)N * N, (long)K * N * N, 1, has_prev ? G_prev : nullptr, G_next, B, K, N, 2, K, 0,
+                      has_prev ? 1 : 0, Xd_next, has_prev ? Xd_prev : nullptr, Xd_next, F, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int mgp_gso_powers(const float* A, float* P, int B, int K, int N, void* stream)
@@ -199,8 +220,8 @@ extern "C" int mgp_gso_powers(const float* A, float* P, int B, int K, int N, voi
     MGP_CHECK_PTR(A); MGP_CHECK_PTR(P);
     hipStream_t st = static_cast<hipStream_t>(stream);
     // slices 0 (I) and 1 (A); then one dependent launch per further power
-    int rc = launch_gso(A, nullptr, P, B, K, N, 2, 2, 1, 1, nullptr, nullptr, nullptr, 0, st);
+    int rc = launch_gso(A, (long)N * N, 0, nullptr, P, B, K, N, 2, 2, 1, 1, nullptr, nullptr, nullptr, 0, st);
     for (int j = 2; j < K && rc == MGP_OK; ++j)
-        rc = launch_gso(A, P, P, B, K, N, j, j + 1, 0, 1, nullptr, nullptr, nullptr, 0, st);
+        rc = launch_gso(A, (long)N * N, 0, P, P, B, K, N, j, j + 1, 0, 1, nullptr, nullptr, nullptr, 0, st);
     return rc;
 }

@@ -167,9 +167,15 @@ class VecFlock(object):
         ops.flock_step(self.x, None, self._c, A=self.network, A64=self.network64, feat=self.features,
                        feat64=self.features64, reward=self.reward, expert=self.expert if self.with_expert else None)
 
-    def step(self, u):
+    def step(self, u, A_out=None, feat_out=None):
         """u (B,N,2) or the Actor output (B,1,2,N), fp32 on device.  Advances every episode one step in place;
-        with `with_expert` the decentralised expert action of the new state lands in `self.expert` for free."""
+        with `with_expert` the decentralised expert action of the new state lands in `self.expert` for free.
+        A_out / feat_out: optional (possibly batch-strided) destinations for the network matrix and the features,
+        e.g. BatchedDelayState.next_slots(); self.network / self.features then alias them."""
+        if A_out is not None:
+            self.network = A_out
+        if feat_out is not None:
+            self.features = feat_out
         ops.flock_step(self.x, u, self._c, A=self.network, A64=self.network64, feat=self.features,
                        feat64=self.features64, reward=self.reward, expert=self.expert if self.with_expert else None)
 

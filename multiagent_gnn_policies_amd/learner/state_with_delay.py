@@ -64,6 +64,9 @@ class BatchedDelayState(object):
         kw = dict(device=device, dtype=torch.float32)
         self._G = [torch.zeros((B, K, N, N), **kw), torch.zeros((B, K, N, N), **kw)]
         self._X = [torch.zeros((B, K, F, N), **kw), torch.zeros((B, K, F, N), **kw)]
+        for g in self._G:
+            g[:, 0] = torch.eye(N, **kw)          # slice 0 is the identity for the whole life of the buffer
+        self._scratch_A = torch.zeros((B, N, N), **kw) if K == 1 else None
         self._cur = 0
         self._has_prev = False
 
@@ -75,6 +78,21 @@ class BatchedDelayState(object):
         nxt = 1 - self._cur
         ops.gso_update_into(A, self._G[self._cur], self._G[nxt], X_t, self._X[self._cur], self._X[nxt],
                             has_prev=self._has_prev)
+        self._cur = nxt
+        self._has_prev = True
+
+    # ---- in-place protocol: the simulator writes A_t / X_t straight into the next buffers ---------------
+    def next_slots(self):
+        """(A_dst (B,N,N) view = next delay_gso[:,1], X_dst (B,F,N) view = next delay_state[:,0]): hand these to
+        VecFlock.step(..., A_out=, feat_out=) and then call advance().  Saves the A read-copy-write and the identity
+        rewrite of push() (3 N^2 instead of 5 N^2 floats of state traffic per episode-step at K = 3)."""
+        nxt = 1 - self._cur
+        A_dst = self._G[nxt][:, 1] if self.K > 1 else self._scratch_A
+        return A_dst, self._X[nxt][:, 0]
+
+    def advance(self):
+        nxt = 1 - self._cur
+        ops.gso_advance(self._G[self._cur], self._G[nxt], self._X[self._cur], self._X[nxt], has_prev=self._has_prev)
         self._cur = nxt
         self._has_prev = True
 

@@ -177,6 +177,15 @@ def gso_update_into(A, G_prev, G_next, X_t, Xd_prev, Xd_next, has_prev=True):
     _lib.check(rc, 'mgp_gso_update')
 
 
+def gso_advance(G_prev, G_next, Xd_prev, Xd_next, has_prev=True):
+    """In-place state transition when the simulator already wrote A_t into G_next[:,1] and X_t into Xd_next[:,0]."""
+    B, K, N, _ = G_next.shape
+    F = Xd_next.shape[2]
+    rc = _lib.lib().mgp_gso_advance(_ptr(G_prev), _ptr(G_next), _ptr(Xd_prev), _ptr(Xd_next), B, K, F, N,
+                                    1 if has_prev else 0, _stream())
+    _lib.check(rc, 'mgp_gso_advance')
+
+
 def gso_powers(A, K):
     """A (B,N,N) -> (B,K,N,N): I, A, A@A, ...   (reference state_with_delay.py:38-41)."""
     _dev(A, 'A')
@@ -203,8 +212,16 @@ def flock_step(x, u, params, A=None, A64=None, feat=None, feat64=None, reward=No
             su_agent, su_axis = 1, N
         else:
             assert u.shape == (B, N, 2), "u must be (B,N,2) or (B,1,2,N)"
+    # A / feat may be strided batch views (e.g. delay_gso_next[:, 1], delay_state_next[:, 0])
+    sAb = sFb = 0
+    if A is not None:
+        assert A.shape == (B, N, N) and A.stride(2) == 1 and A.stride(1) == N
+        sAb = A.stride(0)
+    if feat is not None:
+        assert feat.shape == (B, 6, N) and feat.stride(2) == 1 and feat.stride(1) == N
+        sFb = feat.stride(0)
     rc = _lib.lib().mgp_flock_step(_ptr(x), _ptr(u), su_agent, su_axis, _ptr(A), _ptr(A64), _ptr(feat), _ptr(feat64),
-                                   _ptr(reward), _ptr(expert), ctypes.byref(params), B, N, _stream())
+                                   _ptr(reward), _ptr(expert), sAb, sFb, ctypes.byref(params), B, N, _stream())
     _lib.check(rc, 'mgp_flock_step')
 
 
