@@ -80,17 +80,33 @@ class Rollout(object):
 
 
 def time_kernel(fn, n_sets, iters):
-    """Average duration (ms) of one launch of fn(i), HIP events on the launch stream, back to back."""
-    for i in range(min(n_sets, 3)):
-        fn(i)
+    """Average duration (ms) of one launch of fn(i): HIP events on the launch stream around a captured HIP graph of
+    `n_sets` back-to-back launches (one per rotating input set), replayed until `iters` launches have run.  The graph
+    keeps the measurement GPU-bound (an eager Python loop is host-bound below ~25 us per launch); what remains on
+    top of the kernel is the ~1.5 us dependent-kernel boundary, so the figure is slightly conservative."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(min(n_sets, 3)):
+            fn(i)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for i in range(n_sets):
+            fn(i)
+    reps = max(2, (iters + n_sets - 1) // n_sets)
+    graph.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for it in range(iters):
-        fn(it % n_sets)
+    for _ in range(reps):
+        graph.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+    ms = e0.elapsed_time(e1) / (reps * n_sets)
+    del graph
+    return ms
 
 
 def kernel_rooflines(device, B, N, K, actor, flock_c):
@@ -107,10 +123,11 @@ def kernel_rooflines(device, B, N, K, actor, flock_c):
     ms = time_kernel(lambda i: ops.agg_fwd(Xs[i].permute(0, 2, 1, 3), Gs[i]), n_sets, iters)
     agg_bytes = (4 * K * N * N + 8 * K * F_FEAT * N) * B
     res['agg_fwd'] = dict(ms=ms, bytes=agg_bytes, gbs=agg_bytes / ms / 1e6)
-    # --- whole Actor forward (aggregation + filter GEMM + MLP readout)
+    # --- whole Actor forward (aggregation + filter GEMM + MLP readout), fused kernel
     with torch.no_grad():
         ms = time_kernel(lambda i: actor(Xs[i], Gs[i]), n_sets, iters)
-    act_bytes = (4 * K * N * N + 4 * K * F_FEAT * N + 4 * N_ACT * N) * B
+    n_params = sum(p.numel() for p in actor.parameters())
+    act_bytes = (4 * K * N * N + 4 * K * F_FEAT * N + 4 * N_ACT * N) * B + 4 * n_params
     res['actor_fwd'] = dict(ms=ms, bytes=act_bytes, gbs=act_bytes / ms / 1e6)
     # --- delayed-GSO update: read A, G_prev[1..K-2]; write K slices
     As = [torch.zeros((B, N, N), device=device) for _ in range(n_sets)]
@@ -134,6 +151,23 @@ def kernel_rooflines(device, B, N, K, actor, flock_c):
     del Gs, Xs, As
     torch.cuda.empty_cache()
     return res, n_sets
+
+
+def pmc_traffic(kernel, B, N, K):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json,
+    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; tools/pmc_summary.py), or None when the profile was
+    taken on other shapes or on a different build of the kernels."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        from multiagent_gnn_policies_amd import build as mgp_build
+        meta = d.get('_meta', {})
+        if meta.get('shape') != [B, N, K] or meta.get('source_hash') != mgp_build.source_hash():
+            return None
+        return d[kernel]['total_bytes']
+    except Exception:
+        return None
 
 
 def cpu_baseline(N, K, hidden, budget_s=12.0):
@@ -267,12 +301,21 @@ def main():
         }
     if rank == 0 and not args.no_roofline:
         res, n_sets = kernel_rooflines(device, B, N, K, ro.actor, ro.sim._c)
-        agg = res['agg_fwd']
-        out["roofline"] = {"kernel": "agg_fwd_kernel (graph-shift aggregation X.G)", "bound": "hbm",
-                           "achieved": agg['gbs'], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": agg['gbs'] / HBM_PEAK_GBS, "traffic": None,
-                           "algorithmic_bytes_per_launch": agg['bytes'], "avg_launch_ms": agg['ms'],
-                           "rotating_input_sets": n_sets}
+        # dominant kernel of the step = the fused Actor forward: the graph-shift aggregation X.G (HBM-bound, reads
+        # the dense (B,K,N,N) operator once) with the filter GEMM / MLP readout fused behind it
+        fused = getattr(ro.actor, 'use_fused', False) and ro.actor.ind_agg == 0
+        dom = res['actor_fwd'] if fused else res['agg_fwd']
+        kname = "actor_fwd_kernel (aggregation X.G + MFMA filter/MLP, fused)" if fused else "agg_fwd_kernel (aggregation X.G)"
+        out["roofline"] = {"kernel": kname, "bound": "hbm",
+                           "achieved": dom['gbs'], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": dom['gbs'] / HBM_PEAK_GBS,
+                           "traffic": pmc_traffic('actor_fwd_kernel' if fused else 'agg_fwd_kernel', B, N, K),
+                           "algorithmic_bytes_per_launch": dom['bytes'], "avg_launch_ms": dom['ms'],
+                           "rotating_input_sets": n_sets,
+                           "aggregation_alone": {"kernel": "agg_fwd_kernel", "GBps": res['agg_fwd']['gbs'],
+                                                 "frac": res['agg_fwd']['gbs'] / HBM_PEAK_GBS,
+                                                 "algorithmic_bytes_per_launch": res['agg_fwd']['bytes'],
+                                                 "avg_launch_ms": res['agg_fwd']['ms']}}
         out["kernels"] = {k: {"avg_launch_ms": v['ms'], "algorithmic_bytes": v['bytes'], "GBps": v['gbs']}
                           for k, v in res.items()}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -38,6 +38,12 @@ def main():
         res[k] = dict(read_bytes=rd, write_bytes=wr, total_bytes=rd + wr, launches=fetch.get(k, (0, 0))[0])
         print("%-28s %8d %14.3f %14.3f %14.3f" % (k, res[k]['launches'], rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
     if len(sys.argv) > 3:
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from multiagent_gnn_policies_amd import build as mgp_build
+        shape = [int(v) for v in sys.argv[4].split(',')] if len(sys.argv) > 4 else [256, 100, 3]
+        res['_meta'] = {'shape': shape, 'source_hash': mgp_build.source_hash(),
+                        'note': 'bytes per launch; read = 2 x FETCH_SIZE KiB, write = WRITE_SIZE KiB'}
         with open(sys.argv[3], 'w') as f:
             json.dump(res, f, indent=1)
 
