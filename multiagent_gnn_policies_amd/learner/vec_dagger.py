@@ -1,0 +1,143 @@
+"""Vectorised, device-resident DAGGER: many episodes per GPU, nothing leaves HBM between the simulator, the state
+update, the policy and the replay memory.  An extension of reference learner/gnn_dagger.py:126-243 (which steps ONE
+environment through Python objects); the schedule is the reference's, applied per episode:
+
+  * episode e (global index over rounds, ranks and lanes) uses beta_e = max(beta_coeff^(e+1), 0.5)   (:148)
+  * every step stores (state, expert label) and steps the env with the expert w.p. beta_e else the policy  (:156-178)
+  * after a round of `n_envs` episodes: `updates_per_step` updates per episode of the round            (:182-188)
+  * final statistics = mean / std of `n_test_episodes` policy-only episode rewards                     (:221-237)
+
+`DeviceReplay` keeps the reference's ring + sample-without-replacement semantics (replay_buffer.py:6-49, Python's
+`random` RNG) but stores dense states in HBM: 10,000 transitions of N=100,K=3 are 1.3 GB of 288 GB.
+Ranks shard episodes (parallel.py); the only collective is the flat-gradient all-reduce inside gradient_step.
+"""
+import random
+
+import numpy as np
+import torch
+
+from .. import parallel
+from ..envs import FlockParams, VecFlock
+from ..envs.flocking import _REGISTRY
+from .gnn_dagger import DAGGER
+from .state_with_delay import BatchedDelayState
+
+
+class DeviceReplay(object):
+    """Ring buffer of transitions resident on the device (state = delay_state + delay_gso, label = expert action)."""
+
+    def __init__(self, max_size, K, F, N, n_a, device):
+        self.max_size = max_size
+        kw = dict(device=device, dtype=torch.float32)
+        self.delay_state = torch.empty((max_size, K, F, N), **kw)
+        self.delay_gso = torch.empty((max_size, K, N, N), **kw)
+        self.action = torch.empty((max_size, 1, n_a, N), **kw)
+        self.curr_size = 0
+        self.position = 0
+        self.device = device
+
+    def insert_batch(self, delay_state, delay_gso, action):
+        """Append B transitions (oldest overwritten), same order as B consecutive `insert` calls."""
+        B = delay_state.shape[0]
+        idx = (torch.arange(B, device=self.device) + self.position) % self.max_size
+        self.delay_state.index_copy_(0, idx, delay_state)
+        self.delay_gso.index_copy_(0, idx, delay_gso)
+        self.action.index_copy_(0, idx, action)
+        self.position = (self.position + B) % self.max_size
+        self.curr_size = min(self.max_size, self.curr_size + B)
+
+    def sample(self, num_samples):
+        """Without replacement, Python `random` RNG (reference replay_buffer.py:40)."""
+        ids = random.sample(range(self.curr_size), num_samples)
+        idx = torch.tensor(ids, device=self.device, dtype=torch.long)
+        return (self.delay_state.index_select(0, idx), self.delay_gso.index_select(0, idx),
+                self.action.index_select(0, idx))
+
+    def clear(self):
+        self.curr_size = 0
+        self.position = 0
+
+
+def _params_from_args(args):
+    env_cls = _REGISTRY.get(args.get('env'), None)
+    variant = getattr(env_cls, 'variant', {}) if env_cls is not None else {}
+    kw = dict(n_agents=args.getint('n_agents'), comm_radius=args.getfloat('comm_radius'),
+              v_max=args.getfloat('v_max'), v_bias=args.getfloat('v_max'), init_mode='grid')
+    if args.get('dt') is not None:
+        kw['dt'] = args.getfloat('dt')
+    kw.update(variant)
+    return FlockParams(**kw)
+
+
+def _label(expert):
+    """(B,N,nA) -> (B,1,nA,N)   (reference gnn_dagger.py:174-176, batched)"""
+    return expert.permute(0, 2, 1).unsqueeze(1).contiguous()
+
+
+def evaluate(learner, sim, state, n_episodes, steps):
+    """Policy-only episodes in lanes of sim.B; returns the list of per-episode reward sums."""
+    rewards = []
+    while len(rewards) < n_episodes:
+        sim.reset(np.random)
+        state.reset()
+        state.push(sim.network, sim.features)
+        total = torch.zeros((sim.B,), device=sim.device, dtype=torch.float64)
+        with torch.no_grad():
+            for _ in range(steps):
+                out = learner.actor(state.delay_state, state.delay_gso)
+                A_dst, X_dst = state.next_slots()
+                sim.step(out, A_out=A_dst, feat_out=X_dst)
+                state.advance()
+                total += sim.reward
+        rewards += total.cpu().tolist()
+    return rewards[:n_episodes]
+
+
+def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
+    """Returns {'mean','std'} like train_dagger.  `n_envs` parallel episodes per rank."""
+    device = torch.device(device)
+    p = _params_from_args(args)
+    N, K, F, n_a = p.n_agents, args.getint('k'), args.getint('n_states'), args.getint('n_actions')
+    T = episode_steps or p.max_episode_steps
+    learner = DAGGER(device, args)
+    memory = DeviceReplay(args.getint('buffer_size'), K, F, N, n_a, device)
+    sim = VecFlock(n_envs, p, device, with_expert=True)
+    state = BatchedDelayState(device, n_envs, K, F, N)
+    batch_size = args.getint('batch_size')
+    beta_coeff = args.getfloat('beta_coeff')
+    updates_per_step = args.getint('updates_per_step')
+    n_train_episodes = args.getint('n_train_episodes')
+    n_test_episodes = args.getint('n_test_episodes')
+    debug = args.getboolean('debug')
+    rank, world = parallel.rank(), parallel.world_size()
+    rounds = (n_train_episodes + n_envs * world - 1) // (n_envs * world)
+    updates = 0
+    for rd in range(rounds):
+        e0 = (rd * world + rank) * n_envs
+        beta = np.maximum(beta_coeff ** (np.arange(e0, e0 + n_envs) + 1.0), 0.5)
+        sim.reset(np.random)
+        state.reset()
+        state.push(sim.network, sim.features)
+        for _ in range(T):
+            expert = sim.controller()                                     # by-product of the last sim kernel
+            memory.insert_batch(state.delay_state, state.delay_gso, _label(expert))
+            with torch.no_grad():
+                policy = learner.actor(state.delay_state, state.delay_gso)   # (B,1,nA,N)
+            use_expert = torch.from_numpy(np.random.binomial(1, beta).astype(np.bool_)).to(device)
+            action = torch.where(use_expert.view(-1, 1, 1), expert, policy[:, 0].permute(0, 2, 1)).contiguous()
+            A_dst, X_dst = state.next_slots()
+            sim.step(action, A_out=A_dst, feat_out=X_dst)
+            state.advance()
+        loss_sum = 0.0
+        if memory.curr_size > batch_size:
+            for _ in range(updates_per_step * n_envs):
+                xs, gs, ys = memory.sample(batch_size)
+                loss_sum += learner.gradient_step_tensors(xs, gs, ys)
+                updates += 1
+        if debug and rank == 0:
+            print("Round: {}, episodes: {}, updates: {}, policy loss: {}".format(rd, (rd + 1) * n_envs * world,
+                                                                                   updates, loss_sum))
+    lo, hi = parallel.shard_range(n_test_episodes)
+    n_local = max(1, hi - lo) if world > 1 else n_test_episodes
+    rewards = parallel.all_gather_floats(evaluate(learner, sim, state, n_local, T))
+    return {'mean': float(np.mean(rewards)), 'std': float(np.std(rewards)), 'learner': learner, 'updates': updates}
