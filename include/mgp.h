@@ -192,6 +192,10 @@ int mgp_mse_grad(const float* pred, const float* target, float* dPred, float* lo
                  long n, void* stream);
 int mgp_adam_step(float* param, const float* grad, float* m, float* v, long n,
                   float lr, float beta1, float beta2, float eps, int step, void* stream);
+/* Same update with the 0-based step counter resident on the device (*step_dev is read, then incremented by a
+ * trailing 1-thread kernel): no per-step host scalars, so a whole DAGGER update replays from one HIP graph. */
+int mgp_adam_step_dev(float* param, const float* grad, float* m, float* v, long n,
+                      float lr, float beta1, float beta2, float eps, int* step_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,7 @@ SIGNATURES = {
     'mgp_flock_controller': (_int, [_vp, _vp, _vp, ctypes.POINTER(MgpFlockParams), _int, _int, _int, _vp]),
     'mgp_mse_grad': (_int, [_vp, _vp, _vp, _vp, _long, _vp]),
     'mgp_adam_step': (_int, [_vp, _vp, _vp, _vp, _long, _f32, _f32, _f32, _f32, _int, _vp]),
+    'mgp_adam_step_dev': (_int, [_vp, _vp, _vp, _vp, _long, _f32, _f32, _f32, _f32, _vp, _vp]),
 }
 
 _lock = threading.Lock()

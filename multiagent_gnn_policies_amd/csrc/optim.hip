@@ -45,7 +45,45 @@ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __re
     v[i] = vi;
 }
 
+// Adam with the step count resident on the device (HIP-graph replayable: no per-step host scalars).  Every thread
+// derives the bias corrections from *step_dev + 1 in double precision; step_inc_kernel advances the counter after.
+__global__ __launch_bounds__(256)
+void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                     long n, float lr, float b1, float b2, float eps, const int* __restrict__ step_dev)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double step = (double)(*step_dev + 1);
+    const double bc1 = 1.0 - pow((double)b1, step);
+    const double bc2 = 1.0 - pow((double)b2, step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float one_m_b1 = (float)(1.0 - (double)b1), one_m_b2 = (float)(1.0 - (double)b2);
+    const float gi = g[i];
+    const float mi = m[i] + (gi - m[i]) * one_m_b1;
+    const float vi = v[i] * b2 + one_m_b2 * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+}
+
+__global__ void step_inc_kernel(int* step_dev) { *step_dev += 1; }
+
 }  // namespace
+
+extern "C" int mgp_adam_step_dev(float* param, const float* grad, float* m, float* v, long n,
+                                 float lr, float beta1, float beta2, float eps, int* step_dev, void* stream)
+{
+    if (n <= 0) return MGP_EINVAL;
+    MGP_CHECK_PTR(param); MGP_CHECK_PTR(grad); MGP_CHECK_PTR(m); MGP_CHECK_PTR(v); MGP_CHECK_PTR(step_dev);
+    mgp_clear_error();
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, param, grad, m, v, n,
+                       lr, beta1, beta2, eps, step_dev);
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step_dev);
+    return mgp_launch_status();
+}
 
 extern "C" int mgp_mse_grad(const float* pred, const float* target, float* dPred, float* loss, long n, void* stream)
 {

@@ -59,6 +59,77 @@ class FlatAdam(object):
         ops.adam_step(self.flat, self.flat_grad, self.m, self.v, self.lr, self.step_count,
                       self.betas[0], self.betas[1], self.eps)
 
+    def views(self, flat):
+        """Per-parameter views into a flat buffer laid out like self.flat."""
+        out, off = [], 0
+        for p in self.params:
+            out.append(flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        return out
+
+
+class GraphedUpdate(object):
+    """One DAGGER update (fused forward with saved activations -> MSE gradient -> fused backward straight into the
+    flat gradient buffer -> device-step Adam) captured once per batch size as a HIP graph on static buffers.
+    Five kernel launches replayed with one host call instead of ~40 Python-level ops."""
+
+    def __init__(self, learner, B):
+        import ctypes
+        from .. import _lib
+        from .actor_fused import _ptr_array
+        actor, opt = learner.actor, learner.actor_optim
+        dev = opt.flat.device
+        K, N, F = actor.k, learner.n_agents, actor.n_s
+        dims = tuple(actor.layers)
+        self.cdims = (ctypes.c_int * len(dims))(*dims)
+        L = _lib.lib()
+        self.X = torch.empty((B, K, F, N), device=dev)
+        self.G = torch.empty((B, K, N, N), device=dev)
+        self.Y = torch.empty((B, 1, actor.n_a, N), device=dev)
+        self.out = torch.empty((B, 1, actor.n_a, N), device=dev)
+        self.dOut = torch.empty_like(self.out)
+        self.loss = torch.zeros((1,), device=dev)
+        self.saved = torch.empty((L.mgp_actor_saved_floats(self.cdims, actor.n_layers, B, K, N),), device=dev)
+        self.ws = torch.empty((max(1, L.mgp_actor_bwd_workspace(self.cdims, actor.n_layers, B, K, N)),), device=dev)
+        self.step_dev = torch.full((1,), opt.step_count, device=dev, dtype=torch.int32)
+        pv, gv = opt.views(opt.flat), opt.views(opt.flat_grad)
+        self.Wp, self.bp = _ptr_array(pv[0::2]), _ptr_array(pv[1::2])
+        self.dWp, self.dbp = _ptr_array(gv[0::2]), _ptr_array(gv[1::2])
+        self._keep = (pv, gv)
+        self.B, self.K, self.N, self.nl = B, K, N, actor.n_layers
+        self.opt = opt
+        self.graph = None
+
+    def _enqueue(self):
+        from .. import _lib
+        L, o = _lib.lib(), self.opt
+        st = ops._stream()
+        _lib.check(L.mgp_actor_fwd(ops._ptr(self.X), ops._ptr(self.G), self.Wp, self.bp, self.cdims, self.nl,
+                                   ops._ptr(self.out), ops._ptr(self.saved), self.B, self.K, self.N, st), 'mgp_actor_fwd')
+        _lib.check(L.mgp_mse_grad(ops._ptr(self.out), ops._ptr(self.Y), ops._ptr(self.dOut), ops._ptr(self.loss),
+                                  self.out.numel(), st), 'mgp_mse_grad')
+        _lib.check(L.mgp_actor_bwd(ops._ptr(self.dOut), ops._ptr(self.saved), self.Wp, self.cdims, self.nl, self.dWp,
+                                   self.dbp, self.B, self.K, self.N, ops._ptr(self.ws), st), 'mgp_actor_bwd')
+        _lib.check(L.mgp_adam_step_dev(ops._ptr(o.flat), ops._ptr(o.flat_grad), ops._ptr(o.m), ops._ptr(o.v),
+                                       o.flat.numel(), o.lr, o.betas[0], o.betas[1], o.eps, ops._ptr(self.step_dev), st),
+                   'mgp_adam_step_dev')
+
+    def run(self, X, G, Y):
+        self.X.copy_(X); self.G.copy_(G); self.Y.copy_(Y)
+        if self.graph is None:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.step_dev.fill_(self.opt.step_count)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._enqueue()
+        self.graph.replay()
+        self.opt.step_count += 1
+        return self.loss
+
 
 class DAGGER(object):
 
@@ -82,6 +153,19 @@ class DAGGER(object):
         self.actor_optim = FlatAdam(self.actor, lr=args.getfloat('actor_lr'))
         self.grad_sync = FlatGradSync()           # no-op unless torch.distributed is initialised
         self.grad_sync.broadcast_(self.actor_optim.flat)
+        self._graphed = {}                        # batch size -> GraphedUpdate
+        self.use_graphed_update = True
+
+    def _can_graph(self, X):
+        """Single-process runs whose shape the fused kernels cover replay the update from a HIP graph; the
+        data-parallel path stays eager because the flat-gradient all-reduce sits between backward and Adam."""
+        import ctypes
+        from .. import _lib
+        if not self.use_graphed_update or parallel.is_distributed() or not self.actor.use_fused:
+            return False
+        dims = tuple(self.actor.layers)
+        cd = (ctypes.c_int * len(dims))(*dims)
+        return bool(_lib.lib().mgp_actor_supported(cd, self.actor.n_layers, self.actor.k, X.shape[3])) and X.is_cuda
 
     def select_action(self, state):
         """(1,K,F,N),(1,K,N,N) -> action (N,nA) on the device (reference gnn_dagger.py:55-72)."""
@@ -100,6 +184,12 @@ class DAGGER(object):
         return self.gradient_step_tensors(delay_state_batch, delay_gso_batch, optimal_action_batch)
 
     def gradient_step_tensors(self, delay_state_batch, delay_gso_batch, optimal_action_batch):
+        if self._can_graph(delay_state_batch):
+            B = delay_state_batch.shape[0]
+            gu = self._graphed.get(B)
+            if gu is None:
+                gu = self._graphed[B] = GraphedUpdate(self, B)
+            return gu.run(delay_state_batch, delay_gso_batch, optimal_action_batch).item()
         self.actor_optim.zero_grad()
         actor_batch = self.actor(delay_state_batch, delay_gso_batch)
         policy_loss = ops.mse_loss(actor_batch, optimal_action_batch)
