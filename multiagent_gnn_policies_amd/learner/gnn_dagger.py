@@ -16,6 +16,7 @@ from .. import parallel
 from ..parallel import FlatGradSync
 from .actor import Actor
 from .replay_buffer import ReplayBuffer, Transition
+from .rollouts import policy_episode_reward
 from .state_with_delay import MultiAgentStateWithDelay
 
 
@@ -220,15 +221,7 @@ class DAGGER(object):
 
 
 def _rollout_reward(env, learner, device, args):
-    ep_reward = 0
-    state = MultiAgentStateWithDelay(device, args, env.reset(), prev_state=None)
-    done = False
-    while not done:
-        action = learner.select_action(state)
-        next_state, reward, done, _ = env.step(action.cpu().numpy())
-        state = MultiAgentStateWithDelay(device, args, next_state, prev_state=state)
-        ep_reward += reward
-    return ep_reward
+    return policy_episode_reward(env, learner, device, args)
 
 
 def train_dagger(env, args, device):

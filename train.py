@@ -1,9 +1,12 @@
-"""`python3 train.py cfg/X.cfg` -- same command line, cfg format and printed output as the reference's
-entry point (reference train.py:15-67): one experiment per cfg section, header printed once, then
-`section, mean, std`.  Environments come from this package's registry instead of gym/gym_flock, and the
-learner runs on the MI355X kernels.
+"""Experiment runner with the reference's command line, cfg format and printed output (reference train.py:15-67):
+
+    python3 train.py cfg/dagger.cfg
+
+Every section of the INI file is one experiment (inheriting `[DEFAULT]`); the `header` key is printed once, then one
+line `section, mean, std` per experiment.  Environments come from this package's registry instead of gym / gym_flock and
+all learning runs on the MI355X kernels.  Under torchrun (one process per GPU) episodes are sharded over the ranks and
+rank 0 prints.  Extension: `alg = dagger_vec` (device-resident vectorised DAGGER, `n_envs` episodes per GPU).
 """
-from os import path
 import configparser
 import os
 import random
@@ -13,68 +16,87 @@ import numpy as np
 import torch
 
 from multiagent_gnn_policies_amd import envs, parallel
-from multiagent_gnn_policies_amd.learner.gnn_dagger import train_dagger
-from multiagent_gnn_policies_amd.learner.gnn_cloning import train_cloning
-from multiagent_gnn_policies_amd.learner.gnn_baseline import train_baseline
 
 
-def run_experiment(args):
-    env_name = args.get('env')
-    env = envs.make(env_name, device='cuda:%d' % parallel.local_device_index())
-    if isinstance(env.env, envs.FlockingRelativeEnv):
-        env.env.params_from_cfg(args)
-
-    # one seed for the four RNG streams, as in reference train.py:24-28 (+ rank under torchrun, so every
-    # rank rolls out different episodes; weights are broadcast from rank 0 when the learner is built)
-    rank, world, local_rank = parallel.init_from_env()
-    seed = args.getint('seed') + rank
+def seed_everything(seed, env):
+    """The reference seeds four streams with one number (train.py:24-28): env, random, numpy, torch."""
     env.seed(seed)
     random.seed(seed)
     np.random.seed(seed)
     torch.manual_seed(seed)
 
+
+def _dagger(env, args, device):
+    from multiagent_gnn_policies_amd.learner.gnn_dagger import train_dagger
+    return train_dagger(env, args, device)
+
+
+def _cloning(env, args, device):
+    from multiagent_gnn_policies_amd.learner.gnn_cloning import train_cloning
+    return train_cloning(env, args, device)
+
+
+def _baseline(env, args, device):
+    from multiagent_gnn_policies_amd.learner.gnn_baseline import train_baseline
+    return train_baseline(env, args)
+
+
+def _dagger_vec(env, args, device):
+    from multiagent_gnn_policies_amd.learner.vec_dagger import train_dagger_vec
+    env.close()
+    return train_dagger_vec(args, device, n_envs=args.getint('n_envs', fallback=64))
+
+
+ALGORITHMS = {'dagger': _dagger, 'cloning': _cloning, 'baseline': _baseline, 'dagger_vec': _dagger_vec}
+
+
+def run_experiment(args):
     if not torch.cuda.is_available():
         raise RuntimeError("train.py needs an MI355X (HIP device); this framework has no CPU compute path")
+    rank, _world, local_rank = parallel.init_from_env()
     device = torch.device("cuda", parallel.local_device_index(local_rank))
     torch.cuda.set_device(device)
 
+    env = envs.make(args.get('env'), device=str(device))
+    if isinstance(env.env, envs.FlockingRelativeEnv):
+        env.env.params_from_cfg(args)
+    seed_everything(args.getint('seed') + rank, env)      # + rank: every rank rolls out different episodes
+
     alg = args.get('alg').lower()
-    if alg == 'dagger':
-        stats = train_dagger(env, args, device)
-    elif alg == 'dagger_vec':
-        # extension: device-resident vectorised DAGGER, `n_envs` parallel episodes per GPU (learner/vec_dagger.py)
-        from multiagent_gnn_policies_amd.learner.vec_dagger import train_dagger_vec
-        env.close()
-        stats = train_dagger_vec(args, device, n_envs=args.getint('n_envs', fallback=64))
-    elif alg == 'cloning':
-        stats = train_cloning(env, args, device)
-    elif alg == 'baseline':
-        stats = train_baseline(env, args)
-    else:
+    if alg not in ALGORITHMS:
         raise Exception('Invalid algorithm/mode name')
-    return stats
+    return ALGORITHMS[alg](env, args, device)
 
 
-def main():
-    fname = sys.argv[1]
-    config_file = fname if path.isabs(fname) else path.join(path.dirname(path.abspath(__file__)), fname)
-    if not path.exists(config_file):
-        config_file = fname
+def iter_experiments(config):
+    """(name, section) for every experiment of the file; a file without sections is one unnamed experiment."""
+    names = config.sections()
+    if not names:
+        yield None, config[config.default_section]
+    for name in names:
+        yield name, config[name]
+
+
+def main(argv=None):
+    argv = sys.argv if argv is None else argv
+    fname = argv[1]
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = fname if os.path.exists(fname) else os.path.join(here, fname)
     config = configparser.ConfigParser()
-    config.read(config_file)
-
-    printed_header = False
-    if config.sections():
-        for section_name in config.sections():
-            if not printed_header and int(os.environ.get('RANK', '0')) == 0:
-                print(config[section_name].get('header'))
-                printed_header = True
-            stats = run_experiment(config[section_name])
-            if parallel.rank() == 0:
-                print(section_name + ", " + str(stats['mean']) + ", " + str(stats['std']))
-    else:
-        val = run_experiment(config[config.default_section])
-        print(val)
+    config.read(path)
+    is_root = int(os.environ.get('RANK', '0')) == 0
+    header_done = False
+    for name, section in iter_experiments(config):
+        if name is not None and not header_done and is_root:
+            print(section.get('header'))
+            header_done = True
+        stats = run_experiment(section)
+        if not is_root:
+            continue
+        if name is None:
+            print(stats)
+        else:
+            print(name + ", " + str(stats['mean']) + ", " + str(stats['std']))
 
 
 if __name__ == "__main__":
