@@ -161,7 +161,10 @@ typedef struct MgpFlockParams {
     int    n_leaders;      /* first n_leaders agents ignore u                     */
 } MgpFlockParams;
 
-/* x <- integrate(x, u) in place, then observations.  u is fp32 with batch stride 2N and element (i,a) at
+/* x_out (or x itself when x_out is NULL / == x) <- integrate(x, u), then observations of the new state.  With a
+ * separate x_out (ping-pong state buffers) an episode is processed by several small workgroups, each integrating
+ * the episode redundantly from x -- the fast form for device-resident rollouts; in place it is one workgroup per
+ * 128 rows.  u is fp32 with batch stride 2N and element (i,a) at
  * i*su_agent + a*su_axis: (B,N,2) is (2,1); the Actor's output layout (B,1,2,N) is (1,N) -- no transpose
  * kernel between policy and simulator.  u may be NULL (= refresh observations only).
  *   A    (B,N,N) fp32  network matrix           (may be NULL)
@@ -174,7 +177,7 @@ typedef struct MgpFlockParams {
  *   sAb / sFb          batch strides (elements) of A / feat; 0 = dense (N*N / 6*N).  With sAb = K*N*N and
  *                      A = delay_gso_next + N*N the simulator writes the network matrix straight into slice 1 of
  *                      the next delayed-GSO buffer (feat likewise into delay_state_next[:,0]): see mgp_gso_advance */
-int mgp_flock_step(double* x, const float* u, long su_agent, long su_axis,
+int mgp_flock_step(double* x, double* x_out, const float* u, long su_agent, long su_axis,
                    float* A, double* A64, float* feat, double* feat64,
                    double* reward, float* expert, long sAb, long sFb,
                    const MgpFlockParams* p, int B, int N, void* stream);

@@ -47,7 +47,7 @@ SIGNATURES = {
     'mgp_gso_update': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     'mgp_gso_advance': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     'mgp_gso_powers': (_int, [_vp, _vp, _int, _int, _int, _vp]),
-    'mgp_flock_step': (_int, [_vp, _vp, _long, _long, _vp, _vp, _vp, _vp, _vp, _vp, _long, _long,
+    'mgp_flock_step': (_int, [_vp, _vp, _vp, _long, _long, _vp, _vp, _vp, _vp, _vp, _vp, _long, _long,
                              ctypes.POINTER(MgpFlockParams), _int, _int, _vp]),
     'mgp_flock_controller': (_int, [_vp, _vp, _vp, ctypes.POINTER(MgpFlockParams), _int, _int, _int, _vp]),
     'mgp_mse_grad': (_int, [_vp, _vp, _vp, _vp, _long, _vp]),

@@ -19,14 +19,15 @@
 
 namespace {
 
-constexpr int FL_THREADS = 1024;
-constexpr int FL_WAVES = FL_THREADS / 64;
-constexpr int FL_ROWS = 128;                    // agent rows per workgroup
-constexpr int FL_SPLIT = FL_THREADS / FL_ROWS;  // threads per row (the j range is cut into FL_SPLIT pieces)
+constexpr int FL_THREADS = 1024;                // in-place mode: one workgroup of 1024 threads per 128 rows
+constexpr int FL_ROWS = 128;
+constexpr int FP_THREADS = 256;                 // ping-pong mode (x_out != x): 512 threads per 32 rows -> 4 workgroups per
+constexpr int FP_ROWS = 32;                      // N = 100 episode, 16 threads per row, several workgroups per CU
 
 __device__ __forceinline__ double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-__device__ __forceinline__ double block_sum(double v, double* sh /* [FL_WAVES] */)
+template <int WAVES>
+__device__ __forceinline__ double block_sum(double v, double* sh /* [WAVES] */)
 {
     v = mgp_wave_sum(v);
     __syncthreads();
@@ -34,7 +35,7 @@ __device__ __forceinline__ double block_sum(double v, double* sh /* [FL_WAVES] *
     __syncthreads();
     double t = 0.0;
 #pragma unroll
-    for (int w = 0; w < FL_WAVES; ++w) t += sh[w];
+    for (int w = 0; w < WAVES; ++w) t += sh[w];
     return t;
 }
 
@@ -73,21 +74,31 @@ void flock_integrate_kernel(double* __restrict__ x, const float* __restrict__ u,
     }
 }
 
-// grid: x = row chunk, y = b.  LDS (doubles): px,py,vx,vy [N] | part [FL_SPLIT][FL_ROWS][8] | wrow [FL_ROWS]
-template <bool FUSE_INTEGRATE>
-__global__ __launch_bounds__(FL_THREADS)
-void flock_step_kernel(double* __restrict__ x, const float* __restrict__ u, long su_agent, long su_axis,
-                       FlockOut o, MgpFlockParams p, int N)
+// grid: x = row chunk, y = b.  LDS (doubles): px,py,vx,vy [N] | part [SPLIT][8][ROWS] | wrow [ROWS] | adjacency bits
+// FUSE_INTEGRATE: the workgroup integrates the whole episode into LDS itself.  In-place mode (xo == x) that is only
+// legal with ONE workgroup per episode; ping-pong mode (xo != x) lets every workgroup of the episode do it redundantly
+// (reads x, writes only its own rows of xo), which is what allows small row tiles and many workgroups per episode.
+template <bool FUSE_INTEGRATE, int THREADS, int ROWS>
+__global__ __launch_bounds__(THREADS)
+void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, const float* __restrict__ u,
+                       long su_agent, long su_axis, FlockOut o, MgpFlockParams p, int N)
 {
+    constexpr int FL_SPLIT = THREADS / ROWS;
+    constexpr int FL_WAVES = THREADS / 64;
+    constexpr int FL_ROWS = ROWS;
+    constexpr int FL_THREADS = THREADS;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double sh[FL_WAVES];
     double* spx = sm; double* spy = sm + N; double* svx = sm + 2 * (size_t)N; double* svy = sm + 3 * (size_t)N;
     double* part = sm + 4 * (size_t)N;                     // [FL_SPLIT][FL_ROWS][8]: deg,f0..f5 of each j piece
     double* wrow = part + FL_SPLIT * FL_ROWS * 8;                     // [FL_ROWS] network weight of the row (fp64)
+    unsigned long long* adjw = reinterpret_cast<unsigned long long*>(wrow + FL_ROWS);   // [FL_ROWS][FL_SPLIT][nch]
     const int b = blockIdx.y, tid = threadIdx.x;
     const int i0 = blockIdx.x * FL_ROWS;
     const int rows = min(FL_ROWS, N - i0);
-    double* xb = x + (size_t)b * N * 4;
+    const double* xb = x + (size_t)b * N * 4;
+    double* xob = xo + (size_t)b * N * 4;
+    const bool all_rows = (xo == x);                       // in-place: this workgroup owns the whole episode's state
 
     // ---- load (and, when fused, integrate) every agent of the episode into LDS
     double sum_vx = 0.0, sum_vy = 0.0;
@@ -95,7 +106,9 @@ void flock_step_kernel(double* __restrict__ x, const float* __restrict__ u, long
         double px = xb[i * 4 + 0], py = xb[i * 4 + 1], vx = xb[i * 4 + 2], vy = xb[i * 4 + 3];
         if (FUSE_INTEGRATE && u != nullptr) {
             integrate_one(px, py, vx, vy, u + (size_t)b * N * 2 + (size_t)i * su_agent, su_axis, i < p.n_leaders, p);
-            xb[i * 4 + 0] = px; xb[i * 4 + 1] = py; xb[i * 4 + 2] = vx; xb[i * 4 + 3] = vy;
+            if (all_rows || (i >= i0 && i < i0 + rows)) {
+                xob[i * 4 + 0] = px; xob[i * 4 + 1] = py; xob[i * 4 + 2] = vx; xob[i * 4 + 3] = vy;
+            }
         }
         spx[i] = px; spy[i] = py; svx[i] = vx; svy[i] = vy;
         sum_vx += vx; sum_vy += vy;
@@ -103,9 +116,10 @@ void flock_step_kernel(double* __restrict__ x, const float* __restrict__ u, long
     __syncthreads();
     // ---- episode-level sums (reward, centralised controller): every workgroup of the episode recomputes them
     double tot_vx = 0.0, tot_vy = 0.0;
-    if (o.reward != nullptr || (o.centralized && (o.expert != nullptr || o.expert64 != nullptr))) {
-        tot_vx = block_sum(sum_vx, sh);
-        tot_vy = block_sum(sum_vy, sh);
+    const bool need_cent = o.centralized && (o.expert != nullptr || o.expert64 != nullptr);
+    if ((o.reward != nullptr && blockIdx.x == 0) || need_cent) {      // workgroup-uniform condition
+        tot_vx = block_sum<FL_WAVES>(sum_vx, sh);
+        tot_vy = block_sum<FL_WAVES>(sum_vy, sh);
         if (o.reward != nullptr && blockIdx.x == 0) {
             const double mx = tot_vx / (double)N, my = tot_vy / (double)N;
             double dv = 0.0;
@@ -113,7 +127,7 @@ void flock_step_kernel(double* __restrict__ x, const float* __restrict__ u, long
                 const double ex = svx[i] - mx, ey = svy[i] - my;
                 dv += ex * ex + ey * ey;
             }
-            const double var = block_sum(dv, sh) / (double)N;
+            const double var = block_sum<FL_WAVES>(dv, sh) / (double)N;
             if (tid == 0) o.reward[b] = -1.0 * var * p.reward_scale;
         }
     }
@@ -122,14 +136,29 @@ void flock_step_kernel(double* __restrict__ x, const float* __restrict__ u, long
     const int i = i0 + rl;
     const double R2 = p.comm_radius2;
     double deg = 0.0, f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0;
+    const int jh = (N + FL_SPLIT - 1) / FL_SPLIT;          // j's per piece
+    const int nch = (jh + 63) / 64;                        // 64-bit adjacency words per (row, piece)
     if (rl < rows) {
         const double xi = spx[i], yi = spy[i], vxi = svx[i], vyi = svy[i];
-        const int jh = (N + FL_SPLIT - 1) / FL_SPLIT;
         const int j0 = half * jh, j1 = min(N, j0 + jh);
-        for (int j = j0; j < j1; ++j) {
-            const double dx = xi - spx[j], dy = yi - spy[j];
-            const double r2 = dx * dx + dy * dy;
-            if (j != i && r2 < R2) {
+        for (int c = 0; c < nch; ++c) {
+            // phase 1: cheap membership test for up to 64 j's -> bit mask (the only fp64 work every pair pays)
+            const int ja = j0 + 64 * c, jb = min(j1, ja + 64);
+            unsigned long long mask = 0ull;
+            for (int j = ja; j < jb; ++j) {
+                const double dx = xi - spx[j], dy = yi - spy[j];
+                const double r2 = dx * dx + dy * dy;
+                if (j != i && r2 < R2) mask |= 1ull << (j - ja);
+            }
+            adjw[((size_t)rl * FL_SPLIT + half) * nch + c] = mask;
+            // phase 2: the division and the six feature terms only for actual neighbours, ascending j.  A wave runs
+            // this body max-over-lanes(popcount) times (~2-3) instead of once per j (13), which is where the
+            // divergent fp64 division used to dominate.
+            while (mask) {
+                const int j = ja + __builtin_ctzll(mask);
+                mask &= mask - 1ull;
+                const double dx = xi - spx[j], dy = yi - spy[j];
+                const double r2 = dx * dx + dy * dy;
                 const double q = 1.0 / r2;
                 const double qq = q * q;
                 deg += 1.0;
@@ -142,16 +171,20 @@ void flock_step_kernel(double* __restrict__ x, const float* __restrict__ u, long
             }
         }
         if (half > 0) {
-            double* pr = part + ((size_t)half * FL_ROWS + rl) * 8;
-            pr[0] = deg; pr[1] = f0; pr[2] = f1; pr[3] = f2; pr[4] = f3; pr[5] = f4; pr[6] = f5;
+            // value-major layout part[h][k][row]: consecutive lanes (rows) hit consecutive banks (the row-major
+            // [row][8] layout was a 16-way bank conflict on every one of these stores and of the reads below)
+            double* pr = part + (size_t)half * 8 * FL_ROWS + rl;
+            pr[0 * FL_ROWS] = deg; pr[1 * FL_ROWS] = f0; pr[2 * FL_ROWS] = f1; pr[3 * FL_ROWS] = f2;
+            pr[4 * FL_ROWS] = f3; pr[5 * FL_ROWS] = f4; pr[6 * FL_ROWS] = f5;
         }
     }
     __syncthreads();
     if (half == 0 && rl < rows) {
-#pragma unroll
+#pragma unroll 2      // NOT fully: 15 pieces x 7 doubles in flight cost 222 VGPRs and the second resident workgroup
         for (int h = 1; h < FL_SPLIT; ++h) {                 // ascending j pieces: deterministic
-            const double* pr = part + ((size_t)h * FL_ROWS + rl) * 8;
-            deg += pr[0]; f0 += pr[1]; f1 += pr[2]; f2 += pr[3]; f3 += pr[4]; f4 += pr[5]; f5 += pr[6];
+            const double* pr = part + (size_t)h * 8 * FL_ROWS + rl;
+            deg += pr[0 * FL_ROWS]; f0 += pr[1 * FL_ROWS]; f1 += pr[2 * FL_ROWS]; f2 += pr[3 * FL_ROWS];
+            f3 += pr[4 * FL_ROWS]; f4 += pr[5 * FL_ROWS]; f5 += pr[6 * FL_ROWS];
         }
         wrow[rl] = p.mean_pooling ? 1.0 / (deg == 0.0 ? 1.0 : deg) : 1.0;
         if (o.feat != nullptr) {
@@ -181,16 +214,17 @@ void flock_step_kernel(double* __restrict__ x, const float* __restrict__ u, long
     }
     if (o.A == nullptr && o.A64 == nullptr) return;
     __syncthreads();
-    // ---- network rows i0..i0+rows-1: one flat coalesced sweep, membership recomputed from LDS (same fp64 ops)
+    // ---- network rows i0..i0+rows-1: one flat coalesced sweep; membership comes from the phase-1 bit masks
     const size_t base = ((size_t)b * N + i0) * N;
     const size_t baseA = (size_t)b * o.sAb + (size_t)i0 * N;
     int ri = tid / N, j = tid - ri * N;                     // (row, col) of flat index tid
     const int dri = FL_THREADS / N, dj = FL_THREADS - dri * N;
+    const float inv_jh = 1.0f / (float)jh;
     for (int idx = tid; idx < rows * N; idx += FL_THREADS) {
-        const int gi = i0 + ri;
-        const double dx = spx[gi] - spx[j], dy = spy[gi] - spy[j];
-        const double r2 = dx * dx + dy * dy;
-        const bool nb = (j != gi) && (r2 < R2);
+        const int piece = (int)(((float)j + 0.5f) * inv_jh);          // exact floor(j / jh) for j, jh < 2^20
+        const int off = j - piece * jh;
+        const unsigned long long wbits = adjw[((size_t)ri * FL_SPLIT + piece) * nch + (off >> 6)];
+        const bool nb = (wbits >> (off & 63)) & 1ull;
         const double w = nb ? wrow[ri] : 0.0;
         if (o.A != nullptr) o.A[baseA + idx] = (float)w;
         if (o.A64 != nullptr) o.A64[base + idx] = w;
@@ -207,38 +241,43 @@ int check_params(const MgpFlockParams* p)
     return MGP_OK;
 }
 
-int launch_flock(double* x, const float* u, long su_agent, long su_axis, const FlockOut& o,
+template <bool FUSE, int THREADS, int ROWS>
+int launch_step(const double* x, double* xo, const float* u, long su_agent, long su_axis, const FlockOut& o,
+                const MgpFlockParams* p, int B, int N, hipStream_t st)
+{
+    const int jh = (N + (THREADS / ROWS) - 1) / (THREADS / ROWS);
+    const size_t lds = ((size_t)4 * N + (THREADS / ROWS) * ROWS * 8 + ROWS + (size_t)ROWS * (THREADS / ROWS) * ((jh + 63) / 64)) *
+                       sizeof(double);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(flock_step_kernel<FUSE, THREADS, ROWS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return MGP_ELAUNCH;
+    dim3 grid(mgp_ceil_div(N, ROWS), B);
+    hipLaunchKernelGGL((flock_step_kernel<FUSE, THREADS, ROWS>), grid, dim3(THREADS), lds, st, x, xo, u, su_agent,
+                       su_axis, o, *p, N);
+    return mgp_launch_status();
+}
+
+int launch_flock(double* x, double* x_out, const float* u, long su_agent, long su_axis, const FlockOut& o,
                  const MgpFlockParams* p, int B, int N, hipStream_t st)
 {
     mgp_clear_error();
-    const bool fuse = N <= FL_ROWS;
-    int rc = MGP_OK;
-    if (!fuse && u != nullptr) {
+    if (x_out != nullptr && x_out != x && u != nullptr) {
+        // ping-pong: every workgroup integrates the episode redundantly from x and writes its rows of x_out
+        return launch_step<true, FP_THREADS, FP_ROWS>(x, x_out, u, su_agent, su_axis, o, p, B, N, st);
+    }
+    if (N <= FL_ROWS) return launch_step<true, FL_THREADS, FL_ROWS>(x, x, u, su_agent, su_axis, o, p, B, N, st);
+    if (u != nullptr) {
         hipLaunchKernelGGL(flock_integrate_kernel, dim3(B), dim3(FL_THREADS), 0, st, x, u, su_agent, su_axis, *p, N);
-        rc = mgp_launch_status();
+        const int rc = mgp_launch_status();
         if (rc != MGP_OK) return rc;
     }
-    const size_t lds = ((size_t)4 * N + FL_SPLIT * FL_ROWS * 8 + FL_ROWS) * sizeof(double);
-    dim3 grid(mgp_ceil_div(N, FL_ROWS), B);
-    if (fuse) {
-        if (lds > 48 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(flock_step_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return MGP_ELAUNCH;
-        hipLaunchKernelGGL((flock_step_kernel<true>), grid, dim3(FL_THREADS), lds, st, x, u, su_agent, su_axis, o, *p, N);
-    } else {
-        if (lds > 48 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(flock_step_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return MGP_ELAUNCH;
-        hipLaunchKernelGGL((flock_step_kernel<false>), grid, dim3(FL_THREADS), lds, st, x, u, su_agent, su_axis, o, *p, N);
-    }
-    return mgp_launch_status();
+    return launch_step<false, FP_THREADS, FP_ROWS>(x, x, u, su_agent, su_axis, o, p, B, N, st);
 }
 
 }  // namespace
 
-extern "C" int mgp_flock_step(double* x, const float* u, long su_agent, long su_axis,
+extern "C" int mgp_flock_step(double* x, double* x_out, const float* u, long su_agent, long su_axis,
                               float* A, double* A64, float* feat, double* feat64,
                               double* reward, float* expert, long sAb, long sFb,
                               const MgpFlockParams* p, int B, int N, void* stream)
@@ -249,9 +288,10 @@ extern "C" int mgp_flock_step(double* x, const float* u, long su_agent, long su_
     if (B == 0) return MGP_OK;
     if (B > 65535 || N > 4096) return MGP_EUNSUPPORTED;
     MGP_CHECK_PTR8(x);
+    if (x_out != nullptr && (reinterpret_cast<uintptr_t>(x_out) & 7u)) return MGP_EALIGN;
     if (sAb < 0 || sFb < 0) return MGP_EINVAL;
     FlockOut o = {A, A64, feat, feat64, reward, expert, nullptr, 0, sAb ? sAb : (long)N * N, sFb ? sFb : 6L * N};
-    return launch_flock(x, u, su_agent, su_axis, o, p, B, N, static_cast<hipStream_t>(stream));
+    return launch_flock(x, x_out, u, su_agent, su_axis, o, p, B, N, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int mgp_flock_controller(const double* x, float* u, double* u64, const MgpFlockParams* p,
@@ -266,5 +306,5 @@ extern "C" int mgp_flock_controller(const double* x, float* u, double* u64, cons
     if (u == nullptr && u64 == nullptr) return MGP_EINVAL;
     FlockOut o = {nullptr, nullptr, nullptr, nullptr, nullptr, u, u64, centralized ? 1 : 0, 0, 0};
     // no action => the state is only read
-    return launch_flock(const_cast<double*>(x), nullptr, 2, 1, o, p, B, N, static_cast<hipStream_t>(stream));
+    return launch_flock(const_cast<double*>(x), nullptr, nullptr, 2, 1, o, p, B, N, static_cast<hipStream_t>(stream));
 }

@@ -16,7 +16,7 @@ namespace {
 
 constexpr int GSO_THREADS = 256;
 constexpr int GSO_WAVES = GSO_THREADS / 64;
-constexpr int GSO_ROWS = 8;                 // rows of A per workgroup (2 per wave)
+constexpr int GSO_ROWS = 4;                 // rows of A per workgroup (1 per wave: shortest dependent chain)
 
 template <int V> struct F4 { };
 
@@ -141,6 +141,94 @@ void gso_rows_kernel(const float* __restrict__ A, const float* __restrict__ src,
     }
 }
 
+// ---- N <= 128, N % 4 == 0: a row needs only N/4 <= 32 float4 lanes, so each HALF-wave owns one output row (two
+// rows per wave in flight, half as many waves as gso_rows_kernel for the same work; same arithmetic and order).
+constexpr int GH_ROWS = 2 * GSO_WAVES;       // rows per workgroup
+
+__global__ __launch_bounds__(GSO_THREADS)
+void gso_rows_half_kernel(const float* __restrict__ A, const float* __restrict__ src, float* __restrict__ dst,
+                          long sAb, int mode, int B, int K, int N, int j_lo, int j_hi, int write_base, int has_prev,
+                          int nrt, int nslots, const float* __restrict__ X_t, const float* __restrict__ Xd_prev,
+                          float* __restrict__ Xd_next, int F)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = blockIdx.x / (8 * nslots), rem8 = blockIdx.x - grp * (8 * nslots);
+    const int slot = rem8 / 8, b = grp * 8 + (rem8 & 7);
+    if (b >= B) return;
+    if (slot >= nrt) {                                       // delay-line duty (same contract as gso_rows_kernel)
+        const int nb = nslots - nrt, bi = slot - nrt;
+        const long per = (long)K * F * N;
+        float* out = Xd_next + (long)b * per;
+        for (long i = (long)bi * GSO_THREADS + tid; i < per; i += (long)nb * GSO_THREADS) {
+            const long j = i / ((long)F * N);
+            float v;
+            if (j == 0) { if (mode == 1) continue; v = X_t[(long)b * F * N + i]; }
+            else v = has_prev ? Xd_prev[(long)b * per + i - (long)F * N] : 0.f;
+            out[i] = v;
+        }
+        return;
+    }
+    const int half = lane >> 5, hl = lane & 31;
+    int* idx = reinterpret_cast<int*>(smem) + (size_t)(wave * 2 + half) * 2 * N;   // per half-wave [N] indices
+    float* wgt = reinterpret_cast<float*>(idx + N);                                 // per half-wave [N] weights
+    const size_t NN = (size_t)N * N;
+    const float* Ab = A + (size_t)b * sAb;
+    const float* srcb = src ? src + (size_t)b * K * NN : nullptr;
+    float* dstb = dst + (size_t)b * K * NN;
+    const int i = slot * GH_ROWS + wave * 2 + half;
+    const bool valid = i < N;
+    const float* arow = Ab + (size_t)(valid ? i : 0) * N;
+    int cnt = 0;
+    for (int m0 = 0; m0 < N; m0 += 32) {
+        const int m = m0 + hl;
+        const float a = (valid && m < N) ? arow[m] : 0.f;
+        const bool nz = (a != 0.f);
+        const unsigned long long mask = __ballot(nz);
+        const unsigned hm = (unsigned)(mask >> (32 * half));
+        if (nz) {
+            const int pos = cnt + __popc(hm & ((1u << hl) - 1u));
+            idx[pos] = m;
+            wgt[pos] = a;
+        }
+        cnt += __popc(hm);
+        if (write_base && valid && m < N) {
+            dstb[(size_t)i * N + m] = (m == i) ? 1.f : 0.f;                     // slice 0 = I
+            if (K > 1) dstb[NN + (size_t)i * N + m] = has_prev ? a : 0.f;       // slice 1 = A (A @ I)
+        }
+    }
+    if (mode == 1 && !has_prev && K > 1 && valid) {          // episode start: slice 1 (the sim's A_t) is zeroed too
+        float* r1 = dstb + NN + (size_t)i * N;
+        for (int n = hl; n < N; n += 32) r1[n] = 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int n0 = hl * 4;
+    for (int j = max(j_lo, 2); j < j_hi; ++j) {
+        if (!valid) continue;
+        float* orow = dstb + (size_t)j * NN + (size_t)i * N;
+        if (!has_prev) {
+            if (write_base || mode == 1) for (int n = hl; n < N; n += 32) orow[n] = 0.f;
+            continue;
+        }
+        if (n0 >= N) continue;
+        const float* sj = srcb + (size_t)(j - 1) * NN + n0;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        int e = 0;
+        for (; e + 4 <= cnt; e += 4) {
+            const int m0_ = idx[e], m1_ = idx[e + 1], m2_ = idx[e + 2], m3_ = idx[e + 3];
+            const float w0 = wgt[e], w1 = wgt[e + 1], w2 = wgt[e + 2], w3 = wgt[e + 3];
+            row_axpy<4>(acc, w0, sj + (size_t)m0_ * N);
+            row_axpy<4>(acc, w1, sj + (size_t)m1_ * N);
+            row_axpy<4>(acc, w2, sj + (size_t)m2_ * N);
+            row_axpy<4>(acc, w3, sj + (size_t)m3_ * N);
+        }
+        for (; e < cnt; ++e) row_axpy<4>(acc, wgt[e], sj + (size_t)idx[e] * N);
+        *reinterpret_cast<float4*>(orow + n0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
 int launch_gso(const float* A, long sAb, int mode, const float* src, float* dst, int B, int K, int N, int j_lo, int j_hi,
                int write_base, int has_prev, const float* X_t, const float* Xd_prev, float* Xd_next, int F,
                hipStream_t st)
@@ -157,6 +245,14 @@ int launch_gso(const float* A, long sAb, int mode, const float* src, float* dst,
     const size_t lds = (size_t)GSO_WAVES * 2 * N * sizeof(float);
     if (lds > 150 * 1024) return MGP_EUNSUPPORTED;
     const bool vec = (N % 4 == 0) && mgp_aligned16(dst) && (src == nullptr || mgp_aligned16(src));
+    if (vec && N <= 128) {
+        const int nrt2 = mgp_ceil_div(N, GH_ROWS), ns2 = nrt2 + extra;
+        const size_t lds2 = (size_t)GH_ROWS * 2 * N * sizeof(float);
+        hipLaunchKernelGGL(gso_rows_half_kernel, dim3((unsigned)(((B + 7) / 8) * 8 * ns2)), dim3(GSO_THREADS), lds2, st,
+                           A, src, dst, sAb, mode, B, K, N, j_lo, j_hi, write_base, has_prev, nrt2, ns2, X_t, Xd_prev,
+                           Xd_next, F);
+        return mgp_launch_status();
+    }
     const int nslots = nrt + extra;
     dim3 grid((unsigned)(((B + 7) / 8) * 8 * nslots));
     if (vec) {

@@ -142,7 +142,8 @@ class VecFlock(object):
         N = params.n_agents
         self.N = N
         self._c = params.to_c()
-        self.x = torch.zeros((B, N, 4), device=self.device, dtype=torch.float64)
+        self.x = torch.zeros((B, N, 4), device=self.device, dtype=torch.float64)      # current state
+        self._x_next = torch.zeros_like(self.x)                                        # ping-pong partner
         self.network = torch.zeros((B, N, N), device=self.device, dtype=torch.float32)
         self.features = torch.zeros((B, 6, N), device=self.device, dtype=torch.float32)
         self.reward = torch.zeros((B,), device=self.device, dtype=torch.float64)
@@ -177,7 +178,10 @@ class VecFlock(object):
         if feat_out is not None:
             self.features = feat_out
         ops.flock_step(self.x, u, self._c, A=self.network, A64=self.network64, feat=self.features,
-                       feat64=self.features64, reward=self.reward, expert=self.expert if self.with_expert else None)
+                       feat64=self.features64, reward=self.reward, expert=self.expert if self.with_expert else None,
+                       x_out=self._x_next if u is not None else None)
+        if u is not None:
+            self.x, self._x_next = self._x_next, self.x          # ping-pong: several workgroups per episode
 
     def controller(self, centralized=False):
         """Expert action for the current state -> (B,N,2) fp32 (buffer reused)."""

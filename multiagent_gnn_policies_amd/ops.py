@@ -198,7 +198,7 @@ def gso_powers(A, K):
 
 
 # ------------------------------------------------------------------------------------ flocking sim
-def flock_step(x, u, params, A=None, A64=None, feat=None, feat64=None, reward=None, expert=None):
+def flock_step(x, u, params, A=None, A64=None, feat=None, feat64=None, reward=None, expert=None, x_out=None):
     """In-place sim step on x (B,N,4) fp64; any output may be None.  See include/mgp.h.
     u: (B,N,2) contiguous, or the Actor's output (B,1,2,N) contiguous (consumed without a transpose)."""
     _dev(x, 'x', torch.float64)
@@ -220,7 +220,10 @@ def flock_step(x, u, params, A=None, A64=None, feat=None, feat64=None, reward=No
     if feat is not None:
         assert feat.shape == (B, 6, N) and feat.stride(2) == 1 and feat.stride(1) == N
         sFb = feat.stride(0)
-    rc = _lib.lib().mgp_flock_step(_ptr(x), _ptr(u), su_agent, su_axis, _ptr(A), _ptr(A64), _ptr(feat), _ptr(feat64),
+    if x_out is not None:
+        _dev(x_out, 'x_out', torch.float64)
+        assert x_out.shape == x.shape and x_out.is_contiguous()
+    rc = _lib.lib().mgp_flock_step(_ptr(x), _ptr(x_out), _ptr(u), su_agent, su_axis, _ptr(A), _ptr(A64), _ptr(feat), _ptr(feat64),
                                    _ptr(reward), _ptr(expert), sAb, sFb, ctypes.byref(params), B, N, _stream())
     _lib.check(rc, 'mgp_flock_step')
 

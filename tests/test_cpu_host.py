@@ -56,7 +56,7 @@ def test_c_abi_argument_validation_without_gpu():
     assert L.mgp_agg_fwd(null, null, null, 0, 3, 6, 100, 0, 0, 0, 0, 0, 0, null) == 0       # empty batch
     assert L.mgp_dense_fwd(null, null, null, null, 1, 4, 4, 1, 8, 0, 0, 0, 7, null) == -1   # bad activation
     assert L.mgp_gso_update(null, null, null, null, null, null, 1, 3, 6, 0, 0, null) == -1
-    assert L.mgp_flock_step(null, null, 2, 1, null, null, null, null, null, null, 0, 0, None, 1, 10, null) == -1
+    assert L.mgp_flock_step(null, null, null, 2, 1, null, null, null, null, null, null, 0, 0, None, 1, 10, null) == -1
     assert L.mgp_gso_advance(null, null, null, null, 1, 3, 6, 10, 1, null) == -1
     assert L.mgp_adam_step(null, null, null, null, 10, 1e-3, 0.9, 0.999, 1e-8, 0, null) == -1
     assert L.mgp_dense_bwd_workspace(20, 18, 32, 1, 100) == 20 * 2 * (32 * 18 + 32)

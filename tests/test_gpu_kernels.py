@@ -251,3 +251,27 @@ def test_inplace_state_protocol_equals_classic_update(cfg):
     assert torch.equal(classic.delay_gso, inplace.delay_gso) and torch.equal(classic.delay_state, inplace.delay_state)
     if K > 1:
         assert float(inplace.delay_gso[:, 1:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('n', [100, 33, 200, 1000])
+def test_flock_pingpong_equals_inplace(n):
+    """x_out != x (several workgroups per episode, redundant integration) is bit-identical to the in-place form."""
+    from multiagent_gnn_policies_amd import ops
+    p = _flock_params(n, init_mode='grid')
+    B = 2
+    rs = np.random.RandomState(n)
+    xs = np.stack([ofl.reset(rs, p) for _ in range(B)])
+    us = dev(rs.uniform(-1.2, 1.2, size=(B, n, 2)).astype(np.float32))
+    cp = _c_params(p)
+    outs = []
+    for pingpong in (False, True):
+        x = dev(xs, torch.float64)
+        xo = torch.zeros_like(x) if pingpong else None
+        A = torch.empty((B, n, n), device='cuda'); feat = torch.empty((B, 6, n), device='cuda')
+        rew = torch.empty((B,), device='cuda', dtype=torch.float64); ex = torch.empty((B, n, 2), device='cuda')
+        ops.flock_step(x, us, cp, A=A, feat=feat, reward=rew, expert=ex, x_out=xo)
+        if pingpong:
+            assert np.array_equal(x.cpu().numpy(), xs)                    # the source state is left untouched
+        outs.append((xo if pingpong else x, A, feat, rew, ex))
+    for a, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a, b_)
