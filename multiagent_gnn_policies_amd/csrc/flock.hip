@@ -19,6 +19,14 @@
 
 namespace {
 
+// Optional in-kernel phase timestamps (tools/harness/flock_phase_prof.hip defines MGP_FL_PROFILE; never in the product).
+#ifdef MGP_FL_PROFILE
+__device__ unsigned long long mgp_fl_stamps[32];
+#define FL_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) mgp_fl_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FL_STAMP(i) do { } while (0)
+#endif
+
 constexpr int FL_THREADS = 1024;                // in-place mode: one workgroup of 1024 threads per 128 rows
 constexpr int FL_ROWS = 128;
 constexpr int FP_THREADS = 256;                 // ping-pong mode (x_out != x): 512 threads per 32 rows -> 4 workgroups per
@@ -42,6 +50,7 @@ __device__ __forceinline__ double block_sum(double v, double* sh /* [WAVES] */)
 struct FlockOut {
     float* A; double* A64; float* feat; double* feat64; double* reward;
     float* expert; double* expert64; int centralized;
+    int sep_reward;         // 1: an extra workgroup per episode computes the reward (illegal while integrating in place)
     long sAb, sFb;          // batch strides (elements) of A and feat: lets the sim write straight into delay_gso[:,1] / delay_state[:,0]
 };
 
@@ -94,12 +103,18 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
     double* wrow = part + FL_SPLIT * FL_ROWS * 8;                     // [FL_ROWS] network weight of the row (fp64)
     unsigned long long* adjw = reinterpret_cast<unsigned long long*>(wrow + FL_ROWS);   // [FL_ROWS][FL_SPLIT][nch]
     const int b = blockIdx.y, tid = threadIdx.x;
-    const int i0 = blockIdx.x * FL_ROWS;
-    const int rows = min(FL_ROWS, N - i0);
+    const int ntiles = (N + FL_ROWS - 1) / FL_ROWS;
+    // an extra workgroup (blockIdx.x == ntiles) only computes the episode's reward, so that no row workgroup has the
+    // three block reductions (3.7k cycles) on its critical path
+    const bool reward_wg = o.sep_reward && (int)blockIdx.x == ntiles;
+    const bool does_reward = o.reward != nullptr && (o.sep_reward ? reward_wg : blockIdx.x == 0);
+    const int i0 = reward_wg ? N : blockIdx.x * FL_ROWS;
+    const int rows = reward_wg ? 0 : min(FL_ROWS, N - i0);
     const double* xb = x + (size_t)b * N * 4;
     double* xob = xo + (size_t)b * N * 4;
     const bool all_rows = (xo == x);                       // in-place: this workgroup owns the whole episode's state
 
+    FL_STAMP(0);
     // ---- load (and, when fused, integrate) every agent of the episode into LDS
     double sum_vx = 0.0, sum_vy = 0.0;
     for (int i = tid; i < N; i += FL_THREADS) {
@@ -114,13 +129,14 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
         sum_vx += vx; sum_vy += vy;
     }
     __syncthreads();
+    FL_STAMP(1);
     // ---- episode-level sums (reward, centralised controller): every workgroup of the episode recomputes them
     double tot_vx = 0.0, tot_vy = 0.0;
     const bool need_cent = o.centralized && (o.expert != nullptr || o.expert64 != nullptr);
-    if ((o.reward != nullptr && blockIdx.x == 0) || need_cent) {      // workgroup-uniform condition
+    if (does_reward || need_cent) {                                 // workgroup-uniform condition
         tot_vx = block_sum<FL_WAVES>(sum_vx, sh);
         tot_vy = block_sum<FL_WAVES>(sum_vy, sh);
-        if (o.reward != nullptr && blockIdx.x == 0) {
+        if (does_reward) {
             const double mx = tot_vx / (double)N, my = tot_vy / (double)N;
             double dv = 0.0;
             for (int i = tid; i < N; i += FL_THREADS) {
@@ -131,6 +147,8 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
             if (tid == 0) o.reward[b] = -1.0 * var * p.reward_scale;
         }
     }
+    if (reward_wg) return;
+    FL_STAMP(2);
     // ---- pairwise pass: thread = (row, j-half)
     const int rl = tid % FL_ROWS, half = tid / FL_ROWS;
     const int i = i0 + rl;
@@ -145,10 +163,16 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
             // phase 1: cheap membership test for up to 64 j's -> bit mask (the only fp64 work every pair pays)
             const int ja = j0 + 64 * c, jb = min(j1, ja + 64);
             unsigned long long mask = 0ull;
-            for (int j = ja; j < jb; ++j) {
-                const double dx = xi - spx[j], dy = yi - spy[j];
-                const double r2 = dx * dx + dy * dy;
-                if (j != i && r2 < R2) mask |= 1ull << (j - ja);
+            for (int j = ja; j < jb; j += 4) {                 // explicit batches of 4: the LDS reads of a batch are
+                double ox[4], oy[4];                           // issued together instead of one dependent chain per j
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int jj = min(j + q, jb - 1); ox[q] = spx[jj]; oy[q] = spy[jj]; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double dx = xi - ox[q], dy = yi - oy[q];
+                    const double r2 = dx * dx + dy * dy;
+                    if (j + q < jb && j + q != i && r2 < R2) mask |= 1ull << (j + q - ja);
+                }
             }
             adjw[((size_t)rl * FL_SPLIT + half) * nch + c] = mask;
             // phase 2: the division and the six feature terms only for actual neighbours, ascending j.  A wave runs
@@ -170,6 +194,7 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
                 f5 += dy * q;
             }
         }
+        FL_STAMP(3);
         if (half > 0) {
             // value-major layout part[h][k][row]: consecutive lanes (rows) hit consecutive banks (the row-major
             // [row][8] layout was a 16-way bank conflict on every one of these stores and of the reads below)
@@ -212,25 +237,38 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
             }
         }
     }
+    FL_STAMP(4);
     if (o.A == nullptr && o.A64 == nullptr) return;
     __syncthreads();
+    FL_STAMP(5);
     // ---- network rows i0..i0+rows-1: one flat coalesced sweep; membership comes from the phase-1 bit masks
     const size_t base = ((size_t)b * N + i0) * N;
     const size_t baseA = (size_t)b * o.sAb + (size_t)i0 * N;
-    int ri = tid / N, j = tid - ri * N;                     // (row, col) of flat index tid
-    const int dri = FL_THREADS / N, dj = FL_THREADS - dri * N;
-    const float inv_jh = 1.0f / (float)jh;
-    for (int idx = tid; idx < rows * N; idx += FL_THREADS) {
-        const int piece = (int)(((float)j + 0.5f) * inv_jh);          // exact floor(j / jh) for j, jh < 2^20
-        const int off = j - piece * jh;
-        const unsigned long long wbits = adjw[((size_t)ri * FL_SPLIT + piece) * nch + (off >> 6)];
-        const bool nb = (wbits >> (off & 63)) & 1ull;
-        const double w = nb ? wrow[ri] : 0.0;
-        if (o.A != nullptr) o.A[baseA + idx] = (float)w;
-        if (o.A64 != nullptr) o.A64[base + idx] = w;
-        ri += dri; j += dj;
-        if (j >= N) { j -= N; ri += 1; }
+    const float inv_jh = 1.0f / (float)jh, inv_n = 1.0f / (float)N;
+    const int total = rows * N;
+    for (int idx0 = tid; idx0 < total; idx0 += 4 * FL_THREADS) {        // batches of 4 independent elements per thread
+        unsigned long long wb[4]; double wr[4]; int off[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = min(idx0 + q * FL_THREADS, total - 1);
+            const int ri = (int)(((float)idx + 0.5f) * inv_n);         // exact floor(idx / N) for idx < 2^20
+            const int j = idx - ri * N;
+            const int piece = (int)(((float)j + 0.5f) * inv_jh);       // exact floor(j / jh)
+            off[q] = j - piece * jh;
+            wb[q] = adjw[((size_t)ri * FL_SPLIT + piece) * nch + (off[q] >> 6)];
+            wr[q] = wrow[ri];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = idx0 + q * FL_THREADS;
+            if (idx < total) {
+                const double w = ((wb[q] >> (off[q] & 63)) & 1ull) ? wr[q] : 0.0;
+                if (o.A != nullptr) o.A[baseA + idx] = (float)w;
+                if (o.A64 != nullptr) o.A64[base + idx] = w;
+            }
+        }
     }
+    FL_STAMP(6);
 }
 
 int check_params(const MgpFlockParams* p)
@@ -252,7 +290,7 @@ int launch_step(const double* x, double* xo, const float* u, long su_agent, long
         hipFuncSetAttribute(reinterpret_cast<const void*>(flock_step_kernel<FUSE, THREADS, ROWS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return MGP_ELAUNCH;
-    dim3 grid(mgp_ceil_div(N, ROWS), B);
+    dim3 grid(mgp_ceil_div(N, ROWS) + (o.sep_reward ? 1 : 0), B);
     hipLaunchKernelGGL((flock_step_kernel<FUSE, THREADS, ROWS>), grid, dim3(THREADS), lds, st, x, xo, u, su_agent,
                        su_axis, o, *p, N);
     return mgp_launch_status();
@@ -262,17 +300,23 @@ int launch_flock(double* x, double* x_out, const float* u, long su_agent, long s
                  const MgpFlockParams* p, int B, int N, hipStream_t st)
 {
     mgp_clear_error();
+    FlockOut os = o;
     if (x_out != nullptr && x_out != x && u != nullptr) {
         // ping-pong: every workgroup integrates the episode redundantly from x and writes its rows of x_out
-        return launch_step<true, FP_THREADS, FP_ROWS>(x, x_out, u, su_agent, su_axis, o, p, B, N, st);
+        os.sep_reward = o.reward != nullptr;
+        return launch_step<true, FP_THREADS, FP_ROWS>(x, x_out, u, su_agent, su_axis, os, p, B, N, st);
     }
-    if (N <= FL_ROWS) return launch_step<true, FL_THREADS, FL_ROWS>(x, x, u, su_agent, su_axis, o, p, B, N, st);
+    if (N <= FL_ROWS) {
+        os.sep_reward = (o.reward != nullptr) && (u == nullptr);       // nothing is integrated: x is read-only
+        return launch_step<true, FL_THREADS, FL_ROWS>(x, x, u, su_agent, su_axis, os, p, B, N, st);
+    }
     if (u != nullptr) {
         hipLaunchKernelGGL(flock_integrate_kernel, dim3(B), dim3(FL_THREADS), 0, st, x, u, su_agent, su_axis, *p, N);
         const int rc = mgp_launch_status();
         if (rc != MGP_OK) return rc;
     }
-    return launch_step<false, FP_THREADS, FP_ROWS>(x, x, u, su_agent, su_axis, o, p, B, N, st);
+    os.sep_reward = o.reward != nullptr;                               // x was integrated by the kernel above
+    return launch_step<false, FP_THREADS, FP_ROWS>(x, x, u, su_agent, su_axis, os, p, B, N, st);
 }
 
 }  // namespace
@@ -290,7 +334,7 @@ extern "C" int mgp_flock_step(double* x, double* x_out, const float* u, long su_
     MGP_CHECK_PTR8(x);
     if (x_out != nullptr && (reinterpret_cast<uintptr_t>(x_out) & 7u)) return MGP_EALIGN;
     if (sAb < 0 || sFb < 0) return MGP_EINVAL;
-    FlockOut o = {A, A64, feat, feat64, reward, expert, nullptr, 0, sAb ? sAb : (long)N * N, sFb ? sFb : 6L * N};
+    FlockOut o = {A, A64, feat, feat64, reward, expert, nullptr, 0, 0, sAb ? sAb : (long)N * N, sFb ? sFb : 6L * N};
     return launch_flock(x, x_out, u, su_agent, su_axis, o, p, B, N, static_cast<hipStream_t>(stream));
 }
 
@@ -304,7 +348,7 @@ extern "C" int mgp_flock_controller(const double* x, float* u, double* u64, cons
     if (B > 65535 || N > 4096) return MGP_EUNSUPPORTED;
     MGP_CHECK_PTR8(x);
     if (u == nullptr && u64 == nullptr) return MGP_EINVAL;
-    FlockOut o = {nullptr, nullptr, nullptr, nullptr, nullptr, u, u64, centralized ? 1 : 0, 0, 0};
+    FlockOut o = {nullptr, nullptr, nullptr, nullptr, nullptr, u, u64, centralized ? 1 : 0, 0, 0, 0};
     // no action => the state is only read
     return launch_flock(const_cast<double*>(x), nullptr, nullptr, 2, 1, o, p, B, N, static_cast<hipStream_t>(stream));
 }
