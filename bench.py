@@ -74,9 +74,9 @@ class Rollout(object):
     def step(self):
         with torch.no_grad():
             out = self.actor(self.state.delay_state, self.state.delay_gso)      # (B,1,2,N)
-            A_dst, X_dst = self.state.next_slots()
-            self.sim.step(out, A_out=A_dst, feat_out=X_dst)     # action consumed as (B,1,2,N); A_t, X_t written in place
-            self.state.advance()                                 # G[:,j>=2] = A_t . G_prev[:,j-1], delay-line shift
+            # action consumed as (B,1,2,N); sim step + delayed-GSO / delay-line transition in one fused kernel when
+            # the shape allows it (N % 4 == 0, N <= 128), else mgp_flock_step + mgp_gso_advance
+            self.sim.step_advance(out, self.state)
 
 
 def time_kernel(fn, n_sets, iters):

@@ -182,6 +182,17 @@ int mgp_flock_step(double* x, double* x_out, const float* u, long su_agent, long
                    double* reward, float* expert, long sAb, long sFb,
                    const MgpFlockParams* p, int B, int N, void* stream);
 
+/* Simulator step AND state transition in one launch (device-resident rollouts): bit-for-bit equal to
+ *   mgp_flock_step(x, x_out, u, ..., A = G_next + N*N, sAb = K*N*N, feat = Xd_next, sFb = K*6*N, reward, expert, ...)
+ *   followed by mgp_gso_advance(G_prev, G_next, Xd_prev, Xd_next, ...),
+ * but the delayed-GSO product takes its neighbour lists from the simulator's membership bits instead of re-reading
+ * and compacting the dense network rows, and one kernel boundary disappears.  Covered: x_out != x, u != NULL,
+ * N % 4 == 0, N <= 128, K >= 2 (n_states = 6); otherwise MGP_EUNSUPPORTED (use the two calls above). */
+int mgp_flock_step_advance(double* x, double* x_out, const float* u, long su_agent, long su_axis,
+                           const float* G_prev, float* G_next, const float* Xd_prev, float* Xd_next,
+                           double* reward, float* expert, const MgpFlockParams* p,
+                           int B, int K, int N, int has_prev, void* stream);
+
 /* Expert controller on the current x: u (B,N,2) fp32 and/or u64 (B,N,2) fp64 (either may be NULL). */
 int mgp_flock_controller(const double* x, float* u, double* u64, const MgpFlockParams* p,
                          int centralized, int B, int N, void* stream);

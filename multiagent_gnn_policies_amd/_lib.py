@@ -49,6 +49,8 @@ SIGNATURES = {
     'mgp_gso_powers': (_int, [_vp, _vp, _int, _int, _int, _vp]),
     'mgp_flock_step': (_int, [_vp, _vp, _vp, _long, _long, _vp, _vp, _vp, _vp, _vp, _vp, _long, _long,
                              ctypes.POINTER(MgpFlockParams), _int, _int, _vp]),
+    'mgp_flock_step_advance': (_int, [_vp, _vp, _vp, _long, _long, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     ctypes.POINTER(MgpFlockParams), _int, _int, _int, _int, _vp]),
     'mgp_flock_controller': (_int, [_vp, _vp, _vp, ctypes.POINTER(MgpFlockParams), _int, _int, _int, _vp]),
     'mgp_mse_grad': (_int, [_vp, _vp, _vp, _vp, _long, _vp]),
     'mgp_adam_step': (_int, [_vp, _vp, _vp, _vp, _long, _f32, _f32, _f32, _f32, _int, _vp]),

@@ -30,7 +30,7 @@ __device__ unsigned long long mgp_fl_stamps[32];
 constexpr int FL_THREADS = 1024;                // in-place mode: one workgroup of 1024 threads per 128 rows
 constexpr int FL_ROWS = 128;
 constexpr int FP_THREADS = 256;                 // ping-pong mode (x_out != x): 512 threads per 32 rows -> 4 workgroups per
-constexpr int FP_ROWS = 32;                      // N = 100 episode, 16 threads per row, several workgroups per CU
+constexpr int FP_ROWS = 32; // N = 100 episode, 16 threads per row, several workgroups per CU
 
 __device__ __forceinline__ double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -52,6 +52,9 @@ struct FlockOut {
     float* expert; double* expert64; int centralized;
     int sep_reward;         // 1: an extra workgroup per episode computes the reward (illegal while integrating in place)
     long sAb, sFb;          // batch strides (elements) of A and feat: lets the sim write straight into delay_gso[:,1] / delay_state[:,0]
+    // fused state transition (mgp_flock_step_advance): A = Gn slice 1, feat = Xn tap 0, then
+    // Gn[b,j] = A_t . Gp[b,j-1] (j >= 2) from the membership bits, Xn[b,j] = Xp[b,j-1] (j >= 1)
+    int adv, K, has_prev; const float* Gp; float* Gn; const float* Xp; float* Xn;
 };
 
 // integrate one agent in registers (spec section 1)
@@ -106,7 +109,7 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
     const int ntiles = (N + FL_ROWS - 1) / FL_ROWS;
     // an extra workgroup (blockIdx.x == ntiles) only computes the episode's reward, so that no row workgroup has the
     // three block reductions (3.7k cycles) on its critical path
-    const bool reward_wg = o.sep_reward && (int)blockIdx.x == ntiles;
+    const bool reward_wg = (o.sep_reward || o.adv) && (int)blockIdx.x == ntiles;
     const bool does_reward = o.reward != nullptr && (o.sep_reward ? reward_wg : blockIdx.x == 0);
     const int i0 = reward_wg ? N : blockIdx.x * FL_ROWS;
     const int rows = reward_wg ? 0 : min(FL_ROWS, N - i0);
@@ -147,7 +150,15 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
             if (tid == 0) o.reward[b] = -1.0 * var * p.reward_scale;
         }
     }
-    if (reward_wg) return;
+    if (reward_wg) {
+        if (o.adv && o.K > 1) {                              // delay line: taps 1..K-1 <- previous taps 0..K-2
+            const long tap = 6L * N, per = (long)o.K * tap;
+            float* xn = o.Xn + (long)b * per;
+            const float* xp = o.Xp + (long)b * per;
+            for (long e = tap + tid; e < per; e += FL_THREADS) xn[e] = o.has_prev ? xp[e - tap] : 0.f;
+        }
+        return;
+    }
     FL_STAMP(2);
     // ---- pairwise pass: thread = (row, j-half)
     const int rl = tid % FL_ROWS, half = tid / FL_ROWS;
@@ -262,13 +273,77 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
         for (int q = 0; q < 4; ++q) {
             const int idx = idx0 + q * FL_THREADS;
             if (idx < total) {
-                const double w = ((wb[q] >> (off[q] & 63)) & 1ull) ? wr[q] : 0.0;
+                const double w = (((wb[q] >> (off[q] & 63)) & 1ull) && !(o.adv && !o.has_prev)) ? wr[q] : 0.0;
                 if (o.A != nullptr) o.A[baseA + idx] = (float)w;
                 if (o.A64 != nullptr) o.A64[base + idx] = w;
             }
         }
     }
     FL_STAMP(6);
+    if (!o.adv || o.K <= 2) return;
+    // ---- fused delayed-GSO product for this workgroup's rows: Gn[b,j,i,:] = sum_{p in N(i)} w_i * Gp[b,j-1,p,:], j >= 2.
+    //      Same arithmetic, order and weights as gso_rows_half_kernel (bit-identical), but the neighbour list comes from
+    //      the membership bits instead of re-reading and compacting the dense row of A.
+    {
+        constexpr int HW = FL_THREADS / 32;                       // half-waves in the workgroup
+        int* nlist = reinterpret_cast<int*>(adjw + (size_t)FL_ROWS * FL_SPLIT * nch);   // [HW][N]
+        const int lane = tid & 63, hw = tid >> 5, hl = lane & 31;
+        int* mylist = nlist + (size_t)hw * N;
+        const size_t NN = (size_t)N * N;
+        const int nwords = FL_SPLIT * nch, n4 = N / 4;
+        for (int r0 = hw; r0 < FL_ROWS; r0 += HW) {               // rows of this half-wave (uniform trip count)
+            const bool rvalid = r0 < rows;
+            const int gi = i0 + r0;
+            // neighbour list, ascending j: lane q < nwords expands word q after an exclusive popcount prefix
+            int cnt = 0, pre = 0;
+            unsigned long long mine = 0ull;
+            if (rvalid) {
+                for (int q = 0; q < nwords; ++q) {
+                    const unsigned long long wq = adjw[(size_t)r0 * nwords + q];
+                    const int pc = __popcll(wq);
+                    if (q < hl) pre += pc;
+                    if (q == hl) mine = wq;
+                    cnt += pc;
+                }
+                if (hl < nwords) {
+                    const int piece = hl / nch, c = hl - piece * nch;
+                    const int jbase = piece * jh + 64 * c;
+                    int pos = pre;
+                    while (mine) { mylist[pos++] = jbase + __builtin_ctzll(mine); mine &= mine - 1ull; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (rvalid && hl < n4) {
+                const float w = (float)wrow[r0];
+                for (int j = 2; j < o.K; ++j) {
+                    float* orow = o.Gn + (size_t)b * o.K * NN + (size_t)j * NN + (size_t)gi * N + hl * 4;
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (o.has_prev) {
+                        const float* sj = o.Gp + (size_t)b * o.K * NN + (size_t)(j - 1) * NN + hl * 4;
+                        int e = 0;
+                        for (; e + 4 <= cnt; e += 4) {
+                            const float4 g0 = *reinterpret_cast<const float4*>(sj + (size_t)mylist[e] * N);
+                            const float4 g1 = *reinterpret_cast<const float4*>(sj + (size_t)mylist[e + 1] * N);
+                            const float4 g2 = *reinterpret_cast<const float4*>(sj + (size_t)mylist[e + 2] * N);
+                            const float4 g3 = *reinterpret_cast<const float4*>(sj + (size_t)mylist[e + 3] * N);
+                            acc.x = fmaf(w, g0.x, acc.x); acc.y = fmaf(w, g0.y, acc.y); acc.z = fmaf(w, g0.z, acc.z); acc.w = fmaf(w, g0.w, acc.w);
+                            acc.x = fmaf(w, g1.x, acc.x); acc.y = fmaf(w, g1.y, acc.y); acc.z = fmaf(w, g1.z, acc.z); acc.w = fmaf(w, g1.w, acc.w);
+                            acc.x = fmaf(w, g2.x, acc.x); acc.y = fmaf(w, g2.y, acc.y); acc.z = fmaf(w, g2.z, acc.z); acc.w = fmaf(w, g2.w, acc.w);
+                            acc.x = fmaf(w, g3.x, acc.x); acc.y = fmaf(w, g3.y, acc.y); acc.z = fmaf(w, g3.z, acc.z); acc.w = fmaf(w, g3.w, acc.w);
+                        }
+                        for (; e < cnt; ++e) {
+                            const float4 g0 = *reinterpret_cast<const float4*>(sj + (size_t)mylist[e] * N);
+                            acc.x = fmaf(w, g0.x, acc.x); acc.y = fmaf(w, g0.y, acc.y); acc.z = fmaf(w, g0.z, acc.z); acc.w = fmaf(w, g0.w, acc.w);
+                        }
+                    }
+                    *reinterpret_cast<float4*>(orow) = acc;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                      // the list is rewritten for the next row
+        }
+    }
 }
 
 int check_params(const MgpFlockParams* p)
@@ -285,12 +360,12 @@ int launch_step(const double* x, double* xo, const float* u, long su_agent, long
 {
     const int jh = (N + (THREADS / ROWS) - 1) / (THREADS / ROWS);
     const size_t lds = ((size_t)4 * N + (THREADS / ROWS) * ROWS * 8 + ROWS + (size_t)ROWS * (THREADS / ROWS) * ((jh + 63) / 64)) *
-                       sizeof(double);
+                           sizeof(double) + (o.adv ? (size_t)(THREADS / 32) * N * sizeof(int) : 0);
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(flock_step_kernel<FUSE, THREADS, ROWS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return MGP_ELAUNCH;
-    dim3 grid(mgp_ceil_div(N, ROWS) + (o.sep_reward ? 1 : 0), B);
+    dim3 grid(mgp_ceil_div(N, ROWS) + ((o.sep_reward || o.adv) ? 1 : 0), B);
     hipLaunchKernelGGL((flock_step_kernel<FUSE, THREADS, ROWS>), grid, dim3(THREADS), lds, st, x, xo, u, su_agent,
                        su_axis, o, *p, N);
     return mgp_launch_status();
@@ -334,7 +409,8 @@ extern "C" int mgp_flock_step(double* x, double* x_out, const float* u, long su_
     MGP_CHECK_PTR8(x);
     if (x_out != nullptr && (reinterpret_cast<uintptr_t>(x_out) & 7u)) return MGP_EALIGN;
     if (sAb < 0 || sFb < 0) return MGP_EINVAL;
-    FlockOut o = {A, A64, feat, feat64, reward, expert, nullptr, 0, 0, sAb ? sAb : (long)N * N, sFb ? sFb : 6L * N};
+    FlockOut o = {A, A64, feat, feat64, reward, expert, nullptr, 0, 0, sAb ? sAb : (long)N * N, sFb ? sFb : 6L * N,
+                  0, 0, 0, nullptr, nullptr, nullptr, nullptr};
     return launch_flock(x, x_out, u, su_agent, su_axis, o, p, B, N, static_cast<hipStream_t>(stream));
 }
 
@@ -348,7 +424,39 @@ extern "C" int mgp_flock_controller(const double* x, float* u, double* u64, cons
     if (B > 65535 || N > 4096) return MGP_EUNSUPPORTED;
     MGP_CHECK_PTR8(x);
     if (u == nullptr && u64 == nullptr) return MGP_EINVAL;
-    FlockOut o = {nullptr, nullptr, nullptr, nullptr, nullptr, u, u64, centralized ? 1 : 0, 0, 0, 0};
+    FlockOut o = {nullptr, nullptr, nullptr, nullptr, nullptr, u, u64, centralized ? 1 : 0, 0, 0, 0,
+                  0, 0, 0, nullptr, nullptr, nullptr, nullptr};
     // no action => the state is only read
     return launch_flock(const_cast<double*>(x), nullptr, nullptr, 2, 1, o, p, B, N, static_cast<hipStream_t>(stream));
+}
+
+/* Simulator step + delayed-GSO / delay-line transition in ONE launch (device-resident rollouts).  Equivalent to
+ * mgp_flock_step(x, x_out, u, ..., A = G_next + N*N, sAb = K*N*N, feat = Xd_next, sFb = K*6*N, ...) followed by
+ * mgp_gso_advance(G_prev, G_next, Xd_prev, Xd_next, ...), bit-for-bit, without the second kernel's re-read and
+ * re-compaction of the dense network rows. */
+extern "C" int mgp_flock_step_advance(double* x, double* x_out, const float* u, long su_agent, long su_axis,
+                                      const float* G_prev, float* G_next, const float* Xd_prev, float* Xd_next,
+                                      double* reward, float* expert, const MgpFlockParams* p,
+                                      int B, int K, int N, int has_prev, void* stream)
+{
+    if (B < 0 || N <= 0 || K <= 0) return MGP_EINVAL;
+    int rc = check_params(p);
+    if (rc != MGP_OK) return rc;
+    if (B == 0) return MGP_OK;
+    if (B > 65535) return MGP_EINVAL;
+    // covered: ping-pong state, an action, N a multiple of 4 up to 128 (a row = <= 32 float4 lanes), K >= 2
+    if (N > 128 || (N & 3) || K < 2 || u == nullptr || x_out == nullptr || x_out == x) return MGP_EUNSUPPORTED;
+    MGP_CHECK_PTR8(x); MGP_CHECK_PTR8(x_out); MGP_CHECK_PTR(G_next); MGP_CHECK_PTR(Xd_next);
+    if (!mgp_aligned16(G_next)) return MGP_EUNSUPPORTED;
+    if (has_prev) {
+        MGP_CHECK_PTR(G_prev); MGP_CHECK_PTR(Xd_prev);
+        if (!mgp_aligned16(G_prev)) return MGP_EUNSUPPORTED;
+        if (G_prev == G_next || Xd_prev == Xd_next) return MGP_EINVAL;
+    }
+    const long NN = (long)N * N;
+    FlockOut o = {G_next + NN, nullptr, Xd_next, nullptr, reward, expert, nullptr, 0, reward != nullptr ? 1 : 0,
+                  (long)K * NN, (long)K * 6 * N, 1, K, has_prev ? 1 : 0, G_prev, G_next, Xd_prev, Xd_next};
+    mgp_clear_error();
+    return launch_step<true, FP_THREADS, FP_ROWS>(x, x_out, u, su_agent, su_axis, o, p, B, N,
+                                                  static_cast<hipStream_t>(stream));
 }

@@ -183,6 +183,25 @@ class VecFlock(object):
         if u is not None:
             self.x, self._x_next = self._x_next, self.x          # ping-pong: several workgroups per episode
 
+    def step_advance(self, u, state):
+        """sim step + `state` (BatchedDelayState) transition: ONE fused kernel when the shape allows it
+        (mgp_flock_step_advance), else the two-call in-place protocol.  Leaves `state` advanced."""
+        A_dst, X_dst = state.next_slots()
+        fused = (self.network64 is None and self.features64 is None and state.F == 6 and u is not None
+                 and u.is_contiguous() and state.K > 1)
+        if fused:
+            G_prev, G_next, Xd_prev, Xd_next = state.buffers()
+            fused = ops.flock_step_advance(self.x, self._x_next, u, self._c, G_prev, G_next, Xd_prev, Xd_next,
+                                           state.has_prev, reward=self.reward,
+                                           expert=self.expert if self.with_expert else None)
+        if fused:
+            self.x, self._x_next = self._x_next, self.x
+            self.network, self.features = A_dst, X_dst
+            state.flip()
+        else:
+            self.step(u, A_out=A_dst, feat_out=X_dst)
+            state.advance()
+
     def controller(self, centralized=False):
         """Expert action for the current state -> (B,N,2) fp32 (buffer reused)."""
         if self.with_expert and not centralized and self.expert64 is None:

@@ -90,6 +90,19 @@ class BatchedDelayState(object):
         A_dst = self._G[nxt][:, 1] if self.K > 1 else self._scratch_A
         return A_dst, self._X[nxt][:, 0]
 
+    def buffers(self):
+        """(G_prev, G_next, Xd_prev, Xd_next) for a fused sim+state kernel; call flip() after it ran."""
+        nxt = 1 - self._cur
+        return self._G[self._cur], self._G[nxt], self._X[self._cur], self._X[nxt]
+
+    @property
+    def has_prev(self):
+        return self._has_prev
+
+    def flip(self):
+        self._cur = 1 - self._cur
+        self._has_prev = True
+
     def advance(self):
         nxt = 1 - self._cur
         ops.gso_advance(self._G[self._cur], self._G[nxt], self._X[self._cur], self._X[nxt], has_prev=self._has_prev)

@@ -228,6 +228,21 @@ def flock_step(x, u, params, A=None, A64=None, feat=None, feat64=None, reward=No
     _lib.check(rc, 'mgp_flock_step')
 
 
+def flock_step_advance(x, x_out, u, params, G_prev, G_next, Xd_prev, Xd_next, has_prev, reward=None, expert=None):
+    """Fused simulator step + delayed-GSO/delay-line transition (one launch).  Returns False when the shape is not
+    covered by the fused kernel (the caller then uses flock_step + gso_advance)."""
+    B, N, _ = x.shape
+    K = G_next.shape[1]
+    su_agent, su_axis = (1, N) if (u.shape == (B, 1, 2, N) or u.shape == (B, 2, N)) else (2, 1)
+    rc = _lib.lib().mgp_flock_step_advance(_ptr(x), _ptr(x_out), _ptr(u), su_agent, su_axis, _ptr(G_prev), _ptr(G_next),
+                                           _ptr(Xd_prev), _ptr(Xd_next), _ptr(reward), _ptr(expert),
+                                           ctypes.byref(params), B, K, N, 1 if has_prev else 0, _stream())
+    if rc == -5:
+        return False
+    _lib.check(rc, 'mgp_flock_step_advance')
+    return True
+
+
 def flock_controller(x, params, centralized=False, u=None, u64=None):
     _dev(x, 'x', torch.float64)
     B, N, _ = x.shape

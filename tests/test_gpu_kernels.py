@@ -275,3 +275,36 @@ def test_flock_pingpong_equals_inplace(n):
         outs.append((xo if pingpong else x, A, feat, rew, ex))
     for a, b_ in zip(outs[0], outs[1]):
         assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize('cfg', [(3, 3, 100), (2, 4, 36), (2, 2, 16), (2, 3, 128)])
+def test_fused_sim_state_kernel_equals_two_kernel_protocol(cfg):
+    """mgp_flock_step_advance == mgp_flock_step (strided outputs) + mgp_gso_advance, bit for bit, incl. episode starts."""
+    from multiagent_gnn_policies_amd.envs import FlockParams, VecFlock
+    from multiagent_gnn_policies_amd.learner.state_with_delay import BatchedDelayState
+    B, K, N = cfg
+    p = FlockParams(n_agents=N, init_mode='grid')
+    x0 = np.stack([ofl.reset(np.random.RandomState(9 + b), ofl.FlockParams(n_agents=N, init_mode='grid')) for b in range(B)])
+    sims = [VecFlock(B, p, 'cuda', with_expert=True) for _ in range(2)]
+    states = [BatchedDelayState('cuda', B, K, 6, N) for _ in range(2)]
+    rs = np.random.RandomState(1)
+    for epi in range(2):
+        for s_, st in zip(sims, states):
+            s_.set_state(x0 + 0.01 * epi)
+            st.reset()
+            st.push(s_.network, s_.features)
+        for t in range(K + 2):
+            u = dev(rs.uniform(-1.1, 1.1, size=(B, 1, 2, N)).astype(np.float32))
+            A_dst, X_dst = states[0].next_slots()
+            sims[0].step(u, A_out=A_dst, feat_out=X_dst)
+            states[0].advance()
+            sims[1].step_advance(u, states[1])
+            assert torch.equal(sims[0].x, sims[1].x)
+            assert torch.equal(states[0].delay_gso, states[1].delay_gso)
+            assert torch.equal(states[0].delay_state, states[1].delay_state)
+            assert torch.equal(sims[0].reward, sims[1].reward) and torch.equal(sims[0].expert, sims[1].expert)
+    # episode start through the fused kernel: taps >= 1 read zero
+    st = BatchedDelayState('cuda', B, K, 6, N)
+    sims[1].step_advance(dev(np.zeros((B, 1, 2, N), np.float32)), st)
+    assert float(st.delay_gso[:, 1:].abs().max()) == 0.0 and float(st.delay_state[:, 1:].abs().max()) == 0.0
+    assert torch.equal(st.delay_gso[:, 0], torch.eye(N, device='cuda').expand(B, N, N))
