@@ -31,7 +31,7 @@ constexpr int AF_LDS_LIMIT = 150 * 1024;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Optional in-kernel phase timestamps (scratch/af_prof.hip defines MGP_AF_PROFILE; never in the product build).
+// Optional in-kernel phase timestamps (tools/harness/af_phase_prof.hip defines MGP_AF_PROFILE; never in the product).
 #ifdef MGP_AF_PROFILE
 __device__ unsigned long long mgp_af_stamps[64];
 #define AF_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) mgp_af_stamps[i] = __builtin_readcyclecounter(); } while (0)
@@ -52,8 +52,6 @@ __host__ __device__ inline int pad16(int x) { return (x + 15) & ~15; }
 // m-tiles (16 output rows each) a layer of `cout` rows is run with: 1, 2 or 4 (3 is padded to 4 to limit the
 // number of MLP code instances: this kernel is latency bound and instruction-cache misses show)
 __host__ __device__ inline int mtiles(int cout) { const int m = pad16(cout) / 16; return m == 3 ? 4 : m; }
-// LDS row stride of a padded weight block with `cin` input channels (odd => spread over banks)
-__host__ __device__ inline int wstride(int cin) { return pad4(cin) + 1; }
 
 template <int V> struct GLoad;
 template <> struct GLoad<4> {
@@ -114,10 +112,6 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a)
         const float4 bv = *reinterpret_cast<const float4*>(bias + mt * 16 + lq * 4);
         acc[mt][0] = bv.x; acc[mt][1] = bv.y; acc[mt][2] = bv.z; acc[mt][3] = bv.w;
     }
-#ifdef MGP_AF_MLP_STAMPS
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    AF_STAMP(40 + a.nt * 0 + (a.last ? 8 : 0));
-#endif
     // k-steps run in groups of four (one uniform branch per group instead of per step); the activation buffers are
     // zero-initialised and the weight fragments zero padded, so the surplus steps of a group add exact zeros
 #pragma unroll
@@ -130,10 +124,6 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a)
                     acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][s], fb[s], acc[mt], 0, 0, 0);
         }
     }
-#ifdef MGP_AF_MLP_STAMPS
-    asm volatile("" :: "v"(acc[0][0]));
-    AF_STAMP(41 + (a.last ? 8 : 0));
-#endif
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -143,18 +133,13 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a)
             if (a.last) {
                 if (c < a.cout && col < a.cols) a.out[((size_t)a.b * a.cout + c) * a.N + a.n0 + col] = v;
             } else {
-#ifndef MGP_AF_NO_TANH
                 v = tanh_fast(v);
-#endif
                 a.bout[col * AF_CS + rr * 16 + mt * 4 + lq] = v;   // == bpos(c)
                 if (a.saved != nullptr && c < a.cout && col < a.cols)
                     a.saved[a.soff + ((size_t)a.b * a.cout + c) * a.N + a.n0 + col] = v;
             }
         }
     }
-#ifdef MGP_AF_MLP_STAMPS
-    AF_STAMP(42 + (a.last ? 8 : 0));
-#endif
 }
 
 // LDS carve-up (floats).  `red` (aggregation partials) and the activation ping-pong buffers alias: the MLP
@@ -387,16 +372,10 @@ void actor_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G, 
     // ---- phase 2: per-agent MLP on fp32 MFMA.  Wave w owns the 16 agent columns of n-tile w through ALL layers
     //      (its activations never leave its own LDS columns), so there is no workgroup barrier between layers.
     const int NT = ncols16 / 16;
-#ifdef MGP_AF_MLP_STAMPS
-    if (wave == 0) { AF_STAMP(30); }
-#endif
     if (wave < NT) {
         float* bufA = ys;                                   // layer 0 input; reused as the odd layers' output
         float* bufB = smem + cv.un;                          // aliases `red` (dead after the barrier above)
         size_t soff = (size_t)B * FK * N;                    // running offset into `saved`
-#ifdef MGP_AF_MLP_TWICE
-        for (int rep = 0; rep < 2; ++rep)
-#endif
         for (int l = 0; l < P.n_layers; ++l) {
             const int cin = (l == 0) ? FK : P.dims[l];
             const int cout = P.dims[l + 1];
@@ -410,11 +389,7 @@ void actor_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G, 
             else if (MT == 2) mlp_layer<2>(ma);
             else mlp_layer<4>(ma);                        // MT == 3 runs as 4 (the extra m-tile is all zeros)
             soff += (size_t)B * cout * N;
-#ifdef MGP_AF_MLP_TWICE
-            AF_STAMP(6 + l + 8 * rep);
-#else
             AF_STAMP(6 + l);
-#endif
         }
     }
 }

@@ -211,6 +211,53 @@ class VecFlock(object):
 
 
 # ----------------------------------------------------------------------------------- gym-style facade
+class DeviceObservation(object):
+    """One half of the env's observation tuple that stays on the device until somebody asks for numpy.
+
+    Behaves like the fp64 numpy array the reference expects (`shape`, `dtype`, `np.asarray(obs)`, indexing,
+    `transpose`, arithmetic through `__array__`), but `MultiAgentStateWithDelay` recognises it and takes `.device32`
+    -- the fp32 tensor already on the GPU in the layout it needs -- so the per-step D2H of the 80 KB fp64 network
+    matrix and the H2D of its fp32 copy disappear from the reference-style B = 1 loop."""
+
+    def __init__(self, dev64, device32, zero_diagonal=False):
+        self._dev64 = dev64                  # (N,6) or (N,N) float64 device tensor (snapshot)
+        self.device32 = device32             # (6,N) features / (N,N) network, float32, device
+        self.zero_diagonal = zero_diagonal   # the simulator never sets self-loops (state_with_delay.py:26)
+        self._np = None
+
+    @property
+    def shape(self):
+        return tuple(self._dev64.shape)
+
+    @property
+    def dtype(self):
+        return np.dtype(np.float64)
+
+    @property
+    def ndim(self):
+        return self._dev64.dim()
+
+    def numpy(self):
+        if self._np is None:
+            self._np = self._dev64.cpu().numpy()
+        return self._np
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, idx):
+        return self.numpy()[idx]
+
+    def __getattr__(self, name):             # transpose / reshape / sum / ... : defer to the numpy view
+        if name.startswith('_'):
+            raise AttributeError(name)
+        return getattr(self.numpy(), name)
+
+
 class FlockingRelativeEnv(object):
     """Single-episode environment with the raw-env interface the reference reaches through `env.env`."""
 
@@ -223,6 +270,7 @@ class FlockingRelativeEnv(object):
         self._rng = np.random          # the reference seeds numpy's global RNG (train.py:27)
         self.n_features = 6
         self.nu = 2
+        self.lazy_obs = True           # observations stay on the device until numpy is requested
 
     # -- configuration -------------------------------------------------------------------------
     def params_from_cfg(self, args):
@@ -251,7 +299,11 @@ class FlockingRelativeEnv(object):
 
     def _obs(self):
         s = self._sim
-        return s.features64[0].cpu().numpy(), s.network64[0].cpu().numpy()
+        if not self.lazy_obs:
+            return s.features64[0].cpu().numpy(), s.network64[0].cpu().numpy()
+        # snapshots: the simulator's buffers are overwritten by the next step
+        return (DeviceObservation(s.features64[0].clone(), s.features[0].clone()),
+                DeviceObservation(s.network64[0].clone(), s.network[0].clone(), zero_diagonal=True))
 
     # -- gym API -------------------------------------------------------------------------------
     def reset(self):

@@ -25,17 +25,26 @@ class MultiAgentStateWithDelay(object):
         # contract of reference state_with_delay.py:24-26
         assert state_value.shape == (n_agents, n_states)
         assert state_network.shape == (n_agents, n_agents)
-        assert np.sum(np.diag(state_network)) == 0  # no self loops
+        on_device = hasattr(state_value, 'device32') and hasattr(state_network, 'device32')
+        if on_device:
+            assert state_network.zero_diagonal      # guaranteed by the simulator kernel (no self loops)
+        else:
+            assert np.sum(np.diag(state_network)) == 0  # no self loops
 
         device = torch.device(device)
         if device.type != 'cuda':
             raise ops.MgpError("MultiAgentStateWithDelay needs a HIP device (got %s); this package has no CPU "
                                "compute path" % device)
-        # fp64 -> fp32 on the host (what torch.Tensor(ndarray) does, state_with_delay.py:34-35), then H2D
-        v32 = np.ascontiguousarray(np.asarray(state_value).T, dtype=np.float32).reshape(1, 1, n_states, n_agents)
-        a32 = np.ascontiguousarray(np.asarray(state_network), dtype=np.float32).reshape(1, 1, n_agents, n_agents)
-        self.values = torch.from_numpy(v32).to(device)
-        self.network = torch.from_numpy(a32).to(device)
+        if on_device:
+            # observation produced by this package's simulator: the fp32 tensors are already on the GPU
+            self.values = state_value.device32.to(device).reshape(1, 1, n_states, n_agents)
+            self.network = state_network.device32.to(device).reshape(1, 1, n_agents, n_agents)
+        else:
+            # fp64 -> fp32 on the host (what torch.Tensor(ndarray) does, state_with_delay.py:34-35), then H2D
+            v32 = np.ascontiguousarray(np.asarray(state_value).T, dtype=np.float32).reshape(1, 1, n_states, n_agents)
+            a32 = np.ascontiguousarray(np.asarray(state_network), dtype=np.float32).reshape(1, 1, n_agents, n_agents)
+            self.values = torch.from_numpy(v32).to(device)
+            self.network = torch.from_numpy(a32).to(device)
         self._k = k
 
         has_prev = prev_state is not None and k > 1

@@ -31,11 +31,6 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-def _inner_contig(t, name):
-    if t.stride(-1) != 1 and t.shape[-1] != 1:
-        raise MgpError("%s must be contiguous along its last (agent) axis" % name)
-
-
 # ------------------------------------------------------------------------------------ aggregation
 def agg_fwd(T, G):
     """T (B,C,K,N) (any b/c/k strides, agent axis contiguous), G (B,K,N,N) -> (B,C,K,N) contiguous.

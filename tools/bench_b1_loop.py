@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Reference-style B=1 loop speed (BASELINE.json configs[0]): gym facade + MultiAgentStateWithDelay + select_action,
+exactly as train_dagger's test loop runs it, vs the torch-CPU port of the same loop."""
+import configparser, json, os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from multiagent_gnn_policies_amd import envs
+from multiagent_gnn_policies_amd.learner.gnn_dagger import DAGGER
+from multiagent_gnn_policies_amd.learner.rollouts import PolicyRunner, run_episode
+
+cp = configparser.ConfigParser()
+cp.read(os.path.join(ROOT, 'cfg', 'flocking_dagger_n100_k3.cfg'))
+args = cp['test']
+dev = torch.device('cuda:0')
+env = envs.make(args.get('env'), max_episode_steps=300)
+env.env.params_from_cfg(args)
+env.env.params = env.env.params.__class__(**{**env.env.params.__dict__, 'init_mode': 'grid'})
+env.seed(0)
+learner = DAGGER(dev, args)
+runner = PolicyRunner(learner, dev, args)
+run_episode(env, runner.act)
+runner.reset()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+run_episode(env, runner.act)
+torch.cuda.synchronize()
+el = time.perf_counter() - t0
+print(json.dumps({"loop": "gym facade B=1, N=100, K=3 (reference-style test loop)", "ms_per_env_step": 1e3 * el / 300,
+                  "agent_steps_per_s": 100 * 300 / el}))
