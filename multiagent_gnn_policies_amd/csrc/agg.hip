@@ -100,7 +100,7 @@ void agg_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G, fl
 
     float* Ybk = Y + b * syb + k * syk;
     if (R == 1) {
-        if (col_ok) {
+        if (active && col_ok) {          // threads past the last column group hold zero accumulators: must not store
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
                 if (c0 + c < C) {

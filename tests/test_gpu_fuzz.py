@@ -1,0 +1,88 @@
+"""GPU: randomised shapes.  Actor forward/backward (fused where covered, composed otherwise) and the state / sim kernels
+against the fp64 oracle on 120 / 40 random configurations -- odd N, N not a multiple of 4, F != 6, 0-4 hidden layers,
+every ind_agg, K 1-4."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import actor as oa, state as os_, dagger as od, flock as ofl, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
+
+
+def random_actor_case(rs):
+    B = int(rs.randint(1, 5)); K = int(rs.randint(1, 5)); F = int(rs.choice([1, 2, 3, 6, 6, 6, 8, 11]))
+    N = int(rs.choice([1, 3, 7, 16, 31, 64, 100, 100, 129, 180, 257]))
+    n_hidden = int(rs.randint(0, 5))
+    hidden = [int(rs.choice([1, 4, 5, 16, 32, 32, 48, 64, 96])) for _ in range(n_hidden)]
+    n_a = int(rs.choice([1, 2, 2, 3]))
+    ind_agg = int(rs.randint(0, n_hidden + 1))
+    return B, K, F, N, hidden, n_a, ind_agg
+
+
+@pytest.mark.parametrize('seed', range(120))
+def test_actor_random_configuration(seed):
+    from multiagent_gnn_policies_amd.learner import Actor
+    from multiagent_gnn_policies_amd import ops
+    rs = np.random.RandomState(1000 + seed)
+    B, K, F, N, hidden, n_a, ind_agg = random_actor_case(rs)
+    torch.manual_seed(seed)
+    actor = Actor(F, n_a, hidden, K, ind_agg).cuda()
+    X, G = (synth.make_dense_inputs if seed % 2 else synth.make_inputs)(seed, B, K, F, N)
+    Ws = [c.weight.detach().cpu().numpy() for c in actor.conv_layers]
+    bs = [c.bias.detach().cpu().numpy() for c in actor.conv_layers]
+    ref, cache = oa.forward(X, G, Ws, bs, ind_agg, dtype=np.float64, return_cache=True)
+    target = rs.randn(*ref.shape).astype(np.float32)
+    d_out = od.mse_grad(ref, target)
+    dWs, dbs, dX = oa.backward(d_out, G, Ws, ind_agg, cache, need_dx=True)
+    for fused in (True, False):
+        actor.use_fused = fused
+        actor.zero_grad()
+        xt = torch.from_numpy(X).cuda().requires_grad_(not fused)        # input grads force the composed path
+        out = actor(xt, torch.from_numpy(G).cuda())
+        assert out.shape == ref.shape
+        assert relerr(out.detach().cpu().numpy(), ref) <= 1e-5, (B, K, F, N, hidden, n_a, ind_agg, fused)
+        ops.mse_loss(out, torch.from_numpy(target).cuda()).backward()
+        for i, conv in enumerate(actor.conv_layers):
+            assert relerr(conv.weight.grad.cpu().numpy(), dWs[i]) <= 2e-5
+            assert relerr(conv.bias.grad.cpu().numpy(), dbs[i]) <= 2e-5
+        if not fused:
+            assert relerr(xt.grad.cpu().numpy(), dX) <= 2e-5
+
+
+@pytest.mark.parametrize('seed', range(40))
+def test_state_and_sim_random_sizes(seed):
+    from multiagent_gnn_policies_amd.envs import FlockParams, VecFlock
+    from multiagent_gnn_policies_amd.learner.state_with_delay import BatchedDelayState
+    rs = np.random.RandomState(2000 + seed)
+    B = int(rs.randint(1, 4)); K = int(rs.randint(1, 5)); N = int(rs.choice([5, 12, 17, 36, 50, 100, 128, 130, 200]))
+    op = ofl.FlockParams(n_agents=N, init_mode='grid', comm_radius=float(rs.choice([0.8, 1.0, 1.5])),
+                         mean_pooling=bool(rs.randint(0, 2)), n_leaders=int(rs.randint(0, 3)))
+    p = FlockParams(**{f: getattr(op, f) for f in FlockParams.__dataclass_fields__})
+    xs = np.stack([ofl.sample_candidate_grid(rs, op) for _ in range(B)])
+    sim = VecFlock(B, p, 'cuda', with_expert=True)
+    sim.set_state(xs)
+    st = BatchedDelayState('cuda', B, K, 6, N)
+    st.push(sim.network, sim.features)
+    h = [ofl.helpers(xs[b], op) for b in range(B)]
+    Gp, Xp = os_.gso_update(np.stack([q['network'] for q in h]).astype(np.float32), None,
+                            np.stack([q['values'].T for q in h]).astype(np.float32), None, K, dtype=np.float64)
+    for t in range(K + 1):
+        u = rs.uniform(-1.2, 1.2, size=(B, N, 2)).astype(np.float32)
+        sim.step_advance(torch.from_numpy(u).cuda(), st)
+        xs = np.stack([ofl.integrate(xs[b], u[b], op) for b in range(B)])
+        assert np.array_equal(sim.x.cpu().numpy(), xs)
+        h = [ofl.helpers(xs[b], op) for b in range(B)]
+        A = np.stack([q['network'] for q in h]).astype(np.float32)
+        Xt = np.stack([q['values'].T for q in h]).astype(np.float32)
+        Gp, Xp = os_.gso_update(A.astype(np.float64), Gp, Xt, Xp, K, dtype=np.float64)
+        assert relerr(st.delay_gso.cpu().numpy(), Gp) <= 1e-5
+        assert relerr(st.delay_state.cpu().numpy(), Xp) <= 1e-6
+        for b in range(B):
+            assert relerr(sim.expert[b].cpu().numpy(), ofl.controller(xs[b], op)) <= 1e-6
+            assert abs(sim.reward[b].item() - ofl.reward(xs[b], op)) <= 1e-12 * max(1.0, abs(ofl.reward(xs[b], op)))

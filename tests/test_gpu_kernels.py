@@ -22,7 +22,8 @@ def relerr(a, b):
 
 AGG_SHAPES = [(1, 3, 6, 100), (4, 3, 6, 100), (2, 4, 6, 200), (2, 2, 6, 16), (2, 1, 6, 16), (3, 2, 3, 7),
               (2, 3, 6, 33), (1, 3, 6, 260), (1, 2, 6, 1000), (2, 3, 32, 100), (1, 2, 40, 36), (2, 3, 1, 64),
-              (1, 2, 12, 257), (1, 1, 6, 513), (2, 2, 8, 128), (1, 3, 16, 48)]
+              (1, 2, 12, 257), (1, 1, 6, 513), (2, 2, 8, 128), (1, 3, 16, 48),
+              (2, 2, 6, 129), (2, 2, 6, 130), (1, 3, 6, 255), (1, 2, 3, 201)]     # V = 1, one row phase (fuzz-found bug)
 
 
 @pytest.mark.parametrize('shape', AGG_SHAPES)
