@@ -29,8 +29,11 @@ __device__ unsigned long long mgp_fl_stamps[32];
 
 constexpr int FL_THREADS = 1024;                // in-place mode: one workgroup of 1024 threads per 128 rows
 constexpr int FL_ROWS = 128;
-constexpr int FP_THREADS = 256;                 // ping-pong mode (x_out != x): 512 threads per 32 rows -> 4 workgroups per
-constexpr int FP_ROWS = 32; // N = 100 episode, 16 threads per row, several workgroups per CU
+constexpr int FP_THREADS = 256;                 // ping-pong mode (x_out != x): 256 threads per 32 rows -> 4 workgroups per
+constexpr int FP_ROWS = 32;
+constexpr int FP_PIECES = 8;                    // 8 j-pieces per row for the pairwise phases (256 threads); a wider
+                                                // workgroup adds half-waves for the fused delayed-GSO rows
+// N = 100 episode, 16 threads per row, several workgroups per CU
 
 __device__ __forceinline__ double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -90,12 +93,13 @@ void flock_integrate_kernel(double* __restrict__ x, const float* __restrict__ u,
 // FUSE_INTEGRATE: the workgroup integrates the whole episode into LDS itself.  In-place mode (xo == x) that is only
 // legal with ONE workgroup per episode; ping-pong mode (xo != x) lets every workgroup of the episode do it redundantly
 // (reads x, writes only its own rows of xo), which is what allows small row tiles and many workgroups per episode.
-template <bool FUSE_INTEGRATE, int THREADS, int ROWS>
+template <bool FUSE_INTEGRATE, int THREADS, int ROWS, int PIECES>
 __global__ __launch_bounds__(THREADS)
 void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, const float* __restrict__ u,
                        long su_agent, long su_axis, FlockOut o, MgpFlockParams p, int N)
 {
-    constexpr int FL_SPLIT = THREADS / ROWS;
+    constexpr int FL_SPLIT = PIECES;                       // pairwise threads = ROWS * PIECES (<= THREADS); the rest of
+                                                           // the workgroup only helps with loads, the row sweep and the gso rows
     constexpr int FL_WAVES = THREADS / 64;
     constexpr int FL_ROWS = ROWS;
     constexpr int FL_THREADS = THREADS;
@@ -161,13 +165,14 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
     }
     FL_STAMP(2);
     // ---- pairwise pass: thread = (row, j-half)
-    const int rl = tid % FL_ROWS, half = tid / FL_ROWS;
+    const bool pair_active = tid < FL_ROWS * FL_SPLIT;
+    const int rl = tid % FL_ROWS, half = pair_active ? tid / FL_ROWS : 0;
     const int i = i0 + rl;
     const double R2 = p.comm_radius2;
     double deg = 0.0, f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0;
     const int jh = (N + FL_SPLIT - 1) / FL_SPLIT;          // j's per piece
     const int nch = (jh + 63) / 64;                        // 64-bit adjacency words per (row, piece)
-    if (rl < rows) {
+    if (pair_active && rl < rows) {
         const double xi = spx[i], yi = spy[i], vxi = svx[i], vyi = svy[i];
         const int j0 = half * jh, j1 = min(N, j0 + jh);
         for (int c = 0; c < nch; ++c) {
@@ -215,7 +220,7 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
         }
     }
     __syncthreads();
-    if (half == 0 && rl < rows) {
+    if (pair_active && half == 0 && rl < rows) {
 #pragma unroll 2      // NOT fully: 15 pieces x 7 doubles in flight cost 222 VGPRs and the second resident workgroup
         for (int h = 1; h < FL_SPLIT; ++h) {                 // ascending j pieces: deterministic
             const double* pr = part + (size_t)h * 8 * FL_ROWS + rl;
@@ -354,19 +359,19 @@ int check_params(const MgpFlockParams* p)
     return MGP_OK;
 }
 
-template <bool FUSE, int THREADS, int ROWS>
+template <bool FUSE, int THREADS, int ROWS, int PIECES>
 int launch_step(const double* x, double* xo, const float* u, long su_agent, long su_axis, const FlockOut& o,
                 const MgpFlockParams* p, int B, int N, hipStream_t st)
 {
-    const int jh = (N + (THREADS / ROWS) - 1) / (THREADS / ROWS);
-    const size_t lds = ((size_t)4 * N + (THREADS / ROWS) * ROWS * 8 + ROWS + (size_t)ROWS * (THREADS / ROWS) * ((jh + 63) / 64)) *
+    const int jh = (N + PIECES - 1) / PIECES;
+    const size_t lds = ((size_t)4 * N + PIECES * ROWS * 8 + ROWS + (size_t)ROWS * PIECES * ((jh + 63) / 64)) *
                            sizeof(double) + (o.adv ? (size_t)(THREADS / 32) * N * sizeof(int) : 0);
     if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(flock_step_kernel<FUSE, THREADS, ROWS>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(flock_step_kernel<FUSE, THREADS, ROWS, PIECES>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return MGP_ELAUNCH;
     dim3 grid(mgp_ceil_div(N, ROWS) + ((o.sep_reward || o.adv) ? 1 : 0), B);
-    hipLaunchKernelGGL((flock_step_kernel<FUSE, THREADS, ROWS>), grid, dim3(THREADS), lds, st, x, xo, u, su_agent,
+    hipLaunchKernelGGL((flock_step_kernel<FUSE, THREADS, ROWS, PIECES>), grid, dim3(THREADS), lds, st, x, xo, u, su_agent,
                        su_axis, o, *p, N);
     return mgp_launch_status();
 }
@@ -379,11 +384,11 @@ int launch_flock(double* x, double* x_out, const float* u, long su_agent, long s
     if (x_out != nullptr && x_out != x && u != nullptr) {
         // ping-pong: every workgroup integrates the episode redundantly from x and writes its rows of x_out
         os.sep_reward = o.reward != nullptr;
-        return launch_step<true, FP_THREADS, FP_ROWS>(x, x_out, u, su_agent, su_axis, os, p, B, N, st);
+        return launch_step<true, FP_THREADS, FP_ROWS, FP_PIECES>(x, x_out, u, su_agent, su_axis, os, p, B, N, st);
     }
     if (N <= FL_ROWS) {
         os.sep_reward = (o.reward != nullptr) && (u == nullptr);       // nothing is integrated: x is read-only
-        return launch_step<true, FL_THREADS, FL_ROWS>(x, x, u, su_agent, su_axis, os, p, B, N, st);
+        return launch_step<true, FL_THREADS, FL_ROWS, FL_THREADS / FL_ROWS>(x, x, u, su_agent, su_axis, os, p, B, N, st);
     }
     if (u != nullptr) {
         hipLaunchKernelGGL(flock_integrate_kernel, dim3(B), dim3(FL_THREADS), 0, st, x, u, su_agent, su_axis, *p, N);
@@ -391,7 +396,7 @@ int launch_flock(double* x, double* x_out, const float* u, long su_agent, long s
         if (rc != MGP_OK) return rc;
     }
     os.sep_reward = o.reward != nullptr;                               // x was integrated by the kernel above
-    return launch_step<false, FP_THREADS, FP_ROWS>(x, x, u, su_agent, su_axis, os, p, B, N, st);
+    return launch_step<false, FP_THREADS, FP_ROWS, FP_PIECES>(x, x, u, su_agent, su_axis, os, p, B, N, st);
 }
 
 }  // namespace
@@ -457,6 +462,6 @@ extern "C" int mgp_flock_step_advance(double* x, double* x_out, const float* u, 
     FlockOut o = {G_next + NN, nullptr, Xd_next, nullptr, reward, expert, nullptr, 0, reward != nullptr ? 1 : 0,
                   (long)K * NN, (long)K * 6 * N, 1, K, has_prev ? 1 : 0, G_prev, G_next, Xd_prev, Xd_next};
     mgp_clear_error();
-    return launch_step<true, FP_THREADS, FP_ROWS>(x, x_out, u, su_agent, su_axis, o, p, B, N,
+    return launch_step<true, FP_THREADS, FP_ROWS, FP_PIECES>(x, x_out, u, su_agent, su_axis, o, p, B, N,
                                                   static_cast<hipStream_t>(stream));
 }
