@@ -148,6 +148,22 @@ def kernel_rooflines(device, B, N, K, actor, flock_c):
     ms = time_kernel(lambda i: ops.flock_step(xs, u, flock_c, A=As[i], feat=feat, reward=rew), n_sets, iters)
     sim_bytes = (4 * N * N + 8 * 4 * N * 2 + 4 * (2 + 6) * N) * B
     res['flock_step'] = dict(ms=ms, bytes=sim_bytes, gbs=sim_bytes / ms / 1e6)
+    # --- fused sim step + delayed-GSO / delay-line transition (what the timed step actually launches):
+    #     writes A_t (N^2) and the products (K-2) N^2, gathers (K-2) N^2 of G_prev, features/labels/state are small
+    try:
+        from multiagent_gnn_policies_amd.envs import VecFlock
+        params = FlockParams(n_agents=N, init_mode='grid')
+        sim = VecFlock(B, params, device, with_expert=True)
+        sim.reset(np.random.RandomState(3))
+        states = [BatchedDelayState(device, B, K, F_FEAT, N) for _ in range(min(n_sets, 6))]
+        for st_ in states:
+            st_.push(sim.network, sim.features)
+            sim.step_advance(u.view(B, N, 2), st_)
+        ms = time_kernel(lambda i: sim.step_advance(u.view(B, N, 2), states[i % len(states)]), len(states), iters)
+        ss_bytes = (4 * N * N * (1 + 2 * max(K - 2, 0)) + 8 * 4 * N * 2 + 4 * (2 + 6 + 2) * N + 4 * 2 * (K - 1) * F_FEAT * N) * B
+        res['sim_state_step'] = dict(ms=ms, bytes=ss_bytes, gbs=ss_bytes / ms / 1e6)
+    except Exception as e:                               # shapes the fused kernel does not cover
+        res['sim_state_step'] = dict(ms=float('nan'), bytes=0, gbs=0.0, note=str(e))
     del Gs, Xs, As
     torch.cuda.empty_cache()
     return res, n_sets

@@ -124,21 +124,35 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a)
                     acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][s], fb[s], acc[mt], 0, 0, 0);
         }
     }
+    if (a.last) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int c = mt * 16 + lq * 4 + rr;               // output channel (rows >= cout carry exact zeros)
-            float v = acc[mt][rr];
-            if (a.last) {
-                if (c < a.cout && col < a.cols) a.out[((size_t)a.b * a.cout + c) * a.N + a.n0 + col] = v;
-            } else {
-                v = tanh_fast(v);
-                a.bout[col * AF_CS + rr * 16 + mt * 4 + lq] = v;   // == bpos(c)
-                if (a.saved != nullptr && c < a.cout && col < a.cols)
-                    a.saved[a.soff + ((size_t)a.b * a.cout + c) * a.N + a.n0 + col] = v;
+            for (int rr = 0; rr < 4; ++rr) {
+                const int c = mt * 16 + lq * 4 + rr;           // output channel (rows >= cout carry exact zeros)
+                if (c < a.cout && col < a.cols) a.out[((size_t)a.b * a.cout + c) * a.N + a.n0 + col] = acc[mt][rr];
             }
-        }
+        return;
+    }
+    // all tanh evaluations first, branch-free and independent (they pipeline), then the LDS stores, then -- training
+    // only -- the global copies for backward behind ONE uniform branch
+    float z[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) z[mt][rr] = tanh_fast(acc[mt][rr]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) a.bout[col * AF_CS + rr * 16 + mt * 4 + lq] = z[mt][rr];   // == bpos(c)
+    if (a.saved != nullptr && col < a.cols) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int c = mt * 16 + lq * 4 + rr;
+                if (c < a.cout) a.saved[a.soff + ((size_t)a.b * a.cout + c) * a.N + a.n0 + col] = z[mt][rr];
+            }
     }
 }
 
