@@ -257,6 +257,21 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
     if (o.A == nullptr && o.A64 == nullptr) return;
     __syncthreads();
     FL_STAMP(5);
+    // ---- fused state transition only: every row's ascending neighbour list, filled by all pairwise threads at once
+    //      (thread (row, piece) knows its own membership word; its write position is the popcount of the row's
+    //      earlier words).  rlist[row][N] ints live behind the membership words.
+    // (one byte per entry: the fused path covers N <= 128; 12.8 KB of int lists cost the sixth resident workgroup per CU)
+    unsigned char* rlist = reinterpret_cast<unsigned char*>(adjw + (size_t)FL_ROWS * FL_SPLIT * nch);
+    if (o.adv && o.K > 2 && pair_active && rl < rows) {
+        const unsigned long long* wr_ = adjw + (size_t)rl * FL_SPLIT * nch;
+        int pos = 0;
+        for (int t = 0; t < half * nch; ++t) pos += __popcll(wr_[t]);
+        for (int c = 0; c < nch; ++c) {
+            unsigned long long m = wr_[half * nch + c];
+            const int jbase = half * jh + 64 * c;
+            while (m) { rlist[(size_t)rl * N + pos++] = (unsigned char)(jbase + __builtin_ctzll(m)); m &= m - 1ull; }
+        }
+    }
     // ---- network rows i0..i0+rows-1: one flat coalesced sweep; membership comes from the phase-1 bit masks
     const size_t base = ((size_t)b * N + i0) * N;
     const size_t baseA = (size_t)b * o.sAb + (size_t)i0 * N;
@@ -286,69 +301,51 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
     }
     FL_STAMP(6);
     if (!o.adv || o.K <= 2) return;
+    __syncthreads();                                              // neighbour lists complete
     // ---- fused delayed-GSO product for this workgroup's rows: Gn[b,j,i,:] = sum_{p in N(i)} w_i * Gp[b,j-1,p,:], j >= 2.
     //      Same arithmetic, order and weights as gso_rows_half_kernel (bit-identical), but the neighbour list comes from
-    //      the membership bits instead of re-reading and compacting the dense row of A.
+    //      the membership bits instead of re-reading and compacting the dense row of A.  One half-wave per row.
     {
         constexpr int HW = FL_THREADS / 32;                       // half-waves in the workgroup
-        int* nlist = reinterpret_cast<int*>(adjw + (size_t)FL_ROWS * FL_SPLIT * nch);   // [HW][N]
         const int lane = tid & 63, hw = tid >> 5, hl = lane & 31;
-        int* mylist = nlist + (size_t)hw * N;
         const size_t NN = (size_t)N * N;
         const int nwords = FL_SPLIT * nch, n4 = N / 4;
-        for (int r0 = hw; r0 < FL_ROWS; r0 += HW) {               // rows of this half-wave (uniform trip count)
-            const bool rvalid = r0 < rows;
+        for (int r0 = hw; r0 < rows; r0 += HW) {
+            if (hl >= n4) continue;
             const int gi = i0 + r0;
-            // neighbour list, ascending j: lane q < nwords expands word q after an exclusive popcount prefix
-            int cnt = 0, pre = 0;
-            unsigned long long mine = 0ull;
-            if (rvalid) {
-                for (int q = 0; q < nwords; ++q) {
-                    const unsigned long long wq = adjw[(size_t)r0 * nwords + q];
-                    const int pc = __popcll(wq);
-                    if (q < hl) pre += pc;
-                    if (q == hl) mine = wq;
-                    cnt += pc;
-                }
-                if (hl < nwords) {
-                    const int piece = hl / nch, c = hl - piece * nch;
-                    const int jbase = piece * jh + 64 * c;
-                    int pos = pre;
-                    while (mine) { mylist[pos++] = jbase + __builtin_ctzll(mine); mine &= mine - 1ull; }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (rvalid && hl < n4) {
-                const float w = (float)wrow[r0];
-                for (int j = 2; j < o.K; ++j) {
-                    float* orow = o.Gn + (size_t)b * o.K * NN + (size_t)j * NN + (size_t)gi * N + hl * 4;
-                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (o.has_prev) {
-                        const float* sj = o.Gp + (size_t)b * o.K * NN + (size_t)(j - 1) * NN + hl * 4;
-                        int e = 0;
-                        for (; e + 4 <= cnt; e += 4) {
-                            const float4 g0 = *reinterpret_cast<const float4*>(sj + (size_t)mylist[e] * N);
-                            const float4 g1 = *reinterpret_cast<const float4*>(sj + (size_t)mylist[e + 1] * N);
-                            const float4 g2 = *reinterpret_cast<const float4*>(sj + (size_t)mylist[e + 2] * N);
-                            const float4 g3 = *reinterpret_cast<const float4*>(sj + (size_t)mylist[e + 3] * N);
-                            acc.x = fmaf(w, g0.x, acc.x); acc.y = fmaf(w, g0.y, acc.y); acc.z = fmaf(w, g0.z, acc.z); acc.w = fmaf(w, g0.w, acc.w);
-                            acc.x = fmaf(w, g1.x, acc.x); acc.y = fmaf(w, g1.y, acc.y); acc.z = fmaf(w, g1.z, acc.z); acc.w = fmaf(w, g1.w, acc.w);
-                            acc.x = fmaf(w, g2.x, acc.x); acc.y = fmaf(w, g2.y, acc.y); acc.z = fmaf(w, g2.z, acc.z); acc.w = fmaf(w, g2.w, acc.w);
-                            acc.x = fmaf(w, g3.x, acc.x); acc.y = fmaf(w, g3.y, acc.y); acc.z = fmaf(w, g3.z, acc.z); acc.w = fmaf(w, g3.w, acc.w);
+            const unsigned char* mylist = rlist + (size_t)r0 * N;
+            int cnt = 0;
+            for (int t = 0; t < nwords; ++t) cnt += __popcll(adjw[(size_t)r0 * nwords + t]);
+            const float w = (float)wrow[r0];
+            for (int j = 2; j < o.K; ++j) {
+                float* orow = o.Gn + (size_t)b * o.K * NN + (size_t)j * NN + (size_t)gi * N + hl * 4;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (o.has_prev) {
+                    const float* sj = o.Gp + (size_t)b * o.K * NN + (size_t)(j - 1) * NN + hl * 4;
+                    // chunks of 8 source rows, all 8 loads issued before the first FMA (one L2 round trip per chunk,
+                    // typical degree <= 8); entries past the list end re-read row 0 with weight 0 (adds exact zeros)
+                    for (int e = 0; e < cnt; e += 8) {
+                        float4 g[8];
+                        float wv[8];
+#pragma unroll
+                        for (int d = 0; d < 8; ++d) {
+                            const bool ok = (e + d) < cnt;
+                            const int m = ok ? mylist[e + d] : 0;
+                            g[d] = *reinterpret_cast<const float4*>(sj + (size_t)m * N);
+                            wv[d] = ok ? w : 0.f;
                         }
-                        for (; e < cnt; ++e) {
-                            const float4 g0 = *reinterpret_cast<const float4*>(sj + (size_t)mylist[e] * N);
-                            acc.x = fmaf(w, g0.x, acc.x); acc.y = fmaf(w, g0.y, acc.y); acc.z = fmaf(w, g0.z, acc.z); acc.w = fmaf(w, g0.w, acc.w);
+#pragma unroll
+                        for (int d = 0; d < 8; ++d) {
+                            acc.x = fmaf(wv[d], g[d].x, acc.x); acc.y = fmaf(wv[d], g[d].y, acc.y);
+                            acc.z = fmaf(wv[d], g[d].z, acc.z); acc.w = fmaf(wv[d], g[d].w, acc.w);
                         }
                     }
-                    *reinterpret_cast<float4*>(orow) = acc;
                 }
+                *reinterpret_cast<float4*>(orow) = acc;
             }
-            __builtin_amdgcn_wave_barrier();                      // the list is rewritten for the next row
         }
     }
+    FL_STAMP(7);
 }
 
 int check_params(const MgpFlockParams* p)
@@ -365,7 +362,7 @@ int launch_step(const double* x, double* xo, const float* u, long su_agent, long
 {
     const int jh = (N + PIECES - 1) / PIECES;
     const size_t lds = ((size_t)4 * N + PIECES * ROWS * 8 + ROWS + (size_t)ROWS * PIECES * ((jh + 63) / 64)) *
-                           sizeof(double) + (o.adv ? (size_t)(THREADS / 32) * N * sizeof(int) : 0);
+                           sizeof(double) + (o.adv ? (((size_t)ROWS * N + 15) & ~(size_t)15) : 0);     // + one byte-indexed neighbour list per row
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(flock_step_kernel<FUSE, THREADS, ROWS, PIECES>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

@@ -31,9 +31,23 @@ int main(int argc, char** argv) {
     hipEventRecord(e1, nullptr); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("B=%d N=%d ping-pong sim step: %.2f us per launch\n", B, N, 1e3 * ms / IT);
+    {   // fused sim + delayed-GSO transition (K = 3)
+        const int K = 3; float *G0, *G1, *X0, *X1;
+        hipMalloc(&G0, (size_t)B * K * N * N * 4); hipMalloc(&G1, (size_t)B * K * N * N * 4);
+        hipMalloc(&X0, (size_t)B * K * 6 * N * 4); hipMalloc(&X1, (size_t)B * K * 6 * N * 4);
+        hipMemset(G0, 0, (size_t)B * K * N * N * 4); hipMemset(G1, 0, (size_t)B * K * N * N * 4);
+        hipMemset(X0, 0, (size_t)B * K * 6 * N * 4); hipMemset(X1, 0, (size_t)B * K * 6 * N * 4);
+        for (int it = 0; it < 4; ++it) { mgp_flock_step_advance(x, xo, u, 2, 1, G0, G1, X0, X1, rew, ex, &p, B, K, N, 1, nullptr); std::swap(x, xo); std::swap(G0, G1); std::swap(X0, X1); }
+        hipDeviceSynchronize();
+        hipEventRecord(e0, nullptr);
+        for (int it = 0; it < IT; ++it) { int rc = mgp_flock_step_advance(x, xo, u, 2, 1, G0, G1, X0, X1, rew, ex, &p, B, K, N, 1, nullptr); if (rc) { printf("rc %d\n", rc); return 1; } std::swap(x, xo); std::swap(G0, G1); std::swap(X0, X1); }
+        hipEventRecord(e1, nullptr); hipDeviceSynchronize();
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("B=%d N=%d fused sim + state step (K=3): %.2f us per launch\n", B, N, 1e3 * ms / IT);
+    }
     unsigned long long st[32];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(mgp_fl_stamps), sizeof(st));
-    const char* names[] = {"start", "x/u loaded + integrated (barrier)", "reward sums done (wg 0)", "pairwise phases done", "partials combined, features/expert written", "barrier before sweep", "network rows written"};
-    for (int i = 0; i < 7; ++i) printf("  stamp %d : %8llu  %s\n", i, st[i] - st[0], names[i]);
+    const char* names[] = {"start", "x/u loaded + integrated (barrier)", "reward sums done (wg 0)", "pairwise phases done", "partials combined, features/expert written", "barrier before sweep", "network rows written", "delayed-GSO rows written"};
+    for (int i = 0; i < 8; ++i) printf("  stamp %d : %8llu  %s\n", i, st[i] - st[0], names[i]);
     return 0;
 }
