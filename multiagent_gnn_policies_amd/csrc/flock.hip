@@ -58,6 +58,7 @@ struct FlockOut {
     // fused state transition (mgp_flock_step_advance): A = Gn slice 1, feat = Xn tap 0, then
     // Gn[b,j] = A_t . Gp[b,j-1] (j >= 2) from the membership bits, Xn[b,j] = Xp[b,j-1] (j >= 1)
     int adv, K, has_prev; const float* Gp; float* Gn; const float* Xp; float* Xn;
+    int vecA;               // 1: fp32 network rows may be written with 16-byte stores (N % 4 == 0, aligned, no fp64 copy)
 };
 
 // integrate one agent in registers (spec section 1)
@@ -276,6 +277,37 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
     const size_t base = ((size_t)b * N + i0) * N;
     const size_t baseA = (size_t)b * o.sAb + (size_t)i0 * N;
     const float inv_jh = 1.0f / (float)jh, inv_n = 1.0f / (float)N;
+    if (o.vecA) {
+        // float4 form: thread -> (row, group of 4 columns); 4x fewer stores and index computations than the scalar sweep
+        const int n4 = N >> 2, total4 = rows * n4;
+        const float inv_n4 = 1.0f / (float)n4;
+        const bool zero_all = o.adv && !o.has_prev;
+        for (int idx0 = tid; idx0 < total4; idx0 += 4 * FL_THREADS) {
+            float4 outv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = min(idx0 + q * FL_THREADS, total4 - 1);
+                const int ri = (int)(((float)idx + 0.5f) * inv_n4);       // exact floor(idx / n4)
+                const int j0 = (idx - ri * n4) << 2;
+                const float w = zero_all ? 0.f : (float)wrow[ri];
+                float v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int j = j0 + c;
+                    const int piece = (int)(((float)j + 0.5f) * inv_jh);   // exact floor(j / jh)
+                    const int off = j - piece * jh;
+                    const unsigned long long wbits = adjw[((size_t)ri * FL_SPLIT + piece) * nch + (off >> 6)];
+                    v[c] = ((wbits >> (off & 63)) & 1ull) ? w : 0.f;
+                }
+                outv[q] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = idx0 + q * FL_THREADS;
+                if (idx < total4) *reinterpret_cast<float4*>(o.A + baseA + (size_t)idx * 4) = outv[q];
+            }
+        }
+    } else {
     const int total = rows * N;
     for (int idx0 = tid; idx0 < total; idx0 += 4 * FL_THREADS) {        // batches of 4 independent elements per thread
         unsigned long long wb[4]; double wr[4]; int off[4];
@@ -298,6 +330,7 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
                 if (o.A64 != nullptr) o.A64[base + idx] = w;
             }
         }
+    }
     }
     FL_STAMP(6);
     if (!o.adv || o.K <= 2) return;
@@ -368,8 +401,10 @@ int launch_step(const double* x, double* xo, const float* u, long su_agent, long
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return MGP_ELAUNCH;
     dim3 grid(mgp_ceil_div(N, ROWS) + ((o.sep_reward || o.adv) ? 1 : 0), B);
+    FlockOut ov = o;
+    ov.vecA = (o.A != nullptr && o.A64 == nullptr && (N & 3) == 0 && (o.sAb & 3) == 0 && mgp_aligned16(o.A)) ? 1 : 0;
     hipLaunchKernelGGL((flock_step_kernel<FUSE, THREADS, ROWS, PIECES>), grid, dim3(THREADS), lds, st, x, xo, u, su_agent,
-                       su_axis, o, *p, N);
+                       su_axis, ov, *p, N);
     return mgp_launch_status();
 }
 
@@ -412,7 +447,7 @@ extern "C" int mgp_flock_step(double* x, double* x_out, const float* u, long su_
     if (x_out != nullptr && (reinterpret_cast<uintptr_t>(x_out) & 7u)) return MGP_EALIGN;
     if (sAb < 0 || sFb < 0) return MGP_EINVAL;
     FlockOut o = {A, A64, feat, feat64, reward, expert, nullptr, 0, 0, sAb ? sAb : (long)N * N, sFb ? sFb : 6L * N,
-                  0, 0, 0, nullptr, nullptr, nullptr, nullptr};
+                  0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
     return launch_flock(x, x_out, u, su_agent, su_axis, o, p, B, N, static_cast<hipStream_t>(stream));
 }
 
@@ -427,7 +462,7 @@ extern "C" int mgp_flock_controller(const double* x, float* u, double* u64, cons
     MGP_CHECK_PTR8(x);
     if (u == nullptr && u64 == nullptr) return MGP_EINVAL;
     FlockOut o = {nullptr, nullptr, nullptr, nullptr, nullptr, u, u64, centralized ? 1 : 0, 0, 0, 0,
-                  0, 0, 0, nullptr, nullptr, nullptr, nullptr};
+                  0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
     // no action => the state is only read
     return launch_flock(const_cast<double*>(x), nullptr, nullptr, 2, 1, o, p, B, N, static_cast<hipStream_t>(stream));
 }
@@ -457,7 +492,7 @@ extern "C" int mgp_flock_step_advance(double* x, double* x_out, const float* u, 
     }
     const long NN = (long)N * N;
     FlockOut o = {G_next + NN, nullptr, Xd_next, nullptr, reward, expert, nullptr, 0, reward != nullptr ? 1 : 0,
-                  (long)K * NN, (long)K * 6 * N, 1, K, has_prev ? 1 : 0, G_prev, G_next, Xd_prev, Xd_next};
+                  (long)K * NN, (long)K * 6 * N, 1, K, has_prev ? 1 : 0, G_prev, G_next, Xd_prev, Xd_next, 0};
     mgp_clear_error();
     return launch_step<true, FP_THREADS, FP_ROWS, FP_PIECES>(x, x_out, u, su_agent, su_axis, o, p, B, N,
                                                   static_cast<hipStream_t>(stream));
