@@ -159,6 +159,9 @@ typedef struct MgpFlockParams {
     double reward_scale;
     int    mean_pooling;   /* network = adj / max(deg,1) if nonzero               */
     int    n_leaders;      /* first n_leaders agents ignore u                     */
+    int    centralized;    /* expert written by mgp_flock_step[_advance]: velocity term over ALL agents (the
+                            * global teacher DAGGER imitates) if nonzero, else over radius neighbours only */
+    int    reserved_;      /* keeps sizeof a multiple of 8                        */
 } MgpFlockParams;
 
 /* x_out (or x itself when x_out is NULL / == x) <- integrate(x, u), then observations of the new state.  With a
@@ -172,8 +175,9 @@ typedef struct MgpFlockParams {
  *   feat (B,6,N) fp32  features TRANSPOSED to the (F,N) layout state_with_delay.py:29 builds (may be NULL)
  *   feat64 (B,N,6) fp64 features in the env's own (N,6) layout (may be NULL; gym facade)
  *   reward (B) fp64    -(var vx + var vy) * reward_scale  (may be NULL)
- *   expert (B,N,2) fp32 decentralised expert action for the NEW state (may be NULL): a closed form of the
- *                      features, so the DAGGER label costs no second pairwise pass
+ *   expert (B,N,2) fp32 expert action for the NEW state (may be NULL; centralised or not per p->centralized): a
+ *                      closed form of the features (+ episode velocity sums), so the DAGGER label costs no second
+ *                      pairwise pass
  *   sAb / sFb          batch strides (elements) of A / feat; 0 = dense (N*N / 6*N).  With sAb = K*N*N and
  *                      A = delay_gso_next + N*N the simulator writes the network matrix straight into slice 1 of
  *                      the next delayed-GSO buffer (feat likewise into delay_state_next[:,0]): see mgp_gso_advance */

@@ -446,7 +446,8 @@ extern "C" int mgp_flock_step(double* x, double* x_out, const float* u, long su_
     MGP_CHECK_PTR8(x);
     if (x_out != nullptr && (reinterpret_cast<uintptr_t>(x_out) & 7u)) return MGP_EALIGN;
     if (sAb < 0 || sFb < 0) return MGP_EINVAL;
-    FlockOut o = {A, A64, feat, feat64, reward, expert, nullptr, 0, 0, sAb ? sAb : (long)N * N, sFb ? sFb : 6L * N,
+    FlockOut o = {A, A64, feat, feat64, reward, expert, nullptr, p->centralized ? 1 : 0, 0, sAb ? sAb : (long)N * N,
+                  sFb ? sFb : 6L * N,
                   0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
     return launch_flock(x, x_out, u, su_agent, su_axis, o, p, B, N, static_cast<hipStream_t>(stream));
 }
@@ -491,7 +492,8 @@ extern "C" int mgp_flock_step_advance(double* x, double* x_out, const float* u, 
         if (G_prev == G_next || Xd_prev == Xd_next) return MGP_EINVAL;
     }
     const long NN = (long)N * N;
-    FlockOut o = {G_next + NN, nullptr, Xd_next, nullptr, reward, expert, nullptr, 0, reward != nullptr ? 1 : 0,
+    FlockOut o = {G_next + NN, nullptr, Xd_next, nullptr, reward, expert, nullptr, p->centralized ? 1 : 0,
+                  reward != nullptr ? 1 : 0,
                   (long)K * NN, (long)K * 6 * N, 1, K, has_prev ? 1 : 0, G_prev, G_next, Xd_prev, Xd_next, 0};
     mgp_clear_error();
     return launch_step<true, FP_THREADS, FP_ROWS, FP_PIECES>(x, x_out, u, su_agent, su_axis, o, p, B, N,

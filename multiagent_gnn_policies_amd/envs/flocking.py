@@ -43,6 +43,7 @@ class FlockParams:
     init_mode: str = 'auto'
     grid_spacing: float = 0.6
     grid_jitter: float = 0.1
+    centralized: bool = True     # controller() default: velocity consensus over ALL agents (the DAGGER teacher)
 
     @property
     def comm_radius2(self):
@@ -54,7 +55,8 @@ class FlockParams:
 
     def to_c(self):
         return MgpFlockParams(self.comm_radius2, self.dt, self.action_gain, self.max_accel, self.ctrl_gain,
-                              self.ctrl_clip, self.reward_scale, 1 if self.mean_pooling else 0, self.n_leaders)
+                              self.ctrl_clip, self.reward_scale, 1 if self.mean_pooling else 0, self.n_leaders,
+                              1 if self.centralized else 0, 0)
 
 
 # ----------------------------------------------------------------------------------- reset sampling
@@ -164,13 +166,13 @@ class VecFlock(object):
         self.set_state(np.stack([sample_initial_state(rng, self.p) for _ in range(self.B)]))
 
     def refresh(self):
-        """Recompute observations (and the decentralised expert action) for the current x without integrating."""
+        """Recompute observations (and the expert action, `params.centralized`) for the current x, no integration."""
         ops.flock_step(self.x, None, self._c, A=self.network, A64=self.network64, feat=self.features,
                        feat64=self.features64, reward=self.reward, expert=self.expert if self.with_expert else None)
 
     def step(self, u, A_out=None, feat_out=None):
         """u (B,N,2) or the Actor output (B,1,2,N), fp32 on device.  Advances every episode one step in place;
-        with `with_expert` the decentralised expert action of the new state lands in `self.expert` for free.
+        with `with_expert` the expert action of the new state (`params.centralized`) lands in `self.expert` for free.
         A_out / feat_out: optional (possibly batch-strided) destinations for the network matrix and the features,
         e.g. BatchedDelayState.next_slots(); self.network / self.features then alias them."""
         if A_out is not None:
@@ -202,9 +204,11 @@ class VecFlock(object):
             self.step(u, A_out=A_dst, feat_out=X_dst)
             state.advance()
 
-    def controller(self, centralized=False):
-        """Expert action for the current state -> (B,N,2) fp32 (buffer reused)."""
-        if self.with_expert and not centralized and self.expert64 is None:
+    def controller(self, centralized=None):
+        """Expert action for the current state -> (B,N,2) fp32 (buffer reused).  None = `params.centralized`."""
+        if centralized is None:
+            centralized = self.p.centralized
+        if self.with_expert and bool(centralized) == bool(self.p.centralized) and self.expert64 is None:
             return self.expert                      # already produced by the last step()/refresh()
         ops.flock_controller(self.x, self._c, centralized=bool(centralized), u=self.expert, u64=self.expert64)
         return self.expert
@@ -320,8 +324,9 @@ class FlockingRelativeEnv(object):
         return self._obs(), float(s.reward[0].item()), False, {}
 
     def controller(self, centralized=None):
+        """None -> the env's own `centralized` attribute (True: DAGGER's teacher is the global controller)."""
         s = self._ensure()
-        s.controller(bool(centralized))
+        s.controller(self.params.centralized if centralized is None else bool(centralized))
         return s.expert64[0].cpu().numpy()
 
     def render(self, mode='human'):

@@ -43,6 +43,9 @@ class FlockParams:
     init_mode: str = 'auto'      # 'disc' (uniform in a disc, rejection), 'grid' (jittered lattice), 'auto' = disc if N <= 100
     grid_spacing: float = 0.6    # lattice pitch in units of comm_radius (grid mode)
     grid_jitter: float = 0.1     # uniform jitter amplitude in units of comm_radius (grid mode)
+    centralized: bool = True     # controller() default.  The reference's DAGGER calls controller() with no argument
+                                 # (gnn_dagger.py:156): the teacher is the GLOBAL controller the paper's decentralised
+                                 # policy imitates; the radius-limited variant alone does not flock at this density
 
     @property
     def comm_radius2(self):
@@ -116,7 +119,7 @@ def reward(x, p):
     return float(-1.0 * np.sum(np.var(v, axis=0)) * p.reward_scale)
 
 
-def controller(x, p, centralized=False):
+def controller(x, p, centralized=None):
     """Expert action (N,2), a closed form of the observation (FLOCK-SPEC v1 section 5):
         potential term   gx = 2*f2 - 2*f1 , gy = 2*f5 - 2*f4     (gradient of 1/r^2 + log r^2 over neighbours)
         velocity term    decentralised: f0, f3 (sum over neighbours of v_i - v_j)
@@ -125,6 +128,8 @@ def controller(x, p, centralized=False):
     x = np.asarray(x, dtype=np.float64)
     f = helpers(x, p)['values']
     n = x.shape[0]
+    if centralized is None:
+        centralized = p.centralized
     if centralized:
         vx = n * x[:, 2] - np.sum(x[:, 2])
         vy = n * x[:, 3] - np.sum(x[:, 3])

@@ -190,3 +190,32 @@ def test_shard_range_partitions_episodes():
         assert all(got[i][1] == got[i + 1][0] for i in range(w - 1))
         sizes = [hi - lo for lo, hi in got]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_spec_teacher_flocks_and_is_the_default():
+    """FLOCK-SPEC: controller() with no argument is the global teacher (reference gnn_dagger.py:156 calls it bare) and it
+    must actually flock: velocity variance collapses, which the radius-limited variant alone does not achieve."""
+    from oracle import flock as ofl
+    p = ofl.FlockParams(n_agents=40)
+    assert p.centralized
+    x = ofl.reset(np.random.RandomState(5), p)
+    assert np.array_equal(ofl.controller(x, p), ofl.controller(x, p, centralized=True))
+    first = last = None
+    for t in range(120):
+        x, _, _, r = ofl.step(x, ofl.controller(x, p), p)
+        first = r if first is None else first
+        last = r
+    assert last > 0.05 * first          # rewards are negative: |last| < 5 % of |first|
+
+
+def test_eval_model_refuses_to_run_without_a_gpu(tmp_path):
+    import configparser
+    import eval_model
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    cp = configparser.ConfigParser()
+    cp.read(os.path.join(ROOT, 'cfg', 'smoke.cfg'))
+    with pytest.raises(RuntimeError, match="MI355X"):
+        eval_model.evaluate_section(cp['dagger'], eval_model.DEFAULT_ACTOR)
+    assert os.path.exists(os.path.join(ROOT, eval_model.DEFAULT_ACTOR))

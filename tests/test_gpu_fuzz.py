@@ -62,7 +62,8 @@ def test_state_and_sim_random_sizes(seed):
     rs = np.random.RandomState(2000 + seed)
     B = int(rs.randint(1, 4)); K = int(rs.randint(1, 5)); N = int(rs.choice([5, 12, 17, 36, 50, 100, 128, 130, 200]))
     op = ofl.FlockParams(n_agents=N, init_mode='grid', comm_radius=float(rs.choice([0.8, 1.0, 1.5])),
-                         mean_pooling=bool(rs.randint(0, 2)), n_leaders=int(rs.randint(0, 3)))
+                         mean_pooling=bool(rs.randint(0, 2)), n_leaders=int(rs.randint(0, 3)),
+                         centralized=bool(rs.randint(0, 2)))
     p = FlockParams(**{f: getattr(op, f) for f in FlockParams.__dataclass_fields__})
     xs = np.stack([ofl.sample_candidate_grid(rs, op) for _ in range(B)])
     sim = VecFlock(B, p, 'cuda', with_expert=True)

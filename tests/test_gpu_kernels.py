@@ -151,7 +151,7 @@ def _c_params(p):
 
 
 @pytest.mark.parametrize('n', [100, 16, 33, 200, 1000])
-@pytest.mark.parametrize('variant', [{}, {'mean_pooling': False}, {'n_leaders': 3}])
+@pytest.mark.parametrize('variant', [{}, {'mean_pooling': False}, {'n_leaders': 3}, {'centralized': False}])
 def test_flock_step_and_controller(n, variant):
     from multiagent_gnn_policies_amd import ops
     p = _flock_params(n, **variant)
@@ -171,6 +171,8 @@ def test_flock_step_and_controller(n, variant):
         ops.flock_controller(x_d, cp, centralized=False, u=u_d, u64=u64_d)
         uc_d = torch.empty((B, n, 2), device='cuda', dtype=torch.float64)
         ops.flock_controller(x_d, cp, centralized=True, u64=uc_d)
+        ub_d = torch.empty((B, n, 2), device='cuda')
+        ops.flock_controller(x_d, cp, centralized=p.centralized, u=ub_d)
         for b in range(B):
             x2, vals, net, r = ofl.step(xs[b], us[b], p)
             assert np.array_equal(x_d[b].cpu().numpy(), x2), "integration must be bit-exact fp64"
@@ -183,7 +185,7 @@ def test_flock_step_and_controller(n, variant):
             uo = ofl.controller(x2, p, centralized=False)
             assert relerr(u64_d[b].cpu().numpy(), uo) <= 1e-11
             assert relerr(u_d[b].cpu().numpy(), uo) <= 1e-6
-            assert np.array_equal(ex_d[b].cpu().numpy(), u_d[b].cpu().numpy())     # by-product == dedicated call
+            assert np.array_equal(ex_d[b].cpu().numpy(), ub_d[b].cpu().numpy())    # by-product == dedicated call
             assert relerr(uc_d[b].cpu().numpy(), ofl.controller(x2, p, centralized=True)) <= 1e-11
             xs[b] = x2
         us = rs.uniform(-1.0, 1.0, size=(B, n, 2)).astype(np.float32)
