@@ -197,6 +197,25 @@ int mgp_flock_step_advance(double* x, double* x_out, const float* u, long su_age
                            double* reward, float* expert, const MgpFlockParams* p,
                            int B, int K, int N, int has_prev, void* stream);
 
+/* Episode-resident closed-loop rollout: T policy steps for B episodes in ONE launch (one workgroup per episode, the
+ * episode's state -- delayed operator slices 1..K-1, delay line, agent states, weights -- resident in LDS).
+ * Replaces T iterations of the reference's evaluation loop (test_model.py:38-44, gnn_dagger.py:194-203):
+ *     u = Actor(delay_state, delay_gso)                    actor.py:45-86, ind_agg = 0       (== mgp_actor_fwd)
+ *     x, reward = env.step(u) ; state = State(prev=state)  state_with_delay.py:44-53         (== mgp_flock_step_advance)
+ * In place: x (B,N,4) fp64, G (B,K,N,N), Xd (B,K,6,N) hold the state before the call and the state T steps later
+ * after it.  Slice 0 of G must be the identity (it is by construction; it is neither read nor written).
+ *   action  (B,1,2,N) fp32  the LAST step's policy output (may be NULL)
+ *   rewards (B,T)  fp64     reward of every step (may be NULL)
+ * The simulator arithmetic is the stand-alone kernels' (fp64, bit-exact integration/membership given the action); the
+ * aggregation sums in a different order than mgp_actor_fwd (same 1e-5 parity bound against the reference forward).
+ * Chunking is exact: T1 then T2 steps == T1 + T2 steps, bit for bit.  Coverage (mgp_rollout_supported): dims[0] = 6,
+ * dims[n_layers] = 2, layer widths <= 32, N % 4 == 0, N <= 128 and the state must fit the 160 KB LDS (N = 100: K <= 3);
+ * otherwise MGP_EUNSUPPORTED -- use the two calls above. */
+int mgp_rollout_supported(const int* dims, int n_layers, int K, int N);
+int mgp_rollout_steps(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
+                      const int* dims, int n_layers, float* action, double* rewards,
+                      const MgpFlockParams* p, int B, int K, int N, int T, void* stream);
+
 /* Expert controller on the current x: u (B,N,2) fp32 and/or u64 (B,N,2) fp64 (either may be NULL). */
 int mgp_flock_controller(const double* x, float* u, double* u64, const MgpFlockParams* p,
                          int centralized, int B, int N, void* stream);

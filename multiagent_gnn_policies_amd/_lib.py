@@ -52,6 +52,9 @@ SIGNATURES = {
                              ctypes.POINTER(MgpFlockParams), _int, _int, _vp]),
     'mgp_flock_step_advance': (_int, [_vp, _vp, _vp, _long, _long, _vp, _vp, _vp, _vp, _vp, _vp,
                                      ctypes.POINTER(MgpFlockParams), _int, _int, _int, _int, _vp]),
+    'mgp_rollout_supported': (_int, [_vp, _int, _int, _int]),
+    'mgp_rollout_steps': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, ctypes.POINTER(MgpFlockParams),
+                                _int, _int, _int, _int, _vp]),
     'mgp_flock_controller': (_int, [_vp, _vp, _vp, ctypes.POINTER(MgpFlockParams), _int, _int, _int, _vp]),
     'mgp_mse_grad': (_int, [_vp, _vp, _vp, _vp, _long, _vp]),
     'mgp_adam_step': (_int, [_vp, _vp, _vp, _vp, _long, _f32, _f32, _f32, _f32, _int, _vp]),

@@ -16,7 +16,7 @@
 //   Y and Z never touch HBM unless `saved` is requested (training).
 // Backward: one workgroup per 64-column tile walks the layers in LDS and emits per-tile parameter-gradient
 // partials; a second kernel adds the partials in tile order (deterministic).
-#include "mgp_common.h"
+#include "mgp_device.h"
 
 namespace {
 
@@ -26,10 +26,7 @@ constexpr int AF_WAVES = AF_THREADS / 64;
 constexpr int AF_TILE = 16 * AF_WAVES;    // max agent columns per workgroup: one 16-wide MFMA n-tile per wave
 constexpr int AF_U = 20;                  // G rows in flight per thread (one batch covers N = 100: 17 rows).
                                           // NB: 18 makes hipcc spill 332 B/lane; 20 allocates 240 VGPRs, no scratch
-constexpr int AF_MAXW = 64;               // max layer width covered by the fused kernel
 constexpr int AF_LDS_LIMIT = 150 * 1024;
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Optional in-kernel phase timestamps (tools/harness/af_phase_prof.hip defines MGP_AF_PROFILE; never in the product).
 #ifdef MGP_AF_PROFILE
@@ -47,11 +44,6 @@ struct ActorParams {
     int n_layers;
 };
 
-__host__ __device__ inline int pad4(int x) { return (x + 3) & ~3; }
-__host__ __device__ inline int pad16(int x) { return (x + 15) & ~15; }
-// m-tiles (16 output rows each) a layer of `cout` rows is run with: 1, 2 or 4 (3 is padded to 4 to limit the
-// number of MLP code instances: this kernel is latency bound and instruction-cache misses show)
-__host__ __device__ inline int mtiles(int cout) { const int m = pad16(cout) / 16; return m == 3 ? 4 : m; }
 
 template <int V> struct GLoad;
 template <> struct GLoad<4> {
@@ -64,24 +56,6 @@ template <> struct GLoad<1> {
     static __device__ __forceinline__ void ld(const float* p, float (&g)[1]) { g[0] = *p; }
 };
 
-constexpr int AF_CS = 68;                 // floats per agent column in the activation buffers (64 channels + pad:
-                                          // 68 = 4 mod 64 keeps a 16-lane ds_read_b128 group on disjoint banks)
-constexpr int AF_WFS = 20;                // floats per lane in a weight fragment block (16 k-steps + pad, same reason)
-
-// position of channel c inside an agent column of an activation buffer: MFMA B-fragment order, so that lane
-// (li, lq) of the wave finds its 16 k-step operands B[k = lq][j = li] contiguous (c = 4 s + lq  ->  lq*16 + s)
-__host__ __device__ inline int bpos(int c) { return (c & 3) * 16 + (c >> 2); }
-
-// tanh(x) = 1 - 2 / (1 + exp(2x)): five instructions (v_mul, v_exp_f32, v_add, v_rcp_f32, v_fma), no branches, so
-// the evaluations of a tile epilogue pipeline back to back -- the epilogue is instruction-latency bound at 2 waves
-// per SIMD (libm's branchy tanhf measured 3x longer).  exp overflow -> rcp(inf) = 0 -> 1; underflow -> -1.
-// ABSOLUTE error <= ~2e-7 everywhere (1-ulp v_exp/v_rcp on values in [0,2]); the relative error near 0 is larger,
-// which is irrelevant against the 1e-5 absolute parity budget (measured on the goldens: worst 6e-7).
-__device__ __forceinline__ float tanh_fast(float x)
-{
-    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);     // exp(2x) = 2^(2x log2 e)
-    return fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + e), 1.f);
-}
 
 struct MlpArgs {
     const float* bin; float* bout; const float* wfrag; float* out; float* saved; size_t soff;

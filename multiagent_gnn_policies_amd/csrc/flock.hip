@@ -15,7 +15,7 @@
 // workgroup writes its rows of the network matrix in one flat, coalesced sweep.  For N <= 128 the double
 // integrator and the velocity-variance reward are fused in front (one workgroup == one episode);
 // larger N runs flock_integrate first.
-#include "mgp_common.h"
+#include "mgp_device.h"
 
 namespace {
 
@@ -35,7 +35,6 @@ constexpr int FP_PIECES = 8;                    // 8 j-pieces per row for the pa
                                                 // workgroup adds half-waves for the fused delayed-GSO rows
 // N = 100 episode, 16 threads per row, several workgroups per CU
 
-__device__ __forceinline__ double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 template <int WAVES>
 __device__ __forceinline__ double block_sum(double v, double* sh /* [WAVES] */)
@@ -61,20 +60,6 @@ struct FlockOut {
     int vecA;               // 1: fp32 network rows may be written with 16-byte stores (N % 4 == 0, aligned, no fp64 copy)
 };
 
-// integrate one agent in registers (spec section 1)
-__device__ __forceinline__ void integrate_one(double& px, double& py, double& vx, double& vy, const float* ub,
-                                              long su_axis, bool leader, const MgpFlockParams& p)
-{
-    double ux = 0.0, uy = 0.0;
-    if (!leader) {
-        ux = clipd((double)ub[0], -p.max_accel, p.max_accel) * p.action_gain;
-        uy = clipd((double)ub[su_axis], -p.max_accel, p.max_accel) * p.action_gain;
-    }
-    px = (px + vx * p.dt) + ((ux * p.dt) * p.dt) * 0.5;
-    py = (py + vy * p.dt) + ((uy * p.dt) * p.dt) * 0.5;
-    vx = vx + ux * p.dt;
-    vy = vy + uy * p.dt;
-}
 
 // grid: x = b (N > 128 only)
 __global__ __launch_bounds__(FL_THREADS)

@@ -1,0 +1,48 @@
+// Device helpers shared by the fused kernels (actor_fused.hip, flock.hip, rollout.hip).
+#pragma once
+#include "mgp_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int pad4(int x) { return (x + 3) & ~3; }
+__host__ __device__ inline int pad16(int x) { return (x + 15) & ~15; }
+// m-tiles (16 output rows each) a layer of `cout` rows is run with: 1, 2 or 4 (3 is padded to 4 to limit the
+// number of MLP code instances: this kernel is latency bound and instruction-cache misses show)
+__host__ __device__ inline int mtiles(int cout) { const int m = pad16(cout) / 16; return m == 3 ? 4 : m; }
+
+constexpr int AF_MAXW = 64;               // max layer width covered by the fused kernels
+constexpr int AF_CS = 68;                 // floats per agent column in the activation buffers (64 channels + pad:
+                                          // 68 = 4 mod 64 keeps a 16-lane ds_read_b128 group on disjoint banks)
+constexpr int AF_WFS = 20;                // floats per lane in a weight fragment block (16 k-steps + pad, same reason)
+
+// position of channel c inside an agent column of an activation buffer: MFMA B-fragment order, so that lane
+// (li, lq) of the wave finds its 16 k-step operands B[k = lq][j = li] contiguous (c = 4 s + lq  ->  lq*16 + s)
+__host__ __device__ inline int bpos(int c) { return (c & 3) * 16 + (c >> 2); }
+
+// tanh(x) = 1 - 2 / (1 + exp(2x)): five instructions (v_mul, v_exp_f32, v_add, v_rcp_f32, v_fma), no branches, so
+// the evaluations of a tile epilogue pipeline back to back -- the epilogue is instruction-latency bound at 2 waves
+// per SIMD (libm's branchy tanhf measured 3x longer).  exp overflow -> rcp(inf) = 0 -> 1; underflow -> -1.
+// ABSOLUTE error <= ~2e-7 everywhere (1-ulp v_exp/v_rcp on values in [0,2]); the relative error near 0 is larger,
+// which is irrelevant against the 1e-5 absolute parity budget (measured on the goldens: worst 6e-7).
+__device__ __forceinline__ float tanh_fast(float x)
+{
+    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);     // exp(2x) = 2^(2x log2 e)
+    return fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + e), 1.f);
+}
+
+__device__ __forceinline__ double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// integrate one agent in registers (FLOCK-SPEC section 1; translation units using this are built -ffp-contract=off)
+__device__ __forceinline__ void integrate_one(double& px, double& py, double& vx, double& vy, const float* ub,
+                                              long su_axis, bool leader, const MgpFlockParams& p)
+{
+    double ux = 0.0, uy = 0.0;
+    if (!leader) {
+        ux = clipd((double)ub[0], -p.max_accel, p.max_accel) * p.action_gain;
+        uy = clipd((double)ub[su_axis], -p.max_accel, p.max_accel) * p.action_gain;
+    }
+    px = (px + vx * p.dt) + ((ux * p.dt) * p.dt) * 0.5;
+    py = (py + vy * p.dt) + ((uy * p.dt) * p.dt) * 0.5;
+    vx = vx + ux * p.dt;
+    vy = vy + uy * p.dt;
+}

@@ -47,3 +47,46 @@ def policy_episode_reward(env, learner, device, args):
     """One policy-only episode (the reference's test loop, gnn_dagger.py:194-203)."""
     runner = PolicyRunner(learner, device, args)
     return run_episode(env, runner.act)
+
+
+def _actor_params(actor):
+    ws, bs = [], []
+    for conv in actor.conv_layers:
+        ws.append(conv.weight.detach().view(conv.weight.shape[0], -1))
+        bs.append(conv.bias.detach())
+    return ws, bs
+
+
+def policy_rollout(actor, sim, state, T, rewards=None, action=None, resident=True):
+    """T closed-loop policy steps of every episode lane of `sim` (VecFlock) / `state` (BatchedDelayState): the batched
+    form of the reference's evaluation loop (test_model.py:38-44).  `rewards` (B,T) fp64 receives every step's reward.
+
+    When the shape is covered, the whole call is ONE launch of the episode-resident kernel (mgp_rollout_steps: state in
+    LDS for all T steps); otherwise -- or with resident=False -- each step is the two-launch path (fused Actor forward +
+    fused simulator/state kernel).  Either way sim.x, state.delay_gso, state.delay_state hold the state T steps later.
+    Returns True if the resident kernel ran."""
+    import torch
+    from .. import ops
+    assert state.has_prev, "push the reset observation into the delay state first"
+    if T <= 0:
+        return False
+    if (resident and actor.ind_agg == 0 and state.F == 6 and sim.network64 is None and sim.features64 is None
+            and ops.rollout_supported(tuple(actor.layers), state.K, sim.N)):
+        ws, bs = _actor_params(actor)
+        if ops.rollout_steps(sim.x, state.delay_gso, state.delay_state, ws, bs, tuple(actor.layers), sim._c, T,
+                             action=action, rewards=rewards):
+            if state.K > 1:
+                sim.network = state.delay_gso[:, 1]
+            sim.features = state.delay_state[:, 0]
+            if rewards is not None:
+                sim.reward.copy_(rewards[:, T - 1])
+            return True
+    with torch.no_grad():
+        for t in range(T):
+            out = actor(state.delay_state, state.delay_gso)
+            sim.step_advance(out, state)
+            if rewards is not None:
+                rewards[:, t].copy_(sim.reward)
+        if action is not None:
+            action.copy_(out)
+    return False

@@ -238,6 +238,37 @@ def flock_step_advance(x, x_out, u, params, G_prev, G_next, Xd_prev, Xd_next, ha
     return True
 
 
+def rollout_supported(dims, K, N):
+    cd = (ctypes.c_int * len(dims))(*dims)
+    return bool(_lib.lib().mgp_rollout_supported(cd, len(dims) - 1, K, N))
+
+
+def rollout_steps(x, G, Xd, weights, biases, dims, params, T, action=None, rewards=None):
+    """T closed-loop policy steps for every episode in ONE launch, state updated in place (mgp_rollout_steps).
+    x (B,N,4) f64 | G (B,K,N,N) | Xd (B,K,6,N) | weights[l] (out, in*step) / biases[l] fp32 | rewards (B,T) f64.
+    Returns False when the shape is outside the resident kernel's coverage (nothing was launched)."""
+    _dev(x, 'x', torch.float64); _dev(G, 'G'); _dev(Xd, 'Xd')
+    B, N, _ = x.shape
+    K = G.shape[1]
+    assert G.shape == (B, K, N, N) and Xd.shape == (B, K, 6, N) and G.is_contiguous() and Xd.is_contiguous()
+    assert x.is_contiguous()
+    if rewards is not None:
+        assert rewards.shape == (B, T) and rewards.dtype == torch.float64 and rewards.is_contiguous()
+    if action is not None:
+        assert action.shape == (B, 1, 2, N) and action.is_contiguous()
+    cd = (ctypes.c_int * len(dims))(*dims)
+    Ws = [w.contiguous() for w in weights]
+    bs = [b_.contiguous() for b_ in biases]
+    wa = (ctypes.c_void_p * len(Ws))(*[w.data_ptr() for w in Ws])
+    ba = (ctypes.c_void_p * len(bs))(*[b_.data_ptr() for b_ in bs])
+    rc = _lib.lib().mgp_rollout_steps(_ptr(x), _ptr(G), _ptr(Xd), wa, ba, cd, len(dims) - 1, _ptr(action), _ptr(rewards),
+                                      ctypes.byref(params), B, K, N, int(T), _stream())
+    if rc == -5:
+        return False
+    _lib.check(rc, 'mgp_rollout_steps')
+    return True
+
+
 def flock_controller(x, params, centralized=False, u=None, u64=None):
     _dev(x, 'x', torch.float64)
     B, N, _ = x.shape

@@ -1,0 +1,152 @@
+"""GPU: the episode-resident rollout kernel (mgp_rollout_steps) against the oracle, step by step, and against itself."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, golden_weights
+from oracle import actor as oa, flock as ofl, state as os_
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(1.0, float(np.max(np.abs(b)))))
+
+
+def _make(N, K, hidden, B, seed, **variant):
+    from multiagent_gnn_policies_amd.envs import FlockParams, VecFlock
+    from multiagent_gnn_policies_amd.learner.actor import Actor
+    from multiagent_gnn_policies_amd.learner.state_with_delay import BatchedDelayState
+    rs = np.random.RandomState(seed)
+    op = ofl.FlockParams(n_agents=N, init_mode='grid', **variant)
+    p = FlockParams(**{f: getattr(op, f) for f in FlockParams.__dataclass_fields__})
+    torch.manual_seed(seed)
+    actor = Actor(6, 2, list(hidden), K, 0).cuda()
+    if K == 3 and tuple(hidden) == (32, 32):
+        ws, bs = golden_weights(load_golden('ckpt_dagger_k3'), prefix='')
+        with torch.no_grad():
+            for conv, w, b_ in zip(actor.conv_layers, ws, bs):
+                conv.weight.copy_(torch.from_numpy(w)); conv.bias.copy_(torch.from_numpy(b_))
+    else:
+        with torch.no_grad():
+            for conv in actor.conv_layers:          # larger weights than default init: exercises tanh off the linear range
+                conv.weight.mul_(3.0)
+    xs = np.stack([ofl.sample_candidate_grid(rs, op) for _ in range(B)])
+    sim = VecFlock(B, p, 'cuda')
+    sim.set_state(xs)
+    st = BatchedDelayState('cuda', B, K, 6, N)
+    st.push(sim.network, sim.features)
+    return rs, op, actor, sim, st
+
+
+def _snapshot(sim, st):
+    return (sim.x.cpu().numpy().copy(), st.delay_gso.cpu().numpy().copy(), st.delay_state.cpu().numpy().copy())
+
+
+def _weights_np(actor):
+    Ws = [c.weight.detach().cpu().numpy() for c in actor.conv_layers]
+    bs = [c.bias.detach().cpu().numpy() for c in actor.conv_layers]
+    return Ws, bs
+
+
+CASES = [
+    # N, K, hidden, variant
+    (100, 3, (32, 32), {}),
+    (100, 3, (32, 32), {'mean_pooling': False, 'n_leaders': 2}),
+    (100, 2, (16,), {}),
+    (100, 1, (32, 32), {}),
+    (128, 2, (32, 32), {'comm_radius': 1.5}),
+    (36, 4, (8, 32, 16), {}),
+    (8, 3, (32,), {}),
+    (52, 3, (), {}),
+]
+
+
+@pytest.mark.parametrize('N,K,hidden,variant', CASES)
+def test_rollout_single_steps_match_oracle(N, K, hidden, variant):
+    """Every T = 1 launch is checked against the oracle transition of the state the launch started from."""
+    from multiagent_gnn_policies_amd import ops
+    from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
+    B = 3
+    rs, op, actor, sim, st = _make(N, K, hidden, B, seed=N + K, **variant)
+    assert ops.rollout_supported(tuple(actor.layers), K, N)
+    Ws, bs = _weights_np(actor)
+    action = torch.zeros((B, 1, 2, N), device='cuda')
+    rewards = torch.zeros((B, 1), device='cuda', dtype=torch.float64)
+    for step in range(K + 3):
+        x0, G0, X0 = _snapshot(sim, st)
+        assert policy_rollout(actor, sim, st, 1, rewards=rewards, action=action)
+        x1, G1, X1 = _snapshot(sim, st)
+        u = action.cpu().numpy()                                           # (B,1,2,N)
+        ref_u = oa.forward(X0, G0, Ws, bs, 0, dtype=np.float64)
+        assert relerr(u, ref_u) <= 1e-5, (step, relerr(u, ref_u))
+        for b in range(B):
+            ub = u[b, 0].T.astype(np.float32)                              # (N,2), the action the kernel applied
+            x_ref, vals, net, r = ofl.step(x0[b], ub, op)
+            assert np.array_equal(x1[b], x_ref), "integration must be bit-exact fp64 given the action"
+            if K > 1:
+                assert np.array_equal(G1[b, 1], net.astype(np.float32)), "network must be bit-exact"
+            assert np.array_equal(G1[b, 0], np.eye(N, dtype=np.float32))
+            assert relerr(X1[b, 0], vals.T.astype(np.float32)) <= 1e-6
+            Gr, Xr = os_.gso_update(net[None], G0[b:b + 1], vals.T[None].astype(np.float32), X0[b:b + 1], K,
+                                    dtype=np.float64)
+            assert relerr(G1[b], Gr[0]) <= 1e-6
+            assert np.array_equal(X1[b, 1:], X0[b, :-1])                   # delay line: pure shift
+            assert abs(rewards[b, 0].item() - r) <= 1e-12 * max(1.0, abs(r))
+
+
+@pytest.mark.parametrize('N,K,hidden,variant', CASES[:3] + CASES[5:6])
+def test_rollout_chunking_is_exact(N, K, hidden, variant):
+    """T steps in one launch == T launches of one step, bit for bit (state, last action, every reward)."""
+    from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
+    B, T = 4, 9
+    outs = []
+    for chunks in ([T], [1] * T, [4, 5]):
+        rs, op, actor, sim, st = _make(N, K, hidden, B, seed=7, **variant)
+        rewards = torch.zeros((B, T), device='cuda', dtype=torch.float64)
+        action = torch.zeros((B, 1, 2, N), device='cuda')
+        t0 = 0
+        for c in chunks:
+            rw = torch.zeros((B, c), device='cuda', dtype=torch.float64)
+            assert policy_rollout(actor, sim, st, c, rewards=rw, action=action)
+            rewards[:, t0:t0 + c] = rw
+            t0 += c
+        outs.append(_snapshot(sim, st) + (action.cpu().numpy().copy(), rewards.cpu().numpy().copy()))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)
+
+
+def test_rollout_agrees_with_two_launch_path():
+    """Same start, 8 steps: the resident kernel and the (actor kernel + sim/state kernel) path stay together.  The
+    aggregation orders differ, so actions agree to fp32 rounding only and the closed loop amplifies that (measured:
+    x 5e-7 after 8 steps, 8e-4 after 20) -- hence the short horizon here; exactness is covered by the two tests above."""
+    from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
+    B, T, N, K = 8, 8, 100, 3
+    res = []
+    for resident in (True, False):
+        rs, op, actor, sim, st = _make(N, K, (32, 32), B, seed=3)
+        rewards = torch.zeros((B, T), device='cuda', dtype=torch.float64)
+        action = torch.zeros((B, 1, 2, N), device='cuda')
+        assert policy_rollout(actor, sim, st, T, rewards=rewards, action=action, resident=resident) == resident
+        res.append(_snapshot(sim, st) + (action.cpu().numpy().copy(), rewards.cpu().numpy().copy()))
+    (xa, Ga, Xa, ua, ra), (xb, Gb, Xb, ub, rb) = res
+    assert relerr(xa, xb) <= 1e-5
+    assert relerr(ua, ub) <= 1e-4
+    assert relerr(ra, rb) <= 1e-6
+    assert np.mean(Ga[:, 1] != Gb[:, 1]) <= 1e-3                          # at most a stray threshold flip
+
+
+def test_rollout_unsupported_shapes_fall_back():
+    from multiagent_gnn_policies_amd import ops
+    assert not ops.rollout_supported((6, 64, 64, 2), 3, 100)      # 64-wide layers: not in the resident kernel
+    assert not ops.rollout_supported((6, 32, 32, 2), 4, 100)      # K = 4 at N = 100 does not fit the LDS
+    assert not ops.rollout_supported((6, 32, 32, 2), 3, 130)
+    assert not ops.rollout_supported((6, 32, 32, 3), 3, 100)      # the simulator takes 2-D actions
+    assert ops.rollout_supported((6, 32, 32, 2), 3, 100)
+    from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
+    rs, op, actor, sim, st = _make(100, 4, (32, 32), 2, seed=1)
+    rewards = torch.zeros((2, 3), device='cuda', dtype=torch.float64)
+    assert policy_rollout(actor, sim, st, 3, rewards=rewards) is False
+    assert torch.isfinite(rewards).all() and (rewards < 0).all()

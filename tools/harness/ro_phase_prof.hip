@@ -1,0 +1,55 @@
+// Standalone phase profiler for the episode-resident rollout kernel (cycle stamps of workgroup 0, thread 0, step 1).
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o ro_prof tools/harness/ro_phase_prof.hip && ./ro_prof 256 100 3 200
+#define MGP_RO_PROFILE 1
+#include "../../multiagent_gnn_policies_amd/csrc/rollout.hip"
+#include <cstdio>
+#include <vector>
+#include <cmath>
+thread_local int mgp_tls_hip_error = 0;
+int main(int argc, char** argv) {
+    int B = argc > 1 ? atoi(argv[1]) : 256, N = argc > 2 ? atoi(argv[2]) : 100, K = argc > 3 ? atoi(argv[3]) : 3;
+    int T = argc > 4 ? atoi(argv[4]) : 200;
+    std::vector<double> hx((size_t)B * N * 4);
+    for (int b = 0; b < B; ++b) for (int i = 0; i < N; ++i) {
+        int gx = i % 10, gy = i / 10;
+        hx[((size_t)b * N + i) * 4 + 0] = 0.6 * gx + 0.01 * ((i * 7 + b) % 13);
+        hx[((size_t)b * N + i) * 4 + 1] = 0.6 * gy + 0.01 * ((i * 5 + b) % 11);
+        hx[((size_t)b * N + i) * 4 + 2] = 0.1 * ((i * 3) % 17) - 0.8;
+        hx[((size_t)b * N + i) * 4 + 3] = 0.1 * ((i * 11) % 19) - 0.9;
+    }
+    const int dims[4] = {6, 32, 32, 2};
+    std::vector<float> hw[3], hb[3];
+    float *W[3], *bb[3];
+    for (int l = 0; l < 3; ++l) {
+        const int cin = l == 0 ? 6 * K : dims[l], cout = dims[l + 1];
+        hw[l].resize((size_t)cin * cout); hb[l].resize(cout);
+        for (size_t i = 0; i < hw[l].size(); ++i) hw[l][i] = 0.05f * (float)((int)((i * 37) % 23) - 11) / 11.f;
+        for (int i = 0; i < cout; ++i) hb[l][i] = 0.01f * i;
+        hipMalloc(&W[l], hw[l].size() * 4); hipMalloc(&bb[l], hb[l].size() * 4);
+        hipMemcpy(W[l], hw[l].data(), hw[l].size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(bb[l], hb[l].data(), hb[l].size() * 4, hipMemcpyHostToDevice);
+    }
+    double *x, *rew; float *G, *Xd, *act;
+    hipMalloc(&x, hx.size() * 8); hipMalloc(&rew, (size_t)B * T * 8);
+    hipMalloc(&G, (size_t)B * K * N * N * 4); hipMalloc(&Xd, (size_t)B * K * 6 * N * 4); hipMalloc(&act, (size_t)B * 2 * N * 4);
+    hipMemcpy(x, hx.data(), hx.size() * 8, hipMemcpyHostToDevice);
+    hipMemset(G, 0, (size_t)B * K * N * N * 4); hipMemset(Xd, 0, (size_t)B * K * 6 * N * 4);
+    MgpFlockParams p = {1.0, 0.01, 10.0, 1.0, 0.1, 10.0, 1.0, 1, 0, 1, 0};
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    int rc = mgp_rollout_steps(x, G, Xd, W, bb, dims, 3, act, rew, &p, B, K, N, T, nullptr);
+    if (rc) { printf("rc %d\n", rc); return 1; }
+    hipDeviceSynchronize();
+    const int IT = 5;
+    hipEventRecord(e0, nullptr);
+    for (int it = 0; it < IT; ++it) mgp_rollout_steps(x, G, Xd, W, bb, dims, 3, act, rew, &p, B, K, N, T, nullptr);
+    hipEventRecord(e1, nullptr); hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("B=%d N=%d K=%d T=%d resident rollout: %.1f us per launch, %.2f us per step -> %.3e agent-steps/s\n", B, N, K, T,
+           1e3 * ms / IT, 1e3 * ms / IT / T, (double)B * N * T / (1e-3 * ms / IT));
+    unsigned long long st[64];
+    hipMemcpyFromSymbol(st, HIP_SYMBOL(mgp_ro_stamps), sizeof(st));
+    const char* names[] = {"step start", "A aggregation from LDS done (barrier)", "B MFMA filter + MLP done (barrier)", "C integrated (barrier)",
+                           "D reward + pairwise + shuffles done (barrier)", "E operator transition done (barrier)"};
+    for (int i = 0; i < 6; ++i) printf("  stamp %d : %8llu  %s\n", i, st[i] - st[0], names[i]);
+    return 0;
+}
