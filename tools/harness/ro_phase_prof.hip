@@ -46,10 +46,19 @@ int main(int argc, char** argv) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("B=%d N=%d K=%d T=%d resident rollout: %.1f us per launch, %.2f us per step -> %.3e agent-steps/s\n", B, N, K, T,
            1e3 * ms / IT, 1e3 * ms / IT / T, (double)B * N * T / (1e-3 * ms / IT));
-    unsigned long long st[64];
+    unsigned long long st[256];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(mgp_ro_stamps), sizeof(st));
-    const char* names[] = {"step start", "A aggregation from LDS done (barrier)", "B MFMA filter + MLP done (barrier)", "C integrated (barrier)",
-                           "D reward + pairwise + shuffles done (barrier)", "E operator transition done (barrier)"};
-    for (int i = 0; i < 6; ++i) printf("  stamp %d : %8llu  %s\n", i, st[i] - st[0], names[i]);
+    const char* names[] = {"step start", "A done (barrier)", "B MFMA filter + MLP done (barrier)", "C integrated (barrier)",
+                           "D done (barrier)", "E done (barrier)", "A: role work done (before tap-0 copy)", "D: membership bits done",
+                           "D: neighbour feature terms done", "D: piece shuffles done", "D: lists written", "E: rows of slices >= 2 done", "B: layer 0 tile done (before barrier)", "B: layer 1 tile done", "B: layer 2 tile done"};
+    const int order[] = {0, 6, 1, 12, 13, 14, 2, 3, 7, 8, 4, 11, 5};
+    printf("cycles since step start, lane 0 of waves 0 / 3 / 7 / 9 / 12 / 15\n");
+    const int wv[] = {0, 3, 7, 9, 12, 15};
+    for (int oi = 0; oi < 13; ++oi) {
+        const int i = order[oi];
+        printf("  stamp %2d :", i);
+        for (int w = 0; w < 6; ++w) printf(" %7lld", (long long)(st[wv[w] * 16 + i] - st[0]));
+        printf("  %s\n", names[i]);
+    }
     return 0;
 }
