@@ -4,18 +4,27 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" advances EVERY episode of the batch by one environment step through the whole path
-    sim step (mgp_flock_step)  ->  delayed-GSO / delay-line update (mgp_gso_update)
-    ->  Actor forward (aggregation X.G + filter GEMM + tanh MLP)  ->  action fed back to the sim,
-all inputs resident in HBM, no host round trip (steps are replayed from a captured HIP graph).
+    Actor forward (aggregation X.G + filter GEMM + tanh MLP)  ->  action  ->  sim step
+    ->  delayed-GSO / delay-line update,
+all state resident on the GPU, no host round trip.  Two implementations of the same step are timed in the same run:
+  resident    mgp_rollout_steps: ALL timed steps in one launch of the episode-resident kernel (one workgroup per
+              episode, delayed operator / delay line / agent states / weights in LDS; HBM sees the state on entry
+              and exit).  This is `value` when the shape is covered (N <= 128, N % 4 == 0, widths <= 32, fits LDS).
+  two_launch  mgp_actor_fwd + mgp_flock_step_advance per step (dense operator streamed from HBM every step),
+              replayed from a captured HIP graph; reported next to it, and `value` for shapes the resident kernel
+              does not cover.
 Workload = BASELINE.json configs[1]: FlockingRelative-v0, N=100 agents, K=3 taps, 256 parallel episodes
 PER GPU (weak scaling: episodes are independent, ranks never communicate in the rollout).
 value = (episodes * agents * steps * ranks) / max-over-ranks wall time.
 
 Also reported on the same JSON line:
-  roofline      the graph-shift aggregation kernel (HBM-bound): algorithmic bytes (4KN^2 + 8KFN per
-                episode-step) / average launch duration measured with HIP events on the
-                launch stream, over rotating input sets larger than the 256 MiB Infinity Cache.
-  kernels       same measurement for the other kernels of the step.
+  roofline      the dominant kernel of the timed region.  Resident path: algorithmic bytes of the dense-contract
+                aggregation (4KN^2 + 8KFN per episode-step) x episode-steps per launch / launch duration
+                (HIP events over the timed region) -- an EQUIVALENT rate: the operator never leaves LDS, `traffic` is
+                what HBM really moved.  `dense_kernels` holds the HBM-roofline figures of the kernels that do stream
+                the dense operator from HBM (fused Actor forward, aggregation alone), measured live on rotating
+                input sets larger than the 256 MiB Infinity Cache.
+  kernels       same measurement for the other stand-alone kernels.
   cpu_baseline  the PyTorch-CPU port of the reference op sequence (oracle/torch_port.py, "kind": "port"),
                 reference-style B=1 loop, timed on this host for a bounded sample (rank 0, N=1 only).
 """
@@ -70,6 +79,7 @@ class Rollout(object):
         self.state = BatchedDelayState(device, B, K, F_FEAT, N)
         self.sim.reset(np.random.RandomState(seed))
         self.state.push(self.sim.network, self.sim.features)
+        self._rw = None
 
     def step(self):
         with torch.no_grad():
@@ -77,6 +87,20 @@ class Rollout(object):
             # action consumed as (B,1,2,N); sim step + delayed-GSO / delay-line transition in one fused kernel when
             # the shape allows it (N % 4 == 0, N <= 128), else mgp_flock_step + mgp_gso_advance
             self.sim.step_advance(out, self.state)
+
+    def resident_supported(self):
+        return ops.rollout_supported(tuple(self.actor.layers), self.K, self.N)
+
+    def run_resident(self, n_steps, chunk=2000):
+        """n_steps env steps on the episode-resident kernel (launches of <= chunk steps)."""
+        from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
+        done = 0
+        while done < n_steps:
+            t = min(chunk, n_steps - done)
+            if self._rw is None or self._rw.shape[1] != t:
+                self._rw = torch.zeros((self.B, t), device=self.sim.device, dtype=torch.float64)
+            assert policy_rollout(self.actor, self.sim, self.state, t, rewards=self._rw)
+            done += t
 
 
 def time_kernel(fn, n_sets, iters):
@@ -169,7 +193,7 @@ def kernel_rooflines(device, B, N, K, actor, flock_c):
     return res, n_sets
 
 
-def pmc_traffic(kernel, B, N, K):
+def pmc_traffic(kernel, B, N, K, steps_per_launch=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json,
     FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; tools/pmc_summary.py), or None when the profile was
     taken on other shapes or on a different build of the kernels."""
@@ -180,6 +204,8 @@ def pmc_traffic(kernel, B, N, K):
         from multiagent_gnn_policies_amd import build as mgp_build
         meta = d.get('_meta', {})
         if meta.get('shape') != [B, N, K] or meta.get('source_hash') != mgp_build.source_hash():
+            return None
+        if steps_per_launch is not None and meta.get('rollout_steps_per_launch') != steps_per_launch:
             return None
         return d[kernel]['total_bytes']
     except Exception:
@@ -240,6 +266,7 @@ def main():
     ap.add_argument('--graph-steps', type=int, default=10, help='env steps captured per HIP graph (0 = eager)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-resident', action='store_true', help='time only the two-launch dense path')
     args = ap.parse_args()
 
     rank, world, local = parallel.init_from_env()
@@ -285,18 +312,34 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    run(args.warmup)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.steps)
-    torch.cuda.synchronize()
-    barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        el = float(t.item())
+    def timed(fn):
+        fn(args.warmup)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(args.steps)
+        torch.cuda.synchronize()
+        barrier()
+        el_ = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el_], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el_ = float(t.item())
+        return el_
+
+    el_two = timed(run)
+    resident = ro.resident_supported() and not args.no_resident
+    el_res, res_launch_ms = None, None
+    if resident:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def run_res(n_steps):
+            e0.record()
+            ro.run_resident(n_steps)
+            e1.record()
+        el_res = timed(run_res)
+        res_launch_ms = e0.elapsed_time(e1)                      # HIP events around the timed launches (this rank)
+    el = el_res if resident else el_two
     finite = bool(torch.isfinite(ro.sim.x).all().item())
 
     out = None
@@ -309,29 +352,55 @@ def main():
             "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "FlockingRelative-v0 N=%d K=%d, %d parallel episodes per MI355X "
-                                   "(BASELINE.json configs[1]); per step: sim step -> delayed-GSO update -> "
-                                   "Actor forward (hidden %s) -> action" % (N, K, B, hidden),
+                                   "(BASELINE.json configs[1]); per step: Actor forward (hidden %s) -> action -> "
+                                   "sim step -> delayed-GSO / delay-line update" % (N, K, B, hidden),
+                       "step_path": ("resident: all %d timed steps in one mgp_rollout_steps launch per GPU "
+                                     "(episode state in LDS)" % args.steps) if resident else
+                                    "two_launch: mgp_actor_fwd + mgp_flock_step_advance per step (HIP graph)",
                        "episodes_per_gpu": B, "episodes_total": total_eps, "agents": N, "taps": K,
                        "graph_steps": gs, "weights": ro.weights, "parallelism": "episodes sharded x%d, no "
                        "data-path collective" % world, "state_finite": finite},
+            "paths": {"two_launch": {"ms_per_step": 1e3 * el_two / args.steps,
+                                     "value": total_eps * N * args.steps / el_two, "graph_steps": gs}},
         }
+        if resident:
+            out["paths"]["resident"] = {"ms_per_step": 1e3 * el_res / args.steps,
+                                        "value": total_eps * N * args.steps / el_res,
+                                        "launch_ms_hip_events": res_launch_ms}
     if rank == 0 and not args.no_roofline:
         res, n_sets = kernel_rooflines(device, B, N, K, ro.actor, ro.sim._c)
-        # dominant kernel of the step = the fused Actor forward: the graph-shift aggregation X.G (HBM-bound, reads
-        # the dense (B,K,N,N) operator once) with the filter GEMM / MLP readout fused behind it
         fused = getattr(ro.actor, 'use_fused', False) and ro.actor.ind_agg == 0
         dom = res['actor_fwd'] if fused else res['agg_fwd']
         kname = "actor_fwd_kernel (aggregation X.G + MFMA filter/MLP, fused)" if fused else "agg_fwd_kernel (aggregation X.G)"
-        out["roofline"] = {"kernel": kname, "bound": "hbm",
-                           "achieved": dom['gbs'], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": dom['gbs'] / HBM_PEAK_GBS,
-                           "traffic": pmc_traffic('actor_fwd_kernel' if fused else 'agg_fwd_kernel', B, N, K),
-                           "algorithmic_bytes_per_launch": dom['bytes'], "avg_launch_ms": dom['ms'],
-                           "rotating_input_sets": n_sets,
-                           "aggregation_alone": {"kernel": "agg_fwd_kernel", "GBps": res['agg_fwd']['gbs'],
-                                                 "frac": res['agg_fwd']['gbs'] / HBM_PEAK_GBS,
-                                                 "algorithmic_bytes_per_launch": res['agg_fwd']['bytes'],
-                                                 "avg_launch_ms": res['agg_fwd']['ms']}}
+        dense = {"kernel": kname, "bound": "hbm", "achieved": dom['gbs'], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": dom['gbs'] / HBM_PEAK_GBS,
+                 "traffic": pmc_traffic('actor_fwd_kernel' if fused else 'agg_fwd_kernel', B, N, K),
+                 "algorithmic_bytes_per_launch": dom['bytes'], "avg_launch_ms": dom['ms'],
+                 "rotating_input_sets": n_sets,
+                 "aggregation_alone": {"kernel": "agg_fwd_kernel", "GBps": res['agg_fwd']['gbs'],
+                                       "frac": res['agg_fwd']['gbs'] / HBM_PEAK_GBS,
+                                       "algorithmic_bytes_per_launch": res['agg_fwd']['bytes'],
+                                       "avg_launch_ms": res['agg_fwd']['ms']}}
+        if resident:
+            # dominant (only) kernel of the timed region.  Algorithmic bytes = SURVEY 8(d) per-unit figure of the
+            # dense-contract aggregation (4KN^2 + 8KFN per episode-step) x episode-steps one launch processes.
+            n_launch = (args.steps + 1999) // 2000
+            alg = (4 * K * N * N + 8 * K * F_FEAT * N) * B * args.steps / n_launch
+            ms = res_launch_ms / n_launch
+            tr = pmc_traffic('rollout_kernel', B, N, K, steps_per_launch=args.steps // n_launch)
+            out["roofline"] = {"kernel": "rollout_kernel (episode-resident: aggregation + MFMA filter/MLP + sim step + "
+                                         "operator transition, %d steps per launch)" % (args.steps // n_launch),
+                               "bound": "hbm", "achieved": alg / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": alg / ms / 1e6 / HBM_PEAK_GBS, "traffic": tr,
+                               "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms,
+                               "steps_per_launch": args.steps // n_launch, "resident": True,
+                               "note": "equivalent rate: the dense operator stays in LDS across steps, so HBM moves "
+                                       "only `traffic` (state in/out + rewards); the kernel is issue/latency bound, "
+                                       "not HBM bound.  HBM-roofline fractions of the kernels that stream the dense "
+                                       "operator from HBM every step are under dense_kernels.",
+                               "dense_kernels": dense}
+        else:
+            out["roofline"] = dense
         out["kernels"] = {k: {"avg_launch_ms": v['ms'], "algorithmic_bytes": v['bytes'], "GBps": v['gbs']}
                           for k, v in res.items()}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
