@@ -121,14 +121,13 @@ __device__ __forceinline__ f32x4 ro_mlp_tile(const float* pin, const float* pw, 
     }
     const float4 bv = *reinterpret_cast<const float4*>(pbias);
     f32x4 acc0 = {bv.x, bv.y, bv.z, bv.w}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    // k-steps in groups of four; surplus steps multiply stale-but-finite activations by zero-padded weights
+    // k-steps in pairs (one per accumulator); the surplus step of an odd count multiplies stale-but-finite activations by
+    // zero-padded weights
 #pragma unroll
-    for (int sg = 0; sg < RO_KS / 4; ++sg) {
-        if (4 * sg < ksteps) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[4 * sg], fb[4 * sg], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[4 * sg + 1], fb[4 * sg + 1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[4 * sg + 2], fb[4 * sg + 2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[4 * sg + 3], fb[4 * sg + 3], acc1, 0, 0, 0);
+    for (int sg = 0; sg < RO_KS / 2; ++sg) {
+        if (2 * sg < ksteps) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2 * sg], fb[2 * sg], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2 * sg + 1], fb[2 * sg + 1], acc1, 0, 0, 0);
         }
     }
     return acc0 + acc1;
@@ -252,6 +251,10 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 if (Gd[m * N + n] != 0.f) rlist[n * RS + c++] = (unsigned char)m;
             rcnt[n] = c;
         }
+    for (int e = tid; e < N * 8; e += RO_THREADS) {             // tap 0 of the first step (later steps: written in D3)
+        const int f = e & 7, n = e >> 3;
+        if (f < 6) act[n * RO_CS + rpos(f * K)] = XT[e];          // cur = 0: slot 0 holds tap 0
+    }
     __syncthreads();
 
     // thread roles that do not change over the steps
@@ -265,7 +268,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     const bool sparse_active = sparse_wave && st_ < 2 * N;
     const int sn = st_ >> 1, sq = st_ & 1;
     const int li = lane & 15, lq = lane >> 4;
-    const int m_mt = wave & 1, m_col = (wave >> 1) * 16 + li;               // MLP tile of this wave
+    const int m_mt = wave >> 3, m_col = (wave & 7) * 16 + li;               // MLP tile of this wave (NT <= 8)
     const int m_in = m_col * RO_CS + lq * RO_KS, m_w = (m_mt * 64 + lane) * RO_WFS, m_b = m_mt * 16 + lq * 4;
     const int m_out = m_col * RO_CS + m_mt * 4 + lq;
     const int pi = tid >> 3, piece = tid & 7;                 // membership: agent row pi, piece of the offset range
@@ -286,21 +289,22 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 const float* g = Gd + (size_t)(kq + 1) * NS + lq * N + min(col, N - 1);      // B[k = lq][j = li] = G[4 s + lq][col]
                 const float* xa = XT + (size_t)ro_slot(cur, kq + 2, K) * N * 8 + lq * 8 + (li & 7);   // A[i = li][k = lq] = X[f = li][4 s + lq]
                 const float amask = (li < 8) ? 1.f : 0.f;                       // f = 6, 7 are zero pads in XT; rows 8..15 unused
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                for (int s0 = 0; s0 < n4; s0 += 8) {                            // operands of 8 k-steps first, then 8 MFMAs
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};   // even / odd k-steps: half the dependent chain
+                for (int s0 = 0; s0 < n4; s0 += 8) {                            // operands of 8 k-steps first, then the MFMAs
                     float av[8], bv[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int s_ = min(s0 + u, n4 - 1);
                         bv[u] = g[s_ * 4 * N];
-                        av[u] = xa[s_ * 32];
+                        av[u] = xa[s_ * 32] * amask;
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const float keep = (s0 + u < n4) ? amask : 0.f;         // clamped duplicates contribute exact zeros
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u] * keep, bv[u], acc, 0, 0, 0);
+                    for (int u = 0; u < 8; u += 2) {
+                        if (s0 + u < n4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+                        if (s0 + u + 1 < n4) acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[u + 1], acc_b, 0, 0, 0);
                     }
                 }
+                acc = acc + acc_b;
                 if (lq < 2 && col < N) {                                        // D[row = 4 lq + rr][col = li]: f = 4 lq + rr < 6
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr)
@@ -331,18 +335,11 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             }
         }
         RO_STAMP(6);
-        {
-            const float* x0t = XT + (size_t)cur * N * 8;      // tap 0: G_0 = I  =>  y_0 = X_0
-            for (int e = tid; e < N * 8; e += RO_THREADS) {
-                const int f = e & 7, n = e >> 3;
-                if (f < 6) act[n * RO_CS + rpos(f * K)] = x0t[e];
-            }
-            if (tid == RO_THREADS - 1) mmax[0] = 0u;          // consumed in the previous step's D1, refilled in C
-        }
+        if (tid == RO_THREADS - 1) mmax[0] = 0u;              // consumed in the previous step's D1, refilled in C
         __syncthreads();
         RO_STAMP(1);
         // -------------------------------------------------------------- B: filter GEMM + MLP on MFMA
-        // Wave w owns the tile (n-tile w >> 1, m-tile w & 1) of EVERY layer (16-wide layers leave the odd waves idle), so
+        // Wave w owns the tile (n-tile w & 7, m-tile w >> 3) of EVERY layer (16-wide layers leave waves 8..15 idle), so
         // its LDS addresses are step- and layer-invariant up to the buffer / weight-block base.  Layer metadata comes
         // from bit-packed scalar kernel arguments: P.dims[l] indexed dynamically is re-fetched from the kernel-argument
         // segment every layer of every step.
@@ -352,7 +349,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             const int MT = mtiles(cout);                      // 1 or 2
             const bool last = (l == n_layers - 1);
             const float* wfrag = wl + (int)((((l < 4) ? woffA : woffB) >> (16 * (l & 3))) & 0xFFFFull);
-            if (wave < 2 * NT && m_mt < MT) {
+            if ((wave & 7) < NT && m_mt < MT) {
                 const f32x4 acc = ro_mlp_tile(((l & 1) ? act2 : act) + m_in, wfrag + m_w, wfrag + MT * 64 * RO_WFS + m_b,
                                               pad4(cin) / 4);
                 if (last) {
@@ -424,15 +421,17 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 j = (j >= N) ? j - N : j;
                 sj[q] = sxy[j];
             }
+            unsigned int no_m = 0u;                           // "not clearly outside" (NaN compares false -> stays set)
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float dx = si.x - sj[q].x, dy = si.y - sj[q].y;
                 const float r2 = fmaf(dy, dy, dx * dx);
-                const bool ok = q < nd;
-                const bool in = r2 < t_in, out = r2 > t_out;
-                in_m |= (ok && in) ? (1u << q) : 0u;
-                unc_m |= (ok && !in && !out) ? (1u << q) : 0u;
+                in_m |= (r2 < t_in) ? (1u << q) : 0u;
+                no_m |= (r2 > t_out) ? 0u : (1u << q);
             }
+            const unsigned int valid = (nd > 0) ? ((1u << nd) - 1u) : 0u;      // q >= nd re-tested a duplicate: drop
+            in_m &= valid;
+            unc_m = no_m & ~in_m & valid;
             while (unc_m) {                                   // rare: the spec's own fp64 expression decides
                 const int q = __builtin_ctz(unc_m);
                 unc_m &= unc_m - 1u;
@@ -496,6 +495,9 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 float* xn = XT + ((size_t)(cur + 1 == K ? 0 : cur + 1) * N + fr) * 8;     // overwrites the oldest tap
                 *reinterpret_cast<float4*>(xn) = make_float4((float)f0, (float)f1, (float)f2, (float)f3);
                 *reinterpret_cast<float4*>(xn + 4) = make_float4((float)f4, (float)f5, 0.f, 0.f);
+                float* y0 = act + fr * RO_CS;                 // tap 0 of the next step's aggregation: G_0 = I  =>  y_0 = X_0
+                y0[rpos(0 * K)] = (float)f0; y0[rpos(1 * K)] = (float)f1; y0[rpos(2 * K)] = (float)f2;
+                y0[rpos(3 * K)] = (float)f3; y0[rpos(4 * K)] = (float)f4; y0[rpos(5 * K)] = (float)f5;
             }
         }
         __syncthreads();

@@ -19,6 +19,7 @@ import torch
 from .. import parallel
 from ..envs import FlockParams, VecFlock
 from ..envs.flocking import _REGISTRY
+from .rollouts import policy_rollout
 from .gnn_dagger import DAGGER
 from .state_with_delay import BatchedDelayState
 
@@ -81,14 +82,10 @@ def evaluate(learner, sim, state, n_episodes, steps):
         sim.reset(np.random)
         state.reset()
         state.push(sim.network, sim.features)
-        total = torch.zeros((sim.B,), device=sim.device, dtype=torch.float64)
-        with torch.no_grad():
-            for _ in range(steps):
-                out = learner.actor(state.delay_state, state.delay_gso)
-                A_dst, X_dst = state.next_slots()
-                sim.step(out, A_out=A_dst, feat_out=X_dst)
-                state.advance()
-                total += sim.reward
+        # whole episodes in one launch of the episode-resident kernel when the shape is covered (else step by step)
+        per_step = torch.zeros((sim.B, steps), device=sim.device, dtype=torch.float64)
+        policy_rollout(learner.actor, sim, state, steps, rewards=per_step)
+        total = per_step.sum(dim=1)
         rewards += total.cpu().tolist()
     return rewards[:n_episodes]
 
