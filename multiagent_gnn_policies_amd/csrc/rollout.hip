@@ -18,10 +18,11 @@
 //      is instruction-issue bound (one workgroup per CU), and one MFMA retires 384 useful MACs per issue slot where a
 //      packed VALU FMA retires 128.  Tap 1 walks only the non-zero rows of each column (exact zeros skipped); tap 0 is
 //      X_0 itself.  Results land in MFMA B-fragment order.
-//   B  filter GEMM + tanh MLP on fp32 MFMA 16x16x4 (k-ordered fmaf chain, 1e-5 budget), one wave per (16 agent columns,
-//      16 output channels) tile of a layer, activations ping-pong between two LDS buffers; the last layer leaves the
-//      action in LDS.
-//   C  fp64 integration of every agent (same expression tree as flock.hip / the oracle: bit-exact given the action).
+//   B  filter GEMM + tanh hidden layers on fp32 MFMA 16x16x4 (k-ordered fmaf chain, 1e-5 budget), one wave per (16 agent
+//      columns, 16 output channels) tile of a layer, activations ping-pong between two LDS buffers.
+//   C  one thread per agent: the 2-wide output layer as a packed-FMA chain (a 16-row MFMA tile would be 7/8 padding),
+//      then the fp64 integration of the agent (same expression tree as flock.hip / the oracle: bit-exact given the
+//      action) and its fp32 coordinates for D1.
 //   D  D1 membership: every unordered pair once (row i tests offsets 1..N/2, 8 threads per row); an fp32 test on
 //      coordinates relative to a reference point decides pairs that are clear of the radius by a proven error band, the
 //      exact fp64 expression of the spec decides the rest -- the bits are always the oracle's.  Both rows of a pair get
@@ -227,6 +228,15 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         const int tot = MT * 64 * RO_WFS;
         float* dst = wl + P.woff[l];
         const float* src = P.W[l];
+        if (l == P.n_layers - 1) {
+            // the 2-wide output layer runs on the VALU of the integrating threads: plain pairs (W[0][c], W[1][c]) in
+            // channel order, zero padded to 32 channels, then the bias pair
+            for (int e = tid; e < 2 * 4 * RO_KS + 2; e += RO_THREADS) {
+                const int c = e >> 1, o = e & 1;
+                dst[e] = (c < 4 * RO_KS) ? ((c < cin) ? src[(size_t)o * cin + c] : 0.f) : P.b[l][o];
+            }
+            continue;
+        }
         for (int e = tid; e < tot; e += RO_THREADS) {
             const int mt = e / (64 * RO_WFS), r1 = e - mt * (64 * RO_WFS);
             const int ln = r1 / RO_WFS, sl = r1 - ln * RO_WFS;
@@ -343,41 +353,55 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         // its LDS addresses are step- and layer-invariant up to the buffer / weight-block base.  Layer metadata comes
         // from bit-packed scalar kernel arguments: P.dims[l] indexed dynamically is re-fetched from the kernel-argument
         // segment every layer of every step.
-        for (int l = 0; l < n_layers; ++l) {
+        for (int l = 0; l < n_layers - 1; ++l) {              // hidden layers; the output layer is part of phase C
             const int cin = (l == 0) ? FK : ro_dim(dimsA, dims8, l);
             const int cout = ro_dim(dimsA, dims8, l + 1);
             const int MT = mtiles(cout);                      // 1 or 2
-            const bool last = (l == n_layers - 1);
             const float* wfrag = wl + (int)((((l < 4) ? woffA : woffB) >> (16 * (l & 3))) & 0xFFFFull);
             if ((wave & 7) < NT && m_mt < MT) {
                 const f32x4 acc = ro_mlp_tile(((l & 1) ? act2 : act) + m_in, wfrag + m_w, wfrag + MT * 64 * RO_WFS + m_b,
                                               pad4(cin) / 4);
-                if (last) {
+                float* pout = ((l & 1) ? act : act2) + m_out;
+                float z[4];
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int c = m_mt * 16 + lq * 4 + rr;
-                        if (c < cout && m_col < N) uact[c * N + m_col] = acc[rr];
-                    }
-                } else {
-                    float* pout = ((l & 1) ? act : act2) + m_out;
-                    float z[4];
+                for (int rr = 0; rr < 4; ++rr) z[rr] = tanh_fast(acc[rr]);
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) z[rr] = tanh_fast(acc[rr]);
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) pout[rr * RO_KS] = z[rr];                 // slot rpos(16 mt + 4 lq + rr)
-                }
+                for (int rr = 0; rr < 4; ++rr) pout[rr * RO_KS] = z[rr];                     // slot rpos(16 mt + 4 lq + rr)
             }
             RO_STAMP(12 + l);
-            if (!last) __syncthreads();
+            if (l < n_layers - 2) __syncthreads();
         }
         __syncthreads();
         RO_STAMP(2);
-        // -------------------------------------------------------------- C: integrate (fp64, spec section 1)
+        // -------------------------------------------------------------- C: output layer (VALU) + integrate (fp64, spec section 1)
         if (wave < 2) {                                       // N <= 128 agents: waves 0 and 1 (whole waves: wave_max below)
             float m = 0.f;
             if (tid < N) {
+                // u = b + W . z for this agent: 2 outputs in one packed-FMA chain over the channels in ascending order
+                const int lo_ = n_layers - 1;
+                const float* zin = ((lo_ & 1) ? act2 : act) + tid * RO_CS;
+                const float2* w2 = reinterpret_cast<const float2*>(wl + (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull));
+                float zv[4 * RO_KS];
+#pragma unroll
+                for (int i = 0; i < RO_KS; ++i) {
+                    const float4 v = *reinterpret_cast<const float4*>(zin + 4 * i);
+                    zv[4 * i] = v.x; zv[4 * i + 1] = v.y; zv[4 * i + 2] = v.z; zv[4 * i + 3] = v.w;
+                }
                 double px = spx[tid], py = spy[tid], vx = svx[tid], vy = svy[tid];
-                integrate_one(px, py, vx, vy, uact + tid, N, tid < p.n_leaders, p);
+                const float2 bb = w2[4 * RO_KS];
+                f32x2 u2 = {bb.x, bb.y}, u2b = {0.f, 0.f};       // even / odd channels: half the dependent chain
+                const float4* w4 = reinterpret_cast<const float4*>(w2);
+#pragma unroll
+                for (int c = 0; c < 4 * RO_KS; c += 2) {
+                    const float4 wc = w4[c >> 1];                // (W[0][c], W[1][c], W[0][c+1], W[1][c+1])
+                    const float za = zv[rpos(c)], zb = zv[rpos(c + 1)];
+                    u2 = __builtin_elementwise_fma((f32x2){za, za}, (f32x2){wc.x, wc.y}, u2);
+                    u2b = __builtin_elementwise_fma((f32x2){zb, zb}, (f32x2){wc.z, wc.w}, u2b);
+                }
+                u2 = u2 + u2b;
+                uact[tid] = u2.x; uact[N + tid] = u2.y;
+                const float ub[2] = {u2.x, u2.y};
+                integrate_one(px, py, vx, vy, ub, 1, tid < p.n_leaders, p);
                 spx[tid] = px; spy[tid] = py; svx[tid] = vx; svy[tid] = vy;
                 const float sx = (float)(px - cref[0]), sy = (float)(py - cref[1]);   // fp32 coordinates relative to cref
                 sxy[tid] = make_float2(sx, sy);

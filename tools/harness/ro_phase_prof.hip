@@ -50,7 +50,7 @@ int main(int argc, char** argv) {
     hipMemcpyFromSymbol(st, HIP_SYMBOL(mgp_ro_stamps), sizeof(st));
     const char* names[] = {"step start", "A done (barrier)", "B MFMA filter + MLP done (barrier)", "C integrated (barrier)",
                            "D done (barrier)", "E done (barrier)", "A: role work done (before tap-0 copy)", "D: membership bits done",
-                           "D: neighbour feature terms done", "D: piece shuffles done", "D: lists written", "E: rows of slices >= 2 done", "B: layer 0 tile done (before barrier)", "B: layer 1 tile done", "B: layer 2 tile done"};
+                           "D: neighbour feature terms done", "D: piece shuffles done", "D: lists written", "E: rows of slices >= 2 done", "B: layer 0 tile done (before barrier)", "B: layer 1 tile done", "(unused)"};
     const int order[] = {0, 6, 1, 12, 13, 14, 2, 3, 7, 8, 4, 11, 5};
     printf("cycles since step start, lane 0 of waves 0 / 3 / 7 / 9 / 12 / 15\n");
     const int wv[] = {0, 3, 7, 9, 12, 15};
