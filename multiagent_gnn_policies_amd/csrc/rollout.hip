@@ -431,7 +431,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         if (pi < N) {
             // |r2_fp32 - r2_exact| < band for every pair within 2R of each other (coordinates are
             // rounded once relative to cref, M = max |coordinate|); pairs farther than 2R are outside by a wide margin.
-            // A NaN / inf band makes every comparison false -> every pair goes to the exact test.
+            // An infinite band (M = inf) sends every pair to the exact test.
             const float M = __uint_as_float(mmax[0]);
             const float band = Rf * (16.f * M + 16.f * Rf) * 5.9604645e-8f + R2f * 1.1920929e-7f;
             const float t_in = R2f - band, t_out = R2f + band;
@@ -445,17 +445,23 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 j = (j >= N) ? j - N : j;
                 sj[q] = sxy[j];
             }
-            unsigned int no_m = 0u;                           // "not clearly outside" (NaN compares false -> stays set)
+            // sign bits instead of compare / select pairs (a v_cmp -> v_cndmask pair costs wait states on gfx9): the sign of
+            // r2 - t_in says "clearly inside", the sign of t_out - r2 says "clearly outside"; v_alignbit shifts each into
+            // a mask (first test ends in bit 7).  A NaN distance (diverged episode) classifies arbitrarily -- the state is
+            // garbage by then, and every index stays valid.
+            unsigned int out_m = 0u;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float dx = si.x - sj[q].x, dy = si.y - sj[q].y;
                 const float r2 = fmaf(dy, dy, dx * dx);
-                in_m |= (r2 < t_in) ? (1u << q) : 0u;
-                no_m |= (r2 > t_out) ? 0u : (1u << q);
+                in_m = __builtin_amdgcn_alignbit(in_m, __float_as_uint(r2 - t_in), 31);
+                out_m = __builtin_amdgcn_alignbit(out_m, __float_as_uint(t_out - r2), 31);
             }
+            in_m = __builtin_bitreverse32(in_m) >> 24;        // test q -> bit q
+            out_m = __builtin_bitreverse32(out_m) >> 24;
             const unsigned int valid = (nd > 0) ? ((1u << nd) - 1u) : 0u;      // q >= nd re-tested a duplicate: drop
             in_m &= valid;
-            unc_m = no_m & ~in_m & valid;
+            unc_m = ~out_m & ~in_m & valid;
             while (unc_m) {                                   // rare: the spec's own fp64 expression decides
                 const int q = __builtin_ctz(unc_m);
                 unc_m &= unc_m - 1u;
@@ -558,11 +564,14 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         if (K >= 2) {                                         // G_1 <- A_t from the membership bits
             for (int i = hw; i < N; i += RO_THREADS / 32) {   // half-wave per row, lane = 4 columns
                 const int c0 = hl * 4;
-                const unsigned int nib = (unsigned int)(rowmask[2 * i + (c0 >> 6)] >> (c0 & 63)) & 15u;
-                const float w = wrow[i];
+                const int nib = (int)(unsigned int)(rowmask[2 * i + (c0 >> 6)] >> (c0 & 63));
+                const int wb = __float_as_int(wrow[i]);       // bit k set -> all-ones (v_bfe_i32) & weight bits: 2 ops / element
                 if (hl < n4)
                     *reinterpret_cast<float4*>(Gd + i * N + c0) =
-                        make_float4((nib & 1u) ? w : 0.f, (nib & 2u) ? w : 0.f, (nib & 4u) ? w : 0.f, (nib & 8u) ? w : 0.f);
+                        make_float4(__int_as_float(__builtin_amdgcn_sbfe(nib, 0, 1) & wb),
+                                    __int_as_float(__builtin_amdgcn_sbfe(nib, 1, 1) & wb),
+                                    __int_as_float(__builtin_amdgcn_sbfe(nib, 2, 1) & wb),
+                                    __int_as_float(__builtin_amdgcn_sbfe(nib, 3, 1) & wb));
             }
         }
         if (tid == 0) { cref[0] = spx[0]; cref[1] = spy[0]; }  // next step's reference point (any point is valid)
