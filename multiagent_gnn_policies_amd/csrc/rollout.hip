@@ -429,7 +429,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             if (lane == 0) rewards[(size_t)b * T + t] = -1.0 * var * p.reward_scale;
         }
         if (pi < N) {
-            // |r2_fp32 - r2_exact| < band for every pair within 2R of each other (DESIGN.md section 6: coordinates are
+            // |r2_fp32 - r2_exact| < band for every pair within 2R of each other (DESIGN.md section 4.3: coordinates are
             // rounded once relative to cref, M = max |coordinate|); pairs farther than 2R are outside by a wide margin.
             // An infinite band (M = inf) sends every pair to the exact test.
             const float M = __uint_as_float(mmax[0]);
