@@ -87,3 +87,46 @@ def test_state_and_sim_random_sizes(seed):
         for b in range(B):
             assert relerr(sim.expert[b].cpu().numpy(), ofl.controller(xs[b], op)) <= 1e-6
             assert abs(sim.reward[b].item() - ofl.reward(xs[b], op)) <= 1e-12 * max(1.0, abs(ofl.reward(xs[b], op)))
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_resident_rollout_random_shapes(seed):
+    """mgp_rollout_steps on random (N, K, layers, widths, spec variants): every step against the oracle transition."""
+    from test_gpu_rollout import _make, _snapshot, _weights_np
+    from multiagent_gnn_policies_amd import ops
+    from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
+    rs = np.random.RandomState(5000 + seed)
+    N = int(4 * rs.randint(2, 33))
+    K = int(rs.randint(1, 5))
+    hidden = [(), (4,), (32,), (16, 16), (32, 32), (8, 32, 16), (32, 32, 32), (20, 12)][int(rs.randint(0, 8))]
+    variant = dict(mean_pooling=bool(rs.randint(0, 2)), n_leaders=int(rs.randint(0, 3)),
+                   comm_radius=float(rs.choice([0.8, 1.0, 1.5])))
+    B = int(rs.randint(1, 4))
+    _, op, actor, sim, st = _make(N, K, hidden, B, seed=seed, **variant)
+    action = torch.zeros((B, 1, 2, N), device='cuda')
+    rewards = torch.zeros((B, 1), device='cuda', dtype=torch.float64)
+    if not ops.rollout_supported(tuple(actor.layers), K, N):
+        assert policy_rollout(actor, sim, st, 1, rewards=rewards, action=action) is False
+        assert torch.isfinite(action).all()
+        return
+    Ws, bs = _weights_np(actor)
+    for step in range(K + 1):
+        x0, G0, X0 = _snapshot(sim, st)
+        assert policy_rollout(actor, sim, st, 1, rewards=rewards, action=action)
+        x1, G1, X1 = _snapshot(sim, st)
+        u = action.cpu().numpy()
+        ref = oa.forward(X0, G0, Ws, bs, 0, dtype=np.float64)
+        # sum pooling at K = 4 makes operator entries O(100) and pre-activations O(1e4): there the fp32 evaluation of the
+        # REFERENCE op sequence is itself further than 1e-5 from the exact result, so a multiple of its own rounding noise is allowed on top (orders of summation differ)
+        noise = relerr(oa.forward(X0, G0, Ws, bs, 0, dtype=np.float32), ref)
+        assert relerr(u, ref) <= 1e-5 + 10.0 * noise, (N, K, hidden, step, noise)
+        for b in range(B):
+            x_ref, vals, net, r = ofl.step(x0[b], u[b, 0].T.astype(np.float32), op)
+            assert np.array_equal(x1[b], x_ref)
+            if K > 1:
+                assert np.array_equal(G1[b, 1], net.astype(np.float32))
+            assert relerr(X1[b, 0], vals.T.astype(np.float32)) <= 1e-6
+            Gr, Xr = os_.gso_update(net[None], G0[b:b + 1], vals.T[None].astype(np.float32), X0[b:b + 1], K, dtype=np.float64)
+            assert relerr(G1[b], Gr[0]) <= 1e-6
+            assert np.array_equal(X1[b, 1:], X0[b, :-1])
+            assert abs(rewards[b, 0].item() - r) <= 1e-12 * max(1.0, abs(r))
