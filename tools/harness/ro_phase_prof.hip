@@ -3,6 +3,7 @@
 #define MGP_RO_PROFILE 1
 #include "../../multiagent_gnn_policies_amd/csrc/rollout.hip"
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include <cmath>
 thread_local int mgp_tls_hip_error = 0;
@@ -10,10 +11,16 @@ int main(int argc, char** argv) {
     int B = argc > 1 ? atoi(argv[1]) : 256, N = argc > 2 ? atoi(argv[2]) : 100, K = argc > 3 ? atoi(argv[3]) : 3;
     int T = argc > 4 ? atoi(argv[4]) : 200;
     std::vector<double> hx((size_t)B * N * 4);
+    const bool rnd = argc > 6;                                   // 7th argument: irregular (hash-scattered) positions
     for (int b = 0; b < B; ++b) for (int i = 0; i < N; ++i) {
         int gx = i % 10, gy = i / 10;
-        hx[((size_t)b * N + i) * 4 + 0] = 0.6 * gx + 0.01 * ((i * 7 + b) % 13);
-        hx[((size_t)b * N + i) * 4 + 1] = 0.6 * gy + 0.01 * ((i * 5 + b) % 11);
+        double jx = 0.01 * ((i * 7 + b) % 13), jy = 0.01 * ((i * 5 + b) % 11);
+        if (rnd) {                                               // uniform-ish scatter over a 7 x 7 box: Poisson-like degrees, mean ~6
+            unsigned h1 = (unsigned)(i * 2654435761u + b * 40503u), h2 = (unsigned)(i * 2246822519u + b * 3266489917u + 12345u);
+            jx = 7.0 * ((h1 >> 8) & 0xFFFF) / 65536.0 - 0.6 * gx; jy = 7.0 * ((h2 >> 8) & 0xFFFF) / 65536.0 - 0.6 * gy;
+        }
+        hx[((size_t)b * N + i) * 4 + 0] = 0.6 * gx + jx;
+        hx[((size_t)b * N + i) * 4 + 1] = 0.6 * gy + jy;
         hx[((size_t)b * N + i) * 4 + 2] = 0.1 * ((i * 3) % 17) - 0.8;
         hx[((size_t)b * N + i) * 4 + 3] = 0.1 * ((i * 11) % 19) - 0.9;
     }
@@ -34,12 +41,24 @@ int main(int argc, char** argv) {
     hipMalloc(&G, (size_t)B * K * N * N * 4); hipMalloc(&Xd, (size_t)B * K * 6 * N * 4); hipMalloc(&act, (size_t)B * 2 * N * 4);
     hipMemcpy(x, hx.data(), hx.size() * 8, hipMemcpyHostToDevice);
     hipMemset(G, 0, (size_t)B * K * N * N * 4); hipMemset(Xd, 0, (size_t)B * K * 6 * N * 4);
+    if (const char* dump = getenv("RO_STATE")) {                 // optional: start from a state dumped by tools/dump_rollout_state.py
+        FILE* f = fopen(dump, "rb");
+        if (!f) { printf("cannot open %s\n", dump); return 1; }
+        std::vector<float> hg((size_t)B * K * N * N), hxd((size_t)B * K * 6 * N);
+        size_t ok = fread(hx.data(), 8, hx.size(), f) + fread(hg.data(), 4, hg.size(), f) + fread(hxd.data(), 4, hxd.size(), f);
+        for (int l = 0; l < 3; ++l) { ok += fread(hw[l].data(), 4, hw[l].size(), f); ok += fread(hb[l].data(), 4, hb[l].size(), f); }
+        fclose(f);
+        hipMemcpy(x, hx.data(), hx.size() * 8, hipMemcpyHostToDevice);
+        hipMemcpy(G, hg.data(), hg.size() * 4, hipMemcpyHostToDevice); hipMemcpy(Xd, hxd.data(), hxd.size() * 4, hipMemcpyHostToDevice);
+        for (int l = 0; l < 3; ++l) { hipMemcpy(W[l], hw[l].data(), hw[l].size() * 4, hipMemcpyHostToDevice); hipMemcpy(bb[l], hb[l].data(), hb[l].size() * 4, hipMemcpyHostToDevice); }
+        printf("state from %s (%zu values)\n", dump, ok);
+    }
     MgpFlockParams p = {1.0, 0.01, 10.0, 1.0, 0.1, 10.0, 1.0, 1, 0, 1, 0};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     int rc = mgp_rollout_steps(x, G, Xd, W, bb, dims, 3, act, rew, &p, B, K, N, T, nullptr);
     if (rc) { printf("rc %d\n", rc); return 1; }
     hipDeviceSynchronize();
-    const int IT = 5;
+    const int IT = argc > 5 ? atoi(argv[5]) : 5;
     hipEventRecord(e0, nullptr);
     for (int it = 0; it < IT; ++it) mgp_rollout_steps(x, G, Xd, W, bb, dims, 3, act, rew, &p, B, K, N, T, nullptr);
     hipEventRecord(e1, nullptr); hipDeviceSynchronize();
