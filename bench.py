@@ -313,14 +313,17 @@ def main():
             torch.distributed.barrier()
 
     def timed(fn):
+        """warm-up, then EXACTLY args.steps steps bracketed by barrier + synchronize on both sides; the clock is read
+        between the closing synchronize and the closing barrier (the collective's own latency is not part of a step),
+        and the MAX over ranks is taken below."""
         fn(args.warmup)
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         fn(args.steps)
         torch.cuda.synchronize()
-        barrier()
         el_ = time.perf_counter() - t0
+        barrier()
         if world > 1:
             t = torch.tensor([el_], device=device, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
