@@ -46,6 +46,7 @@ from multiagent_gnn_policies_amd.envs import FlockParams, VecFlock  # noqa: E402
 from multiagent_gnn_policies_amd.learner import Actor  # noqa: E402
 from multiagent_gnn_policies_amd.learner.state_with_delay import BatchedDelayState  # noqa: E402
 
+DEFAULT_STEPS = 1000      # env steps in the timed region (resident path: one launch; ~10 ms)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 F_FEAT, N_ACT = 6, 2
 
@@ -256,8 +257,8 @@ def cpu_baseline(N, K, hidden, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=DEFAULT_STEPS)
+    ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--episodes', type=int, default=256, help='parallel episodes per GPU')
     ap.add_argument('--agents', type=int, default=100)
     ap.add_argument('--taps', type=int, default=3)

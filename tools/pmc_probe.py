@@ -27,7 +27,7 @@ def main():
     res, n_sets = bench.kernel_rooflines(dev, B, N, K, actor, FlockParams(n_agents=N).to_c())
     print({k: round(v['ms'] * 1e3, 2) for k, v in res.items()}, n_sets)
     # episode-resident rollout kernel: a few launches of PROBE_T steps each (bench.py's default timed launch)
-    T = int(os.environ.get('PROBE_T', '200'))
+    T = int(os.environ.get('PROBE_T', '1000'))
     ro = bench.Rollout(dev, B, N, K, [32, 32], seed=1000)
     if ro.resident_supported():
         for _ in range(5):
