@@ -5,7 +5,8 @@ and update as DAGGER's (the reference duplicates the class, gnn_cloning.py:17-12
 import numpy as np
 import torch
 
-from .gnn_dagger import DAGGER, _rollout_reward
+from .gnn_dagger import DAGGER
+from .rollouts import policy_episode_rewards
 from .replay_buffer import ReplayBuffer, Transition
 from .state_with_delay import MultiAgentStateWithDelay
 
@@ -52,7 +53,7 @@ def train_cloning(env, args, device):
                 updates += 1
 
         if i % test_interval == 0:
-            test_rewards = [_rollout_reward(env, learner, device, args) for _ in range(n_test_episodes)]
+            test_rewards = policy_episode_rewards(env, learner, device, args, n_test_episodes)
             mean_reward = np.mean(test_rewards)
             if stats['mean'] < mean_reward:
                 stats['mean'] = mean_reward

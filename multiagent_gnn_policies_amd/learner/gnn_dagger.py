@@ -16,7 +16,7 @@ from .. import parallel
 from ..parallel import FlatGradSync
 from .actor import Actor
 from .replay_buffer import ReplayBuffer, Transition
-from .rollouts import policy_episode_reward
+from .rollouts import policy_episode_rewards
 from .state_with_delay import MultiAgentStateWithDelay
 
 
@@ -225,10 +225,6 @@ class DAGGER(object):
                 raise KeyError("state_dict mismatch: %s" % sorted(missing))
 
 
-def _rollout_reward(env, learner, device, args):
-    return policy_episode_reward(env, learner, device, args)
-
-
 def train_dagger(env, args, device):
     debug = args.getboolean('debug')
     memory = ReplayBuffer(max_size=args.getint('buffer_size'))
@@ -287,13 +283,13 @@ def train_dagger(env, args, device):
                 updates += 1
 
         if (i * world) % test_interval < world and debug:
-            test_rewards = [_rollout_reward(env, learner, device, args) for _ in range(n_test_local)]
+            test_rewards = policy_episode_rewards(env, learner, device, args, n_test_local)
             test_rewards = parallel.all_gather_floats(test_rewards)
             if rank == 0:
                 print("Episode: {}, updates: {}, total numsteps: {}, reward: {}, policy loss: {}".format(
                     i * world, updates, total_numsteps * world, np.mean(test_rewards), policy_loss_sum))
 
-    test_rewards = [_rollout_reward(env, learner, device, args) for _ in range(n_test_local)]
+    test_rewards = policy_episode_rewards(env, learner, device, args, n_test_local)
     test_rewards = parallel.all_gather_floats(test_rewards)
     stats['mean'] = np.mean(test_rewards)
     stats['std'] = np.std(test_rewards)

@@ -90,3 +90,30 @@ def policy_rollout(actor, sim, state, T, rewards=None, action=None, resident=Tru
         if action is not None:
             action.copy_(out)
     return False
+
+
+def policy_episode_rewards(env, learner, device, args, n_episodes):
+    """Reward sums of `n_episodes` policy-only test episodes (the reference's test loop, gnn_dagger.py:194-203, run
+    `n_test_episodes` times).  With this package's flocking environments all episodes run side by side: their reset
+    states are drawn one after the other from the environment's own RNG -- exactly what the sequential loop would draw,
+    since policy rollouts consume no randomness -- and every lane is stepped to the time limit by `policy_rollout`
+    (one launch of the episode-resident kernel when the shape is covered).  Rewards agree with the one-at-a-time loop
+    up to the closed-loop amplification of fp32 rounding (the summation order of the aggregation differs).
+    Any other environment object falls back to the sequential loop."""
+    import torch
+    from ..envs.flocking import FlockingRelativeEnv, VecFlock, sample_initial_state
+    from .state_with_delay import BatchedDelayState
+    raw = getattr(env, 'env', None)
+    steps = getattr(env, '_max_episode_steps', None)
+    if n_episodes <= 0:
+        return []
+    if not isinstance(raw, FlockingRelativeEnv) or steps is None or learner.actor.ind_agg != 0:
+        return [policy_episode_reward(env, learner, device, args) for _ in range(n_episodes)]
+    p = raw.params
+    sim = VecFlock(n_episodes, p, device)
+    sim.set_state(np.stack([sample_initial_state(raw._rng, p) for _ in range(n_episodes)]))
+    state = BatchedDelayState(device, n_episodes, learner.actor.k, learner.n_states, p.n_agents)
+    state.push(sim.network, sim.features)
+    per_step = torch.zeros((n_episodes, steps), device=sim.device, dtype=torch.float64)
+    policy_rollout(learner.actor, sim, state, steps, rewards=per_step)
+    return per_step.sum(dim=1).cpu().tolist()
