@@ -18,8 +18,8 @@
 //      is instruction-issue bound (one workgroup per CU), and one MFMA retires 384 useful MACs per issue slot where a
 //      packed VALU FMA retires 128.  Tap 1 walks only the non-zero rows of each column (exact zeros skipped); tap 0 is
 //      X_0 itself.  Results land in MFMA B-fragment order.
-//   B  filter GEMM + tanh hidden layers on fp32 MFMA 16x16x4 (k-ordered fmaf chain, 1e-5 budget), one wave per (16 agent
-//      columns, 16 output channels) tile of a layer, activations ping-pong between two LDS buffers.
+//   B  filter GEMM + tanh hidden layers on fp32 MFMA 16x16x4 (k-ordered fmaf chain, 1e-5 budget): a wave owns 16 agent
+//      columns through every hidden layer, activations in place in LDS, no barrier between layers.
 //   C  one thread per agent: the 2-wide output layer as a packed-FMA chain (a 16-row MFMA tile would be 7/8 padding),
 //      then the fp64 integration of the agent (same expression tree as flock.hip / the oracle: bit-exact given the
 //      action) and its fp32 coordinates for D1.
@@ -75,7 +75,7 @@ struct RoOff {
     int uact;                             // float [2][N] action (the Actor output layout (nA, N))
     int xt;                               // float [K][N][8] delay line, ring over taps, transposed (6 features + 2 pad)
     int gd;                               // float [K-1][N+1][N] delayed operator, slices 1..K-1 (+ one all-zero row each)
-    int act;                              // float [2][ncols16][RO_CS] activations (layers ping-pong)
+    int act;                              // float [ncols16][RO_CS] activations (in place through the layers)
     int rlist;                            // u8 [N][RS] ascending neighbour lists, padded with N (RS = N rounded to 8, + 8)
     int rcnt;                             // int [N] list lengths
     int sxy;                              // float2 [N] fp32 coordinates relative to the reference point
@@ -95,7 +95,7 @@ __host__ __device__ constexpr RoOff ro_offsets(int N, int K)
     c.uact = ro_take(off, 2 * N * 4);
     c.xt = ro_take(off, K * N * 8 * 4);
     c.gd = ro_take(off, (K - 1) * (N + 1) * N * 4);
-    c.act = ro_take(off, 2 * ((N + 15) & ~15) * RO_CS * 4);
+    c.act = ro_take(off, ((N + 15) & ~15) * RO_CS * 4);
     c.rlist = ro_take(off, N * (((N + 7) & ~7) + 8));
     c.rcnt = ro_take(off, N * 4);
     c.sxy = ro_take(off, N * 8);
@@ -104,34 +104,46 @@ __host__ __device__ constexpr RoOff ro_offsets(int N, int K)
     return c;
 }
 
-// One (16 agent columns) x (16 output channels) tile of one layer: D (16 x 16) = W[mt] (16 x cin) . Act (cin x 16) on
-// fp32 16x16x4 MFMAs, bias preloaded into the accumulator, tanh on the accumulator registers.  The two m-tiles of a
-// 32-wide layer run on two waves (the phase is latency bound: a wave's chain is load -> dependent MFMAs -> tanh ->
-// store), so the activations ping-pong between two LDS buffers and layers are separated by workgroup barriers.
-// Two accumulators (even / odd k-steps) halve the dependent-MFMA chain; they are added before the bias-free half is
-// used: acc = (bias + even steps) + (odd steps).
-__device__ __forceinline__ f32x4 ro_mlp_tile(const float* pin, const float* pw, const float* pbias, int ksteps)
+// One hidden layer for the 16 agent columns a wave owns: D[mt] (16 x 16) = W[mt] (16 x cin) . Act (cin x 16) on fp32
+// 16x16x4 MFMAs, both m-tiles of a 32-wide layer as two independent accumulator chains, bias preloaded into the
+// accumulators, tanh on the accumulator registers.  The wave reads all its B fragments before it stores anything and
+// therefore works in place; no other wave touches these columns, so hidden layers need no workgroup barrier between
+// them.  (Splitting the m-tiles over two waves with ping-pong buffers and a barrier per layer measured the same.)
+template <int MT>
+__device__ __forceinline__ void ro_mlp_cols(float* pcol, const float* pw, const float* pbias, int ksteps, int lq)
 {
-    float fb[RO_KS], fa[RO_KS];
-    const float4* pb = reinterpret_cast<const float4*>(pin);
-    const float4* pa = reinterpret_cast<const float4*>(pw);
+    float fb[RO_KS], fa[MT][RO_KS];
+    f32x4 acc[MT];
+    const float4* pb = reinterpret_cast<const float4*>(pcol + lq * RO_KS);
 #pragma unroll
-    for (int i = 0; i < RO_KS / 4; ++i) {
-        const float4 t = pb[i]; fb[4 * i] = t.x; fb[4 * i + 1] = t.y; fb[4 * i + 2] = t.z; fb[4 * i + 3] = t.w;
-        const float4 u = pa[i]; fa[4 * i] = u.x; fa[4 * i + 1] = u.y; fa[4 * i + 2] = u.z; fa[4 * i + 3] = u.w;
+    for (int i = 0; i < RO_KS / 4; ++i) { const float4 t = pb[i]; fb[4 * i] = t.x; fb[4 * i + 1] = t.y; fb[4 * i + 2] = t.z; fb[4 * i + 3] = t.w; }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const float4* pa = reinterpret_cast<const float4*>(pw + mt * 64 * RO_WFS);
+#pragma unroll
+        for (int i = 0; i < RO_KS / 4; ++i) { const float4 u = pa[i]; fa[mt][4 * i] = u.x; fa[mt][4 * i + 1] = u.y; fa[mt][4 * i + 2] = u.z; fa[mt][4 * i + 3] = u.w; }
+        const float4 bv = *reinterpret_cast<const float4*>(pbias + mt * 16);
+        acc[mt][0] = bv.x; acc[mt][1] = bv.y; acc[mt][2] = bv.z; acc[mt][3] = bv.w;
     }
-    const float4 bv = *reinterpret_cast<const float4*>(pbias);
-    f32x4 acc0 = {bv.x, bv.y, bv.z, bv.w}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    // k-steps in pairs (one per accumulator); the surplus step of an odd count multiplies stale-but-finite activations by
-    // zero-padded weights
 #pragma unroll
     for (int sg = 0; sg < RO_KS / 2; ++sg) {
         if (2 * sg < ksteps) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2 * sg], fb[2 * sg], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2 * sg + 1], fb[2 * sg + 1], acc1, 0, 0, 0);
+#pragma unroll
+            for (int s_ = 2 * sg; s_ < 2 * sg + 2; ++s_)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][s_], fb[s_], acc[mt], 0, 0, 0);
         }
     }
-    return acc0 + acc1;
+    float z[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) z[mt][rr] = tanh_fast(acc[mt][rr]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) pcol[rr * RO_KS + mt * 4 + lq] = z[mt][rr];                 // slot rpos(16 mt + 4 lq + rr)
 }
 
 __device__ __forceinline__ int ro_dim(unsigned long long dimsA, unsigned int dims8, int l)
@@ -188,7 +200,6 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     float* Gd = reinterpret_cast<float*>(smraw + cv.gd);
     float* wl = reinterpret_cast<float*>(smraw + cv.wl);
     float* act = reinterpret_cast<float*>(smraw + cv.act);
-    float* act2 = act + pad16(N) * RO_CS;                     // second activation buffer (layers ping-pong)
     unsigned char* rlist = smraw + cv.rlist;
     int* rcnt = reinterpret_cast<int*>(smraw + cv.rcnt);
     float2* sxy = reinterpret_cast<float2*>(smraw + cv.sxy);
@@ -247,7 +258,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     }
     {
         float4* za = reinterpret_cast<float4*>(act);
-        for (int i = tid; i < 2 * ncols16 * RO_CS / 4; i += RO_THREADS) za[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < ncols16 * RO_CS / 4; i += RO_THREADS) za[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         unsigned int* zl = reinterpret_cast<unsigned int*>(rlist);            // every list byte is always a valid row index
         for (int i = tid; i < N * RS / 4; i += RO_THREADS) zl[i] = 0u;
     }
@@ -278,9 +289,6 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     const bool sparse_active = sparse_wave && st_ < 2 * N;
     const int sn = st_ >> 1, sq = st_ & 1;
     const int li = lane & 15, lq = lane >> 4;
-    const int m_mt = wave >> 3, m_col = (wave & 7) * 16 + li;               // MLP tile of this wave (NT <= 8)
-    const int m_in = m_col * RO_CS + lq * RO_KS, m_w = (m_mt * 64 + lane) * RO_WFS, m_b = m_mt * 16 + lq * 4;
-    const int m_out = m_col * RO_CS + m_mt * 4 + lq;
     const int pi = tid >> 3, piece = tid & 7;                 // membership: agent row pi, piece of the offset range
     const int half = N >> 1, dh = (half + RO_PIECES - 1) / RO_PIECES;          // offsets 1..N/2, <= 8 per piece
     const int fr = tid >> 2, fq = tid & 3;                    // lists / features: agent row fr, lane fq of 4
@@ -349,27 +357,19 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         __syncthreads();
         RO_STAMP(1);
         // -------------------------------------------------------------- B: filter GEMM + MLP on MFMA
-        // Wave w owns the tile (n-tile w & 7, m-tile w >> 3) of EVERY layer (16-wide layers leave waves 8..15 idle), so
-        // its LDS addresses are step- and layer-invariant up to the buffer / weight-block base.  Layer metadata comes
-        // from bit-packed scalar kernel arguments: P.dims[l] indexed dynamically is re-fetched from the kernel-argument
-        // segment every layer of every step.
-        for (int l = 0; l < n_layers - 1; ++l) {              // hidden layers; the output layer is part of phase C
-            const int cin = (l == 0) ? FK : ro_dim(dimsA, dims8, l);
-            const int cout = ro_dim(dimsA, dims8, l + 1);
-            const int MT = mtiles(cout);                      // 1 or 2
-            const float* wfrag = wl + (int)((((l < 4) ? woffA : woffB) >> (16 * (l & 3))) & 0xFFFFull);
-            if ((wave & 7) < NT && m_mt < MT) {
-                const f32x4 acc = ro_mlp_tile(((l & 1) ? act2 : act) + m_in, wfrag + m_w, wfrag + MT * 64 * RO_WFS + m_b,
-                                              pad4(cin) / 4);
-                float* pout = ((l & 1) ? act : act2) + m_out;
-                float z[4];
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) z[rr] = tanh_fast(acc[rr]);
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) pout[rr * RO_KS] = z[rr];                     // slot rpos(16 mt + 4 lq + rr)
+        // Layer metadata comes from bit-packed scalar kernel arguments: P.dims[l] indexed dynamically is re-fetched from
+        // the kernel-argument segment every layer of every step (~700 cycles each).
+        if (wave < NT) {                                      // wave w owns columns 16 w .. 16 w + 15 through every hidden layer
+            float* pcol = act + (wave * 16 + li) * RO_CS;
+            for (int l = 0; l < n_layers - 1; ++l) {
+                const int cin = (l == 0) ? FK : ro_dim(dimsA, dims8, l);
+                const int cout = ro_dim(dimsA, dims8, l + 1);
+                const int MT = mtiles(cout);
+                const float* wfrag = wl + (int)((((l < 4) ? woffA : woffB) >> (16 * (l & 3))) & 0xFFFFull);
+                if (MT == 2) ro_mlp_cols<2>(pcol, wfrag + lane * RO_WFS, wfrag + 2 * 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
+                else ro_mlp_cols<1>(pcol, wfrag + lane * RO_WFS, wfrag + 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
+                RO_STAMP(12 + l);
             }
-            RO_STAMP(12 + l);
-            if (l < n_layers - 2) __syncthreads();
         }
         __syncthreads();
         RO_STAMP(2);
@@ -379,7 +379,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             if (tid < N) {
                 // u = b + W . z for this agent: 2 outputs in one packed-FMA chain over the channels in ascending order
                 const int lo_ = n_layers - 1;
-                const float* zin = ((lo_ & 1) ? act2 : act) + tid * RO_CS;
+                const float* zin = act + tid * RO_CS;
                 const float2* w2 = reinterpret_cast<const float2*>(wl + (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull));
                 float zv[4 * RO_KS];
 #pragma unroll
