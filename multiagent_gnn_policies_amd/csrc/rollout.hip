@@ -30,8 +30,8 @@
 //      sum the fp64 feature terms of actual neighbours.  One otherwise idle wave computes the step's reward.
 //   E  G_j <- A_t . G_{j-1} for j = K-1 .. 2 (row gathers in LDS along the neighbour lists, ascending order, fmaf
 //      chain: the same arithmetic as gso.hip; lists are padded with the index of an all-zero row, so there is no tail
-//      code), then G_1 <- A_t expanded from the membership bits.  The delay line is a ring: the new
-//      features overwrite the oldest tap, nothing is shifted.
+//      code).  G_1 <- A_t itself is expanded from the membership bits by the waves that idle during phase B of the next
+//      step (and once on exit).  The delay line is a ring: the new features overwrite the oldest tap, nothing is shifted.
 // This translation unit is built with -ffp-contract=off (fp64 spec arithmetic); fp32 fused multiply-adds are explicit.
 #include "mgp_device.h"
 
@@ -338,7 +338,9 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 const float* xt = XT + (size_t)ro_slot(cur, 1, K) * N * 8;
                 for (int e = sq; e < cnt; e += 2) {
                     const int m = lp[e];
-                    const float gv = gcol[m * N];
+                    // inside the launch G_1[m][n] = wrow[m] on its pattern (its dense rows are re-expanded during phase B);
+                    // the first step reads the caller's dense slice, which may be any tensor
+                    const float gv = (t == 0) ? gcol[m * N] : wrow[m];
                     const float4 x0 = *reinterpret_cast<const float4*>(xt + m * 8);
                     const float2 x1 = *reinterpret_cast<const float2*>(xt + m * 8 + 4);
                     sa[0] = fmaf(x0.x, gv, sa[0]); sa[1] = fmaf(x0.y, gv, sa[1]); sa[2] = fmaf(x0.z, gv, sa[2]);
@@ -369,6 +371,21 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 if (MT == 2) ro_mlp_cols<2>(pcol, wfrag + lane * RO_WFS, wfrag + 2 * 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
                 else ro_mlp_cols<1>(pcol, wfrag + lane * RO_WFS, wfrag + 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
                 RO_STAMP(12 + l);
+            }
+        } else if (t > 0 && K >= 3) {
+            // meanwhile the other waves expand G_1 <- A_t from the membership bits of the previous simulator step (its dense
+            // rows are only read by the operator transition E, after two more barriers; tap 1 above used the lists)
+            const int nxw = RO_WAVES - NT;
+            for (int i = 2 * (wave - NT) + (lane >> 5); i < N; i += 2 * nxw) {
+                const int c0 = hl * 4;
+                const int nib = (int)(unsigned int)(rowmask[2 * i + (c0 >> 6)] >> (c0 & 63));
+                const int wb = __float_as_int(wrow[i]);       // bit k set -> all-ones (v_bfe_i32) & weight bits: 2 ops / element
+                if (hl < n4)
+                    *reinterpret_cast<float4*>(Gd + i * N + c0) =
+                        make_float4(__int_as_float(__builtin_amdgcn_sbfe(nib, 0, 1) & wb),
+                                    __int_as_float(__builtin_amdgcn_sbfe(nib, 1, 1) & wb),
+                                    __int_as_float(__builtin_amdgcn_sbfe(nib, 2, 1) & wb),
+                                    __int_as_float(__builtin_amdgcn_sbfe(nib, 3, 1) & wb));
             }
         }
         __syncthreads();
@@ -561,26 +578,27 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             __syncthreads();
         }
         RO_STAMP(11);
-        if (K >= 2) {                                         // G_1 <- A_t from the membership bits
-            for (int i = hw; i < N; i += RO_THREADS / 32) {   // half-wave per row, lane = 4 columns
-                const int c0 = hl * 4;
-                const int nib = (int)(unsigned int)(rowmask[2 * i + (c0 >> 6)] >> (c0 & 63));
-                const int wb = __float_as_int(wrow[i]);       // bit k set -> all-ones (v_bfe_i32) & weight bits: 2 ops / element
-                if (hl < n4)
-                    *reinterpret_cast<float4*>(Gd + i * N + c0) =
-                        make_float4(__int_as_float(__builtin_amdgcn_sbfe(nib, 0, 1) & wb),
-                                    __int_as_float(__builtin_amdgcn_sbfe(nib, 1, 1) & wb),
-                                    __int_as_float(__builtin_amdgcn_sbfe(nib, 2, 1) & wb),
-                                    __int_as_float(__builtin_amdgcn_sbfe(nib, 3, 1) & wb));
-            }
-        }
         if (tid == 0) { cref[0] = spx[0]; cref[1] = spy[0]; }  // next step's reference point (any point is valid)
         cur = (cur + 1 == K) ? 0 : cur + 1;
-        __syncthreads();
+        if (K < 3) __syncthreads();                           // K >= 3: the barrier that closed the last operator slice
         RO_STAMP(5);
     }
 
     // ------------------------------------------------------------------ exit: LDS -> the caller's buffers
+    if (T > 0 && K >= 2) {                                    // the expansion G_1 <- A_T is still pending
+        for (int i = hw; i < N; i += RO_THREADS / 32) {       // half-wave per row, lane = 4 columns
+            const int c0 = hl * 4;
+            const int nib = (int)(unsigned int)(rowmask[2 * i + (c0 >> 6)] >> (c0 & 63));
+            const int wb = __float_as_int(wrow[i]);
+            if (hl < n4)
+                *reinterpret_cast<float4*>(Gd + i * N + c0) =
+                    make_float4(__int_as_float(__builtin_amdgcn_sbfe(nib, 0, 1) & wb),
+                                __int_as_float(__builtin_amdgcn_sbfe(nib, 1, 1) & wb),
+                                __int_as_float(__builtin_amdgcn_sbfe(nib, 2, 1) & wb),
+                                __int_as_float(__builtin_amdgcn_sbfe(nib, 3, 1) & wb));
+        }
+        __syncthreads();
+    }
     for (int j = 1; j < K; ++j) {
         const float4* gsrc = reinterpret_cast<const float4*>(Gd + (size_t)(j - 1) * NS);
         float4* gdst = reinterpret_cast<float4*>(Gb + (size_t)j * NN);
