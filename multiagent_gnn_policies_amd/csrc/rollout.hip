@@ -361,8 +361,9 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         // -------------------------------------------------------------- B: filter GEMM + MLP on MFMA
         // Layer metadata comes from bit-packed scalar kernel arguments: P.dims[l] indexed dynamically is re-fetched from
         // the kernel-argument segment every layer of every step (~700 cycles each).
-        if (wave < NT) {                                      // wave w owns columns 16 w .. 16 w + 15 through every hidden layer
-            float* pcol = act + (wave * 16 + li) * RO_CS;
+        if (wave < NT) {                                      // wave w owns columns 16 w .. 16 w + 15 through every layer
+            const int col = wave * 16 + li;
+            float* pcol = act + col * RO_CS;
             for (int l = 0; l < n_layers - 1; ++l) {
                 const int cin = (l == 0) ? FK : ro_dim(dimsA, dims8, l);
                 const int cout = ro_dim(dimsA, dims8, l + 1);
@@ -372,62 +373,68 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 else ro_mlp_cols<1>(pcol, wfrag + lane * RO_WFS, wfrag + 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
                 RO_STAMP(12 + l);
             }
-        } else if (t > 0 && K >= 3) {
-            // meanwhile the other waves expand G_1 <- A_t from the membership bits of the previous simulator step (its dense
-            // rows are only read by the operator transition E, after two more barriers; tap 1 above used the lists)
-            const int nxw = RO_WAVES - NT;
-            for (int i = 2 * (wave - NT) + (lane >> 5); i < N; i += 2 * nxw) {
-                const int c0 = hl * 4;
-                const int nib = (int)(unsigned int)(rowmask[2 * i + (c0 >> 6)] >> (c0 & 63));
-                const int wb = __float_as_int(wrow[i]);       // bit k set -> all-ones (v_bfe_i32) & weight bits: 2 ops / element
-                if (hl < n4)
-                    *reinterpret_cast<float4*>(Gd + i * N + c0) =
-                        make_float4(__int_as_float(__builtin_amdgcn_sbfe(nib, 0, 1) & wb),
-                                    __int_as_float(__builtin_amdgcn_sbfe(nib, 1, 1) & wb),
-                                    __int_as_float(__builtin_amdgcn_sbfe(nib, 2, 1) & wb),
-                                    __int_as_float(__builtin_amdgcn_sbfe(nib, 3, 1) & wb));
+            // ---------------------------------------------------------- C: output layer (VALU) + integrate, same wave
+            // The 2-wide output layer is a packed-FMA chain (a 16-row MFMA tile would be 7/8 padding): lane (li, lq) takes
+            // the 8 channels c = 4 s + lq of agent column li (contiguous in the B-fragment layout), the four lq lanes are
+            // added by DPP.  Lane lq == 0 then integrates the agent (spec section 1, fp64: bit-exact given the action) and
+            // publishes its fp32 coordinates for D1.  No workgroup barrier since the hidden layers: the wave only reads
+            // activations it wrote itself.
+            const int lo_ = n_layers - 1;
+            const float* w2 = wl + (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull);
+            const float4 z0 = *reinterpret_cast<const float4*>(pcol + lq * RO_KS);
+            const float4 z1 = *reinterpret_cast<const float4*>(pcol + lq * RO_KS + 4);
+            const float zc[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+            double px = 0.0, py = 0.0, vx = 0.0, vy = 0.0, cx = 0.0, cy = 0.0;
+            const bool agent = (lq == 0) && col < N;
+            if (agent) { px = spx[col]; py = spy[col]; vx = svx[col]; vy = svy[col]; cx = cref[0]; cy = cref[1]; }
+            f32x2 u2 = {0.f, 0.f}, u2b = {0.f, 0.f};
+#pragma unroll
+            for (int s_ = 0; s_ < RO_KS; s_ += 2) {           // channel c = 4 s + lq: weights (W[0][c], W[1][c]) at w2[2 c]
+                const float2 wa = *reinterpret_cast<const float2*>(w2 + 2 * (4 * s_ + lq));
+                const float2 wb = *reinterpret_cast<const float2*>(w2 + 2 * (4 * (s_ + 1) + lq));
+                u2 = __builtin_elementwise_fma((f32x2){zc[s_], zc[s_]}, (f32x2){wa.x, wa.y}, u2);
+                u2b = __builtin_elementwise_fma((f32x2){zc[s_ + 1], zc[s_ + 1]}, (f32x2){wb.x, wb.y}, u2b);
             }
-        }
-        __syncthreads();
-        RO_STAMP(2);
-        // -------------------------------------------------------------- C: output layer (VALU) + integrate (fp64, spec section 1)
-        if (wave < 2) {                                       // N <= 128 agents: waves 0 and 1 (whole waves: wave_max below)
+            u2 = u2 + u2b;
+            // lanes (li, lq) of one column sit 16 apart: row_ror-free combination through two bpermute-less steps is not
+            // available across rows, so use the wave shuffle (4 values, once per step)
+            float ux = u2.x, uy = u2.y;
+            ux += __shfl_xor(ux, 16, MGP_WAVE); uy += __shfl_xor(uy, 16, MGP_WAVE);
+            ux += __shfl_xor(ux, 32, MGP_WAVE); uy += __shfl_xor(uy, 32, MGP_WAVE);
             float m = 0.f;
-            if (tid < N) {
-                // u = b + W . z for this agent: 2 outputs in one packed-FMA chain over the channels in ascending order
-                const int lo_ = n_layers - 1;
-                const float* zin = act + tid * RO_CS;
-                const float2* w2 = reinterpret_cast<const float2*>(wl + (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull));
-                float zv[4 * RO_KS];
-#pragma unroll
-                for (int i = 0; i < RO_KS; ++i) {
-                    const float4 v = *reinterpret_cast<const float4*>(zin + 4 * i);
-                    zv[4 * i] = v.x; zv[4 * i + 1] = v.y; zv[4 * i + 2] = v.z; zv[4 * i + 3] = v.w;
-                }
-                double px = spx[tid], py = spy[tid], vx = svx[tid], vy = svy[tid];
-                const float2 bb = w2[4 * RO_KS];
-                f32x2 u2 = {bb.x, bb.y}, u2b = {0.f, 0.f};       // even / odd channels: half the dependent chain
-                const float4* w4 = reinterpret_cast<const float4*>(w2);
-#pragma unroll
-                for (int c = 0; c < 4 * RO_KS; c += 2) {
-                    const float4 wc = w4[c >> 1];                // (W[0][c], W[1][c], W[0][c+1], W[1][c+1])
-                    const float za = zv[rpos(c)], zb = zv[rpos(c + 1)];
-                    u2 = __builtin_elementwise_fma((f32x2){za, za}, (f32x2){wc.x, wc.y}, u2);
-                    u2b = __builtin_elementwise_fma((f32x2){zb, zb}, (f32x2){wc.z, wc.w}, u2b);
-                }
-                u2 = u2 + u2b;
-                uact[tid] = u2.x; uact[N + tid] = u2.y;
-                const float ub[2] = {u2.x, u2.y};
-                integrate_one(px, py, vx, vy, ub, 1, tid < p.n_leaders, p);
-                spx[tid] = px; spy[tid] = py; svx[tid] = vx; svy[tid] = vy;
-                const float sx = (float)(px - cref[0]), sy = (float)(py - cref[1]);   // fp32 coordinates relative to cref
-                sxy[tid] = make_float2(sx, sy);
+            if (agent) {
+                const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * 4 * RO_KS);
+                ux += bb.x; uy += bb.y;
+                uact[col] = ux; uact[N + col] = uy;
+                const float ub[2] = {ux, uy};
+                integrate_one(px, py, vx, vy, ub, 1, col < p.n_leaders, p);
+                spx[col] = px; spy[col] = py; svx[col] = vx; svy[col] = vy;
+                const float sx = (float)(px - cx), sy = (float)(py - cy);     // fp32 coordinates relative to cref
+                sxy[col] = make_float2(sx, sy);
                 m = fmaxf(fabsf(sx), fabsf(sy));
             }
             m = wave_max_to_last(m);
             if (lane == 63) atomicMax(mmax, __float_as_uint(m));  // non-negative floats order like their bit patterns
-        } else if (tid - 128 < 2 * N) {
-            rowmask[tid - 128] = 0ull;                        // this step's membership bits start empty
+        } else {
+            // meanwhile the other waves expand G_1 <- A_t from the membership bits of the previous simulator step (its dense
+            // rows are only read by the operator transition E, after two more barriers; tap 1 above used the lists), and
+            // clear the bits of the rows they have read: this step's membership pass starts from empty rows
+            const int nxw = RO_WAVES - NT;
+            const bool expand = t > 0 && K >= 3;
+            for (int i = 2 * (wave - NT) + (lane >> 5); i < N; i += 2 * nxw) {
+                if (expand) {
+                    const int c0 = hl * 4;
+                    const int nib = (int)(unsigned int)(rowmask[2 * i + (c0 >> 6)] >> (c0 & 63));
+                    const int wb = __float_as_int(wrow[i]);   // bit k set -> all-ones (v_bfe_i32) & weight bits: 2 ops / element
+                    if (hl < n4)
+                        *reinterpret_cast<float4*>(Gd + i * N + c0) =
+                            make_float4(__int_as_float(__builtin_amdgcn_sbfe(nib, 0, 1) & wb),
+                                        __int_as_float(__builtin_amdgcn_sbfe(nib, 1, 1) & wb),
+                                        __int_as_float(__builtin_amdgcn_sbfe(nib, 2, 1) & wb),
+                                        __int_as_float(__builtin_amdgcn_sbfe(nib, 3, 1) & wb));
+                }
+                if (hl < 2) rowmask[2 * i + hl] = 0ull;       // (same half-wave, after its own reads: LDS ops of a wave are ordered)
+            }
         }
         __syncthreads();
         RO_STAMP(3);
