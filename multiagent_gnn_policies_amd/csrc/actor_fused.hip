@@ -386,7 +386,6 @@ void actor_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G, 
 // Backward (parameters only).  Workgroup per (b, 64-column tile).  LDS: delta ping-pong [maxw][65],
 // input tile [maxin][65].  Partials: part[tile][P] with P = sum_l cout*cin + cout, layer-major (W then b).
 constexpr int AB_THREADS = 256;
-constexpr int AB_COLS = 64;
 
 struct BwdParams {
     const float* W[MGP_MAX_LAYERS];
@@ -396,16 +395,21 @@ struct BwdParams {
     int n_layers;
 };
 
+// COLS = agent columns per workgroup: 64 for large batches (few partials to add up), 16 for training batches (B = 20
+// gives 40 workgroups at 64 columns -- 31.7 us of one latency chain per workgroup; 140 workgroups at 16 columns).
+template <int COLS>
 __global__ __launch_bounds__(AB_THREADS)
 void actor_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ saved, float* __restrict__ part,
                       BwdParams P, long Ptot, int K, int N, int maxw, int maxin)
 {
+    constexpr int CS = COLS + 1;                        // LDS row stride (odd: conflict-free column walks)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* d0 = smem;                                   // [maxw][65]
-    float* d1 = d0 + (size_t)maxw * 65;                 // [maxw][65]
-    float* ins = d1 + (size_t)maxw * 65;                // [maxin][65]
+    float* d0 = smem;                                   // [maxw][CS]
+    float* d1 = d0 + (size_t)maxw * CS;                 // [maxw][CS]
+    float* ins = d1 + (size_t)maxw * CS;                // [maxin][CS]
+    float* wsh = ins + (size_t)maxin * CS;              // [maxw * maxin] weights of the layer (delta propagation)
     const int tid = threadIdx.x;
-    const int n0 = blockIdx.x * AB_COLS, b = blockIdx.y;
+    const int n0 = blockIdx.x * COLS, b = blockIdx.y;
     const int ntx = gridDim.x;
     float* my = part + ((size_t)b * ntx + blockIdx.x) * Ptot;
     const int L = P.n_layers;
@@ -413,25 +417,27 @@ void actor_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ 
 
     float* dcur = d0;
     float* dnext = d1;
-    for (int i = tid; i < nA * AB_COLS; i += AB_THREADS) {
-        const int o = i >> 6, cl = i & 63;
-        dcur[o * 65 + cl] = (n0 + cl < N) ? dOut[((size_t)b * nA + o) * N + n0 + cl] : 0.f;
+    for (int i = tid; i < nA * COLS; i += AB_THREADS) {
+        const int o = i / COLS, cl = i % COLS;
+        dcur[o * CS + cl] = (n0 + cl < N) ? dOut[((size_t)b * nA + o) * N + n0 + cl] : 0.f;
     }
     for (int l = L - 1; l >= 0; --l) {
         const int cin = (l == 0) ? P.dims[0] * K : P.dims[l];
         const int cout = P.dims[l + 1];
         const float* inb = saved + P.soff[l] + (size_t)b * cin * N;
-        __syncthreads();                                // dcur complete; previous users of ins/dnext done
-        for (int i = tid; i < cin * AB_COLS; i += AB_THREADS) {
-            const int c = i >> 6, cl = i & 63;
-            ins[c * 65 + cl] = (n0 + cl < N) ? inb[(size_t)c * N + n0 + cl] : 0.f;
+        __syncthreads();                                // dcur complete; previous users of ins/dnext/wsh done
+        for (int i = tid; i < cin * COLS; i += AB_THREADS) {
+            const int c = i / COLS, cl = i % COLS;
+            ins[c * CS + cl] = (n0 + cl < N) ? inb[(size_t)c * N + n0 + cl] : 0.f;
         }
+        if (l > 0)
+            for (int i = tid; i < cout * cin; i += AB_THREADS) wsh[i] = P.W[l][i];
         __syncthreads();
         float* myl = my + P.poff[l];
         // db
         for (int o = tid; o < cout; o += AB_THREADS) {
             float s = 0.f;
-            for (int cl = 0; cl < AB_COLS; ++cl) s += dcur[o * 65 + cl];
+            for (int cl = 0; cl < COLS; ++cl) s += dcur[o * CS + cl];
             myl[(size_t)cout * cin + o] = s;
         }
         // dW[o][c] = sum_cols delta[o][col] * in[c][col]
@@ -439,23 +445,25 @@ void actor_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ 
             const int o = p / cin, c = p - o * cin;
             float s = 0.f;
 #pragma unroll 8
-            for (int cl = 0; cl < AB_COLS; ++cl) s = fmaf(dcur[o * 65 + cl], ins[c * 65 + cl], s);
+            for (int cl = 0; cl < COLS; ++cl) s = fmaf(dcur[o * CS + cl], ins[c * CS + cl], s);
             myl[p] = s;
         }
         // delta_{l-1}[c][col] = (sum_o W[o][c] delta[o][col]) * (1 - in[c][col]^2)     (inputs of l>=1 are tanh outputs)
         if (l > 0) {
-            const float* Wl = P.W[l];
-            const int col = tid & 63, cgp = tid >> 6;
-            for (int c = cgp; c < cin; c += AB_THREADS / 64) {
+            const int col = tid % COLS, cgp = tid / COLS;
+            for (int c = cgp; c < cin; c += AB_THREADS / COLS) {
                 float s = 0.f;
-                for (int o = 0; o < cout; ++o) s = fmaf(Wl[(size_t)o * cin + c], dcur[o * 65 + col], s);
-                const float z = ins[c * 65 + col];
-                dnext[c * 65 + col] = s * (1.f - z * z);
+                for (int o = 0; o < cout; ++o) s = fmaf(wsh[o * cin + c], dcur[o * CS + col], s);
+                const float z = ins[c * CS + col];
+                dnext[c * CS + col] = s * (1.f - z * z);
             }
             float* t = dcur; dcur = dnext; dnext = t;
         }
     }
 }
+
+// columns per backward workgroup for a (B, N) problem: enough workgroups to cover the chip
+inline int bwd_cols(int B, int N) { return ((long)B * ((N + 63) / 64) >= 256) ? 64 : 16; }
 
 // scatter the reduced flat block into the caller's dW[l] / db[l] buffers
 struct ScatterParams {
@@ -466,13 +474,20 @@ struct ScatterParams {
     int bsz[MGP_MAX_LAYERS];
     int n_layers;
 };
+// workgroup = 64 parameters x 4 interleaved groups of tiles; the four group sums are added in fixed order (deterministic)
 __global__ __launch_bounds__(256)
 void actor_bwd_scatter_kernel(const float* __restrict__ part, ScatterParams S, long Ptot, long ntiles)
 {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= Ptot) return;
+    __shared__ float sh[4][64];
+    const int pl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + pl;
     float s = 0.f;
-    for (long t = 0; t < ntiles; ++t) s += part[t * Ptot + i];
+    if (i < Ptot)
+        for (long t = g; t < ntiles; t += 4) s += part[t * Ptot + i];
+    sh[g][pl] = s;
+    __syncthreads();
+    if (g != 0 || i >= Ptot) return;
+    s = ((sh[0][pl] + sh[1][pl]) + sh[2][pl]) + sh[3][pl];
     int l = 0;
     while (l + 1 < S.n_layers && i >= S.poff[l + 1]) ++l;
     const long j = i - S.poff[l];
@@ -609,7 +624,8 @@ static long bwd_param_count(const int* dims, int n_layers, int K)
 extern "C" long mgp_actor_bwd_workspace(const int* dims, int n_layers, int B, int K, int N)
 {
     if (dims == nullptr || n_layers <= 0 || n_layers > MGP_MAX_LAYERS || B <= 0 || K <= 0 || N <= 0) return 0;
-    const long ntiles = (long)B * ((N + AB_COLS - 1) / AB_COLS);
+    const int cols = bwd_cols(B, N);
+    const long ntiles = (long)B * ((N + cols - 1) / cols);
     return ntiles * bwd_param_count(dims, n_layers, K);
 }
 
@@ -643,20 +659,25 @@ extern "C" int mgp_actor_bwd(const float* dOut, const float* saved, const float*
         if (cin > maxw && l > 0) maxw = cin;
     }
     const long Ptot = poff;
-    const size_t lds = ((size_t)2 * maxw * 65 + (size_t)maxin * 65) * sizeof(float);
+    const int cols = bwd_cols(B, N);
+    const size_t lds = ((size_t)2 * maxw * (cols + 1) + (size_t)maxin * (cols + 1) + (size_t)maxw * maxin) * sizeof(float);
     if (lds > AF_LDS_LIMIT) return MGP_EUNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     mgp_clear_error();
-    if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(actor_bwd_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    const void* kfn = (cols == 64) ? reinterpret_cast<const void*>(actor_bwd_kernel<64>)
+                                   : reinterpret_cast<const void*>(actor_bwd_kernel<16>);
+    if (lds > 48 * 1024 && hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return MGP_ELAUNCH;
-    const int ntx = (N + AB_COLS - 1) / AB_COLS;
-    hipLaunchKernelGGL(actor_bwd_kernel, dim3(ntx, B), dim3(AB_THREADS), lds, st, dOut, saved, workspace, P, Ptot,
-                       K, N, maxw, maxin);
+    const int ntx = (N + cols - 1) / cols;
+    if (cols == 64)
+        hipLaunchKernelGGL(actor_bwd_kernel<64>, dim3(ntx, B), dim3(AB_THREADS), lds, st, dOut, saved, workspace, P, Ptot, K, N,
+                           maxw, maxin);
+    else
+        hipLaunchKernelGGL(actor_bwd_kernel<16>, dim3(ntx, B), dim3(AB_THREADS), lds, st, dOut, saved, workspace, P, Ptot, K, N,
+                           maxw, maxin);
     int rc = mgp_launch_status();
     if (rc != MGP_OK) return rc;
-    hipLaunchKernelGGL(actor_bwd_scatter_kernel, dim3((unsigned)((Ptot + 255) / 256)), dim3(256), 0, st, workspace, S,
-                       Ptot, (long)B * ntx);
+    hipLaunchKernelGGL(actor_bwd_scatter_kernel, dim3((unsigned)((Ptot + 63) / 64)), dim3(256), 0, st, workspace, S, Ptot,
+                       (long)B * ntx);
     return mgp_launch_status();
 }

@@ -12,7 +12,7 @@
 // state once on entry and once on exit (plus one reward per step).  Slice 0 of G is the identity by construction
 // (state_with_delay.py:44) and is neither read nor written: tap 0 of the aggregation is X_0 itself.
 //
-// Per step (barrier-separated phases, all arithmetic identical in kind to the stand-alone kernels):
+// Per step (five workgroup barriers; all arithmetic identical in kind to the stand-alone kernels):
 //   A  aggregation  y[(f,k), n] = sum_m X_k[f, m] * G_k[m, n]  from LDS.  Taps k >= 2 (dense slices) run on the matrix
 //      cores, one wave per (tap, 16-column tile): D[f, n] += X[f, m..m+3] G[m..m+3, n] as fp32 16x16x4 MFMAs -- the phase
 //      is instruction-issue bound (one workgroup per CU), and one MFMA retires 384 useful MACs per issue slot where a
@@ -20,9 +20,10 @@
 //      X_0 itself.  Results land in MFMA B-fragment order.
 //   B  filter GEMM + tanh hidden layers on fp32 MFMA 16x16x4 (k-ordered fmaf chain, 1e-5 budget): a wave owns 16 agent
 //      columns through every hidden layer, activations in place in LDS, no barrier between layers.
-//   C  one thread per agent: the 2-wide output layer as a packed-FMA chain (a 16-row MFMA tile would be 7/8 padding),
-//      then the fp64 integration of the agent (same expression tree as flock.hip / the oracle: bit-exact given the
-//      action) and its fp32 coordinates for D1.
+//   C  the same wave, no barrier: the 2-wide output layer as a packed-FMA chain (a 16-row MFMA tile would be 7/8
+//      padding; a lane takes 8 channels of its column, four lanes are added), then the fp64 integration of the agent (same
+//      expression tree as flock.hip / the oracle: bit-exact given the action) and its fp32 coordinates for D1.
+//      Meanwhile the nine waves without columns expand G_1 <- A_t from the previous step's membership bits.
 //   D  D1 membership: every unordered pair once (row i tests offsets 1..N/2, 8 threads per row); an fp32 test on
 //      coordinates relative to a reference point decides pairs that are clear of the radius by a proven error band, the
 //      exact fp64 expression of the spec decides the rest -- the bits are always the oracle's.  Both rows of a pair get
@@ -30,8 +31,7 @@
 //      sum the fp64 feature terms of actual neighbours.  One otherwise idle wave computes the step's reward.
 //   E  G_j <- A_t . G_{j-1} for j = K-1 .. 2 (row gathers in LDS along the neighbour lists, ascending order, fmaf
 //      chain: the same arithmetic as gso.hip; lists are padded with the index of an all-zero row, so there is no tail
-//      code).  G_1 <- A_t itself is expanded from the membership bits by the waves that idle during phase B of the next
-//      step (and once on exit).  The delay line is a ring: the new features overwrite the oldest tap, nothing is shifted.
+//      code).  G_1 <- A_t itself is expanded during phase B/C of the next step (and once on exit).  The delay line is a ring: the new features overwrite the oldest tap, nothing is shifted.
 // This translation unit is built with -ffp-contract=off (fp64 spec arithmetic); fp32 fused multiply-adds are explicit.
 #include "mgp_device.h"
 

@@ -116,7 +116,13 @@ class GraphedUpdate(object):
                    'mgp_adam_step_dev')
 
     def run(self, X, G, Y):
-        self.X.copy_(X); self.G.copy_(G); self.Y.copy_(Y)
+        # callers that gathered their batch straight into the static buffers (DeviceReplay.sample(out=...)) skip the copies
+        if X is not self.X:
+            self.X.copy_(X)
+        if G is not self.G:
+            self.G.copy_(G)
+        if Y is not self.Y:
+            self.Y.copy_(Y)
         if self.graph is None:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -184,13 +190,27 @@ class DAGGER(object):
         optimal_action_batch = torch.cat(batch.action).to(self.device)
         return self.gradient_step_tensors(delay_state_batch, delay_gso_batch, optimal_action_batch)
 
-    def gradient_step_tensors(self, delay_state_batch, delay_gso_batch, optimal_action_batch):
+    def graphed_buffers(self, B, N):
+        """(X, G, Y) static input buffers of the HIP-graph update for batch size B, or None when updates run eagerly
+        (distributed run / shape outside the fused kernels): gather a batch straight into them to skip three copies."""
+        probe = torch.empty((0, self.actor.k, self.n_states, N), device=self.device)
+        if not self._can_graph(probe):
+            return None
+        gu = self._graphed.get(B)
+        if gu is None:
+            gu = self._graphed[B] = GraphedUpdate(self, B)
+        return gu.X, gu.G, gu.Y
+
+    def gradient_step_tensors(self, delay_state_batch, delay_gso_batch, optimal_action_batch, sync=True):
+        """One update on device tensors.  sync=False returns the loss as a (1,) device tensor (graph path only) so the
+        host can queue the next update without waiting for this one."""
         if self._can_graph(delay_state_batch):
             B = delay_state_batch.shape[0]
             gu = self._graphed.get(B)
             if gu is None:
                 gu = self._graphed[B] = GraphedUpdate(self, B)
-            return gu.run(delay_state_batch, delay_gso_batch, optimal_action_batch).item()
+            loss = gu.run(delay_state_batch, delay_gso_batch, optimal_action_batch)
+            return loss.item() if sync else loss.clone()
         self.actor_optim.zero_grad()
         actor_batch = self.actor(delay_state_batch, delay_gso_batch)
         policy_loss = ops.mse_loss(actor_batch, optimal_action_batch)

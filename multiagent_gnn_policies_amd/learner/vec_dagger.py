@@ -47,10 +47,16 @@ class DeviceReplay(object):
         self.position = (self.position + B) % self.max_size
         self.curr_size = min(self.max_size, self.curr_size + B)
 
-    def sample(self, num_samples):
-        """Without replacement, Python `random` RNG (reference replay_buffer.py:40)."""
+    def sample(self, num_samples, out=None):
+        """Without replacement, Python `random` RNG (reference replay_buffer.py:40).  `out` = (X, G, Y) destination
+        tensors (e.g. the static buffers of the HIP-graph update): the gather is then the only copy of the batch."""
         ids = random.sample(range(self.curr_size), num_samples)
         idx = torch.tensor(ids, device=self.device, dtype=torch.long)
+        if out is not None:
+            torch.index_select(self.delay_state, 0, idx, out=out[0])
+            torch.index_select(self.delay_gso, 0, idx, out=out[1])
+            torch.index_select(self.action, 0, idx, out=out[2])
+            return out
         return (self.delay_state.index_select(0, idx), self.delay_gso.index_select(0, idx),
                 self.action.index_select(0, idx))
 
@@ -127,10 +133,16 @@ def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
             state.advance()
         loss_sum = 0.0
         if memory.curr_size > batch_size:
+            bufs = learner.graphed_buffers(batch_size, N)        # None: eager / distributed updates
+            loss_dev = torch.zeros((1,), device=device)
             for _ in range(updates_per_step * n_envs):
-                xs, gs, ys = memory.sample(batch_size)
-                loss_sum += learner.gradient_step_tensors(xs, gs, ys)
+                xs, gs, ys = memory.sample(batch_size, out=bufs)
+                if bufs is not None:                              # no host sync per update: losses add up on the device
+                    loss_dev += learner.gradient_step_tensors(xs, gs, ys, sync=False)
+                else:
+                    loss_sum += learner.gradient_step_tensors(xs, gs, ys)
                 updates += 1
+            loss_sum += float(loss_dev.item())
         if debug and rank == 0:
             print("Round: {}, episodes: {}, updates: {}, policy loss: {}".format(rd, (rd + 1) * n_envs * world,
                                                                                    updates, loss_sum))
