@@ -474,20 +474,24 @@ struct ScatterParams {
     int bsz[MGP_MAX_LAYERS];
     int n_layers;
 };
-// workgroup = 64 parameters x 4 interleaved groups of tiles; the four group sums are added in fixed order (deterministic)
-__global__ __launch_bounds__(256)
+// workgroup = 64 parameters x 16 interleaved groups of tiles (the per-parameter chain of dependent loads is what this
+// kernel costs); the sixteen group sums are added in fixed order (deterministic)
+constexpr int SC_GROUPS = 16;
+__global__ __launch_bounds__(64 * SC_GROUPS)
 void actor_bwd_scatter_kernel(const float* __restrict__ part, ScatterParams S, long Ptot, long ntiles)
 {
-    __shared__ float sh[4][64];
+    __shared__ float sh[SC_GROUPS][64];
     const int pl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * 64 + pl;
     float s = 0.f;
     if (i < Ptot)
-        for (long t = g; t < ntiles; t += 4) s += part[t * Ptot + i];
+        for (long t = g; t < ntiles; t += SC_GROUPS) s += part[t * Ptot + i];
     sh[g][pl] = s;
     __syncthreads();
     if (g != 0 || i >= Ptot) return;
-    s = ((sh[0][pl] + sh[1][pl]) + sh[2][pl]) + sh[3][pl];
+    s = 0.f;
+#pragma unroll
+    for (int q = 0; q < SC_GROUPS; ++q) s += sh[q][pl];
     int l = 0;
     while (l + 1 < S.n_layers && i >= S.poff[l + 1]) ++l;
     const long j = i - S.poff[l];
@@ -677,7 +681,7 @@ extern "C" int mgp_actor_bwd(const float* dOut, const float* saved, const float*
                            maxw, maxin);
     int rc = mgp_launch_status();
     if (rc != MGP_OK) return rc;
-    hipLaunchKernelGGL(actor_bwd_scatter_kernel, dim3((unsigned)((Ptot + 63) / 64)), dim3(256), 0, st, workspace, S, Ptot,
+    hipLaunchKernelGGL(actor_bwd_scatter_kernel, dim3((unsigned)((Ptot + 63) / 64)), dim3(64 * SC_GROUPS), 0, st, workspace, S, Ptot,
                        (long)B * ntx);
     return mgp_launch_status();
 }

@@ -70,6 +70,39 @@ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* 
 
 __global__ void step_inc_kernel(int* step_dev) { *step_dev += 1; }
 
+// Small parameter sets (the reference Actor has 1,730): ONE workgroup applies the step and advances the device-side
+// step counter itself -- one graph node instead of two, and the bias corrections (two fp64 pow) are computed once, not
+// once per thread.  Same arithmetic per element as adam_dev_kernel.
+__global__ __launch_bounds__(1024)
+void adam_dev_onewg_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                           float* __restrict__ v, long n, float lr, float b1, float b2, float eps, int* __restrict__ step_dev)
+{
+    __shared__ float sh[2];
+    __shared__ int shs;
+    if (threadIdx.x == 0) {
+        const int s0 = *step_dev;
+        const double step = (double)(s0 + 1);
+        const double bc1 = 1.0 - pow((double)b1, step);
+        const double bc2 = 1.0 - pow((double)b2, step);
+        sh[0] = (float)((double)lr / bc1);
+        sh[1] = (float)sqrt(bc2);
+        shs = s0;
+    }
+    __syncthreads();
+    const float step_size = sh[0], bc2_sqrt = sh[1];
+    const float one_m_b1 = (float)(1.0 - (double)b1), one_m_b2 = (float)(1.0 - (double)b2);
+    for (long i = threadIdx.x; i < n; i += 1024) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * one_m_b1;
+        const float vi = v[i] * b2 + one_m_b2 * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
+    }
+    if (threadIdx.x == 0) *step_dev = shs + 1;
+}
+
 }  // namespace
 
 extern "C" int mgp_adam_step_dev(float* param, const float* grad, float* m, float* v, long n,
@@ -79,6 +112,11 @@ extern "C" int mgp_adam_step_dev(float* param, const float* grad, float* m, floa
     MGP_CHECK_PTR(param); MGP_CHECK_PTR(grad); MGP_CHECK_PTR(m); MGP_CHECK_PTR(v); MGP_CHECK_PTR(step_dev);
     mgp_clear_error();
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n <= 32768) {
+        hipLaunchKernelGGL(adam_dev_onewg_kernel, dim3(1), dim3(1024), 0, st, param, grad, m, v, n, lr, beta1, beta2, eps,
+                           step_dev);
+        return mgp_launch_status();
+    }
     hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, param, grad, m, v, n,
                        lr, beta1, beta2, eps, step_dev);
     hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step_dev);
