@@ -12,7 +12,15 @@ from ._lib import MgpError, MgpFlockParams
 ACT_NONE, ACT_TANH = 0, 1
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    """Handle of the HIP stream torch is currently enqueuing on (honours torch.cuda.stream(...) and graph capture).
+    The raw accessor costs ~1 us; building a torch.cuda.Stream object first costs ~10 us -- four of them per
+    environment step of the one-environment loops."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
