@@ -17,9 +17,17 @@ from .. import ops
 class MultiAgentStateWithDelay(object):
 
     def __init__(self, device, args, env_state, prev_state=None, k=None):
-        n_states = args.getint('n_states')
-        n_agents = args.getint('n_agents')
-        k = k or args.getint('k')
+        # the three cfg lookups of the reference constructor (state_with_delay.py:14-16), parsed once per cfg section:
+        # configparser's getint costs ~6 us a call and this constructor runs once per environment step
+        shape = getattr(args, '_mgp_state_shape', None)
+        if shape is None:
+            shape = (args.getint('n_states'), args.getint('n_agents'), args.getint('k'))
+            try:
+                args._mgp_state_shape = shape
+            except AttributeError:
+                pass
+        n_states, n_agents = shape[0], shape[1]
+        k = k or shape[2]
 
         state_value, state_network = env_state
         # contract of reference state_with_delay.py:24-26
