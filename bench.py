@@ -254,6 +254,69 @@ def cpu_baseline(N, K, hidden, budget_s=12.0):
                 ms_per_env_step=1e3 * best[3] / best[2])
 
 
+def dagger_update_bench():
+    """Secondary measurement (`bench.py --dagger-update`): one DAGGER gradient_step at the reference's training
+    shape (cfg/dagger.cfg: B=20, N=100, K=3) on the HIP path -- fused forward + MSE gradient + fused backward + flat
+    Adam, replayed from one HIP graph -- next to the same op sequence of the CPU port (torch autograd + Adam; this is
+    the cpu_baseline leg of the update measurement: the only place this function touches oracle/)."""
+    import configparser
+    from multiagent_gnn_policies_amd.learner.gnn_dagger import DAGGER
+    B, N, K = 20, 100, 3
+    cp = configparser.ConfigParser()
+    cp['DEFAULT'] = dict(n_states='6', n_actions='2', k=str(K), hidden_size='32', gamma='0.99', tau='0.5',
+                         n_agents=str(N), actor_lr='5e-5')
+    cp['t'] = {}
+    torch.manual_seed(11)
+    dev = torch.device('cuda:0')
+    learner = DAGGER(dev, cp['t'])
+    gen = torch.Generator(device=dev).manual_seed(0)
+    xd = torch.randn((B, K, F_FEAT, N), device=dev, generator=gen)
+    mask = torch.rand((B, K, N, N), device=dev, generator=gen) < (8.0 / N)
+    gd = mask.float() / mask.float().sum(-1, keepdim=True).clamp(min=1)
+    gd[:, 0] = torch.eye(N, device=dev)
+    yd = torch.randn((B, 1, N_ACT, N), device=dev, generator=gen)
+    for _ in range(20):
+        learner.gradient_step_tensors(xd, gd, yd)
+    torch.cuda.synchronize()
+    n = 300
+    t0 = time.perf_counter()
+    for _ in range(n):
+        learner.gradient_step_tensors(xd, gd, yd)                 # drop-in semantics: the host reads every loss
+    torch.cuda.synchronize()
+    gpu_ms = 1e3 * (time.perf_counter() - t0) / n
+    t0 = time.perf_counter()
+    for _ in range(n):
+        learner.gradient_step_tensors(xd, gd, yd, sync=False)     # vectorised DAGGER: losses stay on the device
+    torch.cuda.synchronize()
+    gpu_ms_pipe = 1e3 * (time.perf_counter() - t0) / n
+    from oracle import torch_port                          # CPU leg
+    res = {}
+    xc, gc, yc = xd.cpu(), gd.cpu(), yd.cpu()
+    for thr in sorted({1, torch.get_num_threads()}):
+        torch.set_num_threads(thr)
+        Ws = [torch.nn.Parameter(c.weight.detach().cpu().clone()) for c in learner.actor.conv_layers]
+        bs = [torch.nn.Parameter(c.bias.detach().cpu().clone()) for c in learner.actor.conv_layers]
+        opt = torch.optim.Adam(Ws + bs, lr=5e-5)
+
+        def step():
+            opt.zero_grad()
+            out = torch_port.actor_forward(xc, gc, Ws, bs, 0, K)
+            loss = torch.nn.functional.mse_loss(out, yc)
+            loss.backward()
+            opt.step()
+            return loss.item()
+        for _ in range(5):
+            step()
+        t0 = time.perf_counter()
+        m = 100
+        for _ in range(m):
+            step()
+        res[thr] = 1e3 * (time.perf_counter() - t0) / m
+    return {"update": "DAGGER gradient_step B=20 N=100 K=3", "hip_ms": gpu_ms, "hip_updates_per_s": 1e3 / gpu_ms,
+            "hip_ms_pipelined": gpu_ms_pipe, "hip_updates_per_s_pipelined": 1e3 / gpu_ms_pipe,
+            "cpu_port_ms_by_threads": res, "host_cores": os.cpu_count()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -268,7 +331,14 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-resident', action='store_true', help='time only the two-launch dense path')
+    ap.add_argument('--dagger-update', action='store_true',
+                    help='secondary measurement: DAGGER updates/s at B=20 (prints its own JSON line and exits)')
     args = ap.parse_args()
+    if args.dagger_update:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU path)")
+        print(json.dumps(dagger_update_bench()))
+        return
 
     rank, world, local = parallel.init_from_env()
     if world != args.gpus and world > 1:
