@@ -1,0 +1,19 @@
+"""Copy the outputs of tools/regen_profiles.sh (gpurun_out/final/) into profiles/r01_* (run from the repo root)."""
+import sys
+sys.path.insert(0, ".")
+import json, shutil, os
+O='gpurun_out/final'
+d=json.loads(open(O+'/bench_final.json').read().strip().splitlines()[-1])
+print('value %.4g ms/step %.5f' % (d['value'], d['ms_per_step']), 'traffic', d['roofline']['traffic'], 'frac %.3f' % d['roofline']['frac'], 'paths', {k: '%.3g' % v['value'] for k,v in d['paths'].items()}, 'cpu %.3g' % d['cpu_baseline']['value'])
+d2=json.loads(open(O+'/bench_under_rocprof.json').read().strip().splitlines()[-1])
+print('under rocprof %.4g' % d2['value'])
+shutil.copy(O+'/pmc_traffic.json','profiles/r01_pmc_traffic.json')
+shutil.copy(O+'/pmc_hbm_traffic.txt','profiles/r01_pmc_hbm_traffic.txt')
+open('profiles/r01_bench_final.json','w').write(json.dumps(d)+'\n')
+open('profiles/r01_bench_final_under_rocprof.json','w').write(json.dumps(d2)+'\n')
+shutil.copy(O+'/bench_kernel_trace.txt','profiles/r01_bench_kernel_trace_final.txt')
+shutil.copy(O+'/dagger_update.json','profiles/r01_dagger_update.json')
+hdr = "# bench.py at other shapes (B N K): value, per-path throughput, per-kernel (avg launch us, GB/s), state finite\n# `resident` = mgp_rollout_steps (covered: N <= 128, N % 4 == 0, state fits LDS); otherwise the two-launch path is `value`\n"
+open('profiles/r01_other_configs.txt','w').write(hdr+open(O+'/other_configs.txt').read())
+from multiagent_gnn_policies_amd import build
+print('hash ok', build.source_hash() == json.load(open('profiles/r01_pmc_traffic.json'))['_meta']['source_hash'])
