@@ -11,8 +11,12 @@ shutil.copy(O+'/pmc_traffic.json','profiles/r01_pmc_traffic.json')
 shutil.copy(O+'/pmc_hbm_traffic.txt','profiles/r01_pmc_hbm_traffic.txt')
 open('profiles/r01_bench_final.json','w').write(json.dumps(d)+'\n')
 open('profiles/r01_bench_final_under_rocprof.json','w').write(json.dumps(d2)+'\n')
-shutil.copy(O+'/bench_kernel_trace.txt','profiles/r01_bench_kernel_trace_final.txt')
-shutil.copy(O+'/dagger_update.json','profiles/r01_dagger_update.json')
+_kt = open(O+'/bench_kernel_trace.txt').read().splitlines(True)
+_note = ("# NOTE rollout_kernel<100, 3>: 2 launches = the 100-step warm-up launch (min_us) and the 1000-step TIMED launch (max_us);\n"
+         "#      bench.py's roofline.avg_launch_ms (HIP events around the timed launch) is the max_us figure, not avg_us.\n"
+         "#      The other kernels belong to the two-launch path (timed in the same run) and to the stand-alone roofline leg.\n")
+open('profiles/r01_bench_kernel_trace_final.txt','w').write(''.join(_kt[:2]) + _note + ''.join(_kt[2:]))
+shutil.copy(O+'/dagger_update.json','profiles/r01_dagger_update.json')   # produced by `python bench.py --dagger-update`
 hdr = "# bench.py at other shapes (B N K): value, per-path throughput, per-kernel (avg launch us, GB/s), state finite\n# `resident` = mgp_rollout_steps (covered: N <= 128, N % 4 == 0, state fits LDS); otherwise the two-launch path is `value`\n"
 open('profiles/r01_other_configs.txt','w').write(hdr+open(O+'/other_configs.txt').read())
 from multiagent_gnn_policies_amd import build
