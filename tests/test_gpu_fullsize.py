@@ -120,3 +120,45 @@ def test_rollout_cfg2_finite_and_deterministic():
         outs.append((ro.sim.x.clone(), ro.state.delay_gso.clone()))
     assert torch.isfinite(outs[0][0]).all()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_resident_rollout_cfg2_properties_full_size():
+    """cfg-2 on the episode-resident kernel (what bench.py times): structural properties of the state after a long
+    launch, the operator recursion across one more step checked with an independent device matmul, exact chunking and
+    run-to-run determinism at full size."""
+    import bench
+    B, N, K = CFGS['cfg2']
+
+    def fresh():
+        return bench.Rollout(torch.device('cuda:0'), B, N, K, [32, 32], seed=1000)
+
+    ro = fresh()
+    assert ro.resident_supported()
+    ro.run_resident(300)
+    G = ro.state.delay_gso.clone(); X = ro.state.delay_state.clone(); x = ro.sim.x.clone()
+    assert torch.isfinite(x).all() and torch.isfinite(G).all() and torch.isfinite(X).all()
+    eye = torch.eye(N, device='cuda')
+    assert torch.equal(G[:, 0], eye.expand(B, N, N))                       # slice 0 untouched
+    A = G[:, 1]
+    assert torch.all(torch.diagonal(A, dim1=1, dim2=2) == 0)               # no self loops
+    pat = A != 0
+    assert torch.equal(pat, pat.transpose(1, 2))                            # symmetric radius graph
+    deg = pat.sum(-1, keepdim=True).clamp(min=1).float()
+    assert torch.equal(A, pat.float() / deg)                                # mean pooling: row value = 1 / degree, exactly
+    # one more step: G_2' = A_new . G_1(old) (independent device matmul), delay line = pure shift
+    ro.run_resident(1)
+    G2 = ro.state.delay_gso; X2 = ro.state.delay_state
+    ref = torch.matmul(G2[:, 1].double(), A.double())
+    assert (G2[:, 2].double() - ref).abs().max().item() <= 1e-6
+    assert torch.equal(X2[:, 1:], X[:, :-1])
+    assert ro._rw.shape == (B, 1) and torch.all(ro._rw <= 0)
+    # chunking and determinism at full size
+    outs = []
+    for chunks in ([60], [25, 35], [60]):
+        r = fresh()
+        for c in chunks:
+            r.run_resident(c)
+        outs.append((r.sim.x.clone(), r.state.delay_gso.clone(), r.state.delay_state.clone()))
+    for o in outs[1:]:
+        for a, b_ in zip(outs[0], o):
+            assert torch.equal(a, b_)
