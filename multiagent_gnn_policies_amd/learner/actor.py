@@ -6,7 +6,6 @@ loads and default initialisation consumes the torch RNG exactly like the referen
 NOT ATen: aggregation, filter GEMM, tanh MLP readout and their backward are the HIP kernels of
 libmgp.so (ops.py).  `nn.Conv2d` modules are kept purely as parameter containers.
 """
-import torch
 import torch.nn as nn
 
 from .. import ops

@@ -328,4 +328,4 @@ def adam_step(param, grad, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
 
 __all__ = ['MgpFlockParams', 'MgpError', 'aggregate', 'dense', 'agg_fwd', 'agg_bwd_x', 'dense_fwd', 'dense_bwd',
            'gso_update', 'gso_update_into', 'gso_powers', 'flock_step', 'flock_controller', 'mse_grad', 'mse_loss',
-           'adam_step', 'ACT_NONE', 'ACT_TANH']
+           'gso_advance', 'flock_step_advance', 'rollout_supported', 'rollout_steps', 'adam_step', 'ACT_NONE', 'ACT_TANH']

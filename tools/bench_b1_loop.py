@@ -2,7 +2,7 @@
 """Reference-style B=1 loop speed (BASELINE.json configs[0]): gym facade + MultiAgentStateWithDelay + select_action,
 exactly as train_dagger's test loop runs it, vs the torch-CPU port of the same loop."""
 import configparser, json, os, sys, time
-import numpy as np, torch
+import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from multiagent_gnn_policies_amd import envs

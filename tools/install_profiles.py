@@ -1,7 +1,7 @@
 """Copy the outputs of tools/regen_profiles.sh (gpurun_out/final/) into profiles/r01_* (run from the repo root)."""
 import sys
 sys.path.insert(0, ".")
-import json, shutil, os
+import json, shutil
 O='gpurun_out/final'
 d=json.loads(open(O+'/bench_final.json').read().strip().splitlines()[-1])
 print('value %.4g ms/step %.5f' % (d['value'], d['ms_per_step']), 'traffic', d['roofline']['traffic'], 'frac %.3f' % d['roofline']['frac'], 'paths', {k: '%.3g' % v['value'] for k,v in d['paths'].items()}, 'cpu %.3g' % d['cpu_baseline']['value'])
