@@ -54,6 +54,8 @@ CASES = [
     # N, K, hidden, variant
     (100, 3, (32, 32), {}),
     (100, 3, (32, 32), {'mean_pooling': False, 'n_leaders': 2}),
+    (100, 4, (32, 32), {}),                        # K - 1 dense slices do not fit: slice 1 kept as bits + row weights
+    (128, 3, (32,), {'comm_radius': 1.2}),         # packed as well
     (100, 2, (16,), {}),
     (100, 1, (32, 32), {}),
     (128, 2, (32, 32), {'comm_radius': 1.5}),
@@ -96,7 +98,7 @@ def test_rollout_single_steps_match_oracle(N, K, hidden, variant):
             assert abs(rewards[b, 0].item() - r) <= 1e-12 * max(1.0, abs(r))
 
 
-@pytest.mark.parametrize('N,K,hidden,variant', CASES[:3] + CASES[5:6])
+@pytest.mark.parametrize('N,K,hidden,variant', CASES[:4] + CASES[7:8])
 def test_rollout_chunking_is_exact(N, K, hidden, variant):
     """T steps in one launch == T launches of one step, bit for bit (state, last action, every reward)."""
     from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
@@ -141,12 +143,13 @@ def test_rollout_agrees_with_two_launch_path():
 def test_rollout_unsupported_shapes_fall_back():
     from multiagent_gnn_policies_amd import ops
     assert not ops.rollout_supported((6, 64, 64, 2), 3, 100)      # 64-wide layers: not in the resident kernel
-    assert not ops.rollout_supported((6, 32, 32, 2), 4, 100)      # K = 4 at N = 100 does not fit the LDS
+    assert ops.rollout_supported((6, 32, 32, 2), 4, 100)          # K = 4 at N = 100: packed slice 1
+    assert not ops.rollout_supported((6, 32, 32, 2), 5, 100)      # K = 5 at N = 100 does not fit the LDS either way
     assert not ops.rollout_supported((6, 32, 32, 2), 3, 130)
     assert not ops.rollout_supported((6, 32, 32, 3), 3, 100)      # the simulator takes 2-D actions
     assert ops.rollout_supported((6, 32, 32, 2), 3, 100)
     from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
-    rs, op, actor, sim, st = _make(100, 4, (32, 32), 2, seed=1)
+    rs, op, actor, sim, st = _make(100, 5, (32, 32), 2, seed=1)
     rewards = torch.zeros((2, 3), device='cuda', dtype=torch.float64)
     assert policy_rollout(actor, sim, st, 3, rewards=rewards) is False
     assert torch.isfinite(rewards).all() and (rewards < 0).all()
