@@ -746,6 +746,8 @@ extern "C" int mgp_rollout_steps(double* x, float* G, float* Xd, const float* co
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (N == 100 && K == 3)       // the headline shape (BASELINE.json configs[0..1]) runs a build with compile-time addresses
         return launch_rollout<100, 3, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
+    if (N == 100 && K == 2 && !packed)   // cfg/default.cfg, cloning.cfg, dagger_twoflocks.cfg
+        return launch_rollout<100, 2, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
     // (a <100, 4, true> instantiation trips an LLVM backend error -- "Operand has incorrect register class" -- on this
     //  toolchain; the reference's K = 4 sweeps at N = 100 run the generic packed build, 2.7e9 agent-steps/s)
     if (packed)                   // slice 1 kept as bits + row weights
