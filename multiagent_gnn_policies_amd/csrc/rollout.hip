@@ -229,17 +229,23 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         for (int e = tid; e < N; e += RO_THREADS) Gd[(size_t)(j - SL0) * NS + NN + e] = 0.f;
     }
     if (tid < (PK ? 4 : 2)) rowmask[2 * N + (tid & 1) + (tid >> 1) * 2 * (N + 1)] = 0ull;   // row N (list padding) of the bit buffer(s)
-    if (PK && K >= 2)                                         // packed slice 1: bits + row weight from the caller's dense rows
-        for (int i = tid; i < N; i += RO_THREADS) {
-            unsigned long long lo = 0ull, hi = 0ull;
-            float w = 0.f;
-            const float* grow = Gb + NN + (size_t)i * N;
-            for (int n = 0; n < N; ++n) {
-                const float v = grow[n];
-                if (v != 0.f) { w = v; if (n < 64) lo |= 1ull << n; else hi |= 1ull << (n - 64); }
+    if (PK && K >= 2) {
+        // packed slice 1: bits + row weight from the caller's dense rows -- coalesced float4 reads of the whole slice, every
+        // lane ORs its four pattern bits into the row's words (weights are non-negative, so their float bits order like ints)
+        for (int i = tid; i < N; i += RO_THREADS) { rowmask[2 * i] = 0ull; rowmask[2 * i + 1] = 0ull; wrow[i] = 0.f; }
+        __syncthreads();
+        const float4* g1 = reinterpret_cast<const float4*>(Gb + NN);
+        for (int e = tid; e < NN / 4; e += RO_THREADS) {
+            const float4 v = g1[e];
+            const int i = e / n4, c0 = (e - i * n4) * 4;
+            const unsigned long long nib = (v.x != 0.f ? 1ull : 0ull) | (v.y != 0.f ? 2ull : 0ull) | (v.z != 0.f ? 4ull : 0ull) |
+                                           (v.w != 0.f ? 8ull : 0ull);
+            if (nib) {
+                atomicOr(&rowmask[2 * i + (c0 >> 6)], nib << (c0 & 63));
+                atomicMax(reinterpret_cast<unsigned int*>(wrow) + i, __float_as_uint(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w))));
             }
-            rowmask[2 * i] = lo; rowmask[2 * i + 1] = hi; wrow[i] = w;
         }
+    }
     for (int e = tid; e < K * N * 8; e += RO_THREADS) {                        // tap k -> ring slot (K - k) % K, cur = 0
         const int f = e & 7, mk = e >> 3, k = mk / N, m = mk - k * N;
         const int slot = (k == 0) ? 0 : K - k;
@@ -287,8 +293,14 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     if (K >= 2)
         for (int n = tid; n < N; n += RO_THREADS) {
             int c = 0;
-            for (int m = 0; m < N; ++m)
-                if ((PK ? Gb[NN + (size_t)m * N + n] : Gd[m * N + n]) != 0.f) rlist[n * RS + c++] = (unsigned char)m;
+            if (PK) {                                         // structured slice 1: symmetric pattern, row list = column list
+                unsigned long long lo = rowmask[2 * n], hi = rowmask[2 * n + 1];
+                while (lo) { rlist[n * RS + c++] = (unsigned char)__builtin_ctzll(lo); lo &= lo - 1ull; }
+                while (hi) { rlist[n * RS + c++] = (unsigned char)(64 + __builtin_ctzll(hi)); hi &= hi - 1ull; }
+            } else {
+                for (int m = 0; m < N; ++m)
+                    if (Gd[m * N + n] != 0.f) rlist[n * RS + c++] = (unsigned char)m;
+            }
             rcnt[n] = c;
         }
     for (int e = tid; e < N * 8; e += RO_THREADS) {             // tap 0 of the first step (later steps: written in D3)
