@@ -9,7 +9,7 @@ A "step" advances EVERY episode of the batch by one environment step through the
 all state resident on the GPU, no host round trip.  Two implementations of the same step are timed in the same run:
   resident    mgp_rollout_steps: ALL timed steps in one launch of the episode-resident kernel (one workgroup per
               episode, delayed operator / delay line / agent states / weights in LDS; HBM sees the state on entry
-              and exit).  This is `value` when the shape is covered (N <= 128, N % 4 == 0, widths <= 32, fits LDS).
+              and exit).  This is `value` when the shape is covered (N <= 128, widths <= 32, state fits the LDS).
   two_launch  mgp_actor_fwd + mgp_flock_step_advance per step (dense operator streamed from HBM every step),
               replayed from a captured HIP graph; reported next to it, and `value` for shapes the resident kernel
               does not cover.

@@ -209,7 +209,8 @@ int mgp_flock_step_advance(double* x, double* x_out, const float* u, long su_age
  * The simulator arithmetic is the stand-alone kernels' (fp64, bit-exact integration/membership given the action); the
  * aggregation sums in a different order than mgp_actor_fwd (same 1e-5 parity bound against the reference forward).
  * Chunking is exact: T1 then T2 steps == T1 + T2 steps, bit for bit.  Coverage (mgp_rollout_supported): dims[0] = 6,
- * dims[n_layers] = 2, layer widths <= 32, N % 4 == 0, N <= 128 and the state must fit the 160 KB LDS.  Slices 1..K-1 are
+ * dims[n_layers] = 2, layer widths <= 32, 4 <= N <= 128 (any N: rows are padded to a multiple of 4 inside the kernel) and
+ * the state must fit the 160 KB LDS.  Slices 1..K-1 are
  * kept densely when they fit (N = 100: K <= 3).  Otherwise slice 1 is kept as membership bits + row weights (N = 100:
  * K = 4; N = 128: K = 3) -- in that mode slice 1 MUST be a row-scaled 0/1 matrix (every non-zero of a row equal), which
  * is what the state builder produces.  Anything larger: MGP_EUNSUPPORTED -- use the two calls above. */

@@ -73,8 +73,10 @@ struct RoOff {
     int mask;                             // u64 [N+1][2] membership bits of the network (row N = 0; x2 when G_1 is packed)
     int wrow;                             // float [N+1] network weight of row i (1/deg or 1) (x2 when G_1 is packed)
     int uact;                             // float [2][N] action (the Actor output layout (nA, N))
-    int xt;                               // float [K][N][8] delay line, ring over taps, transposed (6 features + 2 pad)
-    int gd;                               // float [K-1][N+1][N] delayed operator, slices 1..K-1 (2..K-1 when G_1 is packed), + a zero row each
+    int xt;                               // float [K][Np][8] delay line, ring over taps, transposed (6 features + 2 pad); Np = N
+                                          // rounded up to a multiple of 4, rows >= N are zero
+    int gd;                               // float [K-1][Np+1][Np] delayed operator, slices 1..K-1 (2..K-1 when G_1 is packed); rows
+                                          // and columns >= N are zero (row N is what list padding points at)
     int act;                              // float [ncols16][RO_CS] activations (in place through the layers)
     int rlist;                            // u8 [N][RS] ascending neighbour lists, padded with N (RS = N rounded to 8, + 8)
     int rcnt;                             // int [N] list lengths
@@ -94,8 +96,8 @@ __host__ __device__ constexpr RoOff ro_offsets(int N, int K, bool pk)
     c.mask = ro_take(off, (pk ? 2 : 1) * 2 * (N + 1) * 8);
     c.wrow = ro_take(off, (pk ? 2 : 1) * (N + 1) * 4);
     c.uact = ro_take(off, 2 * N * 4);
-    c.xt = ro_take(off, K * N * 8 * 4);
-    c.gd = ro_take(off, (K - (pk ? 2 : 1) > 0 ? K - (pk ? 2 : 1) : 0) * (N + 1) * N * 4);
+    c.xt = ro_take(off, K * ((N + 3) & ~3) * 8 * 4);
+    c.gd = ro_take(off, (K - (pk ? 2 : 1) > 0 ? K - (pk ? 2 : 1) : 0) * (((N + 3) & ~3) + 1) * ((N + 3) & ~3) * 4);
     c.act = ro_take(off, ((N + 15) & ~15) * RO_CS * 4);
     c.rlist = ro_take(off, N * (((N + 7) & ~7) + 8));
     c.rcnt = ro_take(off, N * 4);
@@ -214,19 +216,31 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     const int RS = ((N + 7) & ~7) + 8;                        // list row stride (bytes): aligned 8-entry chunks + padding room
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int NN = N * N, NS = (N + 1) * N, n4 = N >> 2, FK = 6 * K;   // NS: slice stride, row N of every slice is all zeros
+    const int Np = (N + 3) & ~3;                              // LDS row length / k-step range: N rounded up to a multiple of 4
+    const int NN = N * N, NS = (Np + 1) * Np, n4 = Np >> 2, FK = 6 * K;   // NS: slice stride; rows / columns >= N are all zeros
     const int ncols16 = pad16(N), NT = ncols16 / 16;
     double* xb = x + (size_t)b * N * 4;
     float* Gb = G + (size_t)b * K * NN;
     float* Xb = Xd + (size_t)b * K * 6 * N;
 
     // ------------------------------------------------------------------ entry: the episode's state -> LDS
-    for (int j = SL0; j < K; ++j) {
-        const float4* gsrc = reinterpret_cast<const float4*>(Gb + (size_t)j * NN);
-        float4* gdst = reinterpret_cast<float4*>(Gd + (size_t)(j - SL0) * NS);
+    if (Np == N) {                                            // rows are 16-byte aligned on both sides: flat float4 copy
+        for (int j = SL0; j < K; ++j) {
+            const float4* gsrc = reinterpret_cast<const float4*>(Gb + (size_t)j * NN);
+            float4* gdst = reinterpret_cast<float4*>(Gd + (size_t)(j - SL0) * NS);
 #pragma unroll 4
-        for (int e = tid; e < NN / 4; e += RO_THREADS) gdst[e] = gsrc[e];
-        for (int e = tid; e < N; e += RO_THREADS) Gd[(size_t)(j - SL0) * NS + NN + e] = 0.f;
+            for (int e = tid; e < NN / 4; e += RO_THREADS) gdst[e] = gsrc[e];
+            for (int e = tid; e < N; e += RO_THREADS) Gd[(size_t)(j - SL0) * NS + NN + e] = 0.f;
+        }
+    } else {                                                  // N % 4 != 0: padded LDS rows, element-wise copy (once per launch)
+        float4* z4 = reinterpret_cast<float4*>(Gd);
+        for (int e = tid; e < (K - SL0) * NS / 4; e += RO_THREADS) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        for (int j = SL0; j < K; ++j)
+            for (int e = tid; e < NN; e += RO_THREADS) {
+                const int i = e / N, n = e - i * N;
+                Gd[(size_t)(j - SL0) * NS + i * Np + n] = Gb[(size_t)j * NN + e];
+            }
     }
     if (tid < (PK ? 4 : 2)) rowmask[2 * N + (tid & 1) + (tid >> 1) * 2 * (N + 1)] = 0ull;   // row N (list padding) of the bit buffer(s)
     if (PK && K >= 2) {
@@ -234,22 +248,33 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         // lane ORs its four pattern bits into the row's words (weights are non-negative, so their float bits order like ints)
         for (int i = tid; i < N; i += RO_THREADS) { rowmask[2 * i] = 0ull; rowmask[2 * i + 1] = 0ull; wrow[i] = 0.f; }
         __syncthreads();
-        const float4* g1 = reinterpret_cast<const float4*>(Gb + NN);
-        for (int e = tid; e < NN / 4; e += RO_THREADS) {
-            const float4 v = g1[e];
-            const int i = e / n4, c0 = (e - i * n4) * 4;
-            const unsigned long long nib = (v.x != 0.f ? 1ull : 0ull) | (v.y != 0.f ? 2ull : 0ull) | (v.z != 0.f ? 4ull : 0ull) |
-                                           (v.w != 0.f ? 8ull : 0ull);
-            if (nib) {
-                atomicOr(&rowmask[2 * i + (c0 >> 6)], nib << (c0 & 63));
-                atomicMax(reinterpret_cast<unsigned int*>(wrow) + i, __float_as_uint(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w))));
+        if (Np == N) {
+            const float4* g1 = reinterpret_cast<const float4*>(Gb + NN);
+            for (int e = tid; e < NN / 4; e += RO_THREADS) {
+                const float4 v = g1[e];
+                const int i = e / n4, c0 = (e - i * n4) * 4;
+                const unsigned long long nib = (v.x != 0.f ? 1ull : 0ull) | (v.y != 0.f ? 2ull : 0ull) | (v.z != 0.f ? 4ull : 0ull) |
+                                               (v.w != 0.f ? 8ull : 0ull);
+                if (nib) {
+                    atomicOr(&rowmask[2 * i + (c0 >> 6)], nib << (c0 & 63));
+                    atomicMax(reinterpret_cast<unsigned int*>(wrow) + i, __float_as_uint(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w))));
+                }
+            }
+        } else {
+            for (int e = tid; e < NN; e += RO_THREADS) {
+                const float v = Gb[NN + e];
+                const int i = e / N, n = e - i * N;
+                if (v != 0.f) {
+                    atomicOr(&rowmask[2 * i + (n >> 6)], 1ull << (n & 63));
+                    atomicMax(reinterpret_cast<unsigned int*>(wrow) + i, __float_as_uint(v));
+                }
             }
         }
     }
-    for (int e = tid; e < K * N * 8; e += RO_THREADS) {                        // tap k -> ring slot (K - k) % K, cur = 0
-        const int f = e & 7, mk = e >> 3, k = mk / N, m = mk - k * N;
+    for (int e = tid; e < K * Np * 8; e += RO_THREADS) {                       // tap k -> ring slot (K - k) % K, cur = 0
+        const int f = e & 7, mk = e >> 3, k = mk / Np, m = mk - k * Np;
         const int slot = (k == 0) ? 0 : K - k;
-        XT[(slot * N + m) * 8 + f] = (f < 6) ? Xb[((size_t)k * 6 + f) * N + m] : 0.f;
+        XT[(slot * Np + m) * 8 + f] = (f < 6 && m < N) ? Xb[((size_t)k * 6 + f) * N + m] : 0.f;
     }
     for (int i = tid; i < N; i += RO_THREADS) {
         spx[i] = xb[i * 4 + 0]; spy[i] = xb[i * 4 + 1]; svx[i] = xb[i * 4 + 2]; svy[i] = xb[i * 4 + 3];
@@ -299,7 +324,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 while (hi) { rlist[n * RS + c++] = (unsigned char)(64 + __builtin_ctzll(hi)); hi &= hi - 1ull; }
             } else {
                 for (int m = 0; m < N; ++m)
-                    if (Gd[m * N + n] != 0.f) rlist[n * RS + c++] = (unsigned char)m;
+                    if (Gd[m * Np + n] != 0.f) rlist[n * RS + c++] = (unsigned char)m;
             }
             rcnt[n] = c;
         }
@@ -340,8 +365,8 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             for (int task = wave; task < ntasks; task += dwaves) {
                 const int kq = task / NT, nt = task - kq * NT;                  // tap kq + 2, columns 16 nt .. 16 nt + 15
                 const int col = nt * 16 + li;
-                const float* g = Gd + (size_t)(kq + 2 - SL0) * NS + lq * N + min(col, N - 1);  // B[k = lq][j = li] = G[4 s + lq][col]
-                const float* xa = XT + (size_t)ro_slot(cur, kq + 2, K) * N * 8 + lq * 8 + (li & 7);   // A[i = li][k = lq] = X[f = li][4 s + lq]
+                const float* g = Gd + (size_t)(kq + 2 - SL0) * NS + lq * Np + min(col, N - 1); // B[k = lq][j = li] = G[4 s + lq][col]
+                const float* xa = XT + (size_t)ro_slot(cur, kq + 2, K) * Np * 8 + lq * 8 + (li & 7);   // A[i = li][k = lq] = X[f = li][4 s + lq]
                 const float amask = (li < 8) ? 1.f : 0.f;                       // f = 6, 7 are zero pads in XT; rows 8..15 unused
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};   // even / odd k-steps: half the dependent chain
                 for (int s0 = 0; s0 < n4; s0 += 8) {                            // operands of 8 k-steps first, then the MFMAs
@@ -349,7 +374,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int s_ = min(s0 + u, n4 - 1);
-                        bv[u] = g[s_ * 4 * N];
+                        bv[u] = g[s_ * 4 * Np];
                         av[u] = xa[s_ * 32] * amask;
                     }
 #pragma unroll
@@ -371,12 +396,12 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 const int cnt = rcnt[sn];
                 const unsigned char* lp = rlist + sn * RS;
                 const float* gcol = Gd + sn;
-                const float* xt = XT + (size_t)ro_slot(cur, 1, K) * N * 8;
+                const float* xt = XT + (size_t)ro_slot(cur, 1, K) * Np * 8;
                 for (int e = sq; e < cnt; e += 2) {
                     const int m = lp[e];
                     // inside the launch G_1[m][n] = wrow[m] on its pattern (its dense rows are re-expanded during phase B);
                     // the first step reads the caller's dense slice, which may be any tensor
-                    const float gv = (t == 0) ? (PK ? Gb[NN + (size_t)m * N + sn] : gcol[m * N]) : w_cur[m];
+                    const float gv = (t == 0) ? (PK ? Gb[NN + (size_t)m * N + sn] : gcol[m * Np]) : w_cur[m];
                     const float4 x0 = *reinterpret_cast<const float4*>(xt + m * 8);
                     const float2 x1 = *reinterpret_cast<const float2*>(xt + m * 8 + 4);
                     sa[0] = fmaf(x0.x, gv, sa[0]); sa[1] = fmaf(x0.y, gv, sa[1]); sa[2] = fmaf(x0.z, gv, sa[2]);
@@ -463,7 +488,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                     const int nib = (int)(unsigned int)(rm_cur[2 * i + (c0 >> 6)] >> (c0 & 63));
                     const int wb = __float_as_int(w_cur[i]);  // bit k set -> all-ones (v_bfe_i32) & weight bits: 2 ops / element
                     if (hl < n4)
-                        *reinterpret_cast<float4*>(Gd + i * N + c0) =
+                        *reinterpret_cast<float4*>(Gd + i * Np + c0) =
                             make_float4(__int_as_float(__builtin_amdgcn_sbfe(nib, 0, 1) & wb),
                                         __int_as_float(__builtin_amdgcn_sbfe(nib, 1, 1) & wb),
                                         __int_as_float(__builtin_amdgcn_sbfe(nib, 2, 1) & wb),
@@ -582,7 +607,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 const double w = p.mean_pooling ? 1.0 / (deg == 0.0 ? 1.0 : deg) : 1.0;
                 w_new[fr] = (float)w;
                 rcnt[fr] = cnt;
-                float* xn = XT + ((size_t)(cur + 1 == K ? 0 : cur + 1) * N + fr) * 8;     // overwrites the oldest tap
+                float* xn = XT + ((size_t)(cur + 1 == K ? 0 : cur + 1) * Np + fr) * 8;     // overwrites the oldest tap
                 *reinterpret_cast<float4*>(xn) = make_float4((float)f0, (float)f1, (float)f2, (float)f3);
                 *reinterpret_cast<float4*>(xn + 4) = make_float4((float)f4, (float)f5, 0.f, 0.f);
                 float* y0 = act + fr * RO_CS;                 // tap 0 of the next step's aggregation: G_0 = I  =>  y_0 = X_0
@@ -622,7 +647,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                         } else {
 #pragma unroll
                             for (int d = 0; d < 8; ++d)
-                                g[d] = *reinterpret_cast<const float4*>(src + (int)((pk >> (8 * d)) & 255ull) * N);
+                                g[d] = *reinterpret_cast<const float4*>(src + (int)((pk >> (8 * d)) & 255ull) * Np);
                         }
 #pragma unroll
                         for (int d = 0; d < 8; ++d) {
@@ -631,7 +656,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                         }
                     }
                 }
-                if (hl < n4) *reinterpret_cast<float4*>(dst + i * N + hl * 4) = make_float4(a0.x, a0.y, a1.x, a1.y);
+                if (hl < n4) *reinterpret_cast<float4*>(dst + i * Np + hl * 4) = make_float4(a0.x, a0.y, a1.x, a1.y);
             }
             __syncthreads();
         }
@@ -647,29 +672,47 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     if (T > 0 && K >= 2) {                                    // the expansion G_1 <- A_T is still pending (PK: straight to HBM)
         const unsigned long long* rm_fin = rowmask + (PK ? cs * 2 * (N + 1) : 0);
         const float* w_fin = wrow + (PK ? cs * (N + 1) : 0);
-        float* g1 = PK ? Gb + NN : Gd;
         for (int i = hw; i < N; i += RO_THREADS / 32) {       // half-wave per row, lane = 4 columns
             const int c0 = hl * 4;
             const int nib = (int)(unsigned int)(rm_fin[2 * i + (c0 >> 6)] >> (c0 & 63));
             const int wb = __float_as_int(w_fin[i]);
-            if (hl < n4)
-                *reinterpret_cast<float4*>(g1 + i * N + c0) =
-                    make_float4(__int_as_float(__builtin_amdgcn_sbfe(nib, 0, 1) & wb),
-                                __int_as_float(__builtin_amdgcn_sbfe(nib, 1, 1) & wb),
-                                __int_as_float(__builtin_amdgcn_sbfe(nib, 2, 1) & wb),
-                                __int_as_float(__builtin_amdgcn_sbfe(nib, 3, 1) & wb));
+            const float4 v = make_float4(__int_as_float(__builtin_amdgcn_sbfe(nib, 0, 1) & wb),
+                                         __int_as_float(__builtin_amdgcn_sbfe(nib, 1, 1) & wb),
+                                         __int_as_float(__builtin_amdgcn_sbfe(nib, 2, 1) & wb),
+                                         __int_as_float(__builtin_amdgcn_sbfe(nib, 3, 1) & wb));
+            if (hl < n4) {
+                if (!PK) {
+                    *reinterpret_cast<float4*>(Gd + i * Np + c0) = v;
+                } else if (Np == N) {
+                    *reinterpret_cast<float4*>(Gb + NN + (size_t)i * N + c0) = v;
+                } else {                                      // unaligned global rows: element-wise
+                    float* gr = Gb + NN + (size_t)i * N;
+                    if (c0 < N) gr[c0] = v.x;
+                    if (c0 + 1 < N) gr[c0 + 1] = v.y;
+                    if (c0 + 2 < N) gr[c0 + 2] = v.z;
+                    if (c0 + 3 < N) gr[c0 + 3] = v.w;
+                }
+            }
         }
         __syncthreads();
     }
-    for (int j = SL0; j < K; ++j) {
-        const float4* gsrc = reinterpret_cast<const float4*>(Gd + (size_t)(j - SL0) * NS);
-        float4* gdst = reinterpret_cast<float4*>(Gb + (size_t)j * NN);
+    if (Np == N) {
+        for (int j = SL0; j < K; ++j) {
+            const float4* gsrc = reinterpret_cast<const float4*>(Gd + (size_t)(j - SL0) * NS);
+            float4* gdst = reinterpret_cast<float4*>(Gb + (size_t)j * NN);
 #pragma unroll 4
-        for (int e = tid; e < NN / 4; e += RO_THREADS) gdst[e] = gsrc[e];
+            for (int e = tid; e < NN / 4; e += RO_THREADS) gdst[e] = gsrc[e];
+        }
+    } else {
+        for (int j = SL0; j < K; ++j)
+            for (int e = tid; e < NN; e += RO_THREADS) {
+                const int i = e / N, n = e - i * N;
+                Gb[(size_t)j * NN + e] = Gd[(size_t)(j - SL0) * NS + i * Np + n];
+            }
     }
     for (int e = tid; e < K * 6 * N; e += RO_THREADS) {
         const int k = e / (6 * N), r1 = e - k * 6 * N, f = r1 / N, n = r1 - f * N;
-        Xb[e] = XT[((size_t)ro_slot(cur, k, K) * N + n) * 8 + f];
+        Xb[e] = XT[((size_t)ro_slot(cur, k, K) * Np + n) * 8 + f];
     }
     for (int i = tid; i < N; i += RO_THREADS) {
         xb[i * 4 + 0] = spx[i]; xb[i * 4 + 1] = spy[i]; xb[i * 4 + 2] = svx[i]; xb[i * 4 + 3] = svy[i];
@@ -682,7 +725,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
 bool make_carve(const int* dims, int n_layers, int K, int N, RoParams* P, int* lds_bytes, bool* packed)
 {
     if (dims == nullptr || n_layers < 1 || n_layers > MGP_MAX_LAYERS) return false;
-    if (K < 1 || K > 5 || N < 4 || N > RO_MAXN || (N & 3)) return false;
+    if (K < 1 || K > 5 || N < 4 || N > RO_MAXN) return false;
     if (dims[0] != 6 || dims[n_layers] != 2) return false;                      // simulator: 6 features in, 2-D action out
     int wtot = 0;
     for (int l = 0; l < n_layers; ++l) {

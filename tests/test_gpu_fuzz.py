@@ -89,14 +89,14 @@ def test_state_and_sim_random_sizes(seed):
             assert abs(sim.reward[b].item() - ofl.reward(xs[b], op)) <= 1e-12 * max(1.0, abs(ofl.reward(xs[b], op)))
 
 
-@pytest.mark.parametrize('seed', range(24))
+@pytest.mark.parametrize('seed', range(40))
 def test_resident_rollout_random_shapes(seed):
     """mgp_rollout_steps on random (N, K, layers, widths, spec variants): every step against the oracle transition."""
     from test_gpu_rollout import _make, _snapshot, _weights_np
     from multiagent_gnn_policies_amd import ops
     from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
     rs = np.random.RandomState(5000 + seed)
-    N = int(4 * rs.randint(2, 33))
+    N = int(rs.randint(8, 129))                               # any N: rows are padded to a multiple of 4 inside the kernel
     K = int(rs.randint(1, 5))
     hidden = [(), (4,), (32,), (16, 16), (32, 32), (8, 32, 16), (32, 32, 32), (20, 12)][int(rs.randint(0, 8))]
     variant = dict(mean_pooling=bool(rs.randint(0, 2)), n_leaders=int(rs.randint(0, 3)),

@@ -56,6 +56,10 @@ CASES = [
     (100, 3, (32, 32), {'mean_pooling': False, 'n_leaders': 2}),
     (100, 4, (32, 32), {}),                        # K - 1 dense slices do not fit: slice 1 kept as bits + row weights
     (128, 3, (32,), {'comm_radius': 1.2}),         # packed as well
+    (50, 2, (32, 32), {}),                         # N % 4 != 0: LDS rows padded to 52, element-wise state in / out
+    (25, 3, (16,), {'mean_pooling': False}),
+    (125, 3, (32,), {}),                           # padded AND packed
+    (75, 4, (32, 32), {'n_leaders': 1}),
     (100, 2, (16,), {}),
     (100, 1, (32, 32), {}),
     (128, 2, (32, 32), {'comm_radius': 1.5}),
@@ -98,7 +102,7 @@ def test_rollout_single_steps_match_oracle(N, K, hidden, variant):
             assert abs(rewards[b, 0].item() - r) <= 1e-12 * max(1.0, abs(r))
 
 
-@pytest.mark.parametrize('N,K,hidden,variant', CASES[:4] + CASES[7:8])
+@pytest.mark.parametrize('N,K,hidden,variant', CASES[:4] + CASES[7:8] + CASES[10:14])
 def test_rollout_chunking_is_exact(N, K, hidden, variant):
     """T steps in one launch == T launches of one step, bit for bit (state, last action, every reward)."""
     from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
@@ -146,6 +150,7 @@ def test_rollout_unsupported_shapes_fall_back():
     assert ops.rollout_supported((6, 32, 32, 2), 4, 100)          # K = 4 at N = 100: packed slice 1
     assert not ops.rollout_supported((6, 32, 32, 2), 5, 100)      # K = 5 at N = 100 does not fit the LDS either way
     assert not ops.rollout_supported((6, 32, 32, 2), 3, 130)
+    assert ops.rollout_supported((6, 32, 32, 2), 3, 50) and ops.rollout_supported((6, 32, 32, 2), 2, 125)
     assert not ops.rollout_supported((6, 32, 32, 3), 3, 100)      # the simulator takes 2-D actions
     assert ops.rollout_supported((6, 32, 32, 2), 3, 100)
     from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
