@@ -32,7 +32,7 @@ python tools/rocpd_stats.py $T > $O/bench_kernel_trace.txt 2>&1
 ./scratch/af_prof 256 100 > $O/af_phase_stamps.txt 2>&1
 # 4. DAGGER update + other configs
 python tools/bench_update.py > $O/dagger_update.json 2> $O/dagger_update.err
-for cfg in "64 1000 3" "256 200 4" "1 100 3" "2048 100 3" "256 100 4" "256 100 2" "256 100 1" "256 128 3" "256 128 2" "256 64 3" "256 48 4"; do set -- $cfg; python bench.py --episodes $1 --agents $2 --taps $3 --no-cpu-baseline --steps 100 --warmup 10 2>/dev/null | python -c "
+for cfg in "64 1000 3" "256 200 4" "1 100 3" "2048 100 3" "256 100 4" "256 100 2" "256 100 1" "256 125 3" "256 75 3" "256 50 2" "256 25 4"; do set -- $cfg; python bench.py --episodes $1 --agents $2 --taps $3 --no-cpu-baseline --steps 100 --warmup 10 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 k = {a: (round(v['avg_launch_ms']*1e3,1), round(v['GBps'])) for a, v in d.get('kernels', {}).items()}
