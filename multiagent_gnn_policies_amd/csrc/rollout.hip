@@ -435,43 +435,44 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 RO_STAMP(12 + l);
             }
             // ---------------------------------------------------------- C: output layer (VALU) + integrate, same wave
-            // The 2-wide output layer is a packed-FMA chain (a 16-row MFMA tile would be 7/8 padding): lane (li, lq) takes
-            // the 8 channels c = 4 s + lq of agent column li (contiguous in the B-fragment layout), the four lq lanes are
-            // added by DPP.  Lane lq == 0 then integrates the agent (spec section 1, fp64: bit-exact given the action) and
-            // publishes its fp32 coordinates for D1.  No workgroup barrier since the hidden layers: the wave only reads
-            // activations it wrote itself.
+            // The 2-wide output layer is a packed-FMA chain (a 16-row MFMA tile would be 7/8 padding).  For this part the
+            // lanes are regrouped: lane L takes agent column L >> 2 of the wave's tile and the 8 channels c = 4 s + (L & 3)
+            // (contiguous in the B-fragment layout), so the four partial sums of a column sit in one quad and are added by
+            // DPP.  The first lane of the quad then integrates the agent (spec section 1, fp64: bit-exact given the action)
+            // and publishes its fp32 coordinates for D1.  No workgroup barrier since the hidden layers: the wave only
+            // reads activations it wrote itself (LDS operations of one wave are ordered).
             const int lo_ = n_layers - 1;
             const float* w2 = wl + (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull);
-            const float4 z0 = *reinterpret_cast<const float4*>(pcol + lq * RO_KS);
-            const float4 z1 = *reinterpret_cast<const float4*>(pcol + lq * RO_KS + 4);
+            const int ccol = wave * 16 + (lane >> 2), cg = lane & 3;
+            const float* zsrc = act + ccol * RO_CS + cg * RO_KS;
+            const float4 z0 = *reinterpret_cast<const float4*>(zsrc);
+            const float4 z1 = *reinterpret_cast<const float4*>(zsrc + 4);
             const float zc[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
             double px = 0.0, py = 0.0, vx = 0.0, vy = 0.0, cx = 0.0, cy = 0.0;
-            const bool agent = (lq == 0) && col < N;
-            if (agent) { px = spx[col]; py = spy[col]; vx = svx[col]; vy = svy[col]; cx = cref[0]; cy = cref[1]; }
+            const bool agent = (cg == 0) && ccol < N;
+            if (agent) { px = spx[ccol]; py = spy[ccol]; vx = svx[ccol]; vy = svy[ccol]; cx = cref[0]; cy = cref[1]; }
             f32x2 u2 = {0.f, 0.f}, u2b = {0.f, 0.f};
 #pragma unroll
-            for (int s_ = 0; s_ < RO_KS; s_ += 2) {           // channel c = 4 s + lq: weights (W[0][c], W[1][c]) at w2[2 c]
-                const float2 wa = *reinterpret_cast<const float2*>(w2 + 2 * (4 * s_ + lq));
-                const float2 wb = *reinterpret_cast<const float2*>(w2 + 2 * (4 * (s_ + 1) + lq));
+            for (int s_ = 0; s_ < RO_KS; s_ += 2) {           // channel c = 4 s + cg: weights (W[0][c], W[1][c]) at w2[2 c]
+                const float2 wa = *reinterpret_cast<const float2*>(w2 + 2 * (4 * s_ + cg));
+                const float2 wb = *reinterpret_cast<const float2*>(w2 + 2 * (4 * (s_ + 1) + cg));
                 u2 = __builtin_elementwise_fma((f32x2){zc[s_], zc[s_]}, (f32x2){wa.x, wa.y}, u2);
                 u2b = __builtin_elementwise_fma((f32x2){zc[s_ + 1], zc[s_ + 1]}, (f32x2){wb.x, wb.y}, u2b);
             }
             u2 = u2 + u2b;
-            // lanes (li, lq) of one column sit 16 apart: row_ror-free combination through two bpermute-less steps is not
-            // available across rows, so use the wave shuffle (4 values, once per step)
             float ux = u2.x, uy = u2.y;
-            ux += __shfl_xor(ux, 16, MGP_WAVE); uy += __shfl_xor(uy, 16, MGP_WAVE);
-            ux += __shfl_xor(ux, 32, MGP_WAVE); uy += __shfl_xor(uy, 32, MGP_WAVE);
+            ux += dpp_f<0xB1>(ux); uy += dpp_f<0xB1>(uy);
+            ux += dpp_f<0x4E>(ux); uy += dpp_f<0x4E>(uy);
             float m = 0.f;
             if (agent) {
                 const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * 4 * RO_KS);
                 ux += bb.x; uy += bb.y;
-                uact[col] = ux; uact[N + col] = uy;
+                uact[ccol] = ux; uact[N + ccol] = uy;
                 const float ub[2] = {ux, uy};
-                integrate_one(px, py, vx, vy, ub, 1, col < p.n_leaders, p);
-                spx[col] = px; spy[col] = py; svx[col] = vx; svy[col] = vy;
+                integrate_one(px, py, vx, vy, ub, 1, ccol < p.n_leaders, p);
+                spx[ccol] = px; spy[ccol] = py; svx[ccol] = vx; svy[ccol] = vy;
                 const float sx = (float)(px - cx), sy = (float)(py - cy);     // fp32 coordinates relative to cref
-                sxy[col] = make_float2(sx, sy);
+                sxy[ccol] = make_float2(sx, sy);
                 m = fmaxf(fabsf(sx), fabsf(sy));
             }
             m = wave_max_to_last(m);
