@@ -103,7 +103,11 @@ def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
     N, K, F, n_a = p.n_agents, args.getint('k'), args.getint('n_states'), args.getint('n_actions')
     T = episode_steps or p.max_episode_steps
     learner = DAGGER(device, args)
-    memory = DeviceReplay(args.getint('buffer_size'), K, F, N, n_a, device)
+    # The reference's ring of `buffer_size` (10,000) transitions holds its 20 most recent WHOLE episodes.  Here n_envs
+    # episodes advance in lock step, so a ring shorter than one round (n_envs * T transitions) would keep only the last
+    # steps of every episode -- the already-flocked states -- and the policy would never see a start-up state.  The ring
+    # therefore holds at least one full round (128 KB per transition at N = 100, K = 3: 4 GB of the 288 GB for 64 x 500).
+    memory = DeviceReplay(max(args.getint('buffer_size'), n_envs * T), K, F, N, n_a, device)
     sim = VecFlock(n_envs, p, device, with_expert=True)
     state = BatchedDelayState(device, n_envs, K, F, N)
     batch_size = args.getint('batch_size')

@@ -238,3 +238,29 @@ def test_vectorised_test_episodes_match_the_sequential_loop():
     # same reset draws, same policy; the two aggregation orders differ in fp32 rounding, which 60 closed-loop steps
     # amplify to ~5e-4 of the episode reward (measured; test_gpu_rollout.py holds the per-step exactness checks)
     assert np.all(np.abs(a - b) <= 3e-3 * np.abs(b)), (a, b)
+
+
+def test_vectorised_dagger_learns_to_flock():
+    """End to end: 32 episodes of vectorised DAGGER (16 lanes x 150 steps, 1,280 updates) must yield a policy that
+    flocks -- regression test for the replay ring keeping whole episodes (a ring shorter than one lock-step round holds
+    only already-flocked states and the policy never sees a start-up state: reward -4,300 instead of -67 at N = 100)."""
+    import random
+    from multiagent_gnn_policies_amd import envs
+    from multiagent_gnn_policies_amd.learner.rollouts import run_episode
+    from multiagent_gnn_policies_amd.learner.vec_dagger import train_dagger_vec
+    cp = configparser.ConfigParser()
+    cp['DEFAULT'] = dict(alg='dagger', batch_size='20', buffer_size='1000', updates_per_step='40', seed='1',
+                         actor_lr='5e-4', n_train_episodes='32', beta_coeff='0.993', test_interval='40',
+                         n_test_episodes='8', k='3', hidden_size='32', gamma='0.99', tau='0.5',
+                         env='FlockingRelative-v0', v_max='3.0', comm_radius='1.0', n_agents='40', n_actions='2',
+                         n_states='6', debug='False', dt='0.01')
+    cp['t'] = {}
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    stats = train_dagger_vec(cp['t'], 'cuda:0', n_envs=16, episode_steps=150)
+    assert stats['updates'] == 2 * 40 * 16
+    env = envs.make('FlockingRelative-v0', max_episode_steps=150)
+    env.env.params_from_cfg(cp['t'])
+    env.seed(5)
+    idle = np.mean([run_episode(env, lambda _o: np.zeros((40, 2))) for _ in range(3)])
+    assert idle < -500
+    assert stats['mean'] > 0.25 * idle, (stats['mean'], idle)          # measured: -66 vs -860
