@@ -152,7 +152,10 @@ def sample_candidate(rng, p):
     length(N) ; angle(N) ; bias(2) ; vx(N) ; vy(N).  `rng` is numpy's global-RNG-like API."""
     n = p.n_agents
     x = np.zeros((n, 4), dtype=np.float64)
-    length = np.sqrt(rng.uniform(0, p.r_max, size=(n,)))
+    # two flocks: each half is drawn in a disc of HALF the area (same agent density as one flock of N, so the
+    # acceptance test stays feasible), the discs sit side by side one communication radius apart
+    area = p.r_max * (0.5 if p.two_flocks else 1.0)
+    length = np.sqrt(rng.uniform(0, p.r_max, size=(n,)) * (area / p.r_max))
     angle = np.pi * rng.uniform(0, 2, size=(n,))
     x[:, 0] = length * np.cos(angle)
     x[:, 1] = length * np.sin(angle)
@@ -161,9 +164,10 @@ def sample_candidate(rng, p):
     x[:, 3] = rng.uniform(low=-p.v_max, high=p.v_max, size=(n,)) + bias[1]
     if p.two_flocks:
         half = n // 2
-        x[:half, 0] -= np.sqrt(p.r_max)
-        x[half:, 0] += np.sqrt(p.r_max)
-        x[:half, 2] = x[:half, 2] - bias[0] + abs(bias[0])
+        shift = np.sqrt(area) + 0.5 * p.comm_radius
+        x[:half, 0] -= shift
+        x[half:, 0] += shift
+        x[:half, 2] = x[:half, 2] - bias[0] + abs(bias[0])        # the two flocks head for each other
         x[half:, 2] = x[half:, 2] - bias[0] - abs(bias[0])
     return x
 
@@ -194,6 +198,12 @@ def sample_candidate_grid(rng, p):
     bias = rng.uniform(low=-p.v_bias, high=p.v_bias, size=(2,))
     x[:, 2] = rng.uniform(low=-p.v_max, high=p.v_max, size=(n,)) + bias[0]
     x[:, 3] = rng.uniform(low=-p.v_max, high=p.v_max, size=(n,)) + bias[1]
+    if p.two_flocks:                                              # lattice cut at x = 0, halves one radius apart, head-on
+        left = sites[:, 0] < 0
+        x[left, 0] -= 0.5 * p.comm_radius
+        x[~left, 0] += 0.5 * p.comm_radius
+        x[left, 2] = x[left, 2] - bias[0] + abs(bias[0])
+        x[~left, 2] = x[~left, 2] - bias[0] - abs(bias[0])
     return x
 
 
