@@ -161,6 +161,9 @@ typedef struct MgpFlockParams {
     int    n_leaders;      /* first n_leaders agents ignore u                     */
     int    centralized;    /* expert written by mgp_flock_step[_advance]: velocity term over ALL agents (the
                             * global teacher DAGGER imitates) if nonzero, else over radius neighbours only */
+    unsigned int link_drop;/* link fading (FlockingStochastic-v0): a radius pair is connected iff its 32-bit fade
+                            * hash >= link_drop = floor(P(drop) * 2^32); 0 = every radius link is up (no hashing) */
+    unsigned int link_seed;/* mixed into the fade hash                            */
     int    reserved_;      /* keeps sizeof a multiple of 8                        */
 } MgpFlockParams;
 

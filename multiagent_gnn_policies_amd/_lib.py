@@ -23,7 +23,8 @@ class MgpFlockParams(ctypes.Structure):
     _fields_ = [('comm_radius2', ctypes.c_double), ('dt', ctypes.c_double), ('action_gain', ctypes.c_double),
                 ('max_accel', ctypes.c_double), ('ctrl_gain', ctypes.c_double), ('ctrl_clip', ctypes.c_double),
                 ('reward_scale', ctypes.c_double), ('mean_pooling', ctypes.c_int), ('n_leaders', ctypes.c_int),
-                ('centralized', ctypes.c_int), ('reserved_', ctypes.c_int)]
+                ('centralized', ctypes.c_int), ('link_drop', ctypes.c_uint), ('link_seed', ctypes.c_uint),
+                ('reserved_', ctypes.c_int)]
 
 
 # name -> (restype, argtypes).  Pointers are passed as raw integers (tensor.data_ptr()).

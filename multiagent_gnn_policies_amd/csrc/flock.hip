@@ -160,6 +160,7 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
     const int nch = (jh + 63) / 64;                        // 64-bit adjacency words per (row, piece)
     if (pair_active && rl < rows) {
         const double xi = spx[i], yi = spy[i], vxi = svx[i], vyi = svy[i];
+        const unsigned int wi = p.link_drop != 0u ? fade_word(xi, yi) : 0u;
         const int j0 = half * jh, j1 = min(N, j0 + jh);
         for (int c = 0; c < nch; ++c) {
             // phase 1: cheap membership test for up to 64 j's -> bit mask (the only fp64 work every pair pays)
@@ -174,6 +175,14 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
                     const double dx = xi - ox[q], dy = yi - oy[q];
                     const double r2 = dx * dx + dy * dy;
                     if (j + q < jb && j + q != i && r2 < R2) mask |= 1ull << (j + q - ja);
+                }
+            }
+            if (p.link_drop != 0u) {                           // FlockingStochastic-v0: faded links leave the mask
+                unsigned long long m = mask;
+                while (m) {
+                    const int j = ja + __builtin_ctzll(m);
+                    m &= m - 1ull;
+                    if (!link_up(p, i, j, N, wi, fade_word(spx[j], spy[j]))) mask &= ~(1ull << (j - ja));
                 }
             }
             adjw[((size_t)rl * FL_SPLIT + half) * nch + c] = mask;

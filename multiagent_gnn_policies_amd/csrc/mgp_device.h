@@ -46,3 +46,28 @@ __device__ __forceinline__ void integrate_one(double& px, double& py, double& vx
     vx = vx + ux * p.dt;
     vy = vy + uy * p.dt;
 }
+
+// ---- link fading (FLOCK-SPEC item 8, FlockingStochastic-v0): a radius neighbour pair {i,j} is connected at a step
+// iff a 32-bit hash of (seed, pair index, both agents' exact fp64 position words) is >= the drop threshold.  Stateless:
+// the network stays a pure function of the state x, the two directions of a pair agree by construction (the position
+// words are combined with a commutative add), and all of it is integer arithmetic -- bit-exact against the oracle.
+__device__ __forceinline__ unsigned int fmix32(unsigned int h)
+{
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+__device__ __forceinline__ unsigned int fade_word(double px, double py)
+{
+    const unsigned long long bx = (unsigned long long)__double_as_longlong(px);
+    const unsigned long long by = (unsigned long long)__double_as_longlong(py);
+    return fmix32((unsigned int)bx + 0x9E3779B1u * (unsigned int)(bx >> 32)
+                  + 0x85EBCA77u * (unsigned int)by + 0xC2B2AE3Du * (unsigned int)(by >> 32));
+}
+
+__device__ __forceinline__ bool link_up(const MgpFlockParams& p, int i, int j, int N, unsigned int wi, unsigned int wj)
+{
+    const unsigned int lo = (unsigned int)(i < j ? i : j), hi = (unsigned int)(i < j ? j : i);
+    const unsigned int pair = lo * (unsigned int)N + hi;
+    return fmix32((wi + wj) ^ (p.link_seed + 0x27D4EB2Fu * pair)) >= p.link_drop;
+}

@@ -562,6 +562,8 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 in_m &= in_m - 1u;
                 int j = pi + d0 + q;
                 j = (j >= N) ? j - N : j;
+                if (p.link_drop != 0u &&                      // FlockingStochastic-v0: the pair's link is faded this step
+                    !link_up(p, pi, j, N, fade_word(spx[pi], spy[pi]), fade_word(spx[j], spy[j]))) continue;
                 atomicOr(&rm_new[2 * pi + (j >> 6)], 1ull << (j & 63));
                 atomicOr(&rm_new[2 * j + (pi >> 6)], 1ull << (pi & 63));
             }

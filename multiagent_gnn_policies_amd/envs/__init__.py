@@ -1,2 +1,2 @@
 from .flocking import (FlockParams, VecFlock, FlockingRelativeEnv, FlockingLeaderEnv, FlockingTwoFlocksEnv,  # noqa: F401
-                       TimeLimit, make, registered_ids)
+                       FlockingStochasticEnv, TimeLimit, make, registered_ids)

@@ -44,6 +44,13 @@ class FlockParams:
     grid_spacing: float = 0.6
     grid_jitter: float = 0.1
     centralized: bool = True     # controller() default: velocity consensus over ALL agents (the DAGGER teacher)
+    link_drop: float = 0.0       # P(a radius link is down at a step) -- FlockingStochastic-v0 (FLOCK-SPEC item 8)
+    link_seed: int = 0           # mixed into the fade hash (train.py passes the experiment seed)
+
+    @property
+    def link_drop_q32(self):
+        """Drop threshold of the 32-bit fade hash: floor(link_drop * 2^32), saturated."""
+        return max(0, min(0xFFFFFFFF, int(np.floor(float(self.link_drop) * 4294967296.0))))
 
     @property
     def comm_radius2(self):
@@ -56,7 +63,7 @@ class FlockParams:
     def to_c(self):
         return MgpFlockParams(self.comm_radius2, self.dt, self.action_gain, self.max_accel, self.ctrl_gain,
                               self.ctrl_clip, self.reward_scale, 1 if self.mean_pooling else 0, self.n_leaders,
-                              1 if self.centralized else 0, 0)
+                              1 if self.centralized else 0, self.link_drop_q32, int(self.link_seed) & 0xFFFFFFFF, 0)
 
 
 # ----------------------------------------------------------------------------------- reset sampling
@@ -290,13 +297,18 @@ class FlockingRelativeEnv(object):
     def params_from_cfg(self, args):
         kw = dict(n_agents=args.getint('n_agents'), comm_radius=args.getfloat('comm_radius'),
                   v_max=args.getfloat('v_max'), v_bias=args.getfloat('v_max'))
-        if args.get('dt') is not None:
+        if args.get('dt') is not None:                      # absent in the reference's *_stoch.cfg files
             kw['dt'] = args.getfloat('dt')
+        if args.get('link_drop') is not None:               # this package's key; the variant's default otherwise
+            kw['link_drop'] = args.getfloat('link_drop')
         self.params = replace(self.params, **kw)
         self._sim = None
 
     def seed(self, seed=None):
         self._rng = np.random.RandomState(seed) if seed is not None else np.random
+        if seed is not None and self.params.link_drop > 0.0:
+            self.params = replace(self.params, link_seed=int(seed) & 0xFFFFFFFF)
+            self._sim = None
         return [seed]
 
     @property
@@ -356,6 +368,12 @@ class FlockingTwoFlocksEnv(FlockingRelativeEnv):
     variant = dict(two_flocks=True)
 
 
+class FlockingStochasticEnv(FlockingRelativeEnv):
+    """FLOCK-SPEC v1 variant: every radius link is down with probability `link_drop` at each step (position-keyed
+    fading, item 8 of the spec) -- network rows, features and the decentralised controller see the faded graph."""
+    variant = dict(link_drop=0.1)
+
+
 class TimeLimit(object):
     """The part of gym.wrappers.TimeLimit the reference relies on: `.env`, and `done` after
     `max_episode_steps` steps (reference gnn_dagger.py:154,163: `while not done`)."""
@@ -392,6 +410,7 @@ _REGISTRY = {
     'FlockingRelative-v0': FlockingRelativeEnv,
     'FlockingLeader-v0': FlockingLeaderEnv,
     'FlockingTwoFlocks-v0': FlockingTwoFlocksEnv,
+    'FlockingStochastic-v0': FlockingStochasticEnv,
 }
 
 

@@ -73,6 +73,10 @@ def _params_from_args(args):
     if args.get('dt') is not None:
         kw['dt'] = args.getfloat('dt')
     kw.update(variant)
+    if args.get('link_drop') is not None:
+        kw['link_drop'] = args.getfloat('link_drop')
+    if kw.get('link_drop', 0.0) > 0.0:
+        kw['link_seed'] = args.getint('seed', fallback=0) & 0xFFFFFFFF
     return FlockParams(**kw)
 
 

@@ -43,6 +43,8 @@ class FlockParams:
     init_mode: str = 'auto'      # 'disc' (uniform in a disc, rejection), 'grid' (jittered lattice), 'auto' = disc if N <= 100
     grid_spacing: float = 0.6    # lattice pitch in units of comm_radius (grid mode)
     grid_jitter: float = 0.1     # uniform jitter amplitude in units of comm_radius (grid mode)
+    link_drop: float = 0.0       # FlockingStochastic: P(a radius link is down at a step); 0 = deterministic graph
+    link_seed: int = 0           # mixed into the fade hash
     centralized: bool = True     # controller() default.  The reference's DAGGER calls controller() with no argument
                                  # (gnn_dagger.py:156): the teacher is the GLOBAL controller the paper's decentralised
                                  # policy imitates; the radius-limited variant alone does not flock at this density
@@ -100,6 +102,8 @@ def helpers(x, p):
     r2 = diff[:, :, 0] * diff[:, :, 0] + diff[:, :, 1] * diff[:, :, 1]
     np.fill_diagonal(r2, np.inf)
     adj = (r2 < p.comm_radius2).astype(np.float64)
+    if p.link_drop > 0.0:                                    # FlockingStochastic: faded links leave the graph
+        adj = adj * link_up(x, p)
     deg = adj.sum(axis=1)
     degc = np.where(deg == 0, 1.0, deg)
     network = adj / degc[:, None] if p.mean_pooling else adj.copy()
@@ -111,6 +115,49 @@ def helpers(x, p):
     # bit-identical to an explicit loop `for j: values += feats[:, j] * adj[:, j]`)
     values = np.sum(feats * adj[:, :, None], axis=1)
     return dict(diff=diff, r2=r2, adj=adj, deg=deg, network=network, values=values)
+
+
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def fmix32(h):
+    """The 32-bit avalanche finaliser of MurmurHash3 (public domain), on uint64 arrays holding 32-bit values."""
+    h = np.asarray(h, dtype=np.uint64) & _M32
+    h = h ^ (h >> np.uint64(16))
+    h = (h * np.uint64(0x85EBCA6B)) & _M32
+    h = h ^ (h >> np.uint64(13))
+    h = (h * np.uint64(0xC2B2AE35)) & _M32
+    h = h ^ (h >> np.uint64(16))
+    return h
+
+
+def link_drop_q32(p):
+    """Drop threshold of the fade hash: floor(link_drop * 2^32), saturated to 32 bits."""
+    return max(0, min(0xFFFFFFFF, int(np.floor(float(p.link_drop) * 4294967296.0))))
+
+
+def fade_words(x):
+    """Per-agent 32-bit word of the exact fp64 position bits (FLOCK-SPEC v1 item 8)."""
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+    bx = x[:, 0].copy().view(np.uint64)
+    by = x[:, 1].copy().view(np.uint64)
+    s = ((bx & _M32) + np.uint64(0x9E3779B1) * (bx >> np.uint64(32))
+         + np.uint64(0x85EBCA77) * (by & _M32) + np.uint64(0xC2B2AE3D) * (by >> np.uint64(32)))
+    return fmix32(s & _M32)
+
+
+def link_up(x, p):
+    """(N,N) 0/1 f64: link {i,j} survives this step iff fmix32((w_i + w_j) ^ (seed + 0x27D4EB2F * pair)) >= threshold,
+    pair = min(i,j) * N + max(i,j), all mod 2^32.  Symmetric; the diagonal is meaningless (adj is 0 there)."""
+    n = np.asarray(x).shape[0]
+    w = fade_words(x)
+    i = np.arange(n, dtype=np.uint64)
+    lo = np.minimum(i[:, None], i[None, :])
+    hi = np.maximum(i[:, None], i[None, :])
+    pair = (lo * np.uint64(n) + hi) & _M32
+    key = ((w[:, None] + w[None, :]) & _M32) ^ ((np.uint64(int(p.link_seed) & 0xFFFFFFFF)
+                                                 + np.uint64(0x27D4EB2F) * pair) & _M32)
+    return (fmix32(key) >= np.uint64(link_drop_q32(p))).astype(np.float64)
 
 
 def reward(x, p):

@@ -219,3 +219,70 @@ def test_eval_model_refuses_to_run_without_a_gpu(tmp_path):
     with pytest.raises(RuntimeError, match="MI355X"):
         eval_model.evaluate_section(cp['dagger'], eval_model.DEFAULT_ACTOR)
     assert os.path.exists(os.path.join(ROOT, eval_model.DEFAULT_ACTOR))
+
+
+def test_link_fading_spec():
+    """FLOCK-SPEC item 8 (FlockingStochastic-v0): the fade hash and its host plumbing."""
+    from dataclasses import replace
+    from multiagent_gnn_policies_amd import envs
+    from oracle import flock as ofl
+    # MurmurHash3's published fmix32 values
+    assert [int(v) for v in ofl.fmix32(np.array([0, 1, 0xFFFFFFFF]))] == [0, 0x514E28B7, 0x81F16F39]
+    p0 = ofl.FlockParams(n_agents=200)
+    x = ofl.reset(np.random.RandomState(3), p0)
+    h0 = ofl.helpers(x, p0)
+    kept = []
+    for seed in range(6):
+        p = replace(p0, link_drop=0.3, link_seed=seed)
+        h = ofl.helpers(x, p)
+        assert np.array_equal(h['adj'], h['adj'].T) and np.all(h['adj'] <= h0['adj']) and np.trace(h['adj']) == 0
+        assert np.array_equal(h['adj'], ofl.helpers(x.copy(), p)['adj'])        # a pure function of (x, seed)
+        kept.append(h['adj'].sum() / h0['adj'].sum())
+    assert len(set(kept)) > 1 and abs(np.mean(kept) - 0.7) < 0.03
+    x2 = x.copy(); x2[0, 0] = np.nextafter(x2[0, 0], 10.0)                   # one ulp: agent 0's links re-draw
+    a, b = ofl.link_up(x, replace(p0, link_drop=0.5)), ofl.link_up(x2, replace(p0, link_drop=0.5))
+    assert np.array_equal(a[1:, 1:], b[1:, 1:]) and not np.array_equal(a[0], b[0])
+    assert np.array_equal(ofl.helpers(x, replace(p0, link_drop=0.0, link_seed=9))['network'], h0['network'])
+    assert ofl.helpers(x, replace(p0, link_drop=1.0))['adj'].sum() <= 1       # threshold saturates at 2^32 - 1
+    for q in (0.0, 0.1, 0.25, 0.999999, 1.0, 2.0):
+        assert envs.FlockParams(link_drop=q).link_drop_q32 == ofl.link_drop_q32(replace(p0, link_drop=q))
+    assert envs.FlockParams(link_drop=0.5).to_c().link_drop == 1 << 31
+    # the env id of the reference's *_stoch.cfg files; those files carry no `dt`
+    assert 'FlockingStochastic-v0' in envs.registered_ids()
+    env = envs.make('FlockingStochastic-v0')
+    env.env.params_from_cfg(_args(n_agents=50, comm_radius=1.5, v_max=2.0))
+    assert env.env.params.link_drop == 0.1 and env.env.params.dt == envs.FlockParams().dt
+    env.seed(12)
+    assert env.env.params.link_seed == 12
+    env.env.params_from_cfg(_args(n_agents=50, comm_radius=1.5, v_max=2.0, link_drop=0.4))
+    assert env.env.params.link_drop == 0.4
+
+
+REFERENCE_CFG = '/root/reference/cfg'
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_CFG), reason="reference checkout not present")
+def test_reference_cfg_files_are_accepted():
+    """Every experiment section of every cfg file the reference ships passes train.py's host-side pre-flight, except the
+    AirSim backend ids (out of scope) -- those are refused by name."""
+    import configparser
+    import glob
+    import train
+    seen, airsim = 0, 0
+    for path in sorted(glob.glob(os.path.join(REFERENCE_CFG, '*.cfg'))):
+        cp = configparser.ConfigParser()
+        try:
+            cp.read(path)
+        except configparser.DuplicateOptionError:
+            continue                      # default_baseline.cfg repeats `dt`: the reference's own parser rejects it too
+        for name, section in train.iter_experiments(cp):
+            if 'Airsim' in section.get('env'):
+                with pytest.raises(KeyError, match='unknown environment id'):
+                    train.check_experiment(section)
+                airsim += 1
+                continue
+            p = train.check_experiment(section)
+            assert p.n_agents == section.getint('n_agents') and p.comm_radius == section.getfloat('comm_radius')
+            assert (p.link_drop > 0) == (section.get('env') == 'FlockingStochastic-v0')
+            seen += 1
+    assert seen >= 200 and airsim >= 1

@@ -66,6 +66,8 @@ CASES = [
     (36, 4, (8, 32, 16), {}),
     (8, 3, (32,), {}),
     (52, 3, (), {}),
+    (100, 3, (32, 32), {'link_drop': 0.25, 'link_seed': 3}),                 # FlockingStochastic: faded links
+    (100, 4, (32, 32), {'link_drop': 0.5, 'link_seed': 9, 'mean_pooling': False}),
 ]
 
 
@@ -102,7 +104,7 @@ def test_rollout_single_steps_match_oracle(N, K, hidden, variant):
             assert abs(rewards[b, 0].item() - r) <= 1e-12 * max(1.0, abs(r))
 
 
-@pytest.mark.parametrize('N,K,hidden,variant', CASES[:4] + CASES[7:8] + CASES[10:14])
+@pytest.mark.parametrize('N,K,hidden,variant', CASES[:4] + CASES[7:8] + CASES[10:16])
 def test_rollout_chunking_is_exact(N, K, hidden, variant):
     """T steps in one launch == T launches of one step, bit for bit (state, last action, every reward)."""
     from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout

@@ -25,7 +25,8 @@ def _args(**kw):
 
 
 @pytest.mark.parametrize('env_id,variant', [('FlockingRelative-v0', {}), ('FlockingLeader-v0', {'n_leaders': 2}),
-                                            ('FlockingTwoFlocks-v0', {'two_flocks': True})])
+                                            ('FlockingTwoFlocks-v0', {'two_flocks': True}),
+                                            ('FlockingStochastic-v0', {'link_drop': 0.1, 'link_seed': 7})])
 def test_env_facade_matches_oracle_spec(env_id, variant):
     from multiagent_gnn_policies_amd import envs
     n = 30

@@ -50,7 +50,34 @@ def _dagger_vec(env, args, device):
 ALGORITHMS = {'dagger': _dagger, 'cloning': _cloning, 'baseline': _baseline, 'dagger_vec': _dagger_vec}
 
 
+def check_experiment(args):
+    """Host-only pre-flight of one cfg section: everything the run will read (reference train.py:17-42,
+    gnn_dagger.py:29-50,128-146) must be present and well-typed, the env id and algorithm known.  Returns the
+    FlockParams the env will use.  Raises before any device work, naming the section's problem."""
+    alg = (args.get('alg') or '').lower()
+    if alg not in ALGORITHMS:
+        raise Exception('Invalid algorithm/mode name')
+    env = envs.make(args.get('env'))                    # KeyError for ids outside the registry (e.g. the AirSim backend)
+    env.env.params_from_cfg(args)
+    args.getint('seed')
+    if alg == 'baseline':
+        args.getboolean('centralized'); args.getint('n_test_episodes')
+    else:
+        for key in ('n_states', 'n_actions', 'k', 'hidden_size', 'n_agents', 'batch_size', 'buffer_size',
+                    'updates_per_step', 'n_train_episodes', 'test_interval', 'n_test_episodes'):
+            if args.getint(key) is None:
+                raise KeyError("cfg key %r missing" % key)
+        for key in ('actor_lr', 'beta_coeff', 'gamma', 'tau'):
+            if args.getfloat(key) is None:
+                raise KeyError("cfg key %r missing" % key)
+        args.getboolean('debug')
+        if args.getint('n_states') != env.env.n_features or args.getint('n_actions') != env.env.nu:
+            raise ValueError("n_states / n_actions do not match the environment (6 features, 2 action axes)")
+    return env.env.params
+
+
 def run_experiment(args):
+    check_experiment(args)
     if not torch.cuda.is_available():
         raise RuntimeError("train.py needs an MI355X (HIP device); this framework has no CPU compute path")
     rank, _world, local_rank = parallel.init_from_env()
