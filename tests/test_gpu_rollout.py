@@ -68,6 +68,8 @@ CASES = [
     (52, 3, (), {}),
     (100, 3, (32, 32), {'link_drop': 0.25, 'link_seed': 3}),                 # FlockingStochastic: faded links
     (100, 4, (32, 32), {'link_drop': 0.5, 'link_seed': 9, 'mean_pooling': False}),
+    (100, 3, (32, 32), {'grid_spacing': 0.2, 'grid_jitter': 0.02}),          # dense graph (degree 60..99): rad.cfg's 4.0
+    (128, 3, (32,), {'grid_spacing': 0.1, 'grid_jitter': 0.01}),             # complete graph, packed slice 1
 ]
 
 
@@ -88,7 +90,10 @@ def test_rollout_single_steps_match_oracle(N, K, hidden, variant):
         x1, G1, X1 = _snapshot(sim, st)
         u = action.cpu().numpy()                                           # (B,1,2,N)
         ref_u = oa.forward(X0, G0, Ws, bs, 0, dtype=np.float64)
-        assert relerr(u, ref_u) <= 1e-5, (step, relerr(u, ref_u))
+        # crowded lattices make 1/r^4 features O(1e4): there the reference op sequence in fp32 is itself further than 1e-5
+        # from the exact result, and a multiple of that rounding noise is allowed on top (as in test_gpu_fuzz)
+        noise = relerr(oa.forward(X0, G0, Ws, bs, 0, dtype=np.float32), ref_u)
+        assert relerr(u, ref_u) <= 1e-5 + 10.0 * noise, (step, relerr(u, ref_u), noise)
         for b in range(B):
             ub = u[b, 0].T.astype(np.float32)                              # (N,2), the action the kernel applied
             x_ref, vals, net, r = ofl.step(x0[b], ub, op)
@@ -104,7 +109,7 @@ def test_rollout_single_steps_match_oracle(N, K, hidden, variant):
             assert abs(rewards[b, 0].item() - r) <= 1e-12 * max(1.0, abs(r))
 
 
-@pytest.mark.parametrize('N,K,hidden,variant', CASES[:4] + CASES[7:8] + CASES[10:16])
+@pytest.mark.parametrize('N,K,hidden,variant', CASES[:4] + CASES[7:8] + CASES[10:18])
 def test_rollout_chunking_is_exact(N, K, hidden, variant):
     """T steps in one launch == T launches of one step, bit for bit (state, last action, every reward)."""
     from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
