@@ -14,42 +14,32 @@ from .. import ops
 class Actor(nn.Module):
 
     def __init__(self, n_s, n_a, hidden_layers, k, ind_agg):
-        """
-        :param n_s: number of MDP states (features) per agent
-        :param n_a: number of MDP actions per agent
-        :param hidden_layers: list of hidden-layer widths
-        :param k: aggregation filter length (number of delay taps)
-        :param ind_agg: index of the layer before which the single aggregation happens
-        """
-        super(Actor, self).__init__()
-        self.k = k
-        self.n_s = n_s
-        self.n_a = n_a
-        self.layers = [n_s] + list(hidden_layers) + [n_a]
+        """n_s features and n_a action axes per agent; `hidden_layers` lists the hidden widths; `k` delay taps enter
+        the filter of layer `ind_agg`, in front of which the one aggregation takes place."""
+        super().__init__()
+        self.k, self.n_s, self.n_a, self.ind_agg = k, n_s, n_a, ind_agg
+        self.layers = [n_s, *hidden_layers, n_a]
         self.n_layers = len(self.layers) - 1
-        self.ind_agg = ind_agg
-        # parameter containers with the reference's shapes and init order (actor.py:30-42)
-        self.conv_layers = nn.ModuleList([
-            nn.Conv2d(in_channels=self.layers[i], out_channels=self.layers[i + 1],
-                      kernel_size=((k if i == ind_agg else 1), 1), stride=((k if i == ind_agg else 1), 1))
-            for i in range(self.n_layers)])
+        # parameter containers: shapes, names and creation order (hence RNG consumption) of reference actor.py:30-42
+        convs = []
+        for i, (c_in, c_out) in enumerate(zip(self.layers[:-1], self.layers[1:])):
+            taps = k if i == ind_agg else 1
+            convs.append(nn.Conv2d(c_in, c_out, kernel_size=(taps, 1), stride=(taps, 1)))
+        self.conv_layers = nn.ModuleList(convs)
         self.use_fused = True       # fused single-kernel forward when the shape is covered (ind_agg == 0)
 
+    def _check_shapes(self, delay_state, delay_gso):
+        """AssertionError on any mismatch, as the reference's asserts (actor.py:53-61)."""
+        B, K, F, N = delay_state.shape
+        assert tuple(delay_gso.shape) == (B, self.k, N, N) and (K, F) == (self.k, self.n_s), \
+            "expected delay_state (B,%d,%d,N) and delay_gso (B,%d,N,N), got %s and %s" % (
+                self.k, self.n_s, self.k, tuple(delay_state.shape), tuple(delay_gso.shape))
+        return B, N
+
     def forward(self, delay_state, delay_gso):
-        """
-        :param delay_state: (B,K,F,N) history of features x_t, x_{t-1}, ...
-        :param delay_gso:   (B,K,N,N) delayed graph-shift operators I, A_t, A_t A_{t-1}, ...
-        :return: (B,1,nA,N)
-        """
-        batch_size = delay_state.shape[0]
-        n_agents = delay_state.shape[3]
-        # same contract as reference actor.py:53-61
-        assert delay_gso.shape[0] == batch_size
-        assert delay_gso.shape[2] == n_agents
-        assert delay_gso.shape[3] == n_agents
-        assert delay_state.shape[1] == self.k
-        assert delay_state.shape[2] == self.n_s
-        assert delay_gso.shape[1] == self.k
+        """delay_state (B,K,F,N): features x_t, x_{t-1}, ...; delay_gso (B,K,N,N): delayed graph-shift operators
+        I, A_t, A_t A_{t-1}, ...  ->  (B,1,nA,N)."""
+        batch_size, n_agents = self._check_shapes(delay_state, delay_gso)
 
         if self.use_fused and self.ind_agg == 0:
             from . import actor_fused

@@ -15,9 +15,6 @@ from .. import ops
 from .. import parallel
 from ..parallel import FlatGradSync
 from .actor import Actor
-from .replay_buffer import ReplayBuffer, Transition
-from .rollouts import policy_episode_rewards
-from .state_with_delay import MultiAgentStateWithDelay
 
 
 class FlatAdam(object):
@@ -245,76 +242,10 @@ class DAGGER(object):
 
 
 def train_dagger(env, args, device):
-    debug = args.getboolean('debug')
-    memory = ReplayBuffer(max_size=args.getint('buffer_size'))
-    learner = DAGGER(device, args)
-
-    n_a = args.getint('n_actions')
-    n_agents = args.getint('n_agents')
-    batch_size = args.getint('batch_size')
-    n_train_episodes = args.getint('n_train_episodes')
+    """Reference gnn_dagger.py:126-243.  beta of global episode e is max(beta_coeff ** (e + 1), 0.5) -- the closed form
+    of the reference's running product `beta = max(beta * beta_coeff, 0.5)`; evaluation while training only when
+    `debug`; the statistics are those of a final evaluation, after which the model is saved (`debug` and `fname`)."""
+    from .imitation import ImitationRun
     beta_coeff = args.getfloat('beta_coeff')
-    test_interval = args.getint('test_interval')
-    n_test_episodes = args.getint('n_test_episodes')
-    updates_per_step = args.getint('updates_per_step')
-
-    total_numsteps = 0
-    updates = 0
-    stats = {'mean': -1.0 * np.inf, 'std': 0}
-
-    # Data-parallel run (one process per GPU, torchrun): the n_train_episodes episodes are dealt round-robin to
-    # the ranks (global episode e = i * world + rank keeps the reference's beta schedule per episode), every
-    # rank performs the same number of updates and gradients are averaged by ONE flat all-reduce per update.
-    rank, world = parallel.rank(), parallel.world_size()
-    local_episodes = (n_train_episodes + world - 1) // world
-    lo_t, hi_t = parallel.shard_range(n_test_episodes)
-    n_test_local = max(1, hi_t - lo_t) if world > 1 else n_test_episodes
-
-    for i in range(local_episodes):
-        e = i * world + rank
-        beta = max(beta_coeff ** (e + 1), 0.5)          # == the reference's running product max(beta*coeff, 0.5)
-        state = MultiAgentStateWithDelay(device, args, env.reset(), prev_state=None)
-        done = False
-        policy_loss_sum = 0
-        while not done:
-            optimal_action = env.env.controller()
-            if np.random.binomial(1, beta) > 0:
-                action = optimal_action
-            else:
-                action = learner.select_action(state).cpu().numpy()
-            next_obs, reward, done, _ = env.step(action)
-            next_state = MultiAgentStateWithDelay(device, args, next_obs, prev_state=state)
-            total_numsteps += 1
-
-            notdone = torch.tensor([float(not done)], device=device)
-            reward_t = torch.tensor([float(reward)], device=device)
-            # expert label (N,nA) -> (1,1,nA,N)
-            label = torch.from_numpy(np.ascontiguousarray(np.asarray(optimal_action, dtype=np.float32).T))
-            label = label.reshape((1, 1, n_a, n_agents)).to(device)
-            memory.insert(Transition(state, label, notdone, next_state, reward_t))
-            state = next_state
-
-        if memory.curr_size > batch_size:
-            for _ in range(updates_per_step):
-                transitions = memory.sample(batch_size)
-                batch = Transition(*zip(*transitions))
-                policy_loss_sum += learner.gradient_step(batch)
-                updates += 1
-
-        if (i * world) % test_interval < world and debug:
-            test_rewards = policy_episode_rewards(env, learner, device, args, n_test_local)
-            test_rewards = parallel.all_gather_floats(test_rewards)
-            if rank == 0:
-                print("Episode: {}, updates: {}, total numsteps: {}, reward: {}, policy loss: {}".format(
-                    i * world, updates, total_numsteps * world, np.mean(test_rewards), policy_loss_sum))
-
-    test_rewards = policy_episode_rewards(env, learner, device, args, n_test_local)
-    test_rewards = parallel.all_gather_floats(test_rewards)
-    stats['mean'] = np.mean(test_rewards)
-    stats['std'] = np.std(test_rewards)
-
-    if debug and args.get('fname') and rank == 0:
-        learner.save_model(args.get('env'), suffix=args.get('fname'))
-
-    env.close()
-    return stats
+    run = ImitationRun(env, DAGGER(device, args), args, device)
+    return run.run(lambda e: max(beta_coeff ** (e + 1), 0.5), eval_always=False, keep_best=False)
