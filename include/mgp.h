@@ -240,6 +240,31 @@ int mgp_adam_step(float* param, const float* grad, float* m, float* v, long n,
 int mgp_adam_step_dev(float* param, const float* grad, float* m, float* v, long n,
                       float lr, float beta1, float beta2, float eps, int* step_dev, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * One DAGGER update in two launches          reference learner/gnn_dagger.py:85-93
+ *   pred = actor(X, G) ; loss = mse_loss(pred, target) ; loss.backward() ; Adam.step()
+ * for ind_agg = 0 (the only configuration train.py builds, gnn_dagger.py:43).  Forward, MSE gradient and the
+ * parameter backward of 16 agent columns run inside one workgroup (activations never leave LDS); a second launch adds
+ * the per-workgroup partials in a fixed order.  X (B,K,F,N), G (B,K,N,N), target (B,1,nA,N), all fp32 contiguous.
+ *   flat_grad : dW_0 | db_0 | dW_1 | db_1 | ...  (the order torch enumerates Actor.parameters()), overwritten
+ *   loss      : loss[0] = mean squared error (may be NULL)
+ *   workspace : mgp_train_workspace(...) floats; zero it once after allocation (its last word is a ticket counter
+ *               that mgp_train_step leaves at zero)
+ * mgp_train_grads stops at the gradient (data-parallel runs all-reduce it, then call mgp_adam_step*).
+ * mgp_train_step also applies torch.optim.Adam (defaults) in the second launch: flat_param holds the parameters in the
+ * flat_grad order and is what the forward reads; *step_dev (0-based) is read, then incremented -- HIP-graph replayable.
+ * Coverage (mgp_train_supported): F <= 8, F*K <= 64, widths <= 64, B * ceil(N/16) <= 8192, LDS plan (X[b], all parameters, 16-column activations) <= 96 KB;
+ * otherwise MGP_EUNSUPPORTED -- compose mgp_actor_fwd / mgp_mse_grad / mgp_actor_bwd / mgp_adam_step instead. */
+int  mgp_train_supported(const int* dims, int n_layers, int B, int K, int N);
+long mgp_train_workspace(const int* dims, int n_layers, int B, int K, int N);
+int  mgp_train_grads(const float* X, const float* G, const float* target,
+                     const float* const* W, const float* const* b, const int* dims, int n_layers,
+                     float* flat_grad, float* loss, float* workspace, int B, int K, int N, void* stream);
+int  mgp_train_step(const float* X, const float* G, const float* target,
+                    float* flat_param, float* flat_grad, float* m, float* v, const int* dims, int n_layers,
+                    float lr, float beta1, float beta2, float eps, int* step_dev,
+                    float* loss, float* workspace, int B, int K, int N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

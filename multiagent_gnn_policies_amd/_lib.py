@@ -60,6 +60,11 @@ SIGNATURES = {
     'mgp_mse_grad': (_int, [_vp, _vp, _vp, _vp, _long, _vp]),
     'mgp_adam_step': (_int, [_vp, _vp, _vp, _vp, _long, _f32, _f32, _f32, _f32, _int, _vp]),
     'mgp_adam_step_dev': (_int, [_vp, _vp, _vp, _vp, _long, _f32, _f32, _f32, _f32, _vp, _vp]),
+    'mgp_train_supported': (_int, [_vp, _int, _int, _int, _int]),
+    'mgp_train_workspace': (_long, [_vp, _int, _int, _int, _int]),
+    'mgp_train_grads': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _int, _int, _vp]),
+    'mgp_train_step': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _f32, _f32, _f32, _f32, _vp,
+                              _vp, _vp, _int, _int, _int, _vp]),
 }
 
 _lock = threading.Lock()

@@ -1,0 +1,478 @@
+// One DAGGER update in two launches (reference learner/gnn_dagger.py:85-93):
+//
+//     pred = actor(X, G); loss = F.mse_loss(pred, target); loss.backward(); Adam.step()
+//
+// Kernel 1 (train_tile_kernel): one workgroup per (batch item, 16 agent columns).  The aggregation, the filter + tanh MLP,
+//   the MSE gradient and the whole parameter backward of those 16 columns happen inside the workgroup, activations never
+//   leave LDS (the five-launch path writes them to HBM as `saved` and reads them back), and the workgroup emits one partial
+//   of every dW / db plus its share of the squared error.
+// Kernel 2 (train_reduce_kernel): adds the partials in a fixed order (bit-reproducible run to run) into the flat gradient
+//   W_0 | b_0 | W_1 | b_1 | ... -- the order torch enumerates Actor.parameters() -- writes the loss, and, for the
+//   single-GPU update, applies Adam in the same pass (each workgroup owns 64 parameters; the last workgroup to finish
+//   advances the device-side step counter).  A data-parallel run stops after the gradient (all-reduce, then mgp_adam_step*).
+//
+// B = 20, N = 100, K = 3, 6-32-32-2: 140 workgroups; 15.9 (forward) + 4.5 (mse) + 10.0 (backward) + 4.7 (scatter) + 4.0 (adam)
+// microseconds of kernel time in the five-launch graph.
+#include <math.h>
+#include "mgp_common.h"
+#include "mgp_device.h"
+
+namespace {
+
+constexpr int TS_THREADS = 256;
+constexpr int TS_COLS = 16;               // agent columns per workgroup
+constexpr int TS_CSH = 4;                 // log2(TS_COLS)
+constexpr int TS_GROUPS = TS_THREADS / TS_COLS;
+constexpr int TS_CS = TS_COLS + 1;        // odd LDS row stride: conflict-free walks along a column
+constexpr int TS_MAXW = 64;               // layer widths and F*K covered
+constexpr int TS_LDS_LIMIT = 96 * 1024;
+
+struct TrainParams {
+    const float* W[MGP_MAX_LAYERS];
+    const float* b[MGP_MAX_LAYERS];
+    int dims[MGP_MAX_LAYERS + 1];
+    int poff[MGP_MAX_LAYERS];             // offset of layer l's (dW, db) block inside one partial / the flat gradient
+    int ioff[MGP_MAX_LAYERS];             // offset (floats) of layer l's input rows inside the LDS activation area
+    int n_layers;
+    const float* flat;                    // W_0 | b_0 | W_1 | ... when the caller's buffers are contiguous in that order
+};
+
+// LDS (floats): xs [K*F][N] | gs [K][MC][16] (a chunk of G rows, this tile's columns) | red [MP][FK][16] |
+//               acts (inputs of every layer, [rows][17]) | d0, d1 [maxw][17] | wall [Ptot] (W_l then b_l, flat order)
+// Every first-round global read (G tile, X, parameters, targets) is issued before the first LDS write, so a workgroup
+// pays ONE exposed memory latency -- the first version staged weights layer by layer (23 us in fourteen serial round
+// trips).  The workgroup runs one wave per SIMD, so nothing hides an LDS round trip either: the inner loops load a
+// batch of operands into registers, then multiply (sched_barrier keeps the compiler from re-serialising them).
+#ifdef MGP_TS_PROFILE
+__device__ unsigned long long mgp_ts_stamps[32];
+#define TS_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) mgp_ts_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TS_STAMP(i) do { } while (0)
+#endif
+constexpr int TS_GB = 20;                 // G values in flight per thread (covers N = 100 with K = 3: 20 rows per piece)
+
+// n floats global -> LDS with TS_THREADS threads, eight loads in flight per thread before the first LDS write
+__device__ __forceinline__ void stage_lds(float* dst, const float* __restrict__ src, int n, int tid, int first = 0)
+{
+    for (int base = first; base < n; base += 8 * TS_THREADS) {
+        float r[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int i = base + q * TS_THREADS + tid; r[q] = src[min(i, n - 1)]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int i = base + q * TS_THREADS + tid; if (i < n) dst[i] = r[q]; }
+    }
+}
+
+// element e of the G tile [K][mcn rows][16 columns] of rows mc0.. of episode b, columns n0..n0+15 (0 past column N)
+__device__ __forceinline__ float g_tile_elem(const float* __restrict__ Gb, int e, int ne, int mcn, int mc0, int n0, int N)
+{
+    const float inv_mcn = 1.0f / (float)mcn;
+    e = min(e, ne - 1);
+    const int c = e & (TS_COLS - 1), r = e >> TS_CSH;
+    const int k = (int)(((float)r + 0.5f) * inv_mcn), m = r - k * mcn;      // r / mcn exactly (r < 2^11, mcn <= 128)
+    const float v = Gb[((size_t)k * N + mc0 + m) * N + min(n0 + c, N - 1)];
+    return (n0 + c < N) ? v : 0.f;
+}
+
+__device__ __forceinline__ void stage_g_tile(float* gs, const float* __restrict__ Gb, int ne, int mcn, int mc0, int n0,
+                                             int N, int tid, int first)
+{
+    for (int base = first; base < ne; base += 8 * TS_THREADS) {
+        float r[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] = g_tile_elem(Gb, base + q * TS_THREADS + tid, ne, mcn, mc0, n0, N);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int e = base + q * TS_THREADS + tid; if (e < ne) gs[e] = r[q]; }
+    }
+}
+
+__global__ __launch_bounds__(TS_THREADS)
+void train_tile_kernel(const float* __restrict__ X, const float* __restrict__ G, const float* __restrict__ target,
+                       float* __restrict__ part, TrainParams P, int Pstride, int K, int F, int N, int MP, int MC,
+                       int acts_floats, int maxw, float grad_scale)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int n0 = blockIdx.x * TS_COLS, b = blockIdx.y;
+    const int FK = F * K;
+    const int L = P.n_layers;
+    const int nA = P.dims[L];
+    float* xs = smem;                                         // [K*F][N]
+    float* gs = xs + (size_t)FK * N;                          // [K][MC][16]   one chunk of G rows, this tile's columns
+    float* red = gs + (size_t)K * MC * TS_COLS;               // [MP][FK][16]
+    float* acts = red + (size_t)MP * FK * TS_COLS;
+    float* d0 = acts + acts_floats;
+    float* d1 = d0 + (size_t)maxw * TS_CS;
+    float* wall = d1 + (size_t)maxw * TS_CS;
+    float* my = part + ((size_t)b * gridDim.x + blockIdx.x) * Pstride;
+    const int col = tid & (TS_COLS - 1), g = tid >> TS_CSH;
+    const float* Gb = G + (size_t)b * K * N * N;
+    const float* xb = X + (size_t)b * FK * N;
+    TS_STAMP(0);
+
+    // ---- every first-round global read goes out before the first LDS write: G tile (20 per thread), X, parameters
+    //      (8 each), the targets -- one exposed memory latency for the whole workgroup
+    {
+        const int mcn = min(MC, N), ne = K * mcn * TS_COLS, nx = FK * N, nw = Pstride - 1;
+        float rg[TS_GB], rx[8], rw[8];
+#pragma unroll
+        for (int q = 0; q < TS_GB; ++q) rg[q] = g_tile_elem(Gb, q * TS_THREADS + tid, ne, mcn, 0, n0, N);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rx[q] = xb[min(q * TS_THREADS + tid, nx - 1)];
+        if (P.flat != nullptr) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rw[q] = P.flat[min(q * TS_THREADS + tid, nw - 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < TS_GB; ++q) { const int e = q * TS_THREADS + tid; if (e < ne) gs[e] = rg[q]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int i = q * TS_THREADS + tid; if (i < nx) xs[i] = rx[q]; }
+        if (P.flat != nullptr) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int i = q * TS_THREADS + tid; if (i < nw) wall[i] = rw[q]; }
+            stage_lds(wall, P.flat, nw, tid, 8 * TS_THREADS);
+        } else {
+            for (int l = 0; l < L; ++l) {
+                const int cin = (l == 0) ? FK : P.dims[l], cout = P.dims[l + 1];
+                stage_lds(wall + P.poff[l], P.W[l], cout * cin, tid);
+                stage_lds(wall + P.poff[l] + cout * cin, P.b[l], cout, tid);
+            }
+        }
+        stage_lds(xs, xb, nx, tid, 8 * TS_THREADS);
+        stage_g_tile(gs, Gb, ne, mcn, 0, n0, N, tid, TS_GB * TS_THREADS);
+    }
+    // targets of this workgroup's outputs (thread i < nA * 16 owns output (i >> 4, i & 15) of the last layer)
+    float tgt = 0.f;
+    if (tid < nA * TS_COLS && n0 + col < N) tgt = target[((size_t)b * nA + (tid >> TS_CSH)) * N + n0 + col];
+
+    // ---- aggregation y[k,f,col] = sum_m X[b,k,f,m] G[b,k,m,n0+col]: thread = (col, tap k, piece mp of the chunk's rows).
+    //      Eight accumulators whatever F is (feature index clamped, surplus results dropped): no branch in the row loop.
+    const bool agg_on = g < K * MP;
+    const int ak = agg_on ? g / MP : 0, amp = agg_on ? g - ak * MP : 0;
+    float acc[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) acc[f] = 0.f;
+    for (int mc0 = 0; mc0 < N; mc0 += MC) {
+        const int mcn = min(MC, N - mc0);
+        if (mc0 > 0) {                                          // N > MC only: next chunk of G rows
+            __syncthreads();
+            stage_g_tile(gs, Gb, K * mcn * TS_COLS, mcn, mc0, n0, N, tid, 0);
+        }
+        __syncthreads();
+        if (mc0 == 0) TS_STAMP(1);
+        if (agg_on) {
+            const int piece = (mcn + MP - 1) / MP;
+            const int p0 = amp * piece, p1 = min(mcn, p0 + piece);
+            const float* gk = gs + (size_t)ak * mcn * TS_COLS + col;
+            const float* xk = xs + (size_t)ak * F * N + mc0;
+            for (int m = p0; m < p1; m += 4) {
+                float gq[4], xq[4][8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int mm = min(m + q, p1 - 1);
+                    gq[q] = gk[mm * TS_COLS];
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) xq[q][f] = xk[min(f, F - 1) * N + mm];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float gvq = (m + q < p1) ? gq[q] : 0.f;
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) acc[f] = fmaf(xq[q][f], gvq, acc[f]);
+                }
+            }
+        }
+    }
+    if (agg_on) {
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+            if (f < F) red[((size_t)amp * FK + (f * K + ak)) * TS_COLS + col] = acc[f];      // row (f,k) = W_0's column order
+    }
+    __syncthreads();
+    TS_STAMP(2);
+    for (int i = tid; i < FK * TS_COLS; i += TS_THREADS) {
+        const int r = i >> TS_CSH, c = i & (TS_COLS - 1);
+        float s = 0.f;
+        for (int mp = 0; mp < MP; ++mp) s += red[((size_t)mp * FK + r) * TS_COLS + c];        // fixed order
+        acts[r * TS_CS + c] = s;
+    }
+
+    // ---- filter + tanh MLP on the 16 columns; the input of every layer stays in LDS for the backward pass
+    float* dcur = d0;
+    float* dnext = d1;
+    float sq = 0.f;
+    for (int l = 0; l < L; ++l) {
+        const int cin = (l == 0) ? FK : P.dims[l];
+        const int cout = P.dims[l + 1];
+        const float* in = acts + P.ioff[l];
+        const float* wl = wall + P.poff[l];
+        __syncthreads();                                            // inputs complete
+        TS_STAMP(3 + l);
+        for (int i = tid; i < cout * TS_COLS; i += TS_THREADS) {
+            const int o = i >> TS_CSH, c16 = i & (TS_COLS - 1);
+            const float* wr = wl + (size_t)o * cin;
+            float s0 = wl[cout * cin + o], s1 = 0.f;
+            int c = 0;
+            for (; c + 8 <= cin; c += 8) {
+                float wv[8], iv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { wv[q] = wr[c + q]; iv[q] = in[(c + q) * TS_CS + c16]; }
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) { s0 = fmaf(wv[q], iv[q], s0); s1 = fmaf(wv[q + 1], iv[q + 1], s1); }
+            }
+            for (; c < cin; ++c) s0 = fmaf(wr[c], in[c * TS_CS + c16], s0);
+            const float z = s0 + s1;
+            if (l < L - 1) {
+                acts[P.ioff[l + 1] + o * TS_CS + c16] = tanh_fast(z);
+            } else {
+                // d loss / d pred = 2 (pred - target) / n  (reference F.mse_loss, mean over every element)
+                float d = 0.f;
+                if (n0 + c16 < N)
+                    d = z - (i == tid ? tgt : target[((size_t)b * nA + o) * N + n0 + c16]);
+                dcur[o * TS_CS + c16] = grad_scale * d;
+                sq = fmaf(d, d, sq);
+            }
+        }
+    }
+    // squared-error share of this workgroup (fixed order: wave sums, then the four added pairwise)
+    {
+        __shared__ float shq[TS_THREADS / 64];
+        sq = mgp_wave_sum(sq);
+        if ((tid & 63) == 0) shq[tid >> 6] = sq;
+        __syncthreads();
+        if (tid == 0) my[Pstride - 1] = (shq[0] + shq[1]) + (shq[2] + shq[3]);
+    }
+    TS_STAMP(8);
+
+    // ---- backward, parameters only (ind_agg = 0: nothing flows into X or G -- reference actor.py:64-71 inputs are leaves)
+    for (int l = L - 1; l >= 0; --l) {
+        const int cin = (l == 0) ? FK : P.dims[l];
+        const int cout = P.dims[l + 1];
+        const float* in = acts + P.ioff[l];
+        const float* wl = wall + P.poff[l];
+        if (l < L - 1) __syncthreads();                             // dcur complete (the loss block synchronised l = L-1)
+        TS_STAMP(9 + (L - 1 - l));
+        float* myl = my + P.poff[l];
+        for (int o = tid; o < cout; o += TS_THREADS) {
+            float s = 0.f;
+#pragma unroll
+            for (int cl = 0; cl < TS_COLS; ++cl) s += dcur[o * TS_CS + cl];
+            myl[(size_t)cout * cin + o] = s;
+        }
+        {
+            const float inv_cin = 1.0f / (float)cin;
+            for (int p = tid; p < cout * cin; p += TS_THREADS) {
+                const int o = (int)(((float)p + 0.5f) * inv_cin), c = p - o * cin;       // p / cin exactly (p < 2^12)
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int cl = 0; cl < TS_COLS; cl += 2) {
+                    s0 = fmaf(dcur[o * TS_CS + cl], in[c * TS_CS + cl], s0);
+                    s1 = fmaf(dcur[o * TS_CS + cl + 1], in[c * TS_CS + cl + 1], s1);
+                }
+                myl[p] = s0 + s1;
+            }
+        }
+        if (l > 0) {
+            for (int c = g; c < cin; c += TS_THREADS / TS_COLS) {
+                float s = 0.f, s2 = 0.f;
+                int o = 0;
+                for (; o + 8 <= cout; o += 8) {
+                    float wv[8], dv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { wv[q] = wl[(o + q) * cin + c]; dv[q] = dcur[(o + q) * TS_CS + col]; }
+#pragma unroll
+                    for (int q = 0; q < 8; q += 2) { s = fmaf(wv[q], dv[q], s); s2 = fmaf(wv[q + 1], dv[q + 1], s2); }
+                }
+                for (; o < cout; ++o) s = fmaf(wl[o * cin + c], dcur[o * TS_CS + col], s);
+                s += s2;
+                const float z = in[c * TS_CS + col];
+                dnext[c * TS_CS + col] = s * (1.f - z * z);
+            }
+            float* t = dcur; dcur = dnext; dnext = t;
+        }
+    }
+    TS_STAMP(14);
+}
+
+struct AdamArgs {
+    float* p;            // nullptr: gradient only
+    float* m;
+    float* v;
+    int* step_dev;
+    int* ticket;
+    float lr, b1, b2, eps;
+};
+
+// workgroup = 64 entries of the partial x 16 interleaved groups of tiles; entry Ptot is the squared error
+constexpr int TR_GROUPS = 16;
+__global__ __launch_bounds__(64 * TR_GROUPS)
+void train_reduce_kernel(const float* __restrict__ part, int ntiles, int Pstride, float* __restrict__ flat_grad,
+                         float* __restrict__ loss, float inv_n, AdamArgs A)
+{
+    __shared__ float sh[TR_GROUPS][64];
+    __shared__ float shc[2];
+    const int pl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + pl;
+    const int Ptot = Pstride - 1;
+    if (A.p != nullptr && threadIdx.x == 64) {          // bias corrections once per workgroup (fp64 pow), off wave 0
+        const double step = (double)(*A.step_dev + 1);
+        shc[0] = (float)((double)A.lr / (1.0 - pow((double)A.b1, step)));
+        shc[1] = (float)sqrt(1.0 - pow((double)A.b2, step));
+    }
+    float s = 0.f;
+    if (i < Pstride)
+        for (int t = g; t < ntiles; t += TR_GROUPS) s += part[(size_t)t * Pstride + i];
+    sh[g][pl] = s;
+    __syncthreads();
+    if (g == 0 && i < Pstride) {
+        s = 0.f;
+#pragma unroll
+        for (int q = 0; q < TR_GROUPS; ++q) s += sh[q][pl];
+        if (i == Ptot) {
+            if (loss != nullptr) loss[0] = s * inv_n;
+        } else {
+            flat_grad[i] = s;
+            if (A.p != nullptr) {                        // torch.optim.Adam defaults, same expressions as mgp_adam_step_dev
+                const float one_m_b1 = (float)(1.0 - (double)A.b1), one_m_b2 = (float)(1.0 - (double)A.b2);
+                const float mi = A.m[i] + (s - A.m[i]) * one_m_b1;
+                const float vi = A.v[i] * A.b2 + one_m_b2 * s * s;
+                const float denom = sqrtf(vi) / shc[1] + A.eps;
+                A.p[i] = A.p[i] - shc[0] * (mi / denom);
+                A.m[i] = mi;
+                A.v[i] = vi;
+            }
+        }
+    }
+    if (A.p != nullptr) {
+        // every workgroup has read the step counter by now; the last one to get here advances it
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(A.ticket, 1) == (int)gridDim.x - 1) {
+                *A.ticket = 0;
+                *A.step_dev += 1;
+            }
+        }
+    }
+}
+
+struct TrainPlan {
+    int MP, MC, acts_floats, maxw, maxin, Ptot, ntx;
+    size_t lds;
+    int poff[MGP_MAX_LAYERS], ioff[MGP_MAX_LAYERS];
+};
+
+bool make_train_plan(const int* dims, int n_layers, int B, int K, int N, TrainPlan* pl)
+{
+    if (dims == nullptr || n_layers <= 0 || n_layers > MGP_MAX_LAYERS || K <= 0 || K > TS_GROUPS || N <= 0 || B <= 0) return false;
+    const int F = dims[0];
+    if (F <= 0 || F > 8 || F * K > TS_MAXW) return false;
+    for (int i = 1; i <= n_layers; ++i) if (dims[i] <= 0 || dims[i] > TS_MAXW) return false;
+    const int FK = F * K;
+    pl->MP = TS_GROUPS / K;
+    pl->MC = N < 128 ? N : 128;                                          // G rows staged per chunk
+    int maxw = dims[n_layers], maxin = FK, poff = 0, ioff = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        const int cin = (l == 0) ? FK : dims[l], cout = dims[l + 1];
+        pl->poff[l] = poff; poff += cout * cin + cout;
+        pl->ioff[l] = ioff; ioff += cin * TS_CS;
+        if (cout > maxw) maxw = cout;
+        if (cin > maxw && l > 0) maxw = cin;
+        if (cin > maxin) maxin = cin;
+    }
+    pl->acts_floats = ioff; pl->maxw = maxw; pl->maxin = maxin; pl->Ptot = poff;
+    pl->ntx = (N + TS_COLS - 1) / TS_COLS;
+    if ((long)B * pl->ntx > 8192 || B > 65535) return false;             // partials: tiles x (Ptot + 1) floats
+    pl->lds = ((size_t)FK * N + (size_t)K * pl->MC * TS_COLS + (size_t)pl->MP * FK * TS_COLS + ioff + (size_t)2 * maxw * TS_CS
+               + (size_t)poff) * sizeof(float);
+    return pl->lds <= TS_LDS_LIMIT;
+}
+
+int launch_train(const float* X, const float* G, const float* target, const float* const* W, const float* const* b,
+                 const int* dims, int n_layers, float* flat_grad, float* loss, float* workspace, const AdamArgs& A,
+                 int B, int K, int N, hipStream_t st)
+{
+    TrainPlan pl;
+    if (!make_train_plan(dims, n_layers, B, K, N, &pl)) return MGP_EUNSUPPORTED;
+    TrainParams P;
+    P.n_layers = n_layers;
+    for (int i = 0; i <= n_layers; ++i) P.dims[i] = dims[i];
+    for (int l = 0; l < n_layers; ++l) {
+        MGP_CHECK_PTR(W[l]); MGP_CHECK_PTR(b[l]);
+        P.W[l] = W[l]; P.b[l] = b[l]; P.poff[l] = pl.poff[l]; P.ioff[l] = pl.ioff[l];
+    }
+    bool contiguous = true;
+    for (int l = 0; l < n_layers; ++l) {
+        const int cin = (l == 0) ? dims[0] * K : dims[l];
+        contiguous = contiguous && W[l] == W[0] + pl.poff[l] && b[l] == W[l] + (size_t)dims[l + 1] * cin;
+    }
+    P.flat = contiguous ? W[0] : nullptr;
+    const int Pstride = pl.Ptot + 1;
+    const long n_out = (long)B * dims[n_layers] * N;
+    mgp_clear_error();
+    if (pl.lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(train_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)pl.lds) != hipSuccess)
+        return MGP_ELAUNCH;
+    hipLaunchKernelGGL(train_tile_kernel, dim3(pl.ntx, B), dim3(TS_THREADS), pl.lds, st, X, G, target, workspace, P, Pstride,
+                       K, dims[0], N, pl.MP, pl.MC, pl.acts_floats, pl.maxw, 2.0f / (float)n_out);
+    int rc = mgp_launch_status();
+    if (rc != MGP_OK) return rc;
+    hipLaunchKernelGGL(train_reduce_kernel, dim3((unsigned)((Pstride + 63) / 64)), dim3(64 * TR_GROUPS), 0, st, workspace,
+                       B * pl.ntx, Pstride, flat_grad, loss, (float)(1.0 / (double)n_out), A);
+    return mgp_launch_status();
+}
+
+}  // namespace
+
+extern "C" int mgp_train_supported(const int* dims, int n_layers, int B, int K, int N)
+{
+    TrainPlan pl;
+    return make_train_plan(dims, n_layers, B, K, N, &pl) ? 1 : 0;
+}
+
+extern "C" long mgp_train_workspace(const int* dims, int n_layers, int B, int K, int N)
+{
+    TrainPlan pl;
+    if (!make_train_plan(dims, n_layers, B, K, N, &pl)) return 0;
+    return (long)B * pl.ntx * (pl.Ptot + 1) + 1;                         // + the ticket word of mgp_train_step
+}
+
+extern "C" int mgp_train_grads(const float* X, const float* G, const float* target, const float* const* W,
+                               const float* const* b, const int* dims, int n_layers, float* flat_grad, float* loss,
+                               float* workspace, int B, int K, int N, void* stream)
+{
+    if (dims == nullptr || W == nullptr || b == nullptr) return MGP_EINVAL;
+    if (B <= 0 || K <= 0 || N <= 0 || n_layers <= 0 || n_layers > MGP_MAX_LAYERS) return MGP_EINVAL;
+    MGP_CHECK_PTR(X); MGP_CHECK_PTR(G); MGP_CHECK_PTR(target); MGP_CHECK_PTR(flat_grad); MGP_CHECK_PTR(workspace);
+    if (loss != nullptr && (reinterpret_cast<uintptr_t>(loss) & 3u)) return MGP_EALIGN;
+    AdamArgs A = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f};
+    return launch_train(X, G, target, W, b, dims, n_layers, flat_grad, loss, workspace, A, B, K, N,
+                        static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mgp_train_step(const float* X, const float* G, const float* target, float* flat_param, float* flat_grad,
+                              float* m, float* v, const int* dims, int n_layers, float lr, float beta1, float beta2,
+                              float eps, int* step_dev, float* loss, float* workspace, int B, int K, int N, void* stream)
+{
+    if (dims == nullptr) return MGP_EINVAL;
+    if (B <= 0 || K <= 0 || N <= 0 || n_layers <= 0 || n_layers > MGP_MAX_LAYERS) return MGP_EINVAL;
+    MGP_CHECK_PTR(X); MGP_CHECK_PTR(G); MGP_CHECK_PTR(target); MGP_CHECK_PTR(flat_param); MGP_CHECK_PTR(flat_grad);
+    MGP_CHECK_PTR(m); MGP_CHECK_PTR(v); MGP_CHECK_PTR(step_dev); MGP_CHECK_PTR(workspace);
+    if (loss != nullptr && (reinterpret_cast<uintptr_t>(loss) & 3u)) return MGP_EALIGN;
+    TrainPlan pl;
+    if (!make_train_plan(dims, n_layers, B, K, N, &pl)) return MGP_EUNSUPPORTED;
+    const float* W[MGP_MAX_LAYERS];
+    const float* b[MGP_MAX_LAYERS];
+    for (int l = 0; l < n_layers; ++l) {
+        const int cin = (l == 0) ? dims[0] * K : dims[l];
+        W[l] = flat_param + pl.poff[l];
+        b[l] = W[l] + (size_t)dims[l + 1] * cin;
+    }
+    int* ticket = reinterpret_cast<int*>(workspace + (size_t)B * pl.ntx * (pl.Ptot + 1));
+    AdamArgs A = {flat_param, m, v, step_dev, ticket, lr, beta1, beta2, eps};
+    return launch_train(X, G, target, W, b, dims, n_layers, flat_grad, loss, workspace, A, B, K, N,
+                        static_cast<hipStream_t>(stream));
+}

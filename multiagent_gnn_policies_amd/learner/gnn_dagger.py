@@ -67,9 +67,10 @@ class FlatAdam(object):
 
 
 class GraphedUpdate(object):
-    """One DAGGER update (fused forward with saved activations -> MSE gradient -> fused backward straight into the
-    flat gradient buffer -> device-step Adam) captured once per batch size as a HIP graph on static buffers.
-    Five kernel launches replayed with one host call instead of ~40 Python-level ops."""
+    """One DAGGER update captured once per batch size as a HIP graph on static buffers and replayed with one host call
+    instead of ~40 Python-level ops.  Two launches when mgp_train_step covers the shape (forward + MSE gradient +
+    backward per 16-column tile, then partial reduction + device-step Adam); otherwise five (fused forward with saved
+    activations -> MSE gradient -> fused backward straight into the flat gradient buffer -> device-step Adam)."""
 
     def __init__(self, learner, B):
         import ctypes
@@ -97,11 +98,21 @@ class GraphedUpdate(object):
         self.B, self.K, self.N, self.nl = B, K, N, actor.n_layers
         self.opt = opt
         self.graph = None
+        self.two_launch = bool(learner.use_train_step and L.mgp_train_supported(self.cdims, actor.n_layers, B, K, N))
+        if self.two_launch:
+            self.tws = torch.zeros((L.mgp_train_workspace(self.cdims, actor.n_layers, B, K, N),), device=dev)
 
     def _enqueue(self):
         from .. import _lib
         L, o = _lib.lib(), self.opt
         st = ops._stream()
+        if self.two_launch:
+            _lib.check(L.mgp_train_step(ops._ptr(self.X), ops._ptr(self.G), ops._ptr(self.Y), ops._ptr(o.flat),
+                                        ops._ptr(o.flat_grad), ops._ptr(o.m), ops._ptr(o.v), self.cdims, self.nl,
+                                        o.lr, o.betas[0], o.betas[1], o.eps, ops._ptr(self.step_dev),
+                                        ops._ptr(self.loss), ops._ptr(self.tws), self.B, self.K, self.N, st),
+                       'mgp_train_step')
+            return
         _lib.check(L.mgp_actor_fwd(ops._ptr(self.X), ops._ptr(self.G), self.Wp, self.bp, self.cdims, self.nl,
                                    ops._ptr(self.out), ops._ptr(self.saved), self.B, self.K, self.N, st), 'mgp_actor_fwd')
         _lib.check(L.mgp_mse_grad(ops._ptr(self.out), ops._ptr(self.Y), ops._ptr(self.dOut), ops._ptr(self.loss),
@@ -159,6 +170,8 @@ class DAGGER(object):
         self.grad_sync.broadcast_(self.actor_optim.flat)
         self._graphed = {}                        # batch size -> GraphedUpdate
         self.use_graphed_update = True
+        self.use_train_step = True                # two-launch update (mgp_train_step / mgp_train_grads) when covered
+        self._train_ws = {}                       # batch size -> workspace of the eager mgp_train_grads path
 
     def _can_graph(self, X):
         """Single-process runs whose shape the fused kernels cover replay the update from a HIP graph; the
@@ -207,6 +220,11 @@ class DAGGER(object):
                 gu = self._graphed[B] = GraphedUpdate(self, B)
             loss = gu.run(delay_state_batch, delay_gso_batch, optimal_action_batch)
             return loss.item() if sync else loss.clone()
+        loss = self._train_grads(delay_state_batch, delay_gso_batch, optimal_action_batch)
+        if loss is not None:                       # two launches wrote the flat gradient; (all-reduce,) Adam
+            self.grad_sync.all_reduce_mean_(self.actor_optim.flat_grad)
+            self.actor_optim.step()
+            return loss.item() if sync else loss
         self.actor_optim.zero_grad()
         actor_batch = self.actor(delay_state_batch, delay_gso_batch)
         policy_loss = ops.mse_loss(actor_batch, optimal_action_batch)
@@ -215,6 +233,33 @@ class DAGGER(object):
         self.grad_sync.all_reduce_mean_(flat_grad)
         self.actor_optim.step()
         return policy_loss.item()
+
+    def _train_grads(self, X, G, Y):
+        """mgp_train_grads: forward + MSE + parameter backward into the flat gradient buffer; returns the (1,) loss
+        tensor, or None when the shape is outside its coverage (the caller composes the separate kernels)."""
+        import ctypes
+        from .. import _lib
+        from .actor_fused import _ptr_array
+        actor, opt = self.actor, self.actor_optim
+        if not (self.use_train_step and actor.use_fused and actor.ind_agg == 0 and X.is_cuda):
+            return None
+        B, K, _, N = X.shape
+        dims = tuple(actor.layers)
+        cd = (ctypes.c_int * len(dims))(*dims)
+        L = _lib.lib()
+        if not L.mgp_train_supported(cd, actor.n_layers, B, K, N):
+            return None
+        ws = self._train_ws.get((B, N))
+        if ws is None:
+            ws = self._train_ws[(B, N)] = torch.zeros((L.mgp_train_workspace(cd, actor.n_layers, B, K, N),),
+                                                      device=X.device)
+        pv = opt.views(opt.flat)
+        loss = torch.empty((1,), device=X.device)
+        X, G, Y = X.contiguous(), G.contiguous(), Y.contiguous()
+        _lib.check(L.mgp_train_grads(ops._ptr(X), ops._ptr(G), ops._ptr(Y), _ptr_array(pv[0::2]), _ptr_array(pv[1::2]),
+                                     cd, actor.n_layers, ops._ptr(opt.flat_grad), ops._ptr(loss), ops._ptr(ws),
+                                     B, K, N, ops._stream()), 'mgp_train_grads')
+        return loss
 
     def save_model(self, env_name, suffix="", actor_path=None):
         if not os.path.exists('models/'):

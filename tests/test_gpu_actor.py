@@ -132,9 +132,18 @@ def test_state_with_delay_vs_reference(name):
         prev = st
 
 
+UPDATE_PATHS = {                                   # (use_graphed_update, use_train_step)
+    'graph_two_launch': (True, True),              # mgp_train_step replayed from a HIP graph (the default)
+    'graph_five_launch': (True, False),            # fwd / mse / bwd / scatter / adam graph
+    'eager_train_grads': (False, True),            # mgp_train_grads + mgp_adam_step (the data-parallel form)
+    'eager_composed': (False, False),              # autograd over the separate kernels
+}
+
+
+@pytest.mark.parametrize('path', sorted(UPDATE_PATHS))
 @pytest.mark.parametrize('name', DAGGER_GOLDENS)
-def test_dagger_learner_vs_reference(name):
-    """select_action and three gradient_steps of the DAGGER learner against the reference's."""
+def test_dagger_learner_vs_reference(name, path):
+    """select_action and three gradient_steps of the DAGGER learner against the reference's, on every update path."""
     from types import SimpleNamespace
     from multiagent_gnn_policies_amd.learner.gnn_dagger import DAGGER
     from multiagent_gnn_policies_amd.learner import Transition
@@ -143,6 +152,7 @@ def test_dagger_learner_vs_reference(name):
     args = _args(n_agents=n, k=k, batch_size=bsz)
     torch.manual_seed(11)
     learner = DAGGER(torch.device('cuda:0'), args)
+    learner.use_graphed_update, learner.use_train_step = UPDATE_PATHS[path]
     Ws, bs = golden_weights(g, 'w0__')
     for i, conv in enumerate(learner.actor.conv_layers):      # same seed => identical default init
         assert np.array_equal(conv.weight.detach().cpu().numpy(), Ws[i])

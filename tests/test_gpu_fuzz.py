@@ -89,6 +89,48 @@ def test_state_and_sim_random_sizes(seed):
             assert abs(sim.reward[b].item() - ofl.reward(xs[b], op)) <= 1e-12 * max(1.0, abs(ofl.reward(xs[b], op)))
 
 
+@pytest.mark.parametrize('seed', range(60))
+def test_train_grads_random_configuration(seed):
+    """mgp_train_grads (forward + MSE + parameter backward in one tile kernel) on random shapes vs the oracle."""
+    import ctypes
+    from multiagent_gnn_policies_amd import _lib, ops
+    from multiagent_gnn_policies_amd.learner.actor_fused import _ptr_array
+    rs = np.random.RandomState(9000 + seed)
+    B = int(rs.choice([1, 2, 5, 20, 33])); K = int(rs.randint(1, 5)); F = int(rs.choice([2, 6, 6, 8]))
+    N = int(rs.choice([3, 16, 17, 50, 100, 100, 129, 200]))
+    hidden = [int(rs.choice([1, 4, 16, 32, 32, 48, 64])) for _ in range(int(rs.randint(0, 4)))]
+    n_a = int(rs.choice([1, 2, 2, 3]))
+    dims = [F] + hidden + [n_a]
+    L = _lib.lib()
+    cd = (ctypes.c_int * len(dims))(*dims)
+    assert L.mgp_train_supported(cd, len(dims) - 1, B, K, N)
+    X, G = (synth.make_dense_inputs if seed % 2 else synth.make_inputs)(seed, B, K, F, N)
+    Ws, bs = [], []
+    for i in range(len(dims) - 1):
+        cin = dims[i] * (K if i == 0 else 1)
+        Ws.append((rs.randn(dims[i + 1], dims[i], K if i == 0 else 1, 1) / np.sqrt(cin)).astype(np.float32))
+        bs.append((0.1 * rs.randn(dims[i + 1])).astype(np.float32))
+    ref, cache = oa.forward(X, G, Ws, bs, 0, dtype=np.float64, return_cache=True)
+    target = rs.randn(*ref.shape).astype(np.float32)
+    dWs, dbs, _ = oa.backward(od.mse_grad(ref, target), G, Ws, 0, cache, need_dx=False)
+    flat_ref = np.concatenate([np.concatenate([dWs[i].ravel(), dbs[i].ravel()]) for i in range(len(Ws))])
+    Wd = [torch.from_numpy(w).cuda() for w in Ws]; bd = [torch.from_numpy(b).cuda() for b in bs]
+    flat = torch.full((flat_ref.size,), float('nan'), device='cuda')
+    loss = torch.zeros((1,), device='cuda')
+    ws = torch.zeros((L.mgp_train_workspace(cd, len(Ws), B, K, N),), device='cuda')
+    Xd, Gd, Td = torch.from_numpy(X).cuda(), torch.from_numpy(G).cuda(), torch.from_numpy(target).cuda()
+    for rep in range(2):                               # second call: same workspace, bit-identical result
+        _lib.check(L.mgp_train_grads(ops._ptr(Xd), ops._ptr(Gd), ops._ptr(Td), _ptr_array(Wd), _ptr_array(bd), cd,
+                                     len(Ws), ops._ptr(flat), ops._ptr(loss), ops._ptr(ws), B, K, N, ops._stream()),
+                   'mgp_train_grads')
+        got = flat.cpu().numpy()
+        if rep:
+            assert np.array_equal(got, first)
+        first = got.copy()
+    assert relerr(got, flat_ref) <= 2e-5, (B, K, F, N, hidden, n_a)
+    assert abs(loss.item() - od.mse_loss(ref, target)) <= 1e-5 * max(1.0, od.mse_loss(ref, target))
+
+
 @pytest.mark.parametrize('seed', range(40))
 def test_resident_rollout_random_shapes(seed):
     """mgp_rollout_steps on random (N, K, layers, widths, spec variants): every step against the oracle transition."""
