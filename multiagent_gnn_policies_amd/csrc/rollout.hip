@@ -188,7 +188,7 @@ __device__ __forceinline__ float wave_max_to_last(float v)
 // transition needs the previous network as gather source while the new one is being built); rows of G_1 are expanded
 // on the fly where slice 2 is formed, and written out densely on exit.  Precondition in this mode: the caller's slice 1
 // has that structure (every non-zero of a row carries the same value), which is what the state builder produces.
-template <int CN, int CK, bool PK>
+template <int CN, int CK, bool PK, bool FD>
 __global__ __launch_bounds__(RO_THREADS)
 void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __restrict__ Xd, float* __restrict__ action,
                     double* __restrict__ rewards, RoParams P, MgpFlockParams p, int K_arg, int N_arg, int T,
@@ -562,7 +562,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 in_m &= in_m - 1u;
                 int j = pi + d0 + q;
                 j = (j >= N) ? j - N : j;
-                if (p.link_drop != 0u &&                      // FlockingStochastic-v0: the pair's link is faded this step
+                if (FD && p.link_drop != 0u &&                // FlockingStochastic-v0: the pair's link is faded this step
                     !link_up(p, pi, j, N, fade_word(spx[pi], spy[pi]), fade_word(spx[j], spy[j]))) continue;
                 atomicOr(&rm_new[2 * pi + (j >> 6)], 1ull << (j & 63));
                 atomicOr(&rm_new[2 * j + (pi >> 6)], 1ull << (pi & 63));
@@ -747,15 +747,15 @@ bool make_carve(const int* dims, int n_layers, int K, int N, RoParams* P, int* l
     return true;
 }
 
-template <int CN, int CK, bool PK>
+template <int CN, int CK, bool PK, bool FD>
 int launch_rollout(double* x, float* G, float* Xd, float* action, double* rewards, const RoParams& P,
                    const MgpFlockParams* p, int B, int K, int N, int T, unsigned long long dimsA, unsigned int dims8,
                    unsigned long long woffA, unsigned long long woffB, int n_layers, int lds, hipStream_t st)
 {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<CN, CK, PK>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<CN, CK, PK, FD>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MGP_ELAUNCH;
-    hipLaunchKernelGGL((rollout_kernel<CN, CK, PK>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K,
+    hipLaunchKernelGGL((rollout_kernel<CN, CK, PK, FD>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K,
                        N, T, dimsA, dims8, woffA, woffB, n_layers);
     return mgp_launch_status();
 }
@@ -802,13 +802,16 @@ extern "C" int mgp_rollout_steps(double* x, float* G, float* Xd, const float* co
     }
     mgp_clear_error();
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (N == 100 && K == 3)       // the headline shape (BASELINE.json configs[0..1]) runs a build with compile-time addresses
-        return launch_rollout<100, 3, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
-    if (N == 100 && K == 2 && !packed)   // cfg/default.cfg, cloning.cfg, dagger_twoflocks.cfg
-        return launch_rollout<100, 2, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
+    const bool fade = p->link_drop != 0u;   // FlockingStochastic-v0: the generic builds carry the fade hash, the others do not
+    if (N == 100 && K == 3 && !fade)   // the headline shape (BASELINE.json configs[0..1]) runs a build with compile-time addresses
+        return launch_rollout<100, 3, false, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
+    if (N == 100 && K == 2 && !packed && !fade)   // cfg/default.cfg, cloning.cfg, dagger_twoflocks.cfg
+        return launch_rollout<100, 2, false, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
     // (a <100, 4, true> instantiation trips an LLVM backend error -- "Operand has incorrect register class" -- on this
     //  toolchain; the reference's K = 4 sweeps at N = 100 run the generic packed build, 2.7e9 agent-steps/s)
     if (packed)                   // slice 1 kept as bits + row weights
-        return launch_rollout<0, 0, true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
-    return launch_rollout<0, 0, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
+        return fade ? launch_rollout<0, 0, true, true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st)
+                    : launch_rollout<0, 0, true, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
+    return fade ? launch_rollout<0, 0, false, true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st)
+                : launch_rollout<0, 0, false, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
 }

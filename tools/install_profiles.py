@@ -19,5 +19,11 @@ open('profiles/r01_bench_kernel_trace_final.txt','w').write(''.join(_kt[:2]) + _
 shutil.copy(O+'/dagger_update.json','profiles/r01_dagger_update.json')   # produced by `python bench.py --dagger-update`
 hdr = "# bench.py at other shapes (B N K): value, per-path throughput, per-kernel (avg launch us, GB/s), state finite\n# `resident` = mgp_rollout_steps (covered: N <= 128, widths <= 32, state fits LDS); otherwise the two-launch path is `value`\n"
 open('profiles/r01_other_configs.txt','w').write(hdr+open(O+'/other_configs.txt').read())
+import os
+if os.path.exists(O+'/train_phase_stamps.txt'):
+    open('profiles/r01_train_step_phase_stamps.txt','w').write(
+        "# tools/harness/train_phase_prof.hip on MI355X: in-kernel s_memtime stamps of workgroup (0,0), thread 0 of\n"
+        "# train_tile_kernel (shader cycles, ~2.1 GHz); the per-update time is both launches of mgp_train_step\n"
+        + open(O+'/train_phase_stamps.txt').read())
 from multiagent_gnn_policies_amd import build
 print('hash ok', build.source_hash() == json.load(open('profiles/r01_pmc_traffic.json'))['_meta']['source_hash'])

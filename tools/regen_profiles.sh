@@ -6,6 +6,7 @@
 #   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -o scratch/ro_prof tools/harness/ro_phase_prof.hip
 #   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -o scratch/fl_prof tools/harness/flock_phase_prof.hip
 #   hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -o scratch/af_prof tools/harness/af_phase_prof.hip
+#   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -w -o scratch/ts_prof tools/harness/train_phase_prof.hip
 # PMC passes use --pmc with --kernel-trace only (no sys/runtime/hip trace domains).
 set -x
 R=$GRAFT_REPO_ROOT
@@ -30,6 +31,7 @@ python tools/rocpd_stats.py $T > $O/bench_kernel_trace.txt 2>&1
 ./scratch/ro_prof 256 100 3 200 > $O/rollout_phase_stamps.txt 2>&1
 ./scratch/fl_prof 256 100 > $O/flock_phase_stamps.txt 2>&1
 ./scratch/af_prof 256 100 > $O/af_phase_stamps.txt 2>&1
+./scratch/ts_prof 20 100 3 > $O/train_phase_stamps.txt 2>&1
 # 4. DAGGER update + other configs
 python tools/bench_update.py > $O/dagger_update.json 2> $O/dagger_update.err
 for cfg in "64 1000 3" "256 200 4" "1 100 3" "2048 100 3" "256 100 4" "256 100 2" "256 100 1" "256 125 3" "256 75 3" "256 50 2" "256 25 4"; do set -- $cfg; python bench.py --episodes $1 --agents $2 --taps $3 --no-cpu-baseline --steps 100 --warmup 10 2>/dev/null | python -c "
