@@ -20,6 +20,17 @@ shutil.copy(O+'/dagger_update.json','profiles/r01_dagger_update.json')   # produ
 hdr = "# bench.py at other shapes (B N K): value, per-path throughput, per-kernel (avg launch us, GB/s), state finite\n# `resident` = mgp_rollout_steps (covered: N <= 128, widths <= 32, state fits LDS); otherwise the two-launch path is `value`\n"
 open('profiles/r01_other_configs.txt','w').write(hdr+open(O+'/other_configs.txt').read())
 import os
+# phase-stamp files keep their hand-written legend (leading '#' lines); the body is the harness output of this run
+for src, dst in [('rollout_phase_stamps.txt', 'profiles/r01_rollout_phase_stamps.txt'),
+                 ('flock_phase_stamps.txt', 'profiles/r01_flock_step_phase_stamps.txt'),
+                 ('af_phase_stamps.txt', 'profiles/r01_actor_fwd_phase_stamps.txt')]:
+    if os.path.exists(O + '/' + src) and os.path.exists(dst):
+        lead = []
+        for line in open(dst).read().splitlines(True):
+            if not line.startswith('#'):
+                break
+            lead.append(line)
+        open(dst, 'w').write(''.join(lead) + open(O + '/' + src).read())
 if os.path.exists(O+'/train_phase_stamps.txt'):
     open('profiles/r01_train_step_phase_stamps.txt','w').write(
         "# tools/harness/train_phase_prof.hip on MI355X: in-kernel s_memtime stamps of workgroup (0,0), thread 0 of\n"
