@@ -194,8 +194,19 @@ class DAGGER(object):
 
     def gradient_step(self, batch):
         """One supervised update on a batch of transitions (reference gnn_dagger.py:76-96)."""
-        delay_gso_batch = torch.cat(tuple(s.delay_gso for s in batch.state)).to(self.device)
-        delay_state_batch = torch.cat(tuple(s.delay_state for s in batch.state)).to(self.device)
+        gsos = tuple(s.delay_gso for s in batch.state)
+        states = tuple(s.delay_state for s in batch.state)
+        # concatenate straight into the HIP-graph update's static input buffers when that path will run (saves three
+        # device copies per update); otherwise into fresh tensors as the reference does
+        bufs = None
+        if states[0].device == self.device and all(t.shape[0] == 1 for t in states):
+            bufs = self.graphed_buffers(len(states), states[0].shape[3])
+        if bufs is not None:
+            X, G, Y = bufs
+            torch.cat(states, out=X); torch.cat(gsos, out=G); torch.cat(batch.action, out=Y)
+            return self.gradient_step_tensors(X, G, Y)
+        delay_gso_batch = torch.cat(gsos).to(self.device)
+        delay_state_batch = torch.cat(states).to(self.device)
         optimal_action_batch = torch.cat(batch.action).to(self.device)
         return self.gradient_step_tensors(delay_state_batch, delay_gso_batch, optimal_action_batch)
 
