@@ -53,7 +53,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifdef MGP_RO_PROFILE
 __device__ unsigned long long mgp_ro_stamps[16 * 16];     // [wave][stamp]
-#define RO_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == 1) mgp_ro_stamps[(threadIdx.x >> 6) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define RO_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == 5) mgp_ro_stamps[(threadIdx.x >> 6) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define RO_STAMP(i) do { } while (0)
 #endif
@@ -68,39 +68,40 @@ struct RoParams {
 
 // LDS layout (byte offsets).  Every region except the weight image depends on (N, K) only, and the weight image comes
 // last, so a kernel instantiated for a fixed (N, K) has compile-time LDS addresses (ds_read/ds_write immediates).
+// H = max(K - 1, 1) history slots hold the neighbour lists / row weights of the last K - 1 networks (ring over time).
 struct RoOff {
     int pos;                              // double px, py, vx, vy [4][N] + reference point [2]
-    int mask;                             // u64 [N+1][2] membership bits of the network (row N = 0; x2 when G_1 is packed)
-    int wrow;                             // float [N+1] network weight of row i (1/deg or 1) (x2 when G_1 is packed)
+    int mask;                             // u64 [N][2] membership bits of the network being built (cleared in phase B)
+    int wrow;                             // float [H][N] network weight of row i (1/deg or 1)
     int uact;                             // float [2][N] action (the Actor output layout (nA, N))
     int xt;                               // float [K][Np][8] delay line, ring over taps, transposed (6 features + 2 pad); Np = N
                                           // rounded up to a multiple of 4, rows >= N are zero
-    int gd;                               // float [K-1][Np+1][Np] delayed operator, slices 1..K-1 (2..K-1 when G_1 is packed); rows
-                                          // and columns >= N are zero (row N is what list padding points at)
-    int act;                              // float [ncols16][RO_CS] activations (in place through the layers)
-    int rlist;                            // u8 [N][RS] ascending neighbour lists, padded with N (RS = N rounded to 8, + 8)
-    int rcnt;                             // int [N] list lengths
+    int vb;                               // float [2][K-2][Np][8] partial products of taps >= 2 between gather stages (ping-pong)
+    int act;                              // float [ncols16][RO_CS] activations (in place through the layers); row buffers on exit
+    int rlist;                            // u8 [H][N][RS] ascending neighbour lists (RS = N rounded to 8, + 8)
+    int rcnt;                             // int [H][N] list lengths
     int sxy;                              // float2 [N] fp32 coordinates relative to the reference point
     int mmax;                             // uint: max |relative coordinate| of the step (float bits)
     int wl;                               // float weight image: per layer fragments [MT][64][RO_WFS] + bias [MT*16]
 };
 
 __host__ __device__ constexpr int ro_take(int& off, int bytes) { const int o = off; off += (bytes + 15) & ~15; return o; }
+__host__ __device__ constexpr int ro_hist(int K) { return K > 2 ? K - 1 : 1; }
 
-// pk: G_1 is not kept dense (see PK below): one dense slice less, membership bits / row weights double buffered
-__host__ __device__ constexpr RoOff ro_offsets(int N, int K, bool pk)
+__host__ __device__ constexpr RoOff ro_offsets(int N, int K)
 {
     RoOff c = {};
     int off = 0;
+    const int Np = (N + 3) & ~3, H = ro_hist(K);
     c.pos = ro_take(off, (4 * N + 2) * 8);
-    c.mask = ro_take(off, (pk ? 2 : 1) * 2 * (N + 1) * 8);
-    c.wrow = ro_take(off, (pk ? 2 : 1) * (N + 1) * 4);
+    c.mask = ro_take(off, 2 * N * 8);
+    c.wrow = ro_take(off, H * N * 4);
     c.uact = ro_take(off, 2 * N * 4);
-    c.xt = ro_take(off, K * ((N + 3) & ~3) * 8 * 4);
-    c.gd = ro_take(off, (K - (pk ? 2 : 1) > 0 ? K - (pk ? 2 : 1) : 0) * (((N + 3) & ~3) + 1) * ((N + 3) & ~3) * 4);
+    c.xt = ro_take(off, K * Np * 8 * 4);
+    c.vb = ro_take(off, 2 * (K > 2 ? K - 2 : 0) * Np * 8 * 4);
     c.act = ro_take(off, ((N + 15) & ~15) * RO_CS * 4);
-    c.rlist = ro_take(off, N * (((N + 7) & ~7) + 8));
-    c.rcnt = ro_take(off, N * 4);
+    c.rlist = ro_take(off, H * N * (((N + 7) & ~7) + 8));
+    c.rcnt = ro_take(off, H * N * 4);
     c.sxy = ro_take(off, N * 8);
     c.mmax = ro_take(off, 16);
     c.wl = off;
@@ -183,12 +184,8 @@ __device__ __forceinline__ float wave_max_to_last(float v)
 
 // CN / CK: compile-time (N, K) of a specialised instantiation (0 = take the run-time arguments): constant LDS addresses,
 // loop bounds and divisors shorten every phase's address arithmetic and relieve the SGPR file (the generic build spills).
-// PK ("packed G_1"): for shapes whose K-1 dense slices do not fit the LDS (N = 100, K = 4).  Slice 1 is the network
-// matrix itself, A_t = w_i x membership bits, so it is kept only as bits + row weights (double buffered: the operator
-// transition needs the previous network as gather source while the new one is being built); rows of G_1 are expanded
-// on the fly where slice 2 is formed, and written out densely on exit.  Precondition in this mode: the caller's slice 1
-// has that structure (every non-zero of a row carries the same value), which is what the state builder produces.
-template <int CN, int CK, bool PK, bool FD>
+// FD: link fading (FlockingStochastic-v0) compiled in.
+template <int CN, int CK, bool FD>
 __global__ __launch_bounds__(RO_THREADS)
 void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __restrict__ Xd, float* __restrict__ action,
                     double* __restrict__ rewards, RoParams P, MgpFlockParams p, int K_arg, int N_arg, int T,
@@ -196,8 +193,8 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                     int n_layers)
 {
     const int N = CN ? CN : N_arg, K = CK ? CK : K_arg;
-    const RoOff cv = ro_offsets(N, K, PK);
-    constexpr int SL0 = PK ? 2 : 1;                          // first slice held densely; slice j lives at index j - SL0
+    const RoOff cv = ro_offsets(N, K);
+    const int H = ro_hist(K);
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     double* spx = reinterpret_cast<double*>(smraw + cv.pos);
     double* spy = spx + N; double* svx = spx + 2 * N; double* svy = spx + 3 * N;
@@ -206,71 +203,26 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     float* wrow = reinterpret_cast<float*>(smraw + cv.wrow);
     float* uact = reinterpret_cast<float*>(smraw + cv.uact);
     float* XT = reinterpret_cast<float*>(smraw + cv.xt);
-    float* Gd = reinterpret_cast<float*>(smraw + cv.gd);
+    float* VB = reinterpret_cast<float*>(smraw + cv.vb);
     float* wl = reinterpret_cast<float*>(smraw + cv.wl);
     float* act = reinterpret_cast<float*>(smraw + cv.act);
     unsigned char* rlist = smraw + cv.rlist;
     int* rcnt = reinterpret_cast<int*>(smraw + cv.rcnt);
     float2* sxy = reinterpret_cast<float2*>(smraw + cv.sxy);
     unsigned int* mmax = reinterpret_cast<unsigned int*>(smraw + cv.mmax);
-    const int RS = ((N + 7) & ~7) + 8;                        // list row stride (bytes): aligned 8-entry chunks + padding room
+    const int RS = ((N + 7) & ~7) + 8;                        // list row stride (bytes)
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Np = (N + 3) & ~3;                              // LDS row length / k-step range: N rounded up to a multiple of 4
-    const int NN = N * N, NS = (Np + 1) * Np, n4 = Np >> 2, FK = 6 * K;   // NS: slice stride; rows / columns >= N are all zeros
+    const int Np = (N + 3) & ~3;                              // delay-line rows: N rounded up to a multiple of 4
+    const int NN = N * N, FK = 6 * K;
     const int ncols16 = pad16(N), NT = ncols16 / 16;
     double* xb = x + (size_t)b * N * 4;
     float* Gb = G + (size_t)b * K * NN;
     float* Xb = Xd + (size_t)b * K * 6 * N;
 
     // ------------------------------------------------------------------ entry: the episode's state -> LDS
-    if (Np == N) {                                            // rows are 16-byte aligned on both sides: flat float4 copy
-        for (int j = SL0; j < K; ++j) {
-            const float4* gsrc = reinterpret_cast<const float4*>(Gb + (size_t)j * NN);
-            float4* gdst = reinterpret_cast<float4*>(Gd + (size_t)(j - SL0) * NS);
-#pragma unroll 4
-            for (int e = tid; e < NN / 4; e += RO_THREADS) gdst[e] = gsrc[e];
-            for (int e = tid; e < N; e += RO_THREADS) Gd[(size_t)(j - SL0) * NS + NN + e] = 0.f;
-        }
-    } else {                                                  // N % 4 != 0: padded LDS rows, element-wise copy (once per launch)
-        float4* z4 = reinterpret_cast<float4*>(Gd);
-        for (int e = tid; e < (K - SL0) * NS / 4; e += RO_THREADS) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-        __syncthreads();
-        for (int j = SL0; j < K; ++j)
-            for (int e = tid; e < NN; e += RO_THREADS) {
-                const int i = e / N, n = e - i * N;
-                Gd[(size_t)(j - SL0) * NS + i * Np + n] = Gb[(size_t)j * NN + e];
-            }
-    }
-    if (tid < (PK ? 4 : 2)) rowmask[2 * N + (tid & 1) + (tid >> 1) * 2 * (N + 1)] = 0ull;   // row N (list padding) of the bit buffer(s)
-    if (PK && K >= 2) {
-        // packed slice 1: bits + row weight from the caller's dense rows -- coalesced float4 reads of the whole slice, every
-        // lane ORs its four pattern bits into the row's words (weights are non-negative, so their float bits order like ints)
-        for (int i = tid; i < N; i += RO_THREADS) { rowmask[2 * i] = 0ull; rowmask[2 * i + 1] = 0ull; wrow[i] = 0.f; }
-        __syncthreads();
-        if (Np == N) {
-            const float4* g1 = reinterpret_cast<const float4*>(Gb + NN);
-            for (int e = tid; e < NN / 4; e += RO_THREADS) {
-                const float4 v = g1[e];
-                const int i = e / n4, c0 = (e - i * n4) * 4;
-                const unsigned long long nib = (v.x != 0.f ? 1ull : 0ull) | (v.y != 0.f ? 2ull : 0ull) | (v.z != 0.f ? 4ull : 0ull) |
-                                               (v.w != 0.f ? 8ull : 0ull);
-                if (nib) {
-                    atomicOr(&rowmask[2 * i + (c0 >> 6)], nib << (c0 & 63));
-                    atomicMax(reinterpret_cast<unsigned int*>(wrow) + i, __float_as_uint(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w))));
-                }
-            }
-        } else {
-            for (int e = tid; e < NN; e += RO_THREADS) {
-                const float v = Gb[NN + e];
-                const int i = e / N, n = e - i * N;
-                if (v != 0.f) {
-                    atomicOr(&rowmask[2 * i + (n >> 6)], 1ull << (n & 63));
-                    atomicMax(reinterpret_cast<unsigned int*>(wrow) + i, __float_as_uint(v));
-                }
-            }
-        }
-    }
+    // (the caller's dense operator slices stay in HBM: they are read by the first K - 1 steps only, see phase A)
+    for (int i = tid; i < 2 * N; i += RO_THREADS) rowmask[i] = 0ull;
     for (int e = tid; e < K * Np * 8; e += RO_THREADS) {                       // tap k -> ring slot (K - k) % K, cur = 0
         const int f = e & 7, mk = e >> 3, k = mk / Np, m = mk - k * Np;
         const int slot = (k == 0) ? 0 : K - k;
@@ -310,24 +262,10 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         float4* za = reinterpret_cast<float4*>(act);
         for (int i = tid; i < ncols16 * RO_CS / 4; i += RO_THREADS) za[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         unsigned int* zl = reinterpret_cast<unsigned int*>(rlist);            // every list byte is always a valid row index
-        for (int i = tid; i < N * RS / 4; i += RO_THREADS) zl[i] = 0u;
+        for (int i = tid; i < H * N * RS / 4; i += RO_THREADS) zl[i] = 0u;
+        for (int i = tid; i < H * N; i += RO_THREADS) { rcnt[i] = 0; wrow[i] = 0.f; }
     }
     __syncthreads();
-    // non-zero pattern of the entry G_1, by COLUMN (tap 1 of the first step walks it; inside the launch the pattern is the
-    // symmetric network of the last simulator step and the row lists built there serve as column lists)
-    if (K >= 2)
-        for (int n = tid; n < N; n += RO_THREADS) {
-            int c = 0;
-            if (PK) {                                         // structured slice 1: symmetric pattern, row list = column list
-                unsigned long long lo = rowmask[2 * n], hi = rowmask[2 * n + 1];
-                while (lo) { rlist[n * RS + c++] = (unsigned char)__builtin_ctzll(lo); lo &= lo - 1ull; }
-                while (hi) { rlist[n * RS + c++] = (unsigned char)(64 + __builtin_ctzll(hi)); hi &= hi - 1ull; }
-            } else {
-                for (int m = 0; m < N; ++m)
-                    if (Gd[m * Np + n] != 0.f) rlist[n * RS + c++] = (unsigned char)m;
-            }
-            rcnt[n] = c;
-        }
     for (int e = tid; e < N * 8; e += RO_THREADS) {             // tap 0 of the first step (later steps: written in D3)
         const int f = e & 7, n = e >> 3;
         if (f < 6) act[n * RO_CS + rpos(f * K)] = XT[e];          // cur = 0: slot 0 holds tap 0
@@ -335,87 +273,93 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     __syncthreads();
 
     // thread roles that do not change over the steps
-    //   aggregation: dense taps k >= 2 -> one wave per (tap, 16-column tile) task, waves [0, dwaves);
-    //                sparse tap 1      -> thread (column, parity of the list entry), waves [dwaves, dwaves + swaves)
-    const int ntasks = (K > 2) ? (K - 2) * NT : 0;
-    const int swaves = (K >= 2) ? (2 * N + 63) >> 6 : 0;
-    const int dwaves = min(ntasks, RO_WAVES - swaves);
-    const int st_ = tid - dwaves * 64;
-    const bool sparse_wave = wave >= dwaves && wave < dwaves + swaves;
-    const bool sparse_active = sparse_wave && st_ < 2 * N;
-    const int sn = st_ >> 1, sq = st_ & 1;
+    //   aggregation: thread (column gn, tap offset gt, parity gq of the list entry); stage q works on tap q + gt
+    const int gq = tid & 1, gn = (tid >> 1) % N, gt = (tid >> 1) / N;
     const int li = lane & 15, lq = lane >> 4;
     const int pi = tid >> 3, piece = tid & 7;                 // membership: agent row pi, piece of the offset range
     const int half = N >> 1, dh = (half + RO_PIECES - 1) / RO_PIECES;          // offsets 1..N/2, <= 8 per piece
     const int fr = tid >> 2, fq = tid & 3;                    // lists / features: agent row fr, lane fq of 4
-    const int hw = tid >> 5, hl = tid & 31;                   // operator rows: half-wave per row, 4 columns per lane
     const double R2 = p.comm_radius2;
     const float R2f = (float)R2, Rf = sqrtf(R2f);
-    int cur = 0;
-    int cs = 0;                                               // PK: buffer of the CURRENT network's bits / weights
+    int cur = 0;                                              // ring slot of tap 0 in XT
+    int hs = 0;                                               // history slot of the CURRENT network (valid from step 1 on)
 
     for (int t = 0; t < T; ++t) {
         RO_STAMP(0);
-        unsigned long long* rm_new = rowmask + (PK ? (cs ^ 1) * 2 * (N + 1) : 0);    // network of the step being simulated
-        const unsigned long long* rm_cur = rowmask + (PK ? cs * 2 * (N + 1) : 0);     // network of the state the step starts from
-        float* w_new = wrow + (PK ? (cs ^ 1) * (N + 1) : 0);
-        const float* w_cur = wrow + (PK ? cs * (N + 1) : 0);
-        // -------------------------------------------------------------- A: aggregation from LDS
-        if (wave < dwaves) {
-            for (int task = wave; task < ntasks; task += dwaves) {
-                const int kq = task / NT, nt = task - kq * NT;                  // tap kq + 2, columns 16 nt .. 16 nt + 15
-                const int col = nt * 16 + li;
-                const float* g = Gd + (size_t)(kq + 2 - SL0) * NS + lq * Np + min(col, N - 1); // B[k = lq][j = li] = G[4 s + lq][col]
-                const float* xa = XT + (size_t)ro_slot(cur, kq + 2, K) * Np * 8 + lq * 8 + (li & 7);   // A[i = li][k = lq] = X[f = li][4 s + lq]
-                const float amask = (li < 8) ? 1.f : 0.f;                       // f = 6, 7 are zero pads in XT; rows 8..15 unused
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};   // even / odd k-steps: half the dependent chain
-                for (int s0 = 0; s0 < n4; s0 += 8) {                            // operands of 8 k-steps first, then the MFMAs
-                    float av[8], bv[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int s_ = min(s0 + u, n4 - 1);
-                        bv[u] = g[s_ * 4 * Np];
-                        av[u] = xa[s_ * 32] * amask;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u += 2) {
-                        if (s0 + u < n4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
-                        if (s0 + u + 1 < n4) acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[u + 1], acc_b, 0, 0, 0);
-                    }
-                }
-                acc = acc + acc_b;
-                if (lq < 2 && col < N) {                                        // D[row = 4 lq + rr][col = li]: f = 4 lq + rr < 6
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr)
-                        if (lq * 4 + rr < 6) act[col * RO_CS + rpos((lq * 4 + rr) * K + kq + 2)] = acc[rr];
-                }
-            }
-        } else if (sparse_wave) {                             // tap 1: only the non-zero rows of column sn (exact zeros skipped)
+        unsigned long long* rm_new = rowmask;                 // bits of the network of the step being simulated
+        const int hsn = (hs + 1 == H) ? 0 : hs + 1;           // its history slot (the oldest network's, overwritten in D2)
+        unsigned char* rl_new = rlist + (size_t)hsn * N * RS;
+        int* rc_new = rcnt + hsn * N;
+        float* w_new = wrow + hsn * N;
+        // -------------------------------------------------------------- A: aggregation, power-iterated along the lists
+        // y_j(t) = x_{t-j} . A_t . A_{t-1} ... A_{t-j+1}   (state_with_delay.py:44-47: G_j(t) = A_t G_{j-1}(t-1), G_0 = I)
+        // evaluated left to right: K - 1 gather stages, stage q multiplies the running (6 x N) product of every tap j >= q
+        // by A_{t-q+1}.  A is w_m x (symmetric 0/1 pattern), so (v . A)[f, n] = sum over n's neighbour list of w_m v[f, m]:
+        // 6 N deg multiply-adds per tap and stage, where the dense operator costs 6 N^2 per tap plus N^2 deg per slice to
+        // maintain.  No dense slice exists inside the launch.  The networks of the launch's own steps are known as lists;
+        // products that reach back before the launch (the first K - 1 steps) end with one dense multiplication by the
+        // caller's slice G_{j-hv}(t0), read from HBM.
+        const int hv = min(t, K - 1);                         // networks of this launch available as lists: A_t .. A_{t-hv+1}
+        for (int q = 1; q <= hv; ++q) {
+            const int j = q + gt;
             float sa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (sparse_active) {
-                const int cnt = rcnt[sn];
-                const unsigned char* lp = rlist + sn * RS;
-                const float* gcol = Gd + sn;
-                const float* xt = XT + (size_t)ro_slot(cur, 1, K) * Np * 8;
-                for (int e = sq; e < cnt; e += 2) {
+            const bool on = j <= K - 1 && gt < K - 1;
+            int hq = hs - (q - 1); hq = hq < 0 ? hq + H : hq;   // slot of A_{t-q+1}
+            if (on) {
+                const int cnt = rcnt[hq * N + gn];
+                const unsigned char* lp = rlist + ((size_t)hq * N + gn) * RS;
+                const float* wq = wrow + hq * N;
+                const float* src = (q == 1) ? XT + (size_t)ro_slot(cur, j, K) * Np * 8
+                                            : VB + ((size_t)((q - 1) & 1) * (K - 2) + (j - 2)) * Np * 8;
+                for (int e = gq; e < cnt; e += 2) {
                     const int m = lp[e];
-                    // inside the launch G_1[m][n] = wrow[m] on its pattern (its dense rows are re-expanded during phase B);
-                    // the first step reads the caller's dense slice, which may be any tensor
-                    const float gv = (t == 0) ? (PK ? Gb[NN + (size_t)m * N + sn] : gcol[m * Np]) : w_cur[m];
-                    const float4 x0 = *reinterpret_cast<const float4*>(xt + m * 8);
-                    const float2 x1 = *reinterpret_cast<const float2*>(xt + m * 8 + 4);
+                    const float gv = wq[m];
+                    const float4 x0 = *reinterpret_cast<const float4*>(src + m * 8);
+                    const float2 x1 = *reinterpret_cast<const float2*>(src + m * 8 + 4);
                     sa[0] = fmaf(x0.x, gv, sa[0]); sa[1] = fmaf(x0.y, gv, sa[1]); sa[2] = fmaf(x0.z, gv, sa[2]);
                     sa[3] = fmaf(x0.w, gv, sa[3]); sa[4] = fmaf(x1.x, gv, sa[4]); sa[5] = fmaf(x1.y, gv, sa[5]);
                 }
             }
 #pragma unroll
             for (int f = 0; f < 6; ++f) sa[f] += dpp_f<0xB1>(sa[f]);
-            if (sparse_active && sq == 0) {
+            if (on && gq == 0) {
+                if (j == q) {                                 // the tap's last factor: result in MFMA B-fragment order
 #pragma unroll
-                for (int f = 0; f < 6; ++f) act[sn * RO_CS + rpos(f * K + 1)] = sa[f];
+                    for (int f = 0; f < 6; ++f) act[gn * RO_CS + rpos(f * K + j)] = sa[f];
+                } else {
+                    float* dst = VB + ((size_t)(q & 1) * (K - 2) + (j - 2)) * Np * 8 + gn * 8;
+                    *reinterpret_cast<float4*>(dst) = make_float4(sa[0], sa[1], sa[2], sa[3]);
+                    *reinterpret_cast<float2*>(dst + 4) = make_float2(sa[4], sa[5]);
+                }
+            }
+            if (q == 1) RO_STAMP(6);
+            if (q < hv || hv < K - 1) __syncthreads();        // (the last stage of a steady-state step shares A's closing barrier)
+        }
+        if (hv < K - 1) {
+            // taps j > hv: the product so far (x_{t-j} itself on the launch's first step) times the caller's dense slice j - hv
+            if (gq == 0 && gt < K - 1 && gt + 1 > hv) {
+                const int j = gt + 1;
+                const float* src = (hv == 0) ? XT + (size_t)ro_slot(cur, j, K) * Np * 8
+                                             : VB + ((size_t)(hv & 1) * (K - 2) + (j - 2)) * Np * 8;
+                const float* gcol = Gb + (size_t)(j - hv) * NN + gn;
+                float sa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int m = 0; m < N; m += 4) {
+                    float gv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) gv[u] = (m + u < N) ? gcol[(size_t)(m + u) * N] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int mm = min(m + u, N - 1);
+                        const float4 x0 = *reinterpret_cast<const float4*>(src + mm * 8);
+                        const float2 x1 = *reinterpret_cast<const float2*>(src + mm * 8 + 4);
+                        sa[0] = fmaf(x0.x, gv[u], sa[0]); sa[1] = fmaf(x0.y, gv[u], sa[1]); sa[2] = fmaf(x0.z, gv[u], sa[2]);
+                        sa[3] = fmaf(x0.w, gv[u], sa[3]); sa[4] = fmaf(x1.x, gv[u], sa[4]); sa[5] = fmaf(x1.y, gv[u], sa[5]);
+                    }
+                }
+#pragma unroll
+                for (int f = 0; f < 6; ++f) act[gn * RO_CS + rpos(f * K + j)] = sa[f];
             }
         }
-        RO_STAMP(6);
         if (tid == RO_THREADS - 1) mmax[0] = 0u;              // consumed in the previous step's D1, refilled in C
         __syncthreads();
         RO_STAMP(1);
@@ -478,25 +422,8 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             m = wave_max_to_last(m);
             if (lane == 63) atomicMax(mmax, __float_as_uint(m));  // non-negative floats order like their bit patterns
         } else {
-            // meanwhile the other waves expand G_1 <- A_t from the membership bits of the previous simulator step (its dense
-            // rows are only read by the operator transition E, after two more barriers; tap 1 above used the lists), and
-            // clear the bits of the rows they have read: this step's membership pass starts from empty rows
-            const int nxw = RO_WAVES - NT;
-            const bool expand = !PK && t > 0 && K >= 3;
-            for (int i = 2 * (wave - NT) + (lane >> 5); i < N; i += 2 * nxw) {
-                if (expand) {
-                    const int c0 = hl * 4;
-                    const int nib = (int)(unsigned int)(rm_cur[2 * i + (c0 >> 6)] >> (c0 & 63));
-                    const int wb = __float_as_int(w_cur[i]);  // bit k set -> all-ones (v_bfe_i32) & weight bits: 2 ops / element
-                    if (hl < n4)
-                        *reinterpret_cast<float4*>(Gd + i * Np + c0) =
-                            make_float4(__int_as_float(__builtin_amdgcn_sbfe(nib, 0, 1) & wb),
-                                        __int_as_float(__builtin_amdgcn_sbfe(nib, 1, 1) & wb),
-                                        __int_as_float(__builtin_amdgcn_sbfe(nib, 2, 1) & wb),
-                                        __int_as_float(__builtin_amdgcn_sbfe(nib, 3, 1) & wb));
-                }
-                if (hl < 2) rm_new[2 * i + hl] = 0ull;        // (same half-wave, after its own reads: LDS ops of a wave are ordered)
-            }
+            // meanwhile the other waves clear the membership bits: this step's pairwise pass starts from empty rows
+            for (int i = tid - NT * 64; i < 2 * N; i += RO_THREADS - NT * 64) rowmask[i] = 0ull;
         }
         __syncthreads();
         RO_STAMP(3);
@@ -582,7 +509,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 else if (fq == 1) { chunk = (unsigned int)(lo >> 32); pos = __popc((unsigned int)lo); }
                 else if (fq == 2) { chunk = (unsigned int)hi; pos = __popcll(lo); }
                 else { chunk = (unsigned int)(hi >> 32); pos = __popcll(lo) + __popc((unsigned int)hi); }
-                unsigned char* lp = rlist + fr * RS;
+                unsigned char* lp = rl_new + fr * RS;
                 while (chunk) { lp[pos++] = (unsigned char)(32 * fq + __builtin_ctz(chunk)); chunk &= chunk - 1u; }
                 lp[cnt + 2 * fq] = (unsigned char)N; lp[cnt + 2 * fq + 1] = (unsigned char)N;      // pad: index of the zero row
                 const double xi = spx[fr], yi = spy[fr], vxi = svx[fr], vyi = svy[fr];
@@ -609,7 +536,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 const double deg = (double)cnt;
                 const double w = p.mean_pooling ? 1.0 / (deg == 0.0 ? 1.0 : deg) : 1.0;
                 w_new[fr] = (float)w;
-                rcnt[fr] = cnt;
+                rc_new[fr] = cnt;
                 float* xn = XT + ((size_t)(cur + 1 == K ? 0 : cur + 1) * Np + fr) * 8;     // overwrites the oldest tap
                 *reinterpret_cast<float4*>(xn) = make_float4((float)f0, (float)f1, (float)f2, (float)f3);
                 *reinterpret_cast<float4*>(xn + 4) = make_float4((float)f4, (float)f5, 0.f, 0.f);
@@ -620,98 +547,60 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         }
         __syncthreads();
         RO_STAMP(4);
-        // -------------------------------------------------------------- E: operator transition
-        for (int j = K - 1; j >= 2; --j) {                    // G_j <- A_t . G_{j-1}   (slice j lives at index j - SL0)
-            float* dst = Gd + (size_t)(j - SL0) * NS;
-            const float* src = Gd + (size_t)(j - 1 - SL0) * NS + hl * 4;       // (not used for j = 2 when G_1 is packed)
-            const bool packed_src = PK && j == 2;
-            const int c0 = hl * 4, cw = c0 >> 6, cb = c0 & 63;
-            for (int i = hw; i < N; i += RO_THREADS / 32) {
-                const int cnt = rcnt[i];
-                const float w = w_new[i];
-                const f32x2 w2 = {w, w};
-                const unsigned char* lp = rlist + i * RS;
-                f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
-                for (int e = 0; e < cnt; e += 8) {            // chunks of 8 source rows (padding = the zero row), loads first
-                    const unsigned long long pk = *reinterpret_cast<const unsigned long long*>(lp + e);
-                    if (hl < n4) {
-                        float4 g[8];
-                        if (packed_src) {                     // rows of G_1 = previous network, expanded from bits + weight
-#pragma unroll
-                            for (int d = 0; d < 8; ++d) {
-                                const int l = (int)((pk >> (8 * d)) & 255ull);
-                                const int nib = (int)(unsigned int)(rm_cur[2 * l + cw] >> cb);
-                                const int wb = __float_as_int(w_cur[l]);
-                                g[d] = make_float4(__int_as_float(__builtin_amdgcn_sbfe(nib, 0, 1) & wb),
-                                                   __int_as_float(__builtin_amdgcn_sbfe(nib, 1, 1) & wb),
-                                                   __int_as_float(__builtin_amdgcn_sbfe(nib, 2, 1) & wb),
-                                                   __int_as_float(__builtin_amdgcn_sbfe(nib, 3, 1) & wb));
-                            }
-                        } else {
-#pragma unroll
-                            for (int d = 0; d < 8; ++d)
-                                g[d] = *reinterpret_cast<const float4*>(src + (int)((pk >> (8 * d)) & 255ull) * Np);
-                        }
-#pragma unroll
-                        for (int d = 0; d < 8; ++d) {
-                            a0 = __builtin_elementwise_fma(w2, (f32x2){g[d].x, g[d].y}, a0);
-                            a1 = __builtin_elementwise_fma(w2, (f32x2){g[d].z, g[d].w}, a1);
-                        }
-                    }
-                }
-                if (hl < n4) *reinterpret_cast<float4*>(dst + i * Np + hl * 4) = make_float4(a0.x, a0.y, a1.x, a1.y);
-            }
-            __syncthreads();
-        }
-        RO_STAMP(11);
         if (tid == 0) { cref[0] = spx[0]; cref[1] = spy[0]; }  // next step's reference point (any point is valid)
         cur = (cur + 1 == K) ? 0 : cur + 1;
-        cs ^= 1;
-        if (K < 3) __syncthreads();                           // K >= 3: the barrier that closed the last operator slice
+        hs = hsn;
         RO_STAMP(5);
     }
 
     // ------------------------------------------------------------------ exit: LDS -> the caller's buffers
-    if (T > 0 && K >= 2) {                                    // the expansion G_1 <- A_T is still pending (PK: straight to HBM)
-        const unsigned long long* rm_fin = rowmask + (PK ? cs * 2 * (N + 1) : 0);
-        const float* w_fin = wrow + (PK ? cs * (N + 1) : 0);
-        for (int i = hw; i < N; i += RO_THREADS / 32) {       // half-wave per row, lane = 4 columns
-            const int c0 = hl * 4;
-            const int nib = (int)(unsigned int)(rm_fin[2 * i + (c0 >> 6)] >> (c0 & 63));
-            const int wb = __float_as_int(w_fin[i]);
-            const float4 v = make_float4(__int_as_float(__builtin_amdgcn_sbfe(nib, 0, 1) & wb),
-                                         __int_as_float(__builtin_amdgcn_sbfe(nib, 1, 1) & wb),
-                                         __int_as_float(__builtin_amdgcn_sbfe(nib, 2, 1) & wb),
-                                         __int_as_float(__builtin_amdgcn_sbfe(nib, 3, 1) & wb));
-            if (hl < n4) {
-                if (!PK) {
-                    *reinterpret_cast<float4*>(Gd + i * Np + c0) = v;
-                } else if (Np == N) {
-                    *reinterpret_cast<float4*>(Gb + NN + (size_t)i * N + c0) = v;
-                } else {                                      // unaligned global rows: element-wise
-                    float* gr = Gb + NN + (size_t)i * N;
-                    if (c0 < N) gr[c0] = v.x;
-                    if (c0 + 1 < N) gr[c0 + 1] = v.y;
-                    if (c0 + 2 < N) gr[c0 + 2] = v.z;
-                    if (c0 + 3 < N) gr[c0 + 3] = v.w;
+    // Dense operator slices of the final state, one row per wave at a time:
+    //     row i of G_j(T) = e_i . A_T . A_{T-1} ... (min(j, hv) networks of this launch)  [ . G_{j-hv}(t0) when j > hv ]
+    // Slices are produced in descending j (a slice that is still an input -- j - hv < j -- is overwritten later), with a
+    // workgroup barrier between slices.  Row vectors ping-pong in the activation area (no longer needed).
+    if (T > 0 && K >= 2) {
+        const int hv = min(T, K - 1);
+        float* rbuf = act + wave * 2 * Np;                    // [2][Np] per wave (16 x 2 x Np floats fit the activation area)
+        for (int j = K - 1; j >= 1; --j) {
+            const int nsp = min(j, hv);
+            for (int i = wave; i < N; i += RO_WAVES) {
+                float* r0 = rbuf;
+                float* r1 = rbuf + Np;
+                // e_i . A_T = row i of the newest network: w_T(i) on its membership bits (still set: cleared in phase B only)
+                const float wi = wrow[hs * N + i];
+                for (int n = lane; n < N; n += 64)
+                    r0[n] = ((rowmask[2 * i + (n >> 6)] >> (n & 63)) & 1ull) ? wi : 0.f;
+                for (int q = 2; q <= nsp; ++q) {              // . A_{T-q+1}: gather along the (symmetric) lists, source weights
+                    int hq = hs - (q - 1); hq = hq < 0 ? hq + H : hq;
+                    const float* wq = wrow + hq * N;
+                    for (int n = lane; n < N; n += 64) {
+                        const int cnt = rcnt[hq * N + n];
+                        const unsigned char* lp = rlist + ((size_t)hq * N + n) * RS;
+                        float s = 0.f;
+                        for (int e = 0; e < cnt; ++e) { const int m = lp[e]; s = fmaf(r0[m], wq[m], s); }
+                        r1[n] = s;
+                    }
+                    float* tsw = r0; r0 = r1; r1 = tsw;
+                }
+                float* grow = Gb + (size_t)j * NN + (size_t)i * N;
+                if (j > hv) {                                 // dense tail with the caller's slice j - hv (rows with r0[m] != 0 only)
+                    const float* gsrc = Gb + (size_t)(j - hv) * NN;
+                    float s0 = 0.f, s1 = 0.f;
+                    for (int m = 0; m < N; ++m) {
+                        const float rv = r0[m];               // wave-uniform
+                        if (rv != 0.f) {
+                            if (lane < N) s0 = fmaf(rv, gsrc[(size_t)m * N + lane], s0);
+                            if (lane + 64 < N) s1 = fmaf(rv, gsrc[(size_t)m * N + lane + 64], s1);
+                        }
+                    }
+                    if (lane < N) grow[lane] = s0;
+                    if (lane + 64 < N) grow[lane + 64] = s1;
+                } else {
+                    for (int n = lane; n < N; n += 64) grow[n] = r0[n];
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
-    }
-    if (Np == N) {
-        for (int j = SL0; j < K; ++j) {
-            const float4* gsrc = reinterpret_cast<const float4*>(Gd + (size_t)(j - SL0) * NS);
-            float4* gdst = reinterpret_cast<float4*>(Gb + (size_t)j * NN);
-#pragma unroll 4
-            for (int e = tid; e < NN / 4; e += RO_THREADS) gdst[e] = gsrc[e];
-        }
-    } else {
-        for (int j = SL0; j < K; ++j)
-            for (int e = tid; e < NN; e += RO_THREADS) {
-                const int i = e / N, n = e - i * N;
-                Gb[(size_t)j * NN + e] = Gd[(size_t)(j - SL0) * NS + i * Np + n];
-            }
     }
     for (int e = tid; e < K * 6 * N; e += RO_THREADS) {
         const int k = e / (6 * N), r1 = e - k * 6 * N, f = r1 / N, n = r1 - f * N;
@@ -725,10 +614,10 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
 }
 
 // coverage check + weight image plan; returns false when the shape is outside the kernel's coverage
-bool make_carve(const int* dims, int n_layers, int K, int N, RoParams* P, int* lds_bytes, bool* packed)
+bool make_carve(const int* dims, int n_layers, int K, int N, RoParams* P, int* lds_bytes)
 {
     if (dims == nullptr || n_layers < 1 || n_layers > MGP_MAX_LAYERS) return false;
-    if (K < 1 || K > 5 || N < 4 || N > RO_MAXN) return false;
+    if (K < 1 || K > 5 || N < 4 || N > RO_MAXN) return false;                   // 2 N (K - 1) gather threads <= 1024
     if (dims[0] != 6 || dims[n_layers] != 2) return false;                      // simulator: 6 features in, 2-D action out
     int wtot = 0;
     for (int l = 0; l < n_layers; ++l) {
@@ -738,24 +627,21 @@ bool make_carve(const int* dims, int n_layers, int K, int N, RoParams* P, int* l
         wtot += mtiles(cout) * 64 * RO_WFS + mtiles(cout) * 16;
     }
     if (P) { P->dims[n_layers] = dims[n_layers]; P->n_layers = n_layers; }
-    int total = ro_offsets(N, K, false).wl + wtot * 4;        // dense slices 1..K-1 if they fit, else packed G_1 (K >= 3)
-    bool pk = false;
-    if (total > RO_LDS_LIMIT && K >= 3) { pk = true; total = ro_offsets(N, K, true).wl + wtot * 4; }
+    const int total = ro_offsets(N, K).wl + wtot * 4;
     if (total > RO_LDS_LIMIT) return false;
     if (lds_bytes) *lds_bytes = total;
-    if (packed) *packed = pk;
     return true;
 }
 
-template <int CN, int CK, bool PK, bool FD>
+template <int CN, int CK, bool FD>
 int launch_rollout(double* x, float* G, float* Xd, float* action, double* rewards, const RoParams& P,
                    const MgpFlockParams* p, int B, int K, int N, int T, unsigned long long dimsA, unsigned int dims8,
                    unsigned long long woffA, unsigned long long woffB, int n_layers, int lds, hipStream_t st)
 {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<CN, CK, PK, FD>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<CN, CK, FD>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MGP_ELAUNCH;
-    hipLaunchKernelGGL((rollout_kernel<CN, CK, PK, FD>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K,
+    hipLaunchKernelGGL((rollout_kernel<CN, CK, FD>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K,
                        N, T, dimsA, dims8, woffA, woffB, n_layers);
     return mgp_launch_status();
 }
@@ -764,7 +650,7 @@ int launch_rollout(double* x, float* G, float* Xd, float* action, double* reward
 
 extern "C" int mgp_rollout_supported(const int* dims, int n_layers, int K, int N)
 {
-    return make_carve(dims, n_layers, K, N, nullptr, nullptr, nullptr) ? 1 : 0;
+    return make_carve(dims, n_layers, K, N, nullptr, nullptr) ? 1 : 0;
 }
 
 extern "C" int mgp_rollout_steps(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
@@ -775,13 +661,11 @@ extern "C" int mgp_rollout_steps(double* x, float* G, float* Xd, const float* co
     if (!(p->comm_radius2 > 0.0) || !(p->dt > 0.0) || p->n_leaders < 0) return MGP_EINVAL;
     RoParams P;
     int lds = 0;
-    bool packed = false;
-    if (!make_carve(dims, n_layers, K, N, &P, &lds, &packed)) return MGP_EUNSUPPORTED;
+    if (!make_carve(dims, n_layers, K, N, &P, &lds)) return MGP_EUNSUPPORTED;
     if (B == 0 || T == 0) return MGP_OK;
     MGP_CHECK_PTR8(x);
     MGP_CHECK_PTR(G);
     MGP_CHECK_PTR(Xd);
-    if (!mgp_aligned16(G)) return MGP_EALIGN;
     if (action != nullptr && (reinterpret_cast<uintptr_t>(action) & 3u)) return MGP_EALIGN;
     if (rewards != nullptr && (reinterpret_cast<uintptr_t>(rewards) & 7u)) return MGP_EALIGN;
     for (int l = 0; l < n_layers; ++l) {
@@ -804,14 +688,9 @@ extern "C" int mgp_rollout_steps(double* x, float* G, float* Xd, const float* co
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool fade = p->link_drop != 0u;   // FlockingStochastic-v0: the generic builds carry the fade hash, the others do not
     if (N == 100 && K == 3 && !fade)   // the headline shape (BASELINE.json configs[0..1]) runs a build with compile-time addresses
-        return launch_rollout<100, 3, false, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
-    if (N == 100 && K == 2 && !packed && !fade)   // cfg/default.cfg, cloning.cfg, dagger_twoflocks.cfg
-        return launch_rollout<100, 2, false, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
-    // (a <100, 4, true> instantiation trips an LLVM backend error -- "Operand has incorrect register class" -- on this
-    //  toolchain; the reference's K = 4 sweeps at N = 100 run the generic packed build, 2.7e9 agent-steps/s)
-    if (packed)                   // slice 1 kept as bits + row weights
-        return fade ? launch_rollout<0, 0, true, true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st)
-                    : launch_rollout<0, 0, true, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
-    return fade ? launch_rollout<0, 0, false, true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st)
-                : launch_rollout<0, 0, false, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
+        return launch_rollout<100, 3, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
+    if (N == 100 && K == 2 && !fade)   // cfg/default.cfg, cloning.cfg, dagger_twoflocks.cfg
+        return launch_rollout<100, 2, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
+    return fade ? launch_rollout<0, 0, true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st)
+                : launch_rollout<0, 0, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
 }

@@ -67,13 +67,13 @@ int main(int argc, char** argv) {
            1e3 * ms / IT, 1e3 * ms / IT / T, (double)B * N * T / (1e-3 * ms / IT));
     unsigned long long st[256];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(mgp_ro_stamps), sizeof(st));
-    const char* names[] = {"step start", "A done (barrier)", "B hidden layers (waves 0-6) + G_1 expansion (waves 7-15) done (barrier)", "B+C: hidden layers, output layer, integration (waves 0-6) / G_1 expansion (waves 7-15) done (barrier)",
-                           "D2/D3 done (barrier)", "E: step done", "A: dense / sparse tap of this wave done", "D1: membership bits done (barrier)",
+    const char* names[] = {"step start", "A done (barrier)", "B hidden layers (waves 0-6) + G_1 expansion (waves 7-15) done (barrier)", "B+C: hidden layers, output layer, integration (waves 0-6) / bit clearing (waves 7-15) done (barrier)",
+                           "D2/D3 done (barrier)", "step done", "A: first gather stage of this wave done", "D1: membership bits done (barrier)",
                            "D2/D3: lists + neighbour feature terms done (waves 0-6)", "D: piece shuffles done", "D: lists written", "E: rows of slices >= 2 done (barrier)", "B: layer 0 tile done (before barrier)", "B: layer 1 tile done", "(unused)"};
-    const int order[] = {0, 6, 1, 12, 13, 3, 7, 8, 4, 11, 5};
+    const int order[] = {0, 6, 1, 12, 13, 3, 7, 8, 4, 5};
     printf("cycles since step start, lane 0 of waves 0 / 3 / 7 / 9 / 12 / 15\n");
     const int wv[] = {0, 3, 7, 9, 12, 15};
-    for (int oi = 0; oi < 11; ++oi) {
+    for (int oi = 0; oi < 10; ++oi) {
         const int i = order[oi];
         printf("  stamp %2d :", i);
         for (int w = 0; w < 6; ++w) printf(" %7lld", (long long)(st[wv[w] * 16 + i] - st[0]));
