@@ -8,8 +8,9 @@ A "step" advances EVERY episode of the batch by one environment step through the
     ->  delayed-GSO / delay-line update,
 all state resident on the GPU, no host round trip.  Two implementations of the same step are timed in the same run:
   resident    mgp_rollout_steps: ALL timed steps in one launch of the episode-resident kernel (one workgroup per
-              episode, delayed operator / delay line / agent states / weights in LDS; HBM sees the state on entry
-              and exit).  This is `value` when the shape is covered (N <= 128, widths <= 32, state fits the LDS).
+              episode; delay line / agent states / neighbour lists of the last K-1 networks / weights in LDS, the
+              aggregation power-iterated along those lists; HBM sees the state on entry and exit).  This is `value`
+              when the shape is covered (N <= 128, widths and 6K <= 32).
   two_launch  mgp_actor_fwd + mgp_flock_step_advance per step (dense operator streamed from HBM every step),
               replayed from a captured HIP graph; reported next to it, and `value` for shapes the resident kernel
               does not cover.
@@ -466,16 +467,18 @@ def main():
             alg = (4 * K * N * N + 8 * K * F_FEAT * N) * B * args.steps / n_launch
             ms = res_launch_ms / n_launch
             tr = pmc_traffic('rollout_kernel', B, N, K, steps_per_launch=args.steps // n_launch)
-            out["roofline"] = {"kernel": "rollout_kernel (episode-resident: aggregation + MFMA filter/MLP + sim step + "
-                                         "operator transition, %d steps per launch)" % (args.steps // n_launch),
+            out["roofline"] = {"kernel": "rollout_kernel (episode-resident: power-iterated aggregation + MFMA filter/MLP "
+                                         "+ sim step + neighbour lists, %d steps per launch)" % (args.steps // n_launch),
                                "bound": "hbm", "achieved": alg / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": alg / ms / 1e6 / HBM_PEAK_GBS, "traffic": tr,
                                "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms,
                                "steps_per_launch": args.steps // n_launch, "resident": True,
-                               "note": "equivalent rate: the dense operator stays in LDS across steps, so HBM moves "
-                                       "only `traffic` (state in/out + rewards); the kernel is issue/latency bound, "
-                                       "not HBM bound.  HBM-roofline fractions of the kernels that stream the dense "
-                                       "operator from HBM every step are under dense_kernels.",
+                               "note": "equivalent rate: the bytes the dense-contract aggregation WOULD stream for these "
+                                       "steps / launch time.  Inside the launch the operator exists only as neighbour "
+                                       "lists in LDS (y_j = x_{t-j} A_t .. A_{t-j+1}, left to right), so HBM moves only "
+                                       "`traffic` (state in/out + rewards); the kernel is issue/latency bound, not HBM "
+                                       "bound.  HBM-roofline fractions of the kernels that stream the dense operator "
+                                       "from HBM every step are under dense_kernels.",
                                "dense_kernels": dense}
         else:
             out["roofline"] = dense

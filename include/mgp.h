@@ -201,7 +201,7 @@ int mgp_flock_step_advance(double* x, double* x_out, const float* u, long su_age
                            int B, int K, int N, int has_prev, void* stream);
 
 /* Episode-resident closed-loop rollout: T policy steps for B episodes in ONE launch (one workgroup per episode, the
- * episode's state -- delayed operator slices 1..K-1, delay line, agent states, weights -- resident in LDS).
+ * episode's state -- agent states, delay line, the neighbour lists of the last K-1 networks, weights -- resident in LDS).
  * Replaces T iterations of the reference's evaluation loop (test_model.py:38-44, gnn_dagger.py:194-203):
  *     u = Actor(delay_state, delay_gso)                    actor.py:45-86, ind_agg = 0       (== mgp_actor_fwd)
  *     x, reward = env.step(u) ; state = State(prev=state)  state_with_delay.py:44-53         (== mgp_flock_step_advance)
@@ -209,14 +209,16 @@ int mgp_flock_step_advance(double* x, double* x_out, const float* u, long su_age
  * after it.  Slice 0 of G must be the identity (it is by construction; it is neither read nor written).
  *   action  (B,1,2,N) fp32  the LAST step's policy output (may be NULL)
  *   rewards (B,T)  fp64     reward of every step (may be NULL)
- * The simulator arithmetic is the stand-alone kernels' (fp64, bit-exact integration/membership given the action); the
- * aggregation sums in a different order than mgp_actor_fwd (same 1e-5 parity bound against the reference forward).
- * Chunking is exact: T1 then T2 steps == T1 + T2 steps, bit for bit.  Coverage (mgp_rollout_supported): dims[0] = 6,
- * dims[n_layers] = 2, layer widths <= 32, 4 <= N <= 128 (any N: rows are padded to a multiple of 4 inside the kernel) and
- * the state must fit the 160 KB LDS.  Slices 1..K-1 are
- * kept densely when they fit (N = 100: K <= 3).  Otherwise slice 1 is kept as membership bits + row weights (N = 100:
- * K = 4; N = 128: K = 3) -- in that mode slice 1 MUST be a row-scaled 0/1 matrix (every non-zero of a row equal), which
- * is what the state builder produces.  Anything larger: MGP_EUNSUPPORTED -- use the two calls above. */
+ * Inside the launch no dense operator exists: with G_j(t) = A_t G_{j-1}(t-1) (state_with_delay.py:44-47) tap j of the
+ * aggregation is x_{t-j} A_t A_{t-1} ... A_{t-j+1}, evaluated left to right along the neighbour lists of the networks
+ * the launch itself produced.  Products that reach back before the launch (its first K-1 steps) end with one dense
+ * multiplication by the caller's slice, which may be ANY tensor; on exit the dense slices of the final state are
+ * rebuilt the same way.  The simulator arithmetic is the stand-alone kernels' (fp64, bit-exact integration and
+ * membership given the action); the aggregation associates differently from mgp_actor_fwd (same 1e-5 parity bound
+ * against the reference forward).  Consequently chunking (T1 then T2 steps vs T1 + T2) agrees to fp32 rounding, not bit
+ * for bit -- a launch boundary passes through the rounded dense slices -- and a closed loop amplifies that over steps.
+ * Coverage (mgp_rollout_supported): dims[0] = 6, dims[n_layers] = 2, layer widths and 6 K <= 32, 4 <= N <= 128, K <= 5.
+ * Anything else: MGP_EUNSUPPORTED -- use the two calls above. */
 int mgp_rollout_supported(const int* dims, int n_layers, int K, int N);
 int mgp_rollout_steps(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
                       const int* dims, int n_layers, float* action, double* rewards,

@@ -1,5 +1,5 @@
 // Episode-resident closed-loop rollout: T x { Actor forward -> simulator step -> delayed-GSO / delay-line transition }
-// in ONE launch, one 1024-thread workgroup per episode, the episode's whole state in LDS.
+// in ONE launch, one 1024-thread workgroup per episode, the episode's state in LDS.
 //
 // Reference loop being replaced (one episode, test_model.py:38-44 / gnn_dagger.py:194-203):
 //     action = learner.select_action(state)                      -> actor.py:45-86
@@ -7,31 +7,36 @@
 //     state = MultiAgentStateWithDelay(..., prev_state=state)    -> state_with_delay.py:44-53
 // The two-launch form of one step (mgp_actor_fwd + mgp_flock_step_advance) re-reads the dense delayed operator
 // G (B,K,N,N) from HBM twice per step and rewrites it once; that traffic, not arithmetic, is what a step costs at
-// N = 100.  Here G slices 1..K-1 ((K-1)*N*N*4 = 80 KB at N = 100, K = 3), the delay line, the fp64 agent states, the
-// MFMA weight fragments and the activation tile all stay in the CU's 160 KB LDS for the whole launch; HBM sees the
-// state once on entry and once on exit (plus one reward per step).  Slice 0 of G is the identity by construction
-// (state_with_delay.py:44) and is neither read nor written: tap 0 of the aggregation is X_0 itself.
+// N = 100.  Here the dense operator does not exist inside the launch at all.  The state builder's recurrence
+// G_j(t) = A_t G_{j-1}(t-1), G_0 = I (state_with_delay.py:44-47) makes tap j of the aggregation
+//     y_j(t) = x_{t-j} G_j(t) = x_{t-j} A_t A_{t-1} ... A_{t-j+1},
+// and every A is (row weight) x (symmetric 0/1 radius pattern), so the product is evaluated left to right -- the
+// K-hop graph shift iterated on a 6 x N block -- along the neighbour lists the simulator phase builds anyway:
+// 6 N deg multiply-adds per tap and factor, against 6 N^2 per tap for the dense product plus N^2 deg per slice and
+// step to maintain the slices.  LDS holds the fp64 agent states, the delay line (ring), the lists and row weights of
+// the last K-1 networks, the MFMA weight fragments and the activation tile (~70 KB at N = 100, K = 3); HBM sees the
+// state once on entry and once on exit (plus one reward per step).  The caller's dense slices are read only by the
+// first K-1 steps (products that reach back before the launch end with one dense multiplication) and rebuilt on exit.
+// Slice 0 of G is the identity by construction (state_with_delay.py:44) and is neither read nor written.
 //
-// Per step (five workgroup barriers; all arithmetic identical in kind to the stand-alone kernels):
-//   A  aggregation  y[(f,k), n] = sum_m X_k[f, m] * G_k[m, n]  from LDS.  Taps k >= 2 (dense slices) run on the matrix
-//      cores, one wave per (tap, 16-column tile): D[f, n] += X[f, m..m+3] G[m..m+3, n] as fp32 16x16x4 MFMAs -- the phase
-//      is instruction-issue bound (one workgroup per CU), and one MFMA retires 384 useful MACs per issue slot where a
-//      packed VALU FMA retires 128.  Tap 1 walks only the non-zero rows of each column (exact zeros skipped); tap 0 is
+// Per step (K + 3 workgroup barriers):
+//   A  aggregation: K-1 gather stages; stage q multiplies the running product of every tap j >= q by A_{t-q+1}
+//      (thread = (column, tap, parity of the list entry); partial products of taps > q ping-pong in LDS).  Tap 0 is
 //      X_0 itself.  Results land in MFMA B-fragment order.
 //   B  filter GEMM + tanh hidden layers on fp32 MFMA 16x16x4 (k-ordered fmaf chain, 1e-5 budget): a wave owns 16 agent
 //      columns through every hidden layer, activations in place in LDS, no barrier between layers.
 //   C  the same wave, no barrier: the 2-wide output layer as a packed-FMA chain (a 16-row MFMA tile would be 7/8
 //      padding; a lane takes 8 channels of its column, four lanes are added), then the fp64 integration of the agent (same
 //      expression tree as flock.hip / the oracle: bit-exact given the action) and its fp32 coordinates for D1.
-//      Meanwhile the nine waves without columns expand G_1 <- A_t from the previous step's membership bits.
+//      Meanwhile the nine waves without columns clear the membership bits.
 //   D  D1 membership: every unordered pair once (row i tests offsets 1..N/2, 8 threads per row); an fp32 test on
 //      coordinates relative to a reference point decides pairs that are clear of the radius by a proven error band, the
 //      exact fp64 expression of the spec decides the rest -- the bits are always the oracle's.  Both rows of a pair get
-//      their bit by LDS atomic OR.  D2/D3: 4 lanes per row turn the row's bits into an ascending neighbour list and
-//      sum the fp64 feature terms of actual neighbours.  One otherwise idle wave computes the step's reward.
-//   E  G_j <- A_t . G_{j-1} for j = K-1 .. 2 (row gathers in LDS along the neighbour lists, ascending order, fmaf
-//      chain: the same arithmetic as gso.hip; lists are padded with the index of an all-zero row, so there is no tail
-//      code).  G_1 <- A_t itself is expanded during phase B/C of the next step (and once on exit).  The delay line is a ring: the new features overwrite the oldest tap, nothing is shifted.
+//      their bit by LDS atomic OR.  D2/D3: 4 lanes per row turn the row's bits into an ascending neighbour list (into the
+//      history slot of the oldest network) and sum the fp64 feature terms of actual neighbours.  One otherwise idle
+//      wave computes the step's reward.  The delay line is a ring: the new features overwrite the oldest tap.
+// (The first version of this kernel kept slices 1..K-1 densely in LDS -- 80 KB at N = 100, K = 3 -- aggregated taps >= 2
+//  on the matrix cores and advanced the slices with row gathers every step: 8.6 us per step of 256 episodes against 7.2.)
 // This translation unit is built with -ffp-contract=off (fp64 spec arithmetic); fp32 fused multiply-adds are explicit.
 #include "mgp_device.h"
 
@@ -407,6 +412,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             float ux = u2.x, uy = u2.y;
             ux += dpp_f<0xB1>(ux); uy += dpp_f<0xB1>(uy);
             ux += dpp_f<0x4E>(ux); uy += dpp_f<0x4E>(uy);
+            RO_STAMP(14);
             float m = 0.f;
             if (agent) {
                 const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * 4 * RO_KS);
@@ -419,8 +425,10 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 sxy[ccol] = make_float2(sx, sy);
                 m = fmaxf(fabsf(sx), fabsf(sy));
             }
+            RO_STAMP(15);
             m = wave_max_to_last(m);
-            if (lane == 63) atomicMax(mmax, __float_as_uint(m));  // non-negative floats order like their bit patterns
+            if (lane == 63) atomicMax(mmax, __float_as_uint(m));
+            RO_STAMP(9);  // non-negative floats order like their bit patterns
         } else {
             // meanwhile the other waves clear the membership bits: this step's pairwise pass starts from empty rows
             for (int i = tid - NT * 64; i < 2 * N; i += RO_THREADS - NT * 64) rowmask[i] = 0ull;

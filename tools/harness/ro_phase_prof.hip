@@ -69,11 +69,11 @@ int main(int argc, char** argv) {
     hipMemcpyFromSymbol(st, HIP_SYMBOL(mgp_ro_stamps), sizeof(st));
     const char* names[] = {"step start", "A done (barrier)", "B hidden layers (waves 0-6) + G_1 expansion (waves 7-15) done (barrier)", "B+C: hidden layers, output layer, integration (waves 0-6) / bit clearing (waves 7-15) done (barrier)",
                            "D2/D3 done (barrier)", "step done", "A: first gather stage of this wave done", "D1: membership bits done (barrier)",
-                           "D2/D3: lists + neighbour feature terms done (waves 0-6)", "D: piece shuffles done", "D: lists written", "E: rows of slices >= 2 done (barrier)", "B: layer 0 tile done (before barrier)", "B: layer 1 tile done", "(unused)"};
-    const int order[] = {0, 6, 1, 12, 13, 3, 7, 8, 4, 5};
+                           "D2/D3: lists + neighbour feature terms done (waves 0-6)", "C: max published (atomic issued)", "D: lists written", "E: rows of slices >= 2 done (barrier)", "B: layer 0 tile done (before barrier)", "B: layer 1 tile done", "C: output layer + quad sums done", "C: integrated, coordinates stored"};
+    const int order[] = {0, 6, 1, 12, 13, 14, 15, 9, 3, 7, 8, 4, 5};
     printf("cycles since step start, lane 0 of waves 0 / 3 / 7 / 9 / 12 / 15\n");
     const int wv[] = {0, 3, 7, 9, 12, 15};
-    for (int oi = 0; oi < 10; ++oi) {
+    for (int oi = 0; oi < 13; ++oi) {
         const int i = order[oi];
         printf("  stamp %2d :", i);
         for (int w = 0; w < 6; ++w) printf(" %7lld", (long long)(st[wv[w] * 16 + i] - st[0]));
