@@ -341,26 +341,32 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             if (q < hv || hv < K - 1) __syncthreads();        // (the last stage of a steady-state step shares A's closing barrier)
         }
         if (hv < K - 1) {
-            // taps j > hv: the product so far (x_{t-j} itself on the launch's first step) times the caller's dense slice j - hv
-            if (gq == 0 && gt < K - 1 && gt + 1 > hv) {
-                const int j = gt + 1;
+            // taps j > hv: the product so far (x_{t-j} itself on the launch's first step) times the caller's dense slice j - hv,
+            // column gn; the two parity lanes take alternate rows, ten HBM reads in flight each
+            const bool on = gt < K - 1 && gt + 1 > hv;
+            const int j = gt + 1;
+            float sa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (on) {
                 const float* src = (hv == 0) ? XT + (size_t)ro_slot(cur, j, K) * Np * 8
                                              : VB + ((size_t)(hv & 1) * (K - 2) + (j - 2)) * Np * 8;
                 const float* gcol = Gb + (size_t)(j - hv) * NN + gn;
-                float sa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int m = 0; m < N; m += 4) {
-                    float gv[4];
+                for (int m = gq; m < N; m += 20) {
+                    float gv[10];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) gv[u] = (m + u < N) ? gcol[(size_t)(m + u) * N] : 0.f;
+                    for (int u = 0; u < 10; ++u) gv[u] = (m + 2 * u < N) ? gcol[(size_t)(m + 2 * u) * N] : 0.f;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int mm = min(m + u, N - 1);
+                    for (int u = 0; u < 10; ++u) {
+                        const int mm = min(m + 2 * u, N - 1);
                         const float4 x0 = *reinterpret_cast<const float4*>(src + mm * 8);
                         const float2 x1 = *reinterpret_cast<const float2*>(src + mm * 8 + 4);
                         sa[0] = fmaf(x0.x, gv[u], sa[0]); sa[1] = fmaf(x0.y, gv[u], sa[1]); sa[2] = fmaf(x0.z, gv[u], sa[2]);
                         sa[3] = fmaf(x0.w, gv[u], sa[3]); sa[4] = fmaf(x1.x, gv[u], sa[4]); sa[5] = fmaf(x1.y, gv[u], sa[5]);
                     }
                 }
+            }
+#pragma unroll
+            for (int f = 0; f < 6; ++f) sa[f] += dpp_f<0xB1>(sa[f]);
+            if (on && gq == 0) {
 #pragma unroll
                 for (int f = 0; f < 6; ++f) act[gn * RO_CS + rpos(f * K + j)] = sa[f];
             }
