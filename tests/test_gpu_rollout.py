@@ -54,11 +54,11 @@ CASES = [
     # N, K, hidden, variant
     (100, 3, (32, 32), {}),
     (100, 3, (32, 32), {'mean_pooling': False, 'n_leaders': 2}),
-    (100, 4, (32, 32), {}),                        # K - 1 dense slices do not fit: slice 1 kept as bits + row weights
-    (128, 3, (32,), {'comm_radius': 1.2}),         # packed as well
+    (100, 4, (32, 32), {}),                        # three gather stages, three networks of history
+    (128, 3, (32,), {'comm_radius': 1.2}),         # largest N
     (50, 2, (32, 32), {}),                         # N % 4 != 0: LDS rows padded to 52, element-wise state in / out
     (25, 3, (16,), {'mean_pooling': False}),
-    (125, 3, (32,), {}),                           # padded AND packed
+    (125, 3, (32,), {}),                           # padded rows
     (75, 4, (32, 32), {'n_leaders': 1}),
     (100, 2, (16,), {}),
     (100, 1, (32, 32), {}),
@@ -69,7 +69,7 @@ CASES = [
     (100, 3, (32, 32), {'link_drop': 0.25, 'link_seed': 3}),                 # FlockingStochastic: faded links
     (100, 4, (32, 32), {'link_drop': 0.5, 'link_seed': 9, 'mean_pooling': False}),
     (100, 3, (32, 32), {'grid_spacing': 0.2, 'grid_jitter': 0.02}),          # dense graph (degree 60..99): rad.cfg's 4.0
-    (128, 3, (32,), {'grid_spacing': 0.1, 'grid_jitter': 0.01}),             # complete graph, packed slice 1
+    (128, 3, (32,), {'grid_spacing': 0.1, 'grid_jitter': 0.01}),             # complete graph
 ]
 
 
