@@ -627,11 +627,452 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         for (int e = tid; e < 2 * N; e += RO_THREADS) action[(size_t)b * 2 * N + e] = uact[e];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same rollout for 128 < N <= 256 (the reference's n_twoflocks / transfer sweeps: N = 150, 200, 250; BASELINE
+// configs[4]: N = 200, K = 4).  Differences from rollout_kernel, all forced by size: the networks of the last K - 1 steps
+// are kept as membership BITS only (four 64-bit words per row; byte lists of three networks would be 125 KB at N = 200)
+// and every consumer -- gather stages, feature pass, exit -- walks bits; rows / gather items / pair offsets are looped
+// over instead of mapped one to a thread; everything is run-time sized.  Phases, barriers and arithmetic are the same.
+struct RbOff { int pos, bits, wrow, uact, xt, vb, act, sxy, mmax, wl; };
+constexpr int RB_MAXN = 256;
+constexpr int RB_NW = 4;
+
+__host__ __device__ inline RbOff rb_offsets(int N, int K)
+{
+    RbOff c = {};
+    int off = 0;
+    const int Np = (N + 3) & ~3, H = ro_hist(K);
+    c.pos = ro_take(off, (4 * N + 2) * 8);
+    c.bits = ro_take(off, H * N * RB_NW * 8);
+    c.wrow = ro_take(off, H * N * 4);
+    c.uact = ro_take(off, 2 * N * 4);
+    c.xt = ro_take(off, K * Np * 8 * 4);
+    c.vb = ro_take(off, 2 * (K > 2 ? K - 2 : 0) * Np * 8 * 4);
+    c.act = ro_take(off, ((N + 15) & ~15) * RO_CS * 4);
+    c.sxy = ro_take(off, N * 8);
+    c.mmax = ro_take(off, 16);
+    c.wl = off;
+    return c;
+}
+
+// sum over the set bits m of `w` (base index `base`) of wq[m] * src[m][0..5]
+__device__ __forceinline__ void rb_gather_word(unsigned long long w, int base, const float* wq, const float* src, float (&sa)[6])
+{
+    while (w) {
+        const int m = base + __builtin_ctzll(w);
+        w &= w - 1ull;
+        const float gv = wq[m];
+        const float4 x0 = *reinterpret_cast<const float4*>(src + m * 8);
+        const float2 x1 = *reinterpret_cast<const float2*>(src + m * 8 + 4);
+        sa[0] = fmaf(x0.x, gv, sa[0]); sa[1] = fmaf(x0.y, gv, sa[1]); sa[2] = fmaf(x0.z, gv, sa[2]);
+        sa[3] = fmaf(x0.w, gv, sa[3]); sa[4] = fmaf(x1.x, gv, sa[4]); sa[5] = fmaf(x1.y, gv, sa[5]);
+    }
+}
+
+template <bool FD>
+__global__ __launch_bounds__(RO_THREADS)
+void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __restrict__ Xd, float* __restrict__ action,
+                        double* __restrict__ rewards, RoParams P, MgpFlockParams p, int K, int N, int T,
+                        unsigned long long dimsA, unsigned int dims8, unsigned long long woffA, unsigned long long woffB,
+                        int n_layers)
+{
+    const RbOff cv = rb_offsets(N, K);
+    const int H = ro_hist(K);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    double* spx = reinterpret_cast<double*>(smraw + cv.pos);
+    double* spy = spx + N; double* svx = spx + 2 * N; double* svy = spx + 3 * N;
+    double* cref = spx + 4 * N;
+    unsigned long long* bits = reinterpret_cast<unsigned long long*>(smraw + cv.bits);
+    float* wrow = reinterpret_cast<float*>(smraw + cv.wrow);
+    float* uact = reinterpret_cast<float*>(smraw + cv.uact);
+    float* XT = reinterpret_cast<float*>(smraw + cv.xt);
+    float* VB = reinterpret_cast<float*>(smraw + cv.vb);
+    float* wl = reinterpret_cast<float*>(smraw + cv.wl);
+    float* act = reinterpret_cast<float*>(smraw + cv.act);
+    float2* sxy = reinterpret_cast<float2*>(smraw + cv.sxy);
+    unsigned int* mmax = reinterpret_cast<unsigned int*>(smraw + cv.mmax);
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Np = (N + 3) & ~3;
+    const int NN = N * N, FK = 6 * K;
+    const int ncols16 = pad16(N), NT = ncols16 / 16;
+    double* xb = x + (size_t)b * N * 4;
+    float* Gb = G + (size_t)b * K * NN;
+    float* Xb = Xd + (size_t)b * K * 6 * N;
+
+    // ------------------------------------------------------------------ entry
+    for (int i = tid; i < H * N * RB_NW; i += RO_THREADS) bits[i] = 0ull;
+    for (int i = tid; i < H * N; i += RO_THREADS) wrow[i] = 0.f;
+    for (int e = tid; e < K * Np * 8; e += RO_THREADS) {
+        const int f = e & 7, mk = e >> 3, k = mk / Np, m = mk - k * Np;
+        const int slot = (k == 0) ? 0 : K - k;
+        XT[(slot * Np + m) * 8 + f] = (f < 6 && m < N) ? Xb[((size_t)k * 6 + f) * N + m] : 0.f;
+    }
+    for (int i = tid; i < N; i += RO_THREADS) {
+        spx[i] = xb[i * 4 + 0]; spy[i] = xb[i * 4 + 1]; svx[i] = xb[i * 4 + 2]; svy[i] = xb[i * 4 + 3];
+    }
+    if (tid == 0) { cref[0] = xb[0]; cref[1] = xb[1]; mmax[0] = 0u; }
+    // weights in MFMA A-fragment order (see actor_fused.hip): wfrag[mt][lane][RO_WFS], lane = (c & 3) * 16 + (o & 15),
+    // slot s = c >> 2, zero padded; then the bias of the layer's MT*16 rows
+    for (int l = 0; l < P.n_layers; ++l) {
+        const int cin = (l == 0) ? FK : P.dims[l];
+        const int cout = P.dims[l + 1];
+        const int MT = mtiles(cout);
+        const int tot = MT * 64 * RO_WFS;
+        float* dst = wl + P.woff[l];
+        const float* src = P.W[l];
+        if (l == P.n_layers - 1) {
+            // the 2-wide output layer runs on the VALU of the integrating threads: plain pairs (W[0][c], W[1][c]) in
+            // channel order, zero padded to 32 channels, then the bias pair
+            for (int e = tid; e < 2 * 4 * RO_KS + 2; e += RO_THREADS) {
+                const int c = e >> 1, o = e & 1;
+                dst[e] = (c < 4 * RO_KS) ? ((c < cin) ? src[(size_t)o * cin + c] : 0.f) : P.b[l][o];
+            }
+            continue;
+        }
+        for (int e = tid; e < tot; e += RO_THREADS) {
+            const int mt = e / (64 * RO_WFS), r1 = e - mt * (64 * RO_WFS);
+            const int ln = r1 / RO_WFS, sl = r1 - ln * RO_WFS;
+            const int c = 4 * sl + (ln >> 4), o = mt * 16 + (ln & 15);
+            dst[e] = (sl < RO_KS && o < cout && c < cin) ? src[(size_t)o * cin + c] : 0.f;
+        }
+        for (int o = tid; o < MT * 16; o += RO_THREADS) dst[tot + o] = (o < cout) ? P.b[l][o] : 0.f;
+    }
+    {
+        float4* za = reinterpret_cast<float4*>(act);
+        for (int i = tid; i < ncols16 * RO_CS / 4; i += RO_THREADS) za[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    for (int e = tid; e < N * 8; e += RO_THREADS) {
+        const int f = e & 7, n = e >> 3;
+        if (f < 6) act[n * RO_CS + rpos(f * K)] = XT[e];
+    }
+    __syncthreads();
+
+    const int gq = tid & 1;
+    const int li = lane & 15, lq = lane >> 4;
+    const int piece = tid & 7;
+    const int half = N >> 1, dh = (half + RO_PIECES - 1) / RO_PIECES;          // offsets 1..N/2, up to 16 per piece
+    const int fr = tid >> 2, fq = tid & 3;
+    const double R2 = p.comm_radius2;
+    const float R2f = (float)R2, Rf = sqrtf(R2f);
+    const int nitems = N * (K - 1);
+    int cur = 0, hs = 0;
+
+    for (int t = 0; t < T; ++t) {
+        const int hsn = (hs + 1 == H) ? 0 : hs + 1;
+        unsigned long long* rm_new = bits + (size_t)hsn * N * RB_NW;
+        float* w_new = wrow + hsn * N;
+        // -------------------------------------------------------------- A: aggregation, power-iterated along the bit rows
+        const int hv = min(t, K - 1);
+        for (int q = 1; q <= hv; ++q) {
+            int hq = hs - (q - 1); hq = hq < 0 ? hq + H : hq;
+            const unsigned long long* bq = bits + (size_t)hq * N * RB_NW;
+            const float* wq = wrow + hq * N;
+            for (int it0 = 0; it0 < nitems; it0 += RO_THREADS / 2) {
+                const int item = it0 + (tid >> 1);
+                const int gt = item / N, gn = item - gt * N, j = q + gt;
+                const bool on = item < nitems && j <= K - 1;
+                float sa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (on) {
+                    const float* src = (q == 1) ? XT + (size_t)ro_slot(cur, j, K) * Np * 8
+                                                : VB + ((size_t)((q - 1) & 1) * (K - 2) + (j - 2)) * Np * 8;
+                    const unsigned long long* row = bq + (size_t)gn * RB_NW + 2 * gq;      // this lane's two words
+                    rb_gather_word(row[0], 128 * gq, wq, src, sa);
+                    rb_gather_word(row[1], 128 * gq + 64, wq, src, sa);
+                }
+#pragma unroll
+                for (int f = 0; f < 6; ++f) sa[f] += dpp_f<0xB1>(sa[f]);
+                if (on && gq == 0) {
+                    if (j == q) {
+#pragma unroll
+                        for (int f = 0; f < 6; ++f) act[gn * RO_CS + rpos(f * K + j)] = sa[f];
+                    } else {
+                        float* dst = VB + ((size_t)(q & 1) * (K - 2) + (j - 2)) * Np * 8 + gn * 8;
+                        *reinterpret_cast<float4*>(dst) = make_float4(sa[0], sa[1], sa[2], sa[3]);
+                        *reinterpret_cast<float2*>(dst + 4) = make_float2(sa[4], sa[5]);
+                    }
+                }
+            }
+            if (q < hv || hv < K - 1) __syncthreads();
+        }
+        if (hv < K - 1) {
+            for (int it0 = 0; it0 < nitems; it0 += RO_THREADS / 2) {
+                const int item = it0 + (tid >> 1);
+                const int gt = item / N, gn = item - gt * N, j = gt + 1;
+                const bool on = item < nitems && j > hv;
+                float sa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (on) {
+                    const float* src = (hv == 0) ? XT + (size_t)ro_slot(cur, j, K) * Np * 8
+                                                 : VB + ((size_t)(hv & 1) * (K - 2) + (j - 2)) * Np * 8;
+                    const float* gcol = Gb + (size_t)(j - hv) * NN + gn;
+                    for (int m = gq; m < N; m += 20) {
+                        float gv[10];
+#pragma unroll
+                        for (int u = 0; u < 10; ++u) gv[u] = (m + 2 * u < N) ? gcol[(size_t)(m + 2 * u) * N] : 0.f;
+#pragma unroll
+                        for (int u = 0; u < 10; ++u) {
+                            const int mm = min(m + 2 * u, N - 1);
+                            const float4 x0 = *reinterpret_cast<const float4*>(src + mm * 8);
+                            const float2 x1 = *reinterpret_cast<const float2*>(src + mm * 8 + 4);
+                            sa[0] = fmaf(x0.x, gv[u], sa[0]); sa[1] = fmaf(x0.y, gv[u], sa[1]); sa[2] = fmaf(x0.z, gv[u], sa[2]);
+                            sa[3] = fmaf(x0.w, gv[u], sa[3]); sa[4] = fmaf(x1.x, gv[u], sa[4]); sa[5] = fmaf(x1.y, gv[u], sa[5]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int f = 0; f < 6; ++f) sa[f] += dpp_f<0xB1>(sa[f]);
+                if (on && gq == 0) {
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) act[gn * RO_CS + rpos(f * K + j)] = sa[f];
+                }
+            }
+        }
+        if (tid == RO_THREADS - 1) mmax[0] = 0u;
+        __syncthreads();
+        // the slot of the oldest network was read for the last time above: empty rows for this step's pairwise pass
+        for (int i = tid; i < N * RB_NW; i += RO_THREADS) rm_new[i] = 0ull;
+        // -------------------------------------------------------------- B: filter GEMM + MLP on MFMA
+        // Layer metadata comes from bit-packed scalar kernel arguments: P.dims[l] indexed dynamically is re-fetched from
+        // the kernel-argument segment every layer of every step (~700 cycles each).
+        if (wave < NT) {                                      // wave w owns columns 16 w .. 16 w + 15 through every layer
+            const int col = wave * 16 + li;
+            float* pcol = act + col * RO_CS;
+            for (int l = 0; l < n_layers - 1; ++l) {
+                const int cin = (l == 0) ? FK : ro_dim(dimsA, dims8, l);
+                const int cout = ro_dim(dimsA, dims8, l + 1);
+                const int MT = mtiles(cout);
+                const float* wfrag = wl + (int)((((l < 4) ? woffA : woffB) >> (16 * (l & 3))) & 0xFFFFull);
+                if (MT == 2) ro_mlp_cols<2>(pcol, wfrag + lane * RO_WFS, wfrag + 2 * 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
+                else ro_mlp_cols<1>(pcol, wfrag + lane * RO_WFS, wfrag + 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
+                RO_STAMP(12 + l);
+            }
+            // ---------------------------------------------------------- C: output layer (VALU) + integrate, same wave
+            // The 2-wide output layer is a packed-FMA chain (a 16-row MFMA tile would be 7/8 padding).  For this part the
+            // lanes are regrouped: lane L takes agent column L >> 2 of the wave's tile and the 8 channels c = 4 s + (L & 3)
+            // (contiguous in the B-fragment layout), so the four partial sums of a column sit in one quad and are added by
+            // DPP.  The first lane of the quad then integrates the agent (spec section 1, fp64: bit-exact given the action)
+            // and publishes its fp32 coordinates for D1.  No workgroup barrier since the hidden layers: the wave only
+            // reads activations it wrote itself (LDS operations of one wave are ordered).
+            const int lo_ = n_layers - 1;
+            const float* w2 = wl + (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull);
+            const int ccol = wave * 16 + (lane >> 2), cg = lane & 3;
+            const float* zsrc = act + ccol * RO_CS + cg * RO_KS;
+            const float4 z0 = *reinterpret_cast<const float4*>(zsrc);
+            const float4 z1 = *reinterpret_cast<const float4*>(zsrc + 4);
+            const float zc[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+            double px = 0.0, py = 0.0, vx = 0.0, vy = 0.0, cx = 0.0, cy = 0.0;
+            const bool agent = (cg == 0) && ccol < N;
+            if (agent) { px = spx[ccol]; py = spy[ccol]; vx = svx[ccol]; vy = svy[ccol]; cx = cref[0]; cy = cref[1]; }
+            f32x2 u2 = {0.f, 0.f}, u2b = {0.f, 0.f};
+#pragma unroll
+            for (int s_ = 0; s_ < RO_KS; s_ += 2) {           // channel c = 4 s + cg: weights (W[0][c], W[1][c]) at w2[2 c]
+                const float2 wa = *reinterpret_cast<const float2*>(w2 + 2 * (4 * s_ + cg));
+                const float2 wb = *reinterpret_cast<const float2*>(w2 + 2 * (4 * (s_ + 1) + cg));
+                u2 = __builtin_elementwise_fma((f32x2){zc[s_], zc[s_]}, (f32x2){wa.x, wa.y}, u2);
+                u2b = __builtin_elementwise_fma((f32x2){zc[s_ + 1], zc[s_ + 1]}, (f32x2){wb.x, wb.y}, u2b);
+            }
+            u2 = u2 + u2b;
+            float ux = u2.x, uy = u2.y;
+            ux += dpp_f<0xB1>(ux); uy += dpp_f<0xB1>(uy);
+            ux += dpp_f<0x4E>(ux); uy += dpp_f<0x4E>(uy);
+            RO_STAMP(14);
+            float m = 0.f;
+            if (agent) {
+                const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * 4 * RO_KS);
+                ux += bb.x; uy += bb.y;
+                uact[ccol] = ux; uact[N + ccol] = uy;
+                const float ub[2] = {ux, uy};
+                integrate_one(px, py, vx, vy, ub, 1, ccol < p.n_leaders, p);
+                spx[ccol] = px; spy[ccol] = py; svx[ccol] = vx; svy[ccol] = vy;
+                const float sx = (float)(px - cx), sy = (float)(py - cy);     // fp32 coordinates relative to cref
+                sxy[ccol] = make_float2(sx, sy);
+                m = fmaxf(fabsf(sx), fabsf(sy));
+            }
+            RO_STAMP(15);
+            m = wave_max_to_last(m);
+            if (lane == 63) atomicMax(mmax, __float_as_uint(m));
+            RO_STAMP(9);  // non-negative floats order like their bit patterns
+        }
+        __syncthreads();
+        // -------------------------------------------------------------- D1: membership bits, every unordered pair once
+        if (wave == RO_WAVES - 1 && rewards != nullptr) {     // reward: one wave, no workgroup barrier
+            double sx = 0.0, sy = 0.0;
+            for (int i = lane; i < N; i += 64) { sx += svx[i]; sy += svy[i]; }
+            sx = mgp_wave_sum(sx); sy = mgp_wave_sum(sy);
+            const double mx = sx / (double)N, my = sy / (double)N;
+            double dv = 0.0;
+            for (int i = lane; i < N; i += 64) {
+                const double ex = svx[i] - mx, ey = svy[i] - my;
+                dv += ex * ex + ey * ey;
+            }
+            const double var = mgp_wave_sum(dv) / (double)N;
+            if (lane == 0) rewards[(size_t)b * T + t] = -1.0 * var * p.reward_scale;
+        }
+        {
+            const float M = __uint_as_float(mmax[0]);
+            const float band = Rf * (16.f * M + 16.f * Rf) * 5.9604645e-8f + R2f * 1.1920929e-7f;
+            const float t_in = R2f - band, t_out = R2f + band;
+            for (int pi = tid >> 3; pi < N; pi += RO_THREADS / 8) {
+                const float2 si = sxy[pi];
+                for (int ob = 0; ob < dh; ob += 8) {
+                    const int d0 = 1 + piece * dh + ob;
+                    const int nd = min(min(8, dh - ob), half - d0 + 1);              // offsets d0 .. d0 + nd - 1
+                    if (nd <= 0) continue;
+                    unsigned int in_m = 0u, out_m = 0u;
+                    float2 sj[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        int j = pi + d0 + min(q, nd - 1);
+                        j = (j >= N) ? j - N : j;
+                        sj[q] = sxy[j];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float dx = si.x - sj[q].x, dy = si.y - sj[q].y;
+                        const float r2 = fmaf(dy, dy, dx * dx);
+                        in_m = __builtin_amdgcn_alignbit(in_m, __float_as_uint(r2 - t_in), 31);
+                        out_m = __builtin_amdgcn_alignbit(out_m, __float_as_uint(t_out - r2), 31);
+                    }
+                    in_m = __builtin_bitreverse32(in_m) >> 24;
+                    out_m = __builtin_bitreverse32(out_m) >> 24;
+                    const unsigned int valid = (1u << nd) - 1u;
+                    in_m &= valid;
+                    unsigned int unc_m = ~out_m & ~in_m & valid;
+                    while (unc_m) {                           // rare: the spec's own fp64 expression decides
+                        const int q = __builtin_ctz(unc_m);
+                        unc_m &= unc_m - 1u;
+                        int j = pi + d0 + q;
+                        j = (j >= N) ? j - N : j;
+                        const double dx = spx[pi] - spx[j], dy = spy[pi] - spy[j];
+                        const double r2 = dx * dx + dy * dy;
+                        if (r2 < R2) in_m |= 1u << q;
+                    }
+                    while (in_m) {
+                        const int q = __builtin_ctz(in_m);
+                        in_m &= in_m - 1u;
+                        int j = pi + d0 + q;
+                        j = (j >= N) ? j - N : j;
+                        if (FD && p.link_drop != 0u &&
+                            !link_up(p, pi, j, N, fade_word(spx[pi], spy[pi]), fade_word(spx[j], spy[j]))) continue;
+                        atomicOr(&rm_new[RB_NW * pi + (j >> 6)], 1ull << (j & 63));
+                        atomicOr(&rm_new[RB_NW * j + (pi >> 6)], 1ull << (pi & 63));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // -------------------------------------------------------------- D2/D3: fp64 feature terms along the bit rows
+        if (tid < 4 * ncols16) {                              // 4 lanes per row (one 64-bit word each), whole waves
+            double f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0;
+            int cnt = 0;
+            if (fr < N) {
+                unsigned long long w = rm_new[RB_NW * fr + fq];
+                cnt = __popcll(w);
+                const double xi = spx[fr], yi = spy[fr], vxi = svx[fr], vyi = svy[fr];
+                while (w) {
+                    const int j = 64 * fq + __builtin_ctzll(w);
+                    w &= w - 1ull;
+                    const double dx = xi - spx[j], dy = yi - spy[j];
+                    const double r2 = dx * dx + dy * dy;
+                    const double q = 1.0 / r2;
+                    const double qq = q * q;
+                    f0 += vxi - svx[j];
+                    f1 += dx * qq;
+                    f2 += dx * q;
+                    f3 += vyi - svy[j];
+                    f4 += dy * qq;
+                    f5 += dy * q;
+                }
+            }
+            f0 += dpp_d<0xB1>(f0); f1 += dpp_d<0xB1>(f1); f2 += dpp_d<0xB1>(f2);
+            f3 += dpp_d<0xB1>(f3); f4 += dpp_d<0xB1>(f4); f5 += dpp_d<0xB1>(f5);
+            f0 += dpp_d<0x4E>(f0); f1 += dpp_d<0x4E>(f1); f2 += dpp_d<0x4E>(f2);
+            f3 += dpp_d<0x4E>(f3); f4 += dpp_d<0x4E>(f4); f5 += dpp_d<0x4E>(f5);
+            cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xF, 0xF, true);
+            cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xF, 0xF, true);
+            if (fq == 0 && fr < N) {
+                const double deg = (double)cnt;
+                const double w = p.mean_pooling ? 1.0 / (deg == 0.0 ? 1.0 : deg) : 1.0;
+                w_new[fr] = (float)w;
+                float* xn = XT + ((size_t)(cur + 1 == K ? 0 : cur + 1) * Np + fr) * 8;
+                *reinterpret_cast<float4*>(xn) = make_float4((float)f0, (float)f1, (float)f2, (float)f3);
+                *reinterpret_cast<float4*>(xn + 4) = make_float4((float)f4, (float)f5, 0.f, 0.f);
+                float* y0 = act + fr * RO_CS;
+                y0[rpos(0 * K)] = (float)f0; y0[rpos(1 * K)] = (float)f1; y0[rpos(2 * K)] = (float)f2;
+                y0[rpos(3 * K)] = (float)f3; y0[rpos(4 * K)] = (float)f4; y0[rpos(5 * K)] = (float)f5;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { cref[0] = spx[0]; cref[1] = spy[0]; }
+        cur = (cur + 1 == K) ? 0 : cur + 1;
+        hs = hsn;
+    }
+
+    // ------------------------------------------------------------------ exit (see rollout_kernel)
+    if (T > 0 && K >= 2) {
+        const int hv = min(T, K - 1);
+        float* rbuf = act + wave * 2 * Np;
+        for (int j = K - 1; j >= 1; --j) {
+            const int nsp = min(j, hv);
+            for (int i = wave; i < N; i += RO_WAVES) {
+                float* r0 = rbuf;
+                float* r1 = rbuf + Np;
+                const float wi = wrow[hs * N + i];
+                const unsigned long long* rowT = bits + ((size_t)hs * N + i) * RB_NW;
+                for (int n = lane; n < N; n += 64) r0[n] = ((rowT[n >> 6] >> (n & 63)) & 1ull) ? wi : 0.f;
+                for (int q = 2; q <= nsp; ++q) {
+                    int hq = hs - (q - 1); hq = hq < 0 ? hq + H : hq;
+                    const float* wq = wrow + hq * N;
+                    for (int n = lane; n < N; n += 64) {
+                        const unsigned long long* rw = bits + ((size_t)hq * N + n) * RB_NW;
+                        float s = 0.f;
+                        for (int wd = 0; wd < RB_NW; ++wd) {
+                            unsigned long long w = rw[wd];
+                            while (w) { const int m = 64 * wd + __builtin_ctzll(w); w &= w - 1ull; s = fmaf(r0[m], wq[m], s); }
+                        }
+                        r1[n] = s;
+                    }
+                    float* tsw = r0; r0 = r1; r1 = tsw;
+                }
+                float* grow = Gb + (size_t)j * NN + (size_t)i * N;
+                if (j > hv) {
+                    const float* gsrc = Gb + (size_t)(j - hv) * NN;
+                    float sacc[RB_MAXN / 64] = {0.f, 0.f, 0.f, 0.f};
+                    for (int m = 0; m < N; ++m) {
+                        const float rv = r0[m];               // wave-uniform
+                        if (rv != 0.f) {
+#pragma unroll
+                            for (int u = 0; u < RB_MAXN / 64; ++u)
+                                if (lane + 64 * u < N) sacc[u] = fmaf(rv, gsrc[(size_t)m * N + lane + 64 * u], sacc[u]);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < RB_MAXN / 64; ++u)
+                        if (lane + 64 * u < N) grow[lane + 64 * u] = sacc[u];
+                } else {
+                    for (int n = lane; n < N; n += 64) grow[n] = r0[n];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int e = tid; e < K * 6 * N; e += RO_THREADS) {
+        const int k = e / (6 * N), r1 = e - k * 6 * N, f = r1 / N, n = r1 - f * N;
+        Xb[e] = XT[((size_t)ro_slot(cur, k, K) * Np + n) * 8 + f];
+    }
+    for (int i = tid; i < N; i += RO_THREADS) {
+        xb[i * 4 + 0] = spx[i]; xb[i * 4 + 1] = spy[i]; xb[i * 4 + 2] = svx[i]; xb[i * 4 + 3] = svy[i];
+    }
+    if (action != nullptr)
+        for (int e = tid; e < 2 * N; e += RO_THREADS) action[(size_t)b * 2 * N + e] = uact[e];
+}
+
 // coverage check + weight image plan; returns false when the shape is outside the kernel's coverage
 bool make_carve(const int* dims, int n_layers, int K, int N, RoParams* P, int* lds_bytes)
 {
     if (dims == nullptr || n_layers < 1 || n_layers > MGP_MAX_LAYERS) return false;
-    if (K < 1 || K > 5 || N < 4 || N > RO_MAXN) return false;                   // 2 N (K - 1) gather threads <= 1024
+    if (K < 1 || K > 5 || N < 4 || N > RB_MAXN) return false;                   // N <= 128: 2 N (K - 1) gather threads <= 1024
     if (dims[0] != 6 || dims[n_layers] != 2) return false;                      // simulator: 6 features in, 2-D action out
     int wtot = 0;
     for (int l = 0; l < n_layers; ++l) {
@@ -641,7 +1082,7 @@ bool make_carve(const int* dims, int n_layers, int K, int N, RoParams* P, int* l
         wtot += mtiles(cout) * 64 * RO_WFS + mtiles(cout) * 16;
     }
     if (P) { P->dims[n_layers] = dims[n_layers]; P->n_layers = n_layers; }
-    const int total = ro_offsets(N, K).wl + wtot * 4;
+    const int total = (N > RO_MAXN ? rb_offsets(N, K).wl : ro_offsets(N, K).wl) + wtot * 4;   // N > 128: rollout_big_kernel
     if (total > RO_LDS_LIMIT) return false;
     if (lds_bytes) *lds_bytes = total;
     return true;
@@ -657,6 +1098,19 @@ int launch_rollout(double* x, float* G, float* Xd, float* action, double* reward
         return MGP_ELAUNCH;
     hipLaunchKernelGGL((rollout_kernel<CN, CK, FD>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K,
                        N, T, dimsA, dims8, woffA, woffB, n_layers);
+    return mgp_launch_status();
+}
+
+template <bool FD>
+int launch_rollout_big(double* x, float* G, float* Xd, float* action, double* rewards, const RoParams& P,
+                       const MgpFlockParams* p, int B, int K, int N, int T, unsigned long long dimsA, unsigned int dims8,
+                       unsigned long long woffA, unsigned long long woffB, int n_layers, int lds, hipStream_t st)
+{
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_big_kernel<FD>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return MGP_ELAUNCH;
+    hipLaunchKernelGGL((rollout_big_kernel<FD>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K, N, T,
+                       dimsA, dims8, woffA, woffB, n_layers);
     return mgp_launch_status();
 }
 
@@ -701,6 +1155,9 @@ extern "C" int mgp_rollout_steps(double* x, float* G, float* Xd, const float* co
     mgp_clear_error();
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool fade = p->link_drop != 0u;   // FlockingStochastic-v0: the generic builds carry the fade hash, the others do not
+    if (N > RO_MAXN)
+        return fade ? launch_rollout_big<true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st)
+                    : launch_rollout_big<false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
     if (N == 100 && K == 3 && !fade)   // the headline shape (BASELINE.json configs[0..1]) runs a build with compile-time addresses
         return launch_rollout<100, 3, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
     if (N == 100 && K == 2 && !fade)   // cfg/default.cfg, cloning.cfg, dagger_twoflocks.cfg

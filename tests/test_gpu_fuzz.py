@@ -138,7 +138,7 @@ def test_resident_rollout_random_shapes(seed):
     from multiagent_gnn_policies_amd import ops
     from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
     rs = np.random.RandomState(5000 + seed)
-    N = int(rs.randint(8, 129))                               # any N: rows are padded to a multiple of 4 inside the kernel
+    N = int(rs.randint(8, 129)) if seed % 4 else int(rs.randint(129, 257))   # any N; N > 128 runs rollout_big_kernel
     K = int(rs.randint(1, 5))
     hidden = [(), (4,), (32,), (16, 16), (32, 32), (8, 32, 16), (32, 32, 32), (20, 12)][int(rs.randint(0, 8))]
     variant = dict(mean_pooling=bool(rs.randint(0, 2)), n_leaders=int(rs.randint(0, 3)),

@@ -70,6 +70,14 @@ CASES = [
     (100, 4, (32, 32), {'link_drop': 0.5, 'link_seed': 9, 'mean_pooling': False}),
     (100, 3, (32, 32), {'grid_spacing': 0.2, 'grid_jitter': 0.02}),          # dense graph (degree 60..99): rad.cfg's 4.0
     (128, 3, (32,), {'grid_spacing': 0.1, 'grid_jitter': 0.01}),             # complete graph
+    # N > 128: rollout_big_kernel (bit rows instead of byte lists, looped thread roles)
+    (200, 4, (32, 32), {}),                                                   # BASELINE configs[4]
+    (150, 3, (32, 32), {'n_leaders': 2}),
+    (250, 2, (32,), {'mean_pooling': False}),
+    (130, 3, (16, 16), {'comm_radius': 1.5}),
+    (256, 3, (16,), {}),
+    (200, 3, (32, 32), {'link_drop': 0.3, 'link_seed': 5}),
+    (192, 3, (32,), {'grid_spacing': 0.2, 'grid_jitter': 0.02}),             # dense graph
 ]
 
 
@@ -111,7 +119,7 @@ def test_rollout_single_steps_match_oracle(N, K, hidden, variant):
 
 # (not the link-fading cases: the fade hash is keyed on exact position bits, so one rounding of difference in an action
 #  re-draws every link of the next step -- chunkings of a FlockingStochastic episode are different sample paths)
-@pytest.mark.parametrize('N,K,hidden,variant', CASES[:4] + CASES[7:8] + CASES[10:14])
+@pytest.mark.parametrize('N,K,hidden,variant', CASES[:4] + CASES[7:8] + CASES[10:14] + CASES[18:23])
 def test_rollout_chunking_agrees(N, K, hidden, variant):
     """T steps in one launch vs T launches of one step vs 4 + 5.  Inside a launch tap j is the running product
     x_{t-j} . A_t ... A_{t-j+1} along neighbour lists; a launch boundary goes through the dense slices the contract hands
@@ -144,7 +152,7 @@ def test_rollout_chunking_agrees(N, K, hidden, variant):
 TOL_CHUNK = {'x': 5e-4, 'delay_gso': 1e-3, 'delay_state': 1e-3, 'last action': 1e-3, 'rewards': 1e-4}
 
 
-@pytest.mark.parametrize('N,K,hidden,variant', CASES[:3] + CASES[4:5] + CASES[7:8] + CASES[9:10] + CASES[11:12])
+@pytest.mark.parametrize('N,K,hidden,variant', CASES[:3] + CASES[4:5] + CASES[7:8] + CASES[9:10] + CASES[11:12] + CASES[18:23])
 def test_rollout_in_launch_chain_matches_oracle(N, K, hidden, variant):
     """The running products inside ONE launch against the oracle forward.  With dt = 1e-7 the agents hardly move, so a
     T-step launch and T - 1 checked one-step launches reach the same state up to ~1e-6 and the last action of the long
@@ -202,7 +210,9 @@ def test_rollout_unsupported_shapes_fall_back():
     assert ops.rollout_supported((6, 32, 32, 2), 4, 100)          # no dense operator slice lives in LDS: K is bounded by
     assert ops.rollout_supported((6, 32, 32, 2), 5, 128)          # the 2 N (K - 1) gather threads only
     assert not ops.rollout_supported((6, 32, 32, 2), 6, 100)
-    assert not ops.rollout_supported((6, 32, 32, 2), 3, 130)
+    assert ops.rollout_supported((6, 32, 32, 2), 3, 130) and ops.rollout_supported((6, 32, 32, 2), 4, 200)
+    assert not ops.rollout_supported((6, 32, 32, 2), 3, 257)
+    assert not ops.rollout_supported((6, 32, 32, 2), 5, 256)      # N = 256, K = 5 does not fit the 160 KB LDS
     assert ops.rollout_supported((6, 32, 32, 2), 3, 50) and ops.rollout_supported((6, 32, 32, 2), 2, 125)
     assert not ops.rollout_supported((6, 32, 32, 3), 3, 100)      # the simulator takes 2-D actions
     assert ops.rollout_supported((6, 32, 32, 2), 3, 100)
