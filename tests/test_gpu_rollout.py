@@ -78,6 +78,9 @@ CASES = [
     (256, 3, (16,), {}),
     (200, 3, (32, 32), {'link_drop': 0.3, 'link_seed': 5}),
     (192, 3, (32,), {'grid_spacing': 0.2, 'grid_jitter': 0.02}),             # dense graph
+    (160, 1, (32, 32), {}),                                                   # no delayed taps at all
+    (200, 5, (16,), {}),                                                      # four networks of history
+    (100, 5, (32,), {}),
 ]
 
 
