@@ -59,8 +59,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifdef MGP_RO_PROFILE
 __device__ unsigned long long mgp_ro_stamps[16 * 16];     // [wave][stamp]
 #define RO_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == 5) mgp_ro_stamps[(threadIdx.x >> 6) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define RO_STAMPX(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) mgp_ro_stamps[(threadIdx.x >> 6) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define RO_STAMP(i) do { } while (0)
+#define RO_STAMPX(i) do { } while (0)
 #endif
 
 struct RoParams {
@@ -83,7 +85,7 @@ struct RoOff {
                                           // rounded up to a multiple of 4, rows >= N are zero
     int vb;                               // float [2][K-2][Np][8] partial products of taps >= 2 between gather stages (ping-pong)
     int act;                              // float [ncols16][RO_CS] activations (in place through the layers); row buffers on exit
-    int rlist;                            // u8 [H][N][RS] ascending neighbour lists (RS = N rounded to 8, + 8)
+    int rlist;                            // u8 [H][N][RS] ascending neighbour lists (RS = ro_list_stride(N))
     int rcnt;                             // int [H][N] list lengths
     int sxy;                              // float2 [N] fp32 coordinates relative to the reference point
     int mmax;                             // uint: max |relative coordinate| of the step (float bits)
@@ -92,6 +94,9 @@ struct RoOff {
 
 __host__ __device__ constexpr int ro_take(int& off, int bytes) { const int o = off; off += (bytes + 15) & ~15; return o; }
 __host__ __device__ constexpr int ro_hist(int K) { return K > 2 ? K - 1 : 1; }
+// list row stride in bytes: room for N - 1 entries + 8 pad bytes, a multiple of 4 with an ODD word count -- neighbouring
+// lanes walk neighbouring rows, and an even word stride (112 B at N = 100) put them 8 to a bank
+__host__ __device__ constexpr int ro_list_stride(int N) { const int w = (N + 8 + 3) >> 2; return 4 * (w | 1); }
 
 __host__ __device__ constexpr RoOff ro_offsets(int N, int K)
 {
@@ -105,7 +110,7 @@ __host__ __device__ constexpr RoOff ro_offsets(int N, int K)
     c.xt = ro_take(off, K * Np * 8 * 4);
     c.vb = ro_take(off, 2 * (K > 2 ? K - 2 : 0) * Np * 8 * 4);
     c.act = ro_take(off, ((N + 15) & ~15) * RO_CS * 4);
-    c.rlist = ro_take(off, H * N * (((N + 7) & ~7) + 8));
+    c.rlist = ro_take(off, H * N * ro_list_stride(N));
     c.rcnt = ro_take(off, H * N * 4);
     c.sxy = ro_take(off, N * 8);
     c.mmax = ro_take(off, 16);
@@ -215,7 +220,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     int* rcnt = reinterpret_cast<int*>(smraw + cv.rcnt);
     float2* sxy = reinterpret_cast<float2*>(smraw + cv.sxy);
     unsigned int* mmax = reinterpret_cast<unsigned int*>(smraw + cv.mmax);
-    const int RS = ((N + 7) & ~7) + 8;                        // list row stride (bytes)
+    const int RS = ro_list_stride(N);                         // list row stride (bytes)
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Np = (N + 3) & ~3;                              // delay-line rows: N rounded up to a multiple of 4
@@ -572,6 +577,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     //     row i of G_j(T) = e_i . A_T . A_{T-1} ... (min(j, hv) networks of this launch)  [ . G_{j-hv}(t0) when j > hv ]
     // Slices are produced in descending j (a slice that is still an input -- j - hv < j -- is overwritten later), with a
     // workgroup barrier between slices.  Row vectors ping-pong in the activation area (no longer needed).
+    RO_STAMPX(10);
     if (T > 0 && K >= 2) {
         const int hv = min(T, K - 1);
         float* rbuf = act + wave * 2 * Np;                    // [2][Np] per wave (16 x 2 x Np floats fit the activation area)
@@ -614,6 +620,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 }
             }
             __syncthreads();
+            RO_STAMPX(10 + (K - j));
         }
     }
     for (int e = tid; e < K * 6 * N; e += RO_THREADS) {
@@ -625,6 +632,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     }
     if (action != nullptr)
         for (int e = tid; e < 2 * N; e += RO_THREADS) action[(size_t)b * 2 * N + e] = uact[e];
+    RO_STAMPX(2);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -79,5 +79,6 @@ int main(int argc, char** argv) {
         for (int w = 0; w < 6; ++w) printf(" %7lld", (long long)(st[wv[w] * 16 + i] - st[0]));
         printf("  %s\n", names[i]);
     }
+    printf("exit, wave 0 (cycles since exit start): after slice K-1 %lld | after slice K-2 %lld | kernel end %lld\n", (long long)(st[11] - st[10]), (long long)(st[12] - st[10]), (long long)(st[2] - st[10]));
     return 0;
 }
