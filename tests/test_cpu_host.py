@@ -286,3 +286,27 @@ def test_reference_cfg_files_are_accepted():
             assert (p.link_drop > 0) == (section.get('env') == 'FlockingStochastic-v0')
             seen += 1
     assert seen >= 200 and airsim >= 1
+
+
+def test_coverage_predicates_are_host_side():
+    """mgp_rollout_supported / mgp_actor_supported / mgp_train_supported are pure host functions (no device needed): the
+    shapes of every reference sweep are inside the resident rollout's coverage, the documented limits are its edges."""
+    import ctypes
+    from multiagent_gnn_policies_amd import _lib, ops
+    for n in (25, 50, 75, 100, 125, 150, 200, 250):                # cfg/n.cfg, cfg/n_twoflocks.cfg
+        for k in (1, 2, 3, 4):
+            assert ops.rollout_supported((6, 32, 32, 2), k, n), (n, k)
+    for h in (4, 8, 16, 32):                                       # cfg/hidden_size.cfg up to the 32-wide limit
+        for layers in (1, 2, 3, 4):
+            assert ops.rollout_supported((6,) + (h,) * layers + (2,), 3, 100)
+    assert not ops.rollout_supported((6, 64, 2), 3, 100)           # 64- and 128-wide layers: two-launch path
+    assert not ops.rollout_supported((6, 32, 2), 3, 1000)          # BASELINE configs[2]: two-launch path
+    assert not ops.rollout_supported((6, 32, 2), 6, 100) and not ops.rollout_supported((6, 32, 2), 3, 3)
+    assert not ops.rollout_supported((5, 32, 2), 3, 100) and not ops.rollout_supported((6, 32, 3), 3, 100)
+    L = _lib.lib()
+    d = (ctypes.c_int * 4)(6, 32, 32, 2)
+    assert L.mgp_actor_supported(d, 3, 3, 100) and L.mgp_actor_supported(d, 3, 3, 1000)
+    assert L.mgp_train_supported(d, 3, 20, 3, 100) and L.mgp_train_workspace(d, 3, 20, 3, 100) == 20 * 7 * 1731 + 1
+    assert not L.mgp_train_supported(d, 3, 20000, 3, 100)          # > 8192 column tiles
+    d128 = (ctypes.c_int * 3)(6, 128, 2)
+    assert not L.mgp_actor_supported(d128, 2, 3, 100) and not L.mgp_train_supported(d128, 2, 20, 3, 100)
