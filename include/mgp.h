@@ -267,6 +267,35 @@ int  mgp_train_step(const float* X, const float* G, const float* target,
                     float lr, float beta1, float beta2, float eps, int* step_dev,
                     float* loss, float* workspace, int B, int K, int N, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Factored state for episodes beyond the LDS-resident rollout (N > 256)
+ * Same loop as mgp_rollout_steps (test_model.py:38-44), same mathematics -- tap j = x_{t-j} A_t ... A_{t-j+1} evaluated
+ * left to right -- with the state in HBM/L2 instead of LDS and the networks as membership BIT ROWS:
+ *   bits (B,H,N,NW) u64   rows of the last H = max(K-1, 1) networks, ring over time, NW = mgp_sparse_words(N)
+ *   wrow (B,H,N)    f32   row weights (1/deg or 1);  a network that does not exist yet = zero bits, zero weights
+ *   feat (B,K,N,8)  f32   features x_t .. x_{t-K+1} as (N,8) rows (6 used), ring over time; missing history = zeros
+ * A step never touches a dense N x N operator (the dense path moves 12 MB per episode and step at N = 1000).
+ *   mgp_flock_step_sparse   simulator step (FLOCK-SPEC, the arithmetic of mgp_flock_step): x -> x_out, then bit rows, row
+ *                           weights and (N,8) features of the new state into the ring slots the caller points at
+ *                           (batch strides sBb / sWb / sTb in words / floats / floats); u == NULL: observe x itself
+ *   mgp_sparse_policy_image weights -> MFMA fragment image (mgp_sparse_policy_image_floats floats), once per policy
+ *   mgp_sparse_policy_step  action (B,1,2,N) from the factored state: K-2 gather launches + one policy launch
+ *   mgp_sparse_to_dense     G (B,K,N,N) slices 1..K-1 of the reference contract from the bit rows (on demand)
+ * Coverage: dims[0] = 6, dims[n_layers] = 2, widths and 6K <= 32, K <= 5, N <= 4096. */
+int  mgp_sparse_words(int N);
+int  mgp_flock_step_sparse(const double* x, double* x_out, const float* u, long su_agent, long su_axis,
+                           unsigned long long* bits, long sBb, float* wrow, long sWb, float* featT, long sTb,
+                           double* reward, float* expert, const MgpFlockParams* p, int B, int N, void* stream);
+int  mgp_sparse_policy_supported(const int* dims, int n_layers, int K, int N);
+long mgp_sparse_policy_image_floats(const int* dims, int n_layers, int K);
+int  mgp_sparse_policy_image(const float* const* W, const float* const* b, const int* dims, int n_layers, int K,
+                             float* image, void* stream);
+int  mgp_sparse_policy_step(const unsigned long long* bits, const float* wrow, const float* feat, const float* image,
+                            const int* dims, int n_layers, float* scratch, float* action,
+                            int B, int K, int N, int cur, int hs, void* stream);
+int  mgp_sparse_to_dense(const unsigned long long* bits, const float* wrow, float* G, int B, int K, int N, int hs,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

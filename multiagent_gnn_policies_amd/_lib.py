@@ -63,6 +63,14 @@ SIGNATURES = {
     'mgp_train_supported': (_int, [_vp, _int, _int, _int, _int]),
     'mgp_train_workspace': (_long, [_vp, _int, _int, _int, _int]),
     'mgp_train_grads': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _int, _int, _vp]),
+    'mgp_sparse_words': (_int, [_int]),
+    'mgp_flock_step_sparse': (_int, [_vp, _vp, _vp, _long, _long, _vp, _long, _vp, _long, _vp, _long, _vp, _vp, _vp,
+                                     _int, _int, _vp]),
+    'mgp_sparse_policy_supported': (_int, [_vp, _int, _int, _int]),
+    'mgp_sparse_policy_image_floats': (_long, [_vp, _int, _int]),
+    'mgp_sparse_policy_image': (_int, [_vp, _vp, _vp, _int, _int, _vp, _vp]),
+    'mgp_sparse_policy_step': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
+    'mgp_sparse_to_dense': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     'mgp_train_step': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _f32, _f32, _f32, _f32, _vp,
                               _vp, _vp, _int, _int, _int, _vp]),
 }

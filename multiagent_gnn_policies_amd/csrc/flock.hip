@@ -58,6 +58,8 @@ struct FlockOut {
     // Gn[b,j] = A_t . Gp[b,j-1] (j >= 2) from the membership bits, Xn[b,j] = Xp[b,j-1] (j >= 1)
     int adv, K, has_prev; const float* Gp; float* Gn; const float* Xp; float* Xn;
     int vecA;               // 1: fp32 network rows may be written with 16-byte stores (N % 4 == 0, aligned, no fp64 copy)
+    // sparse outputs (mgp_flock_step_sparse): the network as membership bit rows + row weights, features as (N, 8) rows
+    unsigned long long* bits; float* wq; float* featT; long sBb, sWb, sTb;     // batch strides in words / floats / floats
 };
 
 
@@ -156,7 +158,8 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
     const int i = i0 + rl;
     const double R2 = p.comm_radius2;
     double deg = 0.0, f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0;
-    const int jh = (N + FL_SPLIT - 1) / FL_SPLIT;          // j's per piece
+    // j's per piece; sparse outputs: a multiple of 64, so that the (row, piece, word) masks below ARE the row's bit words
+    const int jh = (o.bits != nullptr) ? ((((N + FL_SPLIT - 1) / FL_SPLIT) + 63) & ~63) : (N + FL_SPLIT - 1) / FL_SPLIT;
     const int nch = (jh + 63) / 64;                        // 64-bit adjacency words per (row, piece)
     if (pair_active && rl < rows) {
         const double xi = spx[i], yi = spy[i], vxi = svx[i], vyi = svy[i];
@@ -228,6 +231,12 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
             fb[0 * (size_t)N] = (float)f0; fb[1 * (size_t)N] = (float)f1; fb[2 * (size_t)N] = (float)f2;
             fb[3 * (size_t)N] = (float)f3; fb[4 * (size_t)N] = (float)f4; fb[5 * (size_t)N] = (float)f5;
         }
+        if (o.bits != nullptr) {
+            o.wq[(size_t)b * o.sWb + i] = (float)wrow[rl];
+            float* ft = o.featT + (size_t)b * o.sTb + (size_t)i * 8;
+            *reinterpret_cast<float4*>(ft) = make_float4((float)f0, (float)f1, (float)f2, (float)f3);
+            *reinterpret_cast<float4*>(ft + 4) = make_float4((float)f4, (float)f5, 0.f, 0.f);
+        }
         if (o.feat64 != nullptr) {
             double* fd = o.feat64 + ((size_t)b * N + i) * 6;
             fd[0] = f0; fd[1] = f1; fd[2] = f2; fd[3] = f3; fd[4] = f4; fd[5] = f5;
@@ -249,6 +258,11 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
         }
     }
     FL_STAMP(4);
+    if (o.bits != nullptr) {                              // the masks of this workgroup's rows, [row][piece][word] = [row][nwords]
+        const int nwords = FL_SPLIT * nch;
+        unsigned long long* gb = o.bits + (size_t)b * o.sBb + (size_t)i0 * nwords;
+        for (int idx = tid; idx < rows * nwords; idx += FL_THREADS) gb[idx] = adjw[idx];
+    }
     if (o.A == nullptr && o.A64 == nullptr) return;
     __syncthreads();
     FL_STAMP(5);
@@ -387,7 +401,7 @@ template <bool FUSE, int THREADS, int ROWS, int PIECES>
 int launch_step(const double* x, double* xo, const float* u, long su_agent, long su_axis, const FlockOut& o,
                 const MgpFlockParams* p, int B, int N, hipStream_t st)
 {
-    const int jh = (N + PIECES - 1) / PIECES;
+    const int jh = (o.bits != nullptr) ? ((((N + PIECES - 1) / PIECES) + 63) & ~63) : (N + PIECES - 1) / PIECES;
     const size_t lds = ((size_t)4 * N + PIECES * ROWS * 8 + ROWS + (size_t)ROWS * PIECES * ((jh + 63) / 64)) *
                            sizeof(double) + (o.adv ? (((size_t)ROWS * N + 15) & ~(size_t)15) : 0);     // + one byte-indexed neighbour list per row
     if (lds > 48 * 1024 &&
@@ -492,4 +506,35 @@ extern "C" int mgp_flock_step_advance(double* x, double* x_out, const float* u, 
     mgp_clear_error();
     return launch_step<true, FP_THREADS, FP_ROWS, FP_PIECES>(x, x_out, u, su_agent, su_axis, o, p, B, N,
                                                   static_cast<hipStream_t>(stream));
+}
+
+/* Words per membership bit row written by mgp_flock_step_sparse: 8 row pieces, each a whole number of 64-bit words. */
+extern "C" int mgp_sparse_words(int N)
+{
+    if (N <= 0) return 0;
+    return FP_PIECES * (((((N + FP_PIECES - 1) / FP_PIECES) + 63) & ~63) / 64);
+}
+
+extern "C" int mgp_flock_step_sparse(const double* x, double* x_out, const float* u, long su_agent, long su_axis,
+                                     unsigned long long* bits, long sBb, float* wrow, long sWb, float* featT, long sTb,
+                                     double* reward, float* expert, const MgpFlockParams* p, int B, int N, void* stream)
+{
+    if (B < 0 || N <= 0) return MGP_EINVAL;
+    int rc = check_params(p);
+    if (rc != MGP_OK) return rc;
+    if (B == 0) return MGP_OK;
+    if (B > 65535 || N > 4096) return MGP_EUNSUPPORTED;
+    MGP_CHECK_PTR8(x); MGP_CHECK_PTR8(x_out); MGP_CHECK_PTR8(bits); MGP_CHECK_PTR(wrow); MGP_CHECK_PTR(featT);
+    if (x_out == x) return MGP_EINVAL;                     // ping-pong state only
+    if (!mgp_aligned16(featT) || (sTb & 3)) return MGP_EALIGN;
+    FlockOut o = {};
+    o.reward = reward; o.expert = expert; o.centralized = p->centralized;
+    o.bits = bits; o.wq = wrow; o.featT = featT; o.sBb = sBb; o.sWb = sWb; o.sTb = sTb;
+    o.sep_reward = reward != nullptr;
+    mgp_clear_error();
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (u != nullptr)
+        return launch_step<true, FP_THREADS, FP_ROWS, FP_PIECES>(x, x_out, u, su_agent, su_axis, o, p, B, N, st);
+    // no action: observations of x itself (x_out is not written)
+    return launch_step<false, FP_THREADS, FP_ROWS, FP_PIECES>(x, const_cast<double*>(x), nullptr, su_agent, su_axis, o, p, B, N, st);
 }

@@ -38,7 +38,7 @@
 // (The first version of this kernel kept slices 1..K-1 densely in LDS -- 80 KB at N = 100, K = 3 -- aggregated taps >= 2
 //  on the matrix cores and advanced the slices with row gathers every step: 8.6 us per step of 256 episodes against 7.2.)
 // This translation unit is built with -ffp-contract=off (fp64 spec arithmetic); fp32 fused multiply-adds are explicit.
-#include "mgp_device.h"
+#include "rollout_common.h"
 
 namespace {
 
@@ -47,15 +47,6 @@ constexpr int RO_WAVES = RO_THREADS / 64;
 constexpr int RO_PIECES = 8;              // j-range pieces per agent row in the pairwise pass (adjacent lanes)
 constexpr int RO_MAXN = 128;              // RO_THREADS / RO_PIECES rows; membership bits of a row fit 2 x u64
 constexpr int RO_LDS_LIMIT = 160 * 1024;
-// MLP operand layout: the resident kernel covers layer widths <= 32, i.e. <= 8 MFMA k-steps, so an agent column of the
-// activation buffer holds 4 x 8 floats (+4 pad) and a weight fragment lane 8 floats (+4 pad) -- half of actor_fused.hip's
-// 64-wide layout.  36 and 12 words per lane keep a 16-lane ds_read_b128 group on disjoint banks.
-constexpr int RO_KS = 8;
-constexpr int RO_CS = 4 * RO_KS + 4;
-constexpr int RO_WFS = RO_KS + 4;
-__host__ __device__ inline int rpos(int c) { return (c & 3) * RO_KS + (c >> 2); }   // channel -> slot (B-fragment order)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 #ifdef MGP_RO_PROFILE
 __device__ unsigned long long mgp_ro_stamps[16 * 16];     // [wave][stamp]
 #define RO_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == 5) mgp_ro_stamps[(threadIdx.x >> 6) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
@@ -116,80 +107,6 @@ __host__ __device__ constexpr RoOff ro_offsets(int N, int K)
     c.mmax = ro_take(off, 16);
     c.wl = off;
     return c;
-}
-
-// One hidden layer for the 16 agent columns a wave owns: D[mt] (16 x 16) = W[mt] (16 x cin) . Act (cin x 16) on fp32
-// 16x16x4 MFMAs, both m-tiles of a 32-wide layer as two independent accumulator chains, bias preloaded into the
-// accumulators, tanh on the accumulator registers.  The wave reads all its B fragments before it stores anything and
-// therefore works in place; no other wave touches these columns, so hidden layers need no workgroup barrier between
-// them.  (Splitting the m-tiles over two waves with ping-pong buffers and a barrier per layer measured the same.)
-template <int MT>
-__device__ __forceinline__ void ro_mlp_cols(float* pcol, const float* pw, const float* pbias, int ksteps, int lq)
-{
-    float fb[RO_KS], fa[MT][RO_KS];
-    f32x4 acc[MT];
-    const float4* pb = reinterpret_cast<const float4*>(pcol + lq * RO_KS);
-#pragma unroll
-    for (int i = 0; i < RO_KS / 4; ++i) { const float4 t = pb[i]; fb[4 * i] = t.x; fb[4 * i + 1] = t.y; fb[4 * i + 2] = t.z; fb[4 * i + 3] = t.w; }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const float4* pa = reinterpret_cast<const float4*>(pw + mt * 64 * RO_WFS);
-#pragma unroll
-        for (int i = 0; i < RO_KS / 4; ++i) { const float4 u = pa[i]; fa[mt][4 * i] = u.x; fa[mt][4 * i + 1] = u.y; fa[mt][4 * i + 2] = u.z; fa[mt][4 * i + 3] = u.w; }
-        const float4 bv = *reinterpret_cast<const float4*>(pbias + mt * 16);
-        acc[mt][0] = bv.x; acc[mt][1] = bv.y; acc[mt][2] = bv.z; acc[mt][3] = bv.w;
-    }
-#pragma unroll
-    for (int sg = 0; sg < RO_KS / 2; ++sg) {
-        if (2 * sg < ksteps) {
-#pragma unroll
-            for (int s_ = 2 * sg; s_ < 2 * sg + 2; ++s_)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][s_], fb[s_], acc[mt], 0, 0, 0);
-        }
-    }
-    float z[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) z[mt][rr] = tanh_fast(acc[mt][rr]);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) pcol[rr * RO_KS + mt * 4 + lq] = z[mt][rr];                 // slot rpos(16 mt + 4 lq + rr)
-}
-
-__device__ __forceinline__ int ro_dim(unsigned long long dimsA, unsigned int dims8, int l)
-{
-    return (l < 8) ? (int)((dimsA >> (8 * l)) & 255ull) : (int)dims8;
-}
-
-__device__ __forceinline__ int ro_slot(int cur, int k, int K) { int s = cur - k; return s < 0 ? s + K : s; }
-
-// Cross-lane adds on the DPP path (one VALU instruction per move; __shfl_xor compiles to ds_bpermute + address math).
-// 0xB1 = quad_perm [1,0,3,2] (lane ^ 1), 0x4E = quad_perm [2,3,0,1] (lane ^ 2), 0x141 = row_half_mirror (i -> 7 - i).
-template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-template <int CTRL> __device__ __forceinline__ double dpp_d(double v)
-{
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)b, CTRL, 0xF, 0xF, true);
-    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(b >> 32), CTRL, 0xF, 0xF, true);
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-// max over the 64 lanes, valid in lane 63: four DPP steps inside each row of 16, then row_bcast15 / row_bcast31
-__device__ __forceinline__ float wave_max_to_last(float v)
-{
-    v = fmaxf(v, dpp_f<0xB1>(v));
-    v = fmaxf(v, dpp_f<0x4E>(v));
-    v = fmaxf(v, dpp_f<0x141>(v));                                   // row_half_mirror
-    v = fmaxf(v, dpp_f<0x140>(v));                                   // row_mirror: every lane holds its row's max
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, true)));   // row_bcast15 -> rows 1, 3
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, true)));   // row_bcast31 -> rows 2, 3
-    return v;
 }
 
 // CN / CK: compile-time (N, K) of a specialised instantiation (0 = take the run-time arguments): constant LDS addresses,

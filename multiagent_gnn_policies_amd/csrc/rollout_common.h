@@ -1,0 +1,116 @@
+// Device helpers shared by the episode-resident rollout kernels (rollout.hip) and the sparse policy kernels
+// (sparse_policy.hip): MFMA operand layout of the <= 32-wide tanh MLP, the per-wave hidden-layer routine, DPP moves.
+#ifndef MGP_ROLLOUT_COMMON_H
+#define MGP_ROLLOUT_COMMON_H
+#include "mgp_device.h"
+
+namespace {
+
+// MLP operand layout: the resident kernel covers layer widths <= 32, i.e. <= 8 MFMA k-steps, so an agent column of the
+// activation buffer holds 4 x 8 floats (+4 pad) and a weight fragment lane 8 floats (+4 pad) -- half of actor_fused.hip's
+// 64-wide layout.  36 and 12 words per lane keep a 16-lane ds_read_b128 group on disjoint banks.
+constexpr int RO_KS = 8;
+constexpr int RO_CS = 4 * RO_KS + 4;
+constexpr int RO_WFS = RO_KS + 4;
+__host__ __device__ inline int rpos(int c) { return (c & 3) * RO_KS + (c >> 2); }   // channel -> slot (B-fragment order)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// One hidden layer for the 16 agent columns a wave owns: D[mt] (16 x 16) = W[mt] (16 x cin) . Act (cin x 16) on fp32
+// 16x16x4 MFMAs, both m-tiles of a 32-wide layer as two independent accumulator chains, bias preloaded into the
+// accumulators, tanh on the accumulator registers.  The wave reads all its B fragments before it stores anything and
+// therefore works in place; no other wave touches these columns, so hidden layers need no workgroup barrier between
+// them.  (Splitting the m-tiles over two waves with ping-pong buffers and a barrier per layer measured the same.)
+template <int MT>
+__device__ __forceinline__ void ro_mlp_cols(float* pcol, const float* pw, const float* pbias, int ksteps, int lq)
+{
+    float fb[RO_KS], fa[MT][RO_KS];
+    f32x4 acc[MT];
+    const float4* pb = reinterpret_cast<const float4*>(pcol + lq * RO_KS);
+#pragma unroll
+    for (int i = 0; i < RO_KS / 4; ++i) { const float4 t = pb[i]; fb[4 * i] = t.x; fb[4 * i + 1] = t.y; fb[4 * i + 2] = t.z; fb[4 * i + 3] = t.w; }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const float4* pa = reinterpret_cast<const float4*>(pw + mt * 64 * RO_WFS);
+#pragma unroll
+        for (int i = 0; i < RO_KS / 4; ++i) { const float4 u = pa[i]; fa[mt][4 * i] = u.x; fa[mt][4 * i + 1] = u.y; fa[mt][4 * i + 2] = u.z; fa[mt][4 * i + 3] = u.w; }
+        const float4 bv = *reinterpret_cast<const float4*>(pbias + mt * 16);
+        acc[mt][0] = bv.x; acc[mt][1] = bv.y; acc[mt][2] = bv.z; acc[mt][3] = bv.w;
+    }
+#pragma unroll
+    for (int sg = 0; sg < RO_KS / 2; ++sg) {
+        if (2 * sg < ksteps) {
+#pragma unroll
+            for (int s_ = 2 * sg; s_ < 2 * sg + 2; ++s_)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][s_], fb[s_], acc[mt], 0, 0, 0);
+        }
+    }
+    float z[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) z[mt][rr] = tanh_fast(acc[mt][rr]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) pcol[rr * RO_KS + mt * 4 + lq] = z[mt][rr];                 // slot rpos(16 mt + 4 lq + rr)
+}
+
+__device__ __forceinline__ int ro_dim(unsigned long long dimsA, unsigned int dims8, int l)
+{
+    return (l < 8) ? (int)((dimsA >> (8 * l)) & 255ull) : (int)dims8;
+}
+
+__device__ __forceinline__ int ro_slot(int cur, int k, int K) { int s = cur - k; return s < 0 ? s + K : s; }
+
+// Cross-lane adds on the DPP path (one VALU instruction per move; __shfl_xor compiles to ds_bpermute + address math).
+// 0xB1 = quad_perm [1,0,3,2] (lane ^ 1), 0x4E = quad_perm [2,3,0,1] (lane ^ 2), 0x141 = row_half_mirror (i -> 7 - i).
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)b, CTRL, 0xF, 0xF, true);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// max over the 64 lanes, valid in lane 63: four DPP steps inside each row of 16, then row_bcast15 / row_bcast31
+__device__ __forceinline__ float wave_max_to_last(float v)
+{
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));                                   // row_half_mirror
+    v = fmaxf(v, dpp_f<0x140>(v));                                   // row_mirror: every lane holds its row's max
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, true)));   // row_bcast15 -> rows 1, 3
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, true)));   // row_bcast31 -> rows 2, 3
+    return v;
+}
+
+
+// Weight image of a policy whose layers are <= 32 wide: hidden layers as MFMA A-fragments [MT][64][RO_WFS] + bias [MT*16]
+// (lane = (c & 3) * 16 + (o & 15), slot s = c >> 2, zero padded), the 2-wide output layer as channel-ordered pairs
+// (W[0][c], W[1][c]) padded to 32 channels + the bias pair.  `e` indexes the image of layer l (woff[l] excluded).
+__device__ __forceinline__ float ro_weight_image_elem(const float* __restrict__ src, const float* __restrict__ bias, int cin,
+                                                      int cout, bool last, int e)
+{
+    if (last) {
+        const int c = e >> 1, o = e & 1;
+        return (c < 4 * RO_KS) ? ((c < cin) ? src[(size_t)o * cin + c] : 0.f) : bias[o];
+    }
+    const int MT = mtiles(cout), tot = MT * 64 * RO_WFS;
+    if (e >= tot) { const int o = e - tot; return (o < cout) ? bias[o] : 0.f; }
+    const int mt = e / (64 * RO_WFS), r1 = e - mt * (64 * RO_WFS);
+    const int ln = r1 / RO_WFS, sl = r1 - ln * RO_WFS;
+    const int c = 4 * sl + (ln >> 4), o = mt * 16 + (ln & 15);
+    return (sl < RO_KS && o < cout && c < cin) ? src[(size_t)o * cin + c] : 0.f;
+}
+__host__ __device__ inline int ro_weight_image_size(int cout, bool last)
+{
+    return last ? 2 * 4 * RO_KS + 2 : mtiles(cout) * 64 * RO_WFS + mtiles(cout) * 16;
+}
+
+}  // namespace
+#endif

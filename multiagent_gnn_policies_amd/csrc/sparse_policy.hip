@@ -1,0 +1,376 @@
+// Policy step on the FACTORED state, for episodes too large for the LDS-resident rollout (N > 256; BASELINE configs[2]:
+// N = 1000).  Same mathematics as rollout.hip:
+//
+//     y_j(t) = x_{t-j} G_j(t) = x_{t-j} A_t A_{t-1} ... A_{t-j+1}       (state_with_delay.py:44-47, actor.py:64-71)
+//
+// evaluated left to right along the networks' membership BIT ROWS (mgp_flock_step_sparse writes them: 128 B per row at
+// N = 1000 where the dense row is 4 KB), so a step never touches a dense N x N operator: the two-launch dense path moves
+// 12 MB per episode and step at N = 1000, this one ~0.3 MB.  The state lives in HBM/L2 between launches:
+//     bits  (B, H, N, NW) u64   membership rows of the last H = K-1 networks (ring over time)
+//     wrow  (B, H, N)     f32   row weights (1/deg or 1)
+//     feat  (B, K, N, 8)  f32   features x_t .. x_{t-K+1} as (N, 8) rows (6 used), ring over time
+// One step = K launches: K-2 gather stages (sp_gather_kernel: stage q multiplies the running products of taps j >= q by
+// A_{t-q+1}), the policy tail (sp_policy_kernel: last gather stage + filter GEMM + tanh MLP on MFMA + output layer, the
+// arithmetic of rollout.hip's phases A-C) and the simulator (mgp_flock_step_sparse).  sp_to_dense_kernel rebuilds the
+// dense delayed operator slices of the reference contract from the bit rows when a caller asks for them.
+#include "mgp_common.h"
+#include "rollout_common.h"
+
+namespace {
+
+constexpr int SP_THREADS = 256;
+constexpr int SP_COLS = 64;               // agent columns per workgroup: 4 lanes per column / one 16-column MFMA tile per wave
+constexpr int SP_MAXTAPS = 4;             // K <= 5
+
+// sum over the set bits m of `w` (base index `base`) of wq[m] * src[m][0..5]   (src rows are 8 floats)
+__device__ __forceinline__ void sp_gather_word(unsigned long long w, int base, const float* __restrict__ wq,
+                                               const float* __restrict__ src, float (&sa)[6])
+{
+    while (w) {
+        const int m = base + __builtin_ctzll(w);
+        w &= w - 1ull;
+        const float gv = wq[m];
+        const float4 x0 = *reinterpret_cast<const float4*>(src + (size_t)m * 8);
+        const float2 x1 = *reinterpret_cast<const float2*>(src + (size_t)m * 8 + 4);
+        sa[0] = fmaf(x0.x, gv, sa[0]); sa[1] = fmaf(x0.y, gv, sa[1]); sa[2] = fmaf(x0.z, gv, sa[2]);
+        sa[3] = fmaf(x0.w, gv, sa[3]); sa[4] = fmaf(x1.x, gv, sa[4]); sa[5] = fmaf(x1.y, gv, sa[5]);
+    }
+}
+
+// (v . A)[n, 0..5] for column n = blockIdx.x * 64 + (tid >> 2): the quad's four lanes take a quarter of the row's words
+// each and are added by DPP; valid in every lane of the quad
+__device__ __forceinline__ void sp_gather_column(const unsigned long long* __restrict__ brow, int NW,
+                                                 const float* __restrict__ wq, const float* __restrict__ src, int part,
+                                                 bool live, float (&sa)[6])
+{
+#pragma unroll
+    for (int f = 0; f < 6; ++f) sa[f] = 0.f;
+    if (live) {
+        const int wpl = NW >> 2;                              // words per lane (NW is a multiple of 8)
+        for (int wd = part * wpl; wd < (part + 1) * wpl; ++wd) sp_gather_word(brow[wd], 64 * wd, wq, src, sa);
+    }
+#pragma unroll
+    for (int f = 0; f < 6; ++f) { sa[f] += dpp_f<0xB1>(sa[f]); sa[f] += dpp_f<0x4E>(sa[f]); }
+}
+
+struct SpTaps {                            // one gather stage: taps processed together (same network)
+    const float* src[SP_MAXTAPS];
+    float* dst[SP_MAXTAPS];
+    long ss[SP_MAXTAPS], ds[SP_MAXTAPS];  // batch strides (floats)
+};
+
+// grid: x = column tile, y = tap of the stage, z = b
+__global__ __launch_bounds__(SP_THREADS)
+void sp_gather_kernel(const unsigned long long* __restrict__ bits, long sBb, const float* __restrict__ wq, long sWb,
+                      SpTaps T, int N, int NW)
+{
+    const int tid = threadIdx.x, b = blockIdx.z, tap = blockIdx.y;
+    const int n = blockIdx.x * SP_COLS + (tid >> 2), part = tid & 3;
+    const bool live = n < N;
+    float sa[6];
+    sp_gather_column(bits + (size_t)b * sBb + (size_t)min(n, N - 1) * NW, NW, wq + (size_t)b * sWb,
+                     T.src[tap] + (size_t)b * T.ss[tap], part, live, sa);
+    if (live && part == 0) {
+        float* d = T.dst[tap] + (size_t)b * T.ds[tap] + (size_t)n * 8;
+        *reinterpret_cast<float4*>(d) = make_float4(sa[0], sa[1], sa[2], sa[3]);
+        *reinterpret_cast<float4*>(d + 4) = make_float4(sa[4], sa[5], 0.f, 0.f);
+    }
+}
+
+struct SpPolicy {
+    const float* tap[SP_MAXTAPS + 1];     // tap 0: x_t rows; taps 1..K-2: finished products; tap K-1: INPUT of the last stage
+    long ts[SP_MAXTAPS + 1];              // batch strides (floats)
+    const unsigned long long* bits;       // network of the last stage, A_{t-K+2} (unused when K == 1)
+    long sBb;
+    const float* wq; long sWb;
+    const float* image;                   // weight image (sp_weight_image_kernel), wtot floats
+    int wtot;
+};
+
+// grid: x = tile of 64 columns, y = b.  LDS: act [64][RO_CS] | weight image
+__global__ __launch_bounds__(SP_THREADS)
+void sp_policy_kernel(SpPolicy P, float* __restrict__ action, int K, int N, int NW, unsigned long long dimsA,
+                      unsigned int dims8, unsigned long long woffA, unsigned long long woffB, int n_layers)
+{
+    extern __shared__ __attribute__((aligned(16))) float spm[];
+    float* act = spm;
+    float* wl = spm + SP_COLS * RO_CS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
+    const int c0 = blockIdx.x * SP_COLS;
+    const int FK = 6 * K;
+    {
+        const float4* src = reinterpret_cast<const float4*>(P.image);
+        float4* dst = reinterpret_cast<float4*>(wl);
+        for (int i = tid; i < (P.wtot + 3) / 4; i += SP_THREADS) dst[i] = src[i];
+        float4* za = reinterpret_cast<float4*>(act);
+        for (int i = tid; i < SP_COLS * RO_CS / 4; i += SP_THREADS) za[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    // taps whose product is finished (tap 0 = x_t itself): channel (f, j) of column c -> MFMA B-fragment slot rpos(f K + j)
+    for (int j = 0; j < K - 1 || (j == 0 && K == 1); ++j) {
+        const float* src = P.tap[j] + (size_t)b * P.ts[j];
+        for (int i = tid; i < SP_COLS * 8; i += SP_THREADS) {
+            const int c = i >> 3, f = i & 7;
+            if (f < 6 && c0 + c < N) act[c * RO_CS + rpos(f * K + j)] = src[(size_t)(c0 + c) * 8 + f];
+        }
+    }
+    if (K >= 2) {                                              // last tap: its last factor is applied here
+        const int c = tid >> 2, part = tid & 3, n = c0 + c;
+        float sa[6];
+        sp_gather_column(P.bits + (size_t)b * P.sBb + (size_t)min(n, N - 1) * NW, NW, P.wq + (size_t)b * P.sWb,
+                         P.tap[K - 1] + (size_t)b * P.ts[K - 1], part, n < N, sa);
+        if (part == 0 && n < N) {
+#pragma unroll
+            for (int f = 0; f < 6; ++f) act[c * RO_CS + rpos(f * K + K - 1)] = sa[f];
+        }
+    }
+    __syncthreads();
+    // filter GEMM + tanh hidden layers: wave w owns columns 16 w .. 16 w + 15 (rollout.hip phase B)
+    const int li = lane & 15, lq = lane >> 4;
+    float* pcol = act + (wave * 16 + li) * RO_CS;
+    for (int l = 0; l < n_layers - 1; ++l) {
+        const int cin = (l == 0) ? FK : ((l < 8) ? (int)((dimsA >> (8 * l)) & 255ull) : (int)dims8);
+        const int cout = (l + 1 < 8) ? (int)((dimsA >> (8 * (l + 1))) & 255ull) : (int)dims8;
+        const int MT = mtiles(cout);
+        const float* wfrag = wl + (int)((((l < 4) ? woffA : woffB) >> (16 * (l & 3))) & 0xFFFFull);
+        if (MT == 2) ro_mlp_cols<2>(pcol, wfrag + lane * RO_WFS, wfrag + 2 * 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
+        else ro_mlp_cols<1>(pcol, wfrag + lane * RO_WFS, wfrag + 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
+    }
+    // 2-wide output layer: lane L takes column L >> 2 of the wave's tile and 8 channels, quad sum by DPP (phase C)
+    const int lo_ = n_layers - 1;
+    const float* w2 = wl + (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull);
+    const int ccol = wave * 16 + (lane >> 2), cg = lane & 3;
+    const float* zsrc = act + ccol * RO_CS + cg * RO_KS;
+    const float4 z0 = *reinterpret_cast<const float4*>(zsrc);
+    const float4 z1 = *reinterpret_cast<const float4*>(zsrc + 4);
+    const float zc[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+    f32x2 u2 = {0.f, 0.f}, u2b = {0.f, 0.f};
+#pragma unroll
+    for (int s_ = 0; s_ < RO_KS; s_ += 2) {
+        const float2 wa = *reinterpret_cast<const float2*>(w2 + 2 * (4 * s_ + cg));
+        const float2 wb = *reinterpret_cast<const float2*>(w2 + 2 * (4 * (s_ + 1) + cg));
+        u2 = __builtin_elementwise_fma((f32x2){zc[s_], zc[s_]}, (f32x2){wa.x, wa.y}, u2);
+        u2b = __builtin_elementwise_fma((f32x2){zc[s_ + 1], zc[s_ + 1]}, (f32x2){wb.x, wb.y}, u2b);
+    }
+    u2 = u2 + u2b;
+    float ux = u2.x, uy = u2.y;
+    ux += dpp_f<0xB1>(ux); uy += dpp_f<0xB1>(uy);
+    ux += dpp_f<0x4E>(ux); uy += dpp_f<0x4E>(uy);
+    if (cg == 0 && c0 + ccol < N) {
+        const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * 4 * RO_KS);
+        action[((size_t)b * 2 + 0) * N + c0 + ccol] = ux + bb.x;
+        action[((size_t)b * 2 + 1) * N + c0 + ccol] = uy + bb.y;
+    }
+}
+
+struct SpWeights {
+    const float* W[MGP_MAX_LAYERS];
+    const float* b[MGP_MAX_LAYERS];
+    int dims[MGP_MAX_LAYERS + 1];
+    int woff[MGP_MAX_LAYERS];
+    int n_layers;
+};
+
+__global__ __launch_bounds__(SP_THREADS)
+void sp_weight_image_kernel(SpWeights P, int K, float* __restrict__ image)
+{
+    for (int l = 0; l < P.n_layers; ++l) {
+        const int cin = (l == 0) ? 6 * K : P.dims[l], cout = P.dims[l + 1];
+        const bool last = l == P.n_layers - 1;
+        const int tot = ro_weight_image_size(cout, last);
+        for (int e = threadIdx.x; e < tot; e += SP_THREADS)
+            image[P.woff[l] + e] = ro_weight_image_elem(P.W[l], P.b[l], cin, cout, last, e);
+    }
+}
+
+// Dense slices of the delayed operator from the bit rows: row i of G_j = e_i A_T A_{T-1} ... A_{T-j+1}, one wave per row,
+// row vectors ping-pong in LDS.  hs = ring slot of the newest network; networks that do not exist yet (fewer than K-1
+// steps since the reset) are all-zero rows with zero weights, which makes the products vanish as the reference's do.
+// grid: x = group of 4 rows, y = b.  LDS: [4 waves][2][Np]
+__global__ __launch_bounds__(SP_THREADS)
+void sp_to_dense_kernel(const unsigned long long* __restrict__ bits, const float* __restrict__ wq, float* __restrict__ G,
+                        int K, int H, int N, int NW, int hs)
+{
+    extern __shared__ __attribute__((aligned(16))) float spm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
+    const int i = blockIdx.x * 4 + wave;
+    const int Np = (N + 3) & ~3;
+    if (i >= N) return;                                       // whole wave (no workgroup barrier below)
+    float* r0 = spm + (size_t)wave * 2 * Np;
+    float* r1 = r0 + Np;
+    const unsigned long long* bb = bits + (size_t)b * H * N * NW;
+    const float* wb = wq + (size_t)b * H * N;
+    float* Gb = G + (size_t)b * K * N * N;
+    {   // e_i . A_T
+        const unsigned long long* row = bb + ((size_t)hs * N + i) * NW;
+        const float wi = wb[(size_t)hs * N + i];
+        for (int n = lane; n < N; n += 64) {
+            const float v = ((row[n >> 6] >> (n & 63)) & 1ull) ? wi : 0.f;
+            r0[n] = v;
+            Gb[((size_t)1 * N + i) * N + n] = v;
+        }
+    }
+    for (int j = 2; j < K; ++j) {                             // r1 = r0 . A_{T-j+1}: scatter along the rows m with r0[m] != 0
+        int hq = hs - (j - 1); hq = hq < 0 ? hq + H : hq;
+        const unsigned long long* net = bb + (size_t)hq * N * NW;
+        const float* wn = wb + (size_t)hq * N;
+        for (int n = lane; n < N; n += 64) r1[n] = 0.f;
+        for (int m0 = 0; m0 < N; m0 += 64) {
+            const float rv = (m0 + lane < N) ? r0[m0 + lane] : 0.f;
+            unsigned long long nz = __ballot(rv != 0.f);
+            while (nz) {                                      // wave-uniform loop over the non-zero entries of this chunk
+                const int m = m0 + __builtin_ctzll(nz);
+                nz &= nz - 1ull;
+                const float val = r0[m] * wn[m];
+                // row m of the (symmetric) pattern: lane l walks words l, l + 64, ...: distinct columns, no write conflicts
+                for (int wd = lane; wd < NW; wd += 64) {
+                    unsigned long long w = net[(size_t)m * NW + wd];
+                    while (w) { const int n = 64 * wd + __builtin_ctzll(w); w &= w - 1ull; r1[n] += val; }
+                }
+            }
+        }
+        for (int n = lane; n < N; n += 64) Gb[((size_t)j * N + i) * N + n] = r1[n];
+        float* t = r0; r0 = r1; r1 = t;
+    }
+}
+
+int sp_plan(const int* dims, int n_layers, int K, int* woff, int* wtot)
+{
+    if (dims == nullptr || n_layers < 1 || n_layers > MGP_MAX_LAYERS) return MGP_EINVAL;
+    if (K < 1 || K > SP_MAXTAPS + 1) return MGP_EUNSUPPORTED;
+    if (dims[0] != 6 || dims[n_layers] != 2) return MGP_EUNSUPPORTED;
+    int tot = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        const int cin = (l == 0) ? 6 * K : dims[l], cout = dims[l + 1];
+        if (cin < 1 || cout < 1 || cin > 4 * RO_KS || cout > 4 * RO_KS) return MGP_EUNSUPPORTED;
+        woff[l] = tot;
+        tot += ro_weight_image_size(cout, l == n_layers - 1);
+        tot = (tot + 3) & ~3;
+    }
+    *wtot = tot;
+    return MGP_OK;
+}
+
+}  // namespace
+
+extern "C" int mgp_sparse_policy_supported(const int* dims, int n_layers, int K, int N)
+{
+    int woff[MGP_MAX_LAYERS], wtot = 0;
+    if (N < 1 || N > 4096) return 0;
+    return sp_plan(dims, n_layers, K, woff, &wtot) == MGP_OK ? 1 : 0;
+}
+
+extern "C" long mgp_sparse_policy_image_floats(const int* dims, int n_layers, int K)
+{
+    int woff[MGP_MAX_LAYERS], wtot = 0;
+    return sp_plan(dims, n_layers, K, woff, &wtot) == MGP_OK ? wtot : 0;
+}
+
+extern "C" int mgp_sparse_policy_image(const float* const* W, const float* const* b, const int* dims, int n_layers, int K,
+                                       float* image, void* stream)
+{
+    if (W == nullptr || b == nullptr) return MGP_EINVAL;
+    SpWeights P;
+    int wtot = 0;
+    int rc = sp_plan(dims, n_layers, K, P.woff, &wtot);
+    if (rc != MGP_OK) return rc;
+    MGP_CHECK_PTR(image);
+    if (!mgp_aligned16(image)) return MGP_EALIGN;
+    P.n_layers = n_layers;
+    for (int l = 0; l <= n_layers; ++l) P.dims[l] = dims[l];
+    for (int l = 0; l < n_layers; ++l) { MGP_CHECK_PTR(W[l]); MGP_CHECK_PTR(b[l]); P.W[l] = W[l]; P.b[l] = b[l]; }
+    mgp_clear_error();
+    hipLaunchKernelGGL(sp_weight_image_kernel, dim3(1), dim3(SP_THREADS), 0, static_cast<hipStream_t>(stream), P, K, image);
+    return mgp_launch_status();
+}
+
+/* One policy evaluation on the factored state: action (B,1,2,N) <- Actor(x_t .. x_{t-K+1}; A_t .. A_{t-K+2}).
+ * cur = ring slot of x_t in feat (B,K,N,8); hs = ring slot of A_t in bits (B,H,N,NW) / wrow (B,H,N), H = max(K-1, 1).
+ * scratch: 2 * (K-1) * B * N * 8 floats for K >= 3 (running products between stages), else unused. */
+extern "C" int mgp_sparse_policy_step(const unsigned long long* bits, const float* wrow, const float* feat,
+                                      const float* image, const int* dims, int n_layers, float* scratch, float* action,
+                                      int B, int K, int N, int cur, int hs, void* stream)
+{
+    int woff[MGP_MAX_LAYERS], wtot = 0;
+    int rc = sp_plan(dims, n_layers, K, woff, &wtot);
+    if (rc != MGP_OK) return rc;
+    if (B <= 0 || N <= 0 || N > 4096 || B > 65535) return MGP_EINVAL;
+    MGP_CHECK_PTR8(bits); MGP_CHECK_PTR(wrow); MGP_CHECK_PTR(feat); MGP_CHECK_PTR(image); MGP_CHECK_PTR(action);
+    if (!mgp_aligned16(feat) || !mgp_aligned16(image)) return MGP_EALIGN;
+    if (K >= 3) { MGP_CHECK_PTR(scratch); if (!mgp_aligned16(scratch)) return MGP_EALIGN; }
+    const int H = K > 2 ? K - 1 : 1;
+    const int NW = mgp_sparse_words(N);
+    if (cur < 0 || cur >= K || hs < 0 || hs >= H) return MGP_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long sB = (long)H * N * NW, sW = (long)H * N, sF = (long)K * N * 8, sV = (long)N * 8;
+    auto fslot = [&](int j) { int s = cur - j; if (s < 0) s += K; return feat + (size_t)s * N * 8; };
+    auto hslot = [&](int q) { int s = hs - (q - 1); if (s < 0) s += H; return s; };
+    // running products of taps j >= 1 between stages: V[pp][j-1], each (B, N, 8)
+    auto vbuf = [&](int pp, int j) { return scratch + ((size_t)pp * (K - 1) + (j - 1)) * (size_t)B * N * 8; };
+    const int ntiles = mgp_ceil_div(N, SP_COLS);
+    mgp_clear_error();
+    SpPolicy P = {};
+    P.tap[0] = fslot(0); P.ts[0] = sF;
+    for (int q = 1; q <= K - 2; ++q) {                         // stage q: taps q .. K-1 times A_{t-q+1}
+        SpTaps T = {};
+        int nt = 0;
+        for (int j = q; j <= K - 1; ++j, ++nt) {
+            if (q == 1) { T.src[nt] = fslot(j); T.ss[nt] = sF; }
+            else { T.src[nt] = vbuf((q - 1) & 1, j); T.ss[nt] = sV; }
+            T.dst[nt] = vbuf(q & 1, j); T.ds[nt] = sV;         // tap q's product is finished here: the tail reads it from there
+        }
+        const int s = hslot(q);
+        hipLaunchKernelGGL(sp_gather_kernel, dim3(ntiles, nt, B), dim3(SP_THREADS), 0, st, bits + (size_t)s * N * NW, sB,
+                           wrow + (size_t)s * N, sW, T, N, NW);
+        rc = mgp_launch_status();
+        if (rc != MGP_OK) return rc;
+        P.tap[q] = vbuf(q & 1, q); P.ts[q] = sV;
+    }
+    // NOTE on buffer reuse: stage q writes V[q & 1][j] for every j >= q and reads V[(q-1) & 1][j]; a finished tap q sits in
+    // V[q & 1][q], which later stages q' > q never write (they only touch taps j >= q').
+    if (K >= 2) {
+        if (K == 2) { P.tap[1] = fslot(1); P.ts[1] = sF; }
+        else { P.tap[K - 1] = vbuf((K - 2) & 1, K - 1); P.ts[K - 1] = sV; }
+        const int s = hslot(K - 1);
+        P.bits = bits + (size_t)s * N * NW; P.sBb = sB;
+        P.wq = wrow + (size_t)s * N; P.sWb = sW;
+    }
+    P.image = image; P.wtot = wtot;
+    unsigned long long dimsA = 0ull, woffA = 0ull, woffB = 0ull;
+    unsigned int dims8 = 0u;
+    for (int l = 0; l <= n_layers; ++l) {
+        if (l < 8) dimsA |= (unsigned long long)(dims[l] & 255) << (8 * l);
+        else dims8 = (unsigned int)dims[l];
+    }
+    for (int l = 0; l < n_layers; ++l) {
+        if (woff[l] > 0xFFFF) return MGP_EUNSUPPORTED;
+        if (l < 4) woffA |= (unsigned long long)woff[l] << (16 * l);
+        else woffB |= (unsigned long long)woff[l] << (16 * (l - 4));
+    }
+    const size_t lds = ((size_t)SP_COLS * RO_CS + wtot) * sizeof(float);
+    hipLaunchKernelGGL(sp_policy_kernel, dim3(ntiles, B), dim3(SP_THREADS), lds, st, P, action, K, N, NW, dimsA, dims8,
+                       woffA, woffB, n_layers);
+    return mgp_launch_status();
+}
+
+/* Dense delayed operator of the reference contract from the factored state: G (B,K,N,N) slices 1..K-1 (slice 0, the
+ * identity, is left alone).  hs = ring slot of the newest network. */
+extern "C" int mgp_sparse_to_dense(const unsigned long long* bits, const float* wrow, float* G, int B, int K, int N, int hs,
+                                   void* stream)
+{
+    if (B <= 0 || N <= 0 || K < 1 || K > SP_MAXTAPS + 1 || N > 4096 || B > 65535) return MGP_EINVAL;
+    if (K == 1) return MGP_OK;
+    MGP_CHECK_PTR8(bits); MGP_CHECK_PTR(wrow); MGP_CHECK_PTR(G);
+    const int H = K > 2 ? K - 1 : 1;
+    if (hs < 0 || hs >= H) return MGP_EINVAL;
+    const int NW = mgp_sparse_words(N);
+    const size_t lds = (size_t)4 * 2 * ((N + 3) & ~3) * sizeof(float);
+    mgp_clear_error();
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(sp_to_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return MGP_ELAUNCH;
+    hipLaunchKernelGGL(sp_to_dense_kernel, dim3(mgp_ceil_div(N, 4), B), dim3(SP_THREADS), lds, static_cast<hipStream_t>(stream),
+                       bits, wrow, G, K, H, N, NW, hs);
+    return mgp_launch_status();
+}

@@ -63,8 +63,9 @@ def policy_rollout(actor, sim, state, T, rewards=None, action=None, resident=Tru
 
     When the shape is covered, the whole call is ONE launch of the episode-resident kernel (mgp_rollout_steps: state in
     LDS for all T steps); otherwise -- or with resident=False -- each step is the two-launch path (fused Actor forward +
-    fused simulator/state kernel).  Either way sim.x, state.delay_gso, state.delay_state hold the state T steps later.
-    Returns True if the resident kernel ran."""
+    fused simulator/state kernel).  Flocks beyond that kernel (N > 256) run on the factored state in HBM when the call
+    starts at a reset observation or continues such a rollout (sparse_rollout.py).  Either way sim.x, state.delay_gso,
+    state.delay_state hold the state T steps later.  Returns True unless the two-launch path ran."""
     import torch
     from .. import ops
     assert state.has_prev, "push the reset observation into the delay state first"
@@ -80,7 +81,27 @@ def policy_rollout(actor, sim, state, T, rewards=None, action=None, resident=Tru
             sim.features = state.delay_state[:, 0]
             if rewards is not None:
                 sim.reward.copy_(rewards[:, T - 1])
+            state._pushes += T
             return True
+    if (resident and sim.N > 256 and actor.ind_agg == 0 and state.F == 6 and sim.network64 is None
+            and sim.features64 is None):
+        # beyond the LDS-resident kernel: the factored state in HBM (sparse_rollout.py), K launches per step.  It can be
+        # started at a reset observation or carried over from the previous call; the dense state is refreshed at the end.
+        from .sparse_rollout import SparseFlockState, sparse_policy_rollout, sparse_supported
+        if sparse_supported(actor, state.K, sim.N):
+            sp = getattr(state, '_sparse', None)
+            if not (sp is not None and sp.owner is sim.x and sp.K == state.K and sp.at_push == state._pushes):
+                sp = None
+                if state._pushes == 1:
+                    sp = SparseFlockState(sim, state.K)
+                    sp.observe_reset(sim)
+            if sp is not None:
+                sparse_policy_rollout(actor, sim, sp, T, rewards=rewards, action=action)
+                sp.to_dense(sim, state)
+                state._pushes += T
+                sp.at_push = state._pushes
+                state._sparse = sp
+                return True
     with torch.no_grad():
         for t in range(T):
             out = actor(state.delay_state, state.delay_gso)

@@ -1,0 +1,115 @@
+"""Closed-loop policy rollouts on the factored episode state, for flocks beyond the LDS-resident kernel (N > 256).
+
+Same loop as `policy_rollout` (reference test_model.py:38-44) and the same mathematics as `mgp_rollout_steps`: tap j of the
+Actor's aggregation is x_{t-j} A_t A_{t-1} ... A_{t-j+1} (state_with_delay.py:44-47, actor.py:64-71), evaluated left to right
+along the networks' membership bit rows.  The state is three ring buffers in HBM -- bit rows and row weights of the last
+K - 1 networks, the last K feature blocks as (N, 8) rows -- and one environment step is K kernel launches (K - 2 gather
+stages, the policy tail, the simulator).  The dense `delay_gso (B,K,N,N)` of the reference contract is produced on demand
+(`SparseFlockState.to_dense`), not every step: at N = 1000 it is 12 MB per episode.
+
+A factored state can only be started where the history is known: at a reset (no history: missing networks are zero
+rows with zero weights, missing features zeros, which makes the products vanish exactly as the reference's zero-filled
+state does, state_with_delay.py:47-53) or carried over from the previous sparse rollout of the same simulator.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib, ops
+from .actor_fused import _ptr_array
+
+
+class SparseFlockState(object):
+    """Bit rows / row weights / features of B episodes of `sim` (VecFlock), ring-indexed over time."""
+
+    def __init__(self, sim, K):
+        self.B, self.N, self.K = sim.B, sim.N, K
+        self.H = K - 1 if K > 2 else 1
+        self.NW = _lib.lib().mgp_sparse_words(self.N)
+        dev = sim.device
+        self.bits = torch.zeros((self.B, self.H, self.N, self.NW), device=dev, dtype=torch.int64)
+        self.wrow = torch.zeros((self.B, self.H, self.N), device=dev, dtype=torch.float32)
+        self.feat = torch.zeros((self.B, K, self.N, 8), device=dev, dtype=torch.float32)
+        self.scratch = torch.zeros((max(1, 2 * (K - 1) * self.B * self.N * 8),), device=dev, dtype=torch.float32)
+        self.cur = 0            # ring slot of x_t in feat
+        self.hs = 0             # ring slot of A_t in bits / wrow
+        self.steps = 0          # simulator steps since the reset this state was started at
+        self.owner = None       # the tensor sim.x pointed at when this state was last advanced (continuity check)
+
+    def _sim_call(self, sim, x_in, x_out, u, h, c, reward, expert):
+        L = _lib.lib()
+        su_agent, su_axis = (1, self.N) if u is not None else (2, 1)          # the Actor's output layout (B,1,2,N)
+        rc = L.mgp_flock_step_sparse(
+            ops._ptr(x_in), ops._ptr(x_out), ops._ptr(u), su_agent, su_axis,
+            self.bits.data_ptr() + h * self.N * self.NW * 8, self.H * self.N * self.NW,
+            self.wrow.data_ptr() + h * self.N * 4, self.H * self.N,
+            self.feat.data_ptr() + c * self.N * 8 * 4, self.K * self.N * 8,
+            ops._ptr(reward), ops._ptr(expert), ctypes.byref(sim._c), self.B, self.N, ops._stream())
+        _lib.check(rc, 'mgp_flock_step_sparse')
+
+    def observe_reset(self, sim):
+        """Start at the simulator's current x as a freshly reset episode (no history)."""
+        self.bits.zero_(); self.wrow.zero_(); self.feat.zero_()
+        self.cur = self.hs = self.steps = 0
+        self._sim_call(sim, sim.x, sim._x_next, None, 0, 0, None, None)
+        self.owner = sim.x
+
+    def step(self, sim, action):
+        """Simulator step with the policy output `action` (B,1,2,N); the new network / features enter the rings."""
+        nh = (self.hs + 1) % self.H
+        nc = (self.cur + 1) % self.K
+        self._sim_call(sim, sim.x, sim._x_next, action, nh, nc, sim.reward, sim.expert if sim.with_expert else None)
+        sim.x, sim._x_next = sim._x_next, sim.x
+        self.hs, self.cur = nh, nc
+        self.steps += 1
+        self.owner = sim.x
+
+    def to_dense(self, sim, state):
+        """Materialise the reference's dense state into `state` (BatchedDelayState): delay_gso slices 1..K-1 from the bit
+        rows, delay_state from the feature ring, and point the simulator's observation views at them."""
+        G, X = state.delay_gso, state.delay_state
+        rc = _lib.lib().mgp_sparse_to_dense(self.bits.data_ptr(), ops._ptr(self.wrow), ops._ptr(G), self.B, self.K, self.N,
+                                            self.hs, ops._stream())
+        _lib.check(rc, 'mgp_sparse_to_dense')
+        for k in range(self.K):
+            X[:, k].copy_(self.feat[:, (self.cur - k) % self.K, :, :6].transpose(1, 2))
+        state._has_prev = True
+        if self.K > 1:
+            sim.network = G[:, 1]
+        sim.features = X[:, 0]
+
+
+def sparse_supported(actor, K, N):
+    dims = tuple(actor.layers)
+    cd = (ctypes.c_int * len(dims))(*dims)
+    return actor.ind_agg == 0 and bool(_lib.lib().mgp_sparse_policy_supported(cd, len(dims) - 1, K, N))
+
+
+def sparse_policy_rollout(actor, sim, sp, T, rewards=None, action=None):
+    """T closed-loop policy steps on the factored state `sp` (SparseFlockState of `sim`).  rewards (B,T) fp64 and
+    action (B,1,2,N) as in `policy_rollout`.  K launches per step, nothing else on the device."""
+    L = _lib.lib()
+    K, B, N = sp.K, sp.B, sp.N
+    dims = tuple(actor.layers)
+    cd = (ctypes.c_int * len(dims))(*dims)
+    nl = len(dims) - 1
+    Ws = [c.weight.detach().reshape(c.weight.shape[0], -1).contiguous() for c in actor.conv_layers]
+    bs = [c.bias.detach().contiguous() for c in actor.conv_layers]
+    image = torch.empty((L.mgp_sparse_policy_image_floats(cd, nl, K),), device=sim.device, dtype=torch.float32)
+    _lib.check(L.mgp_sparse_policy_image(_ptr_array(Ws), _ptr_array(bs), cd, nl, K, ops._ptr(image), ops._stream()),
+               'mgp_sparse_policy_image')
+    act = action if action is not None else torch.empty((B, 1, 2, N), device=sim.device, dtype=torch.float32)
+    rw = torch.empty((T, B), device=sim.device, dtype=torch.float64) if rewards is not None else None
+    keep = sim.reward
+    for t in range(T):
+        _lib.check(L.mgp_sparse_policy_step(sp.bits.data_ptr(), ops._ptr(sp.wrow), ops._ptr(sp.feat), ops._ptr(image), cd, nl,
+                                            ops._ptr(sp.scratch), ops._ptr(act), B, K, N, sp.cur, sp.hs, ops._stream()),
+                   'mgp_sparse_policy_step')
+        if rw is not None:
+            sim.reward = rw[t]                 # the simulator writes this step's rewards straight into row t
+        sp.step(sim, act)
+    sim.reward = keep
+    if rw is not None:
+        rewards.copy_(rw.t())
+        keep.copy_(rw[T - 1])
+    return True

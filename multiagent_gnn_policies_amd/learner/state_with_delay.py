@@ -86,9 +86,11 @@ class BatchedDelayState(object):
         self._scratch_A = torch.zeros((B, N, N), **kw) if K == 1 else None
         self._cur = 0
         self._has_prev = False
+        self._pushes = 0                          # states pushed since the last reset (1 = the reset observation only)
 
     def reset(self):
         self._has_prev = False
+        self._pushes = 0
 
     def push(self, A, X_t):
         """A (B,N,N) fp32, X_t (B,F,N) fp32 (both contiguous, on device)."""
@@ -97,6 +99,7 @@ class BatchedDelayState(object):
                             has_prev=self._has_prev)
         self._cur = nxt
         self._has_prev = True
+        self._pushes += 1
 
     # ---- in-place protocol: the simulator writes A_t / X_t straight into the next buffers ---------------
     def next_slots(self):
@@ -119,12 +122,14 @@ class BatchedDelayState(object):
     def flip(self):
         self._cur = 1 - self._cur
         self._has_prev = True
+        self._pushes += 1
 
     def advance(self):
         nxt = 1 - self._cur
         ops.gso_advance(self._G[self._cur], self._G[nxt], self._X[self._cur], self._X[nxt], has_prev=self._has_prev)
         self._cur = nxt
         self._has_prev = True
+        self._pushes += 1
 
     @property
     def delay_gso(self):

@@ -1,0 +1,101 @@
+"""GPU: the factored-state path for flocks beyond the LDS-resident kernel (N > 256): mgp_flock_step_sparse,
+mgp_sparse_policy_step, mgp_sparse_to_dense against the oracle and against the dense two-launch path."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import actor as oa, flock as ofl, state as os_
+from test_gpu_rollout import _make, _snapshot, _weights_np, relerr
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # N, K, hidden, variant
+    (300, 3, (32, 32), {}),
+    (300, 4, (32,), {'mean_pooling': False, 'n_leaders': 2}),
+    (257, 2, (16, 16), {'comm_radius': 1.5}),
+    (513, 3, (32,), {'link_drop': 0.3, 'link_seed': 4}),
+    (300, 1, (32, 32), {}),
+    (320, 5, (16,), {}),
+    (1000, 3, (32, 32), {}),
+]
+
+
+def _bits_to_dense(bits, wrow, N):
+    """(N, NW) int64 rows + (N,) weights -> dense (N, N) fp32 network matrix."""
+    b = bits.astype(np.uint64)
+    cols = np.arange(N)
+    pat = ((b[:, cols >> 6] >> (cols & 63).astype(np.uint64)) & np.uint64(1)).astype(np.float32)
+    return pat * wrow[:, None].astype(np.float32)
+
+
+@pytest.mark.parametrize('N,K,hidden,variant', CASES)
+def test_sparse_rollout_matches_oracle_step_by_step(N, K, hidden, variant):
+    """From a reset: every step's action against the oracle forward on the oracle's own dense state, the simulator outputs
+    (bit rows, weights, features, state) against the oracle transition, and the dense state rebuilt by to_dense."""
+    from multiagent_gnn_policies_amd.learner.sparse_rollout import SparseFlockState, sparse_policy_rollout, sparse_supported
+    B = 2
+    rs, op, actor, sim, st = _make(N, K, hidden, B, seed=N + K, **variant)
+    assert sparse_supported(actor, K, N)
+    Ws, bs = _weights_np(actor)
+    x0, G, X = _snapshot(sim, st)                                        # oracle-side dense state, advanced by the oracle below
+    G = G.astype(np.float64); X = X.astype(np.float64)
+    sp = SparseFlockState(sim, K)
+    sp.observe_reset(sim)
+    xs = x0.copy()
+    action = torch.zeros((B, 1, 2, N), device='cuda')
+    rewards = torch.zeros((B, 1), device='cuda', dtype=torch.float64)
+    for step in range(K + 2):
+        # the factored state of the current step vs the oracle's network / features
+        for b in range(B):
+            h = ofl.helpers(xs[b], op)
+            got = _bits_to_dense(sp.bits[b, sp.hs].cpu().numpy(), sp.wrow[b, sp.hs].cpu().numpy(), N)
+            assert np.array_equal(got, h['network'].astype(np.float32)), "network bits / weights must be exact"
+            assert relerr(sp.feat[b, sp.cur, :, :6].cpu().numpy(), h['values'].astype(np.float32)) <= 1e-6
+        ref = oa.forward(X.astype(np.float32), G.astype(np.float32), Ws, bs, 0, dtype=np.float64)
+        noise = relerr(oa.forward(X.astype(np.float32), G.astype(np.float32), Ws, bs, 0, dtype=np.float32), ref)
+        sparse_policy_rollout(actor, sim, sp, 1, rewards=rewards, action=action)
+        u = action.cpu().numpy()
+        assert relerr(u, ref) <= 1e-5 + 10.0 * noise, (step, relerr(u, ref), noise)
+        for b in range(B):
+            x2, vals, net, r = ofl.step(xs[b], u[b, 0].T.astype(np.float32), op)
+            assert np.array_equal(sim.x[b].cpu().numpy(), x2), "integration must be bit-exact fp64 given the action"
+            assert abs(rewards[b, 0].item() - r) <= 1e-12 * max(1.0, abs(r))
+            xs[b] = x2
+            Gn, Xn = os_.gso_update(net[None], G[b:b + 1].astype(np.float32), vals.T[None].astype(np.float32),
+                                    X[b:b + 1].astype(np.float32), K, dtype=np.float64)
+            G[b], X[b] = Gn[0], Xn[0]
+    sp.to_dense(sim, st)
+    x1, G1, X1 = _snapshot(sim, st)
+    assert relerr(G1, G) <= 1e-6 and relerr(X1, X) <= 1e-6
+    assert np.array_equal(G1[:, 0], np.broadcast_to(np.eye(N, dtype=np.float32), (B, N, N)))
+
+
+@pytest.mark.parametrize('N,K', [(300, 3), (400, 4), (260, 2)])
+def test_policy_rollout_takes_the_sparse_path_and_chunks_exactly(N, K):
+    """policy_rollout from a reset observation: the factored path runs (True), agrees with the dense two-launch path over
+    a few steps, and -- the factored state being carried between calls -- chunked calls are bit-identical."""
+    from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
+    B, T = 2, 6
+    outs = []
+    for mode in ('sparse', 'sparse_chunked', 'dense'):
+        rs, op, actor, sim, st = _make(N, K, (32, 32), B, seed=5)
+        rewards = torch.zeros((B, T), device='cuda', dtype=torch.float64)
+        action = torch.zeros((B, 1, 2, N), device='cuda')
+        if mode == 'sparse_chunked':
+            r1 = torch.zeros((B, 2), device='cuda', dtype=torch.float64); r2 = torch.zeros((B, 4), device='cuda', dtype=torch.float64)
+            assert policy_rollout(actor, sim, st, 2, rewards=r1, action=action)
+            assert policy_rollout(actor, sim, st, 4, rewards=r2, action=action)
+            rewards[:, :2] = r1; rewards[:, 2:] = r2
+        else:
+            ran = policy_rollout(actor, sim, st, T, rewards=rewards, action=action, resident=(mode == 'sparse'))
+            assert ran == (mode == 'sparse')
+        outs.append(_snapshot(sim, st) + (action.cpu().numpy().copy(), rewards.cpu().numpy().copy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)                                       # carried factored state: exact chunking
+    for name, a, b, tol in zip(('x', 'G', 'X', 'u', 'r'), outs[0], outs[2], (1e-5, 1e-3, 1e-3, 1e-3, 1e-5)):
+        assert relerr(a, b) <= tol, (name, relerr(a, b))
+    # mid-episode without a carried factored state: the dense path takes over
+    rs, op, actor, sim, st = _make(N, K, (32, 32), B, seed=5)
+    assert policy_rollout(actor, sim, st, 2, resident=False) is False
+    assert policy_rollout(actor, sim, st, 2) is False
