@@ -286,6 +286,11 @@ int  mgp_sparse_words(int N);
 int  mgp_flock_step_sparse(const double* x, double* x_out, const float* u, long su_agent, long su_axis,
                            unsigned long long* bits, long sBb, float* wrow, long sWb, float* featT, long sTb,
                            double* reward, float* expert, const MgpFlockParams* p, int B, int N, void* stream);
+/* Same step, same outputs, with a cell list instead of the all-pairs sweep (cells no smaller than the radius, the spec's
+ * fp64 membership test on every candidate: identical bit rows; N <= 2048, else MGP_EUNSUPPORTED). */
+int  mgp_flock_step_cells(const double* x, double* x_out, const float* u, long su_agent, long su_axis,
+                          unsigned long long* bits, long sBb, float* wrow, long sWb, float* featT, long sTb,
+                          double* reward, float* expert, const MgpFlockParams* p, int B, int N, void* stream);
 int  mgp_sparse_policy_supported(const int* dims, int n_layers, int K, int N);
 long mgp_sparse_policy_image_floats(const int* dims, int n_layers, int K);
 int  mgp_sparse_policy_image(const float* const* W, const float* const* b, const int* dims, int n_layers, int K,

@@ -66,6 +66,8 @@ SIGNATURES = {
     'mgp_sparse_words': (_int, [_int]),
     'mgp_flock_step_sparse': (_int, [_vp, _vp, _vp, _long, _long, _vp, _long, _vp, _long, _vp, _long, _vp, _vp, _vp,
                                      _int, _int, _vp]),
+    'mgp_flock_step_cells': (_int, [_vp, _vp, _vp, _long, _long, _vp, _long, _vp, _long, _vp, _long, _vp, _vp, _vp,
+                                    _int, _int, _vp]),
     'mgp_sparse_policy_supported': (_int, [_vp, _int, _int, _int]),
     'mgp_sparse_policy_image_floats': (_long, [_vp, _int, _int]),
     'mgp_sparse_policy_image': (_int, [_vp, _vp, _vp, _int, _int, _vp, _vp]),

@@ -35,17 +35,21 @@ class SparseFlockState(object):
         self.hs = 0             # ring slot of A_t in bits / wrow
         self.steps = 0          # simulator steps since the reset this state was started at
         self.owner = None       # the tensor sim.x pointed at when this state was last advanced (continuity check)
+        self.use_cells = True
 
     def _sim_call(self, sim, x_in, x_out, u, h, c, reward, expert):
         L = _lib.lib()
         su_agent, su_axis = (1, self.N) if u is not None else (2, 1)          # the Actor's output layout (B,1,2,N)
-        rc = L.mgp_flock_step_sparse(
+        # cell-list simulator up to N = 2048 (identical bit rows), the all-pairs kernel beyond
+        fn, name = (L.mgp_flock_step_cells, 'mgp_flock_step_cells') if self.N <= 2048 and self.use_cells else \
+                   (L.mgp_flock_step_sparse, 'mgp_flock_step_sparse')
+        rc = fn(
             ops._ptr(x_in), ops._ptr(x_out), ops._ptr(u), su_agent, su_axis,
             self.bits.data_ptr() + h * self.N * self.NW * 8, self.H * self.N * self.NW,
             self.wrow.data_ptr() + h * self.N * 4, self.H * self.N,
             self.feat.data_ptr() + c * self.N * 8 * 4, self.K * self.N * 8,
             ops._ptr(reward), ops._ptr(expert), ctypes.byref(sim._c), self.B, self.N, ops._stream())
-        _lib.check(rc, 'mgp_flock_step_sparse')
+        _lib.check(rc, name)
 
     def observe_reset(self, sim):
         """Start at the simulator's current x as a freshly reset episode (no history)."""

@@ -99,3 +99,39 @@ def test_policy_rollout_takes_the_sparse_path_and_chunks_exactly(N, K):
     rs, op, actor, sim, st = _make(N, K, (32, 32), B, seed=5)
     assert policy_rollout(actor, sim, st, 2, resident=False) is False
     assert policy_rollout(actor, sim, st, 2) is False
+
+
+@pytest.mark.parametrize('N,spread,variant', [(1000, 1.0, {}), (300, 0.02, {}), (2048, 1.0, {'mean_pooling': False}),
+                                              (777, 4.0, {'link_drop': 0.2, 'link_seed': 3}), (260, 1.0, {'n_leaders': 3})])
+def test_cell_list_simulator_equals_the_all_pairs_kernel(N, spread, variant):
+    """mgp_flock_step_cells vs mgp_flock_step_sparse on the same states: identical bit rows, weights and integration;
+    feature sums differ only in the order of their fp64 terms.  spread 0.02 collapses the flock into one cell, 4.0
+    stretches it along x beyond the 64-cell limit."""
+    from multiagent_gnn_policies_amd.envs import FlockParams, VecFlock
+    from multiagent_gnn_policies_amd.learner.sparse_rollout import SparseFlockState
+    B = 2
+    rs = np.random.RandomState(N)
+    op = ofl.FlockParams(n_agents=N, init_mode='grid', **variant)
+    p = FlockParams(**{f: getattr(op, f) for f in FlockParams.__dataclass_fields__})
+    xs = np.stack([ofl.sample_candidate_grid(rs, op) for _ in range(B)])
+    if spread > 1.0:
+        xs[:, :, 0] *= spread                 # stretched along x only: beyond 64 cells of width R, neighbours along y remain
+    else:
+        xs[:, :, :2] *= spread
+    res = []
+    for cells in (True, False):
+        sim = VecFlock(B, p, 'cuda', with_expert=True)
+        sim.x.copy_(torch.from_numpy(xs))
+        sp = SparseFlockState(sim, 3)
+        sp.use_cells = cells
+        sp.observe_reset(sim)
+        u = torch.from_numpy(np.random.RandomState(1).uniform(-1.2, 1.2, size=(B, 1, 2, N)).astype(np.float32)).cuda()
+        sp.step(sim, u)
+        sp.step(sim, u)
+        res.append((sim.x.cpu().numpy().copy(), sp.bits.cpu().numpy().copy(), sp.wrow.cpu().numpy().copy(),
+                    sp.feat.cpu().numpy().copy(), sim.reward.cpu().numpy().copy(), sim.expert.cpu().numpy().copy()))
+    a, b = res
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert relerr(a[3], b[3]) <= 1e-6 and relerr(a[5], b[5]) <= 1e-6
+    assert np.max(np.abs(a[4] - b[4]) / np.maximum(1.0, np.abs(b[4]))) <= 1e-12
+    assert a[1].any()
