@@ -145,6 +145,27 @@ def test_bench_two_ranks_contract():
     assert 'cpu_baseline' not in d and 'roofline' in d
 
 
+@pytest.mark.parametrize('n,k,paths', [(100, 3, {'two_launch', 'resident'}), (200, 4, {'two_launch', 'resident'}),
+                                       (300, 3, {'two_launch', 'factored'})])
+def test_bench_single_gpu_contract_and_paths(n, k, paths):
+    """python bench.py: one JSON line with the contract's keys; the step implementations timed for the shape."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '30', '--warmup', '5', '--episodes', '16',
+                        '--agents', str(n), '--taps', str(k), '--no-cpu-baseline'], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    js = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(js) == 1
+    d = json.loads(js[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+        assert key in d, key
+    assert set(d['paths']) == paths and d['config']['state_finite']
+    assert d['value'] == max(v['value'] for v in d['paths'].values())
+    assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(d['roofline'])
+
+
 def test_device_replay_ring_and_sampling():
     from multiagent_gnn_policies_amd.learner.vec_dagger import DeviceReplay
     import random
