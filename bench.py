@@ -10,7 +10,7 @@ all state resident on the GPU, no host round trip.  Up to three implementations 
   resident    mgp_rollout_steps: ALL timed steps in one launch of the episode-resident kernel (one workgroup per
               episode; delay line / agent states / neighbour lists of the last K-1 networks / weights in LDS, the
               aggregation power-iterated along those lists; HBM sees the state on entry and exit).  This is `value`
-              when the shape is covered (N <= 256, widths and 6K <= 32).
+              when the shape is covered (N <= 256, widths <= 64).
   factored    N > 256 only: the same factored state kept in HBM as bit rows / feature rings, K launches per step
               (mgp_sparse_policy_step + mgp_flock_step_sparse); dense state rebuilt at the end of each call.
   two_launch  mgp_actor_fwd + mgp_flock_step_advance per step (dense operator streamed from HBM every step),

@@ -217,7 +217,8 @@ int mgp_flock_step_advance(double* x, double* x_out, const float* u, long su_age
  * membership given the action); the aggregation associates differently from mgp_actor_fwd (same 1e-5 parity bound
  * against the reference forward).  Consequently chunking (T1 then T2 steps vs T1 + T2) agrees to fp32 rounding, not bit
  * for bit -- a launch boundary passes through the rounded dense slices -- and a closed loop amplifies that over steps.
- * Coverage (mgp_rollout_supported): dims[0] = 6, dims[n_layers] = 2, layer widths and 6 K <= 32, K <= 5, 4 <= N <= 256
+ * Coverage (mgp_rollout_supported): dims[0] = 6, dims[n_layers] = 2, layer widths <= 64 (<= 32: a build with half the
+ * activation tile), K <= 5, 4 <= N <= 256
  * (N > 128: a variant that keeps the K-1 networks as bit rows; its LDS plan must fit 160 KB: N = 200 with any K, N = 256 up to K = 4).  Anything else: MGP_EUNSUPPORTED -- use the two calls above. */
 int mgp_rollout_supported(const int* dims, int n_layers, int K, int N);
 int mgp_rollout_steps(double* x, float* G, float* Xd, const float* const* W, const float* const* b,

@@ -307,7 +307,8 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 const int cout = ro_dim(dimsA, dims8, l + 1);
                 const int MT = mtiles(cout);
                 const float* wfrag = wl + (int)((((l < 4) ? woffA : woffB) >> (16 * (l & 3))) & 0xFFFFull);
-                if (MT == 2) ro_mlp_cols<2>(pcol, wfrag + lane * RO_WFS, wfrag + 2 * 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
+                if (MT == 4) ro_mlp_cols<4>(pcol, wfrag + lane * RO_WFS, wfrag + 4 * 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
+                else if (MT == 2) ro_mlp_cols<2>(pcol, wfrag + lane * RO_WFS, wfrag + 2 * 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
                 else ro_mlp_cols<1>(pcol, wfrag + lane * RO_WFS, wfrag + 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
                 RO_STAMP(12 + l);
             }
@@ -322,9 +323,12 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             const float* w2 = wl + (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull);
             const int ccol = wave * 16 + (lane >> 2), cg = lane & 3;
             const float* zsrc = act + ccol * RO_CS + cg * RO_KS;
-            const float4 z0 = *reinterpret_cast<const float4*>(zsrc);
-            const float4 z1 = *reinterpret_cast<const float4*>(zsrc + 4);
-            const float zc[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+            float zc[RO_KS];
+#pragma unroll
+            for (int i = 0; i < RO_KS / 4; ++i) {
+                const float4 zq = *reinterpret_cast<const float4*>(zsrc + 4 * i);
+                zc[4 * i] = zq.x; zc[4 * i + 1] = zq.y; zc[4 * i + 2] = zq.z; zc[4 * i + 3] = zq.w;
+            }
             double px = 0.0, py = 0.0, vx = 0.0, vy = 0.0, cx = 0.0, cy = 0.0;
             const bool agent = (cg == 0) && ccol < N;
             if (agent) { px = spx[ccol]; py = spy[ccol]; vx = svx[ccol]; vy = svy[ccol]; cx = cref[0]; cy = cref[1]; }
@@ -768,7 +772,8 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
                 const int cout = ro_dim(dimsA, dims8, l + 1);
                 const int MT = mtiles(cout);
                 const float* wfrag = wl + (int)((((l < 4) ? woffA : woffB) >> (16 * (l & 3))) & 0xFFFFull);
-                if (MT == 2) ro_mlp_cols<2>(pcol, wfrag + lane * RO_WFS, wfrag + 2 * 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
+                if (MT == 4) ro_mlp_cols<4>(pcol, wfrag + lane * RO_WFS, wfrag + 4 * 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
+                else if (MT == 2) ro_mlp_cols<2>(pcol, wfrag + lane * RO_WFS, wfrag + 2 * 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
                 else ro_mlp_cols<1>(pcol, wfrag + lane * RO_WFS, wfrag + 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
                 RO_STAMP(12 + l);
             }
@@ -783,9 +788,12 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
             const float* w2 = wl + (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull);
             const int ccol = wave * 16 + (lane >> 2), cg = lane & 3;
             const float* zsrc = act + ccol * RO_CS + cg * RO_KS;
-            const float4 z0 = *reinterpret_cast<const float4*>(zsrc);
-            const float4 z1 = *reinterpret_cast<const float4*>(zsrc + 4);
-            const float zc[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+            float zc[RO_KS];
+#pragma unroll
+            for (int i = 0; i < RO_KS / 4; ++i) {
+                const float4 zq = *reinterpret_cast<const float4*>(zsrc + 4 * i);
+                zc[4 * i] = zq.x; zc[4 * i + 1] = zq.y; zc[4 * i + 2] = zq.z; zc[4 * i + 3] = zq.w;
+            }
             double px = 0.0, py = 0.0, vx = 0.0, vy = 0.0, cx = 0.0, cy = 0.0;
             const bool agent = (cg == 0) && ccol < N;
             if (agent) { px = spx[ccol]; py = spy[ccol]; vx = svx[ccol]; vy = svy[ccol]; cx = cref[0]; cy = cref[1]; }
@@ -1002,7 +1010,7 @@ bool make_carve(const int* dims, int n_layers, int K, int N, RoParams* P, int* l
     int wtot = 0;
     for (int l = 0; l < n_layers; ++l) {
         const int cin = (l == 0) ? 6 * K : dims[l], cout = dims[l + 1];
-        if (cin < 1 || cout < 1 || cin > 4 * RO_KS || cout > 4 * RO_KS) return false;   // <= 8 k-steps, MT <= 2
+        if (cin < 1 || cout < 1 || cin > 4 * RO_KS || cout > 4 * RO_KS) return false;   // <= RO_KS k-steps
         if (P) { P->woff[l] = wtot; P->dims[l] = dims[l]; }
         wtot += mtiles(cout) * 64 * RO_WFS + mtiles(cout) * 16;
     }
@@ -1041,20 +1049,46 @@ int launch_rollout_big(double* x, float* G, float* Xd, float* action, double* re
 
 }  // namespace
 
-extern "C" int mgp_rollout_supported(const int* dims, int n_layers, int K, int N)
+// This file is compiled twice: as is (layer widths <= 32, MGP_RO_KS = 8: half the activation tile and weight image), and
+// through rollout_wide.hip with MGP_RO_KS = 16 for widths up to 64 (cfg/hidden_size.cfg).  The narrow build owns the
+// public entry points and forwards the shapes only the wide build covers.
+#ifdef MGP_RO_WIDE
+#define MGP_RO_SUPPORTED mgp_rollout_wide_supported_
+#define MGP_RO_STEPS mgp_rollout_wide_steps_
+#else
+#define MGP_RO_SUPPORTED mgp_rollout_supported
+#define MGP_RO_STEPS mgp_rollout_steps
+extern "C" int mgp_rollout_wide_supported_(const int* dims, int n_layers, int K, int N);
+extern "C" int mgp_rollout_wide_steps_(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
+                                       const int* dims, int n_layers, float* action, double* rewards,
+                                       const MgpFlockParams* p, int B, int K, int N, int T, void* stream);
+#endif
+
+extern "C" int MGP_RO_SUPPORTED(const int* dims, int n_layers, int K, int N)
 {
-    return make_carve(dims, n_layers, K, N, nullptr, nullptr) ? 1 : 0;
+    if (make_carve(dims, n_layers, K, N, nullptr, nullptr)) return 1;
+#ifndef MGP_RO_WIDE
+    return mgp_rollout_wide_supported_(dims, n_layers, K, N);
+#else
+    return 0;
+#endif
 }
 
-extern "C" int mgp_rollout_steps(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
-                                 const int* dims, int n_layers, float* action, double* rewards,
-                                 const MgpFlockParams* p, int B, int K, int N, int T, void* stream)
+extern "C" int MGP_RO_STEPS(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
+                            const int* dims, int n_layers, float* action, double* rewards,
+                            const MgpFlockParams* p, int B, int K, int N, int T, void* stream)
 {
     if (B < 0 || T < 0 || p == nullptr || W == nullptr || b == nullptr) return MGP_EINVAL;
     if (!(p->comm_radius2 > 0.0) || !(p->dt > 0.0) || p->n_leaders < 0) return MGP_EINVAL;
     RoParams P;
     int lds = 0;
-    if (!make_carve(dims, n_layers, K, N, &P, &lds)) return MGP_EUNSUPPORTED;
+    if (!make_carve(dims, n_layers, K, N, &P, &lds)) {
+#ifndef MGP_RO_WIDE
+        return mgp_rollout_wide_steps_(x, G, Xd, W, b, dims, n_layers, action, rewards, p, B, K, N, T, stream);
+#else
+        return MGP_EUNSUPPORTED;
+#endif
+    }
     if (B == 0 || T == 0) return MGP_OK;
     MGP_CHECK_PTR8(x);
     MGP_CHECK_PTR(G);
@@ -1083,10 +1117,12 @@ extern "C" int mgp_rollout_steps(double* x, float* G, float* Xd, const float* co
     if (N > RO_MAXN)
         return fade ? launch_rollout_big<true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st)
                     : launch_rollout_big<false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
+#ifndef MGP_RO_WIDE
     if (N == 100 && K == 3 && !fade)   // the headline shape (BASELINE.json configs[0..1]) runs a build with compile-time addresses
         return launch_rollout<100, 3, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
     if (N == 100 && K == 2 && !fade)   // cfg/default.cfg, cloning.cfg, dagger_twoflocks.cfg
         return launch_rollout<100, 2, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
+#endif
     return fade ? launch_rollout<0, 0, true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st)
                 : launch_rollout<0, 0, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
 }

@@ -9,7 +9,10 @@ namespace {
 // MLP operand layout: the resident kernel covers layer widths <= 32, i.e. <= 8 MFMA k-steps, so an agent column of the
 // activation buffer holds 4 x 8 floats (+4 pad) and a weight fragment lane 8 floats (+4 pad) -- half of actor_fused.hip's
 // 64-wide layout.  36 and 12 words per lane keep a 16-lane ds_read_b128 group on disjoint banks.
-constexpr int RO_KS = 8;
+#ifndef MGP_RO_KS
+#define MGP_RO_KS 8                      // k-steps of an activation column: layer widths <= 4 * MGP_RO_KS (rollout_wide.hip: 16)
+#endif
+constexpr int RO_KS = MGP_RO_KS;
 constexpr int RO_CS = 4 * RO_KS + 4;
 constexpr int RO_WFS = RO_KS + 4;
 __host__ __device__ inline int rpos(int c) { return (c & 3) * RO_KS + (c >> 2); }   // channel -> slot (B-fragment order)
@@ -23,38 +26,43 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int MT>
 __device__ __forceinline__ void ro_mlp_cols(float* pcol, const float* pw, const float* pbias, int ksteps, int lq)
 {
-    float fb[RO_KS], fa[MT][RO_KS];
-    f32x4 acc[MT];
+    constexpr int CH = MT > 2 ? 2 : MT;                       // m-tiles in flight: two chains hide the MFMA latency, four spill
+    float fb[RO_KS];
     const float4* pb = reinterpret_cast<const float4*>(pcol + lq * RO_KS);
 #pragma unroll
     for (int i = 0; i < RO_KS / 4; ++i) { const float4 t = pb[i]; fb[4 * i] = t.x; fb[4 * i + 1] = t.y; fb[4 * i + 2] = t.z; fb[4 * i + 3] = t.w; }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const float4* pa = reinterpret_cast<const float4*>(pw + mt * 64 * RO_WFS);
+    for (int h = 0; h < MT; h += CH) {                        // (every B fragment is in registers before the first store)
+        float fa[CH][RO_KS];
+        f32x4 acc[CH];
 #pragma unroll
-        for (int i = 0; i < RO_KS / 4; ++i) { const float4 u = pa[i]; fa[mt][4 * i] = u.x; fa[mt][4 * i + 1] = u.y; fa[mt][4 * i + 2] = u.z; fa[mt][4 * i + 3] = u.w; }
-        const float4 bv = *reinterpret_cast<const float4*>(pbias + mt * 16);
-        acc[mt][0] = bv.x; acc[mt][1] = bv.y; acc[mt][2] = bv.z; acc[mt][3] = bv.w;
-    }
+        for (int mt = 0; mt < CH; ++mt) {
+            const float4* pa = reinterpret_cast<const float4*>(pw + (h + mt) * 64 * RO_WFS);
 #pragma unroll
-    for (int sg = 0; sg < RO_KS / 2; ++sg) {
-        if (2 * sg < ksteps) {
-#pragma unroll
-            for (int s_ = 2 * sg; s_ < 2 * sg + 2; ++s_)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][s_], fb[s_], acc[mt], 0, 0, 0);
+            for (int i = 0; i < RO_KS / 4; ++i) { const float4 u = pa[i]; fa[mt][4 * i] = u.x; fa[mt][4 * i + 1] = u.y; fa[mt][4 * i + 2] = u.z; fa[mt][4 * i + 3] = u.w; }
+            const float4 bv = *reinterpret_cast<const float4*>(pbias + (h + mt) * 16);
+            acc[mt][0] = bv.x; acc[mt][1] = bv.y; acc[mt][2] = bv.z; acc[mt][3] = bv.w;
         }
+#pragma unroll
+        for (int sg = 0; sg < RO_KS / 2; ++sg) {
+            if (2 * sg < ksteps) {
+#pragma unroll
+                for (int s_ = 2 * sg; s_ < 2 * sg + 2; ++s_)
+#pragma unroll
+                    for (int mt = 0; mt < CH; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][s_], fb[s_], acc[mt], 0, 0, 0);
+            }
+        }
+        float z[CH][4];
+#pragma unroll
+        for (int mt = 0; mt < CH; ++mt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) z[mt][rr] = tanh_fast(acc[mt][rr]);
+#pragma unroll
+        for (int mt = 0; mt < CH; ++mt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) pcol[rr * RO_KS + (h + mt) * 4 + lq] = z[mt][rr];     // slot rpos(16 (h + mt) + 4 lq + rr)
     }
-    float z[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) z[mt][rr] = tanh_fast(acc[mt][rr]);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) pcol[rr * RO_KS + mt * 4 + lq] = z[mt][rr];                 // slot rpos(16 mt + 4 lq + rr)
 }
 
 __device__ __forceinline__ int ro_dim(unsigned long long dimsA, unsigned int dims8, int l)

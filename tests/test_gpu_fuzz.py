@@ -140,7 +140,7 @@ def test_resident_rollout_random_shapes(seed):
     rs = np.random.RandomState(5000 + seed)
     N = int(rs.randint(8, 129)) if seed % 4 else int(rs.randint(129, 257))   # any N; N > 128 runs rollout_big_kernel
     K = int(rs.randint(1, 5))
-    hidden = [(), (4,), (32,), (16, 16), (32, 32), (8, 32, 16), (32, 32, 32), (20, 12)][int(rs.randint(0, 8))]
+    hidden = [(), (4,), (32,), (16, 16), (32, 32), (8, 32, 16), (32, 32, 32), (20, 12), (64, 64), (40,), (64, 8, 48)][int(rs.randint(0, 11))]
     variant = dict(mean_pooling=bool(rs.randint(0, 2)), n_leaders=int(rs.randint(0, 3)),
                    comm_radius=float(rs.choice([0.8, 1.0, 1.5])))
     B = int(rs.randint(1, 4))

@@ -17,7 +17,7 @@ _note = ("# NOTE rollout_kernel<100, 3>: 2 launches = the 100-step warm-up launc
          "#      The other kernels belong to the two-launch path (timed in the same run) and to the stand-alone roofline leg.\n")
 open('profiles/r01_bench_kernel_trace_final.txt','w').write(''.join(_kt[:2]) + _note + ''.join(_kt[2:]))
 shutil.copy(O+'/dagger_update.json','profiles/r01_dagger_update.json')   # produced by `python bench.py --dagger-update`
-hdr = "# bench.py at other shapes (B N K): value, per-path throughput, per-kernel (avg launch us, GB/s), state finite\n# `resident` = mgp_rollout_steps (covered: N <= 256, widths and 6K <= 32); otherwise the two-launch path is `value`\n"
+hdr = "# bench.py at other shapes (B N K): value, per-path throughput, per-kernel (avg launch us, GB/s), state finite\n# `resident` = mgp_rollout_steps (covered: N <= 256, widths <= 64); `factored` = HBM bit-row state (N > 256); otherwise the two-launch path is `value`\n"
 open('profiles/r01_other_configs.txt','w').write(hdr+open(O+'/other_configs.txt').read())
 import os
 # phase-stamp files keep their hand-written legend (leading '#' lines); the body is the harness output of this run
