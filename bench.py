@@ -303,6 +303,21 @@ def dagger_update_bench():
         learner.gradient_step_tensors(xd, gd, yd, sync=False)     # vectorised DAGGER: losses stay on the device
     torch.cuda.synchronize()
     gpu_ms_pipe = 1e3 * (time.perf_counter() - t0) / n
+    # vectorised DAGGER's round of updates: minibatches gathered from a device replay inside the kernel, index table
+    # uploaded once, one graph replay per update (sampling on the host included: random.sample per update)
+    import random
+    from multiagent_gnn_policies_amd.learner.vec_dagger import DeviceReplay, IndexedUpdates
+    cap, U = 4096, 2000
+    rb = DeviceReplay(cap, K, F_FEAT, N, N_ACT, dev)
+    for i0 in range(0, cap, B):
+        rb.insert_batch(xd, gd, yd)
+    iu = IndexedUpdates(learner, rb, B, U)
+    iu.run([random.sample(range(cap), B) for _ in range(50)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss_round = iu.run([random.sample(range(cap), B) for _ in range(U)]).item()
+    gpu_ms_idx = 1e3 * (time.perf_counter() - t0) / U
+    assert np.isfinite(loss_round)
     from oracle import torch_port                          # CPU leg
     res = {}
     xc, gc, yc = xd.cpu(), gd.cpu(), yd.cpu()
@@ -328,6 +343,7 @@ def dagger_update_bench():
         res[thr] = 1e3 * (time.perf_counter() - t0) / m
     return {"update": "DAGGER gradient_step B=20 N=100 K=3", "hip_ms": gpu_ms, "hip_updates_per_s": 1e3 / gpu_ms,
             "hip_ms_pipelined": gpu_ms_pipe, "hip_updates_per_s_pipelined": 1e3 / gpu_ms_pipe,
+            "hip_ms_indexed_round": gpu_ms_idx, "hip_updates_per_s_indexed_round": 1e3 / gpu_ms_idx,
             "cpu_port_ms_by_threads": res, "host_cores": os.cpu_count()}
 
 

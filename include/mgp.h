@@ -268,6 +268,16 @@ int  mgp_train_step(const float* X, const float* G, const float* target,
                     float lr, float beta1, float beta2, float eps, int* step_dev,
                     float* loss, float* workspace, int B, int K, int N, void* stream);
 
+/* mgp_train_step with the minibatch gathered inside the kernel and no per-update host work (reference
+ * replay_buffer.py:40 + gnn_dagger.py:83-93: sample, cat, update): batch item b of update u reads row
+ * idx[u * B + b] of the replay arrays Xr (cap,K,F,N) / Gr (cap,K,N,N) / Yr (cap,1,nA,N), where u = *cursor is a device
+ * counter the call advances together with *step_dev; the loss of update u lands in loss_hist[u % hist_cap].  The host
+ * uploads a whole round's index table once, zeroes *cursor and replays one HIP graph per update. */
+int  mgp_train_step_indexed(const float* Xr, const float* Gr, const float* Yr, const long* idx, int* cursor,
+                            float* loss_hist, int hist_cap, float* flat_param, float* flat_grad, float* m, float* v,
+                            const int* dims, int n_layers, float lr, float beta1, float beta2, float eps,
+                            int* step_dev, float* workspace, int B, int K, int N, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Factored state for episodes beyond the LDS-resident rollout (N > 256)
  * Same loop as mgp_rollout_steps (test_model.py:38-44), same mathematics -- tap j = x_{t-j} A_t ... A_{t-j+1} evaluated

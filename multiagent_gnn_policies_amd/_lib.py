@@ -63,6 +63,8 @@ SIGNATURES = {
     'mgp_train_supported': (_int, [_vp, _int, _int, _int, _int]),
     'mgp_train_workspace': (_long, [_vp, _int, _int, _int, _int]),
     'mgp_train_grads': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _int, _int, _vp]),
+    'mgp_train_step_indexed': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _int,
+                                      _f32, _f32, _f32, _f32, _vp, _vp, _int, _int, _int, _vp]),
     'mgp_sparse_words': (_int, [_int]),
     'mgp_flock_step_sparse': (_int, [_vp, _vp, _vp, _long, _long, _vp, _long, _vp, _long, _vp, _long, _vp, _vp, _vp,
                                      _int, _int, _vp]),

@@ -35,6 +35,8 @@ struct TrainParams {
     int ioff[MGP_MAX_LAYERS];             // offset (floats) of layer l's input rows inside the LDS activation area
     int n_layers;
     const float* flat;                    // W_0 | b_0 | W_1 | ... when the caller's buffers are contiguous in that order
+    const long* idx;                      // batch item b reads row idx[cursor[0] * B + b] of X / G / target (replay gather
+    const int* cursor;                    //  fused into the update); nullptr: row b
 };
 
 // LDS (floats): xs [K*F][N] | gs [K][MC][16] (a chunk of G rows, this tile's columns) | red [MP][FK][16] |
@@ -106,8 +108,9 @@ void train_tile_kernel(const float* __restrict__ X, const float* __restrict__ G,
     float* wall = d1 + (size_t)maxw * TS_CS;
     float* my = part + ((size_t)b * gridDim.x + blockIdx.x) * Pstride;
     const int col = tid & (TS_COLS - 1), g = tid >> TS_CSH;
-    const float* Gb = G + (size_t)b * K * N * N;
-    const float* xb = X + (size_t)b * FK * N;
+    const size_t src = (P.idx != nullptr) ? (size_t)P.idx[(size_t)P.cursor[0] * gridDim.y + b] : (size_t)b;
+    const float* Gb = G + src * K * N * N;
+    const float* xb = X + src * FK * N;
     TS_STAMP(0);
 
     // ---- every first-round global read goes out before the first LDS write: G tile (20 per thread), X, parameters
@@ -144,7 +147,7 @@ void train_tile_kernel(const float* __restrict__ X, const float* __restrict__ G,
     }
     // targets of this workgroup's outputs (thread i < nA * 16 owns output (i >> 4, i & 15) of the last layer)
     float tgt = 0.f;
-    if (tid < nA * TS_COLS && n0 + col < N) tgt = target[((size_t)b * nA + (tid >> TS_CSH)) * N + n0 + col];
+    if (tid < nA * TS_COLS && n0 + col < N) tgt = target[(src * nA + (tid >> TS_CSH)) * N + n0 + col];
 
     // ---- aggregation y[k,f,col] = sum_m X[b,k,f,m] G[b,k,m,n0+col]: thread = (col, tap k, piece mp of the chunk's rows).
     //      Eight accumulators whatever F is (feature index clamped, surplus results dropped): no branch in the row loop.
@@ -230,7 +233,7 @@ void train_tile_kernel(const float* __restrict__ X, const float* __restrict__ G,
                 // d loss / d pred = 2 (pred - target) / n  (reference F.mse_loss, mean over every element)
                 float d = 0.f;
                 if (n0 + c16 < N)
-                    d = z - (i == tid ? tgt : target[((size_t)b * nA + o) * N + n0 + c16]);
+                    d = z - (i == tid ? tgt : target[(src * nA + o) * N + n0 + c16]);
                 dcur[o * TS_CS + c16] = grad_scale * d;
                 sq = fmaf(d, d, sq);
             }
@@ -303,6 +306,9 @@ struct AdamArgs {
     int* step_dev;
     int* ticket;
     float lr, b1, b2, eps;
+    int* cursor;         // replay-indexed updates: advanced together with the step counter (may be nullptr)
+    float* loss_hist;    // loss of update u of the round -> loss_hist[u % hist_cap] (may be nullptr)
+    int hist_cap;
 };
 
 // workgroup = 64 entries of the partial x 16 interleaved groups of tiles; entry Ptot is the squared error
@@ -332,7 +338,8 @@ void train_reduce_kernel(const float* __restrict__ part, int ntiles, int Pstride
         for (int q = 0; q < TR_GROUPS; ++q) s += sh[q][pl];
         if (i == Ptot) {
             if (loss != nullptr) loss[0] = s * inv_n;
-        } else {
+            if (A.loss_hist != nullptr) A.loss_hist[*A.cursor % A.hist_cap] = s * inv_n;   // (the cursor moves after every
+        } else {                                                                         //  workgroup is through: ticket below)
             flat_grad[i] = s;
             if (A.p != nullptr) {                        // torch.optim.Adam defaults, same expressions as mgp_adam_step_dev
                 const float one_m_b1 = (float)(1.0 - (double)A.b1), one_m_b2 = (float)(1.0 - (double)A.b2);
@@ -353,6 +360,7 @@ void train_reduce_kernel(const float* __restrict__ part, int ntiles, int Pstride
             if (atomicAdd(A.ticket, 1) == (int)gridDim.x - 1) {
                 *A.ticket = 0;
                 *A.step_dev += 1;
+                if (A.cursor != nullptr) *A.cursor += 1;
             }
         }
     }
@@ -392,7 +400,7 @@ bool make_train_plan(const int* dims, int n_layers, int B, int K, int N, TrainPl
 
 int launch_train(const float* X, const float* G, const float* target, const float* const* W, const float* const* b,
                  const int* dims, int n_layers, float* flat_grad, float* loss, float* workspace, const AdamArgs& A,
-                 int B, int K, int N, hipStream_t st)
+                 int B, int K, int N, hipStream_t st, const long* idx = nullptr)
 {
     TrainPlan pl;
     if (!make_train_plan(dims, n_layers, B, K, N, &pl)) return MGP_EUNSUPPORTED;
@@ -409,6 +417,7 @@ int launch_train(const float* X, const float* G, const float* target, const floa
         contiguous = contiguous && W[l] == W[0] + pl.poff[l] && b[l] == W[l] + (size_t)dims[l + 1] * cin;
     }
     P.flat = contiguous ? W[0] : nullptr;
+    P.idx = idx; P.cursor = A.cursor;
     const int Pstride = pl.Ptot + 1;
     const long n_out = (long)B * dims[n_layers] * N;
     mgp_clear_error();
@@ -448,14 +457,15 @@ extern "C" int mgp_train_grads(const float* X, const float* G, const float* targ
     if (B <= 0 || K <= 0 || N <= 0 || n_layers <= 0 || n_layers > MGP_MAX_LAYERS) return MGP_EINVAL;
     MGP_CHECK_PTR(X); MGP_CHECK_PTR(G); MGP_CHECK_PTR(target); MGP_CHECK_PTR(flat_grad); MGP_CHECK_PTR(workspace);
     if (loss != nullptr && (reinterpret_cast<uintptr_t>(loss) & 3u)) return MGP_EALIGN;
-    AdamArgs A = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f};
+    AdamArgs A = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, 0};
     return launch_train(X, G, target, W, b, dims, n_layers, flat_grad, loss, workspace, A, B, K, N,
                         static_cast<hipStream_t>(stream));
 }
 
-extern "C" int mgp_train_step(const float* X, const float* G, const float* target, float* flat_param, float* flat_grad,
-                              float* m, float* v, const int* dims, int n_layers, float lr, float beta1, float beta2,
-                              float eps, int* step_dev, float* loss, float* workspace, int B, int K, int N, void* stream)
+static int train_step_impl(const float* X, const float* G, const float* target, const long* idx, int* cursor, float* loss_hist,
+                           int hist_cap, float* flat_param, float* flat_grad, float* m, float* v, const int* dims,
+                           int n_layers, float lr, float beta1, float beta2, float eps, int* step_dev, float* loss,
+                           float* workspace, int B, int K, int N, void* stream)
 {
     if (dims == nullptr) return MGP_EINVAL;
     if (B <= 0 || K <= 0 || N <= 0 || n_layers <= 0 || n_layers > MGP_MAX_LAYERS) return MGP_EINVAL;
@@ -472,7 +482,26 @@ extern "C" int mgp_train_step(const float* X, const float* G, const float* targe
         b[l] = W[l] + (size_t)dims[l + 1] * cin;
     }
     int* ticket = reinterpret_cast<int*>(workspace + (size_t)B * pl.ntx * (pl.Ptot + 1));
-    AdamArgs A = {flat_param, m, v, step_dev, ticket, lr, beta1, beta2, eps};
+    AdamArgs A = {flat_param, m, v, step_dev, ticket, lr, beta1, beta2, eps, cursor, loss_hist, hist_cap};
     return launch_train(X, G, target, W, b, dims, n_layers, flat_grad, loss, workspace, A, B, K, N,
-                        static_cast<hipStream_t>(stream));
+                        static_cast<hipStream_t>(stream), idx);
+}
+
+extern "C" int mgp_train_step(const float* X, const float* G, const float* target, float* flat_param, float* flat_grad,
+                              float* m, float* v, const int* dims, int n_layers, float lr, float beta1, float beta2,
+                              float eps, int* step_dev, float* loss, float* workspace, int B, int K, int N, void* stream)
+{
+    return train_step_impl(X, G, target, nullptr, nullptr, nullptr, 0, flat_param, flat_grad, m, v, dims, n_layers, lr, beta1,
+                           beta2, eps, step_dev, loss, workspace, B, K, N, stream);
+}
+
+extern "C" int mgp_train_step_indexed(const float* Xr, const float* Gr, const float* Yr, const long* idx, int* cursor,
+                                      float* loss_hist, int hist_cap, float* flat_param, float* flat_grad, float* m, float* v,
+                                      const int* dims, int n_layers, float lr, float beta1, float beta2, float eps,
+                                      int* step_dev, float* workspace, int B, int K, int N, void* stream)
+{
+    if (idx == nullptr || cursor == nullptr || loss_hist == nullptr || hist_cap <= 0) return MGP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(idx) & 7u) || (reinterpret_cast<uintptr_t>(cursor) & 3u)) return MGP_EALIGN;
+    return train_step_impl(Xr, Gr, Yr, idx, cursor, loss_hist, hist_cap, flat_param, flat_grad, m, v, dims, n_layers, lr, beta1,
+                           beta2, eps, step_dev, nullptr, workspace, B, K, N, stream);
 }

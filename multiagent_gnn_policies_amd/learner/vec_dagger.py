@@ -65,6 +65,68 @@ class DeviceReplay(object):
         self.position = 0
 
 
+class IndexedUpdates(object):
+    """A round of DAGGER updates with no per-update host work: the minibatch indices of the whole round are uploaded once,
+    and every update is one replay of a two-launch HIP graph (mgp_train_step_indexed) that gathers its batch from the
+    replay arrays inside the kernel, applies Adam, advances the device-side update cursor and files its loss.
+    Sampling is the reference's (`random.sample` without replacement per update, replay_buffer.py:40)."""
+
+    def __init__(self, learner, memory, batch_size, max_updates):
+        import ctypes
+        from .. import _lib
+        actor, opt = learner.actor, learner.actor_optim
+        dev = opt.flat.device
+        dims = tuple(actor.layers)
+        self.cdims = (ctypes.c_int * len(dims))(*dims)
+        self.nl, self.K, self.N, self.B = actor.n_layers, actor.k, learner.n_agents, batch_size
+        self.learner, self.memory, self.cap = learner, memory, max_updates
+        L = _lib.lib()
+        self.idx = torch.zeros((max_updates, batch_size), device=dev, dtype=torch.long)
+        self.cursor = torch.zeros((1,), device=dev, dtype=torch.int32)
+        self.loss_hist = torch.zeros((max_updates,), device=dev, dtype=torch.float32)
+        self.step_dev = torch.zeros((1,), device=dev, dtype=torch.int32)
+        self.ws = torch.zeros((L.mgp_train_workspace(self.cdims, self.nl, batch_size, self.K, self.N),), device=dev)
+        self.graph = None
+
+    @staticmethod
+    def supported(learner, batch_size, N):
+        import ctypes
+        from .. import _lib
+        if not (learner.use_graphed_update and learner.use_train_step) or parallel.is_distributed():
+            return False
+        dims = tuple(learner.actor.layers)
+        cd = (ctypes.c_int * len(dims))(*dims)
+        return learner.actor.ind_agg == 0 and bool(_lib.lib().mgp_train_supported(cd, learner.actor.n_layers, batch_size,
+                                                                                 learner.actor.k, N))
+
+    def _enqueue(self):
+        from .. import _lib, ops
+        L, o, m = _lib.lib(), self.learner.actor_optim, self.memory
+        _lib.check(L.mgp_train_step_indexed(
+            ops._ptr(m.delay_state), ops._ptr(m.delay_gso), ops._ptr(m.action), self.idx.data_ptr(), self.cursor.data_ptr(),
+            ops._ptr(self.loss_hist), self.cap, ops._ptr(o.flat), ops._ptr(o.flat_grad), ops._ptr(o.m), ops._ptr(o.v),
+            self.cdims, self.nl, o.lr, o.betas[0], o.betas[1], o.eps, self.step_dev.data_ptr(), ops._ptr(self.ws),
+            self.B, self.K, self.N, ops._stream()), 'mgp_train_step_indexed')
+
+    def run(self, ids):
+        """ids: one list of `batch_size` replay rows per update.  Returns the sum of the updates' losses (device tensor)."""
+        U = len(ids)
+        assert 0 < U <= self.cap
+        opt = self.learner.actor_optim
+        self.idx[:U].copy_(torch.tensor(ids, dtype=torch.long), non_blocking=False)
+        self.cursor.zero_()
+        self.step_dev.fill_(opt.step_count)
+        if self.graph is None:
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._enqueue()
+        for _ in range(U):
+            self.graph.replay()
+        opt.step_count += U
+        return self.loss_hist[:U].sum()
+
+
 def _params_from_args(args):
     env_cls = _REGISTRY.get(args.get('env'), None)
     variant = getattr(env_cls, 'variant', {}) if env_cls is not None else {}
@@ -123,6 +185,7 @@ def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
     rank, world = parallel.rank(), parallel.world_size()
     rounds = (n_train_episodes + n_envs * world - 1) // (n_envs * world)
     updates = 0
+    indexed = None
     for rd in range(rounds):
         e0 = (rd * world + rank) * n_envs
         beta = np.maximum(beta_coeff ** (np.arange(e0, e0 + n_envs) + 1.0), 0.5)
@@ -140,7 +203,13 @@ def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
             sim.step(action, A_out=A_dst, feat_out=X_dst)
             state.advance()
         loss_sum = 0.0
-        if memory.curr_size > batch_size:
+        if memory.curr_size > batch_size and IndexedUpdates.supported(learner, batch_size, N):
+            if indexed is None:
+                indexed = IndexedUpdates(learner, memory, batch_size, updates_per_step * n_envs)
+            ids = [random.sample(range(memory.curr_size), batch_size) for _ in range(updates_per_step * n_envs)]
+            loss_sum = float(indexed.run(ids).item())
+            updates += len(ids)
+        elif memory.curr_size > batch_size:
             bufs = learner.graphed_buffers(batch_size, N)        # None: eager / distributed updates
             loss_dev = torch.zeros((1,), device=device)
             for _ in range(updates_per_step * n_envs):

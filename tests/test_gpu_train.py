@@ -186,6 +186,38 @@ def test_device_replay_ring_and_sampling():
         rb.sample(11)
 
 
+def test_indexed_updates_equal_the_sampled_path():
+    """mgp_train_step_indexed (gather inside the kernel, device-side cursor, one graph replay per update) against the
+    same updates through DeviceReplay.sample + GraphedUpdate: identical weights and losses, update by update."""
+    import random
+    from multiagent_gnn_policies_amd.learner.gnn_dagger import DAGGER
+    from multiagent_gnn_policies_amd.learner.vec_dagger import DeviceReplay, IndexedUpdates
+    dev = torch.device('cuda:0')
+    N, K, B, U, cap = 100, 3, 20, 12, 64
+    args = _args(n_agents=N, k=K, hidden_size=32, gamma=0.99, tau=0.5, actor_lr=1e-3)
+    rb = DeviceReplay(cap, K, 6, N, 2, dev)
+    g = torch.Generator(device='cuda').manual_seed(3)
+    for _ in range(cap // 16):
+        rb.insert_batch(torch.randn((16, K, 6, N), device=dev, generator=g),
+                        0.05 * torch.rand((16, K, N, N), device=dev, generator=g),
+                        torch.randn((16, 1, 2, N), device=dev, generator=g))
+    random.seed(5)
+    ids = [random.sample(range(rb.curr_size), B) for _ in range(U)]
+    torch.manual_seed(11); a = DAGGER(dev, args)
+    torch.manual_seed(11); b = DAGGER(dev, args)
+    assert IndexedUpdates.supported(a, B, N)
+    iu = IndexedUpdates(a, rb, B, 16)
+    total = iu.run(ids[:5]).item() + iu.run(ids[5:]).item()        # two rounds: the cursor restarts, the step counter goes on
+    losses = []
+    for row in ids:
+        idx = torch.tensor(row, device=dev)
+        losses.append(b.gradient_step_tensors(rb.delay_state[idx], rb.delay_gso[idx], rb.action[idx]))
+    assert a.actor_optim.step_count == b.actor_optim.step_count == U
+    assert torch.equal(a.actor_optim.flat, b.actor_optim.flat)
+    assert abs(total - sum(losses)) <= 1e-5 * max(1.0, abs(sum(losses)))
+    assert torch.allclose(iu.loss_hist[:7].cpu(), torch.tensor(losses[5:]), rtol=0, atol=1e-6)
+
+
 def test_vectorised_dagger_trains():
     """Device-resident DAGGER on 16 parallel episodes: finite statistics, updates happened, policy improves over
     the untrained network on the imitation loss of fresh expert-labelled states."""
