@@ -9,6 +9,9 @@ d2=json.loads(open(O+'/bench_under_rocprof.json').read().strip().splitlines()[-1
 print('under rocprof %.4g' % d2['value'])
 shutil.copy(O+'/pmc_traffic.json','profiles/r01_pmc_traffic.json')
 shutil.copy(O+'/pmc_hbm_traffic.txt','profiles/r01_pmc_hbm_traffic.txt')
+import os as _os
+if _os.path.exists(O+'/pmc_sq.txt'):
+    shutil.copy(O+'/pmc_sq.txt','profiles/r01_pmc_sq.txt')
 open('profiles/r01_bench_final.json','w').write(json.dumps(d)+'\n')
 open('profiles/r01_bench_final_under_rocprof.json','w').write(json.dumps(d2)+'\n')
 _kt = open(O+'/bench_kernel_trace.txt').read().splitlines(True)

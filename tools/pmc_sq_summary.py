@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Per-kernel SQ counters from a rocprofv3 --pmc pass (rocpd .db): matrix-pipe and issue utilisation evidence.
+
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY \
+              SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU --kernel-trace -d out -o sq -- python tools/pmc_probe.py
+    python tools/pmc_sq_summary.py out/.../sq_results.db
+
+Units (MI355X_MICROARCH.md): SQ_VALU_MFMA_BUSY_CYCLES counts cycles, SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* quad-cycles.
+Values are summed over the device per launch (rocprofv3 reports the accumulated value of a dispatch)."""
+import re
+import sqlite3
+import sys
+
+
+def main(path):
+    db = sqlite3.connect(path)
+    rows = db.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+                      "group by kernel_name, counter_name").fetchall()
+    dur = {}
+    try:
+        for name, n, avg in db.execute("select name, count(*), avg(duration) from kernels group by name"):
+            dur[name] = (n, avg)
+    except sqlite3.Error:
+        pass
+    per = {}
+    for name, ctr, n, avg in rows:
+        m = re.search(r'(\w+_kernel)', name)
+        if not m or 'at::native' in name:
+            continue
+        per.setdefault(m.group(1), {})[ctr] = avg
+        per[m.group(1)]['_n'] = n
+        if name in dur:
+            per[m.group(1)]['_us'] = dur[name][1] / 1e3
+    ctrs = sorted({c for v in per.values() for c in v if not c.startswith('_')})
+    print("# rocprofv3 --pmc (SQ block), average per launch, device totals")
+    for k in sorted(per):
+        v = per[k]
+        print("%s  (launches %d%s)" % (k, v['_n'], ", %.1f us" % v['_us'] if '_us' in v else ''))
+        for c in ctrs:
+            if c in v:
+                print("    %-28s %16.0f" % (c, v[c]))
+        wc = v.get('SQ_WAVE_CYCLES')
+        if wc:
+            for c in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY'):
+                if c in v:
+                    print("    %-28s %15.1f%%  of wave cycles" % (c + ' share', 100.0 * v[c] / wc))
+        if v.get('SQ_VALU_MFMA_BUSY_CYCLES') and v.get('SQ_BUSY_CU_CYCLES'):
+            # one matrix pipe per SIMD, four SIMDs per CU: busy cycles are summed over the SIMDs
+            print("    %-28s %15.1f%%  of (busy CU cycles x 4 SIMDs)" % ('matrix pipe busy', 100.0 * v['SQ_VALU_MFMA_BUSY_CYCLES'] /
+                                                                        (4.0 * v['SQ_BUSY_CU_CYCLES'])))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])

@@ -16,10 +16,12 @@ cd /tmp; export TMPDIR=/tmp
 # 1. PMC passes (counters only + kernel trace)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o fetch -- python $R/tools/pmc_probe.py > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o write -- python $R/tools/pmc_probe.py > $O/pmc_write.log 2>&1
-F=$(find $O/pmc_fetch -name "*results.db" | head -1); W=$(find $O/pmc_write -name "*results.db" | head -1)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU --kernel-trace -d $O/pmc_sq -o sq -- python $R/tools/pmc_probe.py > $O/pmc_sq.log 2>&1
+F=$(find $O/pmc_fetch -name "*results.db" | head -1); W=$(find $O/pmc_write -name "*results.db" | head -1); Q=$(find $O/pmc_sq -name "*results.db" | head -1)
 cd $R
 python tools/pmc_summary.py $F $W $O/pmc_traffic.json 256,100,3 > $O/pmc_hbm_traffic.txt 2>&1
 cp $O/pmc_traffic.json $R/profiles/r01_pmc_traffic.json
+python tools/pmc_sq_summary.py $Q > $O/pmc_sq.txt 2>&1
 # 2. bench (traffic now non-null) plain and under rocprof kernel trace
 python bench.py > $O/bench_final.json 2> $O/bench_final.err
 cd /tmp
@@ -40,5 +42,5 @@ d = json.loads(sys.stdin.read())
 k = {a: (round(v['avg_launch_ms']*1e3,1), round(v['GBps'])) for a, v in d.get('kernels', {}).items()}
 print('$1 $2 $3', 'value %.3e' % d['value'], 'ms/step %.4f' % d['ms_per_step'], 'paths', {a: '%.3e' % b['value'] for a, b in d['paths'].items()}, k, d['config']['state_finite'])
 " >> $O/other_configs.txt; done
-rm -rf $O/pmc_fetch $O/pmc_write $O/trace
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/trace
 ls -la $O
