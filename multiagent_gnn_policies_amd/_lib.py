@@ -110,11 +110,20 @@ def lib():
         # into a runtime that never saw torch's device context: "no ROCm-capable device").
         import torch  # noqa: F401
         path = _build.LIB_PATH
-        if not os.path.exists(path):
-            try:
-                _build.build(verbose=False)
-            except Exception as e:  # loud, never a silent fallback
-                raise MgpError("libmgp.so is missing and could not be built: %s" % e)
+        if not _build.is_current():
+            # missing, or older than the sources / flags it was built from: rebuild (a no-op for the other ranks of a
+            # torchrun launch, which wait on the build lock and then find the stamp current)
+            if _build.hipcc_path() is not None:
+                try:
+                    _build.build(verbose=False)
+                except Exception as e:  # loud, never a silent fallback
+                    raise MgpError("libmgp.so is missing or stale and could not be built: %s" % e)
+            elif not os.path.exists(path):
+                raise MgpError("libmgp.so is missing and hipcc is not available to build it")
+            else:
+                import warnings
+                warnings.warn("libmgp.so does not match the current sources (csrc/build/libmgp.srchash) and hipcc is "
+                              "not available to rebuild it: running the stale library", RuntimeWarning)
         try:
             handle = ctypes.CDLL(path)
         except OSError as e:

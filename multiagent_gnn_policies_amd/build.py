@@ -37,6 +37,8 @@ def source_hash():
             h.update(n.encode())
             h.update(f.read())
     h.update(' '.join(COMMON_FLAGS).encode())
+    for n in sorted(PER_FILE_FLAGS):                     # e.g. -ffp-contract=off decides the fp64 rounding of the simulator
+        h.update((n + ':' + ' '.join(PER_FILE_FLAGS[n])).encode())
     return h.hexdigest()
 
 
@@ -55,9 +57,24 @@ def is_current():
 
 
 def build(force=False, verbose=True):
-    """Compile every .hip under csrc/ for gfx950 and link libmgp.so.  Returns the library path."""
+    """Compile every .hip under csrc/ for gfx950 and link libmgp.so.  Returns the library path.
+    Serialised across processes by an exclusive lock on csrc/build/.lock: under torchrun every rank imports the package
+    at once, and concurrent builds would race on the same object files and on libmgp.so.tmp."""
     if not force and is_current():
         return LIB_PATH
+    import fcntl
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    with open(os.path.join(OBJ_DIR, '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and is_current():               # another process built it while we waited
+                return LIB_PATH
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build libmgp.so (ROCm toolchain required)")
@@ -77,7 +94,7 @@ def build(force=False, verbose=True):
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors='replace')))
         if verbose and out.strip():
             print(out.decode(errors='replace'))
-    tmp = LIB_PATH + '.tmp'
+    tmp = LIB_PATH + '.tmp.%d' % os.getpid()
     cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', tmp] + objs
     if verbose:
         print('[mgp build]', ' '.join(cmd), flush=True)

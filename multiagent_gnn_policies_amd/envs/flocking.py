@@ -163,8 +163,11 @@ class VecFlock(object):
         self._c = params.to_c()
         self.x = torch.zeros((B, N, 4), device=self.device, dtype=torch.float64)      # current state
         self._x_next = torch.zeros_like(self.x)                                        # ping-pong partner
-        self.network = torch.zeros((B, N, N), device=self.device, dtype=torch.float32)
-        self.features = torch.zeros((B, 6, N), device=self.device, dtype=torch.float32)
+        self._network_own = torch.zeros((B, N, N), device=self.device, dtype=torch.float32)
+        self._features_own = torch.zeros((B, 6, N), device=self.device, dtype=torch.float32)
+        # `network` / `features` normally are the two buffers above; step(A_out=, feat_out=) / step_advance / the resident
+        # rollout rebind them to (batch-strided) slots of a BatchedDelayState, refresh() binds them back
+        self.network, self.features = self._network_own, self._features_own
         self.reward = torch.zeros((B,), device=self.device, dtype=torch.float64)
         self.expert = torch.zeros((B, N, 2), device=self.device, dtype=torch.float32)
         self.network64 = torch.zeros((B, N, N), device=self.device, dtype=torch.float64) if want_f64_obs else None
@@ -183,7 +186,11 @@ class VecFlock(object):
         self.set_state(np.stack([sample_initial_state(rng, self.p) for _ in range(self.B)]))
 
     def refresh(self):
-        """Recompute observations (and the expert action, `params.centralized`) for the current x, no integration."""
+        """Recompute observations (and the expert action, `params.centralized`) for the current x, no integration.
+        The observations land in the simulator's OWN contiguous buffers: after a step that wrote them into the slots of a
+        delay state (`step(A_out=...)`, `step_advance`, the resident rollout) `network` / `features` are strided views of
+        that state's buffers, and a reset observation must not be written into -- or later pushed from -- those."""
+        self.network, self.features = self._network_own, self._features_own
         ops.flock_step(self.x, None, self._c, A=self.network, A64=self.network64, feat=self.features,
                        feat64=self.features64, reward=self.reward, expert=self.expert if self.with_expert else None)
 
@@ -192,10 +199,11 @@ class VecFlock(object):
         with `with_expert` the expert action of the new state (`params.centralized`) lands in `self.expert` for free.
         A_out / feat_out: optional (possibly batch-strided) destinations for the network matrix and the features,
         e.g. BatchedDelayState.next_slots(); self.network / self.features then alias them."""
-        if A_out is not None:
-            self.network = A_out
-        if feat_out is not None:
-            self.features = feat_out
+        # without explicit destinations the observations go to the simulator's own buffers (never into slots of a delay
+        # state that an earlier step_advance / resident rollout left `network` / `features` bound to: that state's
+        # current slice 1 must stay A_t until the state itself advances)
+        self.network = A_out if A_out is not None else self._network_own
+        self.features = feat_out if feat_out is not None else self._features_own
         ops.flock_step(self.x, u, self._c, A=self.network, A64=self.network64, feat=self.features,
                        feat64=self.features64, reward=self.reward, expert=self.expert if self.with_expert else None,
                        x_out=self._x_next if u is not None else None)

@@ -41,6 +41,10 @@ class FlatAdam(object):
         self.flat_grad = torch.zeros_like(self.flat)
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
+        # ONE step counter, on the device, shared by every update path (eager, HIP-graph replays of any batch size, the
+        # indexed rounds of vec_dagger): each Adam kernel reads it for the bias corrections and advances it itself, so
+        # mixing paths can never replay a stale step.  `step_count` mirrors it on the host (bookkeeping only).
+        self.step_dev = torch.zeros((1,), device=dev, dtype=torch.int32)
         self.step_count = 0
 
     def zero_grad(self):
@@ -53,9 +57,9 @@ class FlatAdam(object):
         return self.flat_grad
 
     def step(self):
+        ops.adam_step_dev(self.flat, self.flat_grad, self.m, self.v, self.lr, self.step_dev,
+                          self.betas[0], self.betas[1], self.eps)
         self.step_count += 1
-        ops.adam_step(self.flat, self.flat_grad, self.m, self.v, self.lr, self.step_count,
-                      self.betas[0], self.betas[1], self.eps)
 
     def views(self, flat):
         """Per-parameter views into a flat buffer laid out like self.flat."""
@@ -90,7 +94,7 @@ class GraphedUpdate(object):
         self.loss = torch.zeros((1,), device=dev)
         self.saved = torch.empty((L.mgp_actor_saved_floats(self.cdims, actor.n_layers, B, K, N),), device=dev)
         self.ws = torch.empty((max(1, L.mgp_actor_bwd_workspace(self.cdims, actor.n_layers, B, K, N)),), device=dev)
-        self.step_dev = torch.full((1,), opt.step_count, device=dev, dtype=torch.int32)
+        self.step_dev = opt.step_dev                # shared with every other update path (FlatAdam)
         pv, gv = opt.views(opt.flat), opt.views(opt.flat_grad)
         self.Wp, self.bp = _ptr_array(pv[0::2]), _ptr_array(pv[1::2])
         self.dWp, self.dbp = _ptr_array(gv[0::2]), _ptr_array(gv[1::2])
@@ -132,11 +136,6 @@ class GraphedUpdate(object):
         if Y is not self.Y:
             self.Y.copy_(Y)
         if self.graph is None:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                self.step_dev.fill_(self.opt.step_count)
-            torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
@@ -288,20 +287,41 @@ class DAGGER(object):
                     sd = {k_.replace('__', '.'): torch.from_numpy(z[k_]) for k_ in z.files}
             else:
                 sd = torch.load(actor_path, map_location)
+            own = self.actor.state_dict()
+            # validate everything before touching the live parameters (nn.Module.load_state_dict semantics: reference
+            # gnn_dagger.py:122 raises on unexpected / missing keys and on shape mismatches, leaving the model unchanged)
+            unexpected, missing = sorted(set(sd) - set(own)), sorted(set(own) - set(sd))
+            if unexpected or missing:
+                raise KeyError("state_dict mismatch: unexpected keys %s, missing keys %s" % (unexpected, missing))
+            bad = ["%s: checkpoint %s vs model %s" % (k_, tuple(sd[k_].shape), tuple(own[k_].shape))
+                   for k_ in own if tuple(sd[k_].shape) != tuple(own[k_].shape)]
+            if bad:
+                raise RuntimeError("state_dict shape mismatch: " + "; ".join(bad))
             with torch.no_grad():
-                own = self.actor.state_dict()
                 for k_, v in sd.items():
-                    own[k_].copy_(v)              # keeps the flat-buffer views intact
-            missing = set(own) ^ set(sd)
-            if missing:
-                raise KeyError("state_dict mismatch: %s" % sorted(missing))
+                    own[k_].copy_(v)              # in place: keeps the flat-buffer views intact
+
+
+class BetaSchedule(object):
+    """beta of global episode e, computed exactly as the reference does (gnn_dagger.py:141,148): `beta = 1` before the
+    loop, then `beta = max(beta * beta_coeff, 0.5)` once per episode -- a RUNNING product, bit for bit (a closed form
+    beta_coeff ** (e + 1) differs in the last ulp, and beta is the probability handed to np.random.binomial).  Ranks of a
+    data-parallel run ask for non-consecutive episodes, so earlier values are memoised."""
+
+    def __init__(self, beta_coeff):
+        self.beta_coeff = beta_coeff
+        self._betas = []
+
+    def __call__(self, episode):
+        while len(self._betas) <= episode:
+            prev = self._betas[-1] if self._betas else 1
+            self._betas.append(max(prev * self.beta_coeff, 0.5))
+        return self._betas[episode]
 
 
 def train_dagger(env, args, device):
-    """Reference gnn_dagger.py:126-243.  beta of global episode e is max(beta_coeff ** (e + 1), 0.5) -- the closed form
-    of the reference's running product `beta = max(beta * beta_coeff, 0.5)`; evaluation while training only when
-    `debug`; the statistics are those of a final evaluation, after which the model is saved (`debug` and `fname`)."""
+    """Reference gnn_dagger.py:126-243.  Evaluation while training only when `debug`; the statistics are those of a final
+    evaluation, after which the model is saved (`debug` and `fname`)."""
     from .imitation import ImitationRun
-    beta_coeff = args.getfloat('beta_coeff')
     run = ImitationRun(env, DAGGER(device, args), args, device)
-    return run.run(lambda e: max(beta_coeff ** (e + 1), 0.5), eval_always=False, keep_best=False)
+    return run.run(BetaSchedule(args.getfloat('beta_coeff')), eval_always=False, keep_best=False)

@@ -93,7 +93,13 @@ class BatchedDelayState(object):
         self._pushes = 0
 
     def push(self, A, X_t):
-        """A (B,N,N) fp32, X_t (B,F,N) fp32 (both contiguous, on device)."""
+        """A (B,N,N) fp32, X_t (B,F,N) fp32 on the device.  mgp_gso_update reads both with batch strides N*N and F*N, so
+        strided views (e.g. the slots of another delay state that a simulator step wrote into) are compacted first."""
+        assert A.shape == (self.B, self.N, self.N) and X_t.shape == (self.B, self.F, self.N)
+        if not A.is_contiguous():
+            A = A.contiguous()
+        if not X_t.is_contiguous():
+            X_t = X_t.contiguous()
         nxt = 1 - self._cur
         ops.gso_update_into(A, self._G[self._cur], self._G[nxt], X_t, self._X[self._cur], self._X[nxt],
                             has_prev=self._has_prev)

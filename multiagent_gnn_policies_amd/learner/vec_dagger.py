@@ -84,7 +84,7 @@ class IndexedUpdates(object):
         self.idx = torch.zeros((max_updates, batch_size), device=dev, dtype=torch.long)
         self.cursor = torch.zeros((1,), device=dev, dtype=torch.int32)
         self.loss_hist = torch.zeros((max_updates,), device=dev, dtype=torch.float32)
-        self.step_dev = torch.zeros((1,), device=dev, dtype=torch.int32)
+        self.step_dev = opt.step_dev                # FlatAdam's shared device step counter
         self.ws = torch.zeros((L.mgp_train_workspace(self.cdims, self.nl, batch_size, self.K, self.N),), device=dev)
         self.graph = None
 
@@ -115,7 +115,6 @@ class IndexedUpdates(object):
         opt = self.learner.actor_optim
         self.idx[:U].copy_(torch.tensor(ids, dtype=torch.long), non_blocking=False)
         self.cursor.zero_()
-        self.step_dev.fill_(opt.step_count)
         if self.graph is None:
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
@@ -131,7 +130,12 @@ def _params_from_args(args):
     env_cls = _REGISTRY.get(args.get('env'), None)
     variant = getattr(env_cls, 'variant', {}) if env_cls is not None else {}
     kw = dict(n_agents=args.getint('n_agents'), comm_radius=args.getfloat('comm_radius'),
-              v_max=args.getfloat('v_max'), v_bias=args.getfloat('v_max'), init_mode='grid')
+              v_max=args.getfloat('v_max'), v_bias=args.getfloat('v_max'))
+    # same reset distribution as the gym-style environment built from the same cfg section (FlockParams.init_mode 'auto':
+    # disc sampling up to N = 100, jittered lattice beyond), so `alg = dagger_vec` and `alg = dagger` statistics are
+    # comparable; `init_mode = grid` in the cfg selects the lattice explicitly (cheaper resets for many lanes)
+    if args.get('init_mode') is not None:
+        kw['init_mode'] = args.get('init_mode')
     if args.get('dt') is not None:
         kw['dt'] = args.getfloat('dt')
     kw.update(variant)
@@ -226,4 +230,6 @@ def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
     lo, hi = parallel.shard_range(n_test_episodes)
     n_local = max(1, hi - lo) if world > 1 else n_test_episodes
     rewards = parallel.all_gather_floats(evaluate(learner, sim, state, n_local, T))
+    if debug and args.get('fname') and rank == 0:            # reference gnn_dagger.py:239-240
+        learner.save_model(args.get('env'), suffix=args.get('fname'))
     return {'mean': float(np.mean(rewards)), 'std': float(np.std(rewards)), 'learner': learner, 'updates': updates}

@@ -175,6 +175,9 @@ def gso_update_into(A, G_prev, G_next, X_t, Xd_prev, Xd_next, has_prev=True):
     """In-place variant on preallocated ping-pong buffers (no allocation: HIP-graph capturable)."""
     B, K, N, _ = G_next.shape
     F = X_t.shape[1]
+    if not (A.is_contiguous() and X_t.is_contiguous() and G_next.is_contiguous() and Xd_next.is_contiguous()):
+        raise MgpError("mgp_gso_update reads A (B,N,N) and X_t (B,F,N) with dense batch strides: pass contiguous tensors "
+                       "(got strides A %s, X_t %s)" % (tuple(A.stride()), tuple(X_t.stride())))
     rc = _lib.lib().mgp_gso_update(_ptr(A), _ptr(G_prev), _ptr(G_next), _ptr(X_t), _ptr(Xd_prev), _ptr(Xd_next),
                                    B, K, F, N, 1 if has_prev else 0, _stream())
     _lib.check(rc, 'mgp_gso_update')
@@ -326,6 +329,18 @@ def adam_step(param, grad, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
     _lib.check(rc, 'mgp_adam_step')
 
 
+def adam_step_dev(param, grad, m, v, lr, step_dev, beta1=0.9, beta2=0.999, eps=1e-8):
+    """Same update with the step count on the device: `step_dev` (1,) int32 holds the number of steps taken so far; the
+    kernel uses step_dev + 1 for the bias corrections and stores it back (graph-replayable, no host state)."""
+    for t, n in ((param, 'param'), (grad, 'grad'), (m, 'm'), (v, 'v')):
+        _dev(t, n)
+        assert t.is_contiguous()
+    _dev(step_dev, 'step_dev', torch.int32)
+    rc = _lib.lib().mgp_adam_step_dev(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(),
+                                      lr, beta1, beta2, eps, _ptr(step_dev), _stream())
+    _lib.check(rc, 'mgp_adam_step_dev')
+
+
 __all__ = ['MgpFlockParams', 'MgpError', 'aggregate', 'dense', 'agg_fwd', 'agg_bwd_x', 'dense_fwd', 'dense_bwd',
            'gso_update', 'gso_update_into', 'gso_powers', 'flock_step', 'flock_controller', 'mse_grad', 'mse_loss',
-           'gso_advance', 'flock_step_advance', 'rollout_supported', 'rollout_steps', 'adam_step', 'ACT_NONE', 'ACT_TANH']
+           'gso_advance', 'flock_step_advance', 'rollout_supported', 'rollout_steps', 'adam_step', 'adam_step_dev', 'ACT_NONE', 'ACT_TANH']

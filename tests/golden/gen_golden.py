@@ -177,7 +177,52 @@ def gen_dagger():
         print('wrote', path, 'losses', losses)
 
 
+def gen_train_trace():
+    """Row a9: the reference's OWN `train_dagger` (gnn_dagger.py:126-243) and ReplayBuffer (replay_buffer.py:6-49) driven
+    by a deterministic duck-typed environment (tests/fake_env.py); tests/trace_tools.py records the control flow:
+    beta passed to every coin flip and its outcome, who drove each step, every action handed to env.step, labels and ring
+    positions of every insert, the indices of every minibatch, per-update losses, select_action outputs, printed lines,
+    final statistics and weights, and the order of all these events."""
+    import learner.gnn_dagger as ref_mod
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import fake_env
+    import trace_tools as tt
+    if not hasattr(np, 'Inf'):
+        np.Inf = np.inf        # gnn_dagger.py:143 spells it np.Inf (removed in numpy 2.0); a shim for RUNNING the reference here
+    args = tt.trace_args()
+    tr = tt.Trace()
+    env = tt.RecordingEnv(fake_env.FakeFlockEnv(args.getint('n_agents'), episode_steps=tt.TRACE_EPISODE_STEPS,
+                                                seed=args.getint('seed')), tr)
+    saved = (ref_mod.ReplayBuffer, ref_mod.DAGGER)
+    ref_mod.ReplayBuffer = tt.recording_replay(saved[0], tr)
+    ref_mod.DAGGER = tt.recording_learner(saved[1], tr, lambda l: sd_to_np(l.actor.state_dict()))
+    try:
+        tt.seed_all(args.getint('seed'))
+        with tt.recording_binomial(tr), tt.capture_stdout(tr):
+            tr.stats = ref_mod.train_dagger(env, args, torch.device('cpu'))
+    finally:
+        ref_mod.ReplayBuffer, ref_mod.DAGGER = saved
+    tr.final_weights = sd_to_np(tr.learner.actor.state_dict())
+    d = tr.to_npz_dict()
+    d['episode_steps'] = np.int64(tt.TRACE_EPISODE_STEPS)
+    for k, v in tt.TRACE_CFG.items():
+        d['cfg__' + k] = np.array(v)
+    path = os.path.join(HERE, 'train_dagger_trace.npz')
+    np.savez_compressed(path, **d)
+    print('wrote', path)
+    print(' events', ''.join(tr.events))
+    print(' printed:\n' + tr.printed)
+    print(' stats', tr.stats, 'losses', tr.losses[:4], '...', len(tr.losses), 'updates;', len(tr.step_actions), 'env steps;',
+          'expert drove', int(np.sum(tr.step_expert_applied)), 'of', len(tr.binom_out), 'training steps')
+
+
 if __name__ == '__main__':
-    gen_actor()
-    gen_state()
-    gen_dagger()
+    which = sys.argv[1:] or ['actor', 'state', 'dagger', 'trace']
+    if 'actor' in which:
+        gen_actor()
+    if 'state' in which:
+        gen_state()
+    if 'dagger' in which:
+        gen_dagger()
+    if 'trace' in which:
+        gen_train_trace()

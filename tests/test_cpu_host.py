@@ -312,3 +312,16 @@ def test_coverage_predicates_are_host_side():
     assert not L.mgp_train_supported(d, 3, 20000, 3, 100)          # > 8192 column tiles
     d128 = (ctypes.c_int * 3)(6, 128, 2)
     assert not L.mgp_actor_supported(d128, 2, 3, 100) and not L.mgp_train_supported(d128, 2, 20, 3, 100)
+
+
+def test_beta_schedule_is_the_reference_running_product():
+    """gnn_dagger.py:141,148: beta = 1; per episode beta = max(beta * beta_coeff, 0.5) -- bit for bit, any query order."""
+    from multiagent_gnn_policies_amd.learner.gnn_dagger import BetaSchedule
+    for coeff in (0.993, 0.7, 0.9999, 0.5, 1.0):
+        beta, ref = 1, []
+        for _ in range(400):
+            beta = max(beta * coeff, 0.5)
+            ref.append(beta)
+        s = BetaSchedule(coeff)
+        order = np.random.RandomState(0).permutation(400)
+        assert all(s(int(e)) == ref[int(e)] for e in order)

@@ -227,7 +227,7 @@ def test_vectorised_dagger_trains():
                          actor_lr='1e-3', n_train_episodes='32', beta_coeff='0.993', test_interval='40',
                          n_test_episodes='4', k='3', hidden_size='32', gamma='0.99', tau='0.5',
                          env='FlockingRelative-v0', v_max='3.0', comm_radius='1.0', n_agents='40', n_actions='2',
-                         n_states='6', debug='False', dt='0.01')
+                         n_states='6', debug='False', dt='0.01', init_mode='grid')
     cp['t'] = {}
     import random
     random.seed(1); np.random.seed(1); torch.manual_seed(1)
@@ -307,7 +307,7 @@ def test_vectorised_dagger_learns_to_flock():
                          actor_lr='5e-4', n_train_episodes='32', beta_coeff='0.993', test_interval='40',
                          n_test_episodes='8', k='3', hidden_size='32', gamma='0.99', tau='0.5',
                          env='FlockingRelative-v0', v_max='3.0', comm_radius='1.0', n_agents='40', n_actions='2',
-                         n_states='6', debug='False', dt='0.01')
+                         n_states='6', debug='False', dt='0.01', init_mode='grid')
     cp['t'] = {}
     random.seed(1); np.random.seed(1); torch.manual_seed(1)
     stats = train_dagger_vec(cp['t'], 'cuda:0', n_envs=16, episode_steps=150)

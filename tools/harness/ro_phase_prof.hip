@@ -7,6 +7,10 @@
 #include <vector>
 #include <cmath>
 thread_local int mgp_tls_hip_error = 0;
+// the narrow build forwards widths > 32 to the second compilation (rollout_wide.hip); this harness links only the narrow one
+extern "C" int mgp_rollout_wide_supported_(const int*, int, int, int) { return 0; }
+extern "C" int mgp_rollout_wide_steps_(double*, float*, float*, const float* const*, const float* const*, const int*, int, float*,
+                                       double*, const MgpFlockParams*, int, int, int, int, void*) { return MGP_EUNSUPPORTED; }
 int main(int argc, char** argv) {
     int B = argc > 1 ? atoi(argv[1]) : 256, N = argc > 2 ? atoi(argv[2]) : 100, K = argc > 3 ? atoi(argv[3]) : 3;
     int T = argc > 4 ? atoi(argv[4]) : 200;
