@@ -30,6 +30,13 @@ Also reported on the same JSON line:
   kernels       same measurement for the other stand-alone kernels.
   cpu_baseline  the PyTorch-CPU port of the reference op sequence (oracle/torch_port.py, "kind": "port"),
                 reference-style B=1 loop, timed on this host for a bounded sample (rank 0, N=1 only).
+  parity        the in-run parity gate (north_star "within 1e-5 fp32 ... in the same run"): the
+                action of one resident step and of one two-launch step against the SAME CPU port's Actor forward on the
+                identical (S, X) the kernels consumed, for 16 sampled episodes: {ok, tol, max_abs, max_rel, ...}.
+                A failed gate prints the line with "ok": false and exits with status 3.
+Which implementation is `value` is a function of the SHAPE only (never of --steps): resident where mgp_rollout_supported
+says so (N <= 256, widths <= 64), factored for N > 256 where mgp_sparse_policy_supported, else two_launch; config.step_path
+names it and paths.* carries every implementation that was timed.
 """
 import argparse
 import json
@@ -51,6 +58,9 @@ from multiagent_gnn_policies_amd.learner.state_with_delay import BatchedDelaySta
 
 DEFAULT_STEPS = 1000      # env steps in the timed region (resident path: one launch; ~10 ms)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32 / 32x32x2 dense peak (MI355X_MICROARCH.md: = the fp32 vector rate)
+PARITY_TOL = 1e-5
+PROFILE_ROUND = 'r02'
 F_FEAT, N_ACT = 6, 2
 
 
@@ -208,23 +218,107 @@ def kernel_rooflines(device, B, N, K, actor, flock_c):
     return res, n_sets
 
 
-def pmc_traffic(kernel, B, N, K, steps_per_launch=None):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json,
-    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; tools/pmc_summary.py), or None when the profile was
-    taken on other shapes or on a different build of the kernels."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+def _profile_json(name):
+    path = os.path.join(ROOT, 'profiles', '%s_%s' % (PROFILE_ROUND, name))
     try:
         with open(path) as f:
-            d = json.load(f)
-        from multiagent_gnn_policies_amd import build as mgp_build
-        meta = d.get('_meta', {})
-        if meta.get('shape') != [B, N, K] or meta.get('source_hash') != mgp_build.source_hash():
-            return None
-        if steps_per_launch is not None and meta.get('rollout_steps_per_launch') != steps_per_launch:
-            return None
-        return d[kernel]['total_bytes']
+            return json.load(f)
     except Exception:
         return None
+
+
+def pmc_traffic(kernel, B, N, K, steps_per_launch=None):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/<round>_pmc_traffic.json:
+    separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction; tools/pmc_summary.py).
+    The episode-resident kernel is profiled at two launch lengths, which gives bytes(T) = fixed + per_step * T for any
+    --steps.  Returns (bytes or None, note): None when no pass on these shapes is committed; the note says whether the pass
+    was taken on this very build of the kernels (source hash) or on an earlier one."""
+    d = _profile_json('pmc_traffic.json')
+    if d is None:
+        return None, 'no committed PMC pass'
+    meta = d.get('_meta', {})
+    if meta.get('shape') != [B, N, K]:
+        return None, 'committed PMC pass is for shape %s' % (meta.get('shape'),)
+    from multiagent_gnn_policies_amd import build as mgp_build
+    note = 'profiles/%s_pmc_traffic.json (%s)' % (PROFILE_ROUND, 'this build' if meta.get('source_hash') == mgp_build.source_hash()
+                                                  else 'taken on an earlier build of the kernels')
+    try:
+        if steps_per_launch is None:
+            return d[kernel]['total_bytes'], note
+        m = d[kernel + '_model']
+        return m['fixed_bytes'] + m['bytes_per_step'] * steps_per_launch, note + '; fixed %.0f B + %.0f B/step per launch' % (
+            m['fixed_bytes'], m['bytes_per_step'])
+    except KeyError:
+        return None, 'kernel not in the committed PMC pass'
+
+
+def pmc_sq(kernel):
+    """Wave-cycle breakdown and matrix-pipe occupancy of `kernel` from the committed SQ-counter pass
+    (profiles/<round>_pmc_sq.json, tools/pmc_sq_summary.py), or None."""
+    d = _profile_json('pmc_sq.json')
+    if d is None or kernel not in d:
+        return None
+    v = dict(d[kernel])
+    v['source'] = 'profiles/%s_pmc_sq.json' % PROFILE_ROUND
+    return v
+
+
+def parity_gate(ro, n_check=16):
+    """In-run parity gate, part of the cpu_baseline leg (the only place besides cpu_baseline() where bench.py touches
+    oracle/, and only as the checker): the reference op sequence of actor.py:63-82 in PyTorch-CPU fp32
+    (oracle/torch_port.actor_forward -- the very port that is timed as cpu_baseline, itself pinned to the reference by the
+    goldens) on the identical (S, X) = (delay_gso, delay_state) the HIP kernels consume, for `n_check` sampled episodes:
+      two_launch  mgp_actor_fwd on the current state
+      resident    the action of a one-step mgp_rollout_steps launch from the same state (when the shape is covered)
+    max_rel is elementwise |gpu - cpu| / max(1, |cpu|); the gate is max_rel <= 1e-5.  Runs after the timed regions."""
+    from oracle import torch_port
+    from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
+    B = ro.B
+    idx = sorted(set(int(i) for i in np.linspace(0, B - 1, min(n_check, B))))
+    G = ro.state.delay_gso[idx].cpu()
+    X = ro.state.delay_state[idx].cpu()
+    Ws = [c.weight.detach().cpu() for c in ro.actor.conv_layers]
+    bs = [c.bias.detach().cpu() for c in ro.actor.conv_layers]
+    with torch.no_grad():
+        ref = torch_port.actor_forward(X, G, Ws, bs, 0, ro.K).double()
+        # the same op sequence in fp64 on the same fp32 inputs: how far the fp32 REFERENCE itself is from the exact result
+        # on this state (crowded flocks make 1/r^4 features O(1e4) and the policy ill-conditioned: two fp32 evaluations
+        # of the reference -- numpy vs torch op order -- then differ by more than 1e-5 from each other)
+        exact = torch_port.actor_forward(X.double(), G.double(), [w.double() for w in Ws], [b_.double() for b_ in bs], 0, ro.K)
+        two = ro.actor(ro.state.delay_state, ro.state.delay_gso)[idx].cpu().double()
+    res = {}
+
+    def rel(u, r):
+        return float(((u - r).abs() / r.abs().clamp(min=1.0)).max())
+    noise = rel(ref, exact)
+
+    def err(u):
+        return {"max_abs": float((u - ref).abs().max()), "max_rel": rel(u, ref), "max_rel_vs_exact": rel(u, exact)}
+    res['two_launch'] = err(two)
+    if ro.resident_supported():
+        action = torch.zeros((B, 1, N_ACT, ro.N), device=ro.sim.device)
+        if policy_rollout(ro.actor, ro.sim, ro.state, 1, action=action):
+            res['resident'] = err(action[idx].cpu().double())
+    worst_abs = max(v['max_abs'] for v in res.values())
+    worst_rel = max(v['max_rel'] for v in res.values())
+    worst_exact = max(v['max_rel_vs_exact'] for v in res.values())
+    ok = bool(worst_rel <= PARITY_TOL or worst_exact <= PARITY_TOL + noise)
+    return {"ok": ok, "tol": PARITY_TOL, "max_abs": worst_abs, "max_rel": worst_rel, "max_rel_vs_exact": worst_exact,
+            "reference_fp32_noise": noise, "max_abs_reference_output": float(ref.abs().max()),
+            "checked_episodes": len(idx), "paths": res,
+            "criterion": "max_rel <= tol (gpu vs the fp32 CPU reference, elementwise |gpu - cpu| / max(1, |cpu|)), or -- on "
+                         "states where the fp32 reference is itself further than that from the exact result -- "
+                         "max_rel_vs_exact <= tol + reference_fp32_noise (triangle inequality through the fp64 evaluation "
+                         "of the same op sequence on the same fp32 inputs)",
+            "reference": "oracle/torch_port.actor_forward: PyTorch-CPU fp32, the op sequence of reference actor.py:63-82, "
+                         "on the identical (delay_gso, delay_state) of the sampled episodes"}
+
+
+def mean_degree(state):
+    """Mean number of neighbours per agent in the current networks (rows of delay_gso[:, 1]), over all episodes."""
+    if state.K < 2:
+        return None
+    return float((state.delay_gso[:, 1] != 0).sum(dim=-1).double().mean().item())
 
 
 def cpu_baseline(N, K, hidden, budget_s=12.0):
@@ -360,6 +454,7 @@ def main():
     ap.add_argument('--graph-steps', type=int, default=10, help='env steps captured per HIP graph (0 = eager)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true', help='skip the in-run parity gate against the CPU port')
     ap.add_argument('--no-resident', action='store_true', help='time only the two-launch dense path')
     ap.add_argument('--dagger-update', action='store_true',
                     help='secondary measurement: DAGGER updates/s at B=20 (prints its own JSON line and exits)')
@@ -447,15 +542,12 @@ def main():
     if ro.factored_supported() and not args.no_resident:
         ro.restart(1000 + rank)
         el_fact = timed(ro.run_resident)                         # policy_rollout: factored path, state carried between calls
-    # all are complete implementations of the same step; the headline is whichever ran faster at this --steps (tiny
-    # step counts cannot amortise the resident kernel's state load / store and first-launch cost)
+    # every path is a complete implementation of the same step; which one is `value` depends on the SHAPE only
     timed_resident = resident
-    resident = resident and el_res <= el_two
-    el = el_res if resident else el_two
-    factored = el_fact is not None and el_fact <= el
-    if factored:
-        el = el_fact
+    factored = el_fact is not None
+    el = el_fact if factored else (el_res if resident else el_two)
     finite = bool(torch.isfinite(ro.sim.x).all().item())
+    deg = mean_degree(ro.state)
 
     out = None
     if rank == 0:
@@ -475,9 +567,13 @@ def main():
                                     ("resident: all %d timed steps in one mgp_rollout_steps launch per GPU "
                                      "(episode state in LDS)" % args.steps) if resident else
                                     "two_launch: mgp_actor_fwd + mgp_flock_step_advance per step (HIP graph)",
+                       "step_path_rule": "by shape: resident if mgp_rollout_supported (N <= 256, widths <= 64), factored if "
+                                         "N > 256 and mgp_sparse_policy_supported, else two_launch",
                        "episodes_per_gpu": B, "episodes_total": total_eps, "agents": N, "taps": K,
                        "graph_steps": gs, "weights": ro.weights, "parallelism": "episodes sharded x%d, no "
-                       "data-path collective" % world, "state_finite": finite},
+                       "data-path collective" % world, "state_finite": finite,
+                       "mean_degree": deg, "init": "jittered lattice (FlockParams.init_mode='grid'), %d steps since reset "
+                       "at the end of the timed region" % ro.state._pushes},
             "paths": {"two_launch": {"ms_per_step": 1e3 * el_two / args.steps,
                                      "value": total_eps * N * args.steps / el_two, "graph_steps": gs}},
         }
@@ -491,41 +587,63 @@ def main():
     if rank == 0 and not args.no_roofline:
         res, n_sets = kernel_rooflines(device, B, N, K, ro.actor, ro.sim._c)
         fused = getattr(ro.actor, 'use_fused', False) and ro.actor.ind_agg == 0
-        dom = res['actor_fwd'] if fused else res['agg_fwd']
-        kname = "actor_fwd_kernel (aggregation X.G + MFMA filter/MLP, fused)" if fused else "agg_fwd_kernel (aggregation X.G)"
-        dense = {"kernel": kname, "bound": "hbm", "achieved": dom['gbs'], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": dom['gbs'] / HBM_PEAK_GBS,
-                 "traffic": pmc_traffic('actor_fwd_kernel' if fused else 'agg_fwd_kernel', B, N, K),
-                 "algorithmic_bytes_per_launch": dom['bytes'], "avg_launch_ms": dom['ms'],
-                 "rotating_input_sets": n_sets,
-                 "aggregation_alone": {"kernel": "agg_fwd_kernel", "GBps": res['agg_fwd']['gbs'],
-                                       "frac": res['agg_fwd']['gbs'] / HBM_PEAK_GBS,
-                                       "algorithmic_bytes_per_launch": res['agg_fwd']['bytes'],
-                                       "avg_launch_ms": res['agg_fwd']['ms']}}
+
+        def hbm_block(key, kname, pmc_name):
+            r = res[key]
+            tr, tr_note = pmc_traffic(pmc_name, B, N, K) if pmc_name else (None, 'not profiled')
+            return {"kernel": kname, "bound": "hbm", "achieved": r['gbs'], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": r['gbs'] / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_note,
+                    "algorithmic_bytes_per_launch": r['bytes'], "avg_launch_ms": r['ms'],
+                    "sq": pmc_sq(pmc_name) if pmc_name else None}
+        # HBM-roofline figures of the kernels that stream the dense operator G (B,K,N,N) from HBM on every launch --
+        # north_star's "fraction of HBM roofline for the S^k X aggregation" -- measured live with HIP events on the
+        # launch stream over rotating input sets larger than the Infinity Cache; algorithmic bytes per SURVEY.md 8(d)
+        dense = {
+            "actor_fwd": hbm_block('actor_fwd', "actor_fwd_kernel (aggregation X.G + MFMA filter/MLP, fused): "
+                                   "4KN^2 + 4KFN + 4 nA N bytes per episode", 'actor_fwd_kernel'),
+            "agg_fwd": hbm_block('agg_fwd', "agg_fwd_kernel (aggregation X.G alone): 4KN^2 + 8KFN bytes per episode",
+                                 'agg_fwd_kernel'),
+            "sim_state_step": hbm_block('sim_state_step', "flock_step_kernel<advance> (sim step + delayed-GSO / delay-line "
+                                        "transition, fused)", 'flock_step_kernel'),
+            "rotating_input_sets": n_sets,
+        }
         if resident:
-            # dominant (only) kernel of the timed region.  Algorithmic bytes = SURVEY 8(d) per-unit figure of the
-            # dense-contract aggregation (4KN^2 + 8KFN per episode-step) x episode-steps one launch processes.
+            # dominant (only) kernel of the timed region.  Its one roofline-shaped resource is the matrix pipe (filter GEMM +
+            # hidden layers on fp32 MFMA); nothing streams from HBM.  achieved = ALGORITHMIC flops of the MFMA-run layers
+            # (2 N sum_l cin_l cout_l per episode-step, hidden layers only) / launch duration.
             n_launch = (args.steps + 1999) // 2000
-            alg = (4 * K * N * N + 8 * K * F_FEAT * N) * B * args.steps / n_launch
+            spl = args.steps // n_launch
+            dims = [F_FEAT * K] + hidden
+            flops_unit = 2.0 * N * sum(a * b_ for a, b_ in zip(dims[:-1], dims[1:]))
+            flops = flops_unit * B * spl
             ms = res_launch_ms / n_launch
-            tr = pmc_traffic('rollout_kernel', B, N, K, steps_per_launch=args.steps // n_launch)
-            out["roofline"] = {"kernel": "rollout_kernel (episode-resident: power-iterated aggregation + MFMA filter/MLP "
-                                         "+ sim step + neighbour lists, %d steps per launch)" % (args.steps // n_launch),
-                               "bound": "hbm", "achieved": alg / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": alg / ms / 1e6 / HBM_PEAK_GBS, "traffic": tr,
-                               "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms,
-                               "steps_per_launch": args.steps // n_launch, "resident": True,
-                               "note": "equivalent rate: the bytes the dense-contract aggregation WOULD stream for these "
-                                       "steps / launch time.  Inside the launch the operator exists only as neighbour "
-                                       "lists in LDS (y_j = x_{t-j} A_t .. A_{t-j+1}, left to right), so HBM moves only "
-                                       "`traffic` (state in/out + rewards); the kernel is issue/latency bound, not HBM "
-                                       "bound.  HBM-roofline fractions of the kernels that stream the dense operator "
-                                       "from HBM every step are under dense_kernels.",
-                               "dense_kernels": dense}
+            alg = (4 * K * N * N + 8 * K * F_FEAT * N) * B * spl
+            tr, tr_note = pmc_traffic('rollout_kernel', B, N, K, steps_per_launch=spl)
+            out["roofline"] = {
+                "kernel": "rollout_kernel (episode-resident: power-iterated aggregation along neighbour lists + fp32-MFMA "
+                          "filter/MLP + sim step + neighbour lists, %d steps per launch)" % spl,
+                "bound": "mfma", "achieved": flops / ms / 1e9, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": flops / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, "traffic": tr, "traffic_source": tr_note,
+                "algorithmic_flops_per_launch": flops, "algorithmic_flops_per_episode_step": flops_unit,
+                "avg_launch_ms": ms, "steps_per_launch": spl, "resident": True,
+                "limiter": "instruction issue / LDS latency / workgroup barriers: one workgroup per CU, the episode's state "
+                           "in LDS; neither HBM (traffic = state in/out + 8 B of reward per step) nor the matrix pipe "
+                           "(sq.mfma_busy) is saturated -- the fractions in `sq` are the evidence",
+                "sq": pmc_sq('rollout_kernel'),
+                "equivalent_hbm": {"GBps": alg / ms / 1e6, "frac_of_peak": alg / ms / 1e6 / HBM_PEAK_GBS,
+                                   "algorithmic_bytes_per_launch": alg,
+                                   "note": "NOT a roofline fraction: the bytes the dense-contract aggregation (4KN^2 + 8KFN "
+                                           "per episode-step, SURVEY.md 8d) WOULD stream for these steps / launch time; "
+                                           "inside the launch the operator exists only as neighbour lists in LDS"},
+                "dense_kernels": dense}
         else:
-            out["roofline"] = dense
+            out["roofline"] = dict(dense["actor_fwd" if fused else "agg_fwd"], dense_kernels=dense)
         out["kernels"] = {k: {"avg_launch_ms": v['ms'], "algorithmic_bytes": v['bytes'], "GBps": v['gbs']}
                           for k, v in res.items()}
+    parity = None
+    if rank == 0 and not args.no_parity:
+        parity = parity_gate(ro)
+        out["parity"] = parity
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, K, hidden)
     if rank == 0:
@@ -533,6 +651,9 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if parity is not None and not parity["ok"]:
+        sys.stderr.write("bench.py: PARITY GATE FAILED: max_rel %.3g > %.1g\n" % (parity["max_rel"], PARITY_TOL))
+        sys.exit(3)
 
 
 if __name__ == '__main__':

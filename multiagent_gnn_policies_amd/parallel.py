@@ -29,7 +29,8 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rk = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not (dist.is_available() and dist.is_initialized()):
+    force = os.environ.get('MGP_FORCE_DIST') == '1'          # world-size-1 process group (RCCL bring-up on one GPU)
+    if (world > 1 or force) and not (dist.is_available() and dist.is_initialized()):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -73,10 +74,29 @@ class FlatGradSync(object):
         return flat
 
 
+def _comm_device():
+    """Device collectives run on: the rank's GPU under RCCL ("nccl"), the host under gloo."""
+    if dist.get_backend() == 'nccl':
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
+
+
 def all_gather_floats(values):
-    """Gather a python list of floats from every rank (episode rewards for mean/std)."""
+    """Gather a list of floats (episode rewards for mean / std, reference gnn_dagger.py:235-237) from every rank, rank
+    order preserved.  Two fixed-shape tensor collectives -- the counts, then the values padded to the longest list -- as
+    fp64, so the statistics equal a single-process run's bit for bit; no pickling (all_gather_object would serialise
+    through a byte tensor and, under RCCL, bounce it through the GPU twice)."""
     if not is_distributed():
         return list(values)
-    out = [None] * dist.get_world_size()
-    dist.all_gather_object(out, list(values))
-    return [v for part in out for v in part]
+    dev, world = _comm_device(), dist.get_world_size()
+    n = torch.tensor([len(values)], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    width = max(max(counts), 1)
+    mine = torch.zeros((width,), dtype=torch.float64, device=dev)
+    if len(values):
+        mine[:len(values)] = torch.tensor([float(v) for v in values], dtype=torch.float64)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return [float(v) for part, c in zip(parts, counts) for v in part[:c].cpu().tolist()]

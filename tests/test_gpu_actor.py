@@ -57,6 +57,15 @@ def test_actor_forward_backward_vs_reference(name, fused):
     assert relerr(got, exact) <= TOL + ref_noise
     if not int(g['dense']):
         assert relerr(got, g['out']) <= TOL          # realistic operators: the plain 1e-5 bar holds
+        # ... and it holds as an ABSOLUTE bound (max|gpu - cpu| <= 1e-5), elementwise, even where
+        # the shipped checkpoint drives outputs to |33| (1 ulp = 3.8e-6 there); against the exact result the kernel is
+        # within 4 ulp of the largest output
+        abs_err = float(np.max(np.abs(got.astype(np.float64) - g['out'].astype(np.float64))))
+        ulp = float(np.spacing(np.float32(np.max(np.abs(g['out'])))))
+        print('%s fused=%s: max abs err vs reference %.3g (%.2f ulp of max|out| = %.3g), vs exact %.3g' % (
+            name, fused, abs_err, abs_err / ulp, float(np.max(np.abs(g['out']))), float(np.max(np.abs(got - exact)))))
+        assert abs_err <= 1e-5
+        assert float(np.max(np.abs(got - exact))) <= max(4.0 * ulp, 2e-6)
     # parameter gradients of mse_loss against the reference's autograd
     from multiagent_gnn_policies_amd import ops
     loss = ops.mse_loss(out, torch.from_numpy(g['target']).cuda())

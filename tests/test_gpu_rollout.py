@@ -10,8 +10,24 @@ pytestmark = pytest.mark.gpu
 
 
 def relerr(a, b):
+    """state comparisons (positions, operator slices, features): max |a - b| relative to the scale of the tensor"""
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
     return float(np.max(np.abs(a - b)) / max(1.0, float(np.max(np.abs(b)))))
+
+
+def elem_err(a, b):
+    """action parity (north_star's 1e-5): ELEMENTWISE max |a - b| / max(1, |b|)"""
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+
+
+def strict_case(K, hidden, variant):
+    """The shipped checkpoint on a mean-pooling flock at the spec's own density: the plain elementwise 1e-5 bound, no
+    allowance.  (The other cases scale default-init weights x3, sum instead of average over neighbours, or crowd the lattice
+    until 1/r^4 features reach 1e4; there the reference op sequence evaluated in fp32 is itself 1e-5 or further from the
+    exact result, and a multiple of THAT distance is allowed on top, still elementwise.)"""
+    return (K == 3 and tuple(hidden) == (32, 32) and 'grid_spacing' not in variant
+            and variant.get('mean_pooling', True))
 
 
 def _make(N, K, hidden, B, seed, **variant):
@@ -108,8 +124,8 @@ def test_rollout_single_steps_match_oracle(N, K, hidden, variant):
         ref_u = oa.forward(X0, G0, Ws, bs, 0, dtype=np.float64)
         # crowded lattices make 1/r^4 features O(1e4): there the reference op sequence in fp32 is itself further than 1e-5
         # from the exact result, and a multiple of that rounding noise is allowed on top (as in test_gpu_fuzz)
-        noise = relerr(oa.forward(X0, G0, Ws, bs, 0, dtype=np.float32), ref_u)
-        assert relerr(u, ref_u) <= 1e-5 + 10.0 * noise, (step, relerr(u, ref_u), noise)
+        noise = 0.0 if strict_case(K, hidden, variant) else elem_err(oa.forward(X0, G0, Ws, bs, 0, dtype=np.float32), ref_u)
+        assert elem_err(u, ref_u) <= 1e-5 + 10.0 * noise, (step, elem_err(u, ref_u), noise)
         for b in range(B):
             ub = u[b, 0].T.astype(np.float32)                              # (N,2), the action the kernel applied
             x_ref, vals, net, r = ofl.step(x0[b], ub, op)
@@ -175,11 +191,14 @@ def test_rollout_in_launch_chain_matches_oracle(N, K, hidden, variant):
         assert policy_rollout(actor, sim, st, 1)
     x0, G0, X0 = _snapshot(sim, st)
     ref = oa.forward(X0, G0, Ws, bs, 0, dtype=np.float64)
-    noise = relerr(oa.forward(X0, G0, Ws, bs, 0, dtype=np.float32), ref)
+    noise = elem_err(oa.forward(X0, G0, Ws, bs, 0, dtype=np.float32), ref)
     _, op, actor, sim, st = _make(N, K, hidden, B, seed=11, **v)
     action = torch.zeros((B, 1, 2, N), device='cuda')
     assert policy_rollout(actor, sim, st, T, action=action)
-    assert relerr(action.cpu().numpy(), ref) <= 2e-5 + 10.0 * noise, (relerr(action.cpu().numpy(), ref), noise)
+    # (the two runs reach states ~1e-6 apart -- dt = 1e-7 is small, not zero -- hence 2e-5 and the noise allowance here;
+    #  the multi-step launch is held to the plain elementwise 1e-5 in tests/test_gpu_headline_parity.py, where the state
+    #  the launch consumed is reproduced bit for bit)
+    assert elem_err(action.cpu().numpy(), ref) <= 2e-5 + 10.0 * noise, (elem_err(action.cpu().numpy(), ref), noise)
     x1, G1, X1 = _snapshot(sim, st)
     # and the exit state: one oracle transition from the checked state, with the action the long launch applied
     for b in range(B):

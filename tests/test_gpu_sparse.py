@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import actor as oa, flock as ofl, state as os_
-from test_gpu_rollout import _make, _snapshot, _weights_np, relerr
+from test_gpu_rollout import _make, _snapshot, _weights_np, relerr, elem_err
 
 pytestmark = pytest.mark.gpu
 
@@ -53,10 +53,10 @@ def test_sparse_rollout_matches_oracle_step_by_step(N, K, hidden, variant):
             assert np.array_equal(got, h['network'].astype(np.float32)), "network bits / weights must be exact"
             assert relerr(sp.feat[b, sp.cur, :, :6].cpu().numpy(), h['values'].astype(np.float32)) <= 1e-6
         ref = oa.forward(X.astype(np.float32), G.astype(np.float32), Ws, bs, 0, dtype=np.float64)
-        noise = relerr(oa.forward(X.astype(np.float32), G.astype(np.float32), Ws, bs, 0, dtype=np.float32), ref)
+        noise = elem_err(oa.forward(X.astype(np.float32), G.astype(np.float32), Ws, bs, 0, dtype=np.float32), ref)
         sparse_policy_rollout(actor, sim, sp, 1, rewards=rewards, action=action)
         u = action.cpu().numpy()
-        assert relerr(u, ref) <= 1e-5 + 10.0 * noise, (step, relerr(u, ref), noise)
+        assert elem_err(u, ref) <= 1e-5 + 10.0 * noise, (step, elem_err(u, ref), noise)     # elementwise
         for b in range(B):
             x2, vals, net, r = ofl.step(xs[b], u[b, 0].T.astype(np.float32), op)
             assert np.array_equal(sim.x[b].cpu().numpy(), x2), "integration must be bit-exact fp64 given the action"

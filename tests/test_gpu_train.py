@@ -162,7 +162,9 @@ def test_bench_single_gpu_contract_and_paths(n, k, paths):
                 'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
         assert key in d, key
     assert set(d['paths']) == paths and d['config']['state_finite']
-    assert d['value'] == max(v['value'] for v in d['paths'].values())
+    headline = 'factored' if 'factored' in paths else ('resident' if 'resident' in paths else 'two_launch')   # by shape
+    assert d['value'] == d['paths'][headline]['value']
+    assert d['parity']['ok'] and d['parity']['tol'] == 1e-5 and {'max_abs', 'max_rel'} <= set(d['parity'])
     assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(d['roofline'])
 
 

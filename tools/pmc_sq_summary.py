@@ -13,6 +13,7 @@ import sys
 
 
 def main(path):
+    import sys
     db = sqlite3.connect(path)
     rows = db.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
                       "group by kernel_name, counter_name").fetchall()
@@ -48,6 +49,25 @@ def main(path):
             # one matrix pipe per SIMD, four SIMDs per CU: busy cycles are summed over the SIMDs
             print("    %-28s %15.1f%%  of (busy CU cycles x 4 SIMDs)" % ('matrix pipe busy', 100.0 * v['SQ_VALU_MFMA_BUSY_CYCLES'] /
                                                                         (4.0 * v['SQ_BUSY_CU_CYCLES'])))
+
+
+    if len(sys.argv) > 2:                                       # machine-readable fractions for bench.py's roofline.sq
+        import json
+        out = {}
+        for k, v in per.items():
+            wc = v.get('SQ_WAVE_CYCLES')
+            if not wc:
+                continue
+            o = {"wait_any": v.get('SQ_WAIT_ANY', 0.0) / wc, "wait_inst_any": v.get('SQ_WAIT_INST_ANY', 0.0) / wc,
+                 "active_inst_any": v.get('SQ_ACTIVE_INST_ANY', 0.0) / wc, "launches": v['_n'],
+                 "avg_launch_us": v.get('_us'), "valu_insts": v.get('SQ_INSTS_VALU'), "mfma_f32_insts": v.get('SQ_INSTS_VALU_MFMA_F32')}
+            if v.get('SQ_BUSY_CU_CYCLES'):
+                o["mfma_busy"] = v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (4.0 * v['SQ_BUSY_CU_CYCLES'])
+            out[k] = o
+        out['_meta'] = {"units": "fractions of SQ_WAVE_CYCLES (wave residency); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / "
+                                 "(4 SIMDs x SQ_BUSY_CU_CYCLES)", "probe_T": __import__('os').environ.get('PROBE_T', '1000')}
+        with open(sys.argv[2], 'w') as f:
+            json.dump(out, f, indent=1)
 
 
 if __name__ == '__main__':

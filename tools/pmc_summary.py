@@ -37,6 +37,20 @@ def main():
         wr = write.get(k, (0, 0.0))[1] * 1024.0
         res[k] = dict(read_bytes=rd, write_bytes=wr, total_bytes=rd + wr, launches=fetch.get(k, (0, 0))[0])
         print("%-28s %8d %14.3f %14.3f %14.3f" % (k, res[k]['launches'], rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
+    # optional: a second FETCH/WRITE pair taken with another PROBE_T (argv[5], argv[6], its T in argv[7]) turns the
+    # resident kernel's bytes per launch into bytes(T) = fixed + per_step * T (state in/out once, 8 B of reward per step)
+    if len(sys.argv) > 7:
+        f2 = per_kernel(sys.argv[5], 'FETCH_SIZE'); w2 = per_kernel(sys.argv[6], 'WRITE_SIZE')
+        import os as _os
+        T1, T2 = int(_os.environ.get('PROBE_T', '1000')), int(sys.argv[7])
+        for k in list(res):
+            if k.startswith('rollout') and k in f2 and k in w2:
+                b1 = res[k]['total_bytes']
+                b2 = 2.0 * f2[k][1] * 1024.0 + w2[k][1] * 1024.0
+                per_step = (b1 - b2) / float(T1 - T2)
+                res[k + '_model'] = dict(bytes_per_step=per_step, fixed_bytes=b1 - per_step * T1, T=[T1, T2], bytes=[b1, b2])
+                print("%-28s bytes(T) = %.0f + %.1f * T   (from launches of %d and %d steps: %.3f MB, %.3f MB)" % (
+                    k + '_model', b1 - per_step * T1, per_step, T1, T2, b1 / 1e6, b2 / 1e6))
     if len(sys.argv) > 3:
         import os
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
