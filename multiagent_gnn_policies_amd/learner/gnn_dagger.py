@@ -74,7 +74,14 @@ class GraphedUpdate(object):
     """One DAGGER update captured once per batch size as a HIP graph on static buffers and replayed with one host call
     instead of ~40 Python-level ops.  Two launches when mgp_train_step covers the shape (forward + MSE gradient +
     backward per 16-column tile, then partial reduction + device-step Adam); otherwise five (fused forward with saved
-    activations -> MSE gradient -> fused backward straight into the flat gradient buffer -> device-step Adam)."""
+    activations -> MSE gradient -> fused backward straight into the flat gradient buffer -> device-step Adam).
+
+    Data-parallel runs (torch.distributed initialised, world > 1) use the same object: gradients into the flat buffer
+    (mgp_train_grads: two launches, or forward / MSE / backward), ONE in-place all-reduce of that 6,920-byte buffer, the
+    1/world scale, device-step Adam.  Under RCCL ("nccl") the whole sequence INCLUDING the collective is captured into the
+    graph, so an update is still one host call; where the collective cannot be captured (gloo, or a runtime that refuses)
+    the same pre-bound sequence is enqueued eagerly: four kernel launches + one collective, no tensor construction, no
+    autograd, no host synchronisation."""
 
     def __init__(self, learner, B):
         import ctypes
@@ -102,9 +109,16 @@ class GraphedUpdate(object):
         self.B, self.K, self.N, self.nl = B, K, N, actor.n_layers
         self.opt = opt
         self.graph = None
-        self.two_launch = bool(learner.use_train_step and L.mgp_train_supported(self.cdims, actor.n_layers, B, K, N))
-        if self.two_launch:
+        self.dist = parallel.is_distributed()
+        self.world = parallel.world_size()
+        fused_train = bool(learner.use_train_step and L.mgp_train_supported(self.cdims, actor.n_layers, B, K, N))
+        self.two_launch = fused_train and not self.dist          # reduction + Adam fused: no room for a collective
+        self.train_grads = fused_train and self.dist             # gradients only, Adam after the all-reduce
+        if fused_train:
             self.tws = torch.zeros((L.mgp_train_workspace(self.cdims, actor.n_layers, B, K, N),), device=dev)
+        # the collective is captured into the HIP graph under RCCL; gloo moves data through the host and cannot be
+        self.capturable = (not self.dist) or (torch.distributed.get_backend() == 'nccl'
+                                              and os.environ.get('MGP_DIST_GRAPH', '1') != '0')
 
     def _enqueue(self):
         from .. import _lib
@@ -117,12 +131,22 @@ class GraphedUpdate(object):
                                         ops._ptr(self.loss), ops._ptr(self.tws), self.B, self.K, self.N, st),
                        'mgp_train_step')
             return
-        _lib.check(L.mgp_actor_fwd(ops._ptr(self.X), ops._ptr(self.G), self.Wp, self.bp, self.cdims, self.nl,
-                                   ops._ptr(self.out), ops._ptr(self.saved), self.B, self.K, self.N, st), 'mgp_actor_fwd')
-        _lib.check(L.mgp_mse_grad(ops._ptr(self.out), ops._ptr(self.Y), ops._ptr(self.dOut), ops._ptr(self.loss),
-                                  self.out.numel(), st), 'mgp_mse_grad')
-        _lib.check(L.mgp_actor_bwd(ops._ptr(self.dOut), ops._ptr(self.saved), self.Wp, self.cdims, self.nl, self.dWp,
-                                   self.dbp, self.B, self.K, self.N, ops._ptr(self.ws), st), 'mgp_actor_bwd')
+        if self.train_grads:
+            _lib.check(L.mgp_train_grads(ops._ptr(self.X), ops._ptr(self.G), ops._ptr(self.Y), self.Wp, self.bp, self.cdims,
+                                         self.nl, ops._ptr(o.flat_grad), ops._ptr(self.loss), ops._ptr(self.tws),
+                                         self.B, self.K, self.N, st), 'mgp_train_grads')
+        else:
+            _lib.check(L.mgp_actor_fwd(ops._ptr(self.X), ops._ptr(self.G), self.Wp, self.bp, self.cdims, self.nl,
+                                       ops._ptr(self.out), ops._ptr(self.saved), self.B, self.K, self.N, st), 'mgp_actor_fwd')
+            _lib.check(L.mgp_mse_grad(ops._ptr(self.out), ops._ptr(self.Y), ops._ptr(self.dOut), ops._ptr(self.loss),
+                                      self.out.numel(), st), 'mgp_mse_grad')
+            _lib.check(L.mgp_actor_bwd(ops._ptr(self.dOut), ops._ptr(self.saved), self.Wp, self.cdims, self.nl, self.dWp,
+                                       self.dbp, self.B, self.K, self.N, ops._ptr(self.ws), st), 'mgp_actor_bwd')
+        if self.dist:
+            # the ONE exchange of a data-parallel update: 1,730 floats, in place, summed then scaled (reference semantics
+            # of a world-times larger minibatch); latency-bound, so never split per tensor
+            torch.distributed.all_reduce(o.flat_grad, op=torch.distributed.ReduceOp.SUM)
+            o.flat_grad.mul_(1.0 / self.world)
         _lib.check(L.mgp_adam_step_dev(ops._ptr(o.flat), ops._ptr(o.flat_grad), ops._ptr(o.m), ops._ptr(o.v),
                                        o.flat.numel(), o.lr, o.betas[0], o.betas[1], o.eps, ops._ptr(self.step_dev), st),
                    'mgp_adam_step_dev')
@@ -135,12 +159,25 @@ class GraphedUpdate(object):
             self.G.copy_(G)
         if Y is not self.Y:
             self.Y.copy_(Y)
-        if self.graph is None:
+        if self.graph is None and self.capturable:
             torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self._enqueue()
-        self.graph.replay()
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):
+                    self._enqueue()
+                self.graph = graph
+            except Exception as e:                    # e.g. a collective the runtime refuses to capture: stay eager, loudly
+                if not self.dist:
+                    raise
+                import warnings
+                warnings.warn("data-parallel update: HIP-graph capture of the all-reduce failed (%s); updates are enqueued "
+                              "eagerly (same kernels, same collective)" % (e,), RuntimeWarning)
+                self.capturable = False
+                torch.cuda.synchronize()
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._enqueue()
         self.opt.step_count += 1
         return self.loss
 
@@ -173,11 +210,11 @@ class DAGGER(object):
         self._train_ws = {}                       # batch size -> workspace of the eager mgp_train_grads path
 
     def _can_graph(self, X):
-        """Single-process runs whose shape the fused kernels cover replay the update from a HIP graph; the
-        data-parallel path stays eager because the flat-gradient all-reduce sits between backward and Adam."""
+        """Runs whose shape the fused kernels cover go through GraphedUpdate: a HIP-graph replay per update (the
+        data-parallel all-reduce included, under RCCL), or the same pre-bound launch sequence enqueued eagerly (gloo)."""
         import ctypes
         from .. import _lib
-        if not self.use_graphed_update or parallel.is_distributed() or not self.actor.use_fused:
+        if not self.use_graphed_update or not self.actor.use_fused:
             return False
         dims = tuple(self.actor.layers)
         cd = (ctypes.c_int * len(dims))(*dims)
