@@ -94,6 +94,7 @@ class Rollout(object):
         self.sim.reset(np.random.RandomState(seed))
         self.state.push(self.sim.network, self.sim.features)
         self._rw = None
+        self._image = None        # prebuilt weight image of the resident kernel (the weights are fixed for the whole run)
 
     def step(self):
         with torch.no_grad():
@@ -118,13 +119,15 @@ class Rollout(object):
 
     def run_resident(self, n_steps, chunk=2000):
         """n_steps env steps on the episode-resident kernel (launches of <= chunk steps)."""
-        from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
+        from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout, rollout_image_for
+        if self._image is None and self.resident_supported():
+            self._image = rollout_image_for(self.actor, self.K, self.N)
         done = 0
         while done < n_steps:
             t = min(chunk, n_steps - done)
             if self._rw is None or self._rw.shape[1] != t:
                 self._rw = torch.zeros((self.B, t), device=self.sim.device, dtype=torch.float64)
-            assert policy_rollout(self.actor, self.sim, self.state, t, rewards=self._rw)
+            assert policy_rollout(self.actor, self.sim, self.state, t, rewards=self._rw, image=self._image)
             done += t
 
 

@@ -225,6 +225,36 @@ int mgp_rollout_steps(double* x, float* G, float* Xd, const float* const* W, con
                       const int* dims, int n_layers, float* action, double* rewards,
                       const MgpFlockParams* p, int B, int K, int N, int T, void* stream);
 
+/* The same launch for callers that launch REPEATEDLY (the chunked evaluation loops of gnn_dagger.py:190-232, test_model.py,
+ * bench.py): what a launch costs besides its steps is then handed over instead of recomputed.
+ *   image   prebuilt weight image (mgp_rollout_image: the MFMA fragment layout the kernel otherwise derives from W, b at
+ *           every launch), 16-byte aligned, or NULL (then W, b are read; with an image W and b may be NULL)
+ *   carry   B x mgp_rollout_carry_bytes(K, N) bytes: the operator history in FACTORED form -- per episode the membership
+ *           bits (row-major, 2 x u64 per row for N <= 128, 4 beyond) and row weights of the last max(K-1, 1) networks
+ *           A_t, A_{t-1}, ... (newest first).  An all-zero carry is the history of a reset observation.
+ *   flags   MGP_RO_ENTER_CARRY  the history comes from `carry`; the dense slices G[:,1:] are NOT read
+ *           MGP_RO_EXIT_CARRY   the history of the final state is written to `carry`
+ *           MGP_RO_SKIP_DENSE   G[:,1:] is NOT rebuilt on exit (requires MGP_RO_EXIT_CARRY): the dense operator the
+ *                               reference's contract names (state_with_delay.py:44-47) is then materialised on demand by
+ *                               mgp_rollout_carry_to_dense -- same arithmetic, same summation order as the in-launch rebuild
+ * With ENTER|EXIT the chain x_{t-j} A_t .. A_{t-j+1} never passes through rounded dense products, so ANY chunking of an
+ * episode into launches is bit-identical to one launch.  A launch that enters from dense slices can only hand over a
+ * complete history if it runs T >= K - 1 steps (else MGP_EINVAL with EXIT_CARRY / SKIP_DENSE).
+ * x and Xd (B,K,6,N) are always read on entry and written on exit (they are exact: integration and features are fp64). */
+#define MGP_RO_ENTER_CARRY 1
+#define MGP_RO_EXIT_CARRY 2
+#define MGP_RO_SKIP_DENSE 4
+int mgp_rollout_steps_ex(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
+                         const int* dims, int n_layers, float* action, double* rewards,
+                         const MgpFlockParams* p, int B, int K, int N, int T, const float* image, void* carry, int flags,
+                         void* stream);
+long mgp_rollout_image_floats(const int* dims, int n_layers, int K, int N);      /* 0: shape not covered */
+int mgp_rollout_image(const float* const* W, const float* const* b, const int* dims, int n_layers, int K, int N,
+                      float* image, void* stream);
+long mgp_rollout_carry_bytes(int K, int N);                                       /* per episode; 0: shape not covered */
+/* G[:,j] = A_t A_{t-1} .. A_{t-j+1} for j = 1..K-1 from a carry (slice 0, the identity, is not touched). */
+int mgp_rollout_carry_to_dense(const void* carry, float* G, int B, int K, int N, void* stream);
+
 /* Expert controller on the current x: u (B,N,2) fp32 and/or u64 (B,N,2) fp64 (either may be NULL). */
 int mgp_flock_controller(const double* x, float* u, double* u64, const MgpFlockParams* p,
                          int centralized, int B, int N, void* stream);

@@ -56,6 +56,12 @@ SIGNATURES = {
     'mgp_rollout_supported': (_int, [_vp, _int, _int, _int]),
     'mgp_rollout_steps': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, ctypes.POINTER(MgpFlockParams),
                                 _int, _int, _int, _int, _vp]),
+    'mgp_rollout_steps_ex': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, ctypes.POINTER(MgpFlockParams),
+                                   _int, _int, _int, _int, _vp, _vp, _int, _vp]),
+    'mgp_rollout_image_floats': (_long, [_vp, _int, _int, _int]),
+    'mgp_rollout_image': (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
+    'mgp_rollout_carry_bytes': (_long, [_int, _int]),
+    'mgp_rollout_carry_to_dense': (_int, [_vp, _vp, _int, _int, _int, _vp]),
     'mgp_flock_controller': (_int, [_vp, _vp, _vp, ctypes.POINTER(MgpFlockParams), _int, _int, _int, _vp]),
     'mgp_mse_grad': (_int, [_vp, _vp, _vp, _vp, _long, _vp]),
     'mgp_adam_step': (_int, [_vp, _vp, _vp, _vp, _long, _f32, _f32, _f32, _f32, _int, _vp]),

@@ -62,6 +62,7 @@ struct RoParams {
     int dims[MGP_MAX_LAYERS + 1];         // 6, h1, ..., 2
     int woff[MGP_MAX_LAYERS];             // offset (floats) of layer l's fragment block inside the weight image
     int n_layers;
+    int wtot;                             // floats in the weight image
 };
 
 // LDS layout (byte offsets).  Every region except the weight image depends on (N, K) only, and the weight image comes
@@ -88,6 +89,16 @@ __host__ __device__ constexpr int ro_hist(int K) { return K > 2 ? K - 1 : 1; }
 // list row stride in bytes: room for N - 1 entries + 8 pad bytes, a multiple of 4 with an ODD word count -- neighbouring
 // lanes walk neighbouring rows, and an even word stride (112 B at N = 100) put them 8 to a bank
 __host__ __device__ constexpr int ro_list_stride(int N) { const int w = (N + 8 + 3) >> 2; return 4 * (w | 1); }
+
+// Factored hand-over of the operator history between launches ("carry"): per episode the membership BITS of the last
+// H = ro_hist(K) networks, newest first (slot 0 = A_t of the state, slot q = A_{t-q}; NW 64-bit words per row: 2 for
+// N <= 128, 4 beyond), then their row weights [H][N] fp32.  An all-zero carry is the history of a reset observation (no
+// earlier network exists: every product vanishes, as the reference's zero-filled slices do, state_with_delay.py:44-47).
+__host__ __device__ constexpr int ro_carry_nw(int N) { return N > 128 ? 4 : 2; }
+__host__ __device__ constexpr size_t ro_carry_words(int K, int N)     // 64-bit words per episode
+{
+    return (size_t)ro_hist(K) * N * ro_carry_nw(N) + ((size_t)ro_hist(K) * N * 4 + 7) / 8;
+}
 
 __host__ __device__ constexpr RoOff ro_offsets(int N, int K)
 {
@@ -117,7 +128,8 @@ __global__ __launch_bounds__(RO_THREADS)
 void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __restrict__ Xd, float* __restrict__ action,
                     double* __restrict__ rewards, RoParams P, MgpFlockParams p, int K_arg, int N_arg, int T,
                     unsigned long long dimsA, unsigned int dims8, unsigned long long woffA, unsigned long long woffB,
-                    int n_layers)
+                    int n_layers, const float* __restrict__ image, int image_floats, unsigned long long* __restrict__ carry,
+                    int flags)
 {
     const int N = CN ? CN : N_arg, K = CK ? CK : K_arg;
     const RoOff cv = ro_offsets(N, K);
@@ -160,30 +172,21 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     }
     if (tid == 0) { cref[0] = xb[0]; cref[1] = xb[1]; mmax[0] = 0u; }
     // weights in MFMA A-fragment order (see actor_fused.hip): wfrag[mt][lane][RO_WFS], lane = (c & 3) * 16 + (o & 15),
-    // slot s = c >> 2, zero padded; then the bias of the layer's MT*16 rows
-    for (int l = 0; l < P.n_layers; ++l) {
-        const int cin = (l == 0) ? FK : P.dims[l];
-        const int cout = P.dims[l + 1];
-        const int MT = mtiles(cout);
-        const int tot = MT * 64 * RO_WFS;
-        float* dst = wl + P.woff[l];
-        const float* src = P.W[l];
-        if (l == P.n_layers - 1) {
-            // the 2-wide output layer runs on the VALU of the integrating threads: plain pairs (W[0][c], W[1][c]) in
-            // channel order, zero padded to 32 channels, then the bias pair
-            for (int e = tid; e < 2 * 4 * RO_KS + 2; e += RO_THREADS) {
-                const int c = e >> 1, o = e & 1;
-                dst[e] = (c < 4 * RO_KS) ? ((c < cin) ? src[(size_t)o * cin + c] : 0.f) : P.b[l][o];
-            }
-            continue;
+    // slot s = c >> 2, zero padded; then the bias of the layer's MT*16 rows.  A caller that launches repeatedly with the
+    // same weights passes the image prebuilt (mgp_rollout_image: the same elements, computed once): a flat 16-byte copy.
+    if (image != nullptr) {
+        const float4* src4 = reinterpret_cast<const float4*>(image);
+        float4* dst4 = reinterpret_cast<float4*>(wl);
+        for (int e = tid; e < image_floats / 4; e += RO_THREADS) dst4[e] = src4[e];
+    } else {
+        for (int l = 0; l < P.n_layers; ++l) {
+            const int cin = (l == 0) ? FK : P.dims[l];
+            const int cout = P.dims[l + 1];
+            const bool last = l == P.n_layers - 1;
+            const int tot = ro_weight_image_size(cout, last);
+            float* dst = wl + P.woff[l];
+            for (int e = tid; e < tot; e += RO_THREADS) dst[e] = ro_weight_image_elem(P.W[l], P.b[l], cin, cout, last, e);
         }
-        for (int e = tid; e < tot; e += RO_THREADS) {
-            const int mt = e / (64 * RO_WFS), r1 = e - mt * (64 * RO_WFS);
-            const int ln = r1 / RO_WFS, sl = r1 - ln * RO_WFS;
-            const int c = 4 * sl + (ln >> 4), o = mt * 16 + (ln & 15);
-            dst[e] = (sl < RO_KS && o < cout && c < cin) ? src[(size_t)o * cin + c] : 0.f;
-        }
-        for (int o = tid; o < MT * 16; o += RO_THREADS) dst[tot + o] = (o < cout) ? P.b[l][o] : 0.f;
     }
     {
         float4* za = reinterpret_cast<float4*>(act);
@@ -193,6 +196,35 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         for (int i = tid; i < H * N; i += RO_THREADS) { rcnt[i] = 0; wrow[i] = 0.f; }
     }
     __syncthreads();
+    // history networks handed over in factored form (MGP_RO_ENTER_CARRY): bits -> ascending neighbour lists, four lanes per
+    // (network, row) as in phase D2; carry slot q = A_{t0 - q} goes to ring slot (H - q) % H, i.e. hs = 0 is the current
+    // network and every tap's product is available as lists from the first step on (t_off): the dense slices are not read
+    int t_off = 0;
+    const size_t cwords = ro_carry_words(K, N);
+    if (flags & MGP_RO_ENTER_CARRY) {
+        t_off = K - 1;
+        const unsigned long long* cb = carry + (size_t)b * cwords;
+        const float* cw = reinterpret_cast<const float*>(cb + (size_t)H * N * 2);
+        for (int it = tid; it < H * N * 4; it += RO_THREADS) {
+            const int cq = it & 3, rq = it >> 2, q = rq / N, row = rq - q * N;
+            const int slot = (q == 0) ? 0 : H - q;
+            const unsigned long long lo = cb[(size_t)rq * 2], hi = cb[(size_t)rq * 2 + 1];
+            const int cnt = __popcll(lo) + __popcll(hi);
+            unsigned int chunk; int pos;
+            if (cq == 0) { chunk = (unsigned int)lo; pos = 0; }
+            else if (cq == 1) { chunk = (unsigned int)(lo >> 32); pos = __popc((unsigned int)lo); }
+            else if (cq == 2) { chunk = (unsigned int)hi; pos = __popcll(lo); }
+            else { chunk = (unsigned int)(hi >> 32); pos = __popcll(lo) + __popc((unsigned int)hi); }
+            unsigned char* lp = rlist + ((size_t)slot * N + row) * RS;
+            while (chunk) { lp[pos++] = (unsigned char)(32 * cq + __builtin_ctz(chunk)); chunk &= chunk - 1u; }
+            lp[cnt + 2 * cq] = (unsigned char)N; lp[cnt + 2 * cq + 1] = (unsigned char)N;
+            if (cq == 0) {
+                rcnt[slot * N + row] = cnt;
+                wrow[slot * N + row] = cw[rq];
+                if (q == 0) { rowmask[2 * row] = lo; rowmask[2 * row + 1] = hi; }
+            }
+        }
+    }
     for (int e = tid; e < N * 8; e += RO_THREADS) {             // tap 0 of the first step (later steps: written in D3)
         const int f = e & 7, n = e >> 3;
         if (f < 6) act[n * RO_CS + rpos(f * K)] = XT[e];          // cur = 0: slot 0 holds tap 0
@@ -226,7 +258,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         // maintain.  No dense slice exists inside the launch.  The networks of the launch's own steps are known as lists;
         // products that reach back before the launch (the first K - 1 steps) end with one dense multiplication by the
         // caller's slice G_{j-hv}(t0), read from HBM.
-        const int hv = min(t, K - 1);                         // networks of this launch available as lists: A_t .. A_{t-hv+1}
+        const int hv = min(t + t_off, K - 1);                 // networks available as lists: A_t .. A_{t-hv+1}
         for (int q = 1; q <= hv; ++q) {
             const int j = q + gt;
             float sa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -499,8 +531,30 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     // Slices are produced in descending j (a slice that is still an input -- j - hv < j -- is overwritten later), with a
     // workgroup barrier between slices.  Row vectors ping-pong in the activation area (no longer needed).
     RO_STAMPX(10);
-    if (T > 0 && K >= 2) {
-        const int hv = min(T, K - 1);
+    // Factored hand-over (MGP_RO_EXIT_CARRY): bits + row weights of the last H networks, newest first.  The newest network's
+    // bits are still in rowmask (cleared in phase B only); older ones are folded back from their lists.
+    if (flags & MGP_RO_EXIT_CARRY) {
+        unsigned long long* cb = carry + (size_t)b * cwords;
+        float* cw = reinterpret_cast<float*>(cb + (size_t)H * N * 2);
+        for (int it = tid; it < H * N; it += RO_THREADS) {
+            const int q = it / N, row = it - q * N;
+            int hq = hs - q; hq = hq < 0 ? hq + H : hq;
+            unsigned long long lo = 0ull, hi = 0ull;
+            if (q == 0) { lo = rowmask[2 * row]; hi = rowmask[2 * row + 1]; }
+            else {
+                const unsigned char* lp = rlist + ((size_t)hq * N + row) * RS;
+                const int cnt = rcnt[hq * N + row];
+                for (int e = 0; e < cnt; ++e) {
+                    const int m = lp[e];
+                    if (m < 64) lo |= 1ull << m; else hi |= 1ull << (m - 64);
+                }
+            }
+            cb[(size_t)it * 2] = lo; cb[(size_t)it * 2 + 1] = hi;
+            cw[it] = wrow[hq * N + row];
+        }
+    }
+    if (T > 0 && K >= 2 && !(flags & MGP_RO_SKIP_DENSE)) {
+        const int hv = min(T + t_off, K - 1);
         float* rbuf = act + wave * 2 * Np;                    // [2][Np] per wave (16 x 2 x Np floats fit the activation area)
         for (int j = K - 1; j >= 1; --j) {
             const int nsp = min(j, hv);
@@ -603,7 +657,8 @@ __global__ __launch_bounds__(RO_THREADS)
 void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __restrict__ Xd, float* __restrict__ action,
                         double* __restrict__ rewards, RoParams P, MgpFlockParams p, int K, int N, int T,
                         unsigned long long dimsA, unsigned int dims8, unsigned long long woffA, unsigned long long woffB,
-                        int n_layers)
+                        int n_layers, const float* __restrict__ image, int image_floats, unsigned long long* __restrict__ carry,
+                        int flags)
 {
     const RbOff cv = rb_offsets(N, K);
     const int H = ro_hist(K);
@@ -641,31 +696,37 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
         spx[i] = xb[i * 4 + 0]; spy[i] = xb[i * 4 + 1]; svx[i] = xb[i * 4 + 2]; svy[i] = xb[i * 4 + 3];
     }
     if (tid == 0) { cref[0] = xb[0]; cref[1] = xb[1]; mmax[0] = 0u; }
-    // weights in MFMA A-fragment order (see actor_fused.hip): wfrag[mt][lane][RO_WFS], lane = (c & 3) * 16 + (o & 15),
-    // slot s = c >> 2, zero padded; then the bias of the layer's MT*16 rows
-    for (int l = 0; l < P.n_layers; ++l) {
-        const int cin = (l == 0) ? FK : P.dims[l];
-        const int cout = P.dims[l + 1];
-        const int MT = mtiles(cout);
-        const int tot = MT * 64 * RO_WFS;
-        float* dst = wl + P.woff[l];
-        const float* src = P.W[l];
-        if (l == P.n_layers - 1) {
-            // the 2-wide output layer runs on the VALU of the integrating threads: plain pairs (W[0][c], W[1][c]) in
-            // channel order, zero padded to 32 channels, then the bias pair
-            for (int e = tid; e < 2 * 4 * RO_KS + 2; e += RO_THREADS) {
-                const int c = e >> 1, o = e & 1;
-                dst[e] = (c < 4 * RO_KS) ? ((c < cin) ? src[(size_t)o * cin + c] : 0.f) : P.b[l][o];
-            }
-            continue;
+    if (image != nullptr) {                                   // prebuilt weight image (mgp_rollout_image): flat copy
+        const float4* src4 = reinterpret_cast<const float4*>(image);
+        float4* dst4 = reinterpret_cast<float4*>(wl);
+        for (int e = tid; e < image_floats / 4; e += RO_THREADS) dst4[e] = src4[e];
+    } else {
+        for (int l = 0; l < P.n_layers; ++l) {
+            const int cin = (l == 0) ? FK : P.dims[l];
+            const int cout = P.dims[l + 1];
+            const bool last = l == P.n_layers - 1;
+            const int tot = ro_weight_image_size(cout, last);
+            float* dst = wl + P.woff[l];
+            for (int e = tid; e < tot; e += RO_THREADS) dst[e] = ro_weight_image_elem(P.W[l], P.b[l], cin, cout, last, e);
         }
-        for (int e = tid; e < tot; e += RO_THREADS) {
-            const int mt = e / (64 * RO_WFS), r1 = e - mt * (64 * RO_WFS);
-            const int ln = r1 / RO_WFS, sl = r1 - ln * RO_WFS;
-            const int c = 4 * sl + (ln >> 4), o = mt * 16 + (ln & 15);
-            dst[e] = (sl < RO_KS && o < cout && c < cin) ? src[(size_t)o * cin + c] : 0.f;
+    }
+    // factored hand-over of the history networks (see rollout_kernel): carry slot q -> ring slot (H - q) % H, hs = 0
+    int t_off = 0;
+    const size_t cwords = ro_carry_words(K, N);
+    if (flags & MGP_RO_ENTER_CARRY) {
+        t_off = K - 1;
+        __syncthreads();                                      // (the zero fill of bits / wrow above)
+        const unsigned long long* cb = carry + (size_t)b * cwords;
+        const float* cw = reinterpret_cast<const float*>(cb + (size_t)H * N * RB_NW);
+        for (int it = tid; it < H * N * RB_NW; it += RO_THREADS) {
+            const int wd = it % RB_NW, rq = it / RB_NW, q = rq / N, row = rq - q * N;
+            const int slot = (q == 0) ? 0 : H - q;
+            bits[((size_t)slot * N + row) * RB_NW + wd] = cb[it];
         }
-        for (int o = tid; o < MT * 16; o += RO_THREADS) dst[tot + o] = (o < cout) ? P.b[l][o] : 0.f;
+        for (int it = tid; it < H * N; it += RO_THREADS) {
+            const int q = it / N, row = it - q * N;
+            wrow[((q == 0) ? 0 : H - q) * N + row] = cw[it];
+        }
     }
     {
         float4* za = reinterpret_cast<float4*>(act);
@@ -693,7 +754,7 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
         unsigned long long* rm_new = bits + (size_t)hsn * N * RB_NW;
         float* w_new = wrow + hsn * N;
         // -------------------------------------------------------------- A: aggregation, power-iterated along the bit rows
-        const int hv = min(t, K - 1);
+        const int hv = min(t + t_off, K - 1);
         for (int q = 1; q <= hv; ++q) {
             int hq = hs - (q - 1); hq = hq < 0 ? hq + H : hq;
             const unsigned long long* bq = bits + (size_t)hq * N * RB_NW;
@@ -943,8 +1004,22 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
     }
 
     // ------------------------------------------------------------------ exit (see rollout_kernel)
-    if (T > 0 && K >= 2) {
-        const int hv = min(T, K - 1);
+    if (flags & MGP_RO_EXIT_CARRY) {
+        unsigned long long* cb = carry + (size_t)b * cwords;
+        float* cw = reinterpret_cast<float*>(cb + (size_t)H * N * RB_NW);
+        for (int it = tid; it < H * N * RB_NW; it += RO_THREADS) {
+            const int wd = it % RB_NW, rq = it / RB_NW, q = rq / N, row = rq - q * N;
+            int hq = hs - q; hq = hq < 0 ? hq + H : hq;
+            cb[it] = bits[((size_t)hq * N + row) * RB_NW + wd];
+        }
+        for (int it = tid; it < H * N; it += RO_THREADS) {
+            const int q = it / N, row = it - q * N;
+            int hq = hs - q; hq = hq < 0 ? hq + H : hq;
+            cw[it] = wrow[hq * N + row];
+        }
+    }
+    if (T > 0 && K >= 2 && !(flags & MGP_RO_SKIP_DENSE)) {
+        const int hv = min(T + t_off, K - 1);
         float* rbuf = act + wave * 2 * Np;
         for (int j = K - 1; j >= 1; --j) {
             const int nsp = min(j, hv);
@@ -1014,36 +1089,96 @@ bool make_carve(const int* dims, int n_layers, int K, int N, RoParams* P, int* l
         if (P) { P->woff[l] = wtot; P->dims[l] = dims[l]; }
         wtot += mtiles(cout) * 64 * RO_WFS + mtiles(cout) * 16;
     }
-    if (P) { P->dims[n_layers] = dims[n_layers]; P->n_layers = n_layers; }
+    if (P) { P->dims[n_layers] = dims[n_layers]; P->n_layers = n_layers; P->wtot = wtot; }
     const int total = (N > RO_MAXN ? rb_offsets(N, K).wl : ro_offsets(N, K).wl) + wtot * 4;   // N > 128: rollout_big_kernel
     if (total > RO_LDS_LIMIT) return false;
     if (lds_bytes) *lds_bytes = total;
     return true;
 }
 
+// Dense slices of G from a carry (the lazy half of MGP_RO_SKIP_DENSE): row i of G_j = e_i . A_t . A_{t-1} ... A_{t-j+1},
+// left to right along the bit rows, the very loop (and summation order: ascending m) of the kernels' exit section.
+template <int NW>
+__global__ __launch_bounds__(RO_THREADS)
+void carry_to_dense_kernel(const unsigned long long* __restrict__ carry, float* __restrict__ G, int K, int N)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    const int H = ro_hist(K), Np = (N + 3) & ~3;
+    unsigned long long* bits = reinterpret_cast<unsigned long long*>(smraw);                 // [H][N][NW]
+    float* wr = reinterpret_cast<float*>(bits + (size_t)H * N * NW);                        // [H][N]
+    float* rball = wr + ((H * N + 3) & ~3);                                                 // [waves][2][Np]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long* cb = carry + (size_t)b * ro_carry_words(K, N);
+    const float* cw = reinterpret_cast<const float*>(cb + (size_t)H * N * NW);
+    for (int i = tid; i < H * N * NW; i += RO_THREADS) bits[i] = cb[i];
+    for (int i = tid; i < H * N; i += RO_THREADS) wr[i] = cw[i];
+    __syncthreads();
+    float* Gb = G + (size_t)b * K * N * N;
+    float* rbuf = rball + wave * 2 * Np;
+    for (int j = K - 1; j >= 1; --j) {
+        for (int i = wave; i < N; i += RO_WAVES) {
+            float* r0 = rbuf;
+            float* r1 = rbuf + Np;
+            const float wi = wr[i];
+            const unsigned long long* rowT = bits + (size_t)i * NW;
+            for (int n = lane; n < N; n += 64) r0[n] = ((rowT[n >> 6] >> (n & 63)) & 1ull) ? wi : 0.f;
+            for (int q = 1; q < j; ++q) {                     // . A_{t-q}: gather along the (symmetric) bit rows, source weights
+                const float* wq = wr + q * N;
+                for (int n = lane; n < N; n += 64) {
+                    const unsigned long long* rw = bits + ((size_t)q * N + n) * NW;
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int wd = 0; wd < NW; ++wd) {
+                        unsigned long long w = rw[wd];
+                        while (w) { const int m = 64 * wd + __builtin_ctzll(w); w &= w - 1ull; sacc = fmaf(r0[m], wq[m], sacc); }
+                    }
+                    r1[n] = sacc;
+                }
+                float* tsw = r0; r0 = r1; r1 = tsw;
+            }
+            float* grow = Gb + (size_t)j * N * N + (size_t)i * N;
+            for (int n = lane; n < N; n += 64) grow[n] = r0[n];
+        }
+    }
+}
+
+__global__ void rollout_image_kernel(RoParams P, int K, float* __restrict__ image)
+{
+    for (int l = 0; l < P.n_layers; ++l) {
+        const int cin = (l == 0) ? 6 * K : P.dims[l], cout = P.dims[l + 1];
+        const bool last = l == P.n_layers - 1;
+        const int tot = ro_weight_image_size(cout, last);
+        const int span = (l + 1 < P.n_layers ? P.woff[l + 1] : P.wtot) - P.woff[l];
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < span; e += gridDim.x * blockDim.x)
+            image[P.woff[l] + e] = (e < tot) ? ro_weight_image_elem(P.W[l], P.b[l], cin, cout, last, e) : 0.f;
+    }
+}
+
 template <int CN, int CK, bool FD>
 int launch_rollout(double* x, float* G, float* Xd, float* action, double* rewards, const RoParams& P,
                    const MgpFlockParams* p, int B, int K, int N, int T, unsigned long long dimsA, unsigned int dims8,
-                   unsigned long long woffA, unsigned long long woffB, int n_layers, int lds, hipStream_t st)
+                   unsigned long long woffA, unsigned long long woffB, int n_layers, int lds, hipStream_t st,
+                   const float* image, int image_floats, unsigned long long* carry, int flags)
 {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<CN, CK, FD>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MGP_ELAUNCH;
     hipLaunchKernelGGL((rollout_kernel<CN, CK, FD>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K,
-                       N, T, dimsA, dims8, woffA, woffB, n_layers);
+                       N, T, dimsA, dims8, woffA, woffB, n_layers, image, image_floats, carry, flags);
     return mgp_launch_status();
 }
 
 template <bool FD>
 int launch_rollout_big(double* x, float* G, float* Xd, float* action, double* rewards, const RoParams& P,
                        const MgpFlockParams* p, int B, int K, int N, int T, unsigned long long dimsA, unsigned int dims8,
-                       unsigned long long woffA, unsigned long long woffB, int n_layers, int lds, hipStream_t st)
+                       unsigned long long woffA, unsigned long long woffB, int n_layers, int lds, hipStream_t st,
+                       const float* image, int image_floats, unsigned long long* carry, int flags)
 {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_big_kernel<FD>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MGP_ELAUNCH;
     hipLaunchKernelGGL((rollout_big_kernel<FD>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K, N, T,
-                       dimsA, dims8, woffA, woffB, n_layers);
+                       dimsA, dims8, woffA, woffB, n_layers, image, image_floats, carry, flags);
     return mgp_launch_status();
 }
 
@@ -1054,14 +1189,22 @@ int launch_rollout_big(double* x, float* G, float* Xd, float* action, double* re
 // public entry points and forwards the shapes only the wide build covers.
 #ifdef MGP_RO_WIDE
 #define MGP_RO_SUPPORTED mgp_rollout_wide_supported_
-#define MGP_RO_STEPS mgp_rollout_wide_steps_
+#define MGP_RO_STEPS_EX mgp_rollout_wide_steps_ex_
+#define MGP_RO_IMAGE_FLOATS mgp_rollout_wide_image_floats_
+#define MGP_RO_IMAGE mgp_rollout_wide_image_
 #else
 #define MGP_RO_SUPPORTED mgp_rollout_supported
-#define MGP_RO_STEPS mgp_rollout_steps
+#define MGP_RO_STEPS_EX mgp_rollout_steps_ex
+#define MGP_RO_IMAGE_FLOATS mgp_rollout_image_floats
+#define MGP_RO_IMAGE mgp_rollout_image
 extern "C" int mgp_rollout_wide_supported_(const int* dims, int n_layers, int K, int N);
-extern "C" int mgp_rollout_wide_steps_(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
-                                       const int* dims, int n_layers, float* action, double* rewards,
-                                       const MgpFlockParams* p, int B, int K, int N, int T, void* stream);
+extern "C" int mgp_rollout_wide_steps_ex_(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
+                                          const int* dims, int n_layers, float* action, double* rewards,
+                                          const MgpFlockParams* p, int B, int K, int N, int T, const float* image,
+                                          void* carry, int flags, void* stream);
+extern "C" long mgp_rollout_wide_image_floats_(const int* dims, int n_layers, int K, int N);
+extern "C" int mgp_rollout_wide_image_(const float* const* W, const float* const* b, const int* dims, int n_layers, int K, int N,
+                                       float* image, void* stream);
 #endif
 
 extern "C" int MGP_RO_SUPPORTED(const int* dims, int n_layers, int K, int N)
@@ -1074,31 +1217,81 @@ extern "C" int MGP_RO_SUPPORTED(const int* dims, int n_layers, int K, int N)
 #endif
 }
 
-extern "C" int MGP_RO_STEPS(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
-                            const int* dims, int n_layers, float* action, double* rewards,
-                            const MgpFlockParams* p, int B, int K, int N, int T, void* stream)
+extern "C" long MGP_RO_IMAGE_FLOATS(const int* dims, int n_layers, int K, int N)
 {
-    if (B < 0 || T < 0 || p == nullptr || W == nullptr || b == nullptr) return MGP_EINVAL;
+    RoParams P;
+    if (make_carve(dims, n_layers, K, N, &P, nullptr)) return P.wtot;
+#ifndef MGP_RO_WIDE
+    return mgp_rollout_wide_image_floats_(dims, n_layers, K, N);
+#else
+    return 0;
+#endif
+}
+
+extern "C" int MGP_RO_IMAGE(const float* const* W, const float* const* b, const int* dims, int n_layers, int K, int N,
+                            float* image, void* stream)
+{
+    if (W == nullptr || b == nullptr) return MGP_EINVAL;
+    RoParams P;
+    if (!make_carve(dims, n_layers, K, N, &P, nullptr)) {
+#ifndef MGP_RO_WIDE
+        return mgp_rollout_wide_image_(W, b, dims, n_layers, K, N, image, stream);
+#else
+        return MGP_EUNSUPPORTED;
+#endif
+    }
+    MGP_CHECK_PTR(image);
+    if (!mgp_aligned16(image)) return MGP_EALIGN;
+    for (int l = 0; l < n_layers; ++l) {
+        MGP_CHECK_PTR(W[l]);
+        MGP_CHECK_PTR(b[l]);
+        P.W[l] = W[l]; P.b[l] = b[l];
+    }
+    mgp_clear_error();
+    hipLaunchKernelGGL(rollout_image_kernel, dim3(8), dim3(256), 0, static_cast<hipStream_t>(stream), P, K, image);
+    return mgp_launch_status();
+}
+
+extern "C" int MGP_RO_STEPS_EX(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
+                               const int* dims, int n_layers, float* action, double* rewards,
+                               const MgpFlockParams* p, int B, int K, int N, int T, const float* image, void* carry_v,
+                               int flags, void* stream)
+{
+    if (B < 0 || T < 0 || p == nullptr) return MGP_EINVAL;
+    if (image == nullptr && (W == nullptr || b == nullptr)) return MGP_EINVAL;
     if (!(p->comm_radius2 > 0.0) || !(p->dt > 0.0) || p->n_leaders < 0) return MGP_EINVAL;
     RoParams P;
     int lds = 0;
     if (!make_carve(dims, n_layers, K, N, &P, &lds)) {
 #ifndef MGP_RO_WIDE
-        return mgp_rollout_wide_steps_(x, G, Xd, W, b, dims, n_layers, action, rewards, p, B, K, N, T, stream);
+        return mgp_rollout_wide_steps_ex_(x, G, Xd, W, b, dims, n_layers, action, rewards, p, B, K, N, T, image, carry_v, flags,
+                                          stream);
 #else
         return MGP_EUNSUPPORTED;
 #endif
     }
+    unsigned long long* carry = static_cast<unsigned long long*>(carry_v);
+    if (flags & ~(MGP_RO_ENTER_CARRY | MGP_RO_EXIT_CARRY | MGP_RO_SKIP_DENSE)) return MGP_EINVAL;
+    if ((flags & (MGP_RO_ENTER_CARRY | MGP_RO_EXIT_CARRY)) && carry == nullptr) return MGP_EINVAL;
+    // a launch that starts from dense slices knows only the networks it produces itself: it can hand over a complete
+    // history (and skip the dense rebuild) only if it runs at least K - 1 steps
+    if (!(flags & MGP_RO_ENTER_CARRY) && T < K - 1 && (flags & (MGP_RO_EXIT_CARRY | MGP_RO_SKIP_DENSE))) return MGP_EINVAL;
+    if ((flags & MGP_RO_SKIP_DENSE) && !(flags & MGP_RO_EXIT_CARRY)) return MGP_EINVAL;
     if (B == 0 || T == 0) return MGP_OK;
     MGP_CHECK_PTR8(x);
     MGP_CHECK_PTR(G);
     MGP_CHECK_PTR(Xd);
+    if (carry != nullptr && (reinterpret_cast<uintptr_t>(carry) & 7u)) return MGP_EALIGN;
+    if (image != nullptr && !mgp_aligned16(image)) return MGP_EALIGN;
     if (action != nullptr && (reinterpret_cast<uintptr_t>(action) & 3u)) return MGP_EALIGN;
     if (rewards != nullptr && (reinterpret_cast<uintptr_t>(rewards) & 7u)) return MGP_EALIGN;
     for (int l = 0; l < n_layers; ++l) {
-        MGP_CHECK_PTR(W[l]);
-        MGP_CHECK_PTR(b[l]);
-        P.W[l] = W[l]; P.b[l] = b[l];
+        P.W[l] = nullptr; P.b[l] = nullptr;
+        if (image == nullptr) {
+            MGP_CHECK_PTR(W[l]);
+            MGP_CHECK_PTR(b[l]);
+            P.W[l] = W[l]; P.b[l] = b[l];
+        }
     }
     unsigned long long dimsA = 0ull, woffA = 0ull, woffB = 0ull;
     unsigned int dims8 = 0u;
@@ -1113,16 +1306,55 @@ extern "C" int MGP_RO_STEPS(double* x, float* G, float* Xd, const float* const* 
     }
     mgp_clear_error();
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const int wt = P.wtot;
     const bool fade = p->link_drop != 0u;   // FlockingStochastic-v0: the generic builds carry the fade hash, the others do not
     if (N > RO_MAXN)
-        return fade ? launch_rollout_big<true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st)
-                    : launch_rollout_big<false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
+        return fade ? launch_rollout_big<true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags)
+                    : launch_rollout_big<false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags);
 #ifndef MGP_RO_WIDE
     if (N == 100 && K == 3 && !fade)   // the headline shape (BASELINE.json configs[0..1]) runs a build with compile-time addresses
-        return launch_rollout<100, 3, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
+        return launch_rollout<100, 3, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags);
     if (N == 100 && K == 2 && !fade)   // cfg/default.cfg, cloning.cfg, dagger_twoflocks.cfg
-        return launch_rollout<100, 2, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
+        return launch_rollout<100, 2, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags);
 #endif
-    return fade ? launch_rollout<0, 0, true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st)
-                : launch_rollout<0, 0, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st);
+    return fade ? launch_rollout<0, 0, true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags)
+                : launch_rollout<0, 0, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags);
 }
+
+#ifndef MGP_RO_WIDE
+// the original entry point: dense state in, dense state out, weight image built inside the launch
+extern "C" int mgp_rollout_steps(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
+                                 const int* dims, int n_layers, float* action, double* rewards,
+                                 const MgpFlockParams* p, int B, int K, int N, int T, void* stream)
+{
+    if (W == nullptr || b == nullptr) return MGP_EINVAL;
+    return mgp_rollout_steps_ex(x, G, Xd, W, b, dims, n_layers, action, rewards, p, B, K, N, T, nullptr, nullptr, 0, stream);
+}
+
+extern "C" long mgp_rollout_carry_bytes(int K, int N)
+{
+    if (K < 1 || K > 5 || N < 4 || N > RB_MAXN) return 0;
+    return (long)(ro_carry_words(K, N) * 8);
+}
+
+extern "C" int mgp_rollout_carry_to_dense(const void* carry, float* G, int B, int K, int N, void* stream)
+{
+    if (B < 0 || K < 1 || K > 5 || N < 4 || N > RB_MAXN) return MGP_EINVAL;
+    if (B == 0 || K == 1) return MGP_OK;
+    MGP_CHECK_PTR8(carry);
+    MGP_CHECK_PTR(G);
+    const int H = ro_hist(K), Np = (N + 3) & ~3, NW = ro_carry_nw(N);
+    const int lds = H * N * NW * 8 + ((H * N + 3) & ~3) * 4 + RO_WAVES * 2 * Np * 4;
+    mgp_clear_error();
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const unsigned long long* c = static_cast<const unsigned long long*>(carry);
+    if (NW == 2) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(carry_to_dense_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MGP_ELAUNCH;
+        hipLaunchKernelGGL((carry_to_dense_kernel<2>), dim3(B), dim3(RO_THREADS), lds, st, c, G, K, N);
+    } else {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(carry_to_dense_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MGP_ELAUNCH;
+        hipLaunchKernelGGL((carry_to_dense_kernel<4>), dim3(B), dim3(RO_THREADS), lds, st, c, G, K, N);
+    }
+    return mgp_launch_status();
+}
+#endif

@@ -163,6 +163,7 @@ class VecFlock(object):
         self._c = params.to_c()
         self.x = torch.zeros((B, N, 4), device=self.device, dtype=torch.float64)      # current state
         self._x_next = torch.zeros_like(self.x)                                        # ping-pong partner
+        self._network, self._network_lazy = None, None
         self._network_own = torch.zeros((B, N, N), device=self.device, dtype=torch.float32)
         self._features_own = torch.zeros((B, 6, N), device=self.device, dtype=torch.float32)
         # `network` / `features` normally are the two buffers above; step(A_out=, feat_out=) / step_advance / the resident
@@ -173,6 +174,18 @@ class VecFlock(object):
         self.network64 = torch.zeros((B, N, N), device=self.device, dtype=torch.float64) if want_f64_obs else None
         self.features64 = torch.zeros((B, N, 6), device=self.device, dtype=torch.float64) if want_f64_obs else None
         self.expert64 = torch.zeros((B, N, 2), device=self.device, dtype=torch.float64) if want_f64_obs else None
+
+    @property
+    def network(self):
+        """(B,N,N) fp32 network matrices of the current state.  After a resident rollout that left the dense operator
+        unmaterialised this resolves through the delay state (which rebuilds its slices on first use)."""
+        if self._network_lazy is not None:
+            return self._network_lazy()
+        return self._network
+
+    @network.setter
+    def network(self, value):
+        self._network, self._network_lazy = value, None
 
     def set_state(self, x0):
         """x0 (B,N,4) array-like fp64: install states and refresh observations."""

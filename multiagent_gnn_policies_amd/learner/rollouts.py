@@ -57,7 +57,15 @@ def _actor_params(actor):
     return ws, bs
 
 
-def policy_rollout(actor, sim, state, T, rewards=None, action=None, resident=True):
+def rollout_image_for(actor, K, N):
+    """Prebuilt weight image of the episode-resident kernel for `actor` (None: shape not covered).  Valid until the
+    weights change; pass it to policy_rollout(image=...) when the same policy is rolled out in several launches."""
+    from .. import ops
+    ws, bs = _actor_params(actor)
+    return ops.rollout_image(ws, bs, tuple(actor.layers), K, N)
+
+
+def policy_rollout(actor, sim, state, T, rewards=None, action=None, resident=True, image=None, lazy_dense=True):
     """T closed-loop policy steps of every episode lane of `sim` (VecFlock) / `state` (BatchedDelayState): the batched
     form of the reference's evaluation loop (test_model.py:38-44).  `rewards` (B,T) fp64 receives every step's reward.
 
@@ -74,10 +82,26 @@ def policy_rollout(actor, sim, state, T, rewards=None, action=None, resident=Tru
     if (resident and actor.ind_agg == 0 and state.F == 6 and sim.network64 is None and sim.features64 is None
             and ops.rollout_supported(tuple(actor.layers), state.K, sim.N)):
         ws, bs = _actor_params(actor)
-        if ops.rollout_steps(sim.x, state.delay_gso, state.delay_state, ws, bs, tuple(actor.layers), sim._c, T,
-                             action=action, rewards=rewards):
+        # Hand-over between launches in factored form: when the state's operator history is known as bit rows (it was left
+        # by the previous resident launch, or the state is a reset observation) the launch enters from it, leaves it for
+        # the next one, and the dense slices delay_gso[:, 1:] are materialised only if somebody reads them
+        # (state.delay_gso / sim.network) -- chunked launches are then bit-identical to one long launch.
+        carry = state.carry_buffer()
+        flags = 0
+        if carry is not None:
+            if state._carry_valid:
+                flags |= ops.RO_ENTER_CARRY
+            if (flags & ops.RO_ENTER_CARRY) or T >= state.K - 1:
+                flags |= ops.RO_EXIT_CARRY | (ops.RO_SKIP_DENSE if lazy_dense else 0)
+        if not (flags & ops.RO_ENTER_CARRY):
+            state._ensure_dense()                              # the launch reads the dense slices
+        G_cur = state._G[state._cur]
+        if ops.rollout_steps(sim.x, G_cur, state.delay_state, ws, bs, tuple(actor.layers), sim._c, T,
+                             action=action, rewards=rewards, image=image, carry=carry, flags=flags):
+            state._carry_valid = bool(flags & ops.RO_EXIT_CARRY)
+            state._dense_stale = bool(flags & ops.RO_SKIP_DENSE)
             if state.K > 1:
-                sim.network = state.delay_gso[:, 1]
+                sim._network, sim._network_lazy = None, (lambda: state.delay_gso[:, 1])
             sim.features = state.delay_state[:, 0]
             if rewards is not None:
                 sim.reward.copy_(rewards[:, T - 1])

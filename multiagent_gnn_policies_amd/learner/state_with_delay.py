@@ -87,10 +87,34 @@ class BatchedDelayState(object):
         self._cur = 0
         self._has_prev = False
         self._pushes = 0                          # states pushed since the last reset (1 = the reset observation only)
+        # Factored hand-over between launches of the episode-resident kernel (mgp_rollout_steps_ex): `_carry` holds the
+        # membership bits + row weights of the last K-1 networks of the CURRENT state while `_carry_valid`; the dense slices
+        # delay_gso[:, 1:] of the current buffer are materialised from it on first use while `_dense_stale`
+        # (mgp_rollout_carry_to_dense: same arithmetic as the in-launch rebuild).  Any transition made outside the
+        # resident kernel invalidates the carry; a reset observation has the all-zero carry (no earlier network).
+        self._carry = None
+        self._carry_valid = False
+        self._dense_stale = False
 
     def reset(self):
         self._has_prev = False
         self._pushes = 0
+        self._carry_valid = False
+        self._dense_stale = False
+
+    def carry_buffer(self):
+        """(B, mgp_rollout_carry_bytes) uint8 device buffer, or None when the resident kernel does not cover (K, N)."""
+        if self._carry is None:
+            nbytes = ops.rollout_carry_bytes(self.K, self.N)
+            if nbytes <= 0:
+                return None
+            self._carry = torch.zeros((self.B, nbytes), device=self._G[0].device, dtype=torch.uint8)
+        return self._carry
+
+    def _ensure_dense(self):
+        if self._dense_stale:
+            ops.rollout_carry_to_dense(self._carry, self._G[self._cur], self.K)
+            self._dense_stale = False
 
     def push(self, A, X_t):
         """A (B,N,N) fp32, X_t (B,F,N) fp32 on the device.  mgp_gso_update reads both with batch strides N*N and F*N, so
@@ -100,10 +124,17 @@ class BatchedDelayState(object):
             A = A.contiguous()
         if not X_t.is_contiguous():
             X_t = X_t.contiguous()
+        self._ensure_dense()
         nxt = 1 - self._cur
         ops.gso_update_into(A, self._G[self._cur], self._G[nxt], X_t, self._X[self._cur], self._X[nxt],
                             has_prev=self._has_prev)
         self._cur = nxt
+        # the reset observation has no history: its carry is all zeros (every delayed product vanishes, as the zero-filled
+        # slices of the reference do, state_with_delay.py:44-47); later pushes build on dense slices only
+        self._carry_valid = False
+        if not self._has_prev and self.carry_buffer() is not None:
+            self._carry.zero_()
+            self._carry_valid = True
         self._has_prev = True
         self._pushes += 1
 
@@ -112,12 +143,14 @@ class BatchedDelayState(object):
         """(A_dst (B,N,N) view = next delay_gso[:,1], X_dst (B,F,N) view = next delay_state[:,0]): hand these to
         VecFlock.step(..., A_out=, feat_out=) and then call advance().  Saves the A read-copy-write and the identity
         rewrite of push() (3 N^2 instead of 5 N^2 floats of state traffic per episode-step at K = 3)."""
+        self._ensure_dense()
         nxt = 1 - self._cur
         A_dst = self._G[nxt][:, 1] if self.K > 1 else self._scratch_A
         return A_dst, self._X[nxt][:, 0]
 
     def buffers(self):
         """(G_prev, G_next, Xd_prev, Xd_next) for a fused sim+state kernel; call flip() after it ran."""
+        self._ensure_dense()
         nxt = 1 - self._cur
         return self._G[self._cur], self._G[nxt], self._X[self._cur], self._X[nxt]
 
@@ -129,8 +162,11 @@ class BatchedDelayState(object):
         self._cur = 1 - self._cur
         self._has_prev = True
         self._pushes += 1
+        self._carry_valid = False
 
     def advance(self):
+        self._ensure_dense()
+        self._carry_valid = False
         nxt = 1 - self._cur
         ops.gso_advance(self._G[self._cur], self._G[nxt], self._X[self._cur], self._X[nxt], has_prev=self._has_prev)
         self._cur = nxt
@@ -139,6 +175,7 @@ class BatchedDelayState(object):
 
     @property
     def delay_gso(self):
+        self._ensure_dense()
         return self._G[self._cur]
 
     @property

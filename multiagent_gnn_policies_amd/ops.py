@@ -254,9 +254,14 @@ def rollout_supported(dims, K, N):
     return bool(_lib.lib().mgp_rollout_supported(cd, len(dims) - 1, K, N))
 
 
-def rollout_steps(x, G, Xd, weights, biases, dims, params, T, action=None, rewards=None):
-    """T closed-loop policy steps for every episode in ONE launch, state updated in place (mgp_rollout_steps).
+RO_ENTER_CARRY, RO_EXIT_CARRY, RO_SKIP_DENSE = 1, 2, 4          # include/mgp.h: MGP_RO_*
+
+
+def rollout_steps(x, G, Xd, weights, biases, dims, params, T, action=None, rewards=None, image=None, carry=None, flags=0):
+    """T closed-loop policy steps for every episode in ONE launch, state updated in place (mgp_rollout_steps_ex).
     x (B,N,4) f64 | G (B,K,N,N) | Xd (B,K,6,N) | weights[l] (out, in*step) / biases[l] fp32 | rewards (B,T) f64.
+    image: prebuilt weight image (rollout_image), or None (built from weights / biases inside the launch);
+    carry (B, rollout_carry_bytes) uint8 + flags (RO_*): factored hand-over of the operator history, see include/mgp.h.
     Returns False when the shape is outside the resident kernel's coverage (nothing was launched)."""
     _dev(x, 'x', torch.float64); _dev(G, 'G'); _dev(Xd, 'Xd')
     B, N, _ = x.shape
@@ -267,17 +272,53 @@ def rollout_steps(x, G, Xd, weights, biases, dims, params, T, action=None, rewar
         assert rewards.shape == (B, T) and rewards.dtype == torch.float64 and rewards.is_contiguous()
     if action is not None:
         assert action.shape == (B, 1, 2, N) and action.is_contiguous()
+    if carry is not None:
+        assert carry.dtype == torch.uint8 and carry.is_contiguous() and carry.shape == (B, rollout_carry_bytes(K, N))
     cd = (ctypes.c_int * len(dims))(*dims)
+    wa = ba = None
+    if image is None:
+        Ws = [w.contiguous() for w in weights]
+        bs = [b_.contiguous() for b_ in biases]
+        wa = (ctypes.c_void_p * len(Ws))(*[w.data_ptr() for w in Ws])
+        ba = (ctypes.c_void_p * len(bs))(*[b_.data_ptr() for b_ in bs])
+    else:
+        _dev(image, 'image')
+    rc = _lib.lib().mgp_rollout_steps_ex(_ptr(x), _ptr(G), _ptr(Xd), wa, ba, cd, len(dims) - 1, _ptr(action), _ptr(rewards),
+                                         ctypes.byref(params), B, K, N, int(T), _ptr(image), _ptr(carry), int(flags),
+                                         _stream())
+    if rc == -5:
+        return False
+    _lib.check(rc, 'mgp_rollout_steps_ex')
+    return True
+
+
+def rollout_image(weights, biases, dims, K, N):
+    """Weight image of the episode-resident kernel for this policy (MFMA fragment order), built once by a tiny kernel:
+    pass it to rollout_steps(image=...) for as long as the weights do not change.  None when the shape is not covered."""
+    cd = (ctypes.c_int * len(dims))(*dims)
+    L = _lib.lib()
+    n = L.mgp_rollout_image_floats(cd, len(dims) - 1, K, N)
+    if n <= 0:
+        return None
     Ws = [w.contiguous() for w in weights]
     bs = [b_.contiguous() for b_ in biases]
     wa = (ctypes.c_void_p * len(Ws))(*[w.data_ptr() for w in Ws])
     ba = (ctypes.c_void_p * len(bs))(*[b_.data_ptr() for b_ in bs])
-    rc = _lib.lib().mgp_rollout_steps(_ptr(x), _ptr(G), _ptr(Xd), wa, ba, cd, len(dims) - 1, _ptr(action), _ptr(rewards),
-                                      ctypes.byref(params), B, K, N, int(T), _stream())
-    if rc == -5:
-        return False
-    _lib.check(rc, 'mgp_rollout_steps')
-    return True
+    image = torch.empty((n,), device=Ws[0].device, dtype=torch.float32)
+    _lib.check(L.mgp_rollout_image(wa, ba, cd, len(dims) - 1, K, N, _ptr(image), _stream()), 'mgp_rollout_image')
+    return image
+
+
+def rollout_carry_bytes(K, N):
+    return int(_lib.lib().mgp_rollout_carry_bytes(int(K), int(N)))
+
+
+def rollout_carry_to_dense(carry, G, K):
+    """delay_gso slices 1..K-1 of every episode from the factored history `carry` (in place in G (B,K,N,N))."""
+    _dev(G, 'G')
+    B, K_, N, _ = G.shape
+    assert K_ == K and G.is_contiguous() and carry.dtype == torch.uint8 and carry.is_contiguous()
+    _lib.check(_lib.lib().mgp_rollout_carry_to_dense(_ptr(carry), _ptr(G), B, K, N, _stream()), 'mgp_rollout_carry_to_dense')
 
 
 def flock_controller(x, params, centralized=False, u=None, u64=None):
@@ -343,4 +384,4 @@ def adam_step_dev(param, grad, m, v, lr, step_dev, beta1=0.9, beta2=0.999, eps=1
 
 __all__ = ['MgpFlockParams', 'MgpError', 'aggregate', 'dense', 'agg_fwd', 'agg_bwd_x', 'dense_fwd', 'dense_bwd',
            'gso_update', 'gso_update_into', 'gso_powers', 'flock_step', 'flock_controller', 'mse_grad', 'mse_loss',
-           'gso_advance', 'flock_step_advance', 'rollout_supported', 'rollout_steps', 'adam_step', 'adam_step_dev', 'ACT_NONE', 'ACT_TANH']
+           'gso_advance', 'flock_step_advance', 'rollout_supported', 'rollout_steps', 'rollout_image', 'rollout_carry_bytes', 'rollout_carry_to_dense', 'adam_step', 'adam_step_dev', 'ACT_NONE', 'ACT_TANH']

@@ -160,7 +160,8 @@ def test_rollout_chunking_agrees(N, K, hidden, variant):
         t0 = 0
         for c in chunks:
             rw = torch.zeros((B, c), device='cuda', dtype=torch.float64)
-            assert policy_rollout(actor, sim, st, c, rewards=rw, action=action)
+            st._carry_valid = False            # this test is about the DENSE hand-over: every launch enters from G
+            assert policy_rollout(actor, sim, st, c, rewards=rw, action=action, lazy_dense=False)
             rewards[:, t0:t0 + c] = rw
             t0 += c
         outs.append(_snapshot(sim, st) + (action.cpu().numpy().copy(), rewards.cpu().numpy().copy()))
@@ -169,6 +170,69 @@ def test_rollout_chunking_agrees(N, K, hidden, variant):
         for name, a, b in zip(names, outs[0], other):
             assert relerr(a, b) <= TOL_CHUNK[name], (name, relerr(a, b))
         assert np.array_equal(outs[0][1][:, 0], other[1][:, 0])            # slice 0 = I in every chunking
+
+
+@pytest.mark.parametrize('N,K,hidden,variant', CASES)
+def test_rollout_factored_handover_makes_chunkings_bit_identical(N, K, hidden, variant):
+    """With the operator history handed from launch to launch as bit rows + row weights (mgp_rollout_steps_ex: ENTER / EXIT
+    carry) the running products never pass through rounded dense slices: ANY chunking of an episode is bit-identical to
+    one launch -- positions, delay line, rewards, last action, and the dense operator materialised on demand -- for every
+    shape, including link fading (whose hash is keyed on exact position bits).  Also: the lazily rebuilt dense slices equal
+    the ones the launch writes itself (lazy_dense=False), and a prebuilt weight image equals the in-launch build."""
+    from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout, rollout_image_for
+    B, T = 3, 9
+    outs = []
+    for chunks, lazy, use_image in (([T], True, False), ([1] * T, True, False), ([4, 5], True, True), ([2, 7], False, False),
+                                    ([T], False, True)):
+        rs, op, actor, sim, st = _make(N, K, hidden, B, seed=7, **variant)
+        assert st._carry_valid, "a reset observation has the all-zero history"
+        image = rollout_image_for(actor, K, N) if use_image else None
+        assert (image is not None) == use_image
+        rewards = torch.zeros((B, T), device='cuda', dtype=torch.float64)
+        action = torch.zeros((B, 1, 2, N), device='cuda')
+        t0 = 0
+        for c in chunks:
+            rw = torch.zeros((B, c), device='cuda', dtype=torch.float64)
+            assert policy_rollout(actor, sim, st, c, rewards=rw, action=action, image=image, lazy_dense=lazy)
+            assert st._carry_valid and st._dense_stale == (lazy and K > 0)
+            rewards[:, t0:t0 + c] = rw
+            t0 += c
+        net = sim.network.clone() if K > 1 else None          # resolves through the delay state when lazy
+        outs.append(_snapshot(sim, st) + (action.cpu().numpy().copy(), rewards.cpu().numpy().copy(),
+                                          net.cpu().numpy() if net is not None else np.zeros(1)))
+        assert not st._dense_stale
+        if K > 1:
+            assert np.array_equal(outs[-1][1][:, 1], outs[-1][5])
+    for other in outs[1:]:
+        for name, a, b in zip(('x', 'delay_gso', 'delay_state', 'last action', 'rewards', 'network'), outs[0], other):
+            assert np.array_equal(a, b), name
+
+
+def test_rollout_ex_flag_validation():
+    """C-ABI argument checking of mgp_rollout_steps_ex (include/mgp.h)."""
+    import ctypes
+    from multiagent_gnn_policies_amd import _lib, ops
+    rs, op, actor, sim, st = _make(100, 3, (32, 32), 2, seed=1)
+    L = _lib.lib()
+    from multiagent_gnn_policies_amd.learner.rollouts import _actor_params
+    ws, bs = _actor_params(actor)
+    dims = (ctypes.c_int * 4)(6, 32, 32, 2)
+    wa = (ctypes.c_void_p * 3)(*[w.contiguous().data_ptr() for w in ws])
+    ba = (ctypes.c_void_p * 3)(*[b_.data_ptr() for b_ in bs])
+    carry = st.carry_buffer()
+    assert carry.shape == (2, L.mgp_rollout_carry_bytes(3, 100)) and carry.shape[1] == 2 * 100 * 2 * 8 + 2 * 100 * 4
+
+    def call(T, carry_ptr, flags):
+        return L.mgp_rollout_steps_ex(ops._ptr(sim.x), ops._ptr(st._G[st._cur]), ops._ptr(st.delay_state), wa, ba, dims, 3,
+                                      None, None, ctypes.byref(sim._c), 2, 3, 100, T, None, carry_ptr, flags, ops._stream())
+    assert call(1, ops._ptr(carry), ops.RO_EXIT_CARRY) == -1            # dense entry, T < K - 1: history incomplete (EINVAL)
+    assert call(5, None, ops.RO_EXIT_CARRY) == -1                       # flags without a carry buffer
+    assert call(5, ops._ptr(carry), ops.RO_SKIP_DENSE) == -1            # SKIP_DENSE needs EXIT_CARRY
+    assert call(5, ops._ptr(carry), 64) == -1                           # unknown flag
+    assert call(2, ops._ptr(carry), ops.RO_EXIT_CARRY | ops.RO_SKIP_DENSE) == 0
+    assert call(1, ops._ptr(carry), ops.RO_ENTER_CARRY | ops.RO_EXIT_CARRY) == 0
+    assert L.mgp_rollout_carry_bytes(3, 300) == 0 and L.mgp_rollout_carry_bytes(4, 200) == 3 * 200 * 4 * 8 + 3 * 200 * 4
+    torch.cuda.synchronize()
 
 
 # closed loop over 9 steps: an action difference of one fp32 rounding feeds back through the simulator (x10 gain, weights

@@ -9,8 +9,10 @@
 thread_local int mgp_tls_hip_error = 0;
 // the narrow build forwards widths > 32 to the second compilation (rollout_wide.hip); this harness links only the narrow one
 extern "C" int mgp_rollout_wide_supported_(const int*, int, int, int) { return 0; }
-extern "C" int mgp_rollout_wide_steps_(double*, float*, float*, const float* const*, const float* const*, const int*, int, float*,
-                                       double*, const MgpFlockParams*, int, int, int, int, void*) { return MGP_EUNSUPPORTED; }
+extern "C" int mgp_rollout_wide_steps_ex_(double*, float*, float*, const float* const*, const float* const*, const int*, int, float*,
+                                          double*, const MgpFlockParams*, int, int, int, int, const float*, void*, int, void*) { return MGP_EUNSUPPORTED; }
+extern "C" long mgp_rollout_wide_image_floats_(const int*, int, int, int) { return 0; }
+extern "C" int mgp_rollout_wide_image_(const float* const*, const float* const*, const int*, int, int, int, float*, void*) { return MGP_EUNSUPPORTED; }
 int main(int argc, char** argv) {
     int B = argc > 1 ? atoi(argv[1]) : 256, N = argc > 2 ? atoi(argv[2]) : 100, K = argc > 3 ? atoi(argv[3]) : 3;
     int T = argc > 4 ? atoi(argv[4]) : 200;
@@ -59,15 +61,24 @@ int main(int argc, char** argv) {
     }
     MgpFlockParams p = {1.0, 0.01, 10.0, 1.0, 0.1, 10.0, 1.0, 1, 0, 1, 0};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    int rc = mgp_rollout_steps(x, G, Xd, W, bb, dims, 3, act, rew, &p, B, K, N, T, nullptr);
+    // RO_CARRY=1: the repeated-launch form (prebuilt weight image, factored hand-over of the history, dense slices not rebuilt)
+    const bool use_carry = getenv("RO_CARRY") != nullptr;
+    float* image = nullptr; void* carry = nullptr;
+    if (use_carry) {
+        hipMalloc(&image, mgp_rollout_image_floats(dims, 3, K, N) * 4);
+        hipMalloc(&carry, (size_t)B * mgp_rollout_carry_bytes(K, N)); hipMemset(carry, 0, (size_t)B * mgp_rollout_carry_bytes(K, N));
+        if (mgp_rollout_image(W, bb, dims, 3, K, N, image, nullptr)) { printf("image failed\n"); return 1; }
+    }
+    const int fl = use_carry ? (MGP_RO_ENTER_CARRY | MGP_RO_EXIT_CARRY | MGP_RO_SKIP_DENSE) : 0;
+    int rc = mgp_rollout_steps_ex(x, G, Xd, W, bb, dims, 3, act, rew, &p, B, K, N, T, image, carry, fl, nullptr);
     if (rc) { printf("rc %d\n", rc); return 1; }
     hipDeviceSynchronize();
     const int IT = argc > 5 ? atoi(argv[5]) : 5;
     hipEventRecord(e0, nullptr);
-    for (int it = 0; it < IT; ++it) mgp_rollout_steps(x, G, Xd, W, bb, dims, 3, act, rew, &p, B, K, N, T, nullptr);
+    for (int it = 0; it < IT; ++it) mgp_rollout_steps_ex(x, G, Xd, W, bb, dims, 3, act, rew, &p, B, K, N, T, image, carry, fl, nullptr);
     hipEventRecord(e1, nullptr); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("B=%d N=%d K=%d T=%d resident rollout: %.1f us per launch, %.2f us per step -> %.3e agent-steps/s\n", B, N, K, T,
+    printf("%sB=%d N=%d K=%d T=%d resident rollout: %.1f us per launch, %.2f us per step -> %.3e agent-steps/s\n", use_carry ? "[carry] " : "", B, N, K, T,
            1e3 * ms / IT, 1e3 * ms / IT / T, (double)B * N * T / (1e-3 * ms / IT));
     unsigned long long st[256];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(mgp_ro_stamps), sizeof(st));
