@@ -71,11 +71,12 @@ def load_weights(actor):
     if os.path.exists(path):
         with np.load(path) as z:
             sd = {k.replace('__', '.'): torch.from_numpy(z[k]) for k in z.files}
-        try:
+        own = actor.state_dict()
+        # all or nothing: load_state_dict copies the matching tensors before it raises on a mismatch, which would leave a
+        # hybrid (e.g. K = 4: default-init filter, checkpoint readout) -- a policy nobody trained, whose flocks collapse
+        if set(own) == set(sd) and all(tuple(own[k].shape) == tuple(sd[k].shape) for k in own):
             actor.load_state_dict(sd)
             return 'reference checkpoint actor_FlockingRelative-v0_dagger_k3'
-        except RuntimeError:
-            pass
     return 'default init (seed 11)'
 
 
@@ -291,30 +292,35 @@ def parity_gate(ro, n_check=16):
         two = ro.actor(ro.state.delay_state, ro.state.delay_gso)[idx].cpu().double()
     res = {}
 
-    def rel(u, r):
-        return float(((u - r).abs() / r.abs().clamp(min=1.0)).max())
-    noise = rel(ref, exact)
-
-    def err(u):
-        return {"max_abs": float((u - ref).abs().max()), "max_rel": rel(u, ref), "max_rel_vs_exact": rel(u, exact)}
-    res['two_launch'] = err(two)
+    def rel_b(u, r):                                          # per sampled episode: max over (action axis, agent)
+        return ((u - r).abs() / r.abs().clamp(min=1.0)).flatten(1).max(dim=1).values
+    noise_b = rel_b(ref, exact)
+    well = noise_b <= 0.5 * PARITY_TOL                        # episodes where the fp32 reference is determined to < tol
+    paths = {'two_launch': two}
     if ro.resident_supported():
         action = torch.zeros((B, 1, N_ACT, ro.N), device=ro.sim.device)
         if policy_rollout(ro.actor, ro.sim, ro.state, 1, action=action):
-            res['resident'] = err(action[idx].cpu().double())
-    worst_abs = max(v['max_abs'] for v in res.values())
-    worst_rel = max(v['max_rel'] for v in res.values())
-    worst_exact = max(v['max_rel_vs_exact'] for v in res.values())
-    ok = bool(worst_rel <= PARITY_TOL or worst_exact <= PARITY_TOL + 3.0 * noise)
-    return {"ok": ok, "tol": PARITY_TOL, "max_abs": worst_abs, "max_rel": worst_rel, "max_rel_vs_exact": worst_exact,
-            "reference_fp32_noise": noise, "max_abs_reference_output": float(ref.abs().max()),
-            "checked_episodes": len(idx), "paths": res,
-            "criterion": "max_rel <= tol (gpu vs the fp32 CPU reference, elementwise |gpu - cpu| / max(1, |cpu|)), or -- on "
-                         "states where the fp32 reference is itself further than that from the exact result -- "
-                         "max_rel_vs_exact <= tol + 3 x reference_fp32_noise, both measured against the fp64 evaluation of "
-                         "the same op sequence on the same fp32 inputs (a policy that lets agents collide sees 1/r^4 "
-                         "features of 1e6; any two fp32 evaluations then differ by ~1e-3).  The headline configuration "
-                         "(shipped checkpoint, N=100, K=3) passes the first, direct form",
+            paths['resident'] = action[idx].cpu().double()
+    ok = True
+    for name, u in paths.items():
+        r_ref, r_ex = rel_b(u, ref), rel_b(u, exact)
+        res[name] = {"max_abs": float((u - ref).abs().max()), "max_rel": float(r_ref.max()),
+                     "max_rel_vs_exact": float(r_ex.max()),
+                     "max_rel_well_conditioned": float(r_ref[well].max()) if bool(well.any()) else None}
+        ok = ok and bool((r_ref[well] <= PARITY_TOL).all()) and bool((r_ex[~well] <= PARITY_TOL + 10.0 * noise_b[~well]).all())
+    worst = max((v["max_rel_well_conditioned"] for v in res.values() if v["max_rel_well_conditioned"] is not None),
+                default=None)
+    return {"ok": ok, "tol": PARITY_TOL, "max_abs": max(v['max_abs'] for v in res.values()),
+            "max_rel": worst if worst is not None else max(v['max_rel'] for v in res.values()),
+            "max_rel_all_episodes": max(v['max_rel'] for v in res.values()),
+            "reference_fp32_noise": float(noise_b.max()), "max_abs_reference_output": float(ref.abs().max()),
+            "checked_episodes": len(idx), "well_conditioned_episodes": int(well.sum()), "paths": res,
+            "criterion": "elementwise |gpu - cpu| / max(1, |cpu|) <= tol against the fp32 CPU reference on every sampled "
+                         "episode where that reference is itself determined to tol/2 (its distance to the fp64 evaluation "
+                         "of the same op sequence on the same fp32 inputs: reference_fp32_noise per episode); episodes "
+                         "where it is not -- colliding agents drive 1/r^4 features to 1e6 and any two fp32 evaluations "
+                         "apart -- must stay within tol + 10 x their own noise of the fp64 evaluation.  max_rel is the "
+                         "well-conditioned figure; the headline configuration has all 16 episodes well conditioned",
             "reference": "oracle/torch_port.actor_forward: PyTorch-CPU fp32, the op sequence of reference actor.py:63-82, "
                          "on the identical (delay_gso, delay_state) of the sampled episodes"}
 

@@ -81,6 +81,7 @@ struct RoOff {
     int rcnt;                             // int [H][N] list lengths
     int sxy;                              // float2 [N] fp32 coordinates relative to the reference point
     int mmax;                             // uint: max |relative coordinate| of the step (float bits)
+    int wtab;                             // float [N + 1]: row weight of a network row by its degree (1/max(deg,1) or 1)
     int wl;                               // float weight image: per layer fragments [MT][64][RO_WFS] + bias [MT*16]
 };
 
@@ -116,6 +117,7 @@ __host__ __device__ constexpr RoOff ro_offsets(int N, int K)
     c.rcnt = ro_take(off, H * N * 4);
     c.sxy = ro_take(off, N * 8);
     c.mmax = ro_take(off, 16);
+    c.wtab = ro_take(off, (N + 1) * 4);
     c.wl = off;
     return c;
 }
@@ -149,6 +151,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     int* rcnt = reinterpret_cast<int*>(smraw + cv.rcnt);
     float2* sxy = reinterpret_cast<float2*>(smraw + cv.sxy);
     unsigned int* mmax = reinterpret_cast<unsigned int*>(smraw + cv.mmax);
+    float* wtab = reinterpret_cast<float*>(smraw + cv.wtab);
     const int RS = ro_list_stride(N);                         // list row stride (bytes)
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -171,6 +174,10 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         spx[i] = xb[i * 4 + 0]; spy[i] = xb[i * 4 + 1]; svx[i] = xb[i * 4 + 2]; svy[i] = xb[i * 4 + 3];
     }
     if (tid == 0) { cref[0] = xb[0]; cref[1] = xb[1]; mmax[0] = 0u; }
+    for (int c = tid; c <= N; c += RO_THREADS) {              // the expression of phase D3, tabulated by degree
+        const double deg = (double)c;
+        wtab[c] = (float)(p.mean_pooling ? 1.0 / (deg == 0.0 ? 1.0 : deg) : 1.0);
+    }
     // weights in MFMA A-fragment order (see actor_fused.hip): wfrag[mt][lane][RO_WFS], lane = (c & 3) * 16 + (o & 15),
     // slot s = c >> 2, zero padded; then the bias of the layer's MT*16 rows.  A caller that launches repeatedly with the
     // same weights passes the image prebuilt (mgp_rollout_image: the same elements, computed once): a flat 16-byte copy.
@@ -242,6 +249,13 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     const float R2f = (float)R2, Rf = sqrtf(R2f);
     int cur = 0;                                              // ring slot of tap 0 in XT
     int hs = 0;                                               // history slot of the CURRENT network (valid from step 1 on)
+    // Steady state (every factor of every tap known as a list) runs a FUSED schedule with three workgroup barriers per
+    // step instead of K + 3: gather stage 1 of step t + 1 (every tap >= 1 times the network that phase D of step t has just
+    // built) rides in D2/D3's neighbour walk -- same rows, same list -- and the LAST gather stage runs inside the MLP waves
+    // on their own 16 columns, so the hidden layers start without a barrier.  `s1_ready` says the previous step's phase D
+    // produced this step's stage 1; steps before that (and the first step of a launch) run the stage-by-stage phase A.
+    bool s1_ready = false;
+    constexpr int S1T = CK ? (CK > 1 ? CK - 1 : 1) : 4;       // taps >= 1 (K <= 5)
 
     for (int t = 0; t < T; ++t) {
         RO_STAMP(0);
@@ -259,40 +273,57 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         // products that reach back before the launch (the first K - 1 steps) end with one dense multiplication by the
         // caller's slice G_{j-hv}(t0), read from HBM.
         const int hv = min(t + t_off, K - 1);                 // networks available as lists: A_t .. A_{t-hv+1}
-        for (int q = 1; q <= hv; ++q) {
-            const int j = q + gt;
-            float sa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const bool on = j <= K - 1 && gt < K - 1;
+        const bool fused = s1_ready;                          // (implies hv == K - 1)
+        // One summation order for a gather stage wherever it runs (here, inside the MLP waves, inside phase D): four lanes
+        // per column, lane `part` takes list entries part, part + 4, ... in order, quad sum (l ^ 1, then l ^ 2) -- so a step
+        // computes the same bits whether it is the first of a launch or deep inside one.
+        for (int q = fused ? 2 : 1; q <= (fused ? K - 2 : hv); ++q) {
+            float sa[S1T][6];
+#pragma unroll
+            for (int jj = 0; jj < S1T; ++jj)
+#pragma unroll
+                for (int f = 0; f < 6; ++f) sa[jj][f] = 0.f;
             int hq = hs - (q - 1); hq = hq < 0 ? hq + H : hq;   // slot of A_{t-q+1}
-            if (on) {
-                const int cnt = rcnt[hq * N + gn];
-                const unsigned char* lp = rlist + ((size_t)hq * N + gn) * RS;
+            if (fr < N) {
+                const int cnt = rcnt[hq * N + fr];
+                const unsigned char* lp = rlist + ((size_t)hq * N + fr) * RS;
                 const float* wq = wrow + hq * N;
-                const float* src = (q == 1) ? XT + (size_t)ro_slot(cur, j, K) * Np * 8
-                                            : VB + ((size_t)((q - 1) & 1) * (K - 2) + (j - 2)) * Np * 8;
-                for (int e = gq; e < cnt; e += 2) {
+                for (int e = fq; e < cnt; e += 4) {
                     const int m = lp[e];
                     const float gv = wq[m];
-                    const float4 x0 = *reinterpret_cast<const float4*>(src + m * 8);
-                    const float2 x1 = *reinterpret_cast<const float2*>(src + m * 8 + 4);
-                    sa[0] = fmaf(x0.x, gv, sa[0]); sa[1] = fmaf(x0.y, gv, sa[1]); sa[2] = fmaf(x0.z, gv, sa[2]);
-                    sa[3] = fmaf(x0.w, gv, sa[3]); sa[4] = fmaf(x1.x, gv, sa[4]); sa[5] = fmaf(x1.y, gv, sa[5]);
+#pragma unroll
+                    for (int jj = 0; jj < S1T; ++jj) {
+                        if (q + jj <= K - 1) {                // tap j = q + jj
+                            const float* src = ((q == 1) ? XT + (size_t)ro_slot(cur, q + jj, K) * Np * 8
+                                                         : VB + ((size_t)((q - 1) & 1) * (K - 2) + (q + jj - 2)) * Np * 8) + m * 8;
+                            const float4 x0 = *reinterpret_cast<const float4*>(src);
+                            const float2 x1 = *reinterpret_cast<const float2*>(src + 4);
+                            sa[jj][0] = fmaf(x0.x, gv, sa[jj][0]); sa[jj][1] = fmaf(x0.y, gv, sa[jj][1]);
+                            sa[jj][2] = fmaf(x0.z, gv, sa[jj][2]); sa[jj][3] = fmaf(x0.w, gv, sa[jj][3]);
+                            sa[jj][4] = fmaf(x1.x, gv, sa[jj][4]); sa[jj][5] = fmaf(x1.y, gv, sa[jj][5]);
+                        }
+                    }
                 }
             }
 #pragma unroll
-            for (int f = 0; f < 6; ++f) sa[f] += dpp_f<0xB1>(sa[f]);
-            if (on && gq == 0) {
-                if (j == q) {                                 // the tap's last factor: result in MFMA B-fragment order
+            for (int jj = 0; jj < S1T; ++jj) {
+                if (q + jj <= K - 1) {
 #pragma unroll
-                    for (int f = 0; f < 6; ++f) act[gn * RO_CS + rpos(f * K + j)] = sa[f];
-                } else {
-                    float* dst = VB + ((size_t)(q & 1) * (K - 2) + (j - 2)) * Np * 8 + gn * 8;
-                    *reinterpret_cast<float4*>(dst) = make_float4(sa[0], sa[1], sa[2], sa[3]);
-                    *reinterpret_cast<float2*>(dst + 4) = make_float2(sa[4], sa[5]);
+                    for (int f = 0; f < 6; ++f) { sa[jj][f] += dpp_f<0xB1>(sa[jj][f]); sa[jj][f] += dpp_f<0x4E>(sa[jj][f]); }
+                    if (fq == 0 && fr < N) {
+                        if (jj == 0) {                        // the tap's last factor: result in MFMA B-fragment order
+#pragma unroll
+                            for (int f = 0; f < 6; ++f) act[fr * RO_CS + rpos(f * K + q)] = sa[0][f];
+                        } else {
+                            float* dst = VB + ((size_t)(q & 1) * (K - 2) + (q + jj - 2)) * Np * 8 + fr * 8;
+                            *reinterpret_cast<float4*>(dst) = make_float4(sa[jj][0], sa[jj][1], sa[jj][2], sa[jj][3]);
+                            *reinterpret_cast<float2*>(dst + 4) = make_float2(sa[jj][4], sa[jj][5]);
+                        }
+                    }
                 }
             }
             if (q == 1) RO_STAMP(6);
-            if (q < hv || hv < K - 1) __syncthreads();        // (the last stage of a steady-state step shares A's closing barrier)
+            if (fused || q < hv || hv < K - 1) __syncthreads();   // (the last stage of an unfused step shares A's closing barrier)
         }
         if (hv < K - 1) {
             // taps j > hv: the product so far (x_{t-j} itself on the launch's first step) times the caller's dense slice j - hv,
@@ -325,13 +356,56 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 for (int f = 0; f < 6; ++f) act[gn * RO_CS + rpos(f * K + j)] = sa[f];
             }
         }
-        if (tid == RO_THREADS - 1) mmax[0] = 0u;              // consumed in the previous step's D1, refilled in C
-        __syncthreads();
+        if (!fused) __syncthreads();                          // fused: the stages above ended with their own barrier
         RO_STAMP(1);
         // -------------------------------------------------------------- B: filter GEMM + MLP on MFMA
         // Layer metadata comes from bit-packed scalar kernel arguments: P.dims[l] indexed dynamically is re-fetched from
         // the kernel-argument segment every layer of every step (~700 cycles each).
         if (wave < NT) {                                      // wave w owns columns 16 w .. 16 w + 15 through every layer
+            if (fused && K >= 3) {
+                // last gather stage (tap K - 1 times A_{t-K+2}) for the wave's own columns: four lanes per column walk its
+                // list two entries at a time, DPP quad sum, straight into the B-fragment slot the first layer reads below
+                // (LDS operations of one wave are ordered: no barrier)
+                const int q = K - 1;
+                int hq = hs - (q - 1); hq = hq < 0 ? hq + H : hq;
+                const int c4 = wave * 16 + (lane >> 2), part = lane & 3;
+                float sa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (c4 < N) {
+                    const int cnt = rcnt[hq * N + c4];
+                    const unsigned char* lp = rlist + ((size_t)hq * N + c4) * RS;
+                    const float* wq = wrow + hq * N;
+                    const float* src = VB + ((size_t)((q - 1) & 1) * (K - 2) + (q - 2)) * Np * 8;
+                    // four entries per lane per pass (lists of up to 16 neighbours in ONE pass): all list bytes first, then
+                    // every operand read of the pass in flight together, then the multiply-adds in list order -- two LDS
+                    // round trips per pass instead of two per entry (entries beyond the list: weight 0 on a valid row)
+                    for (int e = part; e < cnt; e += 16) {
+                        int m[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) m[u] = lp[min(e + 4 * u, cnt - 1)];
+                        float g[4]; float4 xa[4]; float2 xb[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            g[u] = wq[m[u]];
+                            xa[u] = *reinterpret_cast<const float4*>(src + m[u] * 8);
+                            xb[u] = *reinterpret_cast<const float2*>(src + m[u] * 8 + 4);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (e + 4 * u < cnt) {
+                                sa[0] = fmaf(xa[u].x, g[u], sa[0]); sa[1] = fmaf(xa[u].y, g[u], sa[1]); sa[2] = fmaf(xa[u].z, g[u], sa[2]);
+                                sa[3] = fmaf(xa[u].w, g[u], sa[3]); sa[4] = fmaf(xb[u].x, g[u], sa[4]); sa[5] = fmaf(xb[u].y, g[u], sa[5]);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int f = 0; f < 6; ++f) { sa[f] += dpp_f<0xB1>(sa[f]); sa[f] += dpp_f<0x4E>(sa[f]); }
+                if (part == 0 && c4 < N) {
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) act[c4 * RO_CS + rpos(f * K + q)] = sa[f];
+                }
+                RO_STAMP(6);
+            }
             const int col = wave * 16 + li;
             float* pcol = act + col * RO_CS;
             for (int l = 0; l < n_layers - 1; ++l) {
@@ -470,8 +544,21 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         __syncthreads();
         RO_STAMP(7);
         // -------------------------------------------------------------- D2/D3: neighbour lists + fp64 feature terms
+        // stage 1 of step t + 1 rides along when that step will find every factor as a list: x_{t+1-j} . A_{t+1} for taps
+        // j >= 1 over the very neighbour list this phase walks for the features.  A_{t+1}[m, n] = w(deg m) on the (symmetric)
+        // pattern: the neighbour's degree is the population count of ITS bit row (complete since the D1 barrier), its weight
+        // the table entry -- the same value phase D3 stores in w_new[m].
+        const bool do_s1 = K >= 2 && t + 1 < T && t + 1 + t_off >= K - 1;
+        const int curn = (cur + 1 == K) ? 0 : cur + 1;        // ring slot of tap 0 of step t + 1
+        if (tid == RO_THREADS - 1) mmax[0] = 0u;              // consumed in D1 above, refilled in the next step's phase C
+        if (tid == RO_THREADS - 2) { cref[0] = spx[0]; cref[1] = spy[0]; }   // next step's reference point (any point is valid)
         if (tid < 4 * ((N + 15) & ~15)) {                     // 4 lanes per row, whole waves
             double f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0;
+            float s1[S1T][6];
+#pragma unroll
+            for (int jj = 0; jj < S1T; ++jj)
+#pragma unroll
+                for (int f = 0; f < 6; ++f) s1[jj][f] = 0.f;
             int cnt = 0;
             if (fr < N) {
                 const unsigned long long lo = rm_new[2 * fr], hi = rm_new[2 * fr + 1];
@@ -497,9 +584,42 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                     f3 += vyi - svy[j];
                     f4 += dy * qq;
                     f5 += dy * q;
+                    if (do_s1) {
+                        const float gv = wtab[__popcll(rm_new[2 * j]) + __popcll(rm_new[2 * j + 1])];
+#pragma unroll
+                        for (int jj = 0; jj < S1T; ++jj) {
+                            if (jj < K - 1) {
+                                const float* src = XT + ((size_t)ro_slot(curn, jj + 1, K) * Np + j) * 8;
+                                const float4 x0 = *reinterpret_cast<const float4*>(src);
+                                const float2 x1 = *reinterpret_cast<const float2*>(src + 4);
+                                s1[jj][0] = fmaf(x0.x, gv, s1[jj][0]); s1[jj][1] = fmaf(x0.y, gv, s1[jj][1]);
+                                s1[jj][2] = fmaf(x0.z, gv, s1[jj][2]); s1[jj][3] = fmaf(x0.w, gv, s1[jj][3]);
+                                s1[jj][4] = fmaf(x1.x, gv, s1[jj][4]); s1[jj][5] = fmaf(x1.y, gv, s1[jj][5]);
+                            }
+                        }
+                    }
                 }
             }
             RO_STAMP(8);
+            if (do_s1) {
+#pragma unroll
+                for (int jj = 0; jj < S1T; ++jj) {
+                    if (jj < K - 1) {
+#pragma unroll
+                        for (int f = 0; f < 6; ++f) { s1[jj][f] += dpp_f<0xB1>(s1[jj][f]); s1[jj][f] += dpp_f<0x4E>(s1[jj][f]); }
+                        if (fq == 0 && fr < N) {
+                            if (jj == 0) {                    // tap 1: stage 1 is its only factor -> B-fragment slot
+#pragma unroll
+                                for (int f = 0; f < 6; ++f) act[fr * RO_CS + rpos(f * K + 1)] = s1[0][f];
+                            } else {                          // taps >= 2: running product for stage 2 (buffer parity of q = 1)
+                                float* dst = VB + ((size_t)(K - 2) + (jj - 1)) * Np * 8 + fr * 8;
+                                *reinterpret_cast<float4*>(dst) = make_float4(s1[jj][0], s1[jj][1], s1[jj][2], s1[jj][3]);
+                                *reinterpret_cast<float2*>(dst + 4) = make_float2(s1[jj][4], s1[jj][5]);
+                            }
+                        }
+                    }
+                }
+            }
             f0 += dpp_d<0xB1>(f0); f1 += dpp_d<0xB1>(f1); f2 += dpp_d<0xB1>(f2);
             f3 += dpp_d<0xB1>(f3); f4 += dpp_d<0xB1>(f4); f5 += dpp_d<0xB1>(f5);
             f0 += dpp_d<0x4E>(f0); f1 += dpp_d<0x4E>(f1); f2 += dpp_d<0x4E>(f2);
@@ -519,9 +639,9 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         }
         __syncthreads();
         RO_STAMP(4);
-        if (tid == 0) { cref[0] = spx[0]; cref[1] = spy[0]; }  // next step's reference point (any point is valid)
-        cur = (cur + 1 == K) ? 0 : cur + 1;
+        cur = curn;
         hs = hsn;
+        s1_ready = do_s1;
         RO_STAMP(5);
     }
 
