@@ -248,6 +248,40 @@ int mgp_rollout_steps_ex(double* x, float* G, float* Xd, const float* const* W, 
                          const int* dims, int n_layers, float* action, double* rewards,
                          const MgpFlockParams* p, int B, int K, int N, int T, const float* image, void* carry, int flags,
                          void* stream);
+/* DAGGER data collection on the same kernel (reference gnn_dagger.py:154-178, batched over B lock-step episodes): every
+ * step (i) files the state it starts from as a compact FRAME -- features x_t (6,N) fp32, membership bits of its network
+ * A_t (N x 2 u64), the expert's action for it (2,N) fp32 (the label, :174-176), its age (steps since reset) -- into a ring
+ * laid out [ring_steps][B], at ring step (ring_step0 + t) % ring_steps; (ii) is driven by the expert with probability
+ * beta[b], else by the policy (:157-161), the coin being the counter-based hash dagger_coin(seed, episode[b], age)
+ * (csrc/mgp_device.h; oracle/dagger_vec.py) -- no host RNG, no per-step host traffic.  The K-tap training state of a frame is
+ * rebuilt from it and its K-1 predecessors in the ring (same lane) by mgp_replay_gather: 4.8 KB per transition at N = 100
+ * instead of the 128 KB of a dense (delay_state, delay_gso) pair.
+ * expert_io (B,2,N): in = expert action of the entry state, out = of the final state (chain launches through it).
+ * Requires MGP_RO_ENTER_CARRY | MGP_RO_EXIT_CARRY (collection starts at a reset observation -- all-zero carry -- or continues
+ * a collecting launch) and N <= 128. */
+typedef struct MgpCollect {
+    float* feat;                 /* [ring_steps][B][6][N] */
+    unsigned long long* bits;    /* [ring_steps][B][N][2] */
+    float* label;                /* [ring_steps][B][2][N] */
+    int* age;                    /* [ring_steps][B]       */
+    float* expert_io;            /* (B,2,N) */
+    const float* beta;           /* (B) */
+    const unsigned int* episode; /* (B) global episode index: the coin stream of the lane */
+    unsigned int seed;
+    int age0;                    /* age of the entry state (all lanes advance in lock step) */
+    int ring_step0;              /* ring step of the entry state's frame */
+    int ring_steps;
+} MgpCollect;
+int mgp_rollout_collect(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
+                        const int* dims, int n_layers, double* rewards, const MgpFlockParams* p, int B, int K, int N, int T,
+                        const float* image, void* carry, int flags, const MgpCollect* collect, void* stream);
+/* Minibatch states from the frame ring: for batch element i with frame index r = idx[(cursor ? *cursor : 0) * Bt + i]
+ * (frame index = ring_step * lanes + lane): X[i,k] = features of frame r - k*lanes (ring-wrapped) if age[r] >= k else 0;
+ * Y[i] = label[r]; G[i,0] = I, G[i,j] = A_t A_{t-1} .. A_{t-j+1} from the bits (row weight 1/max(deg,1) or 1) if age[r] >= j
+ * else 0 (state_with_delay.py:44-53 on the stored history).  idx int64 on the device, cursor int32 on the device or NULL. */
+int mgp_replay_gather(const float* feat, const unsigned long long* bits, const float* label, const int* age,
+                      const long* idx, const int* cursor, int Bt, int lanes, int ring_steps, int K, int N, int mean_pooling,
+                      float* X, float* G, float* Y, void* stream);
 long mgp_rollout_image_floats(const int* dims, int n_layers, int K, int N);      /* 0: shape not covered */
 int mgp_rollout_image(const float* const* W, const float* const* b, const int* dims, int n_layers, int K, int N,
                       float* image, void* stream);

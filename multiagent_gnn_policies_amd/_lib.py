@@ -27,6 +27,13 @@ class MgpFlockParams(ctypes.Structure):
                 ('reserved_', ctypes.c_int)]
 
 
+class MgpCollect(ctypes.Structure):
+    """Mirror of struct MgpCollect (include/mgp.h): frame ring + coin parameters of a collecting rollout."""
+    _fields_ = [('feat', ctypes.c_void_p), ('bits', ctypes.c_void_p), ('label', ctypes.c_void_p), ('age', ctypes.c_void_p),
+                ('expert_io', ctypes.c_void_p), ('beta', ctypes.c_void_p), ('episode', ctypes.c_void_p),
+                ('seed', ctypes.c_uint), ('age0', ctypes.c_int), ('ring_step0', ctypes.c_int), ('ring_steps', ctypes.c_int)]
+
+
 # name -> (restype, argtypes).  Pointers are passed as raw integers (tensor.data_ptr()).
 SIGNATURES = {
     'mgp_version': (_int, []),
@@ -58,6 +65,9 @@ SIGNATURES = {
                                 _int, _int, _int, _int, _vp]),
     'mgp_rollout_steps_ex': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, ctypes.POINTER(MgpFlockParams),
                                    _int, _int, _int, _int, _vp, _vp, _int, _vp]),
+    'mgp_rollout_collect': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, ctypes.POINTER(MgpFlockParams),
+                                  _int, _int, _int, _int, _vp, _vp, _int, _vp, _vp]),
+    'mgp_replay_gather': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     'mgp_rollout_image_floats': (_long, [_vp, _int, _int, _int]),
     'mgp_rollout_image': (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
     'mgp_rollout_carry_bytes': (_long, [_int, _int]),

@@ -71,3 +71,12 @@ __device__ __forceinline__ bool link_up(const MgpFlockParams& p, int i, int j, i
     const unsigned int pair = lo * (unsigned int)N + hi;
     return fmix32((wi + wj) ^ (p.link_seed + 0x27D4EB2Fu * pair)) >= p.link_drop;
 }
+
+// ---- DAGGER coin (reference gnn_dagger.py:157: np.random.binomial(1, beta) once per environment step).  Counter-based so
+// that a step's draw depends only on (seed, global episode index, steps since that episode's reset): the same for any
+// chunking of an episode into launches, any lane assignment, any rank.  The expert drives the step iff
+// dagger_coin(seed, episode, step) < floor(beta * 2^32)  (beta >= 1: always).  Spec + oracle: oracle/dagger_vec.py.
+__device__ __forceinline__ unsigned int dagger_coin(unsigned int seed, unsigned int episode, unsigned int step)
+{
+    return fmix32(fmix32(seed + 0x9E3779B1u * episode) ^ (0x85EBCA77u * step + 0xC2B2AE3Du));
+}

@@ -1,0 +1,105 @@
+// Compact DAGGER replay: minibatch states rebuilt from the frame ring the collecting rollout kernel fills
+// (mgp_rollout_collect, rollout.hip).  Replaces the reference's torch.cat over 20 Python state objects of 290 KB each
+// (gnn_dagger.py:83-86, replay_buffer.py:6-49) and the dense device replay of round 1 (128 KB per transition at N = 100):
+// a frame is the features x_t (6,N), the membership bits of the network A_t (N x 2 u64), the expert label (2,N) and the
+// age of the state -- 4.8 KB -- and the K-tap state of a transition is its frame plus its K-1 predecessors in the ring:
+//     delay_state[k] = x_{t-k}                       (state_with_delay.py:50-53; zero before the episode's reset)
+//     delay_gso[0] = I, delay_gso[j] = A_t A_{t-1} .. A_{t-j+1}      (:44-47; zero for j > age: the reference starts every
+//                                                                      episode from zero-filled slices)
+// The products are evaluated row by row along the bit rows, e_i A_t A_{t-1} .., with the summation order of the rollout
+// kernels' own dense rebuild (ascending neighbour index); row weights are (float)(1 / max(deg, 1)) (mean pooling) or 1.
+#include "mgp_common.h"
+
+namespace {
+
+constexpr int RG_THREADS = 1024;
+constexpr int RG_WAVES = RG_THREADS / 64;
+
+__global__ __launch_bounds__(RG_THREADS)
+void replay_gather_kernel(const float* __restrict__ feat, const unsigned long long* __restrict__ bits,
+                          const float* __restrict__ label, const int* __restrict__ age, const long* __restrict__ idx,
+                          const int* __restrict__ cursor, int Bt, int lanes, int ring_steps, int K, int N, int mean_pooling,
+                          float* __restrict__ X, float* __restrict__ G, float* __restrict__ Y)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    const int H = K > 1 ? K - 1 : 1, Np = (N + 3) & ~3;
+    unsigned long long* sb = reinterpret_cast<unsigned long long*>(smraw);                  // [H][N][2]
+    float* sw = reinterpret_cast<float*>(sb + (size_t)H * N * 2);                           // [H][N]
+    float* rball = sw + ((H * N + 3) & ~3);                                                 // [waves][2][Np]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long cur = cursor != nullptr ? (long)cursor[0] : 0L;
+    const long r = idx[cur * Bt + b];
+    const long ring = (long)ring_steps * lanes;
+    const int a = age[r];
+    // delay line and label
+    for (int e = tid; e < K * 6 * N; e += RG_THREADS) {
+        const int k = e / (6 * N), rem = e - k * 6 * N;
+        long rk = r - (long)k * lanes; rk = rk < 0 ? rk + ring : rk;
+        X[(size_t)b * K * 6 * N + e] = (a >= k) ? feat[(size_t)rk * 6 * N + rem] : 0.f;
+    }
+    for (int e = tid; e < 2 * N; e += RG_THREADS) Y[(size_t)b * 2 * N + e] = label[(size_t)r * 2 * N + e];
+    float* Gb = G + (size_t)b * K * N * N;
+    for (int e = tid; e < N * N; e += RG_THREADS) { const int i = e / N, n = e - i * N; Gb[e] = (i == n) ? 1.f : 0.f; }
+    if (K < 2) return;
+    // history networks: slot q = A_{t-q}; only the first min(a, K-1) products exist
+    for (int e = tid; e < H * N; e += RG_THREADS) {
+        const int q = e / N, row = e - q * N;
+        long rq = r - (long)q * lanes; rq = rq < 0 ? rq + ring : rq;
+        unsigned long long lo = 0ull, hi = 0ull;
+        if (a >= q + 1) { lo = bits[((size_t)rq * N + row) * 2]; hi = bits[((size_t)rq * N + row) * 2 + 1]; }
+        sb[(size_t)e * 2] = lo; sb[(size_t)e * 2 + 1] = hi;
+        const double deg = (double)(__popcll(lo) + __popcll(hi));
+        sw[e] = (float)(mean_pooling ? 1.0 / (deg == 0.0 ? 1.0 : deg) : 1.0);
+    }
+    __syncthreads();
+    float* rbuf = rball + wave * 2 * Np;
+    for (int j = 1; j <= K - 1; ++j) {
+        float* Gj = Gb + (size_t)j * N * N;
+        if (a < j) {                                          // no j-step history yet: zero slice (reference: zero-filled)
+            for (int e = tid; e < N * N; e += RG_THREADS) Gj[e] = 0.f;
+            continue;
+        }
+        for (int i = wave; i < N; i += RG_WAVES) {
+            float* r0 = rbuf;
+            float* r1 = rbuf + Np;
+            const float wi = sw[i];
+            const unsigned long long* rowT = sb + (size_t)i * 2;
+            for (int n = lane; n < N; n += 64) r0[n] = ((rowT[n >> 6] >> (n & 63)) & 1ull) ? wi : 0.f;
+            for (int q = 1; q < j; ++q) {
+                const float* wq = sw + q * N;
+                for (int n = lane; n < N; n += 64) {
+                    const unsigned long long* rw = sb + ((size_t)q * N + n) * 2;
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int wd = 0; wd < 2; ++wd) {
+                        unsigned long long w = rw[wd];
+                        while (w) { const int m = 64 * wd + __builtin_ctzll(w); w &= w - 1ull; sacc = fmaf(r0[m], wq[m], sacc); }
+                    }
+                    r1[n] = sacc;
+                }
+                float* tsw = r0; r0 = r1; r1 = tsw;
+            }
+            for (int n = lane; n < N; n += 64) Gj[(size_t)i * N + n] = r0[n];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mgp_replay_gather(const float* feat, const unsigned long long* bits, const float* label, const int* age,
+                                 const long* idx, const int* cursor, int Bt, int lanes, int ring_steps, int K, int N,
+                                 int mean_pooling, float* X, float* G, float* Y, void* stream)
+{
+    if (Bt < 0 || lanes < 1 || ring_steps < 1 || K < 1 || K > 5 || N < 4) return MGP_EINVAL;
+    if (N > 128) return MGP_EUNSUPPORTED;
+    if (Bt == 0) return MGP_OK;
+    MGP_CHECK_PTR(feat); MGP_CHECK_PTR8(bits); MGP_CHECK_PTR(label); MGP_CHECK_PTR(age); MGP_CHECK_PTR8(idx);
+    MGP_CHECK_PTR(X); MGP_CHECK_PTR(G); MGP_CHECK_PTR(Y);
+    if (cursor != nullptr && (reinterpret_cast<uintptr_t>(cursor) & 3u)) return MGP_EALIGN;
+    const int H = K > 1 ? K - 1 : 1, Np = (N + 3) & ~3;
+    const int lds = H * N * 2 * 8 + ((H * N + 3) & ~3) * 4 + RG_WAVES * 2 * Np * 4;
+    mgp_clear_error();
+    hipLaunchKernelGGL(replay_gather_kernel, dim3(Bt), dim3(RG_THREADS), lds, static_cast<hipStream_t>(stream), feat, bits, label,
+                       age, idx, cursor, Bt, lanes, ring_steps, K, N, mean_pooling, X, G, Y);
+    return mgp_launch_status();
+}

@@ -82,6 +82,7 @@ struct RoOff {
     int sxy;                              // float2 [N] fp32 coordinates relative to the reference point
     int mmax;                             // uint: max |relative coordinate| of the step (float bits)
     int wtab;                             // float [N + 1]: row weight of a network row by its degree (1/max(deg,1) or 1)
+    int uexp;                             // float [2][N] expert action of the current state (data collection) + double [2] velocity sums
     int wl;                               // float weight image: per layer fragments [MT][64][RO_WFS] + bias [MT*16]
 };
 
@@ -118,6 +119,7 @@ __host__ __device__ constexpr RoOff ro_offsets(int N, int K)
     c.sxy = ro_take(off, N * 8);
     c.mmax = ro_take(off, 16);
     c.wtab = ro_take(off, (N + 1) * 4);
+    c.uexp = ro_take(off, 2 * N * 4 + 16);
     c.wl = off;
     return c;
 }
@@ -125,13 +127,16 @@ __host__ __device__ constexpr RoOff ro_offsets(int N, int K)
 // CN / CK: compile-time (N, K) of a specialised instantiation (0 = take the run-time arguments): constant LDS addresses,
 // loop bounds and divisors shorten every phase's address arithmetic and relieve the SGPR file (the generic build spills).
 // FD: link fading (FlockingStochastic-v0) compiled in.
-template <int CN, int CK, bool FD>
+// CL: DAGGER data collection (reference gnn_dagger.py:154-178) compiled in: every step files the state it starts from --
+// features, membership bits of its network, expert label, age -- as a compact frame, and the step is driven by the expert
+// with probability beta (a counter-based coin: mgp_device.h dagger_coin), else by the policy.
+template <int CN, int CK, bool FD, bool CL>
 __global__ __launch_bounds__(RO_THREADS)
 void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __restrict__ Xd, float* __restrict__ action,
                     double* __restrict__ rewards, RoParams P, MgpFlockParams p, int K_arg, int N_arg, int T,
                     unsigned long long dimsA, unsigned int dims8, unsigned long long woffA, unsigned long long woffB,
                     int n_layers, const float* __restrict__ image, int image_floats, unsigned long long* __restrict__ carry,
-                    int flags)
+                    int flags, MgpCollect cl)
 {
     const int N = CN ? CN : N_arg, K = CK ? CK : K_arg;
     const RoOff cv = ro_offsets(N, K);
@@ -152,6 +157,8 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     float2* sxy = reinterpret_cast<float2*>(smraw + cv.sxy);
     unsigned int* mmax = reinterpret_cast<unsigned int*>(smraw + cv.mmax);
     float* wtab = reinterpret_cast<float*>(smraw + cv.wtab);
+    float* uexp = reinterpret_cast<float*>(smraw + cv.uexp);                 // [2][N]
+    double* vtot = reinterpret_cast<double*>(smraw + cv.uexp + ((2 * N * 4 + 7) & ~7));
     const int RS = ro_list_stride(N);                         // list row stride (bytes)
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -174,6 +181,14 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         spx[i] = xb[i * 4 + 0]; spy[i] = xb[i * 4 + 1]; svx[i] = xb[i * 4 + 2]; svy[i] = xb[i * 4 + 3];
     }
     if (tid == 0) { cref[0] = xb[0]; cref[1] = xb[1]; mmax[0] = 0u; }
+    unsigned long long coin_thr = 0ull;
+    unsigned int coin_ep = 0u;
+    if (CL) {
+        for (int e = tid; e < 2 * N; e += RO_THREADS) uexp[e] = cl.expert_io[(size_t)b * 2 * N + e];
+        const double bq = floor((double)cl.beta[b] * 4294967296.0);       // P(expert drives) in units of 2^-32
+        coin_thr = bq <= 0.0 ? 0ull : (bq >= 4294967296.0 ? 4294967296ull : (unsigned long long)bq);
+        coin_ep = cl.episode[b];
+    }
     for (int c = tid; c <= N; c += RO_THREADS) {              // the expression of phase D3, tabulated by degree
         const double deg = (double)c;
         wtab[c] = (float)(p.mean_pooling ? 1.0 / (deg == 0.0 ? 1.0 : deg) : 1.0);
@@ -455,6 +470,9 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             if (agent) {
                 const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * 4 * RO_KS);
                 ux += bb.x; uy += bb.y;
+                if (CL && (unsigned long long)dagger_coin(cl.seed, coin_ep, (unsigned int)(cl.age0 + t)) < coin_thr) {
+                    ux = uexp[ccol]; uy = uexp[N + ccol];      // the expert drives this step (gnn_dagger.py:157-158)
+                }
                 uact[ccol] = ux; uact[N + ccol] = uy;
                 const float ub[2] = {ux, uy};
                 integrate_one(px, py, vx, vy, ub, 1, ccol < p.n_leaders, p);
@@ -468,16 +486,31 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             if (lane == 63) atomicMax(mmax, __float_as_uint(m));
             RO_STAMP(9);  // non-negative floats order like their bit patterns
         } else {
+            if (CL) {
+                // meanwhile the other waves file the state this step starts from (reference gnn_dagger.py:178: the transition
+                // stores the state BEFORE the step and the expert's action for it): features = tap 0 of the delay line, the
+                // bits of its network (still in rowmask), the label phase D3 of the previous step left in uexp, its age
+                const int it0 = tid - NT * 64, nth = RO_THREADS - NT * 64;
+                const size_t fs = (size_t)((cl.ring_step0 + t) % cl.ring_steps) * gridDim.x + b;
+                float* ff = cl.feat + fs * 6 * N;
+                for (int e = it0; e < 6 * N; e += nth) { const int f = e / N, n = e - f * N; ff[e] = XT[((size_t)cur * Np + n) * 8 + f]; }
+                unsigned long long* fb = cl.bits + fs * 2 * N;
+                for (int i = it0; i < 2 * N; i += nth) fb[i] = rowmask[i];
+                float* fl = cl.label + fs * 2 * N;
+                for (int e = it0; e < 2 * N; e += nth) fl[e] = uexp[e];
+                if (it0 == 0) cl.age[fs] = cl.age0 + t;
+            }
             // meanwhile the other waves clear the membership bits: this step's pairwise pass starts from empty rows
             for (int i = tid - NT * 64; i < 2 * N; i += RO_THREADS - NT * 64) rowmask[i] = 0ull;
         }
         __syncthreads();
         RO_STAMP(3);
         // -------------------------------------------------------------- D1: membership bits, every unordered pair once
-        if (wave == RO_WAVES - 1 && rewards != nullptr) {     // reward: one wave, no workgroup barrier
+        if (wave == RO_WAVES - 1 && (rewards != nullptr || CL)) {     // reward: one wave, no workgroup barrier
             double sx = 0.0, sy = 0.0;
             for (int i = lane; i < N; i += 64) { sx += svx[i]; sy += svy[i]; }
             sx = mgp_wave_sum(sx); sy = mgp_wave_sum(sy);
+            if (CL && lane == 0) { vtot[0] = sx; vtot[1] = sy; }   // the centralised expert's velocity term (phase D3)
             const double mx = sx / (double)N, my = sy / (double)N;
             double dv = 0.0;
             for (int i = lane; i < N; i += 64) {
@@ -485,7 +518,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 dv += ex * ex + ey * ey;
             }
             const double var = mgp_wave_sum(dv) / (double)N;
-            if (lane == 0) rewards[(size_t)b * T + t] = -1.0 * var * p.reward_scale;
+            if (lane == 0 && rewards != nullptr) rewards[(size_t)b * T + t] = -1.0 * var * p.reward_scale;
         }
         if (pi < N) {
             // |r2_fp32 - r2_exact| < band for every pair within 2R of each other (coordinates are
@@ -632,6 +665,14 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 float* xn = XT + ((size_t)(cur + 1 == K ? 0 : cur + 1) * Np + fr) * 8;     // overwrites the oldest tap
                 *reinterpret_cast<float4*>(xn) = make_float4((float)f0, (float)f1, (float)f2, (float)f3);
                 *reinterpret_cast<float4*>(xn + 4) = make_float4((float)f4, (float)f5, 0.f, 0.f);
+                if (CL) {
+                    // expert action of the NEW state, closed form of its observation (FLOCK-SPEC section 5; the expression of
+                    // flock.hip): the label of the next transition, and what drives the next step when the coin says so
+                    double tvx = f0, tvy = f3;
+                    if (p.centralized) { tvx = (double)N * svx[fr] - vtot[0]; tvy = (double)N * svy[fr] - vtot[1]; }
+                    uexp[fr] = (float)(clipd(-tvx - (2.0 * f2 - 2.0 * f1), -p.ctrl_clip, p.ctrl_clip) * p.ctrl_gain);
+                    uexp[N + fr] = (float)(clipd(-tvy - (2.0 * f5 - 2.0 * f4), -p.ctrl_clip, p.ctrl_clip) * p.ctrl_gain);
+                }
                 float* y0 = act + fr * RO_CS;                 // tap 0 of the next step's aggregation: G_0 = I  =>  y_0 = X_0
                 y0[rpos(0 * K)] = (float)f0; y0[rpos(1 * K)] = (float)f1; y0[rpos(2 * K)] = (float)f2;
                 y0[rpos(3 * K)] = (float)f3; y0[rpos(4 * K)] = (float)f4; y0[rpos(5 * K)] = (float)f5;
@@ -727,6 +768,8 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     }
     if (action != nullptr)
         for (int e = tid; e < 2 * N; e += RO_THREADS) action[(size_t)b * 2 * N + e] = uact[e];
+    if (CL)
+        for (int e = tid; e < 2 * N; e += RO_THREADS) cl.expert_io[(size_t)b * 2 * N + e] = uexp[e];
     RO_STAMPX(2);
 }
 
@@ -1274,17 +1317,18 @@ __global__ void rollout_image_kernel(RoParams P, int K, float* __restrict__ imag
     }
 }
 
-template <int CN, int CK, bool FD>
+template <int CN, int CK, bool FD, bool CL>
 int launch_rollout(double* x, float* G, float* Xd, float* action, double* rewards, const RoParams& P,
                    const MgpFlockParams* p, int B, int K, int N, int T, unsigned long long dimsA, unsigned int dims8,
                    unsigned long long woffA, unsigned long long woffB, int n_layers, int lds, hipStream_t st,
-                   const float* image, int image_floats, unsigned long long* carry, int flags)
+                   const float* image, int image_floats, unsigned long long* carry, int flags, const MgpCollect* cl)
 {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<CN, CK, FD>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<CN, CK, FD, CL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MGP_ELAUNCH;
-    hipLaunchKernelGGL((rollout_kernel<CN, CK, FD>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K,
-                       N, T, dimsA, dims8, woffA, woffB, n_layers, image, image_floats, carry, flags);
+    MgpCollect none = {};
+    hipLaunchKernelGGL((rollout_kernel<CN, CK, FD, CL>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K,
+                       N, T, dimsA, dims8, woffA, woffB, n_layers, image, image_floats, carry, flags, cl ? *cl : none);
     return mgp_launch_status();
 }
 
@@ -1310,11 +1354,13 @@ int launch_rollout_big(double* x, float* G, float* Xd, float* action, double* re
 #ifdef MGP_RO_WIDE
 #define MGP_RO_SUPPORTED mgp_rollout_wide_supported_
 #define MGP_RO_STEPS_EX mgp_rollout_wide_steps_ex_
+#define MGP_RO_COLLECT mgp_rollout_wide_collect_
 #define MGP_RO_IMAGE_FLOATS mgp_rollout_wide_image_floats_
 #define MGP_RO_IMAGE mgp_rollout_wide_image_
 #else
 #define MGP_RO_SUPPORTED mgp_rollout_supported
 #define MGP_RO_STEPS_EX mgp_rollout_steps_ex
+#define MGP_RO_COLLECT mgp_rollout_collect
 #define MGP_RO_IMAGE_FLOATS mgp_rollout_image_floats
 #define MGP_RO_IMAGE mgp_rollout_image
 extern "C" int mgp_rollout_wide_supported_(const int* dims, int n_layers, int K, int N);
@@ -1322,6 +1368,10 @@ extern "C" int mgp_rollout_wide_steps_ex_(double* x, float* G, float* Xd, const 
                                           const int* dims, int n_layers, float* action, double* rewards,
                                           const MgpFlockParams* p, int B, int K, int N, int T, const float* image,
                                           void* carry, int flags, void* stream);
+extern "C" int mgp_rollout_wide_collect_(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
+                                         const int* dims, int n_layers, double* rewards, const MgpFlockParams* p, int B, int K,
+                                         int N, int T, const float* image, void* carry, int flags, const MgpCollect* cl,
+                                         void* stream);
 extern "C" long mgp_rollout_wide_image_floats_(const int* dims, int n_layers, int K, int N);
 extern "C" int mgp_rollout_wide_image_(const float* const* W, const float* const* b, const int* dims, int n_layers, int K, int N,
                                        float* image, void* stream);
@@ -1372,10 +1422,11 @@ extern "C" int MGP_RO_IMAGE(const float* const* W, const float* const* b, const 
     return mgp_launch_status();
 }
 
-extern "C" int MGP_RO_STEPS_EX(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
-                               const int* dims, int n_layers, float* action, double* rewards,
-                               const MgpFlockParams* p, int B, int K, int N, int T, const float* image, void* carry_v,
-                               int flags, void* stream)
+namespace {
+int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
+           const int* dims, int n_layers, float* action, double* rewards,
+           const MgpFlockParams* p, int B, int K, int N, int T, const float* image, void* carry_v,
+           int flags, const MgpCollect* cl, void* stream)
 {
     if (B < 0 || T < 0 || p == nullptr) return MGP_EINVAL;
     if (image == nullptr && (W == nullptr || b == nullptr)) return MGP_EINVAL;
@@ -1384,6 +1435,9 @@ extern "C" int MGP_RO_STEPS_EX(double* x, float* G, float* Xd, const float* cons
     int lds = 0;
     if (!make_carve(dims, n_layers, K, N, &P, &lds)) {
 #ifndef MGP_RO_WIDE
+        if (cl != nullptr)
+            return mgp_rollout_wide_collect_(x, G, Xd, W, b, dims, n_layers, rewards, p, B, K, N, T, image, carry_v, flags, cl,
+                                             stream);
         return mgp_rollout_wide_steps_ex_(x, G, Xd, W, b, dims, n_layers, action, rewards, p, B, K, N, T, image, carry_v, flags,
                                           stream);
 #else
@@ -1391,6 +1445,15 @@ extern "C" int MGP_RO_STEPS_EX(double* x, float* G, float* Xd, const float* cons
 #endif
     }
     unsigned long long* carry = static_cast<unsigned long long*>(carry_v);
+    if (cl != nullptr) {
+        // data collection starts at a reset observation (all-zero carry) or continues a collecting launch: the frame of the
+        // launch's first state takes its network bits from the carry
+        if (N > RO_MAXN) return MGP_EUNSUPPORTED;
+        if (!(flags & MGP_RO_ENTER_CARRY) || !(flags & MGP_RO_EXIT_CARRY)) return MGP_EINVAL;
+        if (cl->ring_steps < 1 || cl->ring_step0 < 0 || cl->age0 < 0) return MGP_EINVAL;
+        MGP_CHECK_PTR(cl->feat); MGP_CHECK_PTR8(cl->bits); MGP_CHECK_PTR(cl->label); MGP_CHECK_PTR(cl->age);
+        MGP_CHECK_PTR(cl->expert_io); MGP_CHECK_PTR(cl->beta); MGP_CHECK_PTR(cl->episode);
+    }
     if (flags & ~(MGP_RO_ENTER_CARRY | MGP_RO_EXIT_CARRY | MGP_RO_SKIP_DENSE)) return MGP_EINVAL;
     if ((flags & (MGP_RO_ENTER_CARRY | MGP_RO_EXIT_CARRY)) && carry == nullptr) return MGP_EINVAL;
     // a launch that starts from dense slices knows only the networks it produces itself: it can hand over a complete
@@ -1431,14 +1494,38 @@ extern "C" int MGP_RO_STEPS_EX(double* x, float* G, float* Xd, const float* cons
     if (N > RO_MAXN)
         return fade ? launch_rollout_big<true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags)
                     : launch_rollout_big<false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags);
+#define RO_LAUNCH(CN_, CK_, FD_, CL_) launch_rollout<CN_, CK_, FD_, CL_>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags, cl)
+    if (cl != nullptr) {               // the data-collection builds (DAGGER rollouts)
+#ifndef MGP_RO_WIDE
+        if (N == 100 && K == 3 && !fade) return RO_LAUNCH(100, 3, false, true);      // cfg/dagger.cfg
+#endif
+        return fade ? RO_LAUNCH(0, 0, true, true) : RO_LAUNCH(0, 0, false, true);
+    }
 #ifndef MGP_RO_WIDE
     if (N == 100 && K == 3 && !fade)   // the headline shape (BASELINE.json configs[0..1]) runs a build with compile-time addresses
-        return launch_rollout<100, 3, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags);
+        return RO_LAUNCH(100, 3, false, false);
     if (N == 100 && K == 2 && !fade)   // cfg/default.cfg, cloning.cfg, dagger_twoflocks.cfg
-        return launch_rollout<100, 2, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags);
+        return RO_LAUNCH(100, 2, false, false);
 #endif
-    return fade ? launch_rollout<0, 0, true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags)
-                : launch_rollout<0, 0, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags);
+    return fade ? RO_LAUNCH(0, 0, true, false) : RO_LAUNCH(0, 0, false, false);
+#undef RO_LAUNCH
+}
+}  // namespace
+
+extern "C" int MGP_RO_STEPS_EX(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
+                               const int* dims, int n_layers, float* action, double* rewards,
+                               const MgpFlockParams* p, int B, int K, int N, int T, const float* image, void* carry,
+                               int flags, void* stream)
+{
+    return ro_run(x, G, Xd, W, b, dims, n_layers, action, rewards, p, B, K, N, T, image, carry, flags, nullptr, stream);
+}
+
+extern "C" int MGP_RO_COLLECT(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
+                              const int* dims, int n_layers, double* rewards, const MgpFlockParams* p, int B, int K, int N,
+                              int T, const float* image, void* carry, int flags, const MgpCollect* cl, void* stream)
+{
+    if (cl == nullptr) return MGP_EINVAL;
+    return ro_run(x, G, Xd, W, b, dims, n_layers, nullptr, rewards, p, B, K, N, T, image, carry, flags, cl, stream);
 }
 
 #ifndef MGP_RO_WIDE

@@ -2,7 +2,7 @@
 update, the policy and the replay memory.  An extension of reference learner/gnn_dagger.py:126-243 (which steps ONE
 environment through Python objects); the schedule is the reference's, applied per episode:
 
-  * episode e (global index over rounds, ranks and lanes) uses beta_e = max(beta_coeff^(e+1), 0.5)   (:148)
+  * episode e (global index over rounds, ranks and lanes) uses the reference's running-product beta_e (:148, BetaSchedule)
   * every step stores (state, expert label) and steps the env with the expert w.p. beta_e else the policy  (:156-178)
   * after a round of `n_envs` episodes: `updates_per_step` updates per episode of the round            (:182-188)
   * final statistics = mean / std of `n_test_episodes` policy-only episode rewards                     (:221-237)
@@ -20,7 +20,7 @@ from .. import parallel
 from ..envs import FlockParams, VecFlock
 from ..envs.flocking import _REGISTRY
 from .rollouts import policy_rollout
-from .gnn_dagger import DAGGER
+from .gnn_dagger import DAGGER, BetaSchedule
 from .state_with_delay import BatchedDelayState
 
 
@@ -126,6 +126,121 @@ class IndexedUpdates(object):
         return self.loss_hist[:U].sum()
 
 
+class FrameReplay(object):
+    """Compact device replay filled by the collecting rollout kernel (mgp_rollout_collect): a ring of FRAMES laid out
+    [ring_steps][lanes] -- features x_t (6,N), membership bits of A_t (N x 2 u64), expert label (2,N), age -- 4.8 KB per
+    transition at N = 100 where a dense (delay_state, delay_gso) pair takes 128 KB.  The K-tap state of a transition is
+    rebuilt from its frame and its K - 1 predecessors in the ring (same lane) by mgp_replay_gather, so the ring keeps K - 1
+    guard steps behind the sampled window.  Ring + sampling semantics are the reference's (replay_buffer.py:21-41): once
+    full, the oldest transitions are overwritten; `sample_ids` draws without replacement from Python's `random` stream."""
+
+    def __init__(self, lanes, capacity, K, N, device):
+        self.lanes, self.K, self.N = lanes, K, N
+        self.window_steps = max(1, (capacity + lanes - 1) // lanes)          # sampled window, in lock-step env steps
+        self.ring_steps = self.window_steps + max(K - 1, 0)                  # + history guard
+        S = self.ring_steps
+        self.feat = torch.zeros((S, lanes, 6, N), device=device, dtype=torch.float32)
+        self.bits = torch.zeros((S, lanes, N, 2), device=device, dtype=torch.int64)
+        self.label = torch.zeros((S, lanes, 2, N), device=device, dtype=torch.float32)
+        self.age = torch.zeros((S, lanes), device=device, dtype=torch.int32)
+        self.head = 0                 # ring step the next collected env step is filed at
+        self.steps_written = 0
+        self.device = device
+
+    @property
+    def max_size(self):
+        return self.window_steps * self.lanes
+
+    @property
+    def curr_size(self):
+        return min(self.steps_written, self.window_steps) * self.lanes
+
+    def bytes_per_transition(self):
+        return (6 * self.N + 2 * self.N) * 4 + self.N * 16 + 4
+
+    def advance(self, T):
+        """The collecting launch filed T env steps starting at ring step `head`."""
+        self.head = (self.head + T) % self.ring_steps
+        self.steps_written += T
+
+    def frame_of(self, position):
+        """Frame index (ring_step * lanes + lane) of the transition at buffer position `position` in [0, curr_size):
+        positions run oldest to newest, lane-minor -- the order B consecutive `insert` calls per env step would give."""
+        n_valid = min(self.steps_written, self.window_steps)
+        step = (self.head - n_valid + position // self.lanes) % self.ring_steps
+        return step * self.lanes + position % self.lanes
+
+    def sample_ids(self, num_samples):
+        """Frame indices of a minibatch: without replacement, Python `random` RNG (reference replay_buffer.py:40)."""
+        return [self.frame_of(i) for i in random.sample(range(self.curr_size), num_samples)]
+
+    def sample(self, num_samples, out, mean_pooling=True):
+        """Gather one minibatch into `out` = (X, G, Y) (the eager / data-parallel update path: one small H2D per update)."""
+        idx = torch.tensor(self.sample_ids(num_samples), device=self.device, dtype=torch.long)
+        from .. import ops
+        ops.replay_gather(self, idx, out[0], out[1], out[2], mean_pooling)
+        return out
+
+    def clear(self):
+        self.head, self.steps_written = 0, 0
+
+
+class FrameUpdates(object):
+    """A round of DAGGER updates on a FrameReplay with no per-update host work: the frame indices of the whole round are
+    uploaded once; every update is one replay of a HIP graph of three launches -- mgp_replay_gather (rebuilds the minibatch's
+    K-tap states from the frame ring at the device-side cursor) and the two launches of mgp_train_step_indexed on the
+    gathered buffers (forward + MSE + backward per tile; reduction + Adam, which advances the cursor and files the loss)."""
+
+    def __init__(self, learner, memory, batch_size, max_updates, mean_pooling):
+        import ctypes
+        from .. import _lib
+        actor, opt = learner.actor, learner.actor_optim
+        dev = opt.flat.device
+        dims = tuple(actor.layers)
+        self.cdims = (ctypes.c_int * len(dims))(*dims)
+        self.nl, self.K, self.N, self.B = actor.n_layers, actor.k, learner.n_agents, batch_size
+        self.learner, self.memory, self.cap, self.mean_pooling = learner, memory, max_updates, mean_pooling
+        L = _lib.lib()
+        self.X = torch.zeros((batch_size, self.K, 6, self.N), device=dev)
+        self.G = torch.zeros((batch_size, self.K, self.N, self.N), device=dev)
+        self.Y = torch.zeros((batch_size, 1, actor.n_a, self.N), device=dev)
+        self.idx = torch.zeros((max_updates, batch_size), device=dev, dtype=torch.long)            # frame indices
+        self.ident = torch.arange(batch_size, device=dev, dtype=torch.long).repeat(max_updates, 1).contiguous()
+        self.cursor = torch.zeros((1,), device=dev, dtype=torch.int32)
+        self.loss_hist = torch.zeros((max_updates,), device=dev, dtype=torch.float32)
+        self.step_dev = opt.step_dev
+        self.ws = torch.zeros((L.mgp_train_workspace(self.cdims, self.nl, batch_size, self.K, self.N),), device=dev)
+        self.graph = None
+
+    supported = staticmethod(IndexedUpdates.supported)
+
+    def _enqueue(self):
+        from .. import _lib, ops
+        L, o = _lib.lib(), self.learner.actor_optim
+        ops.replay_gather(self.memory, self.idx, self.X, self.G, self.Y, self.mean_pooling, cursor=self.cursor)
+        _lib.check(L.mgp_train_step_indexed(
+            ops._ptr(self.X), ops._ptr(self.G), ops._ptr(self.Y), self.ident.data_ptr(), self.cursor.data_ptr(),
+            ops._ptr(self.loss_hist), self.cap, ops._ptr(o.flat), ops._ptr(o.flat_grad), ops._ptr(o.m), ops._ptr(o.v),
+            self.cdims, self.nl, o.lr, o.betas[0], o.betas[1], o.eps, self.step_dev.data_ptr(), ops._ptr(self.ws),
+            self.B, self.K, self.N, ops._stream()), 'mgp_train_step_indexed')
+
+    def run(self, ids):
+        """ids: one list of `batch_size` frame indices per update.  Returns the sum of the updates' losses (device tensor)."""
+        U = len(ids)
+        assert 0 < U <= self.cap
+        self.idx[:U].copy_(torch.tensor(ids, dtype=torch.long), non_blocking=False)
+        self.cursor.zero_()
+        if self.graph is None:
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._enqueue()
+        for _ in range(U):
+            self.graph.replay()
+        self.learner.actor_optim.step_count += U
+        return self.loss_hist[:U].sum()
+
+
 def _params_from_args(args):
     env_cls = _REGISTRY.get(args.get('env'), None)
     variant = getattr(env_cls, 'variant', {}) if env_cls is not None else {}
@@ -166,25 +281,74 @@ def evaluate(learner, sim, state, n_episodes, steps):
     return rewards[:n_episodes]
 
 
+def collect_supported(learner, K, N):
+    """The collecting build of the episode-resident kernel covers the shape (mgp_rollout_collect: N <= 128, 6 features,
+    2-D actions, aggregation in front of the first layer, widths <= 64)."""
+    from .. import ops
+    return (learner.actor.ind_agg == 0 and learner.n_states == 6 and N <= 128
+            and ops.rollout_supported(tuple(learner.actor.layers), K, N))
+
+
+def collect_round(learner, sim, state, memory, beta, episode_ids, seed, T, chunk=None):
+    """One lock-step round of DAGGER data collection ON THE DEVICE (reference gnn_dagger.py:150-178 for every lane): reset,
+    then T steps inside mgp_rollout_collect launches -- policy forward, expert label, beta coin, simulator step, state
+    transition and the filing of every visited state into the frame ring all happen in the kernel; the host draws the reset
+    states and launches.  `beta` (n_envs,) float32 and `episode_ids` (n_envs,) int32 on the device."""
+    from .. import ops
+    from .rollouts import _actor_params
+    sim.reset(np.random)
+    state.reset()
+    state.push(sim.network, sim.features)                      # reset observation: all-zero operator history (carry)
+    expert_io = sim.controller().permute(0, 2, 1).contiguous() # (B,2,N): the expert's action for the reset state
+    ws, bs = _actor_params(learner.actor)
+    image = ops.rollout_image(ws, bs, tuple(learner.actor.layers), state.K, sim.N)      # weights are fixed for the round
+    carry = state.carry_buffer()
+    assert carry is not None and state._carry_valid
+    flags = ops.RO_ENTER_CARRY | ops.RO_EXIT_CARRY | ops.RO_SKIP_DENSE
+    done = 0
+    while done < T:
+        t = min(chunk or T, T - done)
+        ok = ops.rollout_collect(sim.x, state._G[state._cur], state.delay_state, tuple(learner.actor.layers), sim._c, t,
+                                 memory, expert_io, beta, episode_ids, seed, age0=done, ring_step0=memory.head, carry=carry,
+                                 flags=flags, image=image)
+        assert ok
+        memory.advance(t)
+        state._pushes += t
+        state._dense_stale = True
+        done += t
+    sim._network, sim._network_lazy = None, (lambda: state.delay_gso[:, 1])
+    sim.features = state.delay_state[:, 0]
+
+
 def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
-    """Returns {'mean','std'} like train_dagger.  `n_envs` parallel episodes per rank."""
+    """Returns {'mean','std'} like train_dagger.  `n_envs` parallel episodes per rank.
+
+    Where the collecting build of the episode-resident kernel covers the shape (N <= 128: every N of the reference's
+    sweeps up to 125) a round is ONE launch per GPU for the rollouts of all lanes -- no host RNG, no host<->device traffic
+    per step -- into a compact frame replay, and one HIP-graph replay per update.  Other shapes step the two-launch path from
+    the host and keep dense states in the replay (the round-1 loop)."""
     device = torch.device(device)
     p = _params_from_args(args)
     N, K, F, n_a = p.n_agents, args.getint('k'), args.getint('n_states'), args.getint('n_actions')
     T = episode_steps or p.max_episode_steps
     learner = DAGGER(device, args)
+    on_device = collect_supported(learner, K, N) and args.get('collect', 'device') != 'host'
     # The reference's ring of `buffer_size` (10,000) transitions holds its 20 most recent WHOLE episodes.  Here n_envs
     # episodes advance in lock step, so a ring shorter than one round (n_envs * T transitions) would keep only the last
     # steps of every episode -- the already-flocked states -- and the policy would never see a start-up state.  The ring
-    # therefore holds at least one full round (128 KB per transition at N = 100, K = 3: 4 GB of the 288 GB for 64 x 500).
-    memory = DeviceReplay(max(args.getint('buffer_size'), n_envs * T), K, F, N, n_a, device)
+    # therefore holds at least one full round (4.8 KB per transition as frames at N = 100: 154 MB for 64 x 500; the dense
+    # fallback takes 128 KB per transition, 4 GB).
+    capacity = max(args.getint('buffer_size'), n_envs * T)
+    memory = (FrameReplay(n_envs, capacity, K, N, device) if on_device
+              else DeviceReplay(capacity, K, F, N, n_a, device))
     sim = VecFlock(n_envs, p, device, with_expert=True)
     state = BatchedDelayState(device, n_envs, K, F, N)
     batch_size = args.getint('batch_size')
-    beta_coeff = args.getfloat('beta_coeff')
+    beta_of = BetaSchedule(args.getfloat('beta_coeff'))
     updates_per_step = args.getint('updates_per_step')
     n_train_episodes = args.getint('n_train_episodes')
     n_test_episodes = args.getint('n_test_episodes')
+    seed = args.getint('seed', fallback=0)
     debug = args.getboolean('debug')
     rank, world = parallel.rank(), parallel.world_size()
     rounds = (n_train_episodes + n_envs * world - 1) // (n_envs * world)
@@ -192,33 +356,50 @@ def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
     indexed = None
     for rd in range(rounds):
         e0 = (rd * world + rank) * n_envs
-        beta = np.maximum(beta_coeff ** (np.arange(e0, e0 + n_envs) + 1.0), 0.5)
-        sim.reset(np.random)
-        state.reset()
-        state.push(sim.network, sim.features)
-        for _ in range(T):
-            expert = sim.controller()                                     # by-product of the last sim kernel
-            memory.insert_batch(state.delay_state, state.delay_gso, _label(expert))
-            with torch.no_grad():
-                policy = learner.actor(state.delay_state, state.delay_gso)   # (B,1,nA,N)
-            use_expert = torch.from_numpy(np.random.binomial(1, beta).astype(np.bool_)).to(device)
-            action = torch.where(use_expert.view(-1, 1, 1), expert, policy[:, 0].permute(0, 2, 1)).contiguous()
-            A_dst, X_dst = state.next_slots()
-            sim.step(action, A_out=A_dst, feat_out=X_dst)
-            state.advance()
+        beta = np.array([beta_of(e) for e in range(e0, e0 + n_envs)], dtype=np.float64)   # reference schedule per global episode
+        if on_device:
+            collect_round(learner, sim, state, memory, torch.tensor(beta, dtype=torch.float32, device=device),
+                          torch.arange(e0, e0 + n_envs, dtype=torch.int32, device=device), seed, T)
+        else:
+            sim.reset(np.random)
+            state.reset()
+            state.push(sim.network, sim.features)
+            for _ in range(T):
+                expert = sim.controller()                                     # by-product of the last sim kernel
+                memory.insert_batch(state.delay_state, state.delay_gso, _label(expert))
+                with torch.no_grad():
+                    policy = learner.actor(state.delay_state, state.delay_gso)   # (B,1,nA,N)
+                use_expert = torch.from_numpy(np.random.binomial(1, beta).astype(np.bool_)).to(device)
+                action = torch.where(use_expert.view(-1, 1, 1), expert, policy[:, 0].permute(0, 2, 1)).contiguous()
+                A_dst, X_dst = state.next_slots()
+                sim.step(action, A_out=A_dst, feat_out=X_dst)
+                state.advance()
         loss_sum = 0.0
+        n_updates = updates_per_step * n_envs
         if memory.curr_size > batch_size and IndexedUpdates.supported(learner, batch_size, N):
-            if indexed is None:
-                indexed = IndexedUpdates(learner, memory, batch_size, updates_per_step * n_envs)
-            ids = [random.sample(range(memory.curr_size), batch_size) for _ in range(updates_per_step * n_envs)]
+            if on_device:
+                if indexed is None:
+                    indexed = FrameUpdates(learner, memory, batch_size, n_updates, p.mean_pooling)
+                ids = [memory.sample_ids(batch_size) for _ in range(n_updates)]
+            else:
+                if indexed is None:
+                    indexed = IndexedUpdates(learner, memory, batch_size, n_updates)
+                ids = [random.sample(range(memory.curr_size), batch_size) for _ in range(n_updates)]
             loss_sum = float(indexed.run(ids).item())
             updates += len(ids)
         elif memory.curr_size > batch_size:
-            bufs = learner.graphed_buffers(batch_size, N)        # None: eager / distributed updates
+            bufs = learner.graphed_buffers(batch_size, N)        # None: composed eager updates (shape outside the fused kernels)
+            graphed = bufs is not None
+            if bufs is None and on_device:
+                bufs = tuple(torch.empty(sh, device=device) for sh in ((batch_size, K, F, N), (batch_size, K, N, N),
+                                                                       (batch_size, 1, n_a, N)))
             loss_dev = torch.zeros((1,), device=device)
-            for _ in range(updates_per_step * n_envs):
-                xs, gs, ys = memory.sample(batch_size, out=bufs)
-                if bufs is not None:                              # no host sync per update: losses add up on the device
+            for _ in range(n_updates):
+                if on_device:
+                    xs, gs, ys = memory.sample(batch_size, bufs, mean_pooling=p.mean_pooling)
+                else:
+                    xs, gs, ys = memory.sample(batch_size, out=bufs)
+                if graphed:                                       # no host sync per update: losses add up on the device
                     loss_dev += learner.gradient_step_tensors(xs, gs, ys, sync=False)
                 else:
                     loss_sum += learner.gradient_step_tensors(xs, gs, ys)
@@ -232,4 +413,6 @@ def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
     rewards = parallel.all_gather_floats(evaluate(learner, sim, state, n_local, T))
     if debug and args.get('fname') and rank == 0:            # reference gnn_dagger.py:239-240
         learner.save_model(args.get('env'), suffix=args.get('fname'))
-    return {'mean': float(np.mean(rewards)), 'std': float(np.std(rewards)), 'learner': learner, 'updates': updates}
+    return {'mean': float(np.mean(rewards)), 'std': float(np.std(rewards)), 'learner': learner, 'updates': updates,
+            'collect': 'device' if on_device else 'host', 'replay_bytes_per_transition':
+            memory.bytes_per_transition() if on_device else 4 * (K * F * N + K * N * N + n_a * N)}

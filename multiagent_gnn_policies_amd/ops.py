@@ -292,6 +292,54 @@ def rollout_steps(x, G, Xd, weights, biases, dims, params, T, action=None, rewar
     return True
 
 
+def rollout_collect(x, G, Xd, dims, params, T, frames, expert_io, beta, episode, seed, age0, ring_step0, carry, flags,
+                    weights=None, biases=None, image=None, rewards=None):
+    """T DAGGER data-collection steps in ONE launch (mgp_rollout_collect): every step files its starting state as a compact
+    frame into `frames` (a FrameReplay-like object with .feat/.bits/.label/.age rings laid out [ring_steps][B]) and is driven
+    by the expert with probability beta[b] (counter-based coin), else by the policy.  Returns False if the shape is not
+    covered (N > 128 or outside mgp_rollout_supported)."""
+    _dev(x, 'x', torch.float64); _dev(G, 'G'); _dev(Xd, 'Xd'); _dev(expert_io, 'expert_io'); _dev(beta, 'beta')
+    B, N, _ = x.shape
+    K = G.shape[1]
+    assert G.is_contiguous() and Xd.is_contiguous() and x.is_contiguous() and expert_io.is_contiguous()
+    assert expert_io.shape == (B, 2, N) and beta.shape == (B,) and episode.shape == (B,) and episode.dtype == torch.int32
+    S = frames.ring_steps
+    assert frames.feat.shape == (S, B, 6, N) and frames.bits.shape == (S, B, N, 2) and frames.label.shape == (S, B, 2, N)
+    assert frames.age.shape == (S, B) and frames.age.dtype == torch.int32 and frames.bits.dtype == torch.int64
+    if rewards is not None:
+        assert rewards.shape == (B, T) and rewards.dtype == torch.float64 and rewards.is_contiguous()
+    cl = _lib.MgpCollect(frames.feat.data_ptr(), frames.bits.data_ptr(), frames.label.data_ptr(), frames.age.data_ptr(),
+                         expert_io.data_ptr(), beta.data_ptr(), episode.data_ptr(), int(seed) & 0xFFFFFFFF, int(age0),
+                         int(ring_step0), int(S))
+    cd = (ctypes.c_int * len(dims))(*dims)
+    wa = ba = None
+    if image is None:
+        Ws = [w.contiguous() for w in weights]
+        bs = [b_.contiguous() for b_ in biases]
+        wa = (ctypes.c_void_p * len(Ws))(*[w.data_ptr() for w in Ws])
+        ba = (ctypes.c_void_p * len(bs))(*[b_.data_ptr() for b_ in bs])
+    rc = _lib.lib().mgp_rollout_collect(_ptr(x), _ptr(G), _ptr(Xd), wa, ba, cd, len(dims) - 1, _ptr(rewards),
+                                        ctypes.byref(params), B, K, N, int(T), _ptr(image), _ptr(carry), int(flags),
+                                        ctypes.byref(cl), _stream())
+    if rc == -5:
+        return False
+    _lib.check(rc, 'mgp_rollout_collect')
+    return True
+
+
+def replay_gather(frames, idx, X, G, Y, mean_pooling, cursor=None):
+    """Minibatch (X (Bt,K,6,N), G (Bt,K,N,N), Y (Bt,1,2,N)) rebuilt from the frame ring for the frame indices
+    idx[(cursor or 0) * Bt + i] (mgp_replay_gather); idx int64 on the device, cursor (1,) int32 on the device or None."""
+    _dev(X, 'X'); _dev(G, 'G'); _dev(Y, 'Y'); _dev(idx, 'idx', torch.int64)
+    Bt, K, _, N = X.shape
+    assert X.is_contiguous() and G.is_contiguous() and Y.is_contiguous() and G.shape == (Bt, K, N, N) and Y.numel() == Bt * 2 * N
+    S, lanes = frames.feat.shape[0], frames.feat.shape[1]
+    rc = _lib.lib().mgp_replay_gather(_ptr(frames.feat), _ptr(frames.bits), _ptr(frames.label), _ptr(frames.age), _ptr(idx),
+                                      _ptr(cursor), Bt, lanes, S, K, N, 1 if mean_pooling else 0, _ptr(X), _ptr(G), _ptr(Y),
+                                      _stream())
+    _lib.check(rc, 'mgp_replay_gather')
+
+
 def rollout_image(weights, biases, dims, K, N):
     """Weight image of the episode-resident kernel for this policy (MFMA fragment order), built once by a tiny kernel:
     pass it to rollout_steps(image=...) for as long as the weights do not change.  None when the shape is not covered."""
@@ -384,4 +432,4 @@ def adam_step_dev(param, grad, m, v, lr, step_dev, beta1=0.9, beta2=0.999, eps=1
 
 __all__ = ['MgpFlockParams', 'MgpError', 'aggregate', 'dense', 'agg_fwd', 'agg_bwd_x', 'dense_fwd', 'dense_bwd',
            'gso_update', 'gso_update_into', 'gso_powers', 'flock_step', 'flock_controller', 'mse_grad', 'mse_loss',
-           'gso_advance', 'flock_step_advance', 'rollout_supported', 'rollout_steps', 'rollout_image', 'rollout_carry_bytes', 'rollout_carry_to_dense', 'adam_step', 'adam_step_dev', 'ACT_NONE', 'ACT_TANH']
+           'gso_advance', 'flock_step_advance', 'rollout_supported', 'rollout_steps', 'rollout_collect', 'replay_gather', 'rollout_image', 'rollout_carry_bytes', 'rollout_carry_to_dense', 'adam_step', 'adam_step_dev', 'ACT_NONE', 'ACT_TANH']

@@ -1,0 +1,156 @@
+"""GPU: DAGGER data collection on the episode-resident kernel (mgp_rollout_collect) and the compact frame replay
+(mgp_replay_gather) against the oracle: reference gnn_dagger.py:154-178 per lane -- expert label for the state before the
+step, beta coin, expert- or policy-driven step, state transition -- with the coin spec of oracle/dagger_vec.py, and
+state_with_delay.py:44-53 for the K-tap states rebuilt from frames."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import actor as oa, dagger_vec as odv, flock as ofl
+from test_gpu_rollout import _make, _weights_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits_dense(bits_row):
+    """(N,2) int64 -> (N,N) bool"""
+    b = bits_row.astype(np.uint64)
+    N = b.shape[0]
+    cols = np.arange(N)
+    return ((b[:, cols >> 6] >> (cols & 63).astype(np.uint64)) & np.uint64(1)).astype(bool)
+
+
+def _setup(N, K, hidden, B, variant, ring_capacity):
+    from multiagent_gnn_policies_amd.envs import VecFlock
+    from multiagent_gnn_policies_amd.learner.vec_dagger import FrameReplay
+    rs, op, actor, sim0, st = _make(N, K, hidden, B, seed=5, **variant)
+    sim = VecFlock(B, sim0.p, 'cuda', with_expert=True)       # same states, with the expert by-product
+    sim.set_state(sim0.x.cpu().numpy())
+    st.reset(); st.push(sim.network, sim.features)
+    mem = FrameReplay(B, ring_capacity, K, N, torch.device('cuda'))
+    return op, actor, sim, st, mem
+
+
+def _collect(actor, sim, st, mem, expert_io, beta, episode, seed, age0, T):
+    from multiagent_gnn_policies_amd import ops
+    from multiagent_gnn_policies_amd.learner.rollouts import _actor_params
+    ws, bs = _actor_params(actor)
+    flags = ops.RO_ENTER_CARRY | ops.RO_EXIT_CARRY | ops.RO_SKIP_DENSE
+    assert st._carry_valid
+    assert ops.rollout_collect(sim.x, st._G[st._cur], st.delay_state, tuple(actor.layers), sim._c, T, mem, expert_io, beta,
+                               episode, seed, age0=age0, ring_step0=mem.head, carry=st.carry_buffer(), flags=flags,
+                               weights=ws, biases=bs)
+    mem.advance(T)
+    st._pushes += T
+    st._dense_stale = True
+
+
+CASES = [(100, 3, (32, 32), {}), (50, 2, (16,), {'mean_pooling': False, 'n_leaders': 1}), (64, 4, (32, 32), {'centralized': False}),
+         (100, 3, (32, 32), {'link_drop': 0.25, 'link_seed': 3}), (128, 1, (32,), {})]
+
+
+@pytest.mark.parametrize('N,K,hidden,variant', CASES)
+def test_collect_single_steps_match_oracle(N, K, hidden, variant):
+    B, T, seed = 3, 7, 12345
+    op, actor, sim, st, mem = _setup(N, K, hidden, B, variant, ring_capacity=B * T)
+    Ws, bs = _weights_np(actor)
+    beta_np = np.array([0.5, 0.8, 0.3], dtype=np.float32)
+    beta = torch.from_numpy(beta_np).cuda()
+    episode = torch.tensor([7, 1000, 123456], dtype=torch.int32, device='cuda')
+    expert_io = sim.controller().permute(0, 2, 1).contiguous()
+    n_expert = n_policy = 0
+    for t in range(T):
+        x0 = sim.x.cpu().numpy().copy()
+        G0 = st.delay_gso.cpu().numpy().copy(); X0 = st.delay_state.cpu().numpy().copy()
+        lab0 = expert_io.cpu().numpy().copy()
+        ring_step = mem.head
+        _collect(actor, sim, st, mem, expert_io, beta, episode, seed, age0=t, T=1)
+        x1 = sim.x.cpu().numpy()
+        pol = oa.forward(X0, G0, Ws, bs, 0, dtype=np.float64)               # (B,1,2,N)
+        for b in range(B):
+            # the frame of the state the step started from
+            assert np.array_equal(mem.feat[ring_step, b].cpu().numpy(), X0[b, 0])
+            assert int(mem.age[ring_step, b]) == t
+            assert np.array_equal(mem.label[ring_step, b].cpu().numpy(), lab0[b])
+            got_bits = _bits_dense(mem.bits[ring_step, b].cpu().numpy())
+            want = (G0[b, 1] != 0) if (K > 1 and t >= 1) else np.zeros((N, N), dtype=bool)
+            if K > 1:
+                assert np.array_equal(got_bits, want), "membership bits of the frame's network"
+            # its label is the expert's action for that state (FLOCK-SPEC section 5, p.centralized)
+            lab_ref = ofl.controller(x0[b], op).T
+            assert np.max(np.abs(lab0[b] - lab_ref) / np.maximum(1.0, np.abs(lab_ref))) <= 1e-6
+            # who drove: the counter-based coin of oracle/dagger_vec.py
+            drives = odv.expert_drives(seed, int(episode[b]), t, beta_np[b])
+            x_exp = ofl.integrate(x0[b], lab0[b].T.astype(np.float32), op)
+            x_pol = ofl.integrate(x0[b], pol[b, 0].T.astype(np.float32), op)
+            if drives:
+                assert np.array_equal(x1[b], x_exp), "expert-driven step: integration bit-exact given the stored label"
+                n_expert += 1
+            else:
+                assert np.max(np.abs(x1[b] - x_pol)) <= 2e-6 and np.max(np.abs(x1[b] - x_exp)) > 1e-5
+                n_policy += 1
+            # and the transition: network of the new state bit-exact
+            if K > 1:
+                net = ofl.helpers(x1[b], op)['network'].astype(np.float32)
+                assert np.array_equal(st.delay_gso[b, 1].cpu().numpy(), net)
+    assert n_expert > 0 and n_policy > 0
+
+
+@pytest.mark.parametrize('N,K,hidden,variant', CASES[:4])
+def test_collect_chunking_is_bit_identical_and_gather_rebuilds_the_states(N, K, hidden, variant):
+    from multiagent_gnn_policies_amd import ops
+    B, T, seed = 3, 9, 99
+    beta = torch.tensor([0.5, 0.7, 0.2], device='cuda')
+    episode = torch.tensor([3, 4, 5], dtype=torch.int32, device='cuda')
+    runs = []
+    for chunks in ([T], [1] * T, [4, 5]):
+        op, actor, sim, st, mem = _setup(N, K, hidden, B, variant, ring_capacity=B * 6)     # ring shorter than the run: wraps
+        expert_io = sim.controller().permute(0, 2, 1).contiguous()
+        dense = []                                               # (X, G) of every visited state, from one-step launches
+        t0 = 0
+        for c in chunks:
+            if c == 1:
+                dense.append((st.delay_state.cpu().numpy().copy(), st.delay_gso.cpu().numpy().copy()))
+            _collect(actor, sim, st, mem, expert_io, beta, episode, seed, age0=t0, T=c)
+            t0 += c
+        runs.append((sim.x.clone(), st.delay_state.clone(), st.delay_gso.clone(), expert_io.clone(), mem.feat.clone(),
+                     mem.bits.clone(), mem.label.clone(), mem.age.clone(), mem, dense))
+    for other in runs[1:]:
+        for a, b_ in zip(runs[0][:8], other[:8]):
+            assert torch.equal(a, b_)
+    # rebuild every stored transition from the ring (window of 6 steps + K - 1 guard steps) and compare with the dense states
+    mem, dense = runs[1][8], runs[1][9]
+    assert mem.curr_size == B * 6 and mem.bytes_per_transition() == 32 * N + 16 * N + 4
+    ids = [mem.frame_of(i) for i in range(mem.curr_size)]
+    idx = torch.tensor(ids, device='cuda', dtype=torch.long)
+    Bt = len(ids)
+    X = torch.empty((Bt, K, 6, N), device='cuda'); G = torch.empty((Bt, K, N, N), device='cuda')
+    Y = torch.empty((Bt, 1, 2, N), device='cuda')
+    ops.replay_gather(mem, idx, X, G, Y, op.mean_pooling)
+    Xn, Gn = X.cpu().numpy(), G.cpu().numpy()
+    for i in range(Bt):
+        t = T - 6 + i // B                                       # positions run oldest to newest, lane-minor
+        b = i % B
+        Xd, Gd = dense[t]
+        assert int(mem.age.view(-1)[ids[i]]) == t
+        assert np.array_equal(Xn[i], Xd[b])
+        assert np.array_equal(Gn[i, 0], np.eye(N, dtype=np.float32))
+        if K > 1:
+            assert np.array_equal(Gn[i, 1], Gd[b, 1])            # A_t itself: exact
+        assert np.max(np.abs(Gn[i] - Gd[b])) <= 1e-6             # products: fp32 re-association only
+    # device-side cursor form (what FrameUpdates replays): minibatch 1 of a (2, 4) index table
+    tbl = torch.tensor([ids[:4], ids[5:9]], device='cuda', dtype=torch.long)
+    X2 = torch.empty((4, K, 6, N), device='cuda'); G2 = torch.empty((4, K, N, N), device='cuda'); Y2 = torch.empty((4, 1, 2, N), device='cuda')
+    ops.replay_gather(mem, tbl, X2, G2, Y2, op.mean_pooling, cursor=torch.ones((1,), device='cuda', dtype=torch.int32))
+    assert torch.equal(X2, X[5:9]) and torch.equal(G2, G[5:9]) and torch.equal(Y2, Y[5:9])
+    assert torch.equal(Y.view(Bt, 2, N), mem.label.view(-1, 2, N)[idx])
+
+
+def test_dagger_coin_oracle_statistics_and_edges():
+    """The coin spec: beta >= 1 always expert, beta <= 0 never, frequency ~ beta, streams of different episodes differ."""
+    assert all(odv.expert_drives(1, e, s, 1.0) for e in range(5) for s in range(50))
+    assert not any(odv.expert_drives(1, e, s, 0.0) for e in range(5) for s in range(50))
+    hits = sum(odv.expert_drives(11, 3, s, 0.7) for s in range(20000)) / 20000.0
+    assert abs(hits - 0.7) < 0.02
+    a = [odv.dagger_coin(11, 3, s) for s in range(64)]; c = [odv.dagger_coin(11, 4, s) for s in range(64)]
+    assert a != c and len(set(a)) == 64

@@ -236,6 +236,8 @@ def test_vectorised_dagger_trains():
     stats = train_dagger_vec(cp['t'], 'cuda:0', n_envs=16, episode_steps=40)
     assert np.isfinite(stats['mean']) and stats['mean'] < 0 and stats['std'] >= 0
     assert stats['updates'] == 2 * 4 * 16
+    # rollouts on the collecting resident kernel, compact frames in the replay
+    assert stats['collect'] == 'device' and stats['replay_bytes_per_transition'] == 48 * 40 + 4
 
 
 def test_eval_model_shipped_checkpoint_flocks():
