@@ -446,7 +446,48 @@ def dagger_update_bench():
         for _ in range(m):
             step()
         res[thr] = 1e3 * (time.perf_counter() - t0) / m
+    # DAGGER data collection (BASELINE.json configs[3], gnn_dagger.py:154-178): rollouts with expert labels, beta coin and
+    # replay insert -- on the collecting build of the resident kernel (one launch per round) vs the host-stepped two-launch
+    # loop of round 1 (>= 5 launches + host RNG + H2D per step)
+    from multiagent_gnn_policies_amd.learner.vec_dagger import FrameReplay, collect_round, FrameUpdates
+    lanes, Tc = 256, 500
+    pcol = FlockParams(n_agents=N, init_mode='grid')
+    simc = VecFlock(lanes, pcol, dev, with_expert=True)
+    stc = BatchedDelayState(dev, lanes, K, F_FEAT, N)
+    memc = FrameReplay(lanes, lanes * Tc, K, N, dev)
+    beta_t = torch.full((lanes,), 0.75, device=dev)
+    eps = torch.arange(lanes, dtype=torch.int32, device=dev)
+    np.random.seed(3)
+    collect_round(learner, simc, stc, memc, beta_t, eps, 11, 20)                 # warm-up (also the reset sampling cache)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    collect_round(learner, simc, stc, memc, beta_t, eps, 11, Tc)
+    torch.cuda.synchronize()
+    t_round = time.perf_counter() - t0
+    e0c, e1c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    from multiagent_gnn_policies_amd.learner.rollouts import _actor_params
+    wsc, bsc = _actor_params(learner.actor)
+    img = ops.rollout_image(wsc, bsc, tuple(learner.actor.layers), K, N)
+    exp_io = simc.controller().permute(0, 2, 1).contiguous()
+    e0c.record()
+    ops.rollout_collect(simc.x, stc._G[stc._cur], stc.delay_state, tuple(learner.actor.layers), simc._c, Tc, memc, exp_io, beta_t,
+                        eps, 11, age0=Tc, ring_step0=memc.head, carry=stc.carry_buffer(),
+                        flags=ops.RO_ENTER_CARRY | ops.RO_EXIT_CARRY | ops.RO_SKIP_DENSE, image=img)
+    e1c.record()
+    torch.cuda.synchronize()
+    collect_kernel_ms = e0c.elapsed_time(e1c)
+    fu = FrameUpdates(learner, memc, B, 2000, True)
+    fu.run([memc.sample_ids(B) for _ in range(50)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fu.run([memc.sample_ids(B) for _ in range(2000)]).item()
+    frame_update_ms = 1e3 * (time.perf_counter() - t0) / 2000
     return {"update": "DAGGER gradient_step B=20 N=100 K=3", "hip_ms": gpu_ms, "hip_updates_per_s": 1e3 / gpu_ms,
+            "collect": {"lanes": lanes, "steps": Tc, "kernel_ms": collect_kernel_ms,
+                        "kernel_agent_steps_per_s": lanes * N * Tc / (1e-3 * collect_kernel_ms),
+                        "round_wall_s_incl_host_reset_sampling": t_round,
+                        "replay_bytes_per_transition": memc.bytes_per_transition(),
+                        "hip_ms_frame_update_round": frame_update_ms},
             "hip_ms_pipelined": gpu_ms_pipe, "hip_updates_per_s_pipelined": 1e3 / gpu_ms_pipe,
             "hip_ms_indexed_round": gpu_ms_idx, "hip_updates_per_s_indexed_round": 1e3 / gpu_ms_idx,
             "cpu_port_ms_by_threads": res, "host_cores": os.cpu_count()}

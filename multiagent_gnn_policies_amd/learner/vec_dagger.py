@@ -376,7 +376,7 @@ def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
                 state.advance()
         loss_sum = 0.0
         n_updates = updates_per_step * n_envs
-        if memory.curr_size > batch_size and IndexedUpdates.supported(learner, batch_size, N):
+        if n_updates > 0 and memory.curr_size > batch_size and IndexedUpdates.supported(learner, batch_size, N):
             if on_device:
                 if indexed is None:
                     indexed = FrameUpdates(learner, memory, batch_size, n_updates, p.mean_pooling)
@@ -387,7 +387,7 @@ def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
                 ids = [random.sample(range(memory.curr_size), batch_size) for _ in range(n_updates)]
             loss_sum = float(indexed.run(ids).item())
             updates += len(ids)
-        elif memory.curr_size > batch_size:
+        elif n_updates > 0 and memory.curr_size > batch_size:
             bufs = learner.graphed_buffers(batch_size, N)        # None: composed eager updates (shape outside the fused kernels)
             graphed = bufs is not None
             if bufs is None and on_device:

@@ -1,43 +1,52 @@
-"""Copy the outputs of tools/regen_profiles.sh (gpurun_out/final/) into profiles/r01_* (run from the repo root)."""
+"""Copy the outputs of tools/regen_profiles.sh (gpurun_out/final/) into profiles/r02_* (run from the repo root)."""
+import json
+import os
+import shutil
 import sys
 sys.path.insert(0, ".")
-import json, shutil
-O='gpurun_out/final'
-d=json.loads(open(O+'/bench_final.json').read().strip().splitlines()[-1])
-print('value %.4g ms/step %.5f' % (d['value'], d['ms_per_step']), 'traffic', d['roofline']['traffic'], 'frac %.3f' % d['roofline']['frac'], 'paths', {k: '%.3g' % v['value'] for k,v in d['paths'].items()}, 'cpu %.3g' % d['cpu_baseline']['value'])
-d2=json.loads(open(O+'/bench_under_rocprof.json').read().strip().splitlines()[-1])
-print('under rocprof %.4g' % d2['value'])
-shutil.copy(O+'/pmc_traffic.json','profiles/r01_pmc_traffic.json')
-shutil.copy(O+'/pmc_hbm_traffic.txt','profiles/r01_pmc_hbm_traffic.txt')
-import os as _os
-if _os.path.exists(O+'/pmc_sq.txt'):
-    shutil.copy(O+'/pmc_sq.txt','profiles/r01_pmc_sq.txt')
-open('profiles/r01_bench_final.json','w').write(json.dumps(d)+'\n')
-open('profiles/r01_bench_final_under_rocprof.json','w').write(json.dumps(d2)+'\n')
-_kt = open(O+'/bench_kernel_trace.txt').read().splitlines(True)
-_note = ("# NOTE rollout_kernel<100, 3>: 2 launches = the 100-step warm-up launch (min_us) and the 1000-step TIMED launch (max_us);\n"
-         "#      bench.py's roofline.avg_launch_ms (HIP events around the timed launch) is the max_us figure, not avg_us.\n"
-         "#      The other kernels belong to the two-launch path (timed in the same run) and to the stand-alone roofline leg.\n")
-open('profiles/r01_bench_kernel_trace_final.txt','w').write(''.join(_kt[:2]) + _note + ''.join(_kt[2:]))
-shutil.copy(O+'/dagger_update.json','profiles/r01_dagger_update.json')   # produced by `python bench.py --dagger-update`
-hdr = "# bench.py at other shapes (B N K): value, per-path throughput, per-kernel (avg launch us, GB/s), state finite\n# `resident` = mgp_rollout_steps (covered: N <= 256, widths <= 64); `factored` = HBM bit-row state (N > 256); otherwise the two-launch path is `value`\n"
-open('profiles/r01_other_configs.txt','w').write(hdr+open(O+'/other_configs.txt').read())
-import os
-# phase-stamp files keep their hand-written legend (leading '#' lines); the body is the harness output of this run
-for src, dst in [('rollout_phase_stamps.txt', 'profiles/r01_rollout_phase_stamps.txt'),
-                 ('flock_phase_stamps.txt', 'profiles/r01_flock_step_phase_stamps.txt'),
-                 ('af_phase_stamps.txt', 'profiles/r01_actor_fwd_phase_stamps.txt')]:
-    if os.path.exists(O + '/' + src) and os.path.exists(dst):
-        lead = []
-        for line in open(dst).read().splitlines(True):
-            if not line.startswith('#'):
-                break
-            lead.append(line)
-        open(dst, 'w').write(''.join(lead) + open(O + '/' + src).read())
-if os.path.exists(O+'/train_phase_stamps.txt'):
-    open('profiles/r01_train_step_phase_stamps.txt','w').write(
-        "# tools/harness/train_phase_prof.hip on MI355X: in-kernel s_memtime stamps of workgroup (0,0), thread 0 of\n"
-        "# train_tile_kernel (shader cycles, ~2.1 GHz); the per-update time is both launches of mgp_train_step\n"
-        + open(O+'/train_phase_stamps.txt').read())
+O, R = 'gpurun_out/final', 'r02'
+
+
+def last_json(path):
+    return json.loads(open(path).read().strip().splitlines()[-1])
+
+
+d20 = last_json(O + '/bench_steps20.json')
+d = last_json(O + '/bench_final.json')
+d2 = last_json(O + '/bench_under_rocprof.json')
+for name, x in (('--steps 20 --warmup 5', d20), ('default', d), ('--steps 20 under rocprofv3', d2)):
+    r = x['roofline']
+    print('%-28s value %.4g ms/step %.5f | roofline %s frac %.3f traffic %s | parity %s %.2e | mean degree %.2f' % (
+        name, x['value'], x['ms_per_step'], r['bound'], r['frac'], r['traffic'], x['parity']['ok'], x['parity']['max_rel'],
+        x['config']['mean_degree']))
+    print('   dense kernels:', {k: (round(v['avg_launch_ms'] * 1e3, 2), round(v['frac'], 3), v['traffic']) for k, v in r['dense_kernels'].items()
+                                if isinstance(v, dict)})
+shutil.copy(O + '/pmc_traffic.json', 'profiles/%s_pmc_traffic.json' % R)
+shutil.copy(O + '/pmc_hbm_traffic.txt', 'profiles/%s_pmc_hbm_traffic.txt' % R)
+shutil.copy(O + '/pmc_sq.json', 'profiles/%s_pmc_sq.json' % R)
+shutil.copy(O + '/pmc_sq.txt', 'profiles/%s_pmc_sq.txt' % R)
+open('profiles/%s_bench_steps20.json' % R, 'w').write(json.dumps(d20) + '\n')
+open('profiles/%s_bench_default_1000steps.json' % R, 'w').write(json.dumps(d) + '\n')
+open('profiles/%s_bench_steps20_under_rocprof.json' % R, 'w').write(json.dumps(d2) + '\n')
+kt = open(O + '/bench_kernel_trace.txt').read().splitlines(True)
+note = ("# rocprofv3 --kernel-trace --stats of `python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's command line).\n"
+        "# rollout_kernel<100,3,..>: the 5-step warm-up launch (min_us), the 20-step TIMED launch (max_us) and the parity gate's one-step launch;\n"
+        "#      bench.py's roofline.avg_launch_ms (HIP events around the timed launch) is the max_us figure.  The other kernels belong to the\n"
+        "#      two-launch path (timed in the same run) and to the stand-alone dense-kernel roofline leg.\n")
+open('profiles/%s_bench_kernel_trace.txt' % R, 'w').write(''.join(kt[:2]) + note + ''.join(kt[2:]))
+shutil.copy(O + '/dagger_update.json', 'profiles/%s_dagger_update.json' % R)
+hdr = ("# bench.py at other shapes (B N K), 100-step launches right after reset: value, per-path throughput, in-run parity gate, per-kernel\n"
+       "# (avg launch us, GB/s), state finite.  `resident` = mgp_rollout_steps_ex (N <= 256); `factored` = HBM bit-row state (N > 256)\n")
+open('profiles/%s_other_configs.txt' % R, 'w').write(hdr + open(O + '/other_configs.txt').read())
+open('profiles/%s_rollout_phase_stamps.txt' % R, 'w').write(
+    "# tools/harness/ro_phase_prof.hip on MI355X (RO_CARRY=1: prebuilt weight image + factored hand-over, the repeated-launch form):\n"
+    "# in-kernel s_memtime stamps of workgroup 0, lane 0 of six waves, step 5 of the launch (shader cycles).  First block: regular-lattice\n"
+    "# harness state, 200-step launch; second block: bench.py's own state 5 steps after reset (irregular degrees), 20-step launches.\n"
+    "# Fused schedule: stamp 6 = last gather stage inside the MLP waves; stage 1 rides in D2/D3 (stamp 8); 3 barriers per step.\n"
+    + open(O + '/rollout_phase_stamps.txt').read())
+open('profiles/%s_rollout_launch_cost.txt' % R, 'w').write(
+    "# launch length sweep, B=256 N=100 K=3, lattice harness state: dense hand-over (mgp_rollout_steps) vs [carry] = factored hand-over +\n"
+    "# prebuilt weight image + dense slices on demand (mgp_rollout_steps_ex); us per launch averaged over 20 back-to-back launches\n"
+    + open(O + '/rollout_launch_cost.txt').read())
 from multiagent_gnn_policies_amd import build
-print('hash ok', build.source_hash() == json.load(open('profiles/r01_pmc_traffic.json'))['_meta']['source_hash'])
+print('hash ok', build.source_hash() == json.load(open('profiles/%s_pmc_traffic.json' % R))['_meta']['source_hash'])

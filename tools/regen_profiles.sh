@@ -1,46 +1,52 @@
 #!/bin/bash
 # Regenerates every round artefact under profiles/ on the GPU box (run through gpurun from the repo root):
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/regen_profiles.sh > gpurun_out/regen.log 2>&1'
-#   python tools/install_profiles.py          # copies gpurun_out/final/* into profiles/r01_*
-# The phase harnesses must have been built first (they travel with the snapshot under scratch/):
+#   python tools/install_profiles.py          # copies gpurun_out/final/* into profiles/r02_*
+# The phase harness must have been built first (it travels with the snapshot under scratch/):
 #   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -o scratch/ro_prof tools/harness/ro_phase_prof.hip
-#   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -o scratch/fl_prof tools/harness/flock_phase_prof.hip
-#   hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -o scratch/af_prof tools/harness/af_phase_prof.hip
-#   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -w -o scratch/ts_prof tools/harness/train_phase_prof.hip
 # PMC passes use --pmc with --kernel-trace only (no sys/runtime/hip trace domains).
 set -x
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-# 1. PMC passes (counters only + kernel trace)
+# 1. PMC passes (counters only + kernel trace).  The resident kernel is profiled at two launch lengths (1000 and 20 steps):
+#    bytes(T) = fixed + per_step * T
+export PROBE_T=1000
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o fetch -- python $R/tools/pmc_probe.py > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o write -- python $R/tools/pmc_probe.py > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU --kernel-trace -d $O/pmc_sq -o sq -- python $R/tools/pmc_probe.py > $O/pmc_sq.log 2>&1
+export PROBE_T=20
+PROBE_ROLLOUT_ONLY=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch20 -o fetch -- python $R/tools/pmc_probe.py > $O/pmc_fetch20.log 2>&1
+PROBE_ROLLOUT_ONLY=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write20 -o write -- python $R/tools/pmc_probe.py > $O/pmc_write20.log 2>&1
+export PROBE_T=1000
 F=$(find $O/pmc_fetch -name "*results.db" | head -1); W=$(find $O/pmc_write -name "*results.db" | head -1); Q=$(find $O/pmc_sq -name "*results.db" | head -1)
+F2=$(find $O/pmc_fetch20 -name "*results.db" | head -1); W2=$(find $O/pmc_write20 -name "*results.db" | head -1)
 cd $R
-python tools/pmc_summary.py $F $W $O/pmc_traffic.json 256,100,3 > $O/pmc_hbm_traffic.txt 2>&1
-cp $O/pmc_traffic.json $R/profiles/r01_pmc_traffic.json
-python tools/pmc_sq_summary.py $Q > $O/pmc_sq.txt 2>&1
-# 2. bench (traffic now non-null) plain and under rocprof kernel trace
+python tools/pmc_summary.py $F $W $O/pmc_traffic.json 256,100,3 $F2 $W2 20 > $O/pmc_hbm_traffic.txt 2>&1
+cp $O/pmc_traffic.json $R/profiles/r02_pmc_traffic.json
+python tools/pmc_sq_summary.py $Q $O/pmc_sq.json > $O/pmc_sq.txt 2>&1
+cp $O/pmc_sq.json $R/profiles/r02_pmc_sq.json
+# 2. bench (traffic / sq now resolved from the files just written): the driver's command line, the default, and under rocprof
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_steps20.json 2> $O/bench_steps20.err
 python bench.py > $O/bench_final.json 2> $O/bench_final.err
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python $R/bench.py > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 T=$(find $O/trace -name "*results.db" | head -1)
 cd $R
 python tools/rocpd_stats.py $T > $O/bench_kernel_trace.txt 2>&1
-# 3. phase stamps
-./scratch/ro_prof 256 100 3 200 > $O/rollout_phase_stamps.txt 2>&1
-./scratch/fl_prof 256 100 > $O/flock_phase_stamps.txt 2>&1
-./scratch/af_prof 256 100 > $O/af_phase_stamps.txt 2>&1
-./scratch/ts_prof 20 100 3 > $O/train_phase_stamps.txt 2>&1
-# 4. DAGGER update + other configs
+# 3. phase stamps of the resident kernel: lattice harness state and the bench's own state 5 steps after reset
+RO_CARRY=1 ./scratch/ro_prof 256 100 3 200 > $O/rollout_phase_stamps.txt 2>&1
+python tools/dump_rollout_state.py /tmp/ro_state5.bin 5 > /dev/null 2>&1
+RO_STATE=/tmp/ro_state5.bin RO_CARRY=1 ./scratch/ro_prof 256 100 3 20 20 >> $O/rollout_phase_stamps.txt 2>&1
+for T in 1 2 5 20 200; do ./scratch/ro_prof 256 100 3 $T 20 | head -1; RO_CARRY=1 ./scratch/ro_prof 256 100 3 $T 20 | head -1; done > $O/rollout_launch_cost.txt 2>&1
+# 4. DAGGER update / collection + other configs
 python tools/bench_update.py > $O/dagger_update.json 2> $O/dagger_update.err
-for cfg in "64 1000 3" "256 200 4" "1 100 3" "2048 100 3" "256 100 4" "256 100 2" "256 100 1" "256 125 3" "256 75 3" "256 50 2" "256 25 4"; do set -- $cfg; python bench.py --episodes $1 --agents $2 --taps $3 --no-cpu-baseline --steps 100 --warmup 10 2>/dev/null | python -c "
+for cfg in "64 1000 3" "256 200 4" "1 100 3" "2048 100 3" "256 100 4" "256 100 2" "256 125 3" "256 50 2"; do set -- $cfg; python bench.py --episodes $1 --agents $2 --taps $3 --no-cpu-baseline --steps 100 --warmup 10 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 k = {a: (round(v['avg_launch_ms']*1e3,1), round(v['GBps'])) for a, v in d.get('kernels', {}).items()}
-print('$1 $2 $3', 'value %.3e' % d['value'], 'ms/step %.4f' % d['ms_per_step'], 'paths', {a: '%.3e' % b['value'] for a, b in d['paths'].items()}, k, d['config']['state_finite'])
+print('$1 $2 $3', 'value %.3e' % d['value'], 'ms/step %.4f' % d['ms_per_step'], 'paths', {a: '%.3e' % b['value'] for a, b in d['paths'].items()}, 'parity ok', d['parity']['ok'], 'max_rel %.2e' % d['parity']['max_rel'], k, d['config']['state_finite'])
 " >> $O/other_configs.txt; done
-rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/trace
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_fetch20 $O/pmc_write20 $O/trace
 ls -la $O
