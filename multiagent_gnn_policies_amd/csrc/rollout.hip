@@ -88,9 +88,9 @@ struct RoOff {
 
 __host__ __device__ constexpr int ro_take(int& off, int bytes) { const int o = off; off += (bytes + 15) & ~15; return o; }
 __host__ __device__ constexpr int ro_hist(int K) { return K > 2 ? K - 1 : 1; }
-// list row stride in bytes: room for N - 1 entries + 8 pad bytes, a multiple of 4 with an ODD word count -- neighbouring
-// lanes walk neighbouring rows, and an even word stride (112 B at N = 100) put them 8 to a bank
-__host__ __device__ constexpr int ro_list_stride(int N) { const int w = (N + 8 + 3) >> 2; return 4 * (w | 1); }
+// list row stride in bytes: room for N - 1 entries, a multiple of 4 with an ODD word count -- neighbouring lanes walk
+// neighbouring rows, and an even word stride put them 8 to a bank
+__host__ __device__ constexpr int ro_list_stride(int N) { const int w = (N - 1 + 3) >> 2; return 4 * (w | 1); }
 
 // Factored hand-over of the operator history between launches ("carry"): per episode the membership BITS of the last
 // H = ro_hist(K) networks, newest first (slot 0 = A_t of the state, slot q = A_{t-q}; NW 64-bit words per row: 2 for
@@ -239,7 +239,6 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             else { chunk = (unsigned int)(hi >> 32); pos = __popcll(lo) + __popc((unsigned int)hi); }
             unsigned char* lp = rlist + ((size_t)slot * N + row) * RS;
             while (chunk) { lp[pos++] = (unsigned char)(32 * cq + __builtin_ctz(chunk)); chunk &= chunk - 1u; }
-            lp[cnt + 2 * cq] = (unsigned char)N; lp[cnt + 2 * cq + 1] = (unsigned char)N;
             if (cq == 0) {
                 rcnt[slot * N + row] = cnt;
                 wrow[slot * N + row] = cw[rq];
@@ -603,7 +602,6 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 else { chunk = (unsigned int)(hi >> 32); pos = __popcll(lo) + __popc((unsigned int)hi); }
                 unsigned char* lp = rl_new + fr * RS;
                 while (chunk) { lp[pos++] = (unsigned char)(32 * fq + __builtin_ctz(chunk)); chunk &= chunk - 1u; }
-                lp[cnt + 2 * fq] = (unsigned char)N; lp[cnt + 2 * fq + 1] = (unsigned char)N;      // pad: index of the zero row
                 const double xi = spx[fr], yi = spy[fr], vxi = svx[fr], vyi = svy[fr];
                 for (int e = fq; e < cnt; e += 4) {           // entries written by this wave's own lanes just above
                     const int j = lp[e];

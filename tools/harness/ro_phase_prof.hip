@@ -11,6 +11,8 @@ thread_local int mgp_tls_hip_error = 0;
 extern "C" int mgp_rollout_wide_supported_(const int*, int, int, int) { return 0; }
 extern "C" int mgp_rollout_wide_steps_ex_(double*, float*, float*, const float* const*, const float* const*, const int*, int, float*,
                                           double*, const MgpFlockParams*, int, int, int, int, const float*, void*, int, void*) { return MGP_EUNSUPPORTED; }
+extern "C" int mgp_rollout_wide_collect_(double*, float*, float*, const float* const*, const float* const*, const int*, int, double*,
+                                         const MgpFlockParams*, int, int, int, int, const float*, void*, int, const MgpCollect*, void*) { return MGP_EUNSUPPORTED; }
 extern "C" long mgp_rollout_wide_image_floats_(const int*, int, int, int) { return 0; }
 extern "C" int mgp_rollout_wide_image_(const float* const*, const float* const*, const int*, int, int, int, float*, void*) { return MGP_EUNSUPPORTED; }
 int main(int argc, char** argv) {
