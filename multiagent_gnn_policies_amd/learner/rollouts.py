@@ -65,6 +65,68 @@ def rollout_image_for(actor, K, N):
     return ops.rollout_image(ws, bs, tuple(actor.layers), K, N)
 
 
+class ResidentPlan(object):
+    """A repeated resident launch with its host side bound ONCE: weight image, layer table, flock parameters and the argument
+    list of mgp_rollout_steps_ex are prepared here, so that `run(T)` is one ctypes call plus flag bookkeeping (~10 us of host
+    time instead of ~50: the chunked evaluation loops -- gnn_dagger.py:190-232, test_model.py, bench.py -- launch every few
+    hundred microseconds, and whatever the host does before the launch is time the GPU idles).
+    Valid while the actor's weights and the `sim` / `state` objects stay the same; `refresh()` after a weight update."""
+
+    def __init__(self, actor, sim, state):
+        import ctypes
+        from .. import _lib, ops
+        if not (actor.ind_agg == 0 and state.F == 6 and sim.network64 is None and sim.features64 is None
+                and ops.rollout_supported(tuple(actor.layers), state.K, sim.N)):
+            raise ops.MgpError("the episode-resident kernel does not cover this shape (use policy_rollout)")
+        self.actor, self.sim, self.state = actor, sim, state
+        self._L, self._ops, self._ct = _lib.lib(), ops, ctypes
+        dims = tuple(actor.layers)
+        self._cd = (ctypes.c_int * len(dims))(*dims)
+        self._nl = len(dims) - 1
+        self._params = ctypes.byref(sim._c)
+        self._carry = state.carry_buffer()
+        self._carry_p = ops._ptr(self._carry)
+        self.refresh()
+
+    def refresh(self):
+        """Rebuild the weight image (call after the policy's weights changed)."""
+        self.image = rollout_image_for(self.actor, self.state.K, self.sim.N)
+        self._image_p = self._ops._ptr(self.image)
+
+    def run(self, T, rewards=None, action=None, lazy_dense=True, update_sim_reward=True):
+        """T closed-loop policy steps of every lane in one launch; same state bookkeeping as policy_rollout."""
+        ops, state, sim = self._ops, self.state, self.sim
+        flags = 0
+        if self._carry is not None:
+            if state._carry_valid:
+                flags = ops.RO_ENTER_CARRY
+            if flags or T >= state.K - 1:
+                flags |= ops.RO_EXIT_CARRY | (ops.RO_SKIP_DENSE if lazy_dense else 0)
+        if not (flags & ops.RO_ENTER_CARRY):
+            state._ensure_dense()
+        B, N, K = sim.B, sim.N, state.K
+        if rewards is not None:
+            assert rewards.shape == (B, T) and rewards.dtype.is_floating_point and rewards.element_size() == 8
+        rc = self._L.mgp_rollout_steps_ex(sim.x.data_ptr(), state._G[state._cur].data_ptr(), state._X[state._cur].data_ptr(),
+                                          None, None, self._cd, self._nl, ops._ptr(action), ops._ptr(rewards), self._params,
+                                          B, K, N, int(T), self._image_p, self._carry_p, flags, ops._stream())
+        if rc != 0:
+            from .. import _lib
+            _lib.check(rc, 'mgp_rollout_steps_ex')
+        state._carry_valid = bool(flags & ops.RO_EXIT_CARRY)
+        state._dense_stale = bool(flags & ops.RO_SKIP_DENSE)
+        if K > 1:
+            sim._network, sim._network_lazy = None, self._lazy_network
+        sim.features = state._X[state._cur][:, 0]
+        if rewards is not None and update_sim_reward:
+            sim.reward.copy_(rewards[:, T - 1])
+        state._pushes += T
+        return True
+
+    def _lazy_network(self):
+        return self.state.delay_gso[:, 1]
+
+
 def policy_rollout(actor, sim, state, T, rewards=None, action=None, resident=True, image=None, lazy_dense=True):
     """T closed-loop policy steps of every episode lane of `sim` (VecFlock) / `state` (BatchedDelayState): the batched
     form of the reference's evaluation loop (test_model.py:38-44).  `rewards` (B,T) fp64 receives every step's reward.

@@ -208,6 +208,26 @@ def test_rollout_factored_handover_makes_chunkings_bit_identical(N, K, hidden, v
             assert np.array_equal(a, b), name
 
 
+def test_resident_plan_equals_policy_rollout():
+    """ResidentPlan (the host side of a repeated launch bound once) launches the same kernel with the same arguments."""
+    from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout, ResidentPlan
+    outs = []
+    for use_plan in (False, True):
+        rs, op, actor, sim, st = _make(100, 3, (32, 32), 4, seed=9)
+        rw = torch.zeros((4, 6), device='cuda', dtype=torch.float64)
+        action = torch.zeros((4, 1, 2, 100), device='cuda')
+        plan = ResidentPlan(actor, sim, st) if use_plan else None
+        for _ in range(3):
+            if use_plan:
+                assert plan.run(6, rewards=rw, action=action)
+            else:
+                assert policy_rollout(actor, sim, st, 6, rewards=rw, action=action)
+        assert st._pushes == 19 and torch.equal(sim.reward, rw[:, 5])
+        outs.append(_snapshot(sim, st) + (action.cpu().numpy().copy(), rw.cpu().numpy().copy(), sim.network.cpu().numpy()))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
 def test_rollout_ex_flag_validation():
     """C-ABI argument checking of mgp_rollout_steps_ex (include/mgp.h)."""
     import ctypes
