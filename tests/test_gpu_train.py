@@ -131,6 +131,21 @@ def test_train_py_two_ranks_data_parallel():
     assert [l.split(',')[0] for l in lines[1:]] == ['dagger', 'cloning', 'baseline']      # printed once (rank 0)
 
 
+def test_train_py_dagger_vec_single_and_two_ranks():
+    """`alg = dagger_vec` through train.py: the device-collecting vectorised loop, single process and torchrun x2 (episodes
+    and coin streams are functions of the GLOBAL episode index; the data-parallel update goes through GraphedUpdate)."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'train.py'), 'cfg/smoke_vec.cfg'], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rows = [l for l in r.stdout.strip().splitlines() if l.startswith('dagger_vec')]
+    assert len(rows) == 1 and np.isfinite(float(rows[0].split(',')[1])) and float(rows[0].split(',')[1]) < 0
+    r2 = _torchrun([os.path.join(ROOT, 'train.py'), 'cfg/smoke_vec.cfg'])
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    rows2 = [l for l in r2.stdout.strip().splitlines() if l.startswith('dagger_vec')]
+    assert len(rows2) == 1 and np.isfinite(float(rows2[0].split(',')[1]))
+
+
 def test_bench_two_ranks_contract():
     """bench.py under the driver's multi-GPU launch line (2 ranks): one JSON line, weak scaling, aggregate value."""
     import json
