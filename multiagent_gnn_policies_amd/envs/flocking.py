@@ -261,15 +261,16 @@ class DeviceObservation(object):
     -- the fp32 tensor already on the GPU in the layout it needs -- so the per-step D2H of the 80 KB fp64 network
     matrix and the H2D of its fp32 copy disappear from the reference-style B = 1 loop."""
 
-    def __init__(self, dev64, device32, zero_diagonal=False):
-        self._dev64 = dev64                  # (N,6) or (N,N) float64 device tensor (snapshot)
+    def __init__(self, dev64, device32, zero_diagonal=False, shape=None):
+        self._dev64 = dev64                  # (N,6) or (N,N) float64 device tensor (snapshot); None in the fast loop mode
         self.device32 = device32             # (6,N) features / (N,N) network, float32, device
         self.zero_diagonal = zero_diagonal   # the simulator never sets self-loops (state_with_delay.py:26)
+        self._shape = tuple(shape) if shape is not None else tuple(dev64.shape)
         self._np = None
 
     @property
     def shape(self):
-        return tuple(self._dev64.shape)
+        return self._shape
 
     @property
     def dtype(self):
@@ -277,10 +278,13 @@ class DeviceObservation(object):
 
     @property
     def ndim(self):
-        return self._dev64.dim()
+        return len(self._shape)
 
     def numpy(self):
         if self._np is None:
+            if self._dev64 is None:
+                raise ops.MgpError("this observation was produced in the environment's fast loop mode (fast_loop = True): only "
+                                   "its fp32 device side exists; set env.env.fast_loop = False for numpy observations")
             self._np = self._dev64.cpu().numpy()
         return self._np
 
@@ -313,6 +317,22 @@ class FlockingRelativeEnv(object):
         self.n_features = 6
         self.nu = 2
         self.lazy_obs = True           # observations stay on the device until numpy is requested
+        # fast loop mode (set by this package's own one-environment loops, learner/imitation.py / rollouts.py): nothing
+        # crosses PCIe per step -- observations carry only their fp32 device side, step() takes the action as a device
+        # tensor and returns the reward as a 0-d device tensor, controller() returns a device tensor.  The values are the
+        # ones the default mode returns (the device consumes actions as fp32 either way); off by default because code
+        # written against gym_flock expects numpy.
+        self._fast_loop = False
+
+    @property
+    def fast_loop(self):
+        return self._fast_loop
+
+    @fast_loop.setter
+    def fast_loop(self, on):
+        if bool(on) != self._fast_loop:
+            self._fast_loop = bool(on)
+            self._sim = None
 
     # -- configuration -------------------------------------------------------------------------
     def params_from_cfg(self, args):
@@ -341,11 +361,15 @@ class FlockingRelativeEnv(object):
             dev = self.device or ('cuda:0' if torch.cuda.is_available() else None)
             if dev is None:
                 raise ops.MgpError("the flocking simulator needs a HIP device (no CPU simulation path)")
-            self._sim = VecFlock(1, self.params, dev, want_f64_obs=True)
+            self._sim = VecFlock(1, self.params, dev, want_f64_obs=not self._fast_loop, with_expert=self._fast_loop)
         return self._sim
 
     def _obs(self):
         s = self._sim
+        if self._fast_loop:
+            n = self.params.n_agents
+            return (DeviceObservation(None, s.features[0].clone(), shape=(n, 6)),
+                    DeviceObservation(None, s.network[0].clone(), zero_diagonal=True, shape=(n, n)))
         if not self.lazy_obs:
             return s.features64[0].cpu().numpy(), s.network64[0].cpu().numpy()
         # snapshots: the simulator's buffers are overwritten by the next step
@@ -360,16 +384,24 @@ class FlockingRelativeEnv(object):
 
     def step(self, u):
         s = self._ensure()
-        u = np.asarray(u)
-        assert u.shape == (self.params.n_agents, self.nu)
-        ut = torch.from_numpy(np.ascontiguousarray(u, dtype=np.float32)).reshape(1, -1, 2).to(s.device)
+        if torch.is_tensor(u) and u.is_cuda:                    # action already on the device (this package's loops)
+            assert tuple(u.shape) == (self.params.n_agents, self.nu)
+            ut = u.to(torch.float32).reshape(1, -1, 2).contiguous()
+        else:
+            u = np.asarray(u.cpu() if torch.is_tensor(u) else u)
+            assert u.shape == (self.params.n_agents, self.nu)
+            ut = torch.from_numpy(np.ascontiguousarray(u, dtype=np.float32)).reshape(1, -1, 2).to(s.device)
         s.step(ut)
+        if self._fast_loop:
+            return self._obs(), s.reward[0].clone(), False, {}
         return self._obs(), float(s.reward[0].item()), False, {}
 
     def controller(self, centralized=None):
         """None -> the env's own `centralized` attribute (True: DAGGER's teacher is the global controller)."""
         s = self._ensure()
-        s.controller(self.params.centralized if centralized is None else bool(centralized))
+        u = s.controller(self.params.centralized if centralized is None else bool(centralized))
+        if self._fast_loop:
+            return u[0].clone()                                 # (N,2) fp32 on the device
         return s.expert64[0].cpu().numpy()
 
     def render(self, mode='human'):

@@ -58,6 +58,8 @@ class ImitationRun(object):
         self.n_test_local = max(1, hi - lo) if self.world > 1 else self.cfg.n_test_episodes
         self.total_numsteps = 0
         self.updates = 0
+        from .rollouts import enable_fast_loop
+        self.fast = enable_fast_loop(env)          # this package's simulator: the one-environment loop never leaves the device
 
     # ------------------------------------------------------------------ the three stages of one training episode
     def collect(self, beta):
@@ -71,13 +73,19 @@ class ImitationRun(object):
             if beta is None or np.random.binomial(1, beta) > 0:
                 applied = expert
             else:
-                applied = self.learner.select_action(state).cpu().numpy()
+                applied = self.learner.select_action(state)
+                if not self.fast:
+                    applied = applied.cpu().numpy()
             obs, reward, done, _ = env.step(applied)
             nxt = MultiAgentStateWithDelay(dev, self.args, obs, prev_state=state)
-            label = torch.from_numpy(np.ascontiguousarray(np.asarray(expert, dtype=np.float32).T))
-            label = label.reshape((1, 1, c.n_actions, c.n_agents)).to(dev)
-            self.memory.insert(Transition(state, label, torch.tensor([float(not done)], device=dev), nxt,
-                                          torch.tensor([float(reward)], device=dev)))
+            if torch.is_tensor(expert):              # fast loop: (N,nA) fp32 on the device -> (1,1,nA,N), reward 0-d tensor
+                label = expert.t().reshape((1, 1, c.n_actions, c.n_agents)).contiguous()
+                rew = reward.to(torch.float32).reshape(1)
+            else:
+                label = torch.from_numpy(np.ascontiguousarray(np.asarray(expert, dtype=np.float32).T))
+                label = label.reshape((1, 1, c.n_actions, c.n_agents)).to(dev)
+                rew = torch.tensor([float(reward)], device=dev)
+            self.memory.insert(Transition(state, label, torch.tensor([float(not done)], device=dev), nxt, rew))
             state = nxt
             self.total_numsteps += 1
 

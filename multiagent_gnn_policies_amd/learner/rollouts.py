@@ -14,9 +14,20 @@ def run_episode(env, act, on_step=None):
         next_obs, reward, done, _ = env.step(action)
         if on_step is not None:
             on_step(obs, action, next_obs, reward, done)
-        total += reward
+        total = total + reward                       # (a 0-d device tensor in the environment's fast loop mode: no sync)
         obs = next_obs
-    return total
+    return float(total)
+
+
+def enable_fast_loop(env):
+    """Put one of this package's gym-style environments into its fast loop mode (no host<->device traffic per step);
+    returns True if the environment supports it (any other environment object is left alone)."""
+    from ..envs.flocking import FlockingRelativeEnv
+    raw = getattr(env, 'env', None)
+    if isinstance(raw, FlockingRelativeEnv):
+        raw.fast_loop = True
+        return True
+    return False
 
 
 def reward_stats(rewards):
@@ -40,11 +51,13 @@ class PolicyRunner(object):
         return self.state
 
     def act(self, obs):
-        return self.learner.select_action(self.observe(obs)).cpu().numpy()
+        a = self.learner.select_action(self.observe(obs))
+        return a if hasattr(obs[0], 'device32') and obs[0]._dev64 is None else a.cpu().numpy()   # fast loop: stays on the device
 
 
 def policy_episode_reward(env, learner, device, args):
     """One policy-only episode (the reference's test loop, gnn_dagger.py:194-203)."""
+    enable_fast_loop(env)
     runner = PolicyRunner(learner, device, args)
     return run_episode(env, runner.act)
 

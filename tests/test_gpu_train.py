@@ -131,6 +131,44 @@ def test_train_py_two_ranks_data_parallel():
     assert [l.split(',')[0] for l in lines[1:]] == ['dagger', 'cloning', 'baseline']      # printed once (rank 0)
 
 
+def test_fast_loop_mode_is_bit_identical_to_the_numpy_loop():
+    """The one-environment loops of this package run the gym-style env in its fast loop mode (device actions, device rewards,
+    fp32-only observations): same trajectory, same rewards, same replay labels as the gym_flock-compatible numpy mode."""
+    import random
+    from multiagent_gnn_policies_amd import envs
+    from multiagent_gnn_policies_amd.learner.gnn_dagger import DAGGER
+    from multiagent_gnn_policies_amd.learner.imitation import ImitationRun
+    from multiagent_gnn_policies_amd.learner.rollouts import PolicyRunner, run_episode
+    args = _args(n_agents=30, hidden_size=16, gamma=0.99, tau=0.5, actor_lr=1e-3, batch_size=4, buffer_size=100,
+                 updates_per_step=2, n_train_episodes=1, test_interval=1, n_test_episodes=1, debug=False, env='FlockingRelative-v0')
+    res = []
+    for fast in (False, True):
+        random.seed(2); np.random.seed(2); torch.manual_seed(2)
+        env = envs.make('FlockingRelative-v0', max_episode_steps=12)
+        env.env.params_from_cfg(args)
+        env.seed(2)
+        learner = DAGGER('cuda:0', args)
+        run = ImitationRun(env, learner, args, torch.device('cuda:0'))
+        assert run.fast                                          # the loop switches the env to the fast mode itself ...
+        if not fast:
+            env.env.fast_loop = False; run.fast = False          # ... the numpy mode is what a gym_flock user gets
+        run.collect(0.5)
+        labels = torch.cat([t.action for t in run.memory.buffer]).cpu().numpy()
+        rewards = torch.cat([t.reward for t in run.memory.buffer]).cpu().numpy()
+        last = run.memory.buffer[-1].next_state
+        ep = run_episode(env, PolicyRunner(learner, 'cuda:0', args).act)
+        res.append((labels, rewards, last.delay_gso.cpu().numpy(), last.delay_state.cpu().numpy(), ep))
+        assert type(ep) is float
+    for a, b in zip(res[0][:4], res[1][:4]):
+        assert np.array_equal(a, b)
+    assert res[0][4] == res[1][4]
+    env = envs.make('FlockingRelative-v0', max_episode_steps=3)
+    env.env.params_from_cfg(args); env.env.fast_loop = True
+    obs = env.reset()
+    with pytest.raises(Exception):
+        np.asarray(obs[0])                                       # fp32 device side only: asking for numpy fails loudly
+
+
 def test_train_py_dagger_vec_single_and_two_ranks():
     """`alg = dagger_vec` through train.py: the device-collecting vectorised loop, single process and torchrun x2 (episodes
     and coin streams are functions of the GLOBAL episode index; the data-parallel update goes through GraphedUpdate)."""

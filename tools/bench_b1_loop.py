@@ -18,13 +18,16 @@ env.env.params_from_cfg(args)
 env.env.params = env.env.params.__class__(**{**env.env.params.__dict__, 'init_mode': 'grid'})
 env.seed(0)
 learner = DAGGER(dev, args)
-runner = PolicyRunner(learner, dev, args)
-run_episode(env, runner.act)
-runner.reset()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-run_episode(env, runner.act)
-torch.cuda.synchronize()
-el = time.perf_counter() - t0
-print(json.dumps({"loop": "gym facade B=1, N=100, K=3 (reference-style test loop)", "ms_per_env_step": 1e3 * el / 300,
-                  "agent_steps_per_s": 100 * 300 / el}))
+out = {"loop": "gym facade B=1, N=100, K=3 (reference-style test loop, gnn_dagger.py:194-203)"}
+for mode in ("numpy (gym_flock-compatible: action D2H, reward sync per step)", "fast_loop (nothing crosses PCIe per step)"):
+    env.env.fast_loop = mode.startswith("fast")
+    runner = PolicyRunner(learner, dev, args)
+    run_episode(env, runner.act)
+    runner.reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_episode(env, runner.act)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out[mode] = {"ms_per_env_step": 1e3 * el / 300, "agent_steps_per_s": 100 * 300 / el}
+print(json.dumps(out))
