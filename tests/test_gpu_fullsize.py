@@ -166,3 +166,44 @@ def test_resident_rollout_cfg2_properties_full_size():
     # after the boundary, 3e-6 after five, O(0.1) after 35) -- hence a boundary two steps before the end
     dev = (outs[0][0] - outs[1][0]).abs().flatten(1).max(dim=1).values
     assert dev.median().item() <= 1e-5 and (dev <= 1e-3).float().mean().item() >= 0.9, dev.sort().values[-8:]
+
+
+@pytest.mark.parametrize('cfg,T', [('cfg3', 4), ('cfg5', 6)])
+def test_other_baseline_configs_rollout_full_size(cfg, T):
+    """BASELINE configs[2] (B = 64, N = 1000, K = 3: factored state in HBM) and configs[4]'s shape (B = 256, N = 200, K = 4:
+    rollout_big_kernel) at FULL size on the path bench.py times for them: action of the last step of a multi-step call against
+    the fp64 oracle forward on the dense state the call itself hands back one step earlier, elementwise 1e-5 (+ the
+    reference's own fp32 distance, factor one), for sampled episodes; structural properties of the final state for all."""
+    import bench
+    from oracle import actor as oa
+    from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
+    B, N, K = CFGS[cfg]
+
+    def fresh():
+        return bench.Rollout(torch.device('cuda:0'), B, N, K, [32, 32], seed=1000)
+    ro = fresh()
+    assert ro.factored_supported() if cfg == 'cfg3' else ro.resident_supported()
+    ro.run_resident(T - 1)
+    sample = [0, B // 3, 2 * B // 3, B - 1]
+    G = ro.state.delay_gso[sample].cpu().numpy().astype(np.float64)
+    X = ro.state.delay_state[sample].cpu().numpy().astype(np.float64)
+    Ws = [c.weight.detach().cpu().numpy() for c in ro.actor.conv_layers]
+    bs = [c.bias.detach().cpu().numpy() for c in ro.actor.conv_layers]
+    ref = oa.forward(X, G, Ws, bs, 0, dtype=np.float64)
+    noise = float(np.max(np.abs(oa.forward(X.astype(np.float32), G.astype(np.float32), Ws, bs, 0, dtype=np.float32) - ref)
+                         / np.maximum(1.0, np.abs(ref))))
+    ro2 = fresh()
+    action = torch.zeros((B, 1, 2, N), device='cuda')
+    rewards = torch.zeros((B, T), device='cuda', dtype=torch.float64)
+    assert policy_rollout(ro2.actor, ro2.sim, ro2.state, T, rewards=rewards, action=action)
+    u = action[sample].cpu().numpy().astype(np.float64)
+    err = float(np.max(np.abs(u - ref) / np.maximum(1.0, np.abs(ref))))
+    print('%s, last action of a %d-step call, B=%d N=%d K=%d: elementwise err %.3g (reference fp32: %.3g)' % (cfg, T, B, N, K, err, noise))
+    assert err <= 1e-5 + noise
+    Gf = ro2.state.delay_gso
+    assert torch.isfinite(ro2.sim.x).all() and torch.isfinite(Gf).all() and (rewards < 0).all()
+    A = Gf[:, 1]
+    pat = A != 0
+    assert torch.equal(pat, pat.transpose(1, 2)) and torch.all(torch.diagonal(A, dim1=1, dim2=2) == 0)
+    deg = pat.sum(-1, keepdim=True).clamp(min=1).float()
+    assert torch.equal(A, pat.float() / deg)
