@@ -436,10 +436,10 @@ def dagger_update_bench():
     for i0 in range(0, cap, B):
         rb.insert_batch(xd, gd, yd)
     iu = IndexedUpdates(learner, rb, B, U)
-    iu.run([random.sample(range(cap), B) for _ in range(50)])
+    iu.run_sampled(64)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    loss_round = iu.run([random.sample(range(cap), B) for _ in range(U)]).item()
+    loss_round = iu.run_sampled(U).item()
     gpu_ms_idx = 1e3 * (time.perf_counter() - t0) / U
     assert np.isfinite(loss_round)
     from oracle import torch_port                          # CPU leg
@@ -496,11 +496,12 @@ def dagger_update_bench():
     torch.cuda.synchronize()
     collect_kernel_ms = e0c.elapsed_time(e1c)
     fu = FrameUpdates(learner, memc, B, 2000, True)
-    fu.run([memc.sample_ids(B) for _ in range(50)])
+    fu.run_sampled(64)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    fu.run([memc.sample_ids(B) for _ in range(2000)]).item()
+    fu.run_sampled(2000).item()                                # random.sample per update, overlapped with the GPU's replays
     frame_update_ms = 1e3 * (time.perf_counter() - t0) / 2000
+
     return {"update": "DAGGER gradient_step B=20 N=100 K=3", "hip_ms": gpu_ms, "hip_updates_per_s": 1e3 / gpu_ms,
             "collect": {"lanes": lanes, "steps": Tc, "kernel_ms": collect_kernel_ms,
                         "kernel_agent_steps_per_s": lanes * N * Tc / (1e-3 * collect_kernel_ms),

@@ -65,6 +65,62 @@ class DeviceReplay(object):
         self.position = 0
 
 
+UPDATES_PER_GRAPH = 32
+
+
+def _replay_updates(obj, U):
+    """Run U consecutive updates of `obj` (IndexedUpdates / FrameUpdates: everything an update needs -- minibatch indices,
+    cursor, step counter, losses -- lives on the device).  One update is 2-3 short launches (~30 us of GPU time), less than
+    the host spends on one graph replay; so UPDATES_PER_GRAPH updates are captured back to back in ONE graph, and a round of
+    thousands of updates is GPU-bound instead of host-bound (60 -> ~32 us per update).  The remainder runs on a one-update graph."""
+    if obj.graph is None:
+        torch.cuda.synchronize()
+        obj.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(obj.graph):
+            obj._enqueue()
+        obj.graph_many = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(obj.graph_many):
+            for _ in range(UPDATES_PER_GRAPH):
+                obj._enqueue()
+        # capture does not execute: the cursor / step counter / weights are untouched
+    if U <= 0:
+        return
+    full, rest = divmod(U, UPDATES_PER_GRAPH)
+    for _ in range(full):
+        obj.graph_many.replay()
+    for _ in range(rest):
+        obj.graph.replay()
+
+
+def _run_sampled(obj, U, sampler):
+    """U updates whose minibatch indices come from `sampler()` (one list of batch_size indices per call: the reference's
+    `random.sample` per update), pipelined: while the GPU replays one graph of UPDATES_PER_GRAPH updates the host draws the
+    indices of the next one into a pinned staging buffer and enqueues their upload -- a round of updates costs max(host
+    sampling, GPU) per update instead of their sum.  Returns the sum of the losses (device tensor)."""
+    assert 0 < U <= obj.cap
+    if getattr(obj, '_stage', None) is None:
+        obj._stage = [torch.empty((UPDATES_PER_GRAPH, obj.B), dtype=torch.long).pin_memory() for _ in range(2)]
+        obj._stage_done = [None, None]
+    obj.cursor.zero_()
+    _replay_updates(obj, 0)                                       # make sure both graphs exist
+    done, turn = 0, 0
+    while done < U:
+        n = min(UPDATES_PER_GRAPH, U - done)
+        buf = obj._stage[turn]
+        if obj._stage_done[turn] is not None:
+            obj._stage_done[turn].synchronize()                   # its previous upload has been consumed
+        buf[:n] = torch.tensor([sampler() for _ in range(n)], dtype=torch.long)
+        obj.idx[done:done + n].copy_(buf[:n], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        obj._stage_done[turn] = ev
+        _replay_updates(obj, n)
+        done += n
+        turn ^= 1
+    obj.learner.actor_optim.step_count += U
+    return obj.loss_hist[:U].sum()
+
+
 class IndexedUpdates(object):
     """A round of DAGGER updates with no per-update host work: the minibatch indices of the whole round are uploaded once,
     and every update is one replay of a two-launch HIP graph (mgp_train_step_indexed) that gathers its batch from the
@@ -108,6 +164,12 @@ class IndexedUpdates(object):
             self.cdims, self.nl, o.lr, o.betas[0], o.betas[1], o.eps, self.step_dev.data_ptr(), ops._ptr(self.ws),
             self.B, self.K, self.N, ops._stream()), 'mgp_train_step_indexed')
 
+    def run_sampled(self, U, sampler=None):
+        """U updates, indices drawn per update by `sampler` (default: the reference's random.sample over the replay rows),
+        host sampling overlapped with the GPU (see _run_sampled)."""
+        m = self.memory
+        return _run_sampled(self, U, sampler or (lambda: random.sample(range(m.curr_size), self.B)))
+
     def run(self, ids):
         """ids: one list of `batch_size` replay rows per update.  Returns the sum of the updates' losses (device tensor)."""
         U = len(ids)
@@ -115,13 +177,7 @@ class IndexedUpdates(object):
         opt = self.learner.actor_optim
         self.idx[:U].copy_(torch.tensor(ids, dtype=torch.long), non_blocking=False)
         self.cursor.zero_()
-        if self.graph is None:
-            torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self._enqueue()
-        for _ in range(U):
-            self.graph.replay()
+        _replay_updates(self, U)
         opt.step_count += U
         return self.loss_hist[:U].sum()
 
@@ -224,19 +280,19 @@ class FrameUpdates(object):
             self.cdims, self.nl, o.lr, o.betas[0], o.betas[1], o.eps, self.step_dev.data_ptr(), ops._ptr(self.ws),
             self.B, self.K, self.N, ops._stream()), 'mgp_train_step_indexed')
 
+    def run_sampled(self, U, sampler=None):
+        """U updates, frame indices drawn per update by `sampler` (default: FrameReplay.sample_ids -- the reference's
+        random.sample over the buffer positions), host sampling overlapped with the GPU (see _run_sampled)."""
+        m = self.memory
+        return _run_sampled(self, U, sampler or (lambda: m.sample_ids(self.B)))
+
     def run(self, ids):
         """ids: one list of `batch_size` frame indices per update.  Returns the sum of the updates' losses (device tensor)."""
         U = len(ids)
         assert 0 < U <= self.cap
         self.idx[:U].copy_(torch.tensor(ids, dtype=torch.long), non_blocking=False)
         self.cursor.zero_()
-        if self.graph is None:
-            torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self._enqueue()
-        for _ in range(U):
-            self.graph.replay()
+        _replay_updates(self, U)
         self.learner.actor_optim.step_count += U
         return self.loss_hist[:U].sum()
 
@@ -377,16 +433,11 @@ def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
         loss_sum = 0.0
         n_updates = updates_per_step * n_envs
         if n_updates > 0 and memory.curr_size > batch_size and IndexedUpdates.supported(learner, batch_size, N):
-            if on_device:
-                if indexed is None:
-                    indexed = FrameUpdates(learner, memory, batch_size, n_updates, p.mean_pooling)
-                ids = [memory.sample_ids(batch_size) for _ in range(n_updates)]
-            else:
-                if indexed is None:
-                    indexed = IndexedUpdates(learner, memory, batch_size, n_updates)
-                ids = [random.sample(range(memory.curr_size), batch_size) for _ in range(n_updates)]
-            loss_sum = float(indexed.run(ids).item())
-            updates += len(ids)
+            if indexed is None:
+                indexed = (FrameUpdates(learner, memory, batch_size, n_updates, p.mean_pooling) if on_device
+                           else IndexedUpdates(learner, memory, batch_size, n_updates))
+            loss_sum = float(indexed.run_sampled(n_updates).item())     # random.sample per update, overlapped with the GPU
+            updates += n_updates
         elif n_updates > 0 and memory.curr_size > batch_size:
             bufs = learner.graphed_buffers(batch_size, N)        # None: composed eager updates (shape outside the fused kernels)
             graphed = bufs is not None

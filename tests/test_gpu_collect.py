@@ -154,3 +154,59 @@ def test_dagger_coin_oracle_statistics_and_edges():
     assert abs(hits - 0.7) < 0.02
     a = [odv.dagger_coin(11, 3, s) for s in range(64)]; c = [odv.dagger_coin(11, 4, s) for s in range(64)]
     assert a != c and len(set(a)) == 64
+
+
+def test_frame_updates_many_per_graph_equal_one_per_graph():
+    """A round of updates replayed 32-per-graph (device cursor, device step counter) is bit-identical to the same round replayed
+    one update per graph, and to the eager path on gathered minibatches within fp32 rounding."""
+    import configparser
+    import random
+    from multiagent_gnn_policies_amd.learner import vec_dagger as vd
+    from multiagent_gnn_policies_amd.learner.gnn_dagger import DAGGER
+    N, K, B, T = 100, 3, 8, 30
+    op, actor, sim, st, mem = _setup(N, K, (32, 32), B, {}, ring_capacity=B * T)
+    expert_io = sim.controller().permute(0, 2, 1).contiguous()
+    _collect(actor, sim, st, mem, expert_io, torch.full((B,), 0.6, device='cuda'),
+             torch.arange(B, dtype=torch.int32, device='cuda'), 7, age0=0, T=T)
+    cp = configparser.ConfigParser()
+    cp['DEFAULT'] = dict(n_states='6', n_actions='2', k=str(K), hidden_size='32', gamma='0.99', tau='0.5', n_agents=str(N),
+                         actor_lr='1e-3')
+    cp['t'] = {}
+    U, Bt = 70, 20
+    random.seed(4)
+    ids = [mem.sample_ids(Bt) for _ in range(U)]
+    outs = []
+    for per_graph in (32, 10 ** 6, 0):
+        torch.manual_seed(3)
+        learner = DAGGER('cuda:0', cp['t'])
+        if per_graph:
+            vd.UPDATES_PER_GRAPH = per_graph if per_graph < 10 ** 6 else 32
+            fu = vd.FrameUpdates(learner, mem, Bt, U, True)
+            if per_graph == 10 ** 6:                             # one update per replay
+                fu.idx[:U].copy_(torch.tensor(ids)); fu.cursor.zero_()
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    fu._enqueue()
+                for _ in range(U):
+                    g.replay()
+                losses = fu.loss_hist[:U].clone()
+            else:
+                fu.run(ids)
+                losses = fu.loss_hist[:U].clone()
+                assert learner.actor_optim.step_count == U
+            assert int(fu.cursor.item()) == U and int(learner.actor_optim.step_dev.item()) == U
+        else:                                                    # eager: gather, then the learner's own update
+            X = torch.empty((Bt, K, 6, N), device='cuda'); G = torch.empty((Bt, K, N, N), device='cuda')
+            Y = torch.empty((Bt, 1, 2, N), device='cuda')
+            ls = []
+            for u in range(U):
+                from multiagent_gnn_policies_amd import ops
+                ops.replay_gather(mem, torch.tensor(ids[u], device='cuda'), X, G, Y, True)
+                ls.append(learner.gradient_step_tensors(X, G, Y))
+            losses = torch.tensor(ls, device='cuda')
+        outs.append((losses.cpu().numpy(), learner.actor_optim.flat.clone().cpu().numpy()))
+    vd.UPDATES_PER_GRAPH = 32
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.max(np.abs(outs[0][0] - outs[2][0])) <= 1e-5 and np.max(np.abs(outs[0][1] - outs[2][1])) <= 1e-5
+    assert outs[0][0][-1] < outs[0][0][0]                         # and it learns
