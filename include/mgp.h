@@ -250,7 +250,7 @@ int mgp_rollout_steps_ex(double* x, float* G, float* Xd, const float* const* W, 
                          void* stream);
 /* DAGGER data collection on the same kernel (reference gnn_dagger.py:154-178, batched over B lock-step episodes): every
  * step (i) files the state it starts from as a compact FRAME -- features x_t (6,N) fp32, membership bits of its network
- * A_t (N x 2 u64), the expert's action for it (2,N) fp32 (the label, :174-176), its age (steps since reset) -- into a ring
+ * A_t (N x 2 u64, N x 4 beyond N = 128), the expert's action for it (2,N) fp32 (the label, :174-176), its age (steps since reset) -- into a ring
  * laid out [ring_steps][B], at ring step (ring_step0 + t) % ring_steps; (ii) is driven by the expert with probability
  * beta[b], else by the policy (:157-161), the coin being the counter-based hash dagger_coin(seed, episode[b], age)
  * (csrc/mgp_device.h; oracle/dagger_vec.py) -- no host RNG, no per-step host traffic.  The K-tap training state of a frame is
@@ -258,10 +258,10 @@ int mgp_rollout_steps_ex(double* x, float* G, float* Xd, const float* const* W, 
  * instead of the 128 KB of a dense (delay_state, delay_gso) pair.
  * expert_io (B,2,N): in = expert action of the entry state, out = of the final state (chain launches through it).
  * Requires MGP_RO_ENTER_CARRY | MGP_RO_EXIT_CARRY (collection starts at a reset observation -- all-zero carry -- or continues
- * a collecting launch) and N <= 128. */
+ * a collecting launch).  Bit rows: 2 x u64 per row for N <= 128, 4 beyond (N <= 256). */
 typedef struct MgpCollect {
     float* feat;                 /* [ring_steps][B][6][N] */
-    unsigned long long* bits;    /* [ring_steps][B][N][2] */
+    unsigned long long* bits;    /* [ring_steps][B][N][NW], NW = 2 (N <= 128) or 4 */
     float* label;                /* [ring_steps][B][2][N] */
     int* age;                    /* [ring_steps][B]       */
     float* expert_io;            /* (B,2,N) */

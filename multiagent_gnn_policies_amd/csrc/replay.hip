@@ -19,6 +19,7 @@ constexpr int RG_SPLIT = 16;              // workgroups per operator slice (row 
 // grid (Bt, 1 + (K - 1) * RG_SPLIT): y = 0 copies the delay line, the label and the identity slice of sample x; y >= 1
 // builds rows [part * ceil(N / RG_SPLIT), ...) of slice j = 1 + (y - 1) / RG_SPLIT.  Many small workgroups instead of one per sample: the
 // row products are dependent LDS chains (a 20-sample minibatch took 24 us on 20 workgroups of 1024 threads, 16 us on 180 of 256, 9 us on 660).
+template <int NW>
 __global__ __launch_bounds__(RG_THREADS)
 void replay_gather_kernel(const float* __restrict__ feat, const unsigned long long* __restrict__ bits,
                           const float* __restrict__ label, const int* __restrict__ age, const long* __restrict__ idx,
@@ -27,8 +28,8 @@ void replay_gather_kernel(const float* __restrict__ feat, const unsigned long lo
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     const int H = K > 1 ? K - 1 : 1, Np = (N + 3) & ~3;
-    unsigned long long* sb = reinterpret_cast<unsigned long long*>(smraw);                  // [H][N][2]
-    float* sw = reinterpret_cast<float*>(sb + (size_t)H * N * 2);                           // [H][N]
+    unsigned long long* sb = reinterpret_cast<unsigned long long*>(smraw);                  // [H][N][NW]
+    float* sw = reinterpret_cast<float*>(sb + (size_t)H * N * NW);                           // [H][N]
     float* rball = sw + ((H * N + 3) & ~3);                                                 // [waves][2][Np]
     const int b = blockIdx.x, role = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long cur = cursor != nullptr ? (long)cursor[0] : 0L;
@@ -58,9 +59,14 @@ void replay_gather_kernel(const float* __restrict__ feat, const unsigned long lo
     for (int e = tid; e < j * N; e += RG_THREADS) {
         const int q = e / N, row = e - q * N;
         long rq = r - (long)q * lanes; rq = rq < 0 ? rq + ring : rq;
-        const unsigned long long lo = bits[((size_t)rq * N + row) * 2], hi = bits[((size_t)rq * N + row) * 2 + 1];
-        sb[(size_t)e * 2] = lo; sb[(size_t)e * 2 + 1] = hi;
-        const double deg = (double)(__popcll(lo) + __popcll(hi));
+        int cnt = 0;
+#pragma unroll
+        for (int wd = 0; wd < NW; ++wd) {
+            const unsigned long long w = bits[((size_t)rq * N + row) * NW + wd];
+            sb[(size_t)e * NW + wd] = w;
+            cnt += __popcll(w);
+        }
+        const double deg = (double)cnt;
         sw[e] = (float)(mean_pooling ? 1.0 / (deg == 0.0 ? 1.0 : deg) : 1.0);
     }
     __syncthreads();
@@ -69,15 +75,15 @@ void replay_gather_kernel(const float* __restrict__ feat, const unsigned long lo
         float* r0 = rbuf;
         float* r1 = rbuf + Np;
         const float wi = sw[i];
-        const unsigned long long* rowT = sb + (size_t)i * 2;
+        const unsigned long long* rowT = sb + (size_t)i * NW;
         for (int n = lane; n < N; n += 64) r0[n] = ((rowT[n >> 6] >> (n & 63)) & 1ull) ? wi : 0.f;
         for (int q = 1; q < j; ++q) {
             const float* wq = sw + q * N;
             for (int n = lane; n < N; n += 64) {
-                const unsigned long long* rw = sb + ((size_t)q * N + n) * 2;
+                const unsigned long long* rw = sb + ((size_t)q * N + n) * NW;
                 float sacc = 0.f;
 #pragma unroll
-                for (int wd = 0; wd < 2; ++wd) {
+                for (int wd = 0; wd < NW; ++wd) {
                     unsigned long long w = rw[wd];
                     while (w) { const int m = 64 * wd + __builtin_ctzll(w); w &= w - 1ull; sacc = fmaf(r0[m], wq[m], sacc); }
                 }
@@ -96,15 +102,21 @@ extern "C" int mgp_replay_gather(const float* feat, const unsigned long long* bi
                                  int mean_pooling, float* X, float* G, float* Y, void* stream)
 {
     if (Bt < 0 || lanes < 1 || ring_steps < 1 || K < 1 || K > 5 || N < 4) return MGP_EINVAL;
-    if (N > 128) return MGP_EUNSUPPORTED;
+    if (N > 256) return MGP_EUNSUPPORTED;
     if (Bt == 0) return MGP_OK;
     MGP_CHECK_PTR(feat); MGP_CHECK_PTR8(bits); MGP_CHECK_PTR(label); MGP_CHECK_PTR(age); MGP_CHECK_PTR8(idx);
     MGP_CHECK_PTR(X); MGP_CHECK_PTR(G); MGP_CHECK_PTR(Y);
     if (cursor != nullptr && (reinterpret_cast<uintptr_t>(cursor) & 3u)) return MGP_EALIGN;
-    const int H = K > 1 ? K - 1 : 1, Np = (N + 3) & ~3;
-    const int lds = H * N * 2 * 8 + ((H * N + 3) & ~3) * 4 + RG_WAVES * 2 * Np * 4;
+    const int H = K > 1 ? K - 1 : 1, Np = (N + 3) & ~3, NW = N > 128 ? 4 : 2;      // words per bit row: the collecting kernels' layout
+    const int lds = H * N * NW * 8 + ((H * N + 3) & ~3) * 4 + RG_WAVES * 2 * Np * 4;
     mgp_clear_error();
-    hipLaunchKernelGGL(replay_gather_kernel, dim3(Bt, 1 + (K - 1) * RG_SPLIT), dim3(RG_THREADS), lds, static_cast<hipStream_t>(stream), feat, bits, label,
-                       age, idx, cursor, Bt, lanes, ring_steps, K, N, mean_pooling, X, G, Y);
+    const dim3 grid(Bt, 1 + (K - 1) * RG_SPLIT);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (NW == 2)
+        hipLaunchKernelGGL(replay_gather_kernel<2>, grid, dim3(RG_THREADS), lds, st, feat, bits, label,
+                           age, idx, cursor, Bt, lanes, ring_steps, K, N, mean_pooling, X, G, Y);
+    else
+        hipLaunchKernelGGL(replay_gather_kernel<4>, grid, dim3(RG_THREADS), lds, st, feat, bits, label,
+                           age, idx, cursor, Bt, lanes, ring_steps, K, N, mean_pooling, X, G, Y);
     return mgp_launch_status();
 }

@@ -777,7 +777,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
 // are kept as membership BITS only (four 64-bit words per row; byte lists of three networks would be 125 KB at N = 200)
 // and every consumer -- gather stages, feature pass, exit -- walks bits; rows / gather items / pair offsets are looped
 // over instead of mapped one to a thread; everything is run-time sized.  Phases, barriers and arithmetic are the same.
-struct RbOff { int pos, bits, wrow, uact, xt, vb, act, sxy, mmax, wl; };
+struct RbOff { int pos, bits, wrow, uact, xt, vb, act, sxy, mmax, uexp, wl; };
 constexpr int RB_MAXN = 256;
 constexpr int RB_NW = 4;
 
@@ -795,6 +795,7 @@ __host__ __device__ inline RbOff rb_offsets(int N, int K)
     c.act = ro_take(off, ((N + 15) & ~15) * RO_CS * 4);
     c.sxy = ro_take(off, N * 8);
     c.mmax = ro_take(off, 16);
+    c.uexp = ro_take(off, 2 * N * 4 + 16);                    // expert action of the current state (collection) + velocity sums
     c.wl = off;
     return c;
 }
@@ -813,13 +814,13 @@ __device__ __forceinline__ void rb_gather_word(unsigned long long w, int base, c
     }
 }
 
-template <bool FD>
+template <bool FD, bool CL>
 __global__ __launch_bounds__(RO_THREADS)
 void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __restrict__ Xd, float* __restrict__ action,
                         double* __restrict__ rewards, RoParams P, MgpFlockParams p, int K, int N, int T,
                         unsigned long long dimsA, unsigned int dims8, unsigned long long woffA, unsigned long long woffB,
                         int n_layers, const float* __restrict__ image, int image_floats, unsigned long long* __restrict__ carry,
-                        int flags)
+                        int flags, MgpCollect cl)
 {
     const RbOff cv = rb_offsets(N, K);
     const int H = ro_hist(K);
@@ -836,6 +837,8 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
     float* act = reinterpret_cast<float*>(smraw + cv.act);
     float2* sxy = reinterpret_cast<float2*>(smraw + cv.sxy);
     unsigned int* mmax = reinterpret_cast<unsigned int*>(smraw + cv.mmax);
+    float* uexp = reinterpret_cast<float*>(smraw + cv.uexp);                 // [2][N]
+    double* vtot = reinterpret_cast<double*>(smraw + cv.uexp + ((2 * N * 4 + 7) & ~7));
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Np = (N + 3) & ~3;
@@ -857,6 +860,14 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
         spx[i] = xb[i * 4 + 0]; spy[i] = xb[i * 4 + 1]; svx[i] = xb[i * 4 + 2]; svy[i] = xb[i * 4 + 3];
     }
     if (tid == 0) { cref[0] = xb[0]; cref[1] = xb[1]; mmax[0] = 0u; }
+    unsigned long long coin_thr = 0ull;
+    unsigned int coin_ep = 0u;
+    if (CL) {                                                 // data collection (see rollout_kernel)
+        for (int e = tid; e < 2 * N; e += RO_THREADS) uexp[e] = cl.expert_io[(size_t)b * 2 * N + e];
+        const double bq = floor((double)cl.beta[b] * 4294967296.0);
+        coin_thr = bq <= 0.0 ? 0ull : (bq >= 4294967296.0 ? 4294967296ull : (unsigned long long)bq);
+        coin_ep = cl.episode[b];
+    }
     if (image != nullptr) {                                   // prebuilt weight image (mgp_rollout_image): flat copy
         const float4* src4 = reinterpret_cast<const float4*>(image);
         float4* dst4 = reinterpret_cast<float4*>(wl);
@@ -911,6 +922,20 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
     int cur = 0, hs = 0;
 
     for (int t = 0; t < T; ++t) {
+        if (CL) {
+            // file the state this step starts from: features = tap 0 of the delay line, the bit rows of its network (ring
+            // slot hs, intact until phase A's end), the label phase D3 of the previous step left in uexp, its age.  All of
+            // it was written before the previous step's closing barrier (or at entry): no barrier needed here.
+            const size_t fs = (size_t)((cl.ring_step0 + t) % cl.ring_steps) * gridDim.x + b;
+            float* ff = cl.feat + fs * 6 * N;
+            for (int e = tid; e < 6 * N; e += RO_THREADS) { const int f = e / N, n = e - f * N; ff[e] = XT[((size_t)cur * Np + n) * 8 + f]; }
+            unsigned long long* fb = cl.bits + fs * RB_NW * N;
+            const unsigned long long* cb_ = bits + (size_t)hs * N * RB_NW;
+            for (int i = tid; i < RB_NW * N; i += RO_THREADS) fb[i] = cb_[i];
+            float* fl = cl.label + fs * 2 * N;
+            for (int e = tid; e < 2 * N; e += RO_THREADS) fl[e] = uexp[e];
+            if (tid == 0) cl.age[fs] = cl.age0 + t;
+        }
         const int hsn = (hs + 1 == H) ? 0 : hs + 1;
         unsigned long long* rm_new = bits + (size_t)hsn * N * RB_NW;
         float* w_new = wrow + hsn * N;
@@ -1036,6 +1061,9 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
             if (agent) {
                 const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * 4 * RO_KS);
                 ux += bb.x; uy += bb.y;
+                if (CL && (unsigned long long)dagger_coin(cl.seed, coin_ep, (unsigned int)(cl.age0 + t)) < coin_thr) {
+                    ux = uexp[ccol]; uy = uexp[N + ccol];      // the expert drives this step (gnn_dagger.py:157-158)
+                }
                 uact[ccol] = ux; uact[N + ccol] = uy;
                 const float ub[2] = {ux, uy};
                 integrate_one(px, py, vx, vy, ub, 1, ccol < p.n_leaders, p);
@@ -1051,10 +1079,11 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
         }
         __syncthreads();
         // -------------------------------------------------------------- D1: membership bits, every unordered pair once
-        if (wave == RO_WAVES - 1 && rewards != nullptr) {     // reward: one wave, no workgroup barrier
+        if (wave == RO_WAVES - 1 && (rewards != nullptr || CL)) {     // reward: one wave, no workgroup barrier
             double sx = 0.0, sy = 0.0;
             for (int i = lane; i < N; i += 64) { sx += svx[i]; sy += svy[i]; }
             sx = mgp_wave_sum(sx); sy = mgp_wave_sum(sy);
+            if (CL && lane == 0) { vtot[0] = sx; vtot[1] = sy; }
             const double mx = sx / (double)N, my = sy / (double)N;
             double dv = 0.0;
             for (int i = lane; i < N; i += 64) {
@@ -1062,7 +1091,7 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
                 dv += ex * ex + ey * ey;
             }
             const double var = mgp_wave_sum(dv) / (double)N;
-            if (lane == 0) rewards[(size_t)b * T + t] = -1.0 * var * p.reward_scale;
+            if (lane == 0 && rewards != nullptr) rewards[(size_t)b * T + t] = -1.0 * var * p.reward_scale;
         }
         {
             const float M = __uint_as_float(mmax[0]);
@@ -1150,6 +1179,12 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
                 const double deg = (double)cnt;
                 const double w = p.mean_pooling ? 1.0 / (deg == 0.0 ? 1.0 : deg) : 1.0;
                 w_new[fr] = (float)w;
+                if (CL) {                                      // expert action of the NEW state (see rollout_kernel)
+                    double tvx = f0, tvy = f3;
+                    if (p.centralized) { tvx = (double)N * svx[fr] - vtot[0]; tvy = (double)N * svy[fr] - vtot[1]; }
+                    uexp[fr] = (float)(clipd(-tvx - (2.0 * f2 - 2.0 * f1), -p.ctrl_clip, p.ctrl_clip) * p.ctrl_gain);
+                    uexp[N + fr] = (float)(clipd(-tvy - (2.0 * f5 - 2.0 * f4), -p.ctrl_clip, p.ctrl_clip) * p.ctrl_gain);
+                }
                 float* xn = XT + ((size_t)(cur + 1 == K ? 0 : cur + 1) * Np + fr) * 8;
                 *reinterpret_cast<float4*>(xn) = make_float4((float)f0, (float)f1, (float)f2, (float)f3);
                 *reinterpret_cast<float4*>(xn + 4) = make_float4((float)f4, (float)f5, 0.f, 0.f);
@@ -1235,6 +1270,8 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
     }
     if (action != nullptr)
         for (int e = tid; e < 2 * N; e += RO_THREADS) action[(size_t)b * 2 * N + e] = uact[e];
+    if (CL)
+        for (int e = tid; e < 2 * N; e += RO_THREADS) cl.expert_io[(size_t)b * 2 * N + e] = uexp[e];
 }
 
 // coverage check + weight image plan; returns false when the shape is outside the kernel's coverage
@@ -1330,17 +1367,18 @@ int launch_rollout(double* x, float* G, float* Xd, float* action, double* reward
     return mgp_launch_status();
 }
 
-template <bool FD>
+template <bool FD, bool CL>
 int launch_rollout_big(double* x, float* G, float* Xd, float* action, double* rewards, const RoParams& P,
                        const MgpFlockParams* p, int B, int K, int N, int T, unsigned long long dimsA, unsigned int dims8,
                        unsigned long long woffA, unsigned long long woffB, int n_layers, int lds, hipStream_t st,
-                       const float* image, int image_floats, unsigned long long* carry, int flags)
+                       const float* image, int image_floats, unsigned long long* carry, int flags, const MgpCollect* cl)
 {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_big_kernel<FD>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_big_kernel<FD, CL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MGP_ELAUNCH;
-    hipLaunchKernelGGL((rollout_big_kernel<FD>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K, N, T,
-                       dimsA, dims8, woffA, woffB, n_layers, image, image_floats, carry, flags);
+    MgpCollect none = {};
+    hipLaunchKernelGGL((rollout_big_kernel<FD, CL>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K, N, T,
+                       dimsA, dims8, woffA, woffB, n_layers, image, image_floats, carry, flags, cl ? *cl : none);
     return mgp_launch_status();
 }
 
@@ -1446,7 +1484,6 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
     if (cl != nullptr) {
         // data collection starts at a reset observation (all-zero carry) or continues a collecting launch: the frame of the
         // launch's first state takes its network bits from the carry
-        if (N > RO_MAXN) return MGP_EUNSUPPORTED;
         if (!(flags & MGP_RO_ENTER_CARRY) || !(flags & MGP_RO_EXIT_CARRY)) return MGP_EINVAL;
         if (cl->ring_steps < 1 || cl->ring_step0 < 0 || cl->age0 < 0) return MGP_EINVAL;
         MGP_CHECK_PTR(cl->feat); MGP_CHECK_PTR8(cl->bits); MGP_CHECK_PTR(cl->label); MGP_CHECK_PTR(cl->age);
@@ -1489,9 +1526,12 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int wt = P.wtot;
     const bool fade = p->link_drop != 0u;   // FlockingStochastic-v0: the generic builds carry the fade hash, the others do not
-    if (N > RO_MAXN)
-        return fade ? launch_rollout_big<true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags)
-                    : launch_rollout_big<false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags);
+#define RB_LAUNCH(FD_, CL_) launch_rollout_big<FD_, CL_>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags, cl)
+    if (N > RO_MAXN) {
+        if (cl != nullptr) return fade ? RB_LAUNCH(true, true) : RB_LAUNCH(false, true);
+        return fade ? RB_LAUNCH(true, false) : RB_LAUNCH(false, false);
+    }
+#undef RB_LAUNCH
 #define RO_LAUNCH(CN_, CK_, FD_, CL_) launch_rollout<CN_, CK_, FD_, CL_>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags, cl)
     if (cl != nullptr) {               // the data-collection builds (DAGGER rollouts)
 #ifndef MGP_RO_WIDE

@@ -195,8 +195,9 @@ class FrameReplay(object):
         self.window_steps = max(1, (capacity + lanes - 1) // lanes)          # sampled window, in lock-step env steps
         self.ring_steps = self.window_steps + max(K - 1, 0)                  # + history guard
         S = self.ring_steps
+        self.nw = 2 if N <= 128 else 4                                       # 64-bit words per membership row
         self.feat = torch.zeros((S, lanes, 6, N), device=device, dtype=torch.float32)
-        self.bits = torch.zeros((S, lanes, N, 2), device=device, dtype=torch.int64)
+        self.bits = torch.zeros((S, lanes, N, self.nw), device=device, dtype=torch.int64)
         self.label = torch.zeros((S, lanes, 2, N), device=device, dtype=torch.float32)
         self.age = torch.zeros((S, lanes), device=device, dtype=torch.int32)
         self.head = 0                 # ring step the next collected env step is filed at
@@ -212,7 +213,7 @@ class FrameReplay(object):
         return min(self.steps_written, self.window_steps) * self.lanes
 
     def bytes_per_transition(self):
-        return (6 * self.N + 2 * self.N) * 4 + self.N * 16 + 4
+        return (6 * self.N + 2 * self.N) * 4 + self.N * 8 * self.nw + 4
 
     def advance(self, T):
         """The collecting launch filed T env steps starting at ring step `head`."""
@@ -338,10 +339,10 @@ def evaluate(learner, sim, state, n_episodes, steps):
 
 
 def collect_supported(learner, K, N):
-    """The collecting build of the episode-resident kernel covers the shape (mgp_rollout_collect: N <= 128, 6 features,
+    """The collecting builds of the episode-resident kernels cover the shape (mgp_rollout_collect: N <= 256, 6 features,
     2-D actions, aggregation in front of the first layer, widths <= 64)."""
     from .. import ops
-    return (learner.actor.ind_agg == 0 and learner.n_states == 6 and N <= 128
+    return (learner.actor.ind_agg == 0 and learner.n_states == 6 and N <= 256
             and ops.rollout_supported(tuple(learner.actor.layers), K, N))
 
 
@@ -379,8 +380,8 @@ def collect_round(learner, sim, state, memory, beta, episode_ids, seed, T, chunk
 def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
     """Returns {'mean','std'} like train_dagger.  `n_envs` parallel episodes per rank.
 
-    Where the collecting build of the episode-resident kernel covers the shape (N <= 128: every N of the reference's
-    sweeps up to 125) a round is ONE launch per GPU for the rollouts of all lanes -- no host RNG, no host<->device traffic
+    Where the collecting builds of the episode-resident kernels cover the shape (N <= 256: every N of the reference's
+    sweeps) a round is ONE launch per GPU for the rollouts of all lanes -- no host RNG, no host<->device traffic
     per step -- into a compact frame replay, and one HIP-graph replay per update.  Other shapes step the two-launch path from
     the host and keep dense states in the replay (the round-1 loop)."""
     device = torch.device(device)

@@ -297,14 +297,14 @@ def rollout_collect(x, G, Xd, dims, params, T, frames, expert_io, beta, episode,
     """T DAGGER data-collection steps in ONE launch (mgp_rollout_collect): every step files its starting state as a compact
     frame into `frames` (a FrameReplay-like object with .feat/.bits/.label/.age rings laid out [ring_steps][B]) and is driven
     by the expert with probability beta[b] (counter-based coin), else by the policy.  Returns False if the shape is not
-    covered (N > 128 or outside mgp_rollout_supported)."""
+    covered (outside mgp_rollout_supported)."""
     _dev(x, 'x', torch.float64); _dev(G, 'G'); _dev(Xd, 'Xd'); _dev(expert_io, 'expert_io'); _dev(beta, 'beta')
     B, N, _ = x.shape
     K = G.shape[1]
     assert G.is_contiguous() and Xd.is_contiguous() and x.is_contiguous() and expert_io.is_contiguous()
     assert expert_io.shape == (B, 2, N) and beta.shape == (B,) and episode.shape == (B,) and episode.dtype == torch.int32
     S = frames.ring_steps
-    assert frames.feat.shape == (S, B, 6, N) and frames.bits.shape == (S, B, N, 2) and frames.label.shape == (S, B, 2, N)
+    assert frames.feat.shape == (S, B, 6, N) and frames.bits.shape == (S, B, N, 2 if N <= 128 else 4) and frames.label.shape == (S, B, 2, N)
     assert frames.age.shape == (S, B) and frames.age.dtype == torch.int32 and frames.bits.dtype == torch.int64
     if rewards is not None:
         assert rewards.shape == (B, T) and rewards.dtype == torch.float64 and rewards.is_contiguous()
