@@ -205,9 +205,10 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             const int cin = (l == 0) ? FK : P.dims[l];
             const int cout = P.dims[l + 1];
             const bool last = l == P.n_layers - 1;
-            const int tot = ro_weight_image_size(cout, last);
+            const int tot = last ? ro_weight_image_size(cout, true) : ro_chain_image_size(cout, false);
             float* dst = wl + P.woff[l];
-            for (int e = tid; e < tot; e += RO_THREADS) dst[e] = ro_weight_image_elem(P.W[l], P.b[l], cin, cout, last, e);
+            for (int e = tid; e < tot; e += RO_THREADS)
+                dst[e] = last ? ro_weight_image_elem(P.W[l], P.b[l], cin, cout, true, e) : ro_chain_image_elem(P.W[l], P.b[l], cin, cout, l, false, e);
         }
     }
     {
@@ -421,33 +422,63 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 RO_STAMP(6);
             }
             const int col = wave * 16 + li;
-            float* pcol = act + col * RO_CS;
+            // hidden layers on MFMA, activations chained through registers (rollout_common.h): only the first layer reads its B
+            // operand (the aggregation result) from LDS, only the last one stores its activations there (for the output layer)
+            float zc[RO_MAXMT][4];
+#pragma unroll
+            for (int a_ = 0; a_ < RO_MAXMT; ++a_)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) zc[a_][rr] = 0.f;
+            int mtp = 0;
             for (int l = 0; l < n_layers - 1; ++l) {
-                const int cin = (l == 0) ? FK : ro_dim(dimsA, dims8, l);
                 const int cout = ro_dim(dimsA, dims8, l + 1);
                 const int MT = mtiles(cout);
                 const float* wfrag = wl + (int)((((l < 4) ? woffA : woffB) >> (16 * (l & 3))) & 0xFFFFull);
-                if (MT == 4) ro_mlp_cols<4>(pcol, wfrag + lane * RO_WFS, wfrag + 4 * 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
-                else if (MT == 2) ro_mlp_cols<2>(pcol, wfrag + lane * RO_WFS, wfrag + 2 * 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
-                else ro_mlp_cols<1>(pcol, wfrag + lane * RO_WFS, wfrag + 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
+                float fb[RO_KS];
+                int ksteps;
+                if (l == 0) {
+                    const float4* pb = reinterpret_cast<const float4*>(act + col * RO_CS + lq * RO_KS);
+#pragma unroll
+                    for (int i = 0; i < RO_KS / 4; ++i) { const float4 tq = pb[i]; fb[4 * i] = tq.x; fb[4 * i + 1] = tq.y; fb[4 * i + 2] = tq.z; fb[4 * i + 3] = tq.w; }
+                    ksteps = pad4(FK) / 4;
+                } else {
+#pragma unroll
+                    for (int s_ = 0; s_ < RO_KS; ++s_) fb[s_] = zc[s_ >> 2][s_ & 3];
+                    ksteps = 4 * mtp;
+                }
+                const float* pw = wfrag + lane * RO_WFS;
+                const float* pbias = wfrag + MT * 64 * RO_WFS + lq * 4;
+                if (MT == 4) ro_layer_regs<(RO_MAXMT >= 4 ? 4 : 1), true>(fb, pw, pbias, ksteps, zc);
+                else if (MT == 2) ro_layer_regs<2, true>(fb, pw, pbias, ksteps, zc);
+                else ro_layer_regs<1, true>(fb, pw, pbias, ksteps, zc);
+                mtp = MT;
                 RO_STAMP(12 + l);
             }
+            if (n_layers > 1) {                               // last hidden layer -> LDS, channel c at slot rpos(c)
+                float* pcol = act + col * RO_CS;
+#pragma unroll
+                for (int a_ = 0; a_ < RO_MAXMT; ++a_)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+                        if (a_ < mtp) pcol[rr * RO_KS + a_ * 4 + lq] = zc[a_][rr];
+            }
             // ---------------------------------------------------------- C: output layer (VALU) + integrate, same wave
-            // The 2-wide output layer is a packed-FMA chain (a 16-row MFMA tile would be 7/8 padding).  For this part the
-            // lanes are regrouped: lane L takes agent column L >> 2 of the wave's tile and the 8 channels c = 4 s + (L & 3)
-            // (contiguous in the B-fragment layout), so the four partial sums of a column sit in one quad and are added by
-            // DPP.  The first lane of the quad then integrates the agent (spec section 1, fp64: bit-exact given the action)
-            // and publishes its fp32 coordinates for D1.  No workgroup barrier since the hidden layers: the wave only
-            // reads activations it wrote itself (LDS operations of one wave are ordered).
+            // The 2-wide output layer is a packed-FMA chain (as one zero-padded MFMA m-tile fed from the registers it measured
+            // 1.5k cycles against 0.85k: eight dependent MFMAs on one accumulator).  For this part the lanes are regrouped:
+            // lane L takes agent column L >> 2 of the wave's tile and the 8 channels c = 4 s + (L & 3) (contiguous in the
+            // B-fragment layout), so the four partial sums of a column sit in one quad and are added by DPP.  The first lane of
+            // the quad then integrates the agent (spec section 1, fp64: bit-exact given the action) and publishes its fp32
+            // coordinates for D1.  No workgroup barrier since the hidden layers: the wave only reads activations it wrote
+            // itself (LDS operations of one wave are ordered).
             const int lo_ = n_layers - 1;
             const float* w2 = wl + (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull);
             const int ccol = wave * 16 + (lane >> 2), cg = lane & 3;
             const float* zsrc = act + ccol * RO_CS + cg * RO_KS;
-            float zc[RO_KS];
+            float zo[RO_KS];
 #pragma unroll
             for (int i = 0; i < RO_KS / 4; ++i) {
                 const float4 zq = *reinterpret_cast<const float4*>(zsrc + 4 * i);
-                zc[4 * i] = zq.x; zc[4 * i + 1] = zq.y; zc[4 * i + 2] = zq.z; zc[4 * i + 3] = zq.w;
+                zo[4 * i] = zq.x; zo[4 * i + 1] = zq.y; zo[4 * i + 2] = zq.z; zo[4 * i + 3] = zq.w;
             }
             double px = 0.0, py = 0.0, vx = 0.0, vy = 0.0, cx = 0.0, cy = 0.0;
             const bool agent = (cg == 0) && ccol < N;
@@ -457,8 +488,8 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             for (int s_ = 0; s_ < RO_KS; s_ += 2) {           // channel c = 4 s + cg: weights (W[0][c], W[1][c]) at w2[2 c]
                 const float2 wa = *reinterpret_cast<const float2*>(w2 + 2 * (4 * s_ + cg));
                 const float2 wb = *reinterpret_cast<const float2*>(w2 + 2 * (4 * (s_ + 1) + cg));
-                u2 = __builtin_elementwise_fma((f32x2){zc[s_], zc[s_]}, (f32x2){wa.x, wa.y}, u2);
-                u2b = __builtin_elementwise_fma((f32x2){zc[s_ + 1], zc[s_ + 1]}, (f32x2){wb.x, wb.y}, u2b);
+                u2 = __builtin_elementwise_fma((f32x2){zo[s_], zo[s_]}, (f32x2){wa.x, wa.y}, u2);
+                u2b = __builtin_elementwise_fma((f32x2){zo[s_ + 1], zo[s_ + 1]}, (f32x2){wb.x, wb.y}, u2b);
             }
             u2 = u2 + u2b;
             float ux = u2.x, uy = u2.y;
@@ -877,9 +908,10 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
             const int cin = (l == 0) ? FK : P.dims[l];
             const int cout = P.dims[l + 1];
             const bool last = l == P.n_layers - 1;
-            const int tot = ro_weight_image_size(cout, last);
+            const int tot = last ? ro_weight_image_size(cout, true) : ro_chain_image_size(cout, false);
             float* dst = wl + P.woff[l];
-            for (int e = tid; e < tot; e += RO_THREADS) dst[e] = ro_weight_image_elem(P.W[l], P.b[l], cin, cout, last, e);
+            for (int e = tid; e < tot; e += RO_THREADS)
+                dst[e] = last ? ro_weight_image_elem(P.W[l], P.b[l], cin, cout, true, e) : ro_chain_image_elem(P.W[l], P.b[l], cin, cout, l, false, e);
         }
     }
     // factored hand-over of the history networks (see rollout_kernel): carry slot q -> ring slot (H - q) % H, hs = 0
@@ -1013,33 +1045,63 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
         // the kernel-argument segment every layer of every step (~700 cycles each).
         if (wave < NT) {                                      // wave w owns columns 16 w .. 16 w + 15 through every layer
             const int col = wave * 16 + li;
-            float* pcol = act + col * RO_CS;
+            // hidden layers on MFMA, activations chained through registers (rollout_common.h): only the first layer reads its B
+            // operand (the aggregation result) from LDS, only the last one stores its activations there (for the output layer)
+            float zc[RO_MAXMT][4];
+#pragma unroll
+            for (int a_ = 0; a_ < RO_MAXMT; ++a_)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) zc[a_][rr] = 0.f;
+            int mtp = 0;
             for (int l = 0; l < n_layers - 1; ++l) {
-                const int cin = (l == 0) ? FK : ro_dim(dimsA, dims8, l);
                 const int cout = ro_dim(dimsA, dims8, l + 1);
                 const int MT = mtiles(cout);
                 const float* wfrag = wl + (int)((((l < 4) ? woffA : woffB) >> (16 * (l & 3))) & 0xFFFFull);
-                if (MT == 4) ro_mlp_cols<4>(pcol, wfrag + lane * RO_WFS, wfrag + 4 * 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
-                else if (MT == 2) ro_mlp_cols<2>(pcol, wfrag + lane * RO_WFS, wfrag + 2 * 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
-                else ro_mlp_cols<1>(pcol, wfrag + lane * RO_WFS, wfrag + 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
+                float fb[RO_KS];
+                int ksteps;
+                if (l == 0) {
+                    const float4* pb = reinterpret_cast<const float4*>(act + col * RO_CS + lq * RO_KS);
+#pragma unroll
+                    for (int i = 0; i < RO_KS / 4; ++i) { const float4 tq = pb[i]; fb[4 * i] = tq.x; fb[4 * i + 1] = tq.y; fb[4 * i + 2] = tq.z; fb[4 * i + 3] = tq.w; }
+                    ksteps = pad4(FK) / 4;
+                } else {
+#pragma unroll
+                    for (int s_ = 0; s_ < RO_KS; ++s_) fb[s_] = zc[s_ >> 2][s_ & 3];
+                    ksteps = 4 * mtp;
+                }
+                const float* pw = wfrag + lane * RO_WFS;
+                const float* pbias = wfrag + MT * 64 * RO_WFS + lq * 4;
+                if (MT == 4) ro_layer_regs<(RO_MAXMT >= 4 ? 4 : 1), true>(fb, pw, pbias, ksteps, zc);
+                else if (MT == 2) ro_layer_regs<2, true>(fb, pw, pbias, ksteps, zc);
+                else ro_layer_regs<1, true>(fb, pw, pbias, ksteps, zc);
+                mtp = MT;
                 RO_STAMP(12 + l);
             }
+            if (n_layers > 1) {                               // last hidden layer -> LDS, channel c at slot rpos(c)
+                float* pcol = act + col * RO_CS;
+#pragma unroll
+                for (int a_ = 0; a_ < RO_MAXMT; ++a_)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+                        if (a_ < mtp) pcol[rr * RO_KS + a_ * 4 + lq] = zc[a_][rr];
+            }
             // ---------------------------------------------------------- C: output layer (VALU) + integrate, same wave
-            // The 2-wide output layer is a packed-FMA chain (a 16-row MFMA tile would be 7/8 padding).  For this part the
-            // lanes are regrouped: lane L takes agent column L >> 2 of the wave's tile and the 8 channels c = 4 s + (L & 3)
-            // (contiguous in the B-fragment layout), so the four partial sums of a column sit in one quad and are added by
-            // DPP.  The first lane of the quad then integrates the agent (spec section 1, fp64: bit-exact given the action)
-            // and publishes its fp32 coordinates for D1.  No workgroup barrier since the hidden layers: the wave only
-            // reads activations it wrote itself (LDS operations of one wave are ordered).
+            // The 2-wide output layer is a packed-FMA chain (as one zero-padded MFMA m-tile fed from the registers it measured
+            // 1.5k cycles against 0.85k: eight dependent MFMAs on one accumulator).  For this part the lanes are regrouped:
+            // lane L takes agent column L >> 2 of the wave's tile and the 8 channels c = 4 s + (L & 3) (contiguous in the
+            // B-fragment layout), so the four partial sums of a column sit in one quad and are added by DPP.  The first lane of
+            // the quad then integrates the agent (spec section 1, fp64: bit-exact given the action) and publishes its fp32
+            // coordinates for D1.  No workgroup barrier since the hidden layers: the wave only reads activations it wrote
+            // itself (LDS operations of one wave are ordered).
             const int lo_ = n_layers - 1;
             const float* w2 = wl + (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull);
             const int ccol = wave * 16 + (lane >> 2), cg = lane & 3;
             const float* zsrc = act + ccol * RO_CS + cg * RO_KS;
-            float zc[RO_KS];
+            float zo[RO_KS];
 #pragma unroll
             for (int i = 0; i < RO_KS / 4; ++i) {
                 const float4 zq = *reinterpret_cast<const float4*>(zsrc + 4 * i);
-                zc[4 * i] = zq.x; zc[4 * i + 1] = zq.y; zc[4 * i + 2] = zq.z; zc[4 * i + 3] = zq.w;
+                zo[4 * i] = zq.x; zo[4 * i + 1] = zq.y; zo[4 * i + 2] = zq.z; zo[4 * i + 3] = zq.w;
             }
             double px = 0.0, py = 0.0, vx = 0.0, vy = 0.0, cx = 0.0, cy = 0.0;
             const bool agent = (cg == 0) && ccol < N;
@@ -1049,8 +1111,8 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
             for (int s_ = 0; s_ < RO_KS; s_ += 2) {           // channel c = 4 s + cg: weights (W[0][c], W[1][c]) at w2[2 c]
                 const float2 wa = *reinterpret_cast<const float2*>(w2 + 2 * (4 * s_ + cg));
                 const float2 wb = *reinterpret_cast<const float2*>(w2 + 2 * (4 * (s_ + 1) + cg));
-                u2 = __builtin_elementwise_fma((f32x2){zc[s_], zc[s_]}, (f32x2){wa.x, wa.y}, u2);
-                u2b = __builtin_elementwise_fma((f32x2){zc[s_ + 1], zc[s_ + 1]}, (f32x2){wb.x, wb.y}, u2b);
+                u2 = __builtin_elementwise_fma((f32x2){zo[s_], zo[s_]}, (f32x2){wa.x, wa.y}, u2);
+                u2b = __builtin_elementwise_fma((f32x2){zo[s_ + 1], zo[s_ + 1]}, (f32x2){wb.x, wb.y}, u2b);
             }
             u2 = u2 + u2b;
             float ux = u2.x, uy = u2.y;
@@ -1345,10 +1407,11 @@ __global__ void rollout_image_kernel(RoParams P, int K, float* __restrict__ imag
     for (int l = 0; l < P.n_layers; ++l) {
         const int cin = (l == 0) ? 6 * K : P.dims[l], cout = P.dims[l + 1];
         const bool last = l == P.n_layers - 1;
-        const int tot = ro_weight_image_size(cout, last);
+        const int tot = last ? ro_weight_image_size(cout, true) : ro_chain_image_size(cout, false);
         const int span = (l + 1 < P.n_layers ? P.woff[l + 1] : P.wtot) - P.woff[l];
         for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < span; e += gridDim.x * blockDim.x)
-            image[P.woff[l] + e] = (e < tot) ? ro_weight_image_elem(P.W[l], P.b[l], cin, cout, last, e) : 0.f;
+            image[P.woff[l] + e] = (e >= tot) ? 0.f : (last ? ro_weight_image_elem(P.W[l], P.b[l], cin, cout, true, e)
+                                                             : ro_chain_image_elem(P.W[l], P.b[l], cin, cout, l, false, e));
     }
 }
 

@@ -65,6 +65,69 @@ __device__ __forceinline__ void ro_mlp_cols(float* pcol, const float* pw, const 
     }
 }
 
+// ---- register-chained MLP (the episode-resident rollout kernels).  Layer l's 16x16 accumulator tile leaves lane (li, lq)
+// holding rows 16 mt + 4 lq + rr (rr = 0..3) of column li -- which IS a valid B operand layout for layer l + 1 if its K index
+// is enumerated as k-step s = 4 mt + rr, k-lane lq  <->  channel 16 mt + 4 lq + rr.  The weight image of every layer after the
+// first stores its A fragments in that order (ro_chain_image_elem), so activations go from one layer's tanh straight into
+// the next layer's MFMAs: no LDS round trip between layers, and the 2-wide output layer runs as one zero-padded m-tile on the
+// same operands (rows 0, 1 of lanes lq == 0) instead of a separate VALU pass over LDS.
+constexpr int RO_MAXMT = RO_KS / 4;                            // m-tiles of the widest layer (2: widths <= 32, 4: <= 64)
+
+template <int MT, bool TANH>
+__device__ __forceinline__ void ro_layer_regs(const float (&fb)[RO_KS], const float* pw, const float* pbias, int ksteps,
+                                              float (&zn)[RO_MAXMT][4])
+{
+    constexpr int CH = MT > 2 ? 2 : MT;                       // m-tiles in flight: two chains hide the MFMA latency, four spill
+#pragma unroll
+    for (int h = 0; h < MT; h += CH) {
+        float fa[CH][RO_KS];
+        f32x4 acc[CH];
+#pragma unroll
+        for (int mt = 0; mt < CH; ++mt) {
+            const float4* pa = reinterpret_cast<const float4*>(pw + (h + mt) * 64 * RO_WFS);
+#pragma unroll
+            for (int i = 0; i < RO_KS / 4; ++i) { const float4 u = pa[i]; fa[mt][4 * i] = u.x; fa[mt][4 * i + 1] = u.y; fa[mt][4 * i + 2] = u.z; fa[mt][4 * i + 3] = u.w; }
+            const float4 bv = *reinterpret_cast<const float4*>(pbias + (h + mt) * 16);
+            acc[mt][0] = bv.x; acc[mt][1] = bv.y; acc[mt][2] = bv.z; acc[mt][3] = bv.w;
+        }
+#pragma unroll
+        for (int sg = 0; sg < RO_KS / 2; ++sg) {
+            if (2 * sg < ksteps) {
+#pragma unroll
+                for (int s_ = 2 * sg; s_ < 2 * sg + 2; ++s_)
+#pragma unroll
+                    for (int mt = 0; mt < CH; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt][s_], fb[s_], acc[mt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < CH; ++mt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) zn[h + mt][rr] = TANH ? tanh_fast(acc[mt][rr]) : acc[mt][rr];
+    }
+}
+
+// element e of layer `layer`'s block in the chained weight image: A fragments [MT][64][RO_WFS] (lane = lq * 16 + (o & 15), slot
+// s) + bias [MT * 16]; channel of (slot s, k-lane lq): 4 s + lq for the first layer (its B operand comes from the aggregation's
+// LDS tile), 16 (s >> 2) + 4 lq + (s & 3) for the others (B operand = the previous layer's accumulator registers).  The output
+// layer is one m-tile padded with zero rows.
+__device__ __forceinline__ float ro_chain_image_elem(const float* __restrict__ src, const float* __restrict__ bias, int cin,
+                                                     int cout, int layer, bool last, int e)
+{
+    const int MT = last ? 1 : mtiles(cout), tot = MT * 64 * RO_WFS;
+    if (e >= tot) { const int o = e - tot; return (o < cout) ? bias[o] : 0.f; }
+    const int mt = e / (64 * RO_WFS), r1 = e - mt * (64 * RO_WFS);
+    const int ln = r1 / RO_WFS, sl = r1 - ln * RO_WFS;
+    const int lqq = ln >> 4, o = mt * 16 + (ln & 15);
+    const int c = (layer == 0) ? 4 * sl + lqq : 16 * (sl >> 2) + 4 * lqq + (sl & 3);
+    return (sl < RO_KS && o < cout && c < cin) ? src[(size_t)o * cin + c] : 0.f;
+}
+__host__ __device__ inline int ro_chain_image_size(int cout, bool last)
+{
+    const int MT = last ? 1 : mtiles(cout);
+    return MT * 64 * RO_WFS + MT * 16;
+}
+
 __device__ __forceinline__ int ro_dim(unsigned long long dimsA, unsigned int dims8, int l)
 {
     return (l < 8) ? (int)((dimsA >> (8 * l)) & 255ull) : (int)dims8;
