@@ -39,7 +39,7 @@ python tools/rocpd_stats.py $T > $O/bench_kernel_trace.txt 2>&1
 RO_CARRY=1 ./scratch/ro_prof 256 100 3 200 > $O/rollout_phase_stamps.txt 2>&1
 python tools/dump_rollout_state.py /tmp/ro_state5.bin 5 > /dev/null 2>&1
 RO_STATE=/tmp/ro_state5.bin RO_CARRY=1 ./scratch/ro_prof 256 100 3 20 20 >> $O/rollout_phase_stamps.txt 2>&1
-for T in 1 2 5 20 200; do ./scratch/ro_prof 256 100 3 $T 20 | head -1; RO_CARRY=1 ./scratch/ro_prof 256 100 3 $T 20 | head -1; done > $O/rollout_launch_cost.txt 2>&1
+for T in 1 2 5 20 200; do ./scratch/ro_prof 256 100 3 $T 20 | head -1; RO_CARRY=1 ./scratch/ro_prof 256 100 3 $T 20 | head -1; done 2>/dev/null > $O/rollout_launch_cost.txt
 # 4. DAGGER update / collection + other configs
 python tools/bench_update.py > $O/dagger_update.json 2> $O/dagger_update.err
 for cfg in "64 1000 3" "256 200 4" "1 100 3" "2048 100 3" "256 100 4" "256 100 2" "256 125 3" "256 50 2"; do set -- $cfg; python bench.py --episodes $1 --agents $2 --taps $3 --no-cpu-baseline --steps 100 --warmup 10 2>/dev/null | python -c "
