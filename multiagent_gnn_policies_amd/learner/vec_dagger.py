@@ -201,6 +201,7 @@ class FrameReplay(object):
         self.label = torch.zeros((S, lanes, 2, N), device=device, dtype=torch.float32)
         self.age = torch.zeros((S, lanes), device=device, dtype=torch.int32)
         self.head = 0                 # ring step the next collected env step is filed at
+        self._table_key, self._table = None, None
         self.steps_written = 0
         self.device = device
 
@@ -228,8 +229,17 @@ class FrameReplay(object):
         return step * self.lanes + position % self.lanes
 
     def sample_ids(self, num_samples):
-        """Frame indices of a minibatch: without replacement, Python `random` RNG (reference replay_buffer.py:40)."""
-        return [self.frame_of(i) for i in random.sample(range(self.curr_size), num_samples)]
+        """Frame indices of a minibatch: without replacement, Python `random` RNG (reference replay_buffer.py:40).  The
+        position -> frame table is rebuilt only when the ring moved (once per collection round): this runs once per update
+        on the host while the GPU replays the previous updates."""
+        key = (self.head, self.steps_written)
+        if self._table_key != key:
+            n_valid = min(self.steps_written, self.window_steps)
+            steps = (self.head - n_valid + np.arange(n_valid)) % self.ring_steps
+            self._table = (steps[:, None] * self.lanes + np.arange(self.lanes)[None, :]).reshape(-1).tolist()
+            self._table_key = key
+        tbl = self._table
+        return [tbl[i] for i in random.sample(range(len(tbl)), num_samples)]
 
     def sample(self, num_samples, out, mean_pooling=True):
         """Gather one minibatch into `out` = (X, G, Y) (the eager / data-parallel update path: one small H2D per update)."""
