@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MGP_VERSION 100            /* 0.1.0 */
+#define MGP_VERSION 200            /* 0.2.0: + mgp_rollout_steps_ex / _image / _carry_*, mgp_rollout_collect, mgp_replay_gather */
 
 #define MGP_OK            0
 #define MGP_EINVAL       -1        /* bad size / null pointer / unsupported combination */
