@@ -429,7 +429,6 @@ def dagger_update_bench():
     gpu_ms_pipe = 1e3 * (time.perf_counter() - t0) / n
     # vectorised DAGGER's round of updates: minibatches gathered from a device replay inside the kernel, index table
     # uploaded once, one graph replay per update (sampling on the host included: random.sample per update)
-    import random
     from multiagent_gnn_policies_amd.learner.vec_dagger import DeviceReplay, IndexedUpdates
     cap, U = 4096, 2000
     rb = DeviceReplay(cap, K, F_FEAT, N, N_ACT, dev)
