@@ -661,23 +661,28 @@ def main():
         res, n_sets = kernel_rooflines(device, B, N, K, ro.actor, ro.sim._c)
         fused = getattr(ro.actor, 'use_fused', False) and ro.actor.ind_agg == 0
 
-        def hbm_block(key, kname, pmc_name):
+        def hbm_block(key, kname, pmc_names):
             r = res[key]
-            tr, tr_note = pmc_traffic(pmc_name, B, N, K) if pmc_name else (None, 'not profiled')
+            tr, tr_note, sq = None, 'not profiled', None
+            for pmc_name in pmc_names:                       # the variant the library picked for this shape comes first
+                tr, tr_note = pmc_traffic(pmc_name, B, N, K)
+                sq = pmc_sq(pmc_name)
+                if tr is not None:
+                    break
             return {"kernel": kname, "bound": "hbm", "achieved": r['gbs'], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": r['gbs'] / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_note,
-                    "algorithmic_bytes_per_launch": r['bytes'], "avg_launch_ms": r['ms'],
-                    "sq": pmc_sq(pmc_name) if pmc_name else None}
+                    "algorithmic_bytes_per_launch": r['bytes'], "avg_launch_ms": r['ms'], "sq": sq}
         # HBM-roofline figures of the kernels that stream the dense operator G (B,K,N,N) from HBM on every launch --
         # north_star's "fraction of HBM roofline for the S^k X aggregation" -- measured live with HIP events on the
         # launch stream over rotating input sets larger than the Infinity Cache; algorithmic bytes per SURVEY.md 8(d)
         dense = {
-            "actor_fwd": hbm_block('actor_fwd', "actor_fwd_kernel (aggregation X.G + MFMA filter/MLP, fused): "
-                                   "4KN^2 + 4KFN + 4 nA N bytes per episode", 'actor_fwd_kernel'),
+            "actor_fwd": hbm_block('actor_fwd', "mgp_actor_fwd: actor_fwd_mfma_kernel for N <= 128 (aggregation X.G AND filter/"
+                                   "MLP on fp32 MFMA, fused), actor_fwd_kernel otherwise: 4KN^2 + 4KFN + 4 nA N bytes per "
+                                   "episode", ('actor_fwd_mfma_kernel', 'actor_fwd_kernel')),
             "agg_fwd": hbm_block('agg_fwd', "agg_fwd_kernel (aggregation X.G alone): 4KN^2 + 8KFN bytes per episode",
-                                 'agg_fwd_kernel'),
+                                 ('agg_fwd_kernel',)),
             "sim_state_step": hbm_block('sim_state_step', "flock_step_kernel<advance> (sim step + delayed-GSO / delay-line "
-                                        "transition, fused)", 'flock_step_kernel'),
+                                        "transition, fused)", ('flock_step_kernel',)),
             "rotating_input_sets": n_sets,
         }
         if resident:

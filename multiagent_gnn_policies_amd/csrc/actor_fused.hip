@@ -1,7 +1,9 @@
 // Fused Actor forward / backward for ind_agg == 0 (reference learner/actor.py:45-86; the only configuration
 // train.py reaches: gnn_dagger.py:43, gnn_cloning.py:41).
 //
-// Forward, ONE launch, one workgroup (512 threads = 8 waves) per (episode b, tile of <=128 agent columns):
+// Forward, ONE launch.  Two variants: `actor_fwd_mfma_kernel` (aggregation on the matrix pipe; N <= 128, every shipped
+// configuration of that size) further down, and the general one described here --
+// one workgroup (512 threads = 8 waves) per (episode b, tile of <=128 agent columns):
 //   phase 1  aggregation  Y[(f,k), n] = sum_m X[b,k,f,m] * G[b,k,m,n]       (HBM-bound: G is read exactly once)
 //            G[b,k] rows are the contraction index, so a workgroup that owns whole rows streams the operator as
 //            a flat float4 array (N <= 128) / 512-byte row segments (N > 128).  A thread owns 4 adjacent columns
@@ -32,8 +34,10 @@ constexpr int AF_LDS_LIMIT = 150 * 1024;
 #ifdef MGP_AF_PROFILE
 __device__ unsigned long long mgp_af_stamps[64];
 #define AF_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) mgp_af_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#define AF_STAMP_T(i, t) do { if (blockIdx.x == 0 && threadIdx.x == (t)) mgp_af_stamps[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define AF_STAMP(i) do { } while (0)
+#define AF_STAMP_T(i, t) do { } while (0)
 #endif
 
 struct ActorParams {
@@ -59,12 +63,15 @@ template <> struct GLoad<1> {
 
 struct MlpArgs {
     const float* bin; float* bout; const float* wfrag; float* out; float* saved; size_t soff;
-    int ksteps, cout, cols, n0, N, b, nt, lane; bool last;
+    int ksteps, cout, cols, n0, N, b, nt, lane; bool last; int wstride;
 };
 
 // One layer for the 16 agent columns of n-tile a.nt: D[mt] (16 x 16) = W[mt] (16 x cin) . Act (cin x 16), MT m-tiles
 // sharing the B fragment (MT independent accumulator chains), bias preloaded into the accumulators.
-template <int MT>
+// NAT: the layer's weights sit in LDS in their NATURAL order, rows o at stride a.wstride = 16 ceil(cin / 16) + 4 floats
+// (zero padded; that stride spreads a wave's 64 scalar reads over all banks), bias after the MT * 16 rows -- what the MFMA
+// aggregation kernel's staging waves can produce without index arithmetic.  Otherwise: A-fragment order, see above.
+template <int MT, bool NAT = false>
 __device__ __forceinline__ void mlp_layer(const MlpArgs& a)
 {
     const int li = a.lane & 15, lq = a.lane >> 4;
@@ -77,12 +84,26 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a)
     }
     float fa[MT][16];
     f32x4 acc[MT];
-    const float* bias = a.wfrag + MT * 64 * AF_WFS;
+    const float* bias = a.wfrag + (NAT ? MT * 16 * a.wstride : MT * 64 * AF_WFS);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const float4* pa = reinterpret_cast<const float4*>(a.wfrag + (mt * 64 + a.lane) * AF_WFS);
+        if constexpr (NAT) {
+            const float* pa = a.wfrag + (mt * 16 + li) * a.wstride + lq;      // A[i = li][k = lq] of k-step s: W[o][4 s + lq]
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const float4 t = pa[i]; fa[mt][4 * i] = t.x; fa[mt][4 * i + 1] = t.y; fa[mt][4 * i + 2] = t.z; fa[mt][4 * i + 3] = t.w; }
+            for (int sg = 0; sg < 4; ++sg) {
+                if (4 * sg < a.ksteps) {
+#pragma unroll
+                    for (int s2 = 4 * sg; s2 < 4 * sg + 4; ++s2) fa[mt][s2] = pa[4 * s2];
+                } else {
+#pragma unroll
+                    for (int s2 = 4 * sg; s2 < 4 * sg + 4; ++s2) fa[mt][s2] = 0.f;
+                }
+            }
+        } else {
+            const float4* pa = reinterpret_cast<const float4*>(a.wfrag + (mt * 64 + a.lane) * AF_WFS);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float4 t = pa[i]; fa[mt][4 * i] = t.x; fa[mt][4 * i + 1] = t.y; fa[mt][4 * i + 2] = t.z; fa[mt][4 * i + 3] = t.w; }
+        }
         const float4 bv = *reinterpret_cast<const float4*>(bias + mt * 16 + lq * 4);
         acc[mt][0] = bv.x; acc[mt][1] = bv.y; acc[mt][2] = bv.z; acc[mt][3] = bv.w;
     }
@@ -383,6 +404,172 @@ void actor_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Forward, MFMA aggregation variant: one workgroup per episode for 16 <= N <= 128 (N % 4 == 0) and K * nblk <= 6
+// (nblk = 2 column blocks above 64 agents), i.e. every shipped configuration with N <= 128.  13.3 us per launch at
+// B = 256, N = 100, K = 3 against 17.3 us for the VALU variant (10.5 against 14.0 at B = 1).
+//   The aggregation Y_k = X_k (F x N) . G_k (N x N) is itself run on v_mfma_f32_16x16x4_f32: wave u = (tap k, column
+//   block blk of <= 16 four-column groups) owns ALL N contraction rows of its columns, so the sum over rows lives in
+//   the MFMA accumulators and there are no row phases to combine through LDS (the VALU variant above spends 4.5k of
+//   its 14k post-stream cycles writing, synchronising and re-reading those partials).  Lane (li, lq) loads the float4
+//   G[4 s + lq][4 g + 0..3], g = block base + li, for every row step s up front (S dwordx4 in flight per lane: the whole
+//   operator of the episode is requested before anything else); the lane's j-th float is the B operand B[k = lq][j' = li]
+//   of n-tile j (columns {4 g + j}: a column permutation the write-back undoes), A[i = li][k = lq] = X[k, li, 4 s + lq]
+//   (rows li >= F zero).  4 independent accumulator chains per wave.
+//   Weights and zero fill: the two waves that own no part of the operator.  What shaped this (all measured, see
+//   DESIGN 4.1): a lone wave retires an instruction every ~8 cycles, a request issued while the operator streams is
+//   served with it (~5 us), hipcc waits at the join for any load issued under a branch, and every barrier before the
+//   stream delays it.  So: row o of W_l goes straight to its place in LDS by LDS-DMA (global_load_lds_dword: no
+//   registers, no index arithmetic, nothing to wait for until the end), in NATURAL order at a padded row stride
+//   (mlp_layer<.., NAT> reads its A fragments from there); only the weight area and layer 0's k-step padding
+//   channels are zeroed, by the same two waves; the streaming waves start their requests at cycle ~300 and the kernel
+//   has ONE barrier, before the MLP.
+struct CarveM { int ys, bufb, w, wtot, total; };
+
+// One LDS-DMA dword per active lane: LDS[dst_uniform + 4 * lane] = *src (global_load_lds_dword; M0 carries the LDS base).
+// Written as asm, not __builtin_amdgcn_global_load_lds: with the builtin anywhere in the kernel hipcc (ROCm 7.2) drops
+// its partial vmcnt(N) waits for vmcnt(0) everywhere -- the aggregation would wait for the whole operator before its
+// first MFMA.  The caller waits (s_waitcnt vmcnt(0)) before reading what landed.
+__device__ __forceinline__ void lds_dma_dword(const float* src, const float* dst_uniform)
+{
+    const unsigned int base = __builtin_amdgcn_readfirstlane((unsigned int)reinterpret_cast<uintptr_t>(dst_uniform));
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
+                 :: "s"(base), "v"(src) : "memory", "m0");
+}
+struct WLayout {
+    int lw[MGP_MAX_LAYERS], lstride[MGP_MAX_LAYERS];     // per layer: LDS offset and row stride of its weights
+    int osplit[MGP_MAX_LAYERS], bias_owner[MGP_MAX_LAYERS];   // rows < osplit[l] and the biases with owner 0: staging wave 0
+    int split;                                           // the cut (floats from the start of the weight area, % 4 == 0)
+};
+
+template <int S>
+__global__ __launch_bounds__(AF_THREADS)
+void actor_fwd_mfma_kernel(const float* __restrict__ X, const float* __restrict__ G, float* __restrict__ out,
+                           float* __restrict__ saved, ActorParams P, WLayout WC, CarveM cv, int B, int K, int N, int nblk)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int b = blockIdx.x;
+    const int F = P.dims[0], FK = F * K;
+    float* ys = smem + cv.ys;
+    float* bufB = smem + cv.bufb;
+    float* wl = smem + cv.w;
+    const int ncols16 = pad16(N);
+    AF_STAMP(0);
+    const int nstream = K * nblk;                                // waves 0 .. nstream-1 stream, the next two stage
+    const bool staging = wave >= nstream && wave < nstream + 2;
+    if (wave < nstream) {
+        // ---- (a) this wave's share of the operator, in consumption order (vmcnt retires in order; the scheduler is
+        //      kept from reversing the batch)
+        const int gtot = N >> 2, g0 = (nblk == 2) ? ((gtot + 1) >> 1) : gtot;
+        const int k = wave / nblk, blk = wave - k * nblk;
+        const int ng = blk ? gtot - g0 : g0;
+        const int g = blk * g0 + min(li, ng - 1);
+        const float* Gk = G + ((size_t)b * K + k) * (size_t)N * N + 4 * g;
+        const float* Xk = X + ((size_t)b * K + k) * (size_t)F * N + (size_t)min(li, F - 1) * N;
+        float xa[S];
+        f32x4 gv[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) xa[s] = Xk[min(4 * s + lq, N - 1)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            gv[s] = *reinterpret_cast<const f32x4*>(Gk + (size_t)min(4 * s + lq, N - 1) * N);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        AF_STAMP(1);
+        // ---- (b) aggregation on the matrix pipe as the rows arrive
+        f32x4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < S; ++s) {                         // steps past N: clamped rows times a = 0
+            const float a = (li < F && 4 * s + lq < N) ? xa[s] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gv[s][j], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        AF_STAMP(2);
+        // D[i = 4 lq + rr][j' = li] of n-tile j is Y[channel c = 4 lq + rr of tap k][column 4 g + j]
+        if (li < ng) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int c = 4 * lq + rr;
+                if (c < F) {
+                    const int pos = bpos(c * K + k);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ys[(4 * g + j) * AF_CS + pos] = acc[j][rr];
+                }
+            }
+        }
+        AF_STAMP(3);
+    } else if (staging) {
+        // ---- (c) the two staging waves: weights and zero fill, all in the shadow of the stream (ONE barrier in the kernel)
+        const int sw = __builtin_amdgcn_readfirstlane(wave) - nstream;
+        const int st = tid - 64 * nstream;
+        // The weight area is cut at a row boundary (WC.split); staging wave 0 owns everything below, wave 1 everything
+        // above: zeros first (k-step / m-tile padding of the natural-order rows), then -- the wave's own stores retired --
+        // row o of W_l straight to its padded-stride place by LDS-DMA (no registers, no index arithmetic), biases likewise.
+        // No other wave writes there before the barrier, so a late zero can never land on top of a weight.
+        {
+            float4* z = reinterpret_cast<float4*>(wl);
+            const int zlo = (sw ? WC.split : 0) / 4, zhi = (sw ? cv.wtot : WC.split) / 4;
+            for (int i = zlo + lane; i < zhi; i += 64) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int l = 0; l < P.n_layers; ++l) {
+            const int cin = (l == 0) ? FK : P.dims[l], cout = P.dims[l + 1], stride = WC.lstride[l];
+            const float* src = P.W[l] + lane;
+            float* dst = wl + WC.lw[l];
+            const int olo = sw ? WC.osplit[l] : 0, ohi = sw ? cout : WC.osplit[l];
+            if (lane < cin)
+                for (int o = olo; o < ohi; ++o) lds_dma_dword(src + o * cin, dst + o * stride);
+            if (WC.bias_owner[l] == sw && lane < cout) lds_dma_dword(P.b[l] + lane, dst + mtiles(cout) * 16 * stride);
+        }
+        AF_STAMP_T(16, 64 * nstream);
+        // activation buffers: the only positions read before anything wrote them are layer 0's k-step padding channels
+        // FK .. 16 ceil(FK / 16) - 1 of `ys` (a layer writes every channel of its m-tiles, which cover the k-groups the
+        // next layer reads; padded COLUMNS only ever feed their own, never stored, outputs).  One column per thread; the
+        // streaming waves fill the other channels, so no barrier has to order the two.
+        if (st < ncols16)
+            for (int q = FK; q < pad16(FK); ++q) ys[st * AF_CS + bpos(q)] = 0.f;
+        AF_STAMP_T(17, 64 * nstream);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        AF_STAMP_T(19, 64 * nstream);
+    }
+    __syncthreads();
+    AF_STAMP(4);
+    if (saved != nullptr) {
+        float* sy = saved + (size_t)b * FK * N;
+        for (int i = tid; i < FK * N; i += AF_THREADS) {
+            const int q = i / N, col = i - q * N;
+            sy[(size_t)q * N + col] = ys[col * AF_CS + bpos(q)];
+        }
+    }
+    AF_STAMP(5);
+    const int NT = ncols16 / 16;
+    if (wave < NT) {
+        size_t soff = (size_t)B * FK * N;
+        for (int l = 0; l < P.n_layers; ++l) {
+            const int cin = (l == 0) ? FK : P.dims[l];
+            const int cout = P.dims[l + 1];
+            const float* bin = (l & 1) ? bufB : ys;
+            float* bout = (l & 1) ? ys : bufB;
+            const bool last = (l == P.n_layers - 1);
+            MlpArgs ma = {bin, bout, wl + WC.lw[l], out, saved, soff, pad4(cin) / 4, cout, N, 0, N, b, wave, lane, last,
+                          WC.lstride[l]};
+            const int MT = mtiles(cout);
+            if (MT == 1) mlp_layer<1, true>(ma);
+            else if (MT == 2) mlp_layer<2, true>(ma);
+            else mlp_layer<4, true>(ma);
+            soff += (size_t)B * cout * N;
+            AF_STAMP(6 + l);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Backward (parameters only).  Workgroup per (b, 64-column tile).  LDS: delta ping-pong [maxw][65],
 // input tile [maxin][65].  Partials: part[tile][P] with P = sum_l cout*cin + cout, layer-major (W then b).
 constexpr int AB_THREADS = 256;
@@ -550,6 +737,63 @@ bool make_plan(const int* dims, int n_layers, int K, int N, bool vec_ok, Plan* p
     return (size_t)off * sizeof(float) <= AF_LDS_LIMIT;
 }
 
+// MFMA aggregation variant: which shapes, its LDS carve-up and where each layer's weights sit
+struct PlanM { int S, nblk; CarveM cv; WLayout wc; };
+
+inline int nat_stride(int cin) { return 16 * ((cin + 15) / 16) + 4; }
+
+bool make_plan_mfma(const Plan& pl, const float* const* W, const float* const* bias, const int* dims, int n_layers,
+                    int K, int N, PlanM* pm)
+{
+    if (pl.V != 4 || N > 128 || N < 16) return false;
+    const int gtot = N / 4;
+    pm->nblk = gtot > 16 ? 2 : 1;
+    if (K * pm->nblk > AF_WAVES - 2) return false;             // two waves stage the weights
+    pm->S = (N + 3) / 4;
+    WLayout& wc = pm->wc;
+    int wtot = 0;
+    for (int l = 0; l < MGP_MAX_LAYERS; ++l) wc.lw[l] = wc.lstride[l] = wc.osplit[l] = wc.bias_owner[l] = 0;
+    int rows_total = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        const int cin = (l == 0) ? dims[0] * K : dims[l], cout = dims[l + 1];
+        if ((reinterpret_cast<uintptr_t>(W[l]) | reinterpret_cast<uintptr_t>(bias[l])) & 3u) return false;
+        const int stride = nat_stride(cin);
+        wc.lw[l] = wtot; wc.lstride[l] = stride;
+        wtot += mtiles(cout) * 16 * stride + mtiles(cout) * 16;
+        wtot = (wtot + 3) & ~3;
+        rows_total += cout;
+    }
+    // cut the area where half of the weight rows (one LDS-DMA each) lie below
+    wc.split = wtot;
+    for (int l = 0, seen = 0; l < n_layers; ++l) {
+        const int cout = dims[l + 1];
+        int os = (rows_total + 1) / 2 - seen;
+        os = os < 0 ? 0 : (os > cout ? cout : os);
+        wc.osplit[l] = os;
+        if (os < cout && wc.split == wtot) wc.split = wc.lw[l] + os * wc.lstride[l];
+        wc.bias_owner[l] = (wc.lw[l] + mtiles(cout) * 16 * wc.lstride[l] >= wc.split) ? 1 : 0;
+        seen += cout;
+    }
+    const int buf = pad16(N) * AF_CS;
+    pm->cv.ys = 0; pm->cv.bufb = buf; pm->cv.w = 2 * buf; pm->cv.wtot = wtot;
+    pm->cv.total = (2 * buf + wtot + 3) & ~3;
+    return (size_t)pm->cv.total * sizeof(float) <= AF_LDS_LIMIT;
+}
+
+template <int S>
+int launch_fwd_mfma(const float* X, const float* G, float* out, float* saved, const ActorParams& P, const PlanM& pm,
+                    int B, int K, int N, hipStream_t st)
+{
+    const size_t lds = (size_t)pm.cv.total * sizeof(float);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(actor_fwd_mfma_kernel<S>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return MGP_ELAUNCH;
+    hipLaunchKernelGGL((actor_fwd_mfma_kernel<S>), dim3((unsigned)B), dim3(AF_THREADS), lds, st,
+                       X, G, out, saved, P, pm.wc, pm.cv, B, K, N, pm.nblk);
+    return mgp_launch_status();
+}
+
 template <int CT, int V>
 int launch_fwd(const float* X, const float* G, float* out, float* saved, const ActorParams& P, const Plan& pl,
                int B, int K, int N, hipStream_t st)
@@ -602,6 +846,12 @@ extern "C" int mgp_actor_fwd(const float* X, const float* G, const float* const*
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     mgp_clear_error();
+    PlanM pm;
+    if (make_plan_mfma(pl, W, b, dims, n_layers, K, N, &pm)) {
+        if (pm.S <= 16) return launch_fwd_mfma<16>(X, G, out, saved, P, pm, B, K, N, st);
+        if (pm.S <= 25) return launch_fwd_mfma<25>(X, G, out, saved, P, pm, B, K, N, st);
+        return launch_fwd_mfma<32>(X, G, out, saved, P, pm, B, K, N, st);
+    }
 #define MGP_AF_CASE(CT, V) return launch_fwd<CT, V>(X, G, out, saved, P, pl, B, K, N, st)
     if (pl.V == 4) {
         if (pl.CT == 4) MGP_AF_CASE(4, 4);

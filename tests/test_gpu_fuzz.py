@@ -55,6 +55,41 @@ def test_actor_random_configuration(seed):
             assert relerr(xt.grad.cpu().numpy(), dX) <= 2e-5
 
 
+MFMA_SHAPES = [(N, K) for N in (16, 20, 36, 60, 64, 68, 96, 100, 104, 124, 128) for K in (1, 2, 3, 4, 6)
+               if K * (2 if N > 64 else 1) <= 6]
+
+
+@pytest.mark.parametrize('N,K', MFMA_SHAPES)
+def test_actor_fwd_mfma_variant_shapes(N, K):
+    """Every (N, K) class the MFMA-aggregation variant of mgp_actor_fwd takes (N % 4 == 0, 16 <= N <= 128, K * column blocks
+    <= 6: one and two column blocks, partial last blocks, row steps past N, every tap count), F and widths varied with
+    the shape, forward AND the activations it saves for backward, against the fp64 oracle."""
+    from multiagent_gnn_policies_amd.learner import Actor
+    from multiagent_gnn_policies_amd import ops
+    seed = 31 * N + K
+    rs = np.random.RandomState(seed)
+    F = int(rs.choice([1, 3, 6, 8])); B = int(rs.choice([1, 3, 9]))
+    hidden = [int(rs.choice([4, 16, 20, 32, 64])) for _ in range(int(rs.randint(0, 4)))]
+    torch.manual_seed(seed)
+    actor = Actor(F, 2, hidden, K, 0).cuda()
+    actor.use_fused = True
+    X, G = (synth.make_dense_inputs if seed % 2 else synth.make_inputs)(seed, B, K, F, N)
+    Ws = [c.weight.detach().cpu().numpy() for c in actor.conv_layers]
+    bs = [c.bias.detach().cpu().numpy() for c in actor.conv_layers]
+    ref, cache = oa.forward(X, G, Ws, bs, 0, dtype=np.float64, return_cache=True)
+    target = rs.randn(*ref.shape).astype(np.float32)
+    dWs, dbs, _ = oa.backward(od.mse_grad(ref, target), G, Ws, 0, cache, need_dx=False)
+    out = actor(torch.from_numpy(X).cuda(), torch.from_numpy(G).cuda())
+    assert relerr(out.detach().cpu().numpy(), ref) <= 1e-5, (B, K, F, N, hidden)
+    ops.mse_loss(out, torch.from_numpy(target).cuda()).backward()
+    for i, conv in enumerate(actor.conv_layers):
+        assert relerr(conv.weight.grad.cpu().numpy(), dWs[i]) <= 2e-5
+        assert relerr(conv.bias.grad.cpu().numpy(), dbs[i]) <= 2e-5
+    # LDS left over by other kernels must not leak in through padding (NaN-poisoned run-to-run determinism check)
+    out2 = actor(torch.from_numpy(X).cuda(), torch.from_numpy(G).cuda())
+    assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize('seed', range(40))
 def test_state_and_sim_random_sizes(seed):
     from multiagent_gnn_policies_amd.envs import FlockParams, VecFlock

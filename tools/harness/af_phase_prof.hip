@@ -42,6 +42,6 @@ int main(int argc, char** argv) {
     hipMemcpyFromSymbol(st, HIP_SYMBOL(mgp_af_stamps), sizeof(st));
     const char* names[64] = {0};
     printf("block 0 thread 0 cycle stamps (delta from start, cycles @100MHz-ish counter or shader clock):\n");
-    for (int i = 0; i < 64; ++i) if (st[i]) printf("  stamp %2d : %10llu\n", i, st[i] - st[0]);
+    for (int i = 1; i < 64; ++i) if (st[i]) printf("  stamp %2d : %10llu\n", i, st[i] - st[0]);
     return 0;
 }
