@@ -405,16 +405,17 @@ void actor_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G, 
 
 // ---------------------------------------------------------------------------------------------------------
 // Forward, MFMA aggregation variant: one workgroup per episode for 16 <= N <= 128 (N % 4 == 0) and K * nblk <= 6
-// (nblk = 2 column blocks above 64 agents), i.e. every shipped configuration with N <= 128.  13.3 us per launch at
-// B = 256, N = 100, K = 3 against 17.3 us for the VALU variant (10.5 against 14.0 at B = 1).
-//   The aggregation Y_k = X_k (F x N) . G_k (N x N) is itself run on v_mfma_f32_16x16x4_f32: wave u = (tap k, column
-//   block blk of <= 16 four-column groups) owns ALL N contraction rows of its columns, so the sum over rows lives in
-//   the MFMA accumulators and there are no row phases to combine through LDS (the VALU variant above spends 4.5k of
-//   its 14k post-stream cycles writing, synchronising and re-reading those partials).  Lane (li, lq) loads the float4
-//   G[4 s + lq][4 g + 0..3], g = block base + li, for every row step s up front (S dwordx4 in flight per lane: the whole
-//   operator of the episode is requested before anything else); the lane's j-th float is the B operand B[k = lq][j' = li]
-//   of n-tile j (columns {4 g + j}: a column permutation the write-back undoes), A[i = li][k = lq] = X[k, li, 4 s + lq]
-//   (rows li >= F zero).  4 independent accumulator chains per wave.
+// (nblk = 2 column blocks above 64 agents), i.e. every shipped configuration with N <= 128.  12.5 us per launch at
+// B = 256, N = 100, K = 3 against 17.3 us for the VALU variant (9.7 against 14.0 at B = 1).
+//   The aggregation Y_k = X_k (F x N) . G_k (N x N) runs on the matrix pipe: wave u = (tap k, column block blk of <= 16
+//   four-column groups) owns ALL N contraction rows of its columns.  Lane (li, lq) loads the float4 G[row][4 g + 0..3],
+//   g = block base + li, row = 16 (s >> 2) + 4 lq + (s & 3), for every row step s up front (the whole operator of the
+//   episode is requested before anything else: <= 32 dwordx4 + 16 X quads in flight per lane) and multiplies it with
+//   v_mfma_f32_4x4x1 (16 independent 4x4 outer products per instruction, 6 of 8 feature rows useful; the 16x16x4 shape
+//   would use 6 of 16 -- it measured the matrix pipe, not the stream, as the bound on the two SIMDs that carry two
+//   streaming waves).  The sums over a lane's own row class lq live in its accumulators; the four classes are added
+//   through a per-wave LDS area in fixed order -- no workgroup-wide row-phase combine (the VALU variant above spends
+//   4.5k of its 14k post-stream cycles writing, synchronising and re-reading those partials).
 //   Weights and zero fill: the two waves that own no part of the operator.  What shaped this (all measured, see
 //   DESIGN 4.1): a lone wave retires an instruction every ~8 cycles, a request issued while the operator streams is
 //   served with it (~5 us), hipcc waits at the join for any load issued under a branch, and every barrier before the
@@ -423,7 +424,7 @@ void actor_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G, 
 //   (mlp_layer<.., NAT> reads its A fragments from there); only the weight area and layer 0's k-step padding
 //   channels are zeroed, by the same two waves; the streaming waves start their requests at cycle ~300 and the kernel
 //   has ONE barrier, before the MLP.
-struct CarveM { int ys, bufb, w, wtot, total; };
+struct CarveM { int ys, bufb, w, wtot, red, total; };
 
 // One LDS-DMA dword per active lane: LDS[dst_uniform + 4 * lane] = *src (global_load_lds_dword; M0 carries the LDS base).
 // Written as asm, not __builtin_amdgcn_global_load_lds: with the builtin anywhere in the kernel hipcc (ROCm 7.2) drops
@@ -441,7 +442,7 @@ struct WLayout {
     int split;                                           // the cut (floats from the start of the weight area, % 4 == 0)
 };
 
-template <int S>
+template <int S, int FH>                  // S row steps (4 ceil(N / 16)); FH = ceil(F / 4) halves of the feature rows
 __global__ __launch_bounds__(AF_THREADS)
 void actor_fwd_mfma_kernel(const float* __restrict__ X, const float* __restrict__ G, float* __restrict__ out,
                            float* __restrict__ saved, ActorParams P, WLayout WC, CarveM cv, int B, int K, int N, int nblk)
@@ -460,54 +461,90 @@ void actor_fwd_mfma_kernel(const float* __restrict__ X, const float* __restrict_
     const bool staging = wave >= nstream && wave < nstream + 2;
     if (wave < nstream) {
         // ---- (a) this wave's share of the operator, in consumption order (vmcnt retires in order; the scheduler is
-        //      kept from reversing the batch)
+        //      kept from reversing the batch).  Row of (step s, lane quarter lq): 16 (s >> 2) + 4 lq + (s & 3), so that a
+        //      lane's X operands of four consecutive steps are one aligned float4.
         const int gtot = N >> 2, g0 = (nblk == 2) ? ((gtot + 1) >> 1) : gtot;
         const int k = wave / nblk, blk = wave - k * nblk;
         const int ng = blk ? gtot - g0 : g0;
         const int g = blk * g0 + min(li, ng - 1);
         const float* Gk = G + ((size_t)b * K + k) * (size_t)N * N + 4 * g;
-        const float* Xk = X + ((size_t)b * K + k) * (size_t)F * N + (size_t)min(li, F - 1) * N;
-        float xa[S];
+        const float* Xk = X + ((size_t)b * K + k) * (size_t)F * N;
+        f32x4 xa[FH][S / 4];
         f32x4 gv[S];
 #pragma unroll
-        for (int s = 0; s < S; ++s) xa[s] = Xk[min(4 * s + lq, N - 1)];
+        for (int h = 0; h < FH; ++h) {
+            const float* xr = Xk + (size_t)min(4 * h + (li & 3), F - 1) * N;
+#pragma unroll
+            for (int t4 = 0; t4 < S / 4; ++t4)
+                xa[h][t4] = *reinterpret_cast<const f32x4*>(xr + min(16 * t4 + 4 * lq, N - 4));
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            gv[s] = *reinterpret_cast<const f32x4*>(Gk + (size_t)min(4 * s + lq, N - 1) * N);
+            gv[s] = *reinterpret_cast<const f32x4*>(Gk + (size_t)min(16 * (s >> 2) + 4 * lq + (s & 3), N - 1) * N);
             __builtin_amdgcn_sched_barrier(0);
         }
         AF_STAMP(1);
-        // ---- (b) aggregation on the matrix pipe as the rows arrive
-        f32x4 acc[4];
+        // ---- (b) aggregation on the matrix pipe as the rows arrive: v_mfma_f32_4x4x1 (16 independent 4x4 outer
+        //      products per instruction; lanes 4 q .. 4 q + 3 are block q, D[i] of lane l = A(lane 4 (l >> 2) + i) * B(lane
+        //      l)).  Block = (lq, li >> 2): its four lanes hold the same row and four adjacent column groups; instruction
+        //      (t, h) multiplies features 4 h + 0..3 (A: the lane with li & 3 == i supplies X[4 h + i][row]) into float t
+        //      of every lane's G quad, i.e. column 4 g + t.  6 of the 8 A rows carry features (the 16x16x4 shape would use
+        //      6 of 16: twice the pipe time).  What a lane accumulates is the sum over ITS row class lq.
+        f32x4 acc[4][FH];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int s = 0; s < S; ++s) {                         // steps past N: clamped rows times a = 0
-            const float a = (li < F && 4 * s + lq < N) ? xa[s] : 0.f;
+            for (int h = 0; h < FH; ++h) acc[t][h] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gv[s][j], acc[j], 0, 0, 0);
+        for (int s = 0; s < S; ++s) {                         // rows past N: clamped addresses times a = 0
+            const bool rok = 16 * (s >> 2) + 4 * lq + (s & 3) < N;
+#pragma unroll
+            for (int h = 0; h < FH; ++h) {
+                const float a = (rok && 4 * h + (li & 3) < F) ? xa[h][s >> 2][s & 3] : 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[t][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, gv[s][t], acc[t][h], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         AF_STAMP(2);
-        // D[i = 4 lq + rr][j' = li] of n-tile j is Y[channel c = 4 lq + rr of tap k][column 4 g + j]
+        // the four row classes are added through a per-wave LDS area (value-major, so every b128 access of the wave is
+        // contiguous): lane (li, lq) collects column 4 g + lq -- float t = lq of all four classes, fixed order -- and
+        // writes it.  Same-wave write -> read: ordered by the counter wait the compiler places, no barrier.
+        f32x4* red = reinterpret_cast<f32x4*>(smem + cv.red) + wave * (4 * FH * 64);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int h = 0; h < FH; ++h) red[(t * FH + h) * 64 + lane] = acc[t][h];
+        f32x4 tot[FH];
+#pragma unroll
+        for (int h = 0; h < FH; ++h) {
+            const f32x4* p = red + (lq * FH + h) * 64 + li;
+            tot[h] = p[0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) tot[h] += p[16 * q];
+        }
         if (li < ng) {
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int c = 4 * lq + rr;
-                if (c < F) {
-                    const int pos = bpos(c * K + k);
+            for (int h = 0; h < FH; ++h)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) ys[(4 * g + j) * AF_CS + pos] = acc[j][rr];
+                for (int i = 0; i < 4; ++i) {
+                    const int c = 4 * h + i;
+                    if (c < F) ys[(4 * g + lq) * AF_CS + bpos(c * K + k)] = tot[h][i];
                 }
-            }
         }
         AF_STAMP(3);
     } else if (staging) {
         // ---- (c) the two staging waves: weights and zero fill, all in the shadow of the stream (ONE barrier in the kernel)
         const int sw = __builtin_amdgcn_readfirstlane(wave) - nstream;
         const int st = tid - 64 * nstream;
+        // activation buffers: the only positions read before anything wrote them are layer 0's k-step padding channels
+        // FK .. 16 ceil(FK / 16) - 1 of `ys` (a layer writes every channel of its m-tiles, which cover the k-groups the
+        // next layer reads; padded COLUMNS only ever feed their own, never stored, outputs).  One column per thread; the
+        // streaming waves fill the other channels, so no barrier has to order the two.
+        if (st < ncols16)
+            for (int q = FK; q < pad16(FK); ++q) ys[st * AF_CS + bpos(q)] = 0.f;
         // The weight area is cut at a row boundary (WC.split); staging wave 0 owns everything below, wave 1 everything
         // above: zeros first (k-step / m-tile padding of the natural-order rows), then -- the wave's own stores retired --
         // row o of W_l straight to its padded-stride place by LDS-DMA (no registers, no index arithmetic), biases likewise.
@@ -528,12 +565,6 @@ void actor_fwd_mfma_kernel(const float* __restrict__ X, const float* __restrict_
             if (WC.bias_owner[l] == sw && lane < cout) lds_dma_dword(P.b[l] + lane, dst + mtiles(cout) * 16 * stride);
         }
         AF_STAMP_T(16, 64 * nstream);
-        // activation buffers: the only positions read before anything wrote them are layer 0's k-step padding channels
-        // FK .. 16 ceil(FK / 16) - 1 of `ys` (a layer writes every channel of its m-tiles, which cover the k-groups the
-        // next layer reads; padded COLUMNS only ever feed their own, never stored, outputs).  One column per thread; the
-        // streaming waves fill the other channels, so no barrier has to order the two.
-        if (st < ncols16)
-            for (int q = FK; q < pad16(FK); ++q) ys[st * AF_CS + bpos(q)] = 0.f;
         AF_STAMP_T(17, 64 * nstream);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         AF_STAMP_T(19, 64 * nstream);
@@ -749,7 +780,7 @@ bool make_plan_mfma(const Plan& pl, const float* const* W, const float* const* b
     const int gtot = N / 4;
     pm->nblk = gtot > 16 ? 2 : 1;
     if (K * pm->nblk > AF_WAVES - 2) return false;             // two waves stage the weights
-    pm->S = (N + 3) / 4;
+    pm->S = 4 * ((N + 15) / 16);
     WLayout& wc = pm->wc;
     int wtot = 0;
     for (int l = 0; l < MGP_MAX_LAYERS; ++l) wc.lw[l] = wc.lstride[l] = wc.osplit[l] = wc.bias_owner[l] = 0;
@@ -776,20 +807,21 @@ bool make_plan_mfma(const Plan& pl, const float* const* W, const float* const* b
     }
     const int buf = pad16(N) * AF_CS;
     pm->cv.ys = 0; pm->cv.bufb = buf; pm->cv.w = 2 * buf; pm->cv.wtot = wtot;
-    pm->cv.total = (2 * buf + wtot + 3) & ~3;
+    pm->cv.red = (2 * buf + wtot + 3) & ~3;                    // per streaming wave: 4 * FH (<= 8) float4 per lane
+    pm->cv.total = pm->cv.red + K * pm->nblk * 8 * 64 * 4;
     return (size_t)pm->cv.total * sizeof(float) <= AF_LDS_LIMIT;
 }
 
-template <int S>
+template <int S, int FH>
 int launch_fwd_mfma(const float* X, const float* G, float* out, float* saved, const ActorParams& P, const PlanM& pm,
                     int B, int K, int N, hipStream_t st)
 {
     const size_t lds = (size_t)pm.cv.total * sizeof(float);
     if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(actor_fwd_mfma_kernel<S>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(actor_fwd_mfma_kernel<S, FH>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return MGP_ELAUNCH;
-    hipLaunchKernelGGL((actor_fwd_mfma_kernel<S>), dim3((unsigned)B), dim3(AF_THREADS), lds, st,
+    hipLaunchKernelGGL((actor_fwd_mfma_kernel<S, FH>), dim3((unsigned)B), dim3(AF_THREADS), lds, st,
                        X, G, out, saved, P, pm.wc, pm.cv, B, K, N, pm.nblk);
     return mgp_launch_status();
 }
@@ -847,10 +879,13 @@ extern "C" int mgp_actor_fwd(const float* X, const float* G, const float* const*
     hipStream_t st = static_cast<hipStream_t>(stream);
     mgp_clear_error();
     PlanM pm;
-    if (make_plan_mfma(pl, W, b, dims, n_layers, K, N, &pm)) {
-        if (pm.S <= 16) return launch_fwd_mfma<16>(X, G, out, saved, P, pm, B, K, N, st);
-        if (pm.S <= 25) return launch_fwd_mfma<25>(X, G, out, saved, P, pm, B, K, N, st);
-        return launch_fwd_mfma<32>(X, G, out, saved, P, pm, B, K, N, st);
+    if (mgp_aligned16(X) && make_plan_mfma(pl, W, b, dims, n_layers, K, N, &pm)) {      // X operands are float4 loads
+#define MGP_AM_CASE(S_) return dims[0] <= 4 ? launch_fwd_mfma<S_, 1>(X, G, out, saved, P, pm, B, K, N, st) \
+                                             : launch_fwd_mfma<S_, 2>(X, G, out, saved, P, pm, B, K, N, st)
+        if (pm.S <= 16) MGP_AM_CASE(16);
+        if (pm.S <= 28) MGP_AM_CASE(28);
+        MGP_AM_CASE(32);
+#undef MGP_AM_CASE
     }
 #define MGP_AF_CASE(CT, V) return launch_fwd<CT, V>(X, G, out, saved, P, pl, B, K, N, st)
     if (pl.V == 4) {
