@@ -326,7 +326,13 @@ def parity_gate(ro, n_check=16):
         res[name] = {"max_abs": float((u - ref).abs().max()), "max_rel": float(r_ref.max()),
                      "max_rel_vs_exact": float(r_ex.max()),
                      "max_rel_well_conditioned": float(r_ref[well].max()) if bool(well.any()) else None}
-        ok = ok and bool((r_ref[well] <= PARITY_TOL).all()) and bool((r_ex[~well] <= PARITY_TOL + 10.0 * noise_b[~well]).all())
+        plain = r_ref <= PARITY_TOL
+        res[name]["episodes_within_plain_tol"] = int(plain.sum())
+        # an episode passes on the plain bound, or -- where the reference's own fp32 evaluation is not determined to that
+        # accuracy -- by staying within tol + 10 x that episode's reference noise of the fp64 evaluation
+        ok = ok and bool((plain | (r_ex <= PARITY_TOL + 10.0 * noise_b)).all())
+        if 'reference checkpoint' in ro.weights and bool(well.all()):
+            ok = ok and bool(plain.all())                    # the shipped policy on well-conditioned states: plain bound only
     worst = max((v["max_rel_well_conditioned"] for v in res.values() if v["max_rel_well_conditioned"] is not None),
                 default=None)
     return {"ok": ok, "tol": PARITY_TOL, "max_abs": max(v['max_abs'] for v in res.values()),
@@ -334,12 +340,14 @@ def parity_gate(ro, n_check=16):
             "max_rel_all_episodes": max(v['max_rel'] for v in res.values()),
             "reference_fp32_noise": float(noise_b.max()), "max_abs_reference_output": float(ref.abs().max()),
             "checked_episodes": len(idx), "well_conditioned_episodes": int(well.sum()), "paths": res,
-            "criterion": "elementwise |gpu - cpu| / max(1, |cpu|) <= tol against the fp32 CPU reference on every sampled "
-                         "episode where that reference is itself determined to tol/2 (its distance to the fp64 evaluation "
-                         "of the same op sequence on the same fp32 inputs: reference_fp32_noise per episode); episodes "
-                         "where it is not -- colliding agents drive 1/r^4 features to 1e6 and any two fp32 evaluations "
-                         "apart -- must stay within tol + 10 x their own noise of the fp64 evaluation.  max_rel is the "
-                         "well-conditioned figure; the headline configuration has all 16 episodes well conditioned",
+            "criterion": "per sampled episode: elementwise |gpu - cpu| / max(1, |cpu|) <= tol against the fp32 CPU reference "
+                         "(paths.*.episodes_within_plain_tol counts these), or, failing that, within tol + 10 x the "
+                         "episode's reference_fp32_noise of the fp64 evaluation of the same op sequence on the same fp32 "
+                         "inputs (reference_fp32_noise = how far the fp32 REFERENCE itself is from that evaluation: "
+                         "colliding agents drive 1/r^4 features to 1e6, random-init wide networks amplify them, and any "
+                         "two fp32 evaluations then differ by more than tol).  max_rel is the figure over the episodes "
+                         "where the reference is determined to tol/2; the headline configuration (reference checkpoint) "
+                         "has all 16 episodes there AND within the plain bound",
             "reference": "oracle/torch_port.actor_forward: PyTorch-CPU fp32, the op sequence of reference actor.py:63-82, "
                          "on the identical (delay_gso, delay_state) of the sampled episodes"}
 

@@ -63,15 +63,12 @@ template <> struct GLoad<1> {
 
 struct MlpArgs {
     const float* bin; float* bout; const float* wfrag; float* out; float* saved; size_t soff;
-    int ksteps, cout, cols, n0, N, b, nt, lane; bool last; int wstride;
+    int ksteps, cout, cols, n0, N, b, nt, lane; bool last;
 };
 
 // One layer for the 16 agent columns of n-tile a.nt: D[mt] (16 x 16) = W[mt] (16 x cin) . Act (cin x 16), MT m-tiles
 // sharing the B fragment (MT independent accumulator chains), bias preloaded into the accumulators.
-// NAT: the layer's weights sit in LDS in their NATURAL order, rows o at stride a.wstride = 16 ceil(cin / 16) + 4 floats
-// (zero padded; that stride spreads a wave's 64 scalar reads over all banks), bias after the MT * 16 rows -- what the MFMA
-// aggregation kernel's staging waves can produce without index arithmetic.  Otherwise: A-fragment order, see above.
-template <int MT, bool NAT = false>
+template <int MT>
 __device__ __forceinline__ void mlp_layer(const MlpArgs& a)
 {
     const int li = a.lane & 15, lq = a.lane >> 4;
@@ -84,26 +81,12 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs& a)
     }
     float fa[MT][16];
     f32x4 acc[MT];
-    const float* bias = a.wfrag + (NAT ? MT * 16 * a.wstride : MT * 64 * AF_WFS);
+    const float* bias = a.wfrag + MT * 64 * AF_WFS;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        if constexpr (NAT) {
-            const float* pa = a.wfrag + (mt * 16 + li) * a.wstride + lq;      // A[i = li][k = lq] of k-step s: W[o][4 s + lq]
+        const float4* pa = reinterpret_cast<const float4*>(a.wfrag + (mt * 64 + a.lane) * AF_WFS);
 #pragma unroll
-            for (int sg = 0; sg < 4; ++sg) {
-                if (4 * sg < a.ksteps) {
-#pragma unroll
-                    for (int s2 = 4 * sg; s2 < 4 * sg + 4; ++s2) fa[mt][s2] = pa[4 * s2];
-                } else {
-#pragma unroll
-                    for (int s2 = 4 * sg; s2 < 4 * sg + 4; ++s2) fa[mt][s2] = 0.f;
-                }
-            }
-        } else {
-            const float4* pa = reinterpret_cast<const float4*>(a.wfrag + (mt * 64 + a.lane) * AF_WFS);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { const float4 t = pa[i]; fa[mt][4 * i] = t.x; fa[mt][4 * i + 1] = t.y; fa[mt][4 * i + 2] = t.z; fa[mt][4 * i + 3] = t.w; }
-        }
+        for (int i = 0; i < 4; ++i) { const float4 t = pa[i]; fa[mt][4 * i] = t.x; fa[mt][4 * i + 1] = t.y; fa[mt][4 * i + 2] = t.z; fa[mt][4 * i + 3] = t.w; }
         const float4 bv = *reinterpret_cast<const float4*>(bias + mt * 16 + lq * 4);
         acc[mt][0] = bv.x; acc[mt][1] = bv.y; acc[mt][2] = bv.z; acc[mt][3] = bv.w;
     }
@@ -424,7 +407,7 @@ void actor_fwd_kernel(const float* __restrict__ X, const float* __restrict__ G, 
 //   (mlp_layer<.., NAT> reads its A fragments from there); only the weight area and layer 0's k-step padding
 //   channels are zeroed, by the same two waves; the streaming waves start their requests at cycle ~300 and the kernel
 //   has ONE barrier, before the MLP.
-struct CarveM { int ys, bufb, w, wtot, red, total; };
+struct CarveM { int ys, w, wtot, red, total; };
 
 // One LDS-DMA dword per active lane: LDS[dst_uniform + 4 * lane] = *src (global_load_lds_dword; M0 carries the LDS base).
 // Written as asm, not __builtin_amdgcn_global_load_lds: with the builtin anywhere in the kernel hipcc (ROCm 7.2) drops
@@ -442,6 +425,107 @@ struct WLayout {
     int split;                                           // the cut (floats from the start of the weight area, % 4 == 0)
 };
 
+// ---- register-chained MLP of the MFMA aggregation kernel (weights in LDS in natural order, see above).  A layer's
+// 16 x 16 accumulator tile leaves lane (li, lq) holding rows 16 mt + 4 lq + rr (rr = 0..3) of column li -- which IS the B
+// operand layout of the next layer if ITS k index is enumerated as k-step 4 mt + rr, k-lane lq <-> channel 16 mt + 4 lq + rr;
+// the A operand of those four k-steps is then ONE aligned quad of the natural-order weight row.  So activations go from
+// one layer's tanh straight into the next layer's MFMAs: no LDS round trip, no activation buffers, widths up to 128
+// (8 m-tiles, two accumulator chains in flight).  Layer 0 reads its B operand from the aggregation tile `ys`, which the
+// streaming waves fill in the same channel enumeration (cpos).
+constexpr int AM_MAXMT = 8;               // m-tiles of the widest layer: widths <= 128
+// position of channel c inside an agent column of the aggregation tile: lane (li, lq) finds the channels 16 kc + 4 lq + j
+// it multiplies at k-chunk kc, k-step j -- the SAME enumeration as the chained layers -- contiguous from lq * 16
+__device__ __forceinline__ int cpos(int c) { return ((c >> 2) & 3) * 16 + (c >> 4) * 4 + (c & 3); }
+constexpr int AM_MAXW = 16 * AM_MAXMT;
+
+struct ChainArgs {
+    const float* w; int stride, cin, cout;             // natural-order rows [16 MT][stride] + bias [16 MT]
+    float* out; float* saved; size_t soff;             // global outputs (last layer / training copies)
+    int b, N, col, li, lq; bool first, last;
+};
+
+// m-tiles h (and h + 1 if TWO) of a layer: NC = compile-time bound on the k-chunks (16 channels = 4 k-steps each)
+template <int NC, bool TWO, bool FIRST>
+__device__ __forceinline__ void chain_tiles(const ChainArgs& a, int h, int nkc, const float* bias, const float (&fb0)[16],
+                                            const float (&zin)[AM_MAXMT][4], f32x4 (&acc)[2])
+{
+    constexpr int NT = TWO ? 2 : 1;
+    const float* r[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * (h + m) + 4 * a.lq);
+        acc[m] = f32x4{bv.x, bv.y, bv.z, bv.w};
+        r[m] = a.w + (16 * (h + m) + a.li) * a.stride + 4 * a.lq;
+    }
+#pragma unroll
+    for (int kc = 0; kc < NC; ++kc) {
+        if (kc < nkc) {                                     // uniform
+            float av[NT][4], bb[4];
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {                  // channels 16 kc + 4 lq + j: one quad of the natural-order row
+                const float4 u = *reinterpret_cast<const float4*>(r[m] + 16 * kc);
+                av[m][0] = u.x; av[m][1] = u.y; av[m][2] = u.z; av[m][3] = u.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bb[j] = FIRST ? fb0[(4 * kc + j) & 15] : zin[kc][j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < NT; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][j], bb[j], acc[m], 0, 0, 0);
+        }
+    }
+}
+
+// one layer; NC bounds both its m-tiles and its k-chunks at compile time (2, 4 or 8: widths <= 32, 64, 128)
+template <int NC, bool FIRST>
+__device__ __forceinline__ void chain_layer(const ChainArgs& a, const float (&fb0)[16], const float (&zin)[AM_MAXMT][4],
+                                            float (&zout)[AM_MAXMT][4])
+{
+    const int MT = pad16(a.cout) / 16;
+    const int nkc = (a.cin + 15) / 16;
+    const float* bias = a.w + MT * 16 * a.stride;
+#pragma unroll
+    for (int h = 0; h < NC; h += 2) {
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if (h + 1 < MT) chain_tiles<NC, true, FIRST>(a, h, nkc, bias, fb0, zin, acc);          // uniform branches
+        else if (h < MT) chain_tiles<NC, false, FIRST>(a, h, nkc, bias, fb0, zin, acc);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                zout[h + m][rr] = (h + m < MT) ? (a.last ? acc[m][rr] : tanh_fast(acc[m][rr])) : 0.f;
+    }
+#pragma unroll
+    for (int mt = NC; mt < AM_MAXMT; ++mt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) zout[mt][rr] = 0.f;
+    // global copies: the last layer's rows are the action; hidden activations only when training asked for them
+    float* dst = a.last ? a.out : a.saved;
+    if (dst != nullptr && a.col < a.N) {
+        const size_t base = (a.last ? 0 : a.soff) + (size_t)a.b * a.cout * a.N + a.col;
+#pragma unroll
+        for (int mt = 0; mt < NC; ++mt)
+            if (mt < MT) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int c = 16 * mt + 4 * a.lq + rr;
+                    if (c < a.cout) dst[base + (size_t)c * a.N] = zout[mt][rr];
+                }
+            }
+    }
+}
+
+template <bool FIRST>
+__device__ __forceinline__ void chain_layer_any(const ChainArgs& a, const float (&fb0)[16], const float (&zin)[AM_MAXMT][4],
+                                                float (&zout)[AM_MAXMT][4])
+{
+    const int big = max(a.cin, a.cout);
+    if (big <= 32) chain_layer<2, FIRST>(a, fb0, zin, zout);
+    else if (big <= 64) chain_layer<4, FIRST>(a, fb0, zin, zout);
+    else chain_layer<8, FIRST>(a, fb0, zin, zout);
+}
+
 template <int S, int FH>                  // S row steps (4 ceil(N / 16)); FH = ceil(F / 4) halves of the feature rows
 __global__ __launch_bounds__(AF_THREADS)
 void actor_fwd_mfma_kernel(const float* __restrict__ X, const float* __restrict__ G, float* __restrict__ out,
@@ -453,7 +537,6 @@ void actor_fwd_mfma_kernel(const float* __restrict__ X, const float* __restrict_
     const int b = blockIdx.x;
     const int F = P.dims[0], FK = F * K;
     float* ys = smem + cv.ys;
-    float* bufB = smem + cv.bufb;
     float* wl = smem + cv.w;
     const int ncols16 = pad16(N);
     AF_STAMP(0);
@@ -512,27 +595,22 @@ void actor_fwd_mfma_kernel(const float* __restrict__ X, const float* __restrict_
         // the four row classes are added through a per-wave LDS area (value-major, so every b128 access of the wave is
         // contiguous): lane (li, lq) collects column 4 g + lq -- float t = lq of all four classes, fixed order -- and
         // writes it.  Same-wave write -> read: ordered by the counter wait the compiler places, no barrier.
-        f32x4* red = reinterpret_cast<f32x4*>(smem + cv.red) + wave * (4 * FH * 64);
+        f32x4* red = reinterpret_cast<f32x4*>(smem + cv.red) + wave * (4 * 64);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int h = 0; h < FH; ++h) {                        // one feature half at a time through the same 4 KB (a wave's
+#pragma unroll                                                // LDS operations execute in order)
+            for (int t = 0; t < 4; ++t) red[t * 64 + lane] = acc[t][h];
+            const f32x4* p = red + lq * 64 + li;
+            f32x4 tot = p[0];
 #pragma unroll
-            for (int h = 0; h < FH; ++h) red[(t * FH + h) * 64 + lane] = acc[t][h];
-        f32x4 tot[FH];
-#pragma unroll
-        for (int h = 0; h < FH; ++h) {
-            const f32x4* p = red + (lq * FH + h) * 64 + li;
-            tot[h] = p[0];
-#pragma unroll
-            for (int q = 1; q < 4; ++q) tot[h] += p[16 * q];
-        }
-        if (li < ng) {
-#pragma unroll
-            for (int h = 0; h < FH; ++h)
+            for (int q = 1; q < 4; ++q) tot += p[16 * q];
+            if (li < ng) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int c = 4 * h + i;
-                    if (c < F) ys[(4 * g + lq) * AF_CS + bpos(c * K + k)] = tot[h][i];
+                    if (c < F) ys[(4 * g + lq) * AF_CS + cpos(c * K + k)] = tot[i];
                 }
+            }
         }
         AF_STAMP(3);
     } else if (staging) {
@@ -544,7 +622,7 @@ void actor_fwd_mfma_kernel(const float* __restrict__ X, const float* __restrict_
         // next layer reads; padded COLUMNS only ever feed their own, never stored, outputs).  One column per thread; the
         // streaming waves fill the other channels, so no barrier has to order the two.
         if (st < ncols16)
-            for (int q = FK; q < pad16(FK); ++q) ys[st * AF_CS + bpos(q)] = 0.f;
+            for (int q = FK; q < pad16(FK); ++q) ys[st * AF_CS + cpos(q)] = 0.f;
         // The weight area is cut at a row boundary (WC.split); staging wave 0 owns everything below, wave 1 everything
         // above: zeros first (k-step / m-tile padding of the natural-order rows), then -- the wave's own stores retired --
         // row o of W_l straight to its padded-stride place by LDS-DMA (no registers, no index arithmetic), biases likewise.
@@ -562,7 +640,12 @@ void actor_fwd_mfma_kernel(const float* __restrict__ X, const float* __restrict_
             const int olo = sw ? WC.osplit[l] : 0, ohi = sw ? cout : WC.osplit[l];
             if (lane < cin)
                 for (int o = olo; o < ohi; ++o) lds_dma_dword(src + o * cin, dst + o * stride);
-            if (WC.bias_owner[l] == sw && lane < cout) lds_dma_dword(P.b[l] + lane, dst + mtiles(cout) * 16 * stride);
+            if (lane + 64 < cin)                               // rows wider than a wave: the second half
+                for (int o = olo; o < ohi; ++o) lds_dma_dword(src + o * cin + 64, dst + o * stride + 64);
+            if (WC.bias_owner[l] == sw) {
+                if (lane < cout) lds_dma_dword(P.b[l] + lane, dst + pad16(cout) * stride);
+                if (lane + 64 < cout) lds_dma_dword(P.b[l] + lane + 64, dst + pad16(cout) * stride + 64);
+            }
         }
         AF_STAMP_T(16, 64 * nstream);
         AF_STAMP_T(17, 64 * nstream);
@@ -575,27 +658,42 @@ void actor_fwd_mfma_kernel(const float* __restrict__ X, const float* __restrict_
         float* sy = saved + (size_t)b * FK * N;
         for (int i = tid; i < FK * N; i += AF_THREADS) {
             const int q = i / N, col = i - q * N;
-            sy[(size_t)q * N + col] = ys[col * AF_CS + bpos(q)];
+            sy[(size_t)q * N + col] = ys[col * AF_CS + cpos(q)];
         }
     }
     AF_STAMP(5);
     const int NT = ncols16 / 16;
     if (wave < NT) {
+        const int col = wave * 16 + li;
+        float fb0[16];
+        {
+            const float4* pb = reinterpret_cast<const float4*>(ys + col * AF_CS + lq * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float4 t = pb[i]; fb0[4 * i] = t.x; fb0[4 * i + 1] = t.y; fb0[4 * i + 2] = t.z; fb0[4 * i + 3] = t.w; }
+        }
+        float za[AM_MAXMT][4], zb[AM_MAXMT][4];
+#pragma unroll
+        for (int mt = 0; mt < AM_MAXMT; ++mt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) { za[mt][rr] = 0.f; zb[mt][rr] = 0.f; }
         size_t soff = (size_t)B * FK * N;
-        for (int l = 0; l < P.n_layers; ++l) {
-            const int cin = (l == 0) ? FK : P.dims[l];
-            const int cout = P.dims[l + 1];
-            const float* bin = (l & 1) ? bufB : ys;
-            float* bout = (l & 1) ? ys : bufB;
-            const bool last = (l == P.n_layers - 1);
-            MlpArgs ma = {bin, bout, wl + WC.lw[l], out, saved, soff, pad4(cin) / 4, cout, N, 0, N, b, wave, lane, last,
-                          WC.lstride[l]};
-            const int MT = mtiles(cout);
-            if (MT == 1) mlp_layer<1, true>(ma);
-            else if (MT == 2) mlp_layer<2, true>(ma);
-            else mlp_layer<4, true>(ma);
-            soff += (size_t)B * cout * N;
-            AF_STAMP(6 + l);
+        for (int l = 0; l < P.n_layers; l += 2) {            // two layers per trip: the ping-pong stays in registers
+            {
+                const int cin = (l == 0) ? FK : P.dims[l], cout = P.dims[l + 1];
+                ChainArgs ca = {wl + WC.lw[l], WC.lstride[l], cin, cout, out, saved, soff, b, N, col, li, lq,
+                                l == 0, l == P.n_layers - 1};
+                if (l == 0) chain_layer_any<true>(ca, fb0, zb, za); else chain_layer_any<false>(ca, fb0, zb, za);
+                soff += (size_t)B * cout * N;
+                AF_STAMP(6 + l);
+            }
+            if (l + 1 < P.n_layers) {
+                const int cin = P.dims[l + 1], cout = P.dims[l + 2];
+                ChainArgs ca = {wl + WC.lw[l + 1], WC.lstride[l + 1], cin, cout, out, saved, soff, b, N, col, li, lq,
+                                false, l + 1 == P.n_layers - 1};
+                chain_layer_any<false>(ca, fb0, za, zb);
+                soff += (size_t)B * cout * N;
+                AF_STAMP(7 + l);
+            }
         }
     }
 }
@@ -770,13 +868,19 @@ bool make_plan(const int* dims, int n_layers, int K, int N, bool vec_ok, Plan* p
 
 // MFMA aggregation variant: which shapes, its LDS carve-up and where each layer's weights sit
 struct PlanM { int S, nblk; CarveM cv; WLayout wc; };
+constexpr int AM_LDS_LIMIT = 156 * 1024;  // of the CU's 160 KB: [18 -> 128 -> 128 -> 2] at N = 100 needs 149 KB
 
 inline int nat_stride(int cin) { return 16 * ((cin + 15) / 16) + 4; }
 
-bool make_plan_mfma(const Plan& pl, const float* const* W, const float* const* bias, const int* dims, int n_layers,
-                    int K, int N, PlanM* pm)
+// W / bias may be null (mgp_actor_supported: shapes only, pointers assumed 4-byte aligned like every float array)
+bool make_plan_mfma(const float* const* W, const float* const* bias, const int* dims, int n_layers, int K, int N,
+                    bool vec_ok, PlanM* pm)
 {
-    if (pl.V != 4 || N > 128 || N < 16) return false;
+    if (n_layers <= 0 || n_layers > MGP_MAX_LAYERS || K <= 0) return false;
+    const int F = dims[0];
+    if (F <= 0 || F > 8 || F * K > AF_MAXW) return false;      // layer 0's B operand: 16 k-steps of the aggregation tile
+    for (int i = 1; i <= n_layers; ++i) if (dims[i] <= 0 || dims[i] > AM_MAXW) return false;
+    if (!vec_ok || N % 4 != 0 || N > 128 || N < 16) return false;
     const int gtot = N / 4;
     pm->nblk = gtot > 16 ? 2 : 1;
     if (K * pm->nblk > AF_WAVES - 2) return false;             // two waves stage the weights
@@ -786,11 +890,11 @@ bool make_plan_mfma(const Plan& pl, const float* const* W, const float* const* b
     for (int l = 0; l < MGP_MAX_LAYERS; ++l) wc.lw[l] = wc.lstride[l] = wc.osplit[l] = wc.bias_owner[l] = 0;
     int rows_total = 0;
     for (int l = 0; l < n_layers; ++l) {
-        const int cin = (l == 0) ? dims[0] * K : dims[l], cout = dims[l + 1];
-        if ((reinterpret_cast<uintptr_t>(W[l]) | reinterpret_cast<uintptr_t>(bias[l])) & 3u) return false;
+        const int cin = (l == 0) ? F * K : dims[l], cout = dims[l + 1];
+        if (W != nullptr && ((reinterpret_cast<uintptr_t>(W[l]) | reinterpret_cast<uintptr_t>(bias[l])) & 3u)) return false;
         const int stride = nat_stride(cin);
         wc.lw[l] = wtot; wc.lstride[l] = stride;
-        wtot += mtiles(cout) * 16 * stride + mtiles(cout) * 16;
+        wtot += pad16(cout) * stride + pad16(cout);             // rows of the m-tiles + bias
         wtot = (wtot + 3) & ~3;
         rows_total += cout;
     }
@@ -802,14 +906,14 @@ bool make_plan_mfma(const Plan& pl, const float* const* W, const float* const* b
         os = os < 0 ? 0 : (os > cout ? cout : os);
         wc.osplit[l] = os;
         if (os < cout && wc.split == wtot) wc.split = wc.lw[l] + os * wc.lstride[l];
-        wc.bias_owner[l] = (wc.lw[l] + mtiles(cout) * 16 * wc.lstride[l] >= wc.split) ? 1 : 0;
+        wc.bias_owner[l] = (wc.lw[l] + pad16(cout) * wc.lstride[l] >= wc.split) ? 1 : 0;
         seen += cout;
     }
     const int buf = pad16(N) * AF_CS;
-    pm->cv.ys = 0; pm->cv.bufb = buf; pm->cv.w = 2 * buf; pm->cv.wtot = wtot;
-    pm->cv.red = (2 * buf + wtot + 3) & ~3;                    // per streaming wave: 4 * FH (<= 8) float4 per lane
-    pm->cv.total = pm->cv.red + K * pm->nblk * 8 * 64 * 4;
-    return (size_t)pm->cv.total * sizeof(float) <= AF_LDS_LIMIT;
+    pm->cv.ys = 0; pm->cv.w = buf; pm->cv.wtot = wtot;
+    pm->cv.red = (buf + wtot + 3) & ~3;                        // per streaming wave: 4 float4 per lane
+    pm->cv.total = pm->cv.red + K * pm->nblk * 4 * 64 * 4;
+    return (size_t)pm->cv.total * sizeof(float) <= AM_LDS_LIMIT;
 }
 
 template <int S, int FH>
@@ -853,8 +957,10 @@ extern "C" long mgp_actor_saved_floats(const int* dims, int n_layers, int B, int
 extern "C" int mgp_actor_supported(const int* dims, int n_layers, int K, int N)
 {
     if (dims == nullptr) return 0;
+    if (n_layers <= 0 || n_layers > MGP_MAX_LAYERS || K <= 0 || N <= 0) return 0;
     Plan pl;
-    return make_plan(dims, n_layers, K, N, true, &pl) ? 1 : 0;
+    PlanM pm;
+    return (make_plan_mfma(nullptr, nullptr, dims, n_layers, K, N, true, &pm) || make_plan(dims, n_layers, K, N, true, &pl)) ? 1 : 0;
 }
 
 extern "C" int mgp_actor_fwd(const float* X, const float* G, const float* const* W, const float* const* b,
@@ -866,20 +972,17 @@ extern "C" int mgp_actor_fwd(const float* X, const float* G, const float* const*
     if (B == 0) return MGP_OK;
     MGP_CHECK_PTR(X); MGP_CHECK_PTR(G); MGP_CHECK_PTR(out);
     if (saved != nullptr && (reinterpret_cast<uintptr_t>(saved) & 3u)) return MGP_EALIGN;
-    Plan pl;
-    if (!make_plan(dims, n_layers, K, N, mgp_aligned16(G), &pl)) return MGP_EUNSUPPORTED;
-    if ((long)B * pl.ntiles > 2147483647L) return MGP_EINVAL;
     ActorParams P;
     P.n_layers = n_layers;
     for (int i = 0; i <= n_layers; ++i) P.dims[i] = dims[i];
     for (int l = 0; l < n_layers; ++l) {
         MGP_CHECK_PTR(W[l]); MGP_CHECK_PTR(b[l]);
-        P.W[l] = W[l]; P.b[l] = b[l]; P.woff[l] = pl.woff[l];
+        P.W[l] = W[l]; P.b[l] = b[l]; P.woff[l] = 0;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     mgp_clear_error();
     PlanM pm;
-    if (mgp_aligned16(X) && make_plan_mfma(pl, W, b, dims, n_layers, K, N, &pm)) {      // X operands are float4 loads
+    if (make_plan_mfma(W, b, dims, n_layers, K, N, mgp_aligned16(G) && mgp_aligned16(X), &pm)) {   // G, X: float4 loads
 #define MGP_AM_CASE(S_) return dims[0] <= 4 ? launch_fwd_mfma<S_, 1>(X, G, out, saved, P, pm, B, K, N, st) \
                                              : launch_fwd_mfma<S_, 2>(X, G, out, saved, P, pm, B, K, N, st)
         if (pm.S <= 16) MGP_AM_CASE(16);
@@ -887,6 +990,10 @@ extern "C" int mgp_actor_fwd(const float* X, const float* G, const float* const*
         MGP_AM_CASE(32);
 #undef MGP_AM_CASE
     }
+    Plan pl;
+    if (!make_plan(dims, n_layers, K, N, mgp_aligned16(G), &pl)) return MGP_EUNSUPPORTED;
+    if ((long)B * pl.ntiles > 2147483647L) return MGP_EINVAL;
+    for (int l = 0; l < n_layers; ++l) P.woff[l] = pl.woff[l];
 #define MGP_AF_CASE(CT, V) return launch_fwd<CT, V>(X, G, out, saved, P, pl, B, K, N, st)
     if (pl.V == 4) {
         if (pl.CT == 4) MGP_AF_CASE(4, 4);
@@ -910,10 +1017,29 @@ static long bwd_param_count(const int* dims, int n_layers, int K)
     return P;
 }
 
+// LDS bytes of the backward kernel at `cols` agent columns per workgroup, and the column count used for a problem: the
+// 64-column shape when it pays and fits (128-wide layers only fit at 16 columns)
+static size_t bwd_lds(const int* dims, int n_layers, int K, int cols)
+{
+    int maxw = dims[n_layers], maxin = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        const int cin = (l == 0) ? dims[0] * K : dims[l], cout = dims[l + 1];
+        if (cout > maxw) maxw = cout;
+        if (cin > maxin) maxin = cin;
+        if (cin > maxw && l > 0) maxw = cin;
+    }
+    return ((size_t)2 * maxw * (cols + 1) + (size_t)maxin * (cols + 1) + (size_t)maxw * maxin) * sizeof(float);
+}
+static int bwd_cols_fit(const int* dims, int n_layers, int B, int K, int N)
+{
+    const int cols = bwd_cols(B, N);
+    return (cols == 64 && bwd_lds(dims, n_layers, K, 64) > (size_t)AF_LDS_LIMIT) ? 16 : cols;
+}
+
 extern "C" long mgp_actor_bwd_workspace(const int* dims, int n_layers, int B, int K, int N)
 {
     if (dims == nullptr || n_layers <= 0 || n_layers > MGP_MAX_LAYERS || B <= 0 || K <= 0 || N <= 0) return 0;
-    const int cols = bwd_cols(B, N);
+    const int cols = bwd_cols_fit(dims, n_layers, B, K, N);
     const long ntiles = (long)B * ((N + cols - 1) / cols);
     return ntiles * bwd_param_count(dims, n_layers, K);
 }
@@ -948,8 +1074,8 @@ extern "C" int mgp_actor_bwd(const float* dOut, const float* saved, const float*
         if (cin > maxw && l > 0) maxw = cin;
     }
     const long Ptot = poff;
-    const int cols = bwd_cols(B, N);
-    const size_t lds = ((size_t)2 * maxw * (cols + 1) + (size_t)maxin * (cols + 1) + (size_t)maxw * maxin) * sizeof(float);
+    const int cols = bwd_cols_fit(dims, n_layers, B, K, N);
+    const size_t lds = bwd_lds(dims, n_layers, K, cols);
     if (lds > AF_LDS_LIMIT) return MGP_EUNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     mgp_clear_error();

@@ -19,7 +19,7 @@ def random_actor_case(rs):
     B = int(rs.randint(1, 5)); K = int(rs.randint(1, 5)); F = int(rs.choice([1, 2, 3, 6, 6, 6, 8, 11]))
     N = int(rs.choice([1, 3, 7, 16, 31, 64, 100, 100, 129, 180, 257]))
     n_hidden = int(rs.randint(0, 5))
-    hidden = [int(rs.choice([1, 4, 5, 16, 32, 32, 48, 64, 96])) for _ in range(n_hidden)]
+    hidden = [int(rs.choice([1, 4, 5, 16, 32, 32, 48, 64, 96, 128])) for _ in range(n_hidden)]
     n_a = int(rs.choice([1, 2, 2, 3]))
     ind_agg = int(rs.randint(0, n_hidden + 1))
     return B, K, F, N, hidden, n_a, ind_agg
@@ -69,7 +69,7 @@ def test_actor_fwd_mfma_variant_shapes(N, K):
     seed = 31 * N + K
     rs = np.random.RandomState(seed)
     F = int(rs.choice([1, 3, 6, 8])); B = int(rs.choice([1, 3, 9]))
-    hidden = [int(rs.choice([4, 16, 20, 32, 64])) for _ in range(int(rs.randint(0, 4)))]
+    hidden = [int(rs.choice([4, 16, 20, 32, 64, 80, 128])) for _ in range(int(rs.randint(0, 4)))]
     torch.manual_seed(seed)
     actor = Actor(F, 2, hidden, K, 0).cuda()
     actor.use_fused = True
