@@ -39,6 +39,9 @@ __device__ unsigned long long mgp_af_stamps[64];
 #define AF_STAMP(i) do { } while (0)
 #define AF_STAMP_T(i, t) do { } while (0)
 #endif
+#define AGG_STAMP(i) AF_STAMP(i)
+#include "agg_mfma.h"
+
 
 struct ActorParams {
     const float* W[MGP_MAX_LAYERS];
@@ -543,75 +546,22 @@ void actor_fwd_mfma_kernel(const float* __restrict__ X, const float* __restrict_
     const int nstream = K * nblk;                                // waves 0 .. nstream-1 stream, the next two stage
     const bool staging = wave >= nstream && wave < nstream + 2;
     if (wave < nstream) {
-        // ---- (a) this wave's share of the operator, in consumption order (vmcnt retires in order; the scheduler is
-        //      kept from reversing the batch).  Row of (step s, lane quarter lq): 16 (s >> 2) + 4 lq + (s & 3), so that a
-        //      lane's X operands of four consecutive steps are one aligned float4.
+        // ---- (a) this wave's share of the operator: tap k, column block blk (agg_mfma.h)
         const int gtot = N >> 2, g0 = (nblk == 2) ? ((gtot + 1) >> 1) : gtot;
         const int k = wave / nblk, blk = wave - k * nblk;
         const int ng = blk ? gtot - g0 : g0;
         const int g = blk * g0 + min(li, ng - 1);
-        const float* Gk = G + ((size_t)b * K + k) * (size_t)N * N + 4 * g;
-        const float* Xk = X + ((size_t)b * K + k) * (size_t)F * N;
-        f32x4 xa[FH][S / 4];
-        f32x4 gv[S];
+        agg_mfma_unit<S, FH>(G + ((size_t)b * K + k) * (size_t)N * N + 4 * g, X + ((size_t)b * K + k) * (size_t)F * N, N, F, N,
+                             lane, reinterpret_cast<f32x4*>(smem + cv.red) + wave * (4 * 64),
+                             [&](int h, const f32x4& tot) {
+                                 if (li < ng) {
 #pragma unroll
-        for (int h = 0; h < FH; ++h) {
-            const float* xr = Xk + (size_t)min(4 * h + (li & 3), F - 1) * N;
-#pragma unroll
-            for (int t4 = 0; t4 < S / 4; ++t4)
-                xa[h][t4] = *reinterpret_cast<const f32x4*>(xr + min(16 * t4 + 4 * lq, N - 4));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            gv[s] = *reinterpret_cast<const f32x4*>(Gk + (size_t)min(16 * (s >> 2) + 4 * lq + (s & 3), N - 1) * N);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        AF_STAMP(1);
-        // ---- (b) aggregation on the matrix pipe as the rows arrive: v_mfma_f32_4x4x1 (16 independent 4x4 outer
-        //      products per instruction; lanes 4 q .. 4 q + 3 are block q, D[i] of lane l = A(lane 4 (l >> 2) + i) * B(lane
-        //      l)).  Block = (lq, li >> 2): its four lanes hold the same row and four adjacent column groups; instruction
-        //      (t, h) multiplies features 4 h + 0..3 (A: the lane with li & 3 == i supplies X[4 h + i][row]) into float t
-        //      of every lane's G quad, i.e. column 4 g + t.  6 of the 8 A rows carry features (the 16x16x4 shape would use
-        //      6 of 16: twice the pipe time).  What a lane accumulates is the sum over ITS row class lq.
-        f32x4 acc[4][FH];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int h = 0; h < FH; ++h) acc[t][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < S; ++s) {                         // rows past N: clamped addresses times a = 0
-            const bool rok = 16 * (s >> 2) + 4 * lq + (s & 3) < N;
-#pragma unroll
-            for (int h = 0; h < FH; ++h) {
-                const float a = (rok && 4 * h + (li & 3) < F) ? xa[h][s >> 2][s & 3] : 0.f;
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    acc[t][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, gv[s][t], acc[t][h], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        AF_STAMP(2);
-        // the four row classes are added through a per-wave LDS area (value-major, so every b128 access of the wave is
-        // contiguous): lane (li, lq) collects column 4 g + lq -- float t = lq of all four classes, fixed order -- and
-        // writes it.  Same-wave write -> read: ordered by the counter wait the compiler places, no barrier.
-        f32x4* red = reinterpret_cast<f32x4*>(smem + cv.red) + wave * (4 * 64);
-#pragma unroll
-        for (int h = 0; h < FH; ++h) {                        // one feature half at a time through the same 4 KB (a wave's
-#pragma unroll                                                // LDS operations execute in order)
-            for (int t = 0; t < 4; ++t) red[t * 64 + lane] = acc[t][h];
-            const f32x4* p = red + lq * 64 + li;
-            f32x4 tot = p[0];
-#pragma unroll
-            for (int q = 1; q < 4; ++q) tot += p[16 * q];
-            if (li < ng) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = 4 * h + i;
-                    if (c < F) ys[(4 * g + lq) * AF_CS + cpos(c * K + k)] = tot[i];
-                }
-            }
-        }
+                                     for (int i = 0; i < 4; ++i) {
+                                         const int c = 4 * h + i;
+                                         if (c < F) ys[(4 * g + lq) * AF_CS + cpos(c * K + k)] = tot[i];
+                                     }
+                                 }
+                             });
         AF_STAMP(3);
     } else if (staging) {
         // ---- (c) the two staging waves: weights and zero fill, all in the shadow of the stream (ONE barrier in the kernel)

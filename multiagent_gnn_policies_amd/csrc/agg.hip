@@ -10,6 +10,7 @@
 //     CT multipliers of one row come from one or two wide, mostly-broadcast ds_reads;
 //   * the R row-phases are combined through LDS in a fixed order (deterministic, no atomics).
 #include "mgp_common.h"
+#include "agg_mfma.h"
 
 namespace {
 
@@ -213,6 +214,48 @@ int launch_agg_fwd(const float* X, const float* G, float* Y, int B, int K, int C
     return mgp_launch_status();
 }
 
+// ---- forward on the matrix pipe (agg_mfma.h): one workgroup (8 waves) per episode, wave = (tap, column block of <= 16
+// four-column groups) streaming ALL N rows of its columns with every request issued up front; row sums live in the
+// 4x4x1 MFMA accumulators, no row-phase combine through LDS, no barrier at all.  16 <= N <= 128 (N % 4 == 0), C <= 8.
+// 9.3 us at B = 256, N = 100, K = 3 (3.7 TB/s) against 12.3 us for the VALU kernel above.
+constexpr int AGM_THREADS = 512;
+
+template <int S, int FH>
+__global__ __launch_bounds__(AGM_THREADS)
+void agg_fwd_mfma_kernel(const float* __restrict__ X, const float* __restrict__ G, float* __restrict__ Y,
+                         int K, int C, int N, int nblk, long sxb, long sxk, long sxc, long syb, long syk, long syc)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int b = blockIdx.x;
+    const int gtot = N >> 2, g0 = (nblk == 2) ? ((gtot + 1) >> 1) : gtot;
+    f32x4* red = reinterpret_cast<f32x4*>(smem) + wave * (4 * 64);
+    if (wave < K * nblk) {                                     // one unit per wave (the dispatcher checks K * nblk <= 8)
+        const int k = wave / nblk, blk = wave - k * nblk;
+        const int ng = blk ? gtot - g0 : g0;
+        const int g = blk * g0 + min(li, ng - 1);
+        float* Yk = Y + (size_t)b * syb + (size_t)k * syk + 4 * g + lq;
+        agg_mfma_unit<S, FH>(G + ((size_t)b * K + k) * (size_t)N * N + 4 * g, X + (size_t)b * sxb + (size_t)k * sxk, sxc, C, N,
+                             lane, red, [&](int h, const f32x4& tot) {
+                                 if (li < ng) {
+#pragma unroll
+                                     for (int i = 0; i < 4; ++i)
+                                         if (4 * h + i < C) Yk[(size_t)(4 * h + i) * syc] = tot[i];
+                                 }
+                             });
+    }
+}
+
+template <int S, int FH>
+int launch_agg_fwd_mfma(const float* X, const float* G, float* Y, int B, int K, int C, int N, int nblk,
+                        long sxb, long sxk, long sxc, long syb, long syk, long syc, hipStream_t st)
+{
+    hipLaunchKernelGGL((agg_fwd_mfma_kernel<S, FH>), dim3((unsigned)B), dim3(AGM_THREADS), (AGM_THREADS / 64) * 4 * 64 * 16, st,
+                       X, G, Y, K, C, N, nblk, sxb, sxk, sxc, syb, syk, syc);
+    return mgp_launch_status();
+}
+
 template <int V>
 int dispatch_agg_fwd(const float* X, const float* G, float* Y, int B, int K, int C, int N,
                      long sxb, long sxk, long sxc, long syb, long syk, long syc, hipStream_t st)
@@ -253,6 +296,16 @@ extern "C" int mgp_agg_fwd(const float* X, const float* G, float* Y, int B, int 
     hipStream_t st = static_cast<hipStream_t>(stream);
     mgp_clear_error();
     const bool vec = (N % 4 == 0) && mgp_aligned16(G);
+    const int nblk = N > 64 ? 2 : 1;
+    if (vec && N >= 16 && N <= 128 && C <= 8 && K * nblk <= AGM_THREADS / 64 && mgp_aligned16(X) && sxb % 4 == 0 &&
+        sxk % 4 == 0 && sxc % 4 == 0) {                        // X quads are aligned float4 loads
+#define MGP_AGM_CASE(S_) return C <= 4 ? launch_agg_fwd_mfma<S_, 1>(X, G, Y, B, K, C, N, nblk, sxb, sxk, sxc, syb, syk, syc, st) \
+                                       : launch_agg_fwd_mfma<S_, 2>(X, G, Y, B, K, C, N, nblk, sxb, sxk, sxc, syb, syk, syc, st)
+        if (N <= 64) MGP_AGM_CASE(16);
+        if (N <= 112) MGP_AGM_CASE(28);
+        MGP_AGM_CASE(32);
+#undef MGP_AGM_CASE
+    }
     if (vec) return dispatch_agg_fwd<4>(X, G, Y, B, K, C, N, sxb, sxk, sxc, syb, syk, syc, st);
     return dispatch_agg_fwd<1>(X, G, Y, B, K, C, N, sxb, sxk, sxc, syb, syk, syc, st);
 }

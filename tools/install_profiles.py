@@ -35,7 +35,7 @@ note = ("# rocprofv3 --kernel-trace --stats of `python bench.py --gpus 1 --steps
         "#      two-launch path (timed in the same run) and to the stand-alone dense-kernel roofline leg.\n")
 open('profiles/%s_bench_kernel_trace.txt' % R, 'w').write(''.join(kt[:2]) + note + ''.join(kt[2:]))
 shutil.copy(O + '/dagger_update.json', 'profiles/%s_dagger_update.json' % R)
-hdr = ("# bench.py at other shapes (B N K), 100-step launches right after reset: value, per-path throughput, in-run parity gate, per-kernel\n"
+hdr = ("# bench.py at other shapes (B N K, hidden width x layers), 100-step launches right after reset: value, per-path throughput, in-run parity gate, per-kernel\n"
        "# (avg launch us, GB/s), state finite.  `resident` = mgp_rollout_steps_ex (N <= 256); `factored` = HBM bit-row state (N > 256)\n")
 open('profiles/%s_other_configs.txt' % R, 'w').write(hdr + open(O + '/other_configs.txt').read())
 open('profiles/%s_rollout_phase_stamps.txt' % R, 'w').write(
@@ -48,5 +48,12 @@ open('profiles/%s_rollout_launch_cost.txt' % R, 'w').write(
     "# launch length sweep, B=256 N=100 K=3, lattice harness state: dense hand-over (mgp_rollout_steps) vs [carry] = factored hand-over +\n"
     "# prebuilt weight image + dense slices on demand (mgp_rollout_steps_ex); us per launch averaged over 20 back-to-back launches\n"
     + open(O + '/rollout_launch_cost.txt').read())
+open('profiles/%s_actor_fwd_phase_stamps.txt' % R, 'w').write(
+    "# tools/harness/af_phase_prof.hip on MI355X: in-kernel s_memtime stamps of workgroup 0 of actor_fwd_mfma_kernel<28, 2> (shader cycles),\n"
+    "# B = 256 (one workgroup per CU) and B = 1.  Thread 0 (a streaming wave): 1 = its X + G requests issued | 2 = its 4x4x1 MFMAs done\n"
+    "# (consumed as the rows land) | 3 = row classes added, aggregation tile written | 4 = THE barrier passed (all streaming waves + the\n"
+    "# staging waves) | 5 = MLP start | 6, 7, 8 = end of layers 0, 1, 2 (register-chained).  First thread of staging wave 0: 16 = weight area\n"
+    "# zeroed, all LDS-DMA rows issued | 19 = they have landed.\n"
+    + open(O + '/actor_fwd_phase_stamps.txt').read())
 from multiagent_gnn_policies_amd import build
 print('hash ok', build.source_hash() == json.load(open('profiles/%s_pmc_traffic.json' % R))['_meta']['source_hash'])

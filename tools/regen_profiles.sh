@@ -40,13 +40,16 @@ RO_CARRY=1 ./scratch/ro_prof 256 100 3 200 > $O/rollout_phase_stamps.txt 2>&1
 python tools/dump_rollout_state.py /tmp/ro_state5.bin 5 > /dev/null 2>&1
 RO_STATE=/tmp/ro_state5.bin RO_CARRY=1 ./scratch/ro_prof 256 100 3 20 20 >> $O/rollout_phase_stamps.txt 2>&1
 for T in 1 2 5 20 200; do ./scratch/ro_prof 256 100 3 $T 20 | head -1; RO_CARRY=1 ./scratch/ro_prof 256 100 3 $T 20 | head -1; done 2>/dev/null > $O/rollout_launch_cost.txt
+# 3b. phase stamps of the fused Actor forward (MFMA aggregation variant), B = 256 and B = 1
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -w -o /tmp/af_prof tools/harness/af_phase_prof.hip 2>/dev/null
+{ /tmp/af_prof 256 100; /tmp/af_prof 1 100; } > $O/actor_fwd_phase_stamps.txt 2>&1
 # 4. DAGGER update / collection + other configs
 python tools/bench_update.py > $O/dagger_update.json 2> $O/dagger_update.err
-for cfg in "64 1000 3" "256 200 4" "1 100 3" "2048 100 3" "256 100 4" "256 100 2" "256 125 3" "256 50 2"; do set -- $cfg; python bench.py --episodes $1 --agents $2 --taps $3 --no-cpu-baseline --steps 100 --warmup 10 2>/dev/null | python -c "
+for cfg in "64 1000 3 32 2" "256 200 4 32 2" "1 100 3 32 2" "2048 100 3 32 2" "256 100 4 32 2" "256 100 2 32 2" "256 125 3 32 2" "256 50 2 32 2" "256 100 3 64 2" "256 100 3 128 1" "256 100 3 128 2"; do set -- $cfg; python bench.py --episodes $1 --agents $2 --taps $3 --hidden $4 --layers $5 --no-cpu-baseline --steps 100 --warmup 10 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 k = {a: (round(v['avg_launch_ms']*1e3,1), round(v['GBps'])) for a, v in d.get('kernels', {}).items()}
-print('$1 $2 $3', 'value %.3e' % d['value'], 'ms/step %.4f' % d['ms_per_step'], 'paths', {a: '%.3e' % b['value'] for a, b in d['paths'].items()}, 'parity ok', d['parity']['ok'], 'max_rel %.2e' % d['parity']['max_rel'], k, d['config']['state_finite'])
+print('$1 $2 $3 hidden $4 x $5', 'value %.3e' % d['value'], 'ms/step %.4f' % d['ms_per_step'], 'paths', {a: '%.3e' % b['value'] for a, b in d['paths'].items()}, 'parity ok', d['parity']['ok'], 'max_rel %.2e' % d['parity']['max_rel'], k, d['config']['state_finite'])
 " >> $O/other_configs.txt; done
 rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_fetch20 $O/pmc_write20 $O/trace
 ls -la $O
