@@ -687,8 +687,8 @@ def main():
             "actor_fwd": hbm_block('actor_fwd', "mgp_actor_fwd: actor_fwd_mfma_kernel for N <= 128 (aggregation X.G AND filter/"
                                    "MLP on fp32 MFMA, fused), actor_fwd_kernel otherwise: 4KN^2 + 4KFN + 4 nA N bytes per "
                                    "episode", ('actor_fwd_mfma_kernel', 'actor_fwd_kernel')),
-            "agg_fwd": hbm_block('agg_fwd', "agg_fwd_kernel (aggregation X.G alone): 4KN^2 + 8KFN bytes per episode",
-                                 ('agg_fwd_kernel',)),
+            "agg_fwd": hbm_block('agg_fwd', "mgp_agg_fwd: agg_fwd_mfma_kernel for N <= 128, agg_fwd_kernel otherwise (aggregation "
+                                 "X.G alone): 4KN^2 + 8KFN bytes per episode", ('agg_fwd_mfma_kernel', 'agg_fwd_kernel')),
             "sim_state_step": hbm_block('sim_state_step', "flock_step_kernel<advance> (sim step + delayed-GSO / delay-line "
                                         "transition, fused)", ('flock_step_kernel',)),
             "rotating_input_sets": n_sets,
