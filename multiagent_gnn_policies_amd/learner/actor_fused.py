@@ -73,6 +73,8 @@ def try_forward(actor, delay_state, delay_gso):
         return None
     X = delay_state.contiguous()
     G = delay_gso.contiguous()
+    if max(dims[1:]) > 64 and ((X.data_ptr() | G.data_ptr()) & 15):
+        return None         # widths above 64 are covered by the MFMA-aggregation variant only, which loads aligned quads
     params = []
     for conv in actor.conv_layers:
         out_c = conv.weight.shape[0]

@@ -23,7 +23,9 @@ def relerr(a, b):
 AGG_SHAPES = [(1, 3, 6, 100), (4, 3, 6, 100), (2, 4, 6, 200), (2, 2, 6, 16), (2, 1, 6, 16), (3, 2, 3, 7),
               (2, 3, 6, 33), (1, 3, 6, 260), (1, 2, 6, 1000), (2, 3, 32, 100), (1, 2, 40, 36), (2, 3, 1, 64),
               (1, 2, 12, 257), (1, 1, 6, 513), (2, 2, 8, 128), (1, 3, 16, 48),
-              (2, 2, 6, 129), (2, 2, 6, 130), (1, 3, 6, 255), (1, 2, 3, 201)]     # V = 1, one row phase (fuzz-found bug)
+              (2, 2, 6, 129), (2, 2, 6, 130), (1, 3, 6, 255), (1, 2, 3, 201),     # V = 1, one row phase (fuzz-found bug)
+              # the MFMA variant's corners (16 <= N <= 128, N % 4 == 0, C <= 8, K * column blocks <= 8) and just outside
+              (2, 4, 6, 64), (1, 3, 5, 68), (2, 3, 3, 124), (3, 4, 8, 128), (1, 8, 2, 20), (1, 5, 6, 100), (2, 3, 9, 100)]
 
 
 @pytest.mark.parametrize('shape', AGG_SHAPES)
