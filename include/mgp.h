@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define MGP_VERSION 200            /* 0.2.0: + mgp_rollout_steps_ex / _image / _carry_*, mgp_rollout_collect, mgp_replay_gather */
+#define MGP_VERSION 201            /* 0.2.0: + mgp_rollout_steps_ex / _image / _carry_*, mgp_rollout_collect, mgp_replay_gather;
+                                      0.2.1: + mgp_replay_gather_many; mgp_actor_fwd covers layer widths up to 128 at N <= 128 */
 
 #define MGP_OK            0
 #define MGP_EINVAL       -1        /* bad size / null pointer / unsupported combination */
@@ -282,6 +283,12 @@ int mgp_rollout_collect(double* x, float* G, float* Xd, const float* const* W, c
 int mgp_replay_gather(const float* feat, const unsigned long long* bits, const float* label, const int* age,
                       const long* idx, const int* cursor, int Bt, int lanes, int ring_steps, int K, int N, int mean_pooling,
                       float* X, float* G, float* Y, void* stream);
+/* The same for `nb` consecutive minibatches in one launch: sample s < nb * Bt uses idx[(cursor ? *cursor : 0) * Bt + s] and
+ * lands in X / G / Y slot s (buffers of nb * Bt samples) -- the gathers of a whole graph of updates do not depend on the
+ * weights, so they need not sit between the updates. */
+int mgp_replay_gather_many(const float* feat, const unsigned long long* bits, const float* label, const int* age,
+                           const long* idx, const int* cursor, int Bt, int nb, int lanes, int ring_steps, int K, int N,
+                           int mean_pooling, float* X, float* G, float* Y, void* stream);
 long mgp_rollout_image_floats(const int* dims, int n_layers, int K, int N);      /* 0: shape not covered */
 int mgp_rollout_image(const float* const* W, const float* const* b, const int* dims, int n_layers, int K, int N,
                       float* image, void* stream);

@@ -68,6 +68,7 @@ SIGNATURES = {
     'mgp_rollout_collect': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, ctypes.POINTER(MgpFlockParams),
                                   _int, _int, _int, _int, _vp, _vp, _int, _vp, _vp]),
     'mgp_replay_gather': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    'mgp_replay_gather_many': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     'mgp_rollout_image_floats': (_long, [_vp, _int, _int, _int]),
     'mgp_rollout_image': (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
     'mgp_rollout_carry_bytes': (_long, [_int, _int]),

@@ -25,7 +25,7 @@ void replay_gather_kernel(const float* __restrict__ feat, const unsigned long lo
                           const float* __restrict__ label, const int* __restrict__ age, const long* __restrict__ idx,
                           const int* __restrict__ cursor, int Bt, int lanes, int ring_steps, int K, int N, int mean_pooling,
                           float* __restrict__ X, float* __restrict__ G, float* __restrict__ Y)
-{
+{   // Bt = minibatch size = stride of `idx` per cursor step; gridDim.x = Bt * (minibatches gathered by this launch)
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     const int H = K > 1 ? K - 1 : 1, Np = (N + 3) & ~3;
     unsigned long long* sb = reinterpret_cast<unsigned long long*>(smraw);                  // [H][N][NW]
@@ -97,20 +97,21 @@ void replay_gather_kernel(const float* __restrict__ feat, const unsigned long lo
 
 }  // namespace
 
-extern "C" int mgp_replay_gather(const float* feat, const unsigned long long* bits, const float* label, const int* age,
-                                 const long* idx, const int* cursor, int Bt, int lanes, int ring_steps, int K, int N,
-                                 int mean_pooling, float* X, float* G, float* Y, void* stream)
+extern "C" int mgp_replay_gather_many(const float* feat, const unsigned long long* bits, const float* label, const int* age,
+                                      const long* idx, const int* cursor, int Bt, int nb, int lanes, int ring_steps, int K,
+                                      int N, int mean_pooling, float* X, float* G, float* Y, void* stream)
 {
-    if (Bt < 0 || lanes < 1 || ring_steps < 1 || K < 1 || K > 5 || N < 4) return MGP_EINVAL;
+    if (Bt < 0 || nb < 1 || lanes < 1 || ring_steps < 1 || K < 1 || K > 5 || N < 4) return MGP_EINVAL;
     if (N > 256) return MGP_EUNSUPPORTED;
     if (Bt == 0) return MGP_OK;
+    if ((long)Bt * nb > 2147483647L / 64) return MGP_EINVAL;
     MGP_CHECK_PTR(feat); MGP_CHECK_PTR8(bits); MGP_CHECK_PTR(label); MGP_CHECK_PTR(age); MGP_CHECK_PTR8(idx);
     MGP_CHECK_PTR(X); MGP_CHECK_PTR(G); MGP_CHECK_PTR(Y);
     if (cursor != nullptr && (reinterpret_cast<uintptr_t>(cursor) & 3u)) return MGP_EALIGN;
     const int H = K > 1 ? K - 1 : 1, Np = (N + 3) & ~3, NW = N > 128 ? 4 : 2;      // words per bit row: the collecting kernels' layout
     const int lds = H * N * NW * 8 + ((H * N + 3) & ~3) * 4 + RG_WAVES * 2 * Np * 4;
     mgp_clear_error();
-    const dim3 grid(Bt, 1 + (K - 1) * RG_SPLIT);
+    const dim3 grid(Bt * nb, 1 + (K - 1) * RG_SPLIT);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (NW == 2)
         hipLaunchKernelGGL(replay_gather_kernel<2>, grid, dim3(RG_THREADS), lds, st, feat, bits, label,
@@ -119,4 +120,12 @@ extern "C" int mgp_replay_gather(const float* feat, const unsigned long long* bi
         hipLaunchKernelGGL(replay_gather_kernel<4>, grid, dim3(RG_THREADS), lds, st, feat, bits, label,
                            age, idx, cursor, Bt, lanes, ring_steps, K, N, mean_pooling, X, G, Y);
     return mgp_launch_status();
+}
+
+extern "C" int mgp_replay_gather(const float* feat, const unsigned long long* bits, const float* label, const int* age,
+                                 const long* idx, const int* cursor, int Bt, int lanes, int ring_steps, int K, int N,
+                                 int mean_pooling, float* X, float* G, float* Y, void* stream)
+{
+    return mgp_replay_gather_many(feat, bits, label, age, idx, cursor, Bt, 1, lanes, ring_steps, K, N, mean_pooling, X, G, Y,
+                                  stream);
 }

@@ -80,8 +80,11 @@ def _replay_updates(obj, U):
             obj._enqueue()
         obj.graph_many = torch.cuda.CUDAGraph()
         with torch.cuda.graph(obj.graph_many):
-            for _ in range(UPDATES_PER_GRAPH):
-                obj._enqueue()
+            if hasattr(obj, '_enqueue_many'):
+                obj._enqueue_many(UPDATES_PER_GRAPH)
+            else:
+                for _ in range(UPDATES_PER_GRAPH):
+                    obj._enqueue()
         # capture does not execute: the cursor / step counter / weights are untouched
     if U <= 0:
         return
@@ -254,9 +257,11 @@ class FrameReplay(object):
 
 class FrameUpdates(object):
     """A round of DAGGER updates on a FrameReplay with no per-update host work: the frame indices of the whole round are
-    uploaded once; every update is one replay of a HIP graph of three launches -- mgp_replay_gather (rebuilds the minibatch's
-    K-tap states from the frame ring at the device-side cursor) and the two launches of mgp_train_step_indexed on the
-    gathered buffers (forward + MSE + backward per tile; reduction + Adam, which advances the cursor and files the loss)."""
+    uploaded once; an update is mgp_replay_gather (rebuilds the minibatch's K-tap states from the frame ring at the
+    device-side cursor) and the two launches of mgp_train_step_indexed on the gathered buffers (forward + MSE + backward per
+    tile; reduction + Adam, which advances the cursor and files the loss).  The gathers do not depend on the weights: the
+    graph of UPDATES_PER_GRAPH updates starts with ONE launch that gathers all of its minibatches (mgp_replay_gather_many,
+    ~1 us per update instead of 9) into UPDATES_PER_GRAPH slots and each update reads its slot."""
 
     def __init__(self, learner, memory, batch_size, max_updates, mean_pooling):
         import ctypes
@@ -268,11 +273,15 @@ class FrameUpdates(object):
         self.nl, self.K, self.N, self.B = actor.n_layers, actor.k, learner.n_agents, batch_size
         self.learner, self.memory, self.cap, self.mean_pooling = learner, memory, max_updates, mean_pooling
         L = _lib.lib()
-        self.X = torch.zeros((batch_size, self.K, 6, self.N), device=dev)
-        self.G = torch.zeros((batch_size, self.K, self.N, self.N), device=dev)
-        self.Y = torch.zeros((batch_size, 1, actor.n_a, self.N), device=dev)
-        self.idx = torch.zeros((max_updates, batch_size), device=dev, dtype=torch.long)            # frame indices
+        slots = UPDATES_PER_GRAPH * batch_size                      # one slot of batch_size samples per update of a graph
+        self.X = torch.zeros((slots, self.K, 6, self.N), device=dev)
+        self.G = torch.zeros((slots, self.K, self.N, self.N), device=dev)
+        self.Y = torch.zeros((slots, 1, actor.n_a, self.N), device=dev)
+        self.idx = torch.zeros((max_updates + UPDATES_PER_GRAPH, batch_size), device=dev, dtype=torch.long)   # frame indices
         self.ident = torch.arange(batch_size, device=dev, dtype=torch.long).repeat(max_updates, 1).contiguous()
+        # update number c of a round reads slot c % UPDATES_PER_GRAPH (full graphs start at multiples of it)
+        self.ident_many = (self.ident + (torch.arange(max_updates, device=dev, dtype=torch.long) % UPDATES_PER_GRAPH)[:, None]
+                           * batch_size).contiguous()
         self.cursor = torch.zeros((1,), device=dev, dtype=torch.int32)
         self.loss_hist = torch.zeros((max_updates,), device=dev, dtype=torch.float32)
         self.step_dev = opt.step_dev
@@ -281,15 +290,29 @@ class FrameUpdates(object):
 
     supported = staticmethod(IndexedUpdates.supported)
 
-    def _enqueue(self):
+    def _train(self, ident):
         from .. import _lib, ops
         L, o = _lib.lib(), self.learner.actor_optim
-        ops.replay_gather(self.memory, self.idx, self.X, self.G, self.Y, self.mean_pooling, cursor=self.cursor)
         _lib.check(L.mgp_train_step_indexed(
-            ops._ptr(self.X), ops._ptr(self.G), ops._ptr(self.Y), self.ident.data_ptr(), self.cursor.data_ptr(),
+            ops._ptr(self.X), ops._ptr(self.G), ops._ptr(self.Y), ident.data_ptr(), self.cursor.data_ptr(),
             ops._ptr(self.loss_hist), self.cap, ops._ptr(o.flat), ops._ptr(o.flat_grad), ops._ptr(o.m), ops._ptr(o.v),
             self.cdims, self.nl, o.lr, o.betas[0], o.betas[1], o.eps, self.step_dev.data_ptr(), ops._ptr(self.ws),
             self.B, self.K, self.N, ops._stream()), 'mgp_train_step_indexed')
+
+    def _enqueue(self):
+        """one update: gather into slot 0, train on it"""
+        from .. import ops
+        B = self.B
+        ops.replay_gather(self.memory, self.idx, self.X[:B], self.G[:B], self.Y[:B], self.mean_pooling, cursor=self.cursor)
+        self._train(self.ident)
+
+    def _enqueue_many(self, n):
+        """n updates starting at a cursor that is a multiple of n: one gather for all of them, then the n train steps"""
+        from .. import ops
+        assert n == UPDATES_PER_GRAPH
+        ops.replay_gather(self.memory, self.idx, self.X, self.G, self.Y, self.mean_pooling, cursor=self.cursor, nb=n)
+        for _ in range(n):
+            self._train(self.ident_many)
 
     def run_sampled(self, U, sampler=None):
         """U updates, frame indices drawn per update by `sampler` (default: FrameReplay.sample_ids -- the reference's

@@ -327,17 +327,20 @@ def rollout_collect(x, G, Xd, dims, params, T, frames, expert_io, beta, episode,
     return True
 
 
-def replay_gather(frames, idx, X, G, Y, mean_pooling, cursor=None):
+def replay_gather(frames, idx, X, G, Y, mean_pooling, cursor=None, nb=1):
     """Minibatch (X (Bt,K,6,N), G (Bt,K,N,N), Y (Bt,1,2,N)) rebuilt from the frame ring for the frame indices
-    idx[(cursor or 0) * Bt + i] (mgp_replay_gather); idx int64 on the device, cursor (1,) int32 on the device or None."""
+    idx[(cursor or 0) * Bt + i] (mgp_replay_gather); idx int64 on the device, cursor (1,) int32 on the device or None.
+    nb > 1: `nb` consecutive minibatches in one launch, X / G / Y holding nb * Bt samples (mgp_replay_gather_many)."""
     _dev(X, 'X'); _dev(G, 'G'); _dev(Y, 'Y'); _dev(idx, 'idx', torch.int64)
-    Bt, K, _, N = X.shape
-    assert X.is_contiguous() and G.is_contiguous() and Y.is_contiguous() and G.shape == (Bt, K, N, N) and Y.numel() == Bt * 2 * N
+    Bn, K, _, N = X.shape
+    assert Bn % nb == 0
+    Bt = Bn // nb
+    assert X.is_contiguous() and G.is_contiguous() and Y.is_contiguous() and G.shape == (Bn, K, N, N) and Y.numel() == Bn * 2 * N
     S, lanes = frames.feat.shape[0], frames.feat.shape[1]
-    rc = _lib.lib().mgp_replay_gather(_ptr(frames.feat), _ptr(frames.bits), _ptr(frames.label), _ptr(frames.age), _ptr(idx),
-                                      _ptr(cursor), Bt, lanes, S, K, N, 1 if mean_pooling else 0, _ptr(X), _ptr(G), _ptr(Y),
-                                      _stream())
-    _lib.check(rc, 'mgp_replay_gather')
+    rc = _lib.lib().mgp_replay_gather_many(_ptr(frames.feat), _ptr(frames.bits), _ptr(frames.label), _ptr(frames.age), _ptr(idx),
+                                           _ptr(cursor), Bt, nb, lanes, S, K, N, 1 if mean_pooling else 0, _ptr(X), _ptr(G),
+                                           _ptr(Y), _stream())
+    _lib.check(rc, 'mgp_replay_gather_many')
 
 
 def rollout_image(weights, biases, dims, K, N):
