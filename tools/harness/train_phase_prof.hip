@@ -39,5 +39,6 @@ int main(int argc, char** argv) {
     const char* names[] = {"start", "all global reads landed (barrier)", "aggregation pieces done (barrier)", "layer 0 inputs ready", "layer 1 inputs ready",
                            "layer 2 inputs ready", "-", "-", "forward + loss done", "backward layer L-1", "backward layer L-2", "backward layer L-3", "-", "-", "end"};
     for (int i = 0; i < 15; ++i) if (names[i][0] != '-') printf("  stamp %2d : %8llu  %s\n", i, st[i] - st[0], names[i]);
+    for (int i = 20; i < 28; ++i) if (st[i]) printf("  stamp %2d : %8llu\n", i, st[i] - st[0]);
     return 0;
 }
