@@ -28,8 +28,8 @@ constexpr int TS_COLS = 16;               // agent columns per workgroup
 constexpr int TS_CSH = 4;                 // log2(TS_COLS)
 constexpr int TS_GROUPS = TS_THREADS / TS_COLS;
 constexpr int TS_CS = TS_COLS + 1;        // odd LDS row stride: conflict-free walks along a column
-constexpr int TS_MAXW = 64;               // layer widths and F*K covered
-constexpr int TS_LDS_LIMIT = 96 * 1024;
+constexpr int TS_MAXW = 128;              // layer widths covered (F*K <= 64)
+constexpr int TS_LDS_LIMIT = 150 * 1024;  // [18 -> 128 -> 128 -> 2] at N = 100: 141 KB
 
 struct TrainParams {
     const float* W[MGP_MAX_LAYERS];
@@ -416,7 +416,7 @@ bool make_train_plan(const int* dims, int n_layers, int B, int K, int N, TrainPl
 {
     if (dims == nullptr || n_layers <= 0 || n_layers > MGP_MAX_LAYERS || K <= 0 || K > TS_GROUPS || N <= 0 || B <= 0) return false;
     const int F = dims[0];
-    if (F <= 0 || F > 8 || F * K > TS_MAXW) return false;
+    if (F <= 0 || F > 8 || F * K > 64) return false;
     for (int i = 1; i <= n_layers; ++i) if (dims[i] <= 0 || dims[i] > TS_MAXW) return false;
     const int FK = F * K;
     pl->MP = TS_GROUPS / K;

@@ -329,7 +329,8 @@ def test_coverage_predicates_are_host_side():
     assert not L.mgp_actor_supported(d128, 2, 3, 1000)             # ... the general variant stops at 64
     d128x3 = (ctypes.c_int * 5)(6, 128, 128, 128, 2)
     assert not L.mgp_actor_supported(d128x3, 4, 3, 100)            # three 128-wide layers: weights > 160 KB of LDS
-    assert not L.mgp_train_supported(d128, 2, 20, 3, 100)
+    assert L.mgp_train_supported(d128, 2, 20, 3, 100)                  # one-launch update: widths <= 128 too
+    assert not L.mgp_train_supported(d128x3, 4, 20, 3, 100)
 
 
 def test_beta_schedule_is_the_reference_running_product():

@@ -133,12 +133,16 @@ def test_train_grads_random_configuration(seed):
     rs = np.random.RandomState(9000 + seed)
     B = int(rs.choice([1, 2, 5, 20, 33])); K = int(rs.randint(1, 5)); F = int(rs.choice([2, 6, 6, 8]))
     N = int(rs.choice([3, 16, 17, 50, 100, 100, 129, 200]))
-    hidden = [int(rs.choice([1, 4, 16, 32, 32, 48, 64])) for _ in range(int(rs.randint(0, 4)))]
+    hidden = [int(rs.choice([1, 4, 16, 32, 32, 48, 64, 96, 128])) for _ in range(int(rs.randint(0, 4)))]
+    if sum(h > 64 for h in hidden) > 2:
+        hidden = hidden[:2]                                      # three layers wider than 64: beyond the LDS
     n_a = int(rs.choice([1, 2, 2, 3]))
     dims = [F] + hidden + [n_a]
     L = _lib.lib()
     cd = (ctypes.c_int * len(dims))(*dims)
-    assert L.mgp_train_supported(cd, len(dims) - 1, B, K, N)
+    if not L.mgp_train_supported(cd, len(dims) - 1, B, K, N):
+        assert max(hidden) > 64                                     # only layers wider than 64 can outgrow the LDS plan
+        pytest.skip('LDS plan of this wide configuration does not fit')
     X, G = (synth.make_dense_inputs if seed % 2 else synth.make_inputs)(seed, B, K, F, N)
     Ws, bs = [], []
     for i in range(len(dims) - 1):
