@@ -444,7 +444,7 @@ constexpr int AM_MAXW = 16 * AM_MAXMT;
 struct ChainArgs {
     const float* w; int stride, cin, cout;             // natural-order rows [16 MT][stride] + bias [16 MT]
     float* out; float* saved; size_t soff;             // global outputs (last layer / training copies)
-    int b, N, col, li, lq; bool first, last;
+    int b, N, col, li, lq; bool last;
 };
 
 // m-tiles h (and h + 1 if TWO) of a layer: NC = compile-time bound on the k-chunks (16 channels = 4 k-steps each)
@@ -598,7 +598,6 @@ void actor_fwd_mfma_kernel(const float* __restrict__ X, const float* __restrict_
             }
         }
         AF_STAMP_T(16, 64 * nstream);
-        AF_STAMP_T(17, 64 * nstream);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         AF_STAMP_T(19, 64 * nstream);
     }
@@ -631,7 +630,7 @@ void actor_fwd_mfma_kernel(const float* __restrict__ X, const float* __restrict_
             {
                 const int cin = (l == 0) ? FK : P.dims[l], cout = P.dims[l + 1];
                 ChainArgs ca = {wl + WC.lw[l], WC.lstride[l], cin, cout, out, saved, soff, b, N, col, li, lq,
-                                l == 0, l == P.n_layers - 1};
+                                l == P.n_layers - 1};
                 if (l == 0) chain_layer_any<true>(ca, fb0, zb, za); else chain_layer_any<false>(ca, fb0, zb, za);
                 soff += (size_t)B * cout * N;
                 AF_STAMP(6 + l);
@@ -639,7 +638,7 @@ void actor_fwd_mfma_kernel(const float* __restrict__ X, const float* __restrict_
             if (l + 1 < P.n_layers) {
                 const int cin = P.dims[l + 1], cout = P.dims[l + 2];
                 ChainArgs ca = {wl + WC.lw[l + 1], WC.lstride[l + 1], cin, cout, out, saved, soff, b, N, col, li, lq,
-                                false, l + 1 == P.n_layers - 1};
+                                l + 1 == P.n_layers - 1};
                 chain_layer_any<false>(ca, fb0, za, zb);
                 soff += (size_t)B * cout * N;
                 AF_STAMP(7 + l);

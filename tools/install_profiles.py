@@ -53,7 +53,7 @@ open('profiles/%s_actor_fwd_phase_stamps.txt' % R, 'w').write(
     "# B = 256 (one workgroup per CU) and B = 1.  Thread 0 (a streaming wave): 1 = its X + G requests issued | 2 = its 4x4x1 MFMAs done\n"
     "# (consumed as the rows land) | 3 = row classes added, aggregation tile written | 4 = THE barrier passed (all streaming waves + the\n"
     "# staging waves) | 5 = MLP start | 6, 7, 8 = end of layers 0, 1, 2 (register-chained).  First thread of staging wave 0: 16 = weight area\n"
-    "# zeroed, all LDS-DMA rows issued | 19 = they have landed.\n"
+    "# zeroed, all LDS-DMA rows issued | 19 = they have landed (17, if printed by an older harness build: same point as 16).\n"
     + open(O + '/actor_fwd_phase_stamps.txt').read())
 from multiagent_gnn_policies_amd import build
 print('hash ok', build.source_hash() == json.load(open('profiles/%s_pmc_traffic.json' % R))['_meta']['source_hash'])
