@@ -742,6 +742,7 @@ struct ScatterParams {
 // workgroup = 64 parameters x 16 interleaved groups of tiles (the per-parameter chain of dependent loads is what this
 // kernel costs); the sixteen group sums are added in fixed order (deterministic)
 constexpr int SC_GROUPS = 16;
+constexpr int SC_BATCH = 10;
 __global__ __launch_bounds__(64 * SC_GROUPS)
 void actor_bwd_scatter_kernel(const float* __restrict__ part, ScatterParams S, long Ptot, long ntiles)
 {
@@ -749,8 +750,19 @@ void actor_bwd_scatter_kernel(const float* __restrict__ part, ScatterParams S, l
     const int pl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * 64 + pl;
     float s = 0.f;
-    if (i < Ptot)
-        for (long t = g; t < ntiles; t += SC_GROUPS) s += part[t * Ptot + i];
+    if (i < Ptot) {
+        // the first SC_BATCH tiles of the group are requested together (dependent round trips to memory otherwise), added
+        // in the same order as before
+        float v[SC_BATCH];
+#pragma unroll
+        for (int q = 0; q < SC_BATCH; ++q) {
+            const long t = g + (long)SC_GROUPS * q;
+            v[q] = part[(t < ntiles ? t : ntiles - 1) * Ptot + i];
+        }
+#pragma unroll
+        for (int q = 0; q < SC_BATCH; ++q) s += (g + (long)SC_GROUPS * q < ntiles) ? v[q] : 0.f;
+        for (long t = g + (long)SC_GROUPS * SC_BATCH; t < ntiles; t += SC_GROUPS) s += part[t * Ptot + i];
+    }
     sh[g][pl] = s;
     __syncthreads();
     if (g != 0 || i >= Ptot) return;

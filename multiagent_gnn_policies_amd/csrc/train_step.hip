@@ -353,6 +353,7 @@ struct AdamArgs {
 
 // workgroup = 64 entries of the partial x 16 interleaved groups of tiles; entry Ptot is the squared error
 constexpr int TR_GROUPS = 16;
+constexpr int TR_BATCH = 10;               // tiles per group fetched in one batch (B = 20, N = 100: 140 tiles = 9 per group)
 __global__ __launch_bounds__(64 * TR_GROUPS)
 void train_reduce_kernel(const float* __restrict__ part, int ntiles, int Pstride, float* __restrict__ flat_grad,
                          float* __restrict__ loss, float inv_n, AdamArgs A)
@@ -368,8 +369,19 @@ void train_reduce_kernel(const float* __restrict__ part, int ntiles, int Pstride
         shc[1] = (float)sqrt(1.0 - pow((double)A.b2, step));
     }
     float s = 0.f;
-    if (i < Pstride)
-        for (int t = g; t < ntiles; t += TR_GROUPS) s += part[(size_t)t * Pstride + i];
+    if (i < Pstride) {
+        // the first TR_BATCH tiles of this group are requested together (the partials come from the other XCDs' tile
+        // workgroups, i.e. from memory: nine dependent round trips otherwise) and added in the same order as before
+        float v[TR_BATCH];
+#pragma unroll
+        for (int q = 0; q < TR_BATCH; ++q) {
+            const int t = g + TR_GROUPS * q;
+            v[q] = part[(size_t)min(t, ntiles - 1) * Pstride + i];
+        }
+#pragma unroll
+        for (int q = 0; q < TR_BATCH; ++q) s += (g + TR_GROUPS * q < ntiles) ? v[q] : 0.f;
+        for (int t = g + TR_GROUPS * TR_BATCH; t < ntiles; t += TR_GROUPS) s += part[(size_t)t * Pstride + i];
+    }
     sh[g][pl] = s;
     __syncthreads();
     if (g == 0 && i < Pstride) {
