@@ -53,6 +53,7 @@ if ROOT not in sys.path:
 
 from multiagent_gnn_policies_amd import ops, parallel  # noqa: E402
 from multiagent_gnn_policies_amd.envs import FlockParams, VecFlock  # noqa: E402
+from multiagent_gnn_policies_amd.envs.flocking import use_grid  # noqa: E402
 from multiagent_gnn_policies_amd.learner import Actor  # noqa: E402
 from multiagent_gnn_policies_amd.learner.state_with_delay import BatchedDelayState  # noqa: E402
 
@@ -83,9 +84,9 @@ def load_weights(actor):
 class Rollout(object):
     """Device-resident vectorised rollout; one `step()` = one env step for all B episodes."""
 
-    def __init__(self, device, B, N, K, hidden, seed):
+    def __init__(self, device, B, N, K, hidden, seed, init_mode='auto'):
         self.B, self.N, self.K = B, N, K
-        self.params = FlockParams(n_agents=N, init_mode='grid')
+        self.params = FlockParams(n_agents=N, init_mode=init_mode)
         self.sim = VecFlock(B, self.params, device)
         torch.manual_seed(11)
         self.actor = Actor(F_FEAT, N_ACT, hidden, K, 0).to(device)
@@ -328,6 +329,9 @@ def parity_gate(ro, n_check=16):
                      "max_rel_well_conditioned": float(r_ref[well].max()) if bool(well.any()) else None}
         plain = r_ref <= PARITY_TOL
         res[name]["episodes_within_plain_tol"] = int(plain.sum())
+        relaxed = plain | (r_ex <= PARITY_TOL + 10.0 * noise_b)
+        res[name]["passed_on"] = "plain bound" if bool(plain.all()) else ("relaxed bound (see criterion)" if bool(relaxed.all())
+                                                                          else "FAILED")
         # an episode passes on the plain bound, or -- where the reference's own fp32 evaluation is not determined to that
         # accuracy -- by staying within tol + 10 x that episode's reference noise of the fp64 evaluation
         ok = ok and bool((plain | (r_ex <= PARITY_TOL + 10.0 * noise_b)).all())
@@ -336,8 +340,9 @@ def parity_gate(ro, n_check=16):
     worst = max((v["max_rel_well_conditioned"] for v in res.values() if v["max_rel_well_conditioned"] is not None),
                 default=None)
     return {"ok": ok, "tol": PARITY_TOL, "max_abs": max(v['max_abs'] for v in res.values()),
-            "max_rel": worst if worst is not None else max(v['max_rel'] for v in res.values()),
-            "max_rel_all_episodes": max(v['max_rel'] for v in res.values()),
+            "max_rel": max(v['max_rel'] for v in res.values()),            # over ALL checked episodes and paths
+            "max_rel_well_conditioned": worst,
+            "passed_on": {k_: v["passed_on"] for k_, v in res.items()},
             "reference_fp32_noise": float(noise_b.max()), "max_abs_reference_output": float(ref.abs().max()),
             "checked_episodes": len(idx), "well_conditioned_episodes": int(well.sum()), "paths": res,
             "criterion": "per sampled episode: elementwise |gpu - cpu| / max(1, |cpu|) <= tol against the fp32 CPU reference "
@@ -345,9 +350,10 @@ def parity_gate(ro, n_check=16):
                          "episode's reference_fp32_noise of the fp64 evaluation of the same op sequence on the same fp32 "
                          "inputs (reference_fp32_noise = how far the fp32 REFERENCE itself is from that evaluation: "
                          "colliding agents drive 1/r^4 features to 1e6, random-init wide networks amplify them, and any "
-                         "two fp32 evaluations then differ by more than tol).  max_rel is the figure over the episodes "
-                         "where the reference is determined to tol/2; the headline configuration (reference checkpoint) "
-                         "has all 16 episodes there AND within the plain bound",
+                         "two fp32 evaluations then differ by more than tol).  max_rel is over all checked episodes, "
+                         "max_rel_well_conditioned over those where the reference is determined to tol/2; passed_on says "
+                         "per path which bound it passed on.  The shipped reference checkpoint on well-conditioned states is "
+                         "held to the plain bound only",
             "reference": "oracle/torch_port.actor_forward: PyTorch-CPU fp32, the op sequence of reference actor.py:63-82, "
                          "on the identical (delay_gso, delay_state) of the sampled episodes"}
 
@@ -359,7 +365,7 @@ def mean_degree(state):
     return float((state.delay_gso[:, 1] != 0).sum(dim=-1).double().mean().item())
 
 
-def cpu_baseline(N, K, hidden, budget_s=12.0):
+def cpu_baseline(N, K, hidden, budget_s=12.0, init_mode='auto'):
     """Reference-style single-episode CPU loop (oracle/torch_port.py + numpy sim), bounded sample."""
     from oracle import flock as ofl, torch_port
     path = os.path.join(ROOT, 'tests', 'golden', 'ckpt_dagger_k3.npz')
@@ -372,7 +378,7 @@ def cpu_baseline(N, K, hidden, budget_s=12.0):
         dims = [F_FEAT] + hidden + [N_ACT]
         Ws = [torch.randn(dims[i + 1], dims[i], K if i == 0 else 1, 1) * 0.1 for i in range(len(dims) - 1)]
         bs = [torch.zeros(dims[i + 1]) for i in range(len(dims) - 1)]
-    p = ofl.FlockParams(n_agents=N, init_mode='grid')
+    p = ofl.FlockParams(n_agents=N, init_mode=init_mode)
     x0 = ofl.reset(np.random.RandomState(0), p)
     default_threads = torch.get_num_threads()
     runs = []
@@ -520,6 +526,188 @@ def dagger_update_bench():
             "cpu_port_ms_by_threads": res, "host_cores": os.cpu_count()}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher: start N ranks of this very command (one per GPU; RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* as torch.distributed.run would set them), pass rank 0's JSON line through, return the worst exit
+    status.  Refuses -- loudly -- to run more RCCL ranks than there are devices."""
+    import socket
+    import subprocess
+    backend = os.environ.get('MGP_DIST_BACKEND') or 'nccl'
+    have = torch.cuda.device_count()
+    if backend == 'nccl' and n > have:
+        sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible: RCCL needs one GPU per rank "
+                         "(MGP_DIST_BACKEND=gloo lets ranks share a device, for tests)\n" % (n, have))
+        return 2
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for rk in range(n):
+        env = dict(os.environ, RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if rk == 0 else subprocess.DEVNULL))
+    worst = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                pending.remove(p)
+                if rc != 0:
+                    worst = worst or rc
+                    for q in pending:                            # a dead rank leaves the others in a collective: stop them
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return worst
+
+
+def check_one_device_per_rank(world):
+    if world > 1 and torch.distributed.get_backend() == 'nccl' and world > torch.cuda.device_count():
+        raise SystemExit("bench.py: %d RCCL ranks but %d device(s) visible: one GPU per rank" % (world, torch.cuda.device_count()))
+
+
+def dist_record():
+    """What the process group really was (the record shows that RCCL saw N ranks)."""
+    d = torch.distributed
+    if d.is_available() and d.is_initialized():
+        return {"backend": d.get_backend(), "world_size": d.get_world_size(), "devices_visible": torch.cuda.device_count()}
+    return {"backend": None, "world_size": 1, "devices_visible": torch.cuda.device_count()}
+
+
+def dagger_round_bench(args, device, rank, world):
+    """BASELINE.json configs[3] (reference gnn_dagger.py:126-243, one device, one env): one DAGGER round on every rank --
+      collection  --episodes lanes x --steps env steps inside ONE mgp_rollout_collect launch per rank (policy forward, expert
+                  label, beta coin, simulator step, state transition, frame filed into the replay ring); ranks never talk
+      updates     --updates minibatch updates of --batch-size samples PER RANK from the rank's own replay, captured 32 to a
+                  HIP graph; the ranks' gradients (1,730 floats + the loss) are exchanged inside every update -- the one-shot
+                  IPC exchange (csrc/p2p_device.h) or, without it, the RCCL all-reduce captured in the graph
+    Timed with the contract's barrier + synchronize bracketing, MAX over ranks; the weights must be bit-identical on every
+    rank at the end (the run fails otherwise)."""
+    import configparser
+    from multiagent_gnn_policies_amd.learner.gnn_dagger import DAGGER
+    from multiagent_gnn_policies_amd.learner.vec_dagger import (FrameReplay, FrameUpdates, collect_round, collect_supported,
+                                                                _dp_mode)
+    dist = torch.distributed
+    lanes, N, K, T, U, Bt = args.episodes, args.agents, args.taps, args.steps, args.updates, args.batch_size
+    cp = configparser.ConfigParser()
+    cp['DEFAULT'] = dict(n_states=str(F_FEAT), n_actions=str(N_ACT), k=str(K), hidden_size=str(args.hidden),
+                         n_layers=str(args.layers), gamma='0.99', tau='0.5', n_agents=str(N), actor_lr='5e-5')
+    cp['t'] = {}
+    torch.manual_seed(11)
+    learner = DAGGER(device, cp['t'])
+    if not (collect_supported(learner, K, N) and FrameUpdates.supported(learner, Bt, N)):
+        raise SystemExit("bench.py --dagger: shape outside mgp_rollout_collect / the graph-captured update path")
+    p = FlockParams(n_agents=N, init_mode=args.init)
+    sim = VecFlock(lanes, p, device, with_expert=True)
+    state = BatchedDelayState(device, lanes, K, F_FEAT, N)
+    memory = FrameReplay(lanes, lanes * max(T, args.warmup, 1), K, N, device)
+    beta = torch.full((lanes,), 0.75, device=device)
+    eps = torch.arange(rank * lanes, (rank + 1) * lanes, dtype=torch.int32, device=device)
+    np.random.seed(1000 + rank)
+    import random
+    random.seed(1000 + rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    # ---- collection: reset sampling (host, once per round) is outside the timed region, the launch inside
+    from multiagent_gnn_policies_amd.learner.rollouts import _actor_params
+
+    def collect(steps):
+        sim.reset(np.random)
+        state.reset()
+        state.push(sim.network, sim.features)
+        expert_io = sim.controller().permute(0, 2, 1).contiguous()
+        ws, bs = _actor_params(learner.actor)
+        image = ops.rollout_image(ws, bs, tuple(learner.actor.layers), K, N)
+        carry = state.carry_buffer()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ok = ops.rollout_collect(sim.x, state._G[state._cur], state.delay_state, tuple(learner.actor.layers), sim._c, steps,
+                                 memory, expert_io, beta, eps, 11, age0=0, ring_step0=memory.head, carry=carry,
+                                 flags=ops.RO_ENTER_CARRY | ops.RO_EXIT_CARRY | ops.RO_SKIP_DENSE, image=image)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        barrier()
+        assert ok
+        memory.advance(steps)
+        state._pushes += steps
+        state._dense_stale = True
+        return max_over_ranks(el)
+    collect(max(args.warmup, K))
+    t_collect = collect(T)
+    # ---- updates
+    fu = FrameUpdates(learner, memory, Bt, max(U, 64), p.mean_pooling)
+    learner.begin_updates()
+    fu.run_sampled(64)                                           # warm-up: captures both graphs
+    learner.end_updates()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss_sum = fu.run_sampled(U)
+    torch.cuda.synchronize()
+    t_upd = time.perf_counter() - t0
+    barrier()
+    t_upd = max_over_ranks(t_upd)
+    learner.end_updates()
+    loss_mean = float(loss_sum.item()) / U
+    # ---- every rank must hold the same weights, bit for bit
+    identical = True
+    if world > 1:
+        cdev = device if dist.get_backend() == 'nccl' else torch.device('cpu')
+        mine = learner.actor_optim.flat.detach().to(cdev)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        identical = all(torch.equal(parts[0], q) for q in parts[1:])
+    if rank == 0:
+        out = {
+            "metric": "agent-steps/sec of DAGGER data collection, FlockingRelative-v0 N=%d K=%d" % (N, K),
+            "value": world * lanes * N * T / t_collect, "unit": "agent-steps/s", "n_gpus": world, "steps": T,
+            "warmup": args.warmup, "ms_per_step": 1e3 * t_collect / T, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DAGGER round (BASELINE.json configs[3]): %d lanes x %d steps of data collection per rank "
+                                   "(mgp_rollout_collect: policy forward, expert label, beta coin, sim step, frame insert), "
+                                   "then %d updates of %d samples per rank with the gradient exchanged between %d rank(s)"
+                                   % (lanes, T, U, Bt, world),
+                       "episodes_per_gpu": lanes, "agents": N, "taps": K, "hidden": [args.hidden] * args.layers,
+                       "init": args.init, "beta": 0.75,
+                       "parallelism": "episodes sharded x%d; one exchange of %d floats per update"
+                                      % (world, learner.actor_optim.flat.numel() + 1)},
+            "updates": {"count": U, "batch_size_per_rank": Bt, "ms_per_update": 1e3 * t_upd / U,
+                        "updates_per_s": U / t_upd, "samples_per_s": U * Bt * world / t_upd, "mean_loss": loss_mean,
+                        "exchange": (fu.dp or "none (single process)"),
+                        "exchange_mem_kind": getattr(learner.p2p, 'mem_kind', None),
+                        "updates_per_graph": 32},
+            "round_s": t_collect + t_upd,
+            "weights_bit_identical_across_ranks": identical,
+            "dist": dist_record(),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not identical:
+        sys.stderr.write("bench.py --dagger: the ranks' weights differ\n")
+        sys.exit(4)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -535,6 +723,15 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-parity', action='store_true', help='skip the in-run parity gate against the CPU port')
     ap.add_argument('--no-resident', action='store_true', help='time only the two-launch dense path')
+    ap.add_argument('--init', default='auto', choices=['auto', 'disc', 'grid'],
+                    help="reset distribution of the timed episodes: 'auto' = the environment's own (FlockParams.init_mode: "
+                         "uniform disc up to N = 100, jittered lattice beyond); 'grid' = the lattice at any N")
+    ap.add_argument('--dagger', action='store_true',
+                    help='BASELINE configs[3]: one DAGGER round per rank -- data collection (--episodes lanes x --steps env '
+                         'steps) then --updates minibatch updates of --batch-size per rank, gradients exchanged between the '
+                         'ranks; prints its own JSON line')
+    ap.add_argument('--updates', type=int, default=2048, help='--dagger: timed updates')
+    ap.add_argument('--batch-size', type=int, default=20, help='--dagger: per-rank minibatch (cfg/dagger.cfg:6)')
     ap.add_argument('--dagger-update', action='store_true',
                     help='secondary measurement: DAGGER updates/s at B=20 (prints its own JSON line and exits)')
     args = ap.parse_args()
@@ -544,18 +741,27 @@ def main():
         print(json.dumps(dagger_update_bench()))
         return
 
-    rank, world, local = parallel.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))                         # `python bench.py --gpus N` starts its own N ranks
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: one rank per GPU, launch with --nproc-per-node %d (or without a "
+                         "launcher: bench.py starts the ranks itself)" % (args.gpus, world, args.gpus))
+    check_one_device_per_rank(world)
     dev_index = parallel.local_device_index(local)
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
     B, N, K = args.episodes, args.agents, args.taps
     hidden = [args.hidden] * args.layers
+    if args.dagger:
+        dagger_round_bench(args, device, rank, world)
+        return
 
-    ro = Rollout(device, B, N, K, hidden, seed=1000 + rank)
+    ro = Rollout(device, B, N, K, hidden, seed=1000 + rank, init_mode=args.init)
+    deg_start = float((ro.sim.network != 0).sum(dim=-1).double().mean().item())
+    init_name = ('jittered lattice' if use_grid(ro.params) else 'uniform disc') + " (FlockParams.init_mode='%s')" % args.init
 
     # ---- capture `gs` consecutive env steps into one HIP graph (even count: ping-pong buffers realign)
     gs = args.graph_steps
@@ -653,8 +859,9 @@ def main():
                        "episodes_per_gpu": B, "episodes_total": total_eps, "agents": N, "taps": K,
                        "graph_steps": gs, "weights": ro.weights, "parallelism": "episodes sharded x%d, no "
                        "data-path collective" % world, "state_finite": finite,
-                       "mean_degree": deg, "init": "jittered lattice (FlockParams.init_mode='grid'), %d steps since reset "
-                       "at the end of the timed region" % ro.state._pushes},
+                       "mean_degree": deg, "mean_degree_at_reset": deg_start,
+                       "init": "%s, %d steps since reset at the end of the timed region" % (init_name, ro.state._pushes)},
+            "dist": dist_record(),
             "paths": {"two_launch": {"ms_per_step": 1e3 * el_two / args.steps,
                                      "value": total_eps * N * args.steps / el_two, "graph_steps": gs}},
         }
@@ -731,7 +938,7 @@ def main():
         parity = parity_gate(ro)
         out["parity"] = parity
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(N, K, hidden)
+        out["cpu_baseline"] = cpu_baseline(N, K, hidden, init_mode=args.init)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

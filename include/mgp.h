@@ -23,8 +23,9 @@
 extern "C" {
 #endif
 
-#define MGP_VERSION 201            /* 0.2.0: + mgp_rollout_steps_ex / _image / _carry_*, mgp_rollout_collect, mgp_replay_gather;
-                                      0.2.1: + mgp_replay_gather_many; mgp_actor_fwd covers layer widths up to 128 at N <= 128 */
+#define MGP_VERSION 300            /* 0.2.0: + mgp_rollout_steps_ex / _image / _carry_*, mgp_rollout_collect, mgp_replay_gather;
+                                      0.2.1: + mgp_replay_gather_many; mgp_actor_fwd covers layer widths up to 128 at N <= 128;
+                                      0.3.0: + mgp_p2p_* (one-shot gradient exchange), mgp_train_step_p2p, mgp_adam_step_filed */
 
 #define MGP_OK            0
 #define MGP_EINVAL       -1        /* bad size / null pointer / unsupported combination */
@@ -348,6 +349,52 @@ int  mgp_train_step_indexed(const float* Xr, const float* Gr, const float* Yr, c
                             float* loss_hist, int hist_cap, float* flat_param, float* flat_grad, float* m, float* v,
                             const int* dims, int n_layers, float lr, float beta1, float beta2, float eps,
                             int* step_dev, float* workspace, int B, int K, int N, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Data-parallel DAGGER update: the one-shot gradient exchange
+ * The reference trains on one device (train.py:31; gradient_step: gnn_dagger.py:76-96).  Sharding its episodes over the
+ * GPUs of a node leaves exactly one exchange per update: the flat gradient (1,730 floats at cfg/dagger.cfg) plus the
+ * loss -- 6.9 KB, pure latency.  Instead of a ring all-reduce (2(W-1) dependent hops) every rank pushes its values into a
+ * mailbox in every peer's memory (hipIpc-mapped; xGMI is point to point) as 64-bit {sequence number | fp32} packets, one
+ * 8-byte system-scope store each, and adds what arrives in rank order 0..W-1, then divides by W: one hop, no fence, and
+ * bit-identical results on every rank.  Two slots per source make back-to-back exchanges safe without a barrier.
+ *   mgp_p2p_create         allocates the local mailbox (world x 2 x n_floats packets of uncached device memory) -- the one
+ *                          entry point of this library that allocates; world <= 8, one communicator per process and device
+ *   mgp_p2p_handle         copies out the mailbox's IPC handle (mgp_p2p_handle_bytes() = 64 bytes); the caller gathers the
+ *                          handles of all ranks, in rank order, by any means (torch.distributed.all_gather here)
+ *   mgp_p2p_connect        opens every peer's mailbox from the gathered handles (world x 64 bytes)
+ *   mgp_p2p_allreduce_mean buf[i] <- mean over ranks of buf[i], i < n <= n_floats, in place, one launch on `stream`;
+ *                          every rank must make the same sequence of exchange calls (this and mgp_train_step_p2p)
+ *   mgp_p2p_status         synchronises `stream`; *status != 0 if a poll gave up (a peer did not publish within the timeout,
+ *                          default 5 s: its values counted as 0) -- an error for the caller to raise, never a hung GPU;
+ *                          *seq = number of exchanges completed
+ *   mgp_p2p_info           *mem_kind: 2 = uncached, 1 = fine-grained, 0 = plain device memory (what the runtime granted)
+ * HIP-graph capturable (the sequence number lives on the device).  Ranks may share one device (IPC between processes). */
+typedef struct MgpP2P MgpP2P;
+int  mgp_p2p_create(int world, int rank, int n_floats, MgpP2P** out);
+int  mgp_p2p_handle_bytes(void);
+int  mgp_p2p_handle(const MgpP2P* comm, void* handle_out);
+int  mgp_p2p_connect(MgpP2P* comm, const void* handles);
+int  mgp_p2p_set_timeout_ms(MgpP2P* comm, int ms);
+int  mgp_p2p_info(const MgpP2P* comm, int* world, int* rank, int* n_floats, int* mem_kind);
+int  mgp_p2p_status(MgpP2P* comm, int* status, int* seq, void* stream);
+int  mgp_p2p_destroy(MgpP2P* comm);
+int  mgp_p2p_allreduce_mean(MgpP2P* comm, float* buf, int n, void* stream);
+
+/* mgp_train_step / mgp_train_step_indexed for a data-parallel run (gnn_dagger.py:85-93 on a world-times larger minibatch):
+ * the same two launches, with the exchange above between the local reduction and Adam inside the second one -- each of its
+ * workgroups exchanges the 64 gradient entries it has just reduced.  flat_grad receives the averaged gradient, loss[0] /
+ * loss_hist the averaged loss; every rank applies the identical step.  idx, cursor and loss_hist: all NULL (mgp_train_step
+ * semantics) or all given (mgp_train_step_indexed semantics).  comm: n_floats >= parameter count + 1. */
+int  mgp_train_step_p2p(const float* X, const float* G, const float* target, const long* idx, int* cursor,
+                        float* loss_hist, int hist_cap, float* flat_param, float* flat_grad, float* m, float* v,
+                        const int* dims, int n_layers, float lr, float beta1, float beta2, float eps,
+                        int* step_dev, float* loss, float* workspace, int B, int K, int N, MgpP2P* comm, void* stream);
+/* mgp_adam_step_dev + the bookkeeping of an indexed round (loss_hist[*cursor % hist_cap] = *loss; *cursor += 1): the tail
+ * of a data-parallel update whose gradient went through a library collective after mgp_train_grads. */
+int  mgp_adam_step_filed(float* param, const float* grad, float* m, float* v, long n,
+                         float lr, float beta1, float beta2, float eps, int* step_dev,
+                         const float* loss, float* loss_hist, int hist_cap, int* cursor, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Factored state for episodes beyond the LDS-resident rollout (N > 256)

@@ -82,6 +82,18 @@ SIGNATURES = {
     'mgp_train_grads': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _int, _int, _vp]),
     'mgp_train_step_indexed': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _int,
                                       _f32, _f32, _f32, _f32, _vp, _vp, _int, _int, _int, _vp]),
+    'mgp_p2p_create': (_int, [_int, _int, _int, ctypes.POINTER(_vp)]),
+    'mgp_p2p_handle_bytes': (_int, []),
+    'mgp_p2p_handle': (_int, [_vp, _vp]),
+    'mgp_p2p_connect': (_int, [_vp, _vp]),
+    'mgp_p2p_set_timeout_ms': (_int, [_vp, _int]),
+    'mgp_p2p_info': (_int, [_vp, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    'mgp_p2p_status': (_int, [_vp, ctypes.POINTER(_int), ctypes.POINTER(_int), _vp]),
+    'mgp_p2p_destroy': (_int, [_vp]),
+    'mgp_p2p_allreduce_mean': (_int, [_vp, _vp, _int, _vp]),
+    'mgp_train_step_p2p': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _int,
+                                  _f32, _f32, _f32, _f32, _vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
+    'mgp_adam_step_filed': (_int, [_vp, _vp, _vp, _vp, _long, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _int, _vp, _vp]),
     'mgp_sparse_words': (_int, [_int]),
     'mgp_flock_step_sparse': (_int, [_vp, _vp, _vp, _long, _long, _vp, _long, _vp, _long, _vp, _long, _vp, _vp, _vp,
                                      _int, _int, _vp]),

@@ -81,19 +81,33 @@ def _build_locked(verbose):
     os.makedirs(OBJ_DIR, exist_ok=True)
     objs = []
     procs = []
+    # per-object stamps: a translation unit is recompiled only when it, a header or its flags changed
+    hdr = hashlib.sha256()
+    for n in sorted(f for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join('..', '..', 'include', 'mgp.h')]:
+        with open(os.path.join(CSRC, n), 'rb') as f:
+            hdr.update(n.encode())
+            hdr.update(f.read())
     for src in sources():
         obj = os.path.join(OBJ_DIR, src[:-4] + '.o')
-        cmd = [hipcc] + COMMON_FLAGS + PER_FILE_FLAGS.get(src, []) + ['-c', os.path.join(CSRC, src), '-o', obj]
+        flags = COMMON_FLAGS + PER_FILE_FLAGS.get(src, [])
+        with open(os.path.join(CSRC, src), 'rb') as f:
+            key = hashlib.sha256(hdr.digest() + f.read() + ' '.join(flags).encode()).hexdigest()
+        stamp = obj + '.key'
+        objs.append(obj)
+        if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == key:
+            continue
+        cmd = [hipcc] + flags + ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print('[mgp build]', ' '.join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
-    for src, p in procs:
+        procs.append((src, stamp, key, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, stamp, key, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors='replace')))
         if verbose and out.strip():
             print(out.decode(errors='replace'))
+        with open(stamp, 'w') as f:
+            f.write(key)
     tmp = LIB_PATH + '.tmp.%d' % os.getpid()
     cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', tmp] + objs
     if verbose:

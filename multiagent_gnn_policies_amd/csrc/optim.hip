@@ -70,6 +70,15 @@ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* 
 
 __global__ void step_inc_kernel(int* step_dev) { *step_dev += 1; }
 
+// bookkeeping of one update of an indexed round (mgp_train_step_indexed does this inside its reduce kernel): file the loss
+// at the cursor, advance the cursor
+__global__ void file_loss_kernel(const float* loss, float* loss_hist, int hist_cap, int* cursor)
+{
+    const int c = *cursor;
+    if (loss != nullptr && loss_hist != nullptr) loss_hist[c % hist_cap] = *loss;
+    *cursor = c + 1;
+}
+
 // Small parameter sets (the reference Actor has 1,730): ONE workgroup applies the step and advances the device-side
 // step counter itself -- one graph node instead of two, and the bias corrections (two fp64 pow) are computed once, not
 // once per thread.  Same arithmetic per element as adam_dev_kernel.
@@ -148,5 +157,20 @@ extern "C" int mgp_adam_step(float* param, const float* grad, float* m, float* v
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                        param, grad, m, v, n, (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2),
                        step_size, bc2_sqrt, eps);
+    return mgp_launch_status();
+}
+
+// mgp_adam_step_dev followed by the bookkeeping of an indexed round of updates: loss_hist[*cursor % hist_cap] = *loss and
+// *cursor += 1 (both on the device).  For data-parallel rounds that exchange the gradient with a library collective between
+// mgp_train_grads and the step (the one-shot exchange has all of this inside mgp_train_step_p2p).
+extern "C" int mgp_adam_step_filed(float* param, const float* grad, float* m, float* v, long n,
+                                   float lr, float beta1, float beta2, float eps, int* step_dev,
+                                   const float* loss, float* loss_hist, int hist_cap, int* cursor, void* stream)
+{
+    if (cursor == nullptr || (loss_hist != nullptr && hist_cap <= 0)) return MGP_EINVAL;
+    if (reinterpret_cast<uintptr_t>(cursor) & 3u) return MGP_EALIGN;
+    const int rc = mgp_adam_step_dev(param, grad, m, v, n, lr, beta1, beta2, eps, step_dev, stream);
+    if (rc != MGP_OK) return rc;
+    hipLaunchKernelGGL(file_loss_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), loss, loss_hist, hist_cap, cursor);
     return mgp_launch_status();
 }

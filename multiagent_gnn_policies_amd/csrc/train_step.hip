@@ -18,7 +18,9 @@
 // B = 20, N = 100, K = 3, 6-32-32-2: 140 workgroups; 15.9 (forward) + 4.5 (mse) + 10.0 (backward) + 4.7 (scatter) + 4.0 (adam)
 // microseconds of kernel time in the five-launch graph.
 #include <math.h>
+#include <string.h>
 #include "mgp_common.h"
+#include "p2p_device.h"
 #include "mgp_device.h"
 
 namespace {
@@ -354,10 +356,16 @@ struct AdamArgs {
 // workgroup = 64 entries of the partial x 16 interleaved groups of tiles; entry Ptot is the squared error
 constexpr int TR_GROUPS = 16;
 constexpr int TR_BATCH = 10;               // tiles per group fetched in one batch (B = 20, N = 100: 140 tiles = 9 per group)
+// P2P: data-parallel update -- the entry this thread owns (gradient element or squared error) is exchanged with the other
+// ranks' (p2p_device.h: pushed into every peer's mailbox, the W values added in rank order, / W) between the local
+// reduction and Adam, so the whole data-parallel update stays two launches and every rank applies bit-identical steps.
+template <bool P2P>
 __global__ __launch_bounds__(64 * TR_GROUPS)
 void train_reduce_kernel(const float* __restrict__ part, int ntiles, int Pstride, float* __restrict__ flat_grad,
-                         float* __restrict__ loss, float inv_n, AdamArgs A)
+                         float* __restrict__ loss, float inv_n, AdamArgs A, P2PDev X)
 {
+    unsigned xseq = 0;
+    if (P2P) xseq = (unsigned)X.ctl[0] + 1u;
     __shared__ float sh[TR_GROUPS][64];
     __shared__ float shc[2];
     const int pl = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -388,9 +396,11 @@ void train_reduce_kernel(const float* __restrict__ part, int ntiles, int Pstride
         s = 0.f;
 #pragma unroll
         for (int q = 0; q < TR_GROUPS; ++q) s += sh[q][pl];
+        if (i == Ptot) s *= inv_n;
+        if (P2P) s = p2p_exchange_mean(X, i, s, xseq);
         if (i == Ptot) {
-            if (loss != nullptr) loss[0] = s * inv_n;
-            if (A.loss_hist != nullptr) A.loss_hist[*A.cursor % A.hist_cap] = s * inv_n;   // (the cursor moves after every
+            if (loss != nullptr) loss[0] = s;
+            if (A.loss_hist != nullptr) A.loss_hist[*A.cursor % A.hist_cap] = s;   // (the cursor moves after every
         } else {                                                                         //  workgroup is through: ticket below)
             flat_grad[i] = s;
             if (A.p != nullptr) {                        // torch.optim.Adam defaults, same expressions as mgp_adam_step_dev
@@ -413,6 +423,7 @@ void train_reduce_kernel(const float* __restrict__ part, int ntiles, int Pstride
                 *A.ticket = 0;
                 *A.step_dev += 1;
                 if (A.cursor != nullptr) *A.cursor += 1;
+                if (P2P) X.ctl[0] = (int)xseq;
             }
         }
     }
@@ -452,7 +463,7 @@ bool make_train_plan(const int* dims, int n_layers, int B, int K, int N, TrainPl
 
 int launch_train(const float* X, const float* G, const float* target, const float* const* W, const float* const* b,
                  const int* dims, int n_layers, float* flat_grad, float* loss, float* workspace, const AdamArgs& A,
-                 int B, int K, int N, hipStream_t st, const long* idx = nullptr)
+                 int B, int K, int N, hipStream_t st, const long* idx = nullptr, const MgpP2P* comm = nullptr)
 {
     TrainPlan pl;
     if (!make_train_plan(dims, n_layers, B, K, N, &pl)) return MGP_EUNSUPPORTED;
@@ -481,8 +492,16 @@ int launch_train(const float* X, const float* G, const float* target, const floa
                        K, dims[0], N, pl.MP, pl.MC, pl.acts_floats, pl.maxw, 2.0f / (float)n_out);
     int rc = mgp_launch_status();
     if (rc != MGP_OK) return rc;
-    hipLaunchKernelGGL(train_reduce_kernel, dim3((unsigned)((Pstride + 63) / 64)), dim3(64 * TR_GROUPS), 0, st, workspace,
-                       B * pl.ntx, Pstride, flat_grad, loss, (float)(1.0 / (double)n_out), A);
+    if (comm != nullptr) {
+        if (!comm->connected || comm->dev.n < Pstride || A.p == nullptr) return MGP_EINVAL;
+        hipLaunchKernelGGL(train_reduce_kernel<true>, dim3((unsigned)((Pstride + 63) / 64)), dim3(64 * TR_GROUPS), 0, st,
+                           workspace, B * pl.ntx, Pstride, flat_grad, loss, (float)(1.0 / (double)n_out), A, comm->dev);
+        return mgp_launch_status();
+    }
+    P2PDev none;
+    memset(&none, 0, sizeof(none));
+    hipLaunchKernelGGL(train_reduce_kernel<false>, dim3((unsigned)((Pstride + 63) / 64)), dim3(64 * TR_GROUPS), 0, st, workspace,
+                       B * pl.ntx, Pstride, flat_grad, loss, (float)(1.0 / (double)n_out), A, none);
     return mgp_launch_status();
 }
 
@@ -517,7 +536,7 @@ extern "C" int mgp_train_grads(const float* X, const float* G, const float* targ
 static int train_step_impl(const float* X, const float* G, const float* target, const long* idx, int* cursor, float* loss_hist,
                            int hist_cap, float* flat_param, float* flat_grad, float* m, float* v, const int* dims,
                            int n_layers, float lr, float beta1, float beta2, float eps, int* step_dev, float* loss,
-                           float* workspace, int B, int K, int N, void* stream)
+                           float* workspace, int B, int K, int N, void* stream, const MgpP2P* comm = nullptr)
 {
     if (dims == nullptr) return MGP_EINVAL;
     if (B <= 0 || K <= 0 || N <= 0 || n_layers <= 0 || n_layers > MGP_MAX_LAYERS) return MGP_EINVAL;
@@ -536,7 +555,7 @@ static int train_step_impl(const float* X, const float* G, const float* target, 
     int* ticket = reinterpret_cast<int*>(workspace + (size_t)B * pl.ntx * (pl.Ptot + 1));
     AdamArgs A = {flat_param, m, v, step_dev, ticket, lr, beta1, beta2, eps, cursor, loss_hist, hist_cap};
     return launch_train(X, G, target, W, b, dims, n_layers, flat_grad, loss, workspace, A, B, K, N,
-                        static_cast<hipStream_t>(stream), idx);
+                        static_cast<hipStream_t>(stream), idx, comm);
 }
 
 extern "C" int mgp_train_step(const float* X, const float* G, const float* target, float* flat_param, float* flat_grad,
@@ -556,4 +575,23 @@ extern "C" int mgp_train_step_indexed(const float* Xr, const float* Gr, const fl
     if ((reinterpret_cast<uintptr_t>(idx) & 7u) || (reinterpret_cast<uintptr_t>(cursor) & 3u)) return MGP_EALIGN;
     return train_step_impl(Xr, Gr, Yr, idx, cursor, loss_hist, hist_cap, flat_param, flat_grad, m, v, dims, n_layers, lr, beta1,
                            beta2, eps, step_dev, nullptr, workspace, B, K, N, stream);
+}
+
+
+// Data-parallel forms: the same two launches with the one-shot exchange of p2p_device.h between the local reduction and
+// Adam (every rank of `comm` must make the same calls in the same order).  idx / cursor / loss_hist may all be NULL
+// (mgp_train_step semantics, loss -> loss[0]) or all given (mgp_train_step_indexed semantics).
+extern "C" int mgp_train_step_p2p(const float* X, const float* G, const float* target, const long* idx, int* cursor,
+                                  float* loss_hist, int hist_cap, float* flat_param, float* flat_grad, float* m, float* v,
+                                  const int* dims, int n_layers, float lr, float beta1, float beta2, float eps,
+                                  int* step_dev, float* loss, float* workspace, int B, int K, int N, MgpP2P* comm, void* stream)
+{
+    if (comm == nullptr) return MGP_EINVAL;
+    const bool indexed = idx != nullptr || cursor != nullptr || loss_hist != nullptr;
+    if (indexed) {
+        if (idx == nullptr || cursor == nullptr || loss_hist == nullptr || hist_cap <= 0) return MGP_EINVAL;
+        if ((reinterpret_cast<uintptr_t>(idx) & 7u) || (reinterpret_cast<uintptr_t>(cursor) & 3u)) return MGP_EALIGN;
+    }
+    return train_step_impl(X, G, target, idx, cursor, loss_hist, hist_cap, flat_param, flat_grad, m, v, dims, n_layers, lr, beta1,
+                           beta2, eps, step_dev, loss, workspace, B, K, N, stream, comm);
 }

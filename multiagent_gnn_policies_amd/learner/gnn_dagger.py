@@ -112,13 +112,16 @@ class GraphedUpdate(object):
         self.dist = parallel.is_distributed()
         self.world = parallel.world_size()
         fused_train = bool(learner.use_train_step and L.mgp_train_supported(self.cdims, actor.n_layers, B, K, N))
+        # data parallel with the one-shot exchange up: still two launches, the exchange runs inside the second one
+        self.p2p = learner.p2p if (self.dist and fused_train and getattr(learner, 'p2p', None) is not None
+                                   and learner.p2p.n_floats > opt.flat.numel()) else None
         self.two_launch = fused_train and not self.dist          # reduction + Adam fused: no room for a collective
-        self.train_grads = fused_train and self.dist             # gradients only, Adam after the all-reduce
+        self.train_grads = fused_train and self.dist and self.p2p is None   # gradients only, Adam after the all-reduce
         if fused_train:
             self.tws = torch.zeros((L.mgp_train_workspace(self.cdims, actor.n_layers, B, K, N),), device=dev)
         # the collective is captured into the HIP graph under RCCL; gloo moves data through the host and cannot be
-        self.capturable = (not self.dist) or (torch.distributed.get_backend() == 'nccl'
-                                              and os.environ.get('MGP_DIST_GRAPH', '1') != '0')
+        self.capturable = (not self.dist) or self.p2p is not None or (torch.distributed.get_backend() == 'nccl'
+                                                                      and os.environ.get('MGP_DIST_GRAPH', '1') != '0')
 
     def _enqueue(self):
         from .. import _lib
@@ -130,6 +133,13 @@ class GraphedUpdate(object):
                                         o.lr, o.betas[0], o.betas[1], o.eps, ops._ptr(self.step_dev),
                                         ops._ptr(self.loss), ops._ptr(self.tws), self.B, self.K, self.N, st),
                        'mgp_train_step')
+            return
+        if self.p2p is not None:
+            _lib.check(L.mgp_train_step_p2p(ops._ptr(self.X), ops._ptr(self.G), ops._ptr(self.Y), None, None, None, 0,
+                                            ops._ptr(o.flat), ops._ptr(o.flat_grad), ops._ptr(o.m), ops._ptr(o.v), self.cdims,
+                                            self.nl, o.lr, o.betas[0], o.betas[1], o.eps, ops._ptr(self.step_dev),
+                                            ops._ptr(self.loss), ops._ptr(self.tws), self.B, self.K, self.N,
+                                            self.p2p.handle, st), 'mgp_train_step_p2p')
             return
         if self.train_grads:
             _lib.check(L.mgp_train_grads(ops._ptr(self.X), ops._ptr(self.G), ops._ptr(self.Y), self.Wp, self.bp, self.cdims,
@@ -146,7 +156,7 @@ class GraphedUpdate(object):
             # the ONE exchange of a data-parallel update: 1,730 floats, in place, summed then scaled (reference semantics
             # of a world-times larger minibatch); latency-bound, so never split per tensor
             torch.distributed.all_reduce(o.flat_grad, op=torch.distributed.ReduceOp.SUM)
-            o.flat_grad.mul_(1.0 / self.world)
+            o.flat_grad.div_(self.world)                     # as FlatGradSync: bit-identical paths for any world size
         _lib.check(L.mgp_adam_step_dev(ops._ptr(o.flat), ops._ptr(o.flat_grad), ops._ptr(o.m), ops._ptr(o.v),
                                        o.flat.numel(), o.lr, o.betas[0], o.betas[1], o.eps, ops._ptr(self.step_dev), st),
                    'mgp_adam_step_dev')
@@ -160,14 +170,16 @@ class GraphedUpdate(object):
         if Y is not self.Y:
             self.Y.copy_(Y)
         if self.graph is None and self.capturable:
+            if self.dist and self.p2p is None:
+                parallel.warm_up_collective(self.opt.flat.device)   # communicator set-up must not happen under capture
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             try:
                 with torch.cuda.graph(graph):
                     self._enqueue()
                 self.graph = graph
-            except Exception as e:                    # e.g. a collective the runtime refuses to capture: stay eager, loudly
-                if not self.dist:
+            except RuntimeError as e:                 # a collective the runtime refuses to capture: stay eager, loudly
+                if not self.dist or self.p2p is not None:
                     raise
                 import warnings
                 warnings.warn("data-parallel update: HIP-graph capture of the all-reduce failed (%s); updates are enqueued "
@@ -204,10 +216,32 @@ class DAGGER(object):
         self.actor_optim = FlatAdam(self.actor, lr=args.getfloat('actor_lr'))
         self.grad_sync = FlatGradSync()           # no-op unless torch.distributed is initialised
         self.grad_sync.broadcast_(self.actor_optim.flat)
+        # data-parallel runs: the one-shot exchange of the flat gradient (+ the loss), csrc/p2p_device.h; None = the
+        # torch.distributed collective (single process, MGP_P2P=0, or the exchange could not be brought up)
+        self.p2p = parallel.P2PExchange.create(self.actor_optim.flat.numel() + 1, self.device)
+        self.grad_sync.p2p = self.p2p
         self._graphed = {}                        # batch size -> GraphedUpdate
         self.use_graphed_update = True
         self.use_train_step = True                # two-launch update (mgp_train_step / mgp_train_grads) when covered
         self._train_ws = {}                       # batch size -> workspace of the eager mgp_train_grads path
+
+    def begin_updates(self):
+        """Call before a round of updates of a data-parallel run: aligns the ranks on the host, so that no rank's exchange
+        kernel polls for a peer that is still seconds away (the exchange gives up after 5 s)."""
+        if self.p2p is not None:
+            torch.distributed.barrier()
+
+    def end_updates(self):
+        """After a round of updates: raises if an exchange timed out (synchronises the stream)."""
+        if self.p2p is not None:
+            self.p2p.check()
+
+    def __del__(self):
+        try:
+            if getattr(self, 'p2p', None) is not None:
+                self.p2p.close()
+        except Exception:
+            pass
 
     def _can_graph(self, X):
         """Runs whose shape the fused kernels cover go through GraphedUpdate: a HIP-graph replay per update (the

@@ -95,8 +95,13 @@ class ImitationRun(object):
         if self.memory.curr_size <= c.batch_size:
             return 0
         loss_sum = 0
+        begin, end = getattr(self.learner, 'begin_updates', None), getattr(self.learner, 'end_updates', None)
+        if begin is not None:
+            begin()                                  # data-parallel runs: align the ranks before the exchanges
         for _ in range(c.updates_per_step):
             loss_sum += self.learner.gradient_step(Transition(*zip(*self.memory.sample(c.batch_size))))
+        if end is not None:
+            end()
         self.updates += c.updates_per_step
         return loss_sum
 

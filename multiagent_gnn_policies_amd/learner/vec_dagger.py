@@ -68,6 +68,21 @@ class DeviceReplay(object):
 UPDATES_PER_GRAPH = 32
 
 
+def _dp_mode(learner, frames):
+    """How a data-parallel round of graph-captured updates exchanges its gradients:
+      'p2p'   the one-shot exchange inside the update's second launch (mgp_train_step_p2p); any process-group backend
+      'rccl'  mgp_train_grads -> dist.all_reduce captured in the graph -> mgp_adam_step_filed (frame replay only: the
+              gradient kernel takes its minibatch from the gathered slots)
+      None    neither (gloo without the exchange): updates are enqueued one by one by the caller"""
+    import os
+    import torch.distributed as dist
+    if getattr(learner, 'p2p', None) is not None and learner.p2p.n_floats > learner.actor_optim.flat.numel():
+        return 'p2p'
+    if frames and dist.get_backend() == 'nccl' and os.environ.get('MGP_DIST_GRAPH', '1') != '0':
+        return 'rccl'
+    return None
+
+
 def _replay_updates(obj, U):
     """Run U consecutive updates of `obj` (IndexedUpdates / FrameUpdates: everything an update needs -- minibatch indices,
     cursor, step counter, losses -- lives on the device).  One update is 2-3 short launches (~30 us of GPU time), less than
@@ -101,6 +116,7 @@ def _run_sampled(obj, U, sampler):
     indices of the next one into a pinned staging buffer and enqueues their upload -- a round of updates costs max(host
     sampling, GPU) per update instead of their sum.  Returns the sum of the losses (device tensor)."""
     assert 0 < U <= obj.cap
+    assert obj.idx.shape[0] >= min(obj.cap, U) and obj.idx.shape[1] == obj.B
     if getattr(obj, '_stage', None) is None:
         obj._stage = [torch.empty((UPDATES_PER_GRAPH, obj.B), dtype=torch.long).pin_memory() for _ in range(2)]
         obj._stage_done = [None, None]
@@ -117,6 +133,8 @@ def _run_sampled(obj, U, sampler):
         ev = torch.cuda.Event()
         ev.record()
         obj._stage_done[turn] = ev
+        # a graph of UPDATES_PER_GRAPH updates maps update c to gather slot c % UPDATES_PER_GRAPH: it must start on a multiple
+        assert done % UPDATES_PER_GRAPH == 0
         _replay_updates(obj, n)
         done += n
         turn ^= 1
@@ -148,10 +166,12 @@ class IndexedUpdates(object):
         self.graph = None
 
     @staticmethod
-    def supported(learner, batch_size, N):
+    def supported(learner, batch_size, N, frames=False):
         import ctypes
         from .. import _lib
-        if not (learner.use_graphed_update and learner.use_train_step) or parallel.is_distributed():
+        if not (learner.use_graphed_update and learner.use_train_step):
+            return False
+        if parallel.is_distributed() and _dp_mode(learner, frames) is None:
             return False
         dims = tuple(learner.actor.layers)
         cd = (ctypes.c_int * len(dims))(*dims)
@@ -161,6 +181,13 @@ class IndexedUpdates(object):
     def _enqueue(self):
         from .. import _lib, ops
         L, o, m = _lib.lib(), self.learner.actor_optim, self.memory
+        if parallel.is_distributed():                # data parallel: the one-shot exchange inside the second launch
+            _lib.check(L.mgp_train_step_p2p(
+                ops._ptr(m.delay_state), ops._ptr(m.delay_gso), ops._ptr(m.action), self.idx.data_ptr(), self.cursor.data_ptr(),
+                ops._ptr(self.loss_hist), self.cap, ops._ptr(o.flat), ops._ptr(o.flat_grad), ops._ptr(o.m), ops._ptr(o.v),
+                self.cdims, self.nl, o.lr, o.betas[0], o.betas[1], o.eps, self.step_dev.data_ptr(), None, ops._ptr(self.ws),
+                self.B, self.K, self.N, self.learner.p2p.handle, ops._stream()), 'mgp_train_step_p2p')
+            return
         _lib.check(L.mgp_train_step_indexed(
             ops._ptr(m.delay_state), ops._ptr(m.delay_gso), ops._ptr(m.action), self.idx.data_ptr(), self.cursor.data_ptr(),
             ops._ptr(self.loss_hist), self.cap, ops._ptr(o.flat), ops._ptr(o.flat_grad), ops._ptr(o.m), ops._ptr(o.v),
@@ -287,12 +314,46 @@ class FrameUpdates(object):
         self.step_dev = opt.step_dev
         self.ws = torch.zeros((L.mgp_train_workspace(self.cdims, self.nl, batch_size, self.K, self.N),), device=dev)
         self.graph = None
+        self.dp = _dp_mode(learner, True) if parallel.is_distributed() else None
+        if self.dp == 'rccl':
+            from .actor_fused import _ptr_array
+            pv = opt.views(opt.flat)
+            self.Wp, self.bp, self._keep = _ptr_array(pv[0::2]), _ptr_array(pv[1::2]), pv
+            self.xbuf = torch.zeros((opt.flat.numel() + 1,), device=dev)       # gradient | loss: one all-reduce
+            parallel.warm_up_collective(dev)
 
-    supported = staticmethod(IndexedUpdates.supported)
+    @staticmethod
+    def supported(learner, batch_size, N):
+        return IndexedUpdates.supported(learner, batch_size, N, frames=True)
 
-    def _train(self, ident):
+    def _train(self, ident, slot=0):
+        """One update on the gathered slots: `ident` maps (update cursor, batch item) to a row of X / G / Y; `slot` is the
+        slot this update of the captured sequence reads (only the 'rccl' form needs it spelled out)."""
         from .. import _lib, ops
         L, o = _lib.lib(), self.learner.actor_optim
+        if self.dp == 'p2p':
+            _lib.check(L.mgp_train_step_p2p(
+                ops._ptr(self.X), ops._ptr(self.G), ops._ptr(self.Y), ident.data_ptr(), self.cursor.data_ptr(),
+                ops._ptr(self.loss_hist), self.cap, ops._ptr(o.flat), ops._ptr(o.flat_grad), ops._ptr(o.m), ops._ptr(o.v),
+                self.cdims, self.nl, o.lr, o.betas[0], o.betas[1], o.eps, self.step_dev.data_ptr(), None, ops._ptr(self.ws),
+                self.B, self.K, self.N, self.learner.p2p.handle, ops._stream()), 'mgp_train_step_p2p')
+            return
+        if self.dp == 'rccl':
+            # gradients of this rank's minibatch (+ its loss) into one flat buffer, ONE all-reduce, the step with the
+            # round's bookkeeping (loss filed at the cursor, cursor advanced) -- all captured
+            import torch.distributed as dist
+            B, P = self.B, o.flat.numel()
+            lo = slot * B
+            _lib.check(L.mgp_train_grads(ops._ptr(self.X[lo:lo + B]), ops._ptr(self.G[lo:lo + B]), ops._ptr(self.Y[lo:lo + B]),
+                                         self.Wp, self.bp, self.cdims, self.nl, ops._ptr(self.xbuf), ops._ptr(self.xbuf[P:]),
+                                         ops._ptr(self.ws), B, self.K, self.N, ops._stream()), 'mgp_train_grads')
+            dist.all_reduce(self.xbuf, op=dist.ReduceOp.SUM)
+            self.xbuf.div_(parallel.world_size())
+            _lib.check(L.mgp_adam_step_filed(ops._ptr(o.flat), ops._ptr(self.xbuf), ops._ptr(o.m), ops._ptr(o.v), P, o.lr,
+                                             o.betas[0], o.betas[1], o.eps, self.step_dev.data_ptr(), ops._ptr(self.xbuf[P:]),
+                                             ops._ptr(self.loss_hist), self.cap, self.cursor.data_ptr(), ops._stream()),
+                       'mgp_adam_step_filed')
+            return
         _lib.check(L.mgp_train_step_indexed(
             ops._ptr(self.X), ops._ptr(self.G), ops._ptr(self.Y), ident.data_ptr(), self.cursor.data_ptr(),
             ops._ptr(self.loss_hist), self.cap, ops._ptr(o.flat), ops._ptr(o.flat_grad), ops._ptr(o.m), ops._ptr(o.v),
@@ -311,8 +372,8 @@ class FrameUpdates(object):
         from .. import ops
         assert n == UPDATES_PER_GRAPH
         ops.replay_gather(self.memory, self.idx, self.X, self.G, self.Y, self.mean_pooling, cursor=self.cursor, nb=n)
-        for _ in range(n):
-            self._train(self.ident_many)
+        for i in range(n):
+            self._train(self.ident_many, slot=i)
 
     def run_sampled(self, U, sampler=None):
         """U updates, frame indices drawn per update by `sampler` (default: FrameReplay.sample_ids -- the reference's
@@ -466,11 +527,14 @@ def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
                 state.advance()
         loss_sum = 0.0
         n_updates = updates_per_step * n_envs
-        if n_updates > 0 and memory.curr_size > batch_size and IndexedUpdates.supported(learner, batch_size, N):
+        if n_updates > 0 and memory.curr_size > batch_size and (FrameUpdates if on_device else IndexedUpdates).supported(
+                learner, batch_size, N):
             if indexed is None:
                 indexed = (FrameUpdates(learner, memory, batch_size, n_updates, p.mean_pooling) if on_device
                            else IndexedUpdates(learner, memory, batch_size, n_updates))
+            learner.begin_updates()                                     # data parallel: ranks aligned before the exchanges
             loss_sum = float(indexed.run_sampled(n_updates).item())     # random.sample per update, overlapped with the GPU
+            learner.end_updates()
             updates += n_updates
         elif n_updates > 0 and memory.curr_size > batch_size:
             bufs = learner.graphed_buffers(batch_size, N)        # None: composed eager updates (shape outside the fused kernels)

@@ -62,8 +62,12 @@ def shard_range(n_items, rk=None, world=None):
 class FlatGradSync(object):
     """All-reduce (mean) of one flat gradient buffer + one-off parameter broadcast."""
 
+    p2p = None        # P2PExchange when the one-shot exchange is up (set by the learner)
+
     def all_reduce_mean_(self, flat):
         if is_distributed():
+            if self.p2p is not None and flat.is_cuda and flat.numel() <= self.p2p.n_floats:
+                return self.p2p.allreduce_mean_(flat)
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             flat.div_(dist.get_world_size())
         return flat
@@ -72,6 +76,19 @@ class FlatGradSync(object):
         if is_distributed():
             dist.broadcast(flat, src=src)
         return flat
+
+
+def warm_up_collective(device):
+    """One throw-away all-reduce on a side stream before a collective is captured into a HIP graph (PyTorch's rule for
+    graph capture: whatever a first call sets up -- communicator, streams, buffers -- must exist before capture begins)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        dist.all_reduce(torch.zeros((8,), device=device), op=dist.ReduceOp.SUM)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
 
 
 def _comm_device():
@@ -100,3 +117,111 @@ def all_gather_floats(values):
     parts = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine)
     return [float(v) for part, c in zip(parts, counts) for v in part[:c].cpu().tolist()]
+
+
+class P2PExchange(object):
+    """One-shot exchange of the flat gradient between the ranks of one node (libmgp's mgp_p2p_*: IPC-mapped mailboxes,
+    64-bit {sequence | fp32} packets pushed into every peer's memory, summed in rank order -- bit-identical on every rank;
+    csrc/p2p_device.h).  Replaces the ring all-reduce of `dist.all_reduce` for the 6.9 KB gradient of a data-parallel
+    DAGGER update (one hop instead of 2(W-1)) and lets the exchange run INSIDE the update's second kernel
+    (mgp_train_step_p2p).  Built on top of an initialised process group, which only carries the 64-byte IPC handles and
+    the bring-up check; ranks may share a device (IPC between processes), which is how the one-GPU test box runs it.
+
+    `P2PExchange.create(n_floats)` returns None when the exchange cannot be brought up (MGP_P2P=0, world > 8, IPC refused,
+    or the self-test failing on any rank): callers then keep the torch.distributed collective."""
+
+    def __init__(self, handle, world, rank, n_floats, mem_kind):
+        self.handle, self.world, self.rank, self.n_floats, self.mem_kind = handle, world, rank, n_floats, mem_kind
+
+    @classmethod
+    def create(cls, n_floats, device=None, self_test=True):
+        import ctypes
+        from . import _lib
+        if not is_distributed() or os.environ.get('MGP_P2P', '1') == '0' or not torch.cuda.is_available():
+            return None
+        world, rk = dist.get_world_size(), dist.get_rank()
+        if world < 2:
+            return None
+        L = _lib.lib()
+        cdev = _comm_device()
+        ok = torch.ones((1,), dtype=torch.int32, device=cdev)
+        ptr, comm = ctypes.c_void_p(), None
+        hb = L.mgp_p2p_handle_bytes()
+        mine = torch.zeros((hb,), dtype=torch.uint8)
+        if world > 8 or L.mgp_p2p_create(world, rk, int(n_floats), ctypes.byref(ptr)) != 0:
+            ok.zero_()
+        else:
+            raw = (ctypes.c_ubyte * hb)()
+            _lib.check(L.mgp_p2p_handle(ptr, raw), 'mgp_p2p_handle')
+            mine = torch.tensor(list(raw), dtype=torch.uint8)
+        # every rank takes part in every collective below, whatever happened locally (no rank may be left waiting)
+        parts = [torch.zeros((hb,), dtype=torch.uint8, device=cdev) for _ in range(world)]
+        dist.all_gather(parts, mine.to(cdev))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            blob = bytes(torch.cat([p_.cpu() for p_ in parts]).tolist())
+            if L.mgp_p2p_connect(ptr, blob) != 0:
+                ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            kind = ctypes.c_int()
+            L.mgp_p2p_info(ptr, None, None, None, ctypes.byref(kind))
+            comm = cls(ptr, world, rk, int(n_floats), kind.value)
+            if self_test and not comm._self_test(device):
+                ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) != 1:
+            if ptr.value:
+                L.mgp_p2p_destroy(ptr)
+            return None
+        return comm
+
+    def _self_test(self, device=None):
+        """Two exchanges of known values with a short timeout: both slots, every entry, every peer."""
+        from . import _lib
+        L = _lib.lib()
+        dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        L.mgp_p2p_set_timeout_ms(self.handle, 2000)
+        good = True
+        dist.barrier()
+        for rep in range(2):
+            buf = (torch.arange(self.n_floats, device=dev, dtype=torch.float32) * 0.5 + (self.rank + 1) * (rep + 1))
+            self.allreduce_mean_(buf)
+            # the kernel adds in rank order; this reference adds the same values in the same order
+            ref = torch.zeros_like(buf)
+            for q in range(self.world):
+                ref += torch.arange(self.n_floats, device=dev, dtype=torch.float32) * 0.5 + (q + 1) * (rep + 1)
+            ref /= self.world
+            good = good and bool(torch.equal(buf, ref))
+        good = good and self.status()[0] == 0
+        L.mgp_p2p_set_timeout_ms(self.handle, 5000)
+        return good
+
+    def allreduce_mean_(self, flat):
+        """flat <- mean over ranks, in place, one launch on the current stream (graph capturable)."""
+        from . import _lib, ops
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous() and flat.numel() <= self.n_floats
+        _lib.check(_lib.lib().mgp_p2p_allreduce_mean(self.handle, ops._ptr(flat), flat.numel(), ops._stream()),
+                   'mgp_p2p_allreduce_mean')
+        return flat
+
+    def status(self):
+        """(status, exchanges completed) after synchronising the current stream; status != 0: a peer was late (error)."""
+        import ctypes
+        from . import _lib, ops
+        st, seq = ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.lib().mgp_p2p_status(self.handle, ctypes.byref(st), ctypes.byref(seq), ops._stream()), 'mgp_p2p_status')
+        return st.value, seq.value
+
+    def check(self):
+        st, _ = self.status()
+        if st != 0:
+            from ._lib import MgpError
+            raise MgpError("one-shot gradient exchange: a peer did not publish within the timeout (rank %d of %d)"
+                           % (self.rank, self.world))
+
+    def close(self):
+        from . import _lib
+        if self.handle is not None and self.handle.value:
+            _lib.lib().mgp_p2p_destroy(self.handle)
+        self.handle = None

@@ -112,6 +112,57 @@ def test_data_parallel_update_is_one_graph_replay_with_the_rccl_all_reduce_insid
     assert r.returncode == 0 and 'DP_UPDATE_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
+ROUND = r'''
+import configparser, random, numpy as np, torch, torch.distributed as dist
+from multiagent_gnn_policies_amd import parallel
+parallel.init_from_env()
+assert dist.get_backend() == 'nccl'
+from multiagent_gnn_policies_amd.envs import FlockParams, VecFlock
+from multiagent_gnn_policies_amd.learner.gnn_dagger import DAGGER
+from multiagent_gnn_policies_amd.learner.state_with_delay import BatchedDelayState
+from multiagent_gnn_policies_amd.learner.vec_dagger import FrameReplay, FrameUpdates, collect_round, UPDATES_PER_GRAPH
+cp = configparser.ConfigParser()
+cp['DEFAULT'] = dict(n_states='6', n_actions='2', k='3', hidden_size='32', gamma='0.99', tau='0.5', n_agents='100', actor_lr='1e-3')
+cp['t'] = {}
+dev = torch.device('cuda:0')
+lanes, T, B, N, K, U = 8, 16, 20, 100, 3, 2 * UPDATES_PER_GRAPH + 6
+p = FlockParams(n_agents=N, init_mode='grid')
+res = {}
+mem = None
+for mode in ('single', 'data_parallel'):
+    parallel.is_distributed = (lambda: True) if mode == 'data_parallel' else (lambda: False)   # world 1: the mean is the identity
+    torch.manual_seed(5)
+    learner = DAGGER(dev, cp['t'])
+    if mem is None:
+        sim = VecFlock(lanes, p, dev, with_expert=True)
+        st = BatchedDelayState(dev, lanes, K, 6, N)
+        mem = FrameReplay(lanes, lanes * T, K, N, dev)
+        np.random.seed(3)
+        collect_round(learner, sim, st, mem, torch.full((lanes,), 0.7, device=dev), torch.arange(lanes, dtype=torch.int32, device=dev), 3, T)
+        random.seed(9)
+        ids = [mem.sample_ids(B) for _ in range(U)]
+    assert FrameUpdates.supported(learner, B, N)
+    fu = FrameUpdates(learner, mem, B, U, True)
+    assert fu.dp == ('rccl' if mode == 'data_parallel' else None), fu.dp
+    it = iter(ids)
+    loss = float(fu.run_sampled(U, sampler=lambda: next(it)).item())
+    res[mode] = (loss, learner.actor_optim.flat.clone(), int(learner.actor_optim.step_dev.item()), fu.loss_hist[:U].clone())
+(l0, w0, s0, h0), (l1, w1, s1, h1) = res['single'], res['data_parallel']
+assert s0 == s1 == U
+assert float((h0 - h1).abs().max()) <= 1e-6, float((h0 - h1).abs().max())
+assert float((w0 - w1).abs().max()) <= 1e-7, float((w0 - w1).abs().max())
+dist.destroy_process_group()
+print("DP_ROUND_OK", l0, l1)
+'''
+
+
+def test_data_parallel_round_of_32_update_graphs_with_the_rccl_all_reduce_inside():
+    """World-1 RCCL: the graph of 32 updates with mgp_train_grads -> all_reduce -> mgp_adam_step_filed captured equals the
+    single-process graph of 32 two-launch updates (weights <= 1e-7 after 70 updates, same losses)."""
+    r = _run(ROUND, MGP_P2P='0')
+    assert r.returncode == 0 and 'DP_ROUND_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 def _torchrun_nccl(script_args, nproc=2, timeout=900):
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0')
     env.pop('MGP_DIST_BACKEND', None)
@@ -131,10 +182,38 @@ def test_train_py_two_ranks_rccl():
     assert lines[0] == 'alg, reward' and [l.split(',')[0] for l in lines[1:]] == ['dagger', 'cloning', 'baseline']
 
 
+def _bench_direct(extra, timeout=900):
+    """the driver's form: `python bench.py --gpus 2 ...`, no launcher -- bench.py starts the ranks (RCCL, one GPU each)"""
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k_ in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'MGP_DIST_BACKEND'):
+        env.pop(k_, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + extra, cwd=ROOT, env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
 @needs_two_gpus
-def test_bench_two_ranks_rccl():
+@pytest.mark.parametrize('launcher', ['torchrun', 'none'])
+def test_bench_two_ranks_rccl(launcher):
     import json
-    r = _torchrun_nccl([os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5'])
+    args = ['--steps', '20', '--warmup', '5']
+    r = (_torchrun_nccl([os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + args) if launcher == 'torchrun' else _bench_direct(args))
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['episodes_total'] == 512
+    assert d['dist']['backend'] == 'nccl' and d['dist']['world_size'] == 2
+
+
+@needs_two_gpus
+@pytest.mark.parametrize('p2p', ['1', '0'])
+def test_bench_dagger_two_ranks_rccl(p2p):
+    """configs[3] on two GPUs: the one-shot exchange over xGMI (MGP_P2P=1) and the RCCL all-reduce captured in the graph (0)."""
+    import json
+    os.environ['MGP_P2P'] = p2p
+    try:
+        r = _bench_direct(['--dagger', '--steps', '50', '--warmup', '8', '--updates', '256'])
+    finally:
+        os.environ.pop('MGP_P2P', None)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert d['n_gpus'] == 2 and d['weights_bit_identical_across_ranks'] is True
+    assert d['updates']['exchange'] == ('p2p' if p2p == '1' else 'rccl')

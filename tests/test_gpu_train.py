@@ -198,6 +198,56 @@ def test_bench_two_ranks_contract():
     assert 'cpu_baseline' not in d and 'roofline' in d
 
 
+def _bench_no_launcher(extra, backend='gloo', timeout=900):
+    """`python bench.py --gpus 2 ...` exactly as typed -- NO torchrun, WORLD_SIZE unset: bench.py starts its own ranks."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k_ in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'MGP_DIST_BACKEND'):
+        env.pop(k_, None)
+    if backend is not None:
+        env['MGP_DIST_BACKEND'] = backend
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + extra, cwd=ROOT, env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
+    import json
+    r = _bench_no_launcher(['--steps', '20', '--warmup', '4', '--episodes', '32', '--no-roofline'])
+    assert r.returncode == 0, r.stderr[-3000:]
+    js = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(js) == 1
+    d = json.loads(js[0])
+    assert d['n_gpus'] == 2 and d['dist'] == {'backend': 'gloo', 'world_size': 2, 'devices_visible': torch.cuda.device_count()}
+    assert d['config']['episodes_total'] == 64 and d['parity']['ok']
+
+
+def test_bench_refuses_more_rccl_ranks_than_devices():
+    """The driver's `python bench.py --gpus 8` on a box with fewer devices must fail loudly, not print n_gpus: 1."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer devices than ranks")
+    r = _bench_no_launcher(['--steps', '20', '--warmup', '4'], backend=None)
+    assert r.returncode != 0 and 'one GPU per rank' in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
+
+
+@pytest.mark.parametrize('gpus', [1, 2])
+def test_bench_dagger_round(gpus):
+    """bench.py --dagger (BASELINE configs[3]): collection + graph-captured updates; with 2 ranks (no launcher, sharing the GPU)
+    the gradient goes through the one-shot exchange and the ranks' weights end bit-identical."""
+    import json
+    extra = ['--dagger', '--steps', '40', '--warmup', '8', '--episodes', '16', '--updates', '100']
+    if gpus == 2:
+        r = _bench_no_launcher(extra)
+    else:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + extra, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert d['n_gpus'] == gpus and d['weights_bit_identical_across_ranks'] is True
+    assert d['updates']['count'] == 100 and np.isfinite(d['updates']['mean_loss']) and d['value'] > 0
+    assert d['updates']['exchange'] == ('p2p' if gpus == 2 else 'none (single process)')
+    assert d['dist']['world_size'] == gpus
+
+
 @pytest.mark.parametrize('n,k,paths', [(100, 3, {'two_launch', 'resident'}), (200, 4, {'two_launch', 'resident'}),
                                        (300, 3, {'two_launch', 'factored'})])
 def test_bench_single_gpu_contract_and_paths(n, k, paths):
