@@ -35,7 +35,7 @@ def _seed(seed, env):
 def evaluate_section(args, actor_path, lanes=0, k=None, verbose=True):
     """Episode rewards (list of float) of one cfg section."""
     from multiagent_gnn_policies_amd.learner.gnn_dagger import DAGGER
-    from multiagent_gnn_policies_amd.learner.rollouts import PolicyRunner, run_episode, enable_fast_loop
+    from multiagent_gnn_policies_amd.learner.rollouts import PolicyRunner, run_episode, fast_loop_mode
     if not torch.cuda.is_available():
         raise RuntimeError("eval_model.py needs an MI355X (HIP device); this framework has no CPU compute path")
     device = torch.device("cuda:0")
@@ -55,13 +55,13 @@ def evaluate_section(args, actor_path, lanes=0, k=None, verbose=True):
         state = BatchedDelayState(device, lanes, learner.actor.k, args.getint('n_states'), p.n_agents)
         rewards = evaluate(learner, sim, state, n_episodes, p.max_episode_steps)
     else:
-        enable_fast_loop(env)
         rewards = []
-        for _ in range(n_episodes):
-            runner = PolicyRunner(learner, device, args) if k is None else _RunnerK(learner, device, args, k)
-            rewards.append(run_episode(env, runner.act))       # (fast loop mode: nothing crosses PCIe per step)
-            if verbose:
-                print(rewards[-1])
+        with fast_loop_mode(env):                                  # nothing crosses PCIe per step; previous mode restored
+            for _ in range(n_episodes):
+                runner = PolicyRunner(learner, device, args) if k is None else _RunnerK(learner, device, args, k)
+                rewards.append(run_episode(env, runner.act))
+                if verbose:
+                    print(rewards[-1])
     env.close()
     return rewards
 

@@ -280,7 +280,10 @@ int mgp_rollout_collect(double* x, float* G, float* Xd, const float* const* W, c
 /* Minibatch states from the frame ring: for batch element i with frame index r = idx[(cursor ? *cursor : 0) * Bt + i]
  * (frame index = ring_step * lanes + lane): X[i,k] = features of frame r - k*lanes (ring-wrapped) if age[r] >= k else 0;
  * Y[i] = label[r]; G[i,0] = I, G[i,j] = A_t A_{t-1} .. A_{t-j+1} from the bits (row weight 1/max(deg,1) or 1) if age[r] >= j
- * else 0 (state_with_delay.py:44-53 on the stored history).  idx int64 on the device, cursor int32 on the device or NULL. */
+ * else 0 (state_with_delay.py:44-53 on the stored history).  idx int64 on the device, cursor int32 on the device or NULL.
+ * REQUIRES symmetric membership (bit m of row n == bit n of row m): row i of the product is accumulated along bit ROWS,
+ * reading row n of the stored bits as column n of A -- true for every network of FLOCK-SPEC v1 (radius test; link fading
+ * hashes the unordered pair), wrong for a directed network (e.g. k nearest neighbours), which must not be filed as frames. */
 int mgp_replay_gather(const float* feat, const unsigned long long* bits, const float* label, const int* age,
                       const long* idx, const int* cursor, int Bt, int lanes, int ring_steps, int K, int N, int mean_pooling,
                       float* X, float* G, float* Y, void* stream);

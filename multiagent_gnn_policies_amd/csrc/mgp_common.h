@@ -51,3 +51,19 @@ __device__ __forceinline__ double mgp_wave_sum(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, MGP_WAVE);
     return v;
 }
+
+// One element of torch.optim.Adam (defaults; reference gnn_dagger.py:49,93): exp_avg.lerp_(g, 1-b1);
+// exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2); p.addcdiv_(exp_avg, sqrt(exp_avg_sq)/sqrt(bc2) + eps, -lr/bc1).
+// The roundings are spelled out (explicit fused multiply-adds, nothing left to -ffp-contract) so that every kernel that
+// applies the step -- mgp_adam_step*, the fused reduce of mgp_train_step*, its data-parallel forms -- produces the same
+// bits from the same gradient.
+__device__ __forceinline__ void mgp_adam_elem(float& p, float& m, float& v, float g, float one_m_b1, float b2,
+                                              float one_m_b2, float step_size, float bc2_sqrt, float eps)
+{
+    const float mi = __fmaf_rn(g - m, one_m_b1, m);
+    const float vi = __fmaf_rn(__fmul_rn(one_m_b2, g), g, __fmul_rn(v, b2));
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), eps);
+    p = __fmaf_rn(-step_size, __fdiv_rn(mi, denom), p);
+    m = mi;
+    v = vi;
+}

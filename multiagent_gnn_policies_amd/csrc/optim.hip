@@ -36,13 +36,7 @@ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __re
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float gi = g[i];
-    const float mi = m[i] + (gi - m[i]) * one_m_b1;          // exp_avg.lerp_(grad, 1-beta1)
-    const float vi = v[i] * b2 + one_m_b2 * gi * gi;         // mul_(beta2).addcmul_(grad, grad, 1-beta2)
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = p[i] - step_size * (mi / denom);                  // addcdiv_(exp_avg, denom, -step_size)
-    m[i] = mi;
-    v[i] = vi;
+    mgp_adam_elem(p[i], m[i], v[i], g[i], one_m_b1, b2, one_m_b2, step_size, bc2_sqrt, eps);
 }
 
 // Adam with the step count resident on the device (HIP-graph replayable: no per-step host scalars).  Every thread
@@ -59,13 +53,7 @@ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* 
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
     const float one_m_b1 = (float)(1.0 - (double)b1), one_m_b2 = (float)(1.0 - (double)b2);
-    const float gi = g[i];
-    const float mi = m[i] + (gi - m[i]) * one_m_b1;
-    const float vi = v[i] * b2 + one_m_b2 * gi * gi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = p[i] - step_size * (mi / denom);
-    m[i] = mi;
-    v[i] = vi;
+    mgp_adam_elem(p[i], m[i], v[i], g[i], one_m_b1, b2, one_m_b2, step_size, bc2_sqrt, eps);
 }
 
 __global__ void step_inc_kernel(int* step_dev) { *step_dev += 1; }
@@ -100,15 +88,8 @@ void adam_dev_onewg_kernel(float* __restrict__ p, const float* __restrict__ g, f
     __syncthreads();
     const float step_size = sh[0], bc2_sqrt = sh[1];
     const float one_m_b1 = (float)(1.0 - (double)b1), one_m_b2 = (float)(1.0 - (double)b2);
-    for (long i = threadIdx.x; i < n; i += 1024) {
-        const float gi = g[i];
-        const float mi = m[i] + (gi - m[i]) * one_m_b1;
-        const float vi = v[i] * b2 + one_m_b2 * gi * gi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] = p[i] - step_size * (mi / denom);
-        m[i] = mi;
-        v[i] = vi;
-    }
+    for (long i = threadIdx.x; i < n; i += 1024)
+        mgp_adam_elem(p[i], m[i], v[i], g[i], one_m_b1, b2, one_m_b2, step_size, bc2_sqrt, eps);
     if (threadIdx.x == 0) *step_dev = shs + 1;
 }
 

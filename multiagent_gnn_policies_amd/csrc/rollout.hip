@@ -48,9 +48,9 @@ constexpr int RO_PIECES = 8;              // j-range pieces per agent row in the
 constexpr int RO_MAXN = 128;              // RO_THREADS / RO_PIECES rows; membership bits of a row fit 2 x u64
 constexpr int RO_LDS_LIMIT = 160 * 1024;
 #ifdef MGP_RO_PROFILE
-__device__ unsigned long long mgp_ro_stamps[16 * 16];     // [wave][stamp]
-#define RO_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == 5) mgp_ro_stamps[(threadIdx.x >> 6) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
-#define RO_STAMPX(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) mgp_ro_stamps[(threadIdx.x >> 6) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+__device__ unsigned long long mgp_ro_stamps[16 * 32];     // [wave][stamp]
+#define RO_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == 5) mgp_ro_stamps[(threadIdx.x >> 6) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define RO_STAMPX(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) mgp_ro_stamps[(threadIdx.x >> 6) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define RO_STAMP(i) do { } while (0)
 #define RO_STAMPX(i) do { } while (0)
@@ -80,7 +80,7 @@ struct RoOff {
     int rlist;                            // u8 [H][N][RS] ascending neighbour lists (RS = ro_list_stride(N))
     int rcnt;                             // int [H][N] list lengths
     int sxy;                              // float2 [N] fp32 coordinates relative to the reference point
-    int mmax;                             // uint: max |relative coordinate| of the step (float bits)
+    int mmax;                             // float [8]: max |relative coordinate| of the step, one slot per MLP wave
     int wtab;                             // float [N + 1]: row weight of a network row by its degree (1/max(deg,1) or 1)
     int uexp;                             // float [2][N] expert action of the current state (data collection) + double [2] velocity sums
     int wl;                               // float weight image: per layer fragments [MT][64][RO_WFS] + bias [MT*16]
@@ -117,7 +117,7 @@ __host__ __device__ constexpr RoOff ro_offsets(int N, int K)
     c.rlist = ro_take(off, H * N * ro_list_stride(N));
     c.rcnt = ro_take(off, H * N * 4);
     c.sxy = ro_take(off, N * 8);
-    c.mmax = ro_take(off, 16);
+    c.mmax = ro_take(off, 32);
     c.wtab = ro_take(off, (N + 1) * 4);
     c.uexp = ro_take(off, 2 * N * 4 + 16);
     c.wl = off;
@@ -155,7 +155,6 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     unsigned char* rlist = smraw + cv.rlist;
     int* rcnt = reinterpret_cast<int*>(smraw + cv.rcnt);
     float2* sxy = reinterpret_cast<float2*>(smraw + cv.sxy);
-    unsigned int* mmax = reinterpret_cast<unsigned int*>(smraw + cv.mmax);
     float* wtab = reinterpret_cast<float*>(smraw + cv.wtab);
     float* uexp = reinterpret_cast<float*>(smraw + cv.uexp);                 // [2][N]
     double* vtot = reinterpret_cast<double*>(smraw + cv.uexp + ((2 * N * 4 + 7) & ~7));
@@ -180,7 +179,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     for (int i = tid; i < N; i += RO_THREADS) {
         spx[i] = xb[i * 4 + 0]; spy[i] = xb[i * 4 + 1]; svx[i] = xb[i * 4 + 2]; svy[i] = xb[i * 4 + 3];
     }
-    if (tid == 0) { cref[0] = xb[0]; cref[1] = xb[1]; mmax[0] = 0u; }
+    if (tid == 0) { cref[0] = xb[0]; cref[1] = xb[1]; }
     unsigned long long coin_thr = 0ull;
     unsigned int coin_ep = 0u;
     if (CL) {
@@ -258,7 +257,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     const int gq = tid & 1, gn = (tid >> 1) % N, gt = (tid >> 1) / N;
     const int li = lane & 15, lq = lane >> 4;
     const int pi = tid >> 3, piece = tid & 7;                 // membership: agent row pi, piece of the offset range
-    const int half = N >> 1, dh = (half + RO_PIECES - 1) / RO_PIECES;          // offsets 1..N/2, <= 8 per piece
+    const int dh8 = (N + RO_PIECES - 1) / RO_PIECES;          // candidates per lane of a row in S1: the full row in 8 pieces (<= 16)
     const int fr = tid >> 2, fq = tid & 3;                    // lists / features: agent row fr, lane fq of 4
     const double R2 = p.comm_radius2;
     const float R2f = (float)R2, Rf = sqrtf(R2f);
@@ -393,10 +392,12 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                     // four entries per lane per pass (lists of up to 16 neighbours in ONE pass): all list bytes first, then
                     // every operand read of the pass in flight together, then the multiply-adds in list order -- two LDS
                     // round trips per pass instead of two per entry (entries beyond the list: weight 0 on a valid row)
-                    for (int e = part; e < cnt; e += 16) {
+                    // (the first pass reads its list bytes without waiting for the length: every list byte is a valid row index,
+                    //  entries beyond the list are masked at the multiply-add -- one LDS round trip less on the critical path)
+                    for (int e = part; e == part || e < cnt; e += 16) {
                         int m[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) m[u] = lp[min(e + 4 * u, cnt - 1)];
+                        for (int u = 0; u < 4; ++u) m[u] = lp[min(e + 4 * u, RS - 1)];
                         float g[4]; float4 xa[4]; float2 xb[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
@@ -454,67 +455,92 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 mtp = MT;
                 RO_STAMP(12 + l);
             }
-            if (n_layers > 1) {                               // last hidden layer -> LDS, channel c at slot rpos(c)
-                float* pcol = act + col * RO_CS;
-#pragma unroll
-                for (int a_ = 0; a_ < RO_MAXMT; ++a_)
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr)
-                        if (a_ < mtp) pcol[rr * RO_KS + a_ * 4 + lq] = zc[a_][rr];
-            }
-            // ---------------------------------------------------------- C: output layer (VALU) + integrate, same wave
-            // The 2-wide output layer is a packed-FMA chain (as one zero-padded MFMA m-tile fed from the registers it measured
-            // 1.5k cycles against 0.85k: eight dependent MFMAs on one accumulator).  For this part the lanes are regrouped:
-            // lane L takes agent column L >> 2 of the wave's tile and the 8 channels c = 4 s + (L & 3) (contiguous in the
-            // B-fragment layout), so the four partial sums of a column sit in one quad and are added by DPP.  The first lane of
-            // the quad then integrates the agent (spec section 1, fp64: bit-exact given the action) and publishes its fp32
-            // coordinates for D1.  No workgroup barrier since the hidden layers: the wave only reads activations it wrote
-            // itself (LDS operations of one wave are ordered).
+            // ---------------------------------------------------------- C: output layer + integration, same wave, no barrier
             const int lo_ = n_layers - 1;
             const float* w2 = wl + (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull);
-            const int ccol = wave * 16 + (lane >> 2), cg = lane & 3;
-            const float* zsrc = act + ccol * RO_CS + cg * RO_KS;
-            float zo[RO_KS];
+            if (n_layers > 1) {
+                // The 2-wide output layer on the accumulator registers of the last hidden layer: lane (li, lq) holds channels
+                // c = 16 a + 4 lq + rr of column li, whose weight pairs (W[0][c], W[1][c]) are two 16-byte reads per m-tile;
+                // packed-FMA partials, then the four row groups (lq) of the wave are added with two lane swaps
+                // (v_permlane16_swap / v_permlane32_swap: rows 0+1 | 2+3, then halves) -- every lane of a column ends with the
+                // same (ux, uy), nothing goes through LDS.  Then the agent is integrated by TWO lanes, the x axis by lane
+                // (li, 0) and the y axis by lane (li, 1): the spec's per-axis expression tree (fp64, bit-exact given the
+                // action), half the dependent chain.  (History: activations stored to LDS and re-read by four lanes per column,
+                // 8 channels each, measured 1.35k cycles for this layer; one zero-padded MFMA m-tile 1.5k.)
+                f32x2 u2 = {0.f, 0.f}, u2b = {0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < RO_KS / 4; ++i) {
-                const float4 zq = *reinterpret_cast<const float4*>(zsrc + 4 * i);
-                zo[4 * i] = zq.x; zo[4 * i + 1] = zq.y; zo[4 * i + 2] = zq.z; zo[4 * i + 3] = zq.w;
-            }
-            double px = 0.0, py = 0.0, vx = 0.0, vy = 0.0, cx = 0.0, cy = 0.0;
-            const bool agent = (cg == 0) && ccol < N;
-            if (agent) { px = spx[ccol]; py = spy[ccol]; vx = svx[ccol]; vy = svy[ccol]; cx = cref[0]; cy = cref[1]; }
-            f32x2 u2 = {0.f, 0.f}, u2b = {0.f, 0.f};
-#pragma unroll
-            for (int s_ = 0; s_ < RO_KS; s_ += 2) {           // channel c = 4 s + cg: weights (W[0][c], W[1][c]) at w2[2 c]
-                const float2 wa = *reinterpret_cast<const float2*>(w2 + 2 * (4 * s_ + cg));
-                const float2 wb = *reinterpret_cast<const float2*>(w2 + 2 * (4 * (s_ + 1) + cg));
-                u2 = __builtin_elementwise_fma((f32x2){zo[s_], zo[s_]}, (f32x2){wa.x, wa.y}, u2);
-                u2b = __builtin_elementwise_fma((f32x2){zo[s_ + 1], zo[s_ + 1]}, (f32x2){wb.x, wb.y}, u2b);
-            }
-            u2 = u2 + u2b;
-            float ux = u2.x, uy = u2.y;
-            ux += dpp_f<0xB1>(ux); uy += dpp_f<0xB1>(uy);
-            ux += dpp_f<0x4E>(ux); uy += dpp_f<0x4E>(uy);
-            RO_STAMP(14);
-            float m = 0.f;
-            if (agent) {
-                const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * 4 * RO_KS);
-                ux += bb.x; uy += bb.y;
-                if (CL && (unsigned long long)dagger_coin(cl.seed, coin_ep, (unsigned int)(cl.age0 + t)) < coin_thr) {
-                    ux = uexp[ccol]; uy = uexp[N + ccol];      // the expert drives this step (gnn_dagger.py:157-158)
+                for (int a_ = 0; a_ < RO_MAXMT; ++a_) {
+                    if (a_ < mtp) {
+                        const float4 wa = *reinterpret_cast<const float4*>(w2 + 2 * (16 * a_ + 4 * lq));
+                        const float4 wb = *reinterpret_cast<const float4*>(w2 + 2 * (16 * a_ + 4 * lq) + 4);
+                        u2 = __builtin_elementwise_fma((f32x2){zc[a_][0], zc[a_][0]}, (f32x2){wa.x, wa.y}, u2);
+                        u2b = __builtin_elementwise_fma((f32x2){zc[a_][1], zc[a_][1]}, (f32x2){wa.z, wa.w}, u2b);
+                        u2 = __builtin_elementwise_fma((f32x2){zc[a_][2], zc[a_][2]}, (f32x2){wb.x, wb.y}, u2);
+                        u2b = __builtin_elementwise_fma((f32x2){zc[a_][3], zc[a_][3]}, (f32x2){wb.z, wb.w}, u2b);
+                    }
                 }
-                uact[ccol] = ux; uact[N + ccol] = uy;
-                const float ub[2] = {ux, uy};
-                integrate_one(px, py, vx, vy, ub, 1, ccol < p.n_leaders, p);
-                spx[ccol] = px; spy[ccol] = py; svx[ccol] = vx; svy[ccol] = vy;
-                const float sx = (float)(px - cx), sy = (float)(py - cy);     // fp32 coordinates relative to cref
-                sxy[ccol] = make_float2(sx, sy);
-                m = fmaxf(fabsf(sx), fabsf(sy));
+                u2 = u2 + u2b;
+                const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * 4 * RO_KS);
+                const float ux = rows_sum4(u2.x) + bb.x, uy = rows_sum4(u2.y) + bb.y;
+                RO_STAMP(14);
+                const int axis = lq;                            // 0: x, 1: y, 2 / 3: idle
+                const bool agent = axis < 2 && col < N;
+                if (agent) {
+                    float ua = axis ? uy : ux;
+                    if (CL && (unsigned long long)dagger_coin(cl.seed, coin_ep, (unsigned int)(cl.age0 + t)) < coin_thr)
+                        ua = uexp[axis * N + col];              // the expert drives this step (gnn_dagger.py:157-158)
+                    uact[axis * N + col] = ua;
+                    double pp = spx[axis * N + col], vv = spx[(2 + axis) * N + col];   // (px | py), (vx | vy): [4][N] doubles
+                    const double cc = cref[axis];
+                    double ue = 0.0;
+                    if (col >= p.n_leaders) ue = clipd((double)ua, -p.max_accel, p.max_accel) * p.action_gain;
+                    pp = (pp + vv * p.dt) + ((ue * p.dt) * p.dt) * 0.5;      // integrate_one, one axis
+                    vv = vv + ue * p.dt;
+                    spx[axis * N + col] = pp; spx[(2 + axis) * N + col] = vv;
+                    const float sc = (float)(pp - cc);          // fp32 coordinate relative to cref
+                    reinterpret_cast<float*>(sxy)[2 * col + axis] = sc;
+                }
+                RO_STAMP(15);
+            } else {
+                // no hidden layer: the output layer reads the aggregation tile from LDS; lane L takes agent column L >> 2 of the
+                // wave's tile and the 8 channels c = 4 s + (L & 3), the four partial sums of a column are added by DPP
+                const int ccol = wave * 16 + (lane >> 2), cg = lane & 3;
+                const float* zsrc = act + ccol * RO_CS + cg * RO_KS;
+                float zo[RO_KS];
+#pragma unroll
+                for (int i = 0; i < RO_KS / 4; ++i) {
+                    const float4 zq = *reinterpret_cast<const float4*>(zsrc + 4 * i);
+                    zo[4 * i] = zq.x; zo[4 * i + 1] = zq.y; zo[4 * i + 2] = zq.z; zo[4 * i + 3] = zq.w;
+                }
+                double px = 0.0, py = 0.0, vx = 0.0, vy = 0.0, cx = 0.0, cy = 0.0;
+                const bool agent = (cg == 0) && ccol < N;
+                if (agent) { px = spx[ccol]; py = spy[ccol]; vx = svx[ccol]; vy = svy[ccol]; cx = cref[0]; cy = cref[1]; }
+                f32x2 u2 = {0.f, 0.f}, u2b = {0.f, 0.f};
+#pragma unroll
+                for (int s_ = 0; s_ < RO_KS; s_ += 2) {           // channel c = 4 s + cg: weights (W[0][c], W[1][c]) at w2[2 c]
+                    const float2 wa = *reinterpret_cast<const float2*>(w2 + 2 * (4 * s_ + cg));
+                    const float2 wb = *reinterpret_cast<const float2*>(w2 + 2 * (4 * (s_ + 1) + cg));
+                    u2 = __builtin_elementwise_fma((f32x2){zo[s_], zo[s_]}, (f32x2){wa.x, wa.y}, u2);
+                    u2b = __builtin_elementwise_fma((f32x2){zo[s_ + 1], zo[s_ + 1]}, (f32x2){wb.x, wb.y}, u2b);
+                }
+                u2 = u2 + u2b;
+                float ux = u2.x, uy = u2.y;
+                ux += dpp_f<0xB1>(ux); uy += dpp_f<0xB1>(uy);
+                ux += dpp_f<0x4E>(ux); uy += dpp_f<0x4E>(uy);
+                if (agent) {
+                    const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * 4 * RO_KS);
+                    ux += bb.x; uy += bb.y;
+                    if (CL && (unsigned long long)dagger_coin(cl.seed, coin_ep, (unsigned int)(cl.age0 + t)) < coin_thr) {
+                        ux = uexp[ccol]; uy = uexp[N + ccol];
+                    }
+                    uact[ccol] = ux; uact[N + ccol] = uy;
+                    const float ub[2] = {ux, uy};
+                    integrate_one(px, py, vx, vy, ub, 1, ccol < p.n_leaders, p);
+                    spx[ccol] = px; spy[ccol] = py; svx[ccol] = vx; svy[ccol] = vy;
+                    const float sx = (float)(px - cx), sy = (float)(py - cy);
+                    sxy[ccol] = make_float2(sx, sy);
+                }
             }
-            RO_STAMP(15);
-            m = wave_max_to_last(m);
-            if (lane == 63) atomicMax(mmax, __float_as_uint(m));
-            RO_STAMP(9);  // non-negative floats order like their bit patterns
         } else {
             if (CL) {
                 // meanwhile the other waves file the state this step starts from (reference gnn_dagger.py:178: the transition
@@ -530,111 +556,149 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 for (int e = it0; e < 2 * N; e += nth) fl[e] = uexp[e];
                 if (it0 == 0) cl.age[fs] = cl.age0 + t;
             }
-            // meanwhile the other waves clear the membership bits: this step's pairwise pass starts from empty rows
-            for (int i = tid - NT * 64; i < 2 * N; i += RO_THREADS - NT * 64) rowmask[i] = 0ull;
         }
         __syncthreads();
         RO_STAMP(3);
-        // -------------------------------------------------------------- D1: membership bits, every unordered pair once
-        if (wave == RO_WAVES - 1 && (rewards != nullptr || CL)) {     // reward: one wave, no workgroup barrier
+        // -------------------------------------------------------------- S1: membership bits + neighbour lists of the new state
+        // reward (spec section 4: two-pass population variance of the velocities), one wave, split around the S1 barrier so
+        // that its serial fp64 chain is not what the barrier waits for: the sums here, the variance pass in S2
+        double rw_mx = 0.0, rw_my = 0.0;
+        if (wave == RO_WAVES - 1 && (rewards != nullptr || CL)) {
             double sx = 0.0, sy = 0.0;
             for (int i = lane; i < N; i += 64) { sx += svx[i]; sy += svy[i]; }
-            sx = mgp_wave_sum(sx); sy = mgp_wave_sum(sy);
-            if (CL && lane == 0) { vtot[0] = sx; vtot[1] = sy; }   // the centralised expert's velocity term (phase D3)
-            const double mx = sx / (double)N, my = sy / (double)N;
-            double dv = 0.0;
-            for (int i = lane; i < N; i += 64) {
-                const double ex = svx[i] - mx, ey = svy[i] - my;
-                dv += ex * ex + ey * ey;
-            }
-            const double var = mgp_wave_sum(dv) / (double)N;
-            if (lane == 0 && rewards != nullptr) rewards[(size_t)b * T + t] = -1.0 * var * p.reward_scale;
+            sx = wave_sum_d(sx); sy = wave_sum_d(sy);
+            if (CL && lane == 0) { vtot[0] = sx; vtot[1] = sy; }   // the centralised expert's velocity term (phase S2)
+            rw_mx = sx / (double)N; rw_my = sy / (double)N;
         }
+        // Eight lanes per row, each tests its piece (dh8 = ceil(N / 8) <= 16 candidates) of the FULL row: every unordered pair
+        // is tested by both of its rows -- the fp32 expression is symmetric under i <-> j (dx, dy change sign, their squares do
+        // not), so are the fp64 fallback and the fade hash, hence so are the bits -- which is what removes the cross-row
+        // atomics, the clearing pass and one barrier round trip of dependent LDS traffic: the row's 128-bit word is OR-combined
+        // across its eight lanes on the DPP path and every lane ends up holding it.  The same lanes then write the row's
+        // ASCENDING neighbour list (each its own piece, at the offset the population count of the lower pieces gives), its
+        // length and its row weight.  (History: D1 tested every unordered pair once and set both bits with LDS atomic ORs:
+        // 3.1k cycles for this phase; ballots: 5.6k; the matrix pipe: 3.0k.)
         if (pi < N) {
             // |r2_fp32 - r2_exact| < band for every pair within 2R of each other (coordinates are
             // rounded once relative to cref, M = max |coordinate|); pairs farther than 2R are outside by a wide margin.
             // An infinite band (M = inf) sends every pair to the exact test.
-            const float M = __uint_as_float(mmax[0]);
+            // The band of a pair needs a bound M on the coordinates of ITS two agents only, and only for pairs within 2R of
+            // each other (farther ones miss R^2 by a wide margin): |s_j| <= |s_i| + 2R there, so M = |s_i|_inf + 2R is sound for
+            // every candidate of this row -- no maximum over the flock, and a sound band gives the same final bits whatever
+            // its width (pairs it cannot certify go to the exact test).
+            const float2 si = sxy[pi];
+            const int j0 = piece * dh8, nd = max(0, min(dh8, N - j0));          // this lane's candidates j0 .. j0 + nd - 1
+            const float M = fmaxf(fabsf(si.x), fabsf(si.y)) + 2.0f * Rf;
             const float band = Rf * (16.f * M + 16.f * Rf) * 5.9604645e-8f + R2f * 1.1920929e-7f;
             const float t_in = R2f - band, t_out = R2f + band;
-            const float2 si = sxy[pi];
-            const int d0 = 1 + piece * dh, nd = min(dh, half - d0 + 1);          // this thread's offsets d0 .. d0 + nd - 1
             unsigned int in_m = 0u, unc_m = 0u;
-            float2 sj[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                int j = pi + d0 + min(q, max(nd - 1, 0));
-                j = (j >= N) ? j - N : j;
-                sj[q] = sxy[j];
-            }
-            // sign bits instead of compare / select pairs (a v_cmp -> v_cndmask pair costs wait states on gfx9): the sign of
-            // r2 - t_in says "clearly inside", the sign of t_out - r2 says "clearly outside"; v_alignbit shifts each into
-            // a mask (first test ends in bit 7).  A NaN distance (diverged episode) classifies arbitrarily -- the state is
-            // garbage by then, and every index stays valid.
-            unsigned int out_m = 0u;
+            for (int c0 = 0; c0 < 16; c0 += 8) {
+                if (c0 < dh8) {
+                    float2 sj[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float dx = si.x - sj[q].x, dy = si.y - sj[q].y;
-                const float r2 = fmaf(dy, dy, dx * dx);
-                in_m = __builtin_amdgcn_alignbit(in_m, __float_as_uint(r2 - t_in), 31);
-                out_m = __builtin_amdgcn_alignbit(out_m, __float_as_uint(t_out - r2), 31);
+                    for (int q = 0; q < 8; ++q) sj[q] = sxy[min(j0 + c0 + q, N - 1)];
+                    // sign bits instead of compare / select pairs (a v_cmp -> v_cndmask pair costs wait states on gfx9): the
+                    // sign of r2 - t_in says "clearly inside", the sign of t_out - r2 says "clearly outside"; v_alignbit shifts
+                    // each into a mask (first test ends in bit 7).  A NaN distance (diverged episode) classifies arbitrarily --
+                    // the state is garbage by then, and every index stays valid.
+                    unsigned int im = 0u, om = 0u;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float dx = si.x - sj[q].x, dy = si.y - sj[q].y;
+                        const float r2 = fmaf(dy, dy, dx * dx);
+                        im = __builtin_amdgcn_alignbit(im, __float_as_uint(r2 - t_in), 31);
+                        om = __builtin_amdgcn_alignbit(om, __float_as_uint(t_out - r2), 31);
+                    }
+                    im = __builtin_bitreverse32(im) >> 24;        // test q -> bit q
+                    om = __builtin_bitreverse32(om) >> 24;
+                    in_m |= im << c0;
+                    unc_m |= (~om & ~im & 0xFFu) << c0;
+                }
             }
-            in_m = __builtin_bitreverse32(in_m) >> 24;        // test q -> bit q
-            out_m = __builtin_bitreverse32(out_m) >> 24;
-            const unsigned int valid = (nd > 0) ? ((1u << nd) - 1u) : 0u;      // q >= nd re-tested a duplicate: drop
+            RO_STAMP(16);
+            unsigned int valid = (nd > 0) ? ((1u << nd) - 1u) : 0u;            // candidates beyond the piece re-tested row N - 1
+            const int self = pi - j0;
+            if (self >= 0 && self < nd) valid &= ~(1u << self);                // (r2 = 0 is "inside": the diagonal is not a link)
             in_m &= valid;
-            unc_m = ~out_m & ~in_m & valid;
+            unc_m &= valid;
             while (unc_m) {                                   // rare: the spec's own fp64 expression decides
                 const int q = __builtin_ctz(unc_m);
                 unc_m &= unc_m - 1u;
-                int j = pi + d0 + q;
-                j = (j >= N) ? j - N : j;
+                const int j = j0 + q;
                 const double dx = spx[pi] - spx[j], dy = spy[pi] - spy[j];
                 const double r2 = dx * dx + dy * dy;
                 if (r2 < R2) in_m |= 1u << q;
             }
-            while (in_m) {
-                const int q = __builtin_ctz(in_m);
-                in_m &= in_m - 1u;
-                int j = pi + d0 + q;
-                j = (j >= N) ? j - N : j;
-                if (FD && p.link_drop != 0u &&                // FlockingStochastic-v0: the pair's link is faded this step
-                    !link_up(p, pi, j, N, fade_word(spx[pi], spy[pi]), fade_word(spx[j], spy[j]))) continue;
-                atomicOr(&rm_new[2 * pi + (j >> 6)], 1ull << (j & 63));
-                atomicOr(&rm_new[2 * j + (pi >> 6)], 1ull << (pi & 63));
+            if (FD && p.link_drop != 0u) {                    // FlockingStochastic-v0: links that are faded this step
+                unsigned int mq = in_m;
+                const unsigned int wi = fade_word(spx[pi], spy[pi]);
+                while (mq) {
+                    const int q = __builtin_ctz(mq);
+                    mq &= mq - 1u;
+                    const int j = j0 + q;
+                    if (!link_up(p, pi, j, N, wi, fade_word(spx[j], spy[j]))) in_m &= ~(1u << q);
+                }
+            }
+            RO_STAMP(17);
+            // this lane's bits at their place in the row's 128-bit word
+            unsigned long long lo = 0ull, hi = 0ull;
+            if (j0 < 64) {
+                lo = (unsigned long long)in_m << j0;
+                if (j0 > 48) hi = (unsigned long long)in_m >> (64 - j0);
+            } else {
+                hi = (unsigned long long)in_m << (j0 - 64);
+            }
+            unsigned int w0 = (unsigned int)lo, w1 = (unsigned int)(lo >> 32), w2_ = (unsigned int)hi, w3 = (unsigned int)(hi >> 32);
+            w0 |= dpp_u<0xB1>(w0); w1 |= dpp_u<0xB1>(w1); w2_ |= dpp_u<0xB1>(w2_); w3 |= dpp_u<0xB1>(w3);       // lane ^ 1
+            w0 |= dpp_u<0x4E>(w0); w1 |= dpp_u<0x4E>(w1); w2_ |= dpp_u<0x4E>(w2_); w3 |= dpp_u<0x4E>(w3);       // lane ^ 2
+            w0 |= dpp_u<0x141>(w0); w1 |= dpp_u<0x141>(w1); w2_ |= dpp_u<0x141>(w2_); w3 |= dpp_u<0x141>(w3);   // i -> 7 - i
+            const unsigned long long flo = ((unsigned long long)w1 << 32) | w0, fhi = ((unsigned long long)w3 << 32) | w2_;
+            RO_STAMP(18);
+            int pos;
+            if (j0 < 64) pos = __popcll(flo & ((1ull << j0) - 1ull));
+            else pos = __popcll(flo) + __popcll(fhi & ((1ull << (j0 - 64)) - 1ull));
+            unsigned char* lp = rl_new + pi * RS;
+            unsigned int mq = in_m;
+            while (mq) { lp[pos++] = (unsigned char)(j0 + __builtin_ctz(mq)); mq &= mq - 1u; }
+            RO_STAMP(19);
+            if (piece == 0) {
+                const int cnt = __popcll(flo) + __popcll(fhi);
+                rm_new[2 * pi] = flo; rm_new[2 * pi + 1] = fhi;
+                rc_new[pi] = cnt;
+                w_new[pi] = wtab[cnt];                          // (float)(1 / max(deg, 1)) or 1: the value the spec's row weight rounds to
             }
         }
         __syncthreads();
         RO_STAMP(7);
-        // -------------------------------------------------------------- D2/D3: neighbour lists + fp64 feature terms
-        // stage 1 of step t + 1 rides along when that step will find every factor as a list: x_{t+1-j} . A_{t+1} for taps
-        // j >= 1 over the very neighbour list this phase walks for the features.  A_{t+1}[m, n] = w(deg m) on the (symmetric)
-        // pattern: the neighbour's degree is the population count of ITS bit row (complete since the D1 barrier), its weight
-        // the table entry -- the same value phase D3 stores in w_new[m].
+        // -------------------------------------------------------------- S2: fp64 feature terms  ||  gather stage 1 of step t + 1
+        // Two groups of 4 x pad16(N) threads (four lanes per row, whole waves) work side by side on the lists S1 has written:
+        // the first sums the spec's fp64 feature terms of actual neighbours (and the expert label in collecting builds), the
+        // second runs gather stage 1 of step t + 1 -- x_{t+1-j} . A_{t+1} for taps j >= 1 -- when that step will find every
+        // factor as a list.  A_{t+1}[m, n] = w_new[m] on the (symmetric) pattern.  (History: one group did both inside one
+        // neighbour walk, after building the list itself: 3.7 - 4.7k cycles for this phase.)
         const bool do_s1 = K >= 2 && t + 1 < T && t + 1 + t_off >= K - 1;
         const int curn = (cur + 1 == K) ? 0 : cur + 1;        // ring slot of tap 0 of step t + 1
-        if (tid == RO_THREADS - 1) mmax[0] = 0u;              // consumed in D1 above, refilled in the next step's phase C
         if (tid == RO_THREADS - 2) { cref[0] = spx[0]; cref[1] = spy[0]; }   // next step's reference point (any point is valid)
-        if (tid < 4 * ((N + 15) & ~15)) {                     // 4 lanes per row, whole waves
+        const int grp = 4 * ((N + 15) & ~15);                 // threads per group
+        if (wave == RO_WAVES - 1 && rewards != nullptr) {     // second half of the reward (velocities change in phase C only)
+            double dv = 0.0;
+            for (int i = lane; i < N; i += 64) {
+                const double ex = svx[i] - rw_mx, ey = svy[i] - rw_my;
+                dv += ex * ex + ey * ey;
+            }
+            const double var = wave_sum_d(dv) / (double)N;
+            if (lane == 0) rewards[(size_t)b * T + t] = -1.0 * var * p.reward_scale;
+            RO_STAMP(21);
+        }
+        if (tid < grp) {
             double f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0;
-            float s1[S1T][6];
-#pragma unroll
-            for (int jj = 0; jj < S1T; ++jj)
-#pragma unroll
-                for (int f = 0; f < 6; ++f) s1[jj][f] = 0.f;
             int cnt = 0;
             if (fr < N) {
-                const unsigned long long lo = rm_new[2 * fr], hi = rm_new[2 * fr + 1];
-                cnt = __popcll(lo) + __popcll(hi);
-                unsigned int chunk; int pos;
-                if (fq == 0) { chunk = (unsigned int)lo; pos = 0; }
-                else if (fq == 1) { chunk = (unsigned int)(lo >> 32); pos = __popc((unsigned int)lo); }
-                else if (fq == 2) { chunk = (unsigned int)hi; pos = __popcll(lo); }
-                else { chunk = (unsigned int)(hi >> 32); pos = __popcll(lo) + __popc((unsigned int)hi); }
-                unsigned char* lp = rl_new + fr * RS;
-                while (chunk) { lp[pos++] = (unsigned char)(32 * fq + __builtin_ctz(chunk)); chunk &= chunk - 1u; }
+                cnt = rc_new[fr];
+                const unsigned char* lp = rl_new + fr * RS;
                 const double xi = spx[fr], yi = spy[fr], vxi = svx[fr], vyi = svy[fr];
-                for (int e = fq; e < cnt; e += 4) {           // entries written by this wave's own lanes just above
+                for (int e = fq; e < cnt; e += 4) {
                     const int j = lp[e];
                     const double dx = xi - spx[j], dy = yi - spy[j];
                     const double r2 = dx * dx + dy * dy;
@@ -646,52 +710,15 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                     f3 += vyi - svy[j];
                     f4 += dy * qq;
                     f5 += dy * q;
-                    if (do_s1) {
-                        const float gv = wtab[__popcll(rm_new[2 * j]) + __popcll(rm_new[2 * j + 1])];
-#pragma unroll
-                        for (int jj = 0; jj < S1T; ++jj) {
-                            if (jj < K - 1) {
-                                const float* src = XT + ((size_t)ro_slot(curn, jj + 1, K) * Np + j) * 8;
-                                const float4 x0 = *reinterpret_cast<const float4*>(src);
-                                const float2 x1 = *reinterpret_cast<const float2*>(src + 4);
-                                s1[jj][0] = fmaf(x0.x, gv, s1[jj][0]); s1[jj][1] = fmaf(x0.y, gv, s1[jj][1]);
-                                s1[jj][2] = fmaf(x0.z, gv, s1[jj][2]); s1[jj][3] = fmaf(x0.w, gv, s1[jj][3]);
-                                s1[jj][4] = fmaf(x1.x, gv, s1[jj][4]); s1[jj][5] = fmaf(x1.y, gv, s1[jj][5]);
-                            }
-                        }
-                    }
                 }
             }
             RO_STAMP(8);
-            if (do_s1) {
-#pragma unroll
-                for (int jj = 0; jj < S1T; ++jj) {
-                    if (jj < K - 1) {
-#pragma unroll
-                        for (int f = 0; f < 6; ++f) { s1[jj][f] += dpp_f<0xB1>(s1[jj][f]); s1[jj][f] += dpp_f<0x4E>(s1[jj][f]); }
-                        if (fq == 0 && fr < N) {
-                            if (jj == 0) {                    // tap 1: stage 1 is its only factor -> B-fragment slot
-#pragma unroll
-                                for (int f = 0; f < 6; ++f) act[fr * RO_CS + rpos(f * K + 1)] = s1[0][f];
-                            } else {                          // taps >= 2: running product for stage 2 (buffer parity of q = 1)
-                                float* dst = VB + ((size_t)(K - 2) + (jj - 1)) * Np * 8 + fr * 8;
-                                *reinterpret_cast<float4*>(dst) = make_float4(s1[jj][0], s1[jj][1], s1[jj][2], s1[jj][3]);
-                                *reinterpret_cast<float2*>(dst + 4) = make_float2(s1[jj][4], s1[jj][5]);
-                            }
-                        }
-                    }
-                }
-            }
             f0 += dpp_d<0xB1>(f0); f1 += dpp_d<0xB1>(f1); f2 += dpp_d<0xB1>(f2);
             f3 += dpp_d<0xB1>(f3); f4 += dpp_d<0xB1>(f4); f5 += dpp_d<0xB1>(f5);
             f0 += dpp_d<0x4E>(f0); f1 += dpp_d<0x4E>(f1); f2 += dpp_d<0x4E>(f2);
             f3 += dpp_d<0x4E>(f3); f4 += dpp_d<0x4E>(f4); f5 += dpp_d<0x4E>(f5);
             if (fq == 0 && fr < N) {
-                const double deg = (double)cnt;
-                const double w = p.mean_pooling ? 1.0 / (deg == 0.0 ? 1.0 : deg) : 1.0;
-                w_new[fr] = (float)w;
-                rc_new[fr] = cnt;
-                float* xn = XT + ((size_t)(cur + 1 == K ? 0 : cur + 1) * Np + fr) * 8;     // overwrites the oldest tap
+                float* xn = XT + ((size_t)curn * Np + fr) * 8;     // overwrites the oldest tap (tap K - 1 of step t: not a source of stage 1)
                 *reinterpret_cast<float4*>(xn) = make_float4((float)f0, (float)f1, (float)f2, (float)f3);
                 *reinterpret_cast<float4*>(xn + 4) = make_float4((float)f4, (float)f5, 0.f, 0.f);
                 if (CL) {
@@ -706,6 +733,70 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 y0[rpos(0 * K)] = (float)f0; y0[rpos(1 * K)] = (float)f1; y0[rpos(2 * K)] = (float)f2;
                 y0[rpos(3 * K)] = (float)f3; y0[rpos(4 * K)] = (float)f4; y0[rpos(5 * K)] = (float)f5;
             }
+            RO_STAMP(22);
+        } else if (do_s1 && tid < 2 * grp) {
+            // one summation order for a gather stage wherever it runs: lane `part` of the column's four takes list entries
+            // part, part + 4, ... in order, then the quad sum (l ^ 1, l ^ 2)
+            const int c4 = (tid - grp) >> 2, part = tid & 3;
+            float s1[S1T][6];
+#pragma unroll
+            for (int jj = 0; jj < S1T; ++jj)
+#pragma unroll
+                for (int f = 0; f < 6; ++f) s1[jj][f] = 0.f;
+            if (c4 < N) {
+                const int cnt = rc_new[c4];
+                const unsigned char* lp = rl_new + c4 * RS;
+                // four entries per lane per pass (lists of up to 16 neighbours in ONE pass): the list bytes without waiting for
+                // the length, then every operand read of the pass in flight together, then the multiply-adds in list order
+                // (entries beyond the list are masked; every list byte is a valid row index)
+                for (int e = part; e == part || e < cnt; e += 16) {
+                    int jn[4]; float gv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) jn[u] = lp[min(e + 4 * u, RS - 1)];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) gv[u] = w_new[jn[u]];
+#pragma unroll
+                    for (int jj = 0; jj < S1T; ++jj) {
+                        if (jj < K - 1) {
+                            // tap jj + 1 of step t + 1 = tap jj of step t: ring slot ro_slot(curn, jj + 1) = ro_slot(cur, jj)
+                            const float* src = XT + (size_t)ro_slot(curn, jj + 1, K) * Np * 8;
+                            float4 x0[4]; float2 x1[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                x0[u] = *reinterpret_cast<const float4*>(src + jn[u] * 8);
+                                x1[u] = *reinterpret_cast<const float2*>(src + jn[u] * 8 + 4);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                if (e + 4 * u < cnt) {
+                                    s1[jj][0] = fmaf(x0[u].x, gv[u], s1[jj][0]); s1[jj][1] = fmaf(x0[u].y, gv[u], s1[jj][1]);
+                                    s1[jj][2] = fmaf(x0[u].z, gv[u], s1[jj][2]); s1[jj][3] = fmaf(x0[u].w, gv[u], s1[jj][3]);
+                                    s1[jj][4] = fmaf(x1[u].x, gv[u], s1[jj][4]); s1[jj][5] = fmaf(x1[u].y, gv[u], s1[jj][5]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            RO_STAMP(20);
+#pragma unroll
+            for (int jj = 0; jj < S1T; ++jj) {
+                if (jj < K - 1) {
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) { s1[jj][f] += dpp_f<0xB1>(s1[jj][f]); s1[jj][f] += dpp_f<0x4E>(s1[jj][f]); }
+                    if (part == 0 && c4 < N) {
+                        if (jj == 0) {                        // tap 1: stage 1 is its only factor -> B-fragment slot
+#pragma unroll
+                            for (int f = 0; f < 6; ++f) act[c4 * RO_CS + rpos(f * K + 1)] = s1[0][f];
+                        } else {                              // taps >= 2: running product for stage 2 (buffer parity of q = 1)
+                            float* dst = VB + ((size_t)(K - 2) + (jj - 1)) * Np * 8 + c4 * 8;
+                            *reinterpret_cast<float4*>(dst) = make_float4(s1[jj][0], s1[jj][1], s1[jj][2], s1[jj][3]);
+                            *reinterpret_cast<float2*>(dst + 4) = make_float2(s1[jj][4], s1[jj][5]);
+                        }
+                    }
+                }
+            }
+            RO_STAMP(23);
         }
         __syncthreads();
         RO_STAMP(4);

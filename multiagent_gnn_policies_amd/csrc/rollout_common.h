@@ -141,6 +141,10 @@ template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
+template <int CTRL> __device__ __forceinline__ unsigned int dpp_u(unsigned int v)
+{
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
 template <int CTRL> __device__ __forceinline__ double dpp_d(double v)
 {
     const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
@@ -160,6 +164,38 @@ __device__ __forceinline__ float wave_max_to_last(float v)
     return v;
 }
 
+
+// sum of v over the four 16-lane rows of the wave (lanes l, l ^ 16, l ^ 32, l ^ 48), the same bits in every lane: rows 0 + 1
+// and 2 + 3 with v_permlane16_swap (odd rows of one copy <-> even rows of the other), then the halves with
+// v_permlane32_swap.  Inline asm with two distinct registers (the builtin folds identical operands and adds a copy to itself);
+// s_nop 1 = the two wait states the swap needs after a VALU write of its operands.
+__device__ __forceinline__ float rows_sum4(float v)
+{
+    unsigned int a = __float_as_uint(v), b = __float_as_uint(v);
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    v = __uint_as_float(a) + __uint_as_float(b);
+    a = __float_as_uint(v); b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return __uint_as_float(a) + __uint_as_float(b);
+}
+
+// sum over the 64 lanes of a wave on the VALU cross-lane paths (DPP inside rows of 16, lane swaps across rows), every lane
+// gets the total; fixed order.  (__shfl_xor compiles to ds_bpermute: 12 dependent LDS-pipe round trips per fp64 sum.)
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+    v += dpp_d<0xB1>(v);                                             // lane ^ 1
+    v += dpp_d<0x4E>(v);                                             // lane ^ 2
+    v += dpp_d<0x141>(v);                                            // row_half_mirror
+    v += dpp_d<0x140>(v);                                            // row_mirror: every lane holds its row's sum
+    unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    unsigned int a0 = (unsigned int)b, b0 = a0, a1 = (unsigned int)(b >> 32), b1 = a1;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
+    v = __builtin_bit_cast(double, ((unsigned long long)a1 << 32) | a0) + __builtin_bit_cast(double, ((unsigned long long)b1 << 32) | b0);
+    b = __builtin_bit_cast(unsigned long long, v);
+    a0 = (unsigned int)b; b0 = a0; a1 = (unsigned int)(b >> 32); b1 = a1;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
+    return __builtin_bit_cast(double, ((unsigned long long)a1 << 32) | a0) + __builtin_bit_cast(double, ((unsigned long long)b1 << 32) | b0);
+}
 
 // Weight image of a policy whose layers are <= 32 wide: hidden layers as MFMA A-fragments [MT][64][RO_WFS] + bias [MT*16]
 // (lane = (c & 3) * 16 + (o & 15), slot s = c >> 2, zero padded), the 2-wide output layer as channel-ordered pairs

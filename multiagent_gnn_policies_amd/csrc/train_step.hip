@@ -405,12 +405,7 @@ void train_reduce_kernel(const float* __restrict__ part, int ntiles, int Pstride
             flat_grad[i] = s;
             if (A.p != nullptr) {                        // torch.optim.Adam defaults, same expressions as mgp_adam_step_dev
                 const float one_m_b1 = (float)(1.0 - (double)A.b1), one_m_b2 = (float)(1.0 - (double)A.b2);
-                const float mi = A.m[i] + (s - A.m[i]) * one_m_b1;
-                const float vi = A.v[i] * A.b2 + one_m_b2 * s * s;
-                const float denom = sqrtf(vi) / shc[1] + A.eps;
-                A.p[i] = A.p[i] - shc[0] * (mi / denom);
-                A.m[i] = mi;
-                A.v[i] = vi;
+                mgp_adam_elem(A.p[i], A.m[i], A.v[i], s, one_m_b1, A.b2, one_m_b2, shc[0], shc[1], A.eps);
             }
         }
     }

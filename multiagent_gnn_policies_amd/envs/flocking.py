@@ -53,6 +53,14 @@ class FlockParams:
         return max(0, min(0xFFFFFFFF, int(np.floor(float(self.link_drop) * 4294967296.0))))
 
     @property
+    def symmetric_network(self):
+        """Membership of the network is symmetric (j in N(i) <=> i in N(j)): true for every variant of FLOCK-SPEC v1 -- the
+        radius test is, and link fading hashes the unordered pair.  The frame replay REQUIRES it (mgp_replay_gather walks bit
+        ROW n as column n of A); a directed network (e.g. k nearest neighbours) must return False here, which keeps it off
+        the frame-collecting path."""
+        return True
+
+    @property
     def comm_radius2(self):
         return self.comm_radius * self.comm_radius
 
@@ -301,6 +309,10 @@ class DeviceObservation(object):
     def __getattr__(self, name):             # transpose / reshape / sum / ... : defer to the numpy view
         if name.startswith('_'):
             raise AttributeError(name)
+        if self._np is None and self._dev64 is None:
+            # fast loop mode: there is no numpy view to defer to -- an AttributeError, so that hasattr() / getattr(obj, name,
+            # default) behave (np.asarray(obs) still raises the MgpError that explains the mode)
+            raise AttributeError("%s (observation of the environment's fast loop mode: only its fp32 device side exists)" % name)
         return getattr(self.numpy(), name)
 
 
@@ -332,7 +344,10 @@ class FlockingRelativeEnv(object):
     def fast_loop(self, on):
         if bool(on) != self._fast_loop:
             self._fast_loop = bool(on)
+            old = self._sim
             self._sim = None
+            if old is not None:                      # mid-episode toggle: the new simulator continues from the same state
+                self._ensure().set_state(old.x.cpu().numpy())
 
     # -- configuration -------------------------------------------------------------------------
     def params_from_cfg(self, args):

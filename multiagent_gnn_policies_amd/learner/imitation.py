@@ -58,8 +58,11 @@ class ImitationRun(object):
         self.n_test_local = max(1, hi - lo) if self.world > 1 else self.cfg.n_test_episodes
         self.total_numsteps = 0
         self.updates = 0
-        from .rollouts import enable_fast_loop
-        self.fast = enable_fast_loop(env)          # this package's simulator: the one-environment loop never leaves the device
+        from .rollouts import fast_loop_mode
+        # this package's simulator: the one-environment loop never leaves the device; run() hands the env back in the mode
+        # it came in (a gym_flock-style caller keeps getting numpy observations afterwards)
+        self._mode = fast_loop_mode(env)
+        self.fast = self._mode.__enter__()
 
     # ------------------------------------------------------------------ the three stages of one training episode
     def collect(self, beta):
@@ -121,6 +124,12 @@ class ImitationRun(object):
 
     # ------------------------------------------------------------------ the loop
     def run(self, beta_of_episode, eval_always, keep_best):
+        try:
+            return self._run(beta_of_episode, eval_always, keep_best)
+        finally:
+            self._mode.__exit__(None, None, None)
+
+    def _run(self, beta_of_episode, eval_always, keep_best):
         c, world = self.cfg, self.world
         stats = {'mean': -1.0 * np.inf, 'std': 0}
         for i in range((c.n_train_episodes + world - 1) // world):

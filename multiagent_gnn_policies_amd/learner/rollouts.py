@@ -21,13 +21,38 @@ def run_episode(env, act, on_step=None):
 
 def enable_fast_loop(env):
     """Put one of this package's gym-style environments into its fast loop mode (no host<->device traffic per step);
-    returns True if the environment supports it (any other environment object is left alone)."""
+    returns True if the environment supports it (any other environment object is left alone).  Callers that borrow the
+    user's environment use `fast_loop_mode(env)` instead, which puts the previous mode back."""
     from ..envs.flocking import FlockingRelativeEnv
     raw = getattr(env, 'env', None)
     if isinstance(raw, FlockingRelativeEnv):
         raw.fast_loop = True
         return True
     return False
+
+
+class fast_loop_mode(object):
+    """`with fast_loop_mode(env) as fast:` -- the environment runs in its fast loop mode inside the block (fast = True if it
+    is one of this package's environments) and is handed back in the mode it came in: code written against gym_flock that
+    reuses the env after one of this package's loops keeps getting numpy observations and float rewards."""
+
+    def __init__(self, env):
+        from ..envs.flocking import FlockingRelativeEnv
+        raw = getattr(env, 'env', None)
+        self.raw = raw if isinstance(raw, FlockingRelativeEnv) else None
+        self.prev = None
+
+    def __enter__(self):
+        if self.raw is None:
+            return False
+        self.prev = self.raw.fast_loop
+        self.raw.fast_loop = True
+        return True
+
+    def __exit__(self, *exc):
+        if self.raw is not None:
+            self.raw.fast_loop = self.prev
+        return False
 
 
 def reward_stats(rewards):
@@ -57,9 +82,9 @@ class PolicyRunner(object):
 
 def policy_episode_reward(env, learner, device, args):
     """One policy-only episode (the reference's test loop, gnn_dagger.py:194-203)."""
-    enable_fast_loop(env)
-    runner = PolicyRunner(learner, device, args)
-    return run_episode(env, runner.act)
+    with fast_loop_mode(env):
+        runner = PolicyRunner(learner, device, args)
+        return run_episode(env, runner.act)
 
 
 def _actor_params(actor):

@@ -217,7 +217,8 @@ class FrameReplay(object):
     [ring_steps][lanes] -- features x_t (6,N), membership bits of A_t (N x 2 u64), expert label (2,N), age -- 4.8 KB per
     transition at N = 100 where a dense (delay_state, delay_gso) pair takes 128 KB.  The K-tap state of a transition is
     rebuilt from its frame and its K - 1 predecessors in the ring (same lane) by mgp_replay_gather, so the ring keeps K - 1
-    guard steps behind the sampled window.  Ring + sampling semantics are the reference's (replay_buffer.py:21-41): once
+    guard steps behind the sampled window.  Requires networks with SYMMETRIC membership (row n of the bits is used as column
+    n of A_t; FlockParams.symmetric_network, checked by collect_supported).  Ring + sampling semantics are the reference's (replay_buffer.py:21-41): once
     full, the oldest transitions are overwritten; `sample_ids` draws without replacement from Python's `random` stream."""
 
     def __init__(self, lanes, capacity, K, N, device):
@@ -432,10 +433,14 @@ def evaluate(learner, sim, state, n_episodes, steps):
     return rewards[:n_episodes]
 
 
-def collect_supported(learner, K, N):
+def collect_supported(learner, K, N, params=None):
     """The collecting builds of the episode-resident kernels cover the shape (mgp_rollout_collect: N <= 256, 6 features,
-    2-D actions, aggregation in front of the first layer, widths <= 64)."""
+    2-D actions, aggregation in front of the first layer, widths <= 64) AND the simulator's networks have symmetric
+    membership (`params.symmetric_network`): the frame replay stores bit ROWS and rebuilds `A_t A_{t-1} ...` reading row n as
+    column n, which a directed network would silently get wrong."""
     from .. import ops
+    if params is not None and not getattr(params, 'symmetric_network', True):
+        return False
     return (learner.actor.ind_agg == 0 and learner.n_states == 6 and N <= 256
             and ops.rollout_supported(tuple(learner.actor.layers), K, N))
 
@@ -483,7 +488,7 @@ def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
     N, K, F, n_a = p.n_agents, args.getint('k'), args.getint('n_states'), args.getint('n_actions')
     T = episode_steps or p.max_episode_steps
     learner = DAGGER(device, args)
-    on_device = collect_supported(learner, K, N) and args.get('collect', 'device') != 'host'
+    on_device = collect_supported(learner, K, N, p) and args.get('collect', 'device') != 'host'
     # The reference's ring of `buffer_size` (10,000) transitions holds its 20 most recent WHOLE episodes.  Here n_envs
     # episodes advance in lock step, so a ring shorter than one round (n_envs * T transitions) would keep only the last
     # steps of every episode -- the already-flocked states -- and the policy would never see a start-up state.  The ring

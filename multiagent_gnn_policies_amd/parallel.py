@@ -83,11 +83,17 @@ def warm_up_collective(device):
     graph capture: whatever a first call sets up -- communicator, streams, buffers -- must exist before capture begins)."""
     if not (dist.is_available() and dist.is_initialized()):
         return
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
+    mode = os.environ.get('MGP_WARMUP', 'side')
+    if mode == 'none':
+        return
+    if mode == 'side':
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            dist.all_reduce(torch.zeros((8,), device=device), op=dist.ReduceOp.SUM)
+        torch.cuda.current_stream().wait_stream(side)
+    else:
         dist.all_reduce(torch.zeros((8,), device=device), op=dist.ReduceOp.SUM)
-    torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
 
 

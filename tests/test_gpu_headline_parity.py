@@ -34,9 +34,43 @@ def elem_err(u, ref):
     return float(np.max(np.abs(u - ref) / np.maximum(1.0, np.abs(ref))))
 
 
-def _fresh(seed=1000, B=B_FULL):
+def elem_err_per_episode(u, ref):
+    u = np.asarray(u, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
+    return (np.abs(u - ref) / np.maximum(1.0, np.abs(ref))).reshape(u.shape[0], -1).max(axis=1)
+
+
+def _fresh(seed=1000, B=B_FULL, init='grid'):
     import bench
-    return bench.Rollout(torch.device('cuda:0'), B, N, K, [32, 32], seed=seed)
+    return bench.Rollout(torch.device('cuda:0'), B, N, K, [32, 32], seed=seed, init_mode=init)
+
+
+def _reference_fp32(G, X, Ws, bs, idx):
+    """The reference op sequence evaluated in fp32 twice: numpy (oracle/actor.py) and PyTorch-CPU (oracle/torch_port.py, the
+    reference's own framework and op order: actor.py:63-82)."""
+    from oracle import torch_port
+    a = oa.forward(X[idx], G[idx], Ws, bs, 0, dtype=np.float32)
+    with torch.no_grad():
+        b = torch_port.actor_forward(torch.from_numpy(X[idx]), torch.from_numpy(G[idx]), [torch.from_numpy(w) for w in Ws],
+                                     [torch.from_numpy(v) for v in bs], 0, K).numpy()
+    return a, b
+
+
+def _check_bound(u, ref, noise_refs, what, plain_everywhere):
+    """Elementwise 1e-5 against the exact result on every episode where the fp32 REFERENCE is itself determined to 5e-6;
+    elsewhere (agents about to collide: 1/r^4 features of 1e4 and more) within 1e-5 + the reference's own distance to the
+    exact result, factor one -- the triangle-inequality form of "within 1e-5 of the fp32 reference".  The reference's distance
+    is the larger of its two fp32 evaluations' (numpy and PyTorch-CPU op order: on such states they differ from each other by
+    several 1e-5)."""
+    err = elem_err_per_episode(u, ref)
+    noise = np.maximum.reduce([elem_err_per_episode(r_, ref) for r_ in noise_refs])
+    well = noise <= 5e-6
+    print('%s: worst elementwise err %.3g (well-conditioned episodes: %d of %d, worst there %.3g); reference fp32 itself %.3g; '
+          'max |ref| %.3g' % (what, err.max(), int(well.sum()), len(well), err[well].max() if well.any() else 0.0, noise.max(),
+                              float(np.max(np.abs(ref)))))
+    assert np.all(err <= 1e-5 + noise)
+    assert np.all(err[well] <= 1e-5)
+    if plain_everywhere:
+        assert np.all(err <= 1e-5)
 
 
 def _weights():
@@ -47,35 +81,33 @@ def _oracle_action(G, X, Ws, bs, idx):
     return oa.forward(X[idx].astype(np.float64), G[idx].astype(np.float64), Ws, bs, 0, dtype=np.float64)
 
 
+@pytest.mark.parametrize('init', ['grid', 'disc'])
 @pytest.mark.parametrize('T', [1, 2, 3, 5, 20, 61])
-def test_resident_last_action_elementwise_1e5_full_batch(T):
+def test_resident_last_action_elementwise_1e5_full_batch(T, init):
+    """init = 'grid': the jittered lattice; 'disc': the environment's own reset distribution at N = 100 (bench.py's default:
+    mean degree 8.5 at reset, agents as close as 0.1 R, so some episodes are ill-conditioned early on)."""
     from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
     Ws, bs = _weights()
-    ro = _fresh()
+    ro = _fresh(init=init)
     assert 'reference checkpoint' in ro.weights
     if T > 1:
         ro.run_resident(T - 1)
     G = ro.state.delay_gso.cpu().numpy(); X = ro.state.delay_state.cpu().numpy()
     ref = _oracle_action(G, X, Ws, bs, SAMPLED)
-    ro2 = _fresh()
+    ro2 = _fresh(init=init)
     action = torch.zeros((B_FULL, 1, 2, N), device='cuda')
     rewards = torch.zeros((B_FULL, T), device='cuda', dtype=torch.float64)
     assert policy_rollout(ro2.actor, ro2.sim, ro2.state, T, rewards=rewards, action=action)
     u = action.cpu().numpy()[SAMPLED]
-    err = elem_err(u, ref)
     # how far the REFERENCE op sequence evaluated in fp32 is from the exact result on these very inputs: 1e-6 .. 3e-6 on
-    # the states of this test except around step 20, where the freshly reset lattice has collapsed locally (1/r^4 features
-    # reach 1e4) and the reference's own fp32 evaluations -- numpy vs torch op order -- differ by 4e-5 from each other
-    noise = elem_err(oa.forward(X[SAMPLED], G[SAMPLED], Ws, bs, 0, dtype=np.float32), ref)
-    print('resident kernel, last action of a %d-step launch, B=%d: elementwise err %.3g vs exact (reference fp32 itself: '
-          '%.3g; max |ref| %.3g)' % (T, B_FULL, err, noise, float(np.max(np.abs(ref)))))
-    assert err <= 1e-5 + noise                 # within 1e-5 of the fp32 reference (triangle inequality through exact)
-    if T != 20:
-        assert err <= 1e-5                     # well-conditioned states: the plain bound, no allowance at all
+    # the lattice states of this test except around step 20, where the freshly reset lattice has collapsed locally (1/r^4
+    # features reach 1e4) and the reference's own fp32 evaluations -- numpy vs torch op order -- differ by 4e-5 from each other
+    _check_bound(u, ref, _reference_fp32(G, X, Ws, bs, SAMPLED), 'resident kernel, last action of a %d-step launch, B=%d, %s resets' % (T, B_FULL, init),
+                 plain_everywhere=(init == 'grid' and T != 20))
     # the step itself: integration bit-exact given that action, network bit-exact (oracle/flock.py: FLOCK-SPEC v1)
     x_before = ro.sim.x.cpu().numpy(); x_after = ro2.sim.x.cpu().numpy()
     G_after = ro2.state.delay_gso.cpu().numpy()
-    op = ofl.FlockParams(n_agents=N, init_mode='grid')
+    op = ofl.FlockParams(n_agents=N, init_mode=init)
     for k_, b in enumerate(SAMPLED[:6]):
         x_ref, vals, net, r = ofl.step(x_before[b], u[k_, 0].T.astype(np.float32), op)
         assert np.array_equal(x_after[b], x_ref)
@@ -83,20 +115,19 @@ def test_resident_last_action_elementwise_1e5_full_batch(T):
         assert abs(rewards[b, T - 1].item() - r) <= 1e-12 * max(1.0, abs(r))
 
 
-def test_two_launch_actor_elementwise_1e5_full_batch():
+@pytest.mark.parametrize('init', ['grid', 'disc'])
+def test_two_launch_actor_elementwise_1e5_full_batch(init):
     """mgp_actor_fwd (the dense-contract kernel) on the states of a running flock, elementwise 1e-5, all 256 episodes'
     kernel outputs, 16 through the oracle."""
     Ws, bs = _weights()
-    ro = _fresh()
-    worst = 0.0
+    ro = _fresh(init=init)
     for t in range(6):
         G = ro.state.delay_gso.cpu().numpy(); X = ro.state.delay_state.cpu().numpy()
         with torch.no_grad():
             out = ro.actor(ro.state.delay_state, ro.state.delay_gso).cpu().numpy()
-        worst = max(worst, elem_err(out[SAMPLED], _oracle_action(G, X, Ws, bs, SAMPLED)))
+        _check_bound(out[SAMPLED], _oracle_action(G, X, Ws, bs, SAMPLED), _reference_fp32(G, X, Ws, bs, SAMPLED),
+                     'mgp_actor_fwd, state %d after a %s reset, B=256' % (t, init), plain_everywhere=(init == 'grid'))
         ro.step()
-    print('mgp_actor_fwd on six consecutive states, B=256: elementwise err %.3g' % worst)
-    assert worst <= 1e-5
 
 
 def test_reset_push_after_strided_steps_reads_the_reset_observation():

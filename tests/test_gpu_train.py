@@ -323,6 +323,80 @@ def test_indexed_updates_equal_the_sampled_path():
     assert torch.allclose(iu.loss_hist[:7].cpu(), torch.tensor(losses[5:]), rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize('kind', ['dense', 'frames'])
+def test_pipelined_sampling_equals_the_uploaded_round(kind):
+    """`run_sampled` (the update path of train_dagger_vec: pinned double-buffered index staging, graphs of 32 updates + a
+    remainder on the one-update graph) against `run(ids)` on the same ids, U not a multiple of 32: identical weights and
+    per-update losses -- for the dense replay (IndexedUpdates) and the frame replay (FrameUpdates: gather-many slots)."""
+    import random
+    from multiagent_gnn_policies_amd.envs import FlockParams, VecFlock
+    from multiagent_gnn_policies_amd.learner.gnn_dagger import DAGGER
+    from multiagent_gnn_policies_amd.learner.state_with_delay import BatchedDelayState
+    from multiagent_gnn_policies_amd.learner.vec_dagger import (DeviceReplay, IndexedUpdates, FrameReplay, FrameUpdates,
+                                                                collect_round, UPDATES_PER_GRAPH)
+    dev = torch.device('cuda:0')
+    N, K, B, U = 100, 3, 20, 2 * UPDATES_PER_GRAPH + 7
+    args = _args(n_agents=N, k=K, hidden_size=32, gamma=0.99, tau=0.5, actor_lr=1e-3)
+    torch.manual_seed(11); a = DAGGER(dev, args)
+    torch.manual_seed(11); b = DAGGER(dev, args)
+    if kind == 'dense':
+        mem = DeviceReplay(64, K, 6, N, 2, dev)
+        g = torch.Generator(device='cuda').manual_seed(3)
+        for _ in range(4):
+            mem.insert_batch(torch.randn((16, K, 6, N), device=dev, generator=g),
+                             0.05 * torch.rand((16, K, N, N), device=dev, generator=g),
+                             torch.randn((16, 1, 2, N), device=dev, generator=g))
+        random.seed(5)
+        ids = [random.sample(range(mem.curr_size), B) for _ in range(U)]
+        ua, ub = IndexedUpdates(a, mem, B, U), IndexedUpdates(b, mem, B, U)
+    else:
+        lanes, T = 8, 12
+        sim = VecFlock(lanes, FlockParams(n_agents=N, init_mode='grid'), dev, with_expert=True)
+        st = BatchedDelayState(dev, lanes, K, 6, N)
+        mem = FrameReplay(lanes, lanes * T, K, N, dev)
+        np.random.seed(2)
+        collect_round(a, sim, st, mem, torch.full((lanes,), 0.6, device=dev), torch.arange(lanes, dtype=torch.int32, device=dev), 1, T)
+        random.seed(5)
+        ids = [mem.sample_ids(B) for _ in range(U)]
+        ua, ub = FrameUpdates(a, mem, B, U, True), FrameUpdates(b, mem, B, U, True)
+    it = iter(ids)
+    la = float(ua.run_sampled(U, sampler=lambda: next(it)).item())
+    lb = float(ub.run(ids).item())
+    assert a.actor_optim.step_count == b.actor_optim.step_count == U
+    assert int(a.actor_optim.step_dev.item()) == U
+    assert torch.equal(a.actor_optim.flat, b.actor_optim.flat)
+    assert torch.equal(ua.loss_hist[:U], ub.loss_hist[:U]) and la == lb
+
+
+def test_borrowed_env_is_handed_back_in_numpy_mode():
+    """This package's loops run the user's gym-style env in its fast loop mode and must hand it back as they found it: a
+    gym_flock-style caller keeps getting numpy-convertible observations and float rewards afterwards."""
+    from multiagent_gnn_policies_amd import envs
+    from multiagent_gnn_policies_amd.learner.gnn_dagger import DAGGER
+    from multiagent_gnn_policies_amd.learner.rollouts import policy_episode_reward, fast_loop_mode
+    dev = torch.device('cuda:0')
+    args = _args(n_agents=20, k=2, hidden_size=16, gamma=0.99, tau=0.5, actor_lr=1e-3, comm_radius=1.0, v_max=3.0)
+    env = envs.make('FlockingRelative-v0', device='cuda:0', max_episode_steps=6)
+    env.env.params_from_cfg(args)
+    env.seed(3)
+    assert env.env.fast_loop is False
+    r = policy_episode_reward(env, DAGGER(dev, args), dev, args)
+    assert np.isfinite(r) and env.env.fast_loop is False
+    obs = env.reset()
+    assert np.asarray(obs[0]).shape == (20, 6) and np.asarray(obs[1]).shape == (20, 20)
+    obs, rew, done, _ = env.step(np.zeros((20, 2)))
+    assert isinstance(rew, float) and np.asarray(obs[0]).dtype == np.float64
+    # a mid-episode toggle continues the episode, and fast-mode observations answer hasattr() instead of raising
+    x_before = env.env._sim.x.clone()
+    with fast_loop_mode(env) as fast:
+        assert fast and torch.equal(env.env._sim.x, x_before)
+        o2, r2, _, _ = env.step(torch.zeros((20, 2), device=dev))
+        assert torch.is_tensor(r2) and not hasattr(o2[0], 'transpose')
+        with pytest.raises(Exception):
+            np.asarray(o2[0])
+    assert env.env.fast_loop is False
+
+
 def test_vectorised_dagger_trains():
     """Device-resident DAGGER on 16 parallel episodes: finite statistics, updates happened, policy improves over
     the untrained network on the imitation loss of fresh expert-labelled states."""

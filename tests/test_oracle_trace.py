@@ -47,8 +47,7 @@ def test_golden_trace_is_the_configuration_the_tests_assume():
 
 def test_oracle_loop_reproduces_the_reference_trace():
     tr, g = run_oracle_trace()
-    err = tt.compare_with_golden(tr, g)
-    assert err['weights'] > 0 or err['losses'] >= 0
+    tt.compare_with_golden(tr, g)                     # asserts event order, betas, outcomes, indices, losses, weights
 
 
 def test_trace_comparison_is_sensitive():

@@ -82,18 +82,21 @@ int main(int argc, char** argv) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("%sB=%d N=%d K=%d T=%d resident rollout: %.1f us per launch, %.2f us per step -> %.3e agent-steps/s\n", use_carry ? "[carry] " : "", B, N, K, T,
            1e3 * ms / IT, 1e3 * ms / IT / T, (double)B * N * T / (1e-3 * ms / IT));
-    unsigned long long st[256];
+    unsigned long long st[512];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(mgp_ro_stamps), sizeof(st));
     const char* names[] = {"step start", "A done (barrier)", "B hidden layers (waves 0-6) + G_1 expansion (waves 7-15) done (barrier)", "B+C: hidden layers, output layer, integration (waves 0-6) / bit clearing (waves 7-15) done (barrier)",
                            "D2/D3 done (barrier)", "step done", "A: first gather stage of this wave done", "D1: membership bits done (barrier)",
-                           "D2/D3: lists + neighbour feature terms done (waves 0-6)", "C: max published (atomic issued)", "D: lists written", "E: rows of slices >= 2 done (barrier)", "B: layer 0 tile done (before barrier)", "B: layer 1 tile done", "C: output layer + quad sums done", "C: integrated, coordinates stored"};
-    const int order[] = {0, 6, 1, 12, 13, 14, 15, 9, 3, 7, 8, 4, 5};
-    printf("cycles since step start, lane 0 of waves 0 / 3 / 7 / 9 / 12 / 15\n");
-    const int wv[] = {0, 3, 7, 9, 12, 15};
-    for (int oi = 0; oi < 13; ++oi) {
+                           "D2/D3: lists + neighbour feature terms done (waves 0-6)", "C: max published (atomic issued)", "D: lists written", "E: rows of slices >= 2 done (barrier)", "B: layer 0 tile done (before barrier)", "B: layer 1 tile done", "C: output layer + quad sums done", "C: integrated, coordinates stored", "S1: pair tests done", "S1: fallback / fading done", "S1: row word combined", "S1: list written", "S2: gather group loop done", "S2: reward wave done", "S2: features group done", "S2: gather group done"};
+    const int order[] = {0, 6, 1, 12, 13, 14, 15, 3, 16, 17, 18, 19, 7, 8, 22, 20, 23, 21, 4, 5};
+    printf("cycles since step start, lane 0 of waves 0 1 2 3 4 5 6 | 7 9 13 15\n");
+    const int wv[] = {0, 1, 2, 3, 4, 5, 6, 7, 9, 13, 15};
+    for (int oi = 0; oi < 20; ++oi) {
         const int i = order[oi];
         printf("  stamp %2d :", i);
-        for (int w = 0; w < 6; ++w) printf(" %7lld", (long long)(st[wv[w] * 16 + i] - st[0]));
+        for (int w = 0; w < 11; ++w) {
+            const long long d = (long long)(st[wv[w] * 32 + i] - st[0]);
+            if (d > -100000 && d < 10000000) printf(" %6lld", d); else printf("      -");
+        }
         printf("  %s\n", names[i]);
     }
     printf("exit, wave 0 (cycles since exit start): after slice K-1 %lld | after slice K-2 %lld | kernel end %lld\n", (long long)(st[11] - st[10]), (long long)(st[12] - st[10]), (long long)(st[2] - st[10]));
