@@ -815,16 +815,35 @@ def main():
     resident = ro.resident_supported() and not args.no_resident
     el_res, res_launch_ms = None, None
     if resident:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-
+        # HIP events stamped by the kernel launch itself (mgp_set_launch_events -> hipExtLaunchKernel: the kernel's own begin /
+        # end on its stream): an event RECORDED in front of the launch makes the host wait tens of microseconds on an idle
+        # stream before it can enqueue the kernel -- a fifth of a 20-step region.  One launch per timed region
+        # (--steps <= 2000); longer regions sum their launches.
+        from multiagent_gnn_policies_amd import _lib as mgp_lib
+        n_l = (args.steps + 1999) // 2000
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_l)]
+        for a_, b_ in evs:
+            a_.record(); b_.record()                             # creates the underlying hipEvent_t handles (outside the timed region)
+        torch.cuda.synchronize()
         ro.prepare_resident([args.warmup, args.steps])
+        timing_on = [False]
 
         def run_res(n_steps):
-            e0.record()
-            ro.run_resident(n_steps)
-            e1.record()
-        el_res = timed(run_res)
-        res_launch_ms = e0.elapsed_time(e1)                      # HIP events around the timed launches (this rank)
+            if not timing_on[0]:
+                ro.run_resident(n_steps)
+                return
+            done = 0
+            for a_, b_ in evs:
+                t = min(2000, n_steps - done)
+                mgp_lib.lib().mgp_set_launch_events(a_.cuda_event, b_.cuda_event)
+                ro.run_resident(t)
+                done += t
+
+        def run_res_timed(n_steps):
+            timing_on[0] = (n_steps == args.steps)
+            run_res(n_steps)
+        el_res = timed(run_res_timed)
+        res_launch_ms = sum(a_.elapsed_time(b_) for a_, b_ in evs)   # the timed launches' own durations (this rank)
     el_fact = None
     if ro.factored_supported() and not args.no_resident:
         ro.restart(1000 + rank)

@@ -41,6 +41,12 @@ extern "C" {
 
 int         mgp_version(void);
 const char* mgp_strerror(int code);
+/* Kernel timing without marker packets: the NEXT mgp_rollout_steps / _steps_ex / _collect launch of the calling thread stamps
+ * the given hipEvent_t handles (either may be NULL) with the kernel's own begin and end (hipExtLaunchKernel), then forgets
+ * them.  The events must have been created with timing enabled; hipEventElapsedTime(start, stop) after completion is the
+ * kernel's duration.  (An event recorded in front of a launch on an idle stream delays that launch by tens of microseconds.) */
+int  mgp_set_launch_events(void* start_event, void* stop_event);
+
 /* Text of the HIP error behind the calling thread's most recent MGP_ELAUNCH. */
 const char* mgp_last_hip_error(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName; returns CU count or a negative code. */

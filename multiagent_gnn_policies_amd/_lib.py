@@ -40,6 +40,7 @@ SIGNATURES = {
     'mgp_strerror': (ctypes.c_char_p, [_int]),
     'mgp_last_hip_error': (ctypes.c_char_p, []),
     'mgp_device_info': (_int, [ctypes.c_char_p, _int]),
+    'mgp_set_launch_events': (_int, [_vp, _vp]),
     'mgp_agg_fwd': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _long, _long, _long, _long, _long, _long, _vp]),
     'mgp_agg_bwd_x': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _long, _long, _long, _long, _long, _long, _vp]),
     'mgp_dense_fwd': (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _long, _long, _long, _int, _vp]),

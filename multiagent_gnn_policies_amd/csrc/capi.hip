@@ -3,6 +3,7 @@
 #include "mgp_common.h"
 
 thread_local int mgp_tls_hip_error = 0;
+thread_local void* mgp_tls_launch_events[2] = {nullptr, nullptr};
 
 extern "C" int mgp_version(void) { return MGP_VERSION; }
 
@@ -35,4 +36,11 @@ extern "C" int mgp_device_info(char* name, int cap)
         name[cap - 1] = '\0';
     }
     return prop.multiProcessorCount;
+}
+
+extern "C" int mgp_set_launch_events(void* start_event, void* stop_event)
+{
+    mgp_tls_launch_events[0] = start_event;
+    mgp_tls_launch_events[1] = stop_event;
+    return MGP_OK;
 }

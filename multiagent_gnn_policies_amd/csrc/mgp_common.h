@@ -26,6 +26,7 @@
 static inline void mgp_clear_error() { (void)hipGetLastError(); }
 
 extern thread_local int mgp_tls_hip_error;      // defined in capi.hip; read by mgp_last_hip_error()
+extern thread_local void* mgp_tls_launch_events[2];   // defined in capi.hip; set by mgp_set_launch_events()
 
 static inline int mgp_launch_status() {
     const hipError_t e = hipGetLastError();

@@ -38,6 +38,7 @@
 // (The first version of this kernel kept slices 1..K-1 densely in LDS -- 80 KB at N = 100, K = 3 -- aggregated taps >= 2
 //  on the matrix cores and advanced the slices with row gathers every step: 8.6 us per step of 256 episodes against 7.2.)
 // This translation unit is built with -ffp-contract=off (fp64 spec arithmetic); fp32 fused multiply-adds are explicit.
+#include <hip/hip_ext.h>
 #include "rollout_common.h"
 
 namespace {
@@ -47,6 +48,7 @@ constexpr int RO_WAVES = RO_THREADS / 64;
 constexpr int RO_PIECES = 8;              // j-range pieces per agent row in the pairwise pass (adjacent lanes)
 constexpr int RO_MAXN = 128;              // RO_THREADS / RO_PIECES rows; membership bits of a row fit 2 x u64
 constexpr int RO_LDS_LIMIT = 160 * 1024;
+constexpr int GU = 4;                     // list entries per lane and pass in the S2 gather group (2: 4 % slower)
 #ifdef MGP_RO_PROFILE
 __device__ unsigned long long mgp_ro_stamps[16 * 32];     // [wave][stamp]
 #define RO_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == 5) mgp_ro_stamps[(threadIdx.x >> 6) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
@@ -394,19 +396,19 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                     // round trips per pass instead of two per entry (entries beyond the list: weight 0 on a valid row)
                     // (the first pass reads its list bytes without waiting for the length: every list byte is a valid row index,
                     //  entries beyond the list are masked at the multiply-add -- one LDS round trip less on the critical path)
-                    for (int e = part; e == part || e < cnt; e += 16) {
+                    for (int e = part; e == part || e < cnt; e += 4 * GU) {
                         int m[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) m[u] = lp[min(e + 4 * u, RS - 1)];
+                        for (int u = 0; u < GU; ++u) m[u] = lp[min(e + 4 * u, RS - 1)];
                         float g[4]; float4 xa[4]; float2 xb[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < GU; ++u) {
                             g[u] = wq[m[u]];
                             xa[u] = *reinterpret_cast<const float4*>(src + m[u] * 8);
                             xb[u] = *reinterpret_cast<const float2*>(src + m[u] * 8 + 4);
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < GU; ++u) {
                             if (e + 4 * u < cnt) {
                                 sa[0] = fmaf(xa[u].x, g[u], sa[0]); sa[1] = fmaf(xa[u].y, g[u], sa[1]); sa[2] = fmaf(xa[u].z, g[u], sa[2]);
                                 sa[3] = fmaf(xa[u].w, g[u], sa[3]); sa[4] = fmaf(xb[u].x, g[u], sa[4]); sa[5] = fmaf(xb[u].y, g[u], sa[5]);
@@ -423,6 +425,14 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 RO_STAMP(6);
             }
             const int col = wave * 16 + li;
+            // B operand of the first layer: the aggregation tile of column li, k-steps s = 0 .. RO_KS - 1, k-lane lq (channel
+            // 4 s + lq at slot rpos); taps 0 .. K - 2 were written by the previous step's S2
+            float fb0[RO_KS];
+            {
+                const float4* pb = reinterpret_cast<const float4*>(act + col * RO_CS + lq * RO_KS);
+#pragma unroll
+                for (int i = 0; i < RO_KS / 4; ++i) { const float4 tq = pb[i]; fb0[4 * i] = tq.x; fb0[4 * i + 1] = tq.y; fb0[4 * i + 2] = tq.z; fb0[4 * i + 3] = tq.w; }
+            }
             // hidden layers on MFMA, activations chained through registers (rollout_common.h): only the first layer reads its B
             // operand (the aggregation result) from LDS, only the last one stores its activations there (for the output layer)
             float zc[RO_MAXMT][4];
@@ -438,9 +448,8 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 float fb[RO_KS];
                 int ksteps;
                 if (l == 0) {
-                    const float4* pb = reinterpret_cast<const float4*>(act + col * RO_CS + lq * RO_KS);
 #pragma unroll
-                    for (int i = 0; i < RO_KS / 4; ++i) { const float4 tq = pb[i]; fb[4 * i] = tq.x; fb[4 * i + 1] = tq.y; fb[4 * i + 2] = tq.z; fb[4 * i + 3] = tq.w; }
+                    for (int s_ = 0; s_ < RO_KS; ++s_) fb[s_] = fb0[s_];
                     ksteps = pad4(FK) / 4;
                 } else {
 #pragma unroll
@@ -467,6 +476,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 // (li, 0) and the y axis by lane (li, 1): the spec's per-axis expression tree (fp64, bit-exact given the
                 // action), half the dependent chain.  (History: activations stored to LDS and re-read by four lanes per column,
                 // 8 channels each, measured 1.35k cycles for this layer; one zero-padded MFMA m-tile 1.5k.)
+                const int axis = lq;                            // 0: x, 1: y, 2 / 3: idle
                 f32x2 u2 = {0.f, 0.f}, u2b = {0.f, 0.f};
 #pragma unroll
                 for (int a_ = 0; a_ < RO_MAXMT; ++a_) {
@@ -483,7 +493,6 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * 4 * RO_KS);
                 const float ux = rows_sum4(u2.x) + bb.x, uy = rows_sum4(u2.y) + bb.y;
                 RO_STAMP(14);
-                const int axis = lq;                            // 0: x, 1: y, 2 / 3: idle
                 const bool agent = axis < 2 && col < N;
                 if (agent) {
                     float ua = axis ? uy : ux;
@@ -702,7 +711,12 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                     const int j = lp[e];
                     const double dx = xi - spx[j], dy = yi - spy[j];
                     const double r2 = dx * dx + dy * dy;
-                    const double q = 1.0 / r2;
+                    // q = 1 / r2 to within an ulp: fp32 reciprocal seed (1 ulp of fp32), two Newton steps in fp64 -- five
+                    // instructions where the correctly rounded division takes eleven (measured: 1 % of the step); the feature
+                    // sums already differ from the oracle's by their summation order (1e-11), the tests hold them to 1e-6
+                    double q = (double)__builtin_amdgcn_rcpf((float)r2);
+                    q = __builtin_fma(q, __builtin_fma(-r2, q, 1.0), q);
+                    q = __builtin_fma(q, __builtin_fma(-r2, q, 1.0), q);
                     const double qq = q * q;
                     f0 += vxi - svx[j];
                     f1 += dx * qq;
@@ -749,25 +763,25 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 // four entries per lane per pass (lists of up to 16 neighbours in ONE pass): the list bytes without waiting for
                 // the length, then every operand read of the pass in flight together, then the multiply-adds in list order
                 // (entries beyond the list are masked; every list byte is a valid row index)
-                for (int e = part; e == part || e < cnt; e += 16) {
-                    int jn[4]; float gv[4];
+                for (int e = part; e == part || e < cnt; e += 4 * GU) {
+                    int jn[GU]; float gv[GU];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) jn[u] = lp[min(e + 4 * u, RS - 1)];
+                    for (int u = 0; u < GU; ++u) jn[u] = lp[min(e + 4 * u, RS - 1)];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) gv[u] = w_new[jn[u]];
+                    for (int u = 0; u < GU; ++u) gv[u] = w_new[jn[u]];
 #pragma unroll
                     for (int jj = 0; jj < S1T; ++jj) {
                         if (jj < K - 1) {
                             // tap jj + 1 of step t + 1 = tap jj of step t: ring slot ro_slot(curn, jj + 1) = ro_slot(cur, jj)
                             const float* src = XT + (size_t)ro_slot(curn, jj + 1, K) * Np * 8;
-                            float4 x0[4]; float2 x1[4];
+                            float4 x0[GU]; float2 x1[GU];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
+                            for (int u = 0; u < GU; ++u) {
                                 x0[u] = *reinterpret_cast<const float4*>(src + jn[u] * 8);
                                 x1[u] = *reinterpret_cast<const float2*>(src + jn[u] * 8 + 4);
                             }
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
+                            for (int u = 0; u < GU; ++u) {
                                 if (e + 4 * u < cnt) {
                                     s1[jj][0] = fmaf(x0[u].x, gv[u], s1[jj][0]); s1[jj][1] = fmaf(x0[u].y, gv[u], s1[jj][1]);
                                     s1[jj][2] = fmaf(x0[u].z, gv[u], s1[jj][2]); s1[jj][3] = fmaf(x0[u].w, gv[u], s1[jj][3]);
@@ -1506,18 +1520,39 @@ __global__ void rollout_image_kernel(RoParams P, int K, float* __restrict__ imag
     }
 }
 
+// mgp_set_launch_events (capi.hip): events the NEXT resident launch of this thread stamps with the kernel's own begin / end
+// (hipExtLaunchKernel: no marker packets in front of or behind the kernel, nothing for the host to wait for before it can
+// enqueue the launch); consumed by that launch.
+static void take_launch_events(hipEvent_t* start, hipEvent_t* stop)
+{
+    *start = static_cast<hipEvent_t>(mgp_tls_launch_events[0]);
+    *stop = static_cast<hipEvent_t>(mgp_tls_launch_events[1]);
+    mgp_tls_launch_events[0] = mgp_tls_launch_events[1] = nullptr;
+}
+
 template <int CN, int CK, bool FD, bool CL>
 int launch_rollout(double* x, float* G, float* Xd, float* action, double* rewards, const RoParams& P,
                    const MgpFlockParams* p, int B, int K, int N, int T, unsigned long long dimsA, unsigned int dims8,
                    unsigned long long woffA, unsigned long long woffB, int n_layers, int lds, hipStream_t st,
                    const float* image, int image_floats, unsigned long long* carry, int flags, const MgpCollect* cl)
 {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<CN, CK, FD, CL>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-        return MGP_ELAUNCH;
+    static thread_local int lds_set = 0;                       // the attribute sticks to the function: set it when it grows
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<CN, CK, FD, CL>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return MGP_ELAUNCH;
+        lds_set = lds;
+    }
     MgpCollect none = {};
-    hipLaunchKernelGGL((rollout_kernel<CN, CK, FD, CL>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K,
-                       N, T, dimsA, dims8, woffA, woffB, n_layers, image, image_floats, carry, flags, cl ? *cl : none);
+    hipEvent_t ev0, ev1;
+    take_launch_events(&ev0, &ev1);
+    if (ev0 != nullptr || ev1 != nullptr)
+        hipExtLaunchKernelGGL((rollout_kernel<CN, CK, FD, CL>), dim3(B), dim3(RO_THREADS), lds, st, ev0, ev1, 0, x, G, Xd, action,
+                              rewards, P, *p, K, N, T, dimsA, dims8, woffA, woffB, n_layers, image, image_floats, carry, flags,
+                              cl ? *cl : none);
+    else
+        hipLaunchKernelGGL((rollout_kernel<CN, CK, FD, CL>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K,
+                           N, T, dimsA, dims8, woffA, woffB, n_layers, image, image_floats, carry, flags, cl ? *cl : none);
     return mgp_launch_status();
 }
 
@@ -1527,12 +1562,23 @@ int launch_rollout_big(double* x, float* G, float* Xd, float* action, double* re
                        unsigned long long woffA, unsigned long long woffB, int n_layers, int lds, hipStream_t st,
                        const float* image, int image_floats, unsigned long long* carry, int flags, const MgpCollect* cl)
 {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_big_kernel<FD, CL>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-        return MGP_ELAUNCH;
+    static thread_local int lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_big_kernel<FD, CL>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return MGP_ELAUNCH;
+        lds_set = lds;
+    }
     MgpCollect none = {};
-    hipLaunchKernelGGL((rollout_big_kernel<FD, CL>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K, N, T,
-                       dimsA, dims8, woffA, woffB, n_layers, image, image_floats, carry, flags, cl ? *cl : none);
+    hipEvent_t ev0, ev1;
+    take_launch_events(&ev0, &ev1);
+    if (ev0 != nullptr || ev1 != nullptr)
+        hipExtLaunchKernelGGL((rollout_big_kernel<FD, CL>), dim3(B), dim3(RO_THREADS), lds, st, ev0, ev1, 0, x, G, Xd, action, rewards,
+                              P, *p, K, N, T, dimsA, dims8, woffA, woffB, n_layers, image, image_floats, carry, flags,
+                              cl ? *cl : none);
+    else
+        hipLaunchKernelGGL((rollout_big_kernel<FD, CL>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K, N, T,
+                           dimsA, dims8, woffA, woffB, n_layers, image, image_floats, carry, flags, cl ? *cl : none);
     return mgp_launch_status();
 }
 

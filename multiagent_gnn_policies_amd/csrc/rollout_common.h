@@ -179,6 +179,26 @@ __device__ __forceinline__ float rows_sum4(float v)
     return __uint_as_float(a) + __uint_as_float(b);
 }
 
+// rows_sum4 for six values at once (one pair of wait states per swap kind)
+__device__ __forceinline__ void rows_sum4x6(float (&v)[6])
+{
+    unsigned int a[6], b[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { a[i] = __float_as_uint(v[i]); b[i] = a[i]; }
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\tv_permlane16_swap_b32 %4, %5\n\t"
+                 "v_permlane16_swap_b32 %6, %7\n\tv_permlane16_swap_b32 %8, %9\n\tv_permlane16_swap_b32 %10, %11"
+                 : "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]), "+v"(a[2]), "+v"(b[2]), "+v"(a[3]), "+v"(b[3]), "+v"(a[4]), "+v"(b[4]),
+                   "+v"(a[5]), "+v"(b[5]));
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { v[i] = __uint_as_float(a[i]) + __uint_as_float(b[i]); a[i] = __float_as_uint(v[i]); b[i] = a[i]; }
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\tv_permlane32_swap_b32 %4, %5\n\t"
+                 "v_permlane32_swap_b32 %6, %7\n\tv_permlane32_swap_b32 %8, %9\n\tv_permlane32_swap_b32 %10, %11"
+                 : "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]), "+v"(a[2]), "+v"(b[2]), "+v"(a[3]), "+v"(b[3]), "+v"(a[4]), "+v"(b[4]),
+                   "+v"(a[5]), "+v"(b[5]));
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = __uint_as_float(a[i]) + __uint_as_float(b[i]);
+}
+
 // sum over the 64 lanes of a wave on the VALU cross-lane paths (DPP inside rows of 16, lane swaps across rows), every lane
 // gets the total; fixed order.  (__shfl_xor compiles to ds_bpermute: 12 dependent LDS-pipe round trips per fp64 sum.)
 __device__ __forceinline__ double wave_sum_d(double v)

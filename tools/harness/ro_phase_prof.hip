@@ -7,6 +7,7 @@
 #include <vector>
 #include <cmath>
 thread_local int mgp_tls_hip_error = 0;
+thread_local void* mgp_tls_launch_events[2] = {nullptr, nullptr};
 // the narrow build forwards widths > 32 to the second compilation (rollout_wide.hip); this harness links only the narrow one
 extern "C" int mgp_rollout_wide_supported_(const int*, int, int, int) { return 0; }
 extern "C" int mgp_rollout_wide_steps_ex_(double*, float*, float*, const float* const*, const float* const*, const int*, int, float*,
