@@ -45,7 +45,10 @@ namespace {
 
 constexpr int RO_THREADS = 1024;
 constexpr int RO_WAVES = RO_THREADS / 64;
-constexpr int RO_PIECES = 8;              // j-range pieces per agent row in the pairwise pass (adjacent lanes)
+#ifndef RO_S1L
+#define RO_S1L 8                          // (4 lanes per row -- 7 waves instead of 13, 25 candidates each -- measured 1 % slower)
+#endif
+constexpr int RO_PIECES = RO_S1L;         // lanes per agent row in the pairwise pass S1 (adjacent lanes): 8 or 4
 constexpr int RO_MAXN = 128;              // RO_THREADS / RO_PIECES rows; membership bits of a row fit 2 x u64
 constexpr int RO_LDS_LIMIT = 160 * 1024;
 constexpr int GU = 4;                     // list entries per lane and pass in the S2 gather group (2: 4 % slower)
@@ -258,8 +261,8 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     //   aggregation: thread (column gn, tap offset gt, parity gq of the list entry); stage q works on tap q + gt
     const int gq = tid & 1, gn = (tid >> 1) % N, gt = (tid >> 1) / N;
     const int li = lane & 15, lq = lane >> 4;
-    const int pi = tid >> 3, piece = tid & 7;                 // membership: agent row pi, piece of the offset range
-    const int dh8 = (N + RO_PIECES - 1) / RO_PIECES;          // candidates per lane of a row in S1: the full row in 8 pieces (<= 16)
+    const int pi = tid / RO_PIECES, piece = tid % RO_PIECES;  // membership: agent row pi, piece of the row's candidates
+    const int dh8 = (N + RO_PIECES - 1) / RO_PIECES;          // candidates per lane of a row in S1: the full row in RO_PIECES pieces (<= 128 / RO_PIECES)
     const int fr = tid >> 2, fq = tid & 3;                    // lists / features: agent row fr, lane fq of 4
     const double R2 = p.comm_radius2;
     const float R2f = (float)R2, Rf = sqrtf(R2f);
@@ -602,7 +605,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             const float t_in = R2f - band, t_out = R2f + band;
             unsigned int in_m = 0u, unc_m = 0u;
 #pragma unroll
-            for (int c0 = 0; c0 < 16; c0 += 8) {
+            for (int c0 = 0; c0 < 128 / RO_PIECES; c0 += 8) {
                 if (c0 < dh8) {
                     float2 sj[8];
 #pragma unroll
@@ -626,7 +629,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 }
             }
             RO_STAMP(16);
-            unsigned int valid = (nd > 0) ? ((1u << nd) - 1u) : 0u;            // candidates beyond the piece re-tested row N - 1
+            unsigned int valid = (nd >= 32) ? 0xFFFFFFFFu : ((1u << nd) - 1u);   // candidates beyond the piece re-tested row N - 1
             const int self = pi - j0;
             if (self >= 0 && self < nd) valid &= ~(1u << self);                // (r2 = 0 is "inside": the diagonal is not a link)
             in_m &= valid;
@@ -654,14 +657,14 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             unsigned long long lo = 0ull, hi = 0ull;
             if (j0 < 64) {
                 lo = (unsigned long long)in_m << j0;
-                if (j0 > 48) hi = (unsigned long long)in_m >> (64 - j0);
+                if (j0 > 32) hi = (unsigned long long)in_m >> (64 - j0);
             } else {
                 hi = (unsigned long long)in_m << (j0 - 64);
             }
             unsigned int w0 = (unsigned int)lo, w1 = (unsigned int)(lo >> 32), w2_ = (unsigned int)hi, w3 = (unsigned int)(hi >> 32);
             w0 |= dpp_u<0xB1>(w0); w1 |= dpp_u<0xB1>(w1); w2_ |= dpp_u<0xB1>(w2_); w3 |= dpp_u<0xB1>(w3);       // lane ^ 1
             w0 |= dpp_u<0x4E>(w0); w1 |= dpp_u<0x4E>(w1); w2_ |= dpp_u<0x4E>(w2_); w3 |= dpp_u<0x4E>(w3);       // lane ^ 2
-            w0 |= dpp_u<0x141>(w0); w1 |= dpp_u<0x141>(w1); w2_ |= dpp_u<0x141>(w2_); w3 |= dpp_u<0x141>(w3);   // i -> 7 - i
+            if (RO_PIECES == 8) { w0 |= dpp_u<0x141>(w0); w1 |= dpp_u<0x141>(w1); w2_ |= dpp_u<0x141>(w2_); w3 |= dpp_u<0x141>(w3); }   // i -> 7 - i
             const unsigned long long flo = ((unsigned long long)w1 << 32) | w0, fhi = ((unsigned long long)w3 << 32) | w2_;
             RO_STAMP(18);
             int pos;
@@ -700,6 +703,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             if (lane == 0) rewards[(size_t)b * T + t] = -1.0 * var * p.reward_scale;
             RO_STAMP(21);
         }
+        const int gtid = tid - grp;                           // (the groups swapped -- gather on the older waves -- measured the same)
         if (tid < grp) {
             double f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0;
             int cnt = 0;
@@ -748,10 +752,10 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 y0[rpos(3 * K)] = (float)f3; y0[rpos(4 * K)] = (float)f4; y0[rpos(5 * K)] = (float)f5;
             }
             RO_STAMP(22);
-        } else if (do_s1 && tid < 2 * grp) {
+        } else if (do_s1 && gtid >= 0 && gtid < grp) {
             // one summation order for a gather stage wherever it runs: lane `part` of the column's four takes list entries
             // part, part + 4, ... in order, then the quad sum (l ^ 1, l ^ 2)
-            const int c4 = (tid - grp) >> 2, part = tid & 3;
+            const int c4 = gtid >> 2, part = gtid & 3;
             float s1[S1T][6];
 #pragma unroll
             for (int jj = 0; jj < S1T; ++jj)
