@@ -10,7 +10,7 @@ all state resident on the GPU, no host round trip.  Up to three implementations 
   resident    mgp_rollout_steps: ALL timed steps in one launch of the episode-resident kernel (one workgroup per
               episode; delay line / agent states / neighbour lists of the last K-1 networks / weights in LDS, the
               aggregation power-iterated along those lists; HBM sees the state on entry and exit).  This is `value`
-              when the shape is covered (N <= 256, widths <= 64).
+              when the shape is covered (N <= 256, widths <= 64; one hidden layer up to 128 wide at N <= 128).
   factored    N > 256 only: the same factored state kept in HBM as bit rows / feature rings, K launches per step
               (mgp_sparse_policy_step + mgp_flock_step_sparse); dense state rebuilt at the end of each call.
   two_launch  mgp_actor_fwd + mgp_flock_step_advance per step (dense operator streamed from HBM every step),
@@ -35,7 +35,7 @@ Also reported on the same JSON line:
                 identical (S, X) the kernels consumed, for 16 sampled episodes: {ok, tol, max_abs, max_rel, ...}.
                 A failed gate prints the line with "ok": false and exits with status 3.
 Which implementation is `value` is a function of the SHAPE only (never of --steps): resident where mgp_rollout_supported
-says so (N <= 256, widths <= 64), factored for N > 256 where mgp_sparse_policy_supported, else two_launch; config.step_path
+says so (N <= 256, widths <= 64; one hidden layer up to 128 wide at N <= 128), factored for N > 256 where mgp_sparse_policy_supported, else two_launch; config.step_path
 names it and paths.* carries every implementation that was timed.
 """
 import argparse
@@ -314,7 +314,14 @@ def parity_gate(ro, n_check=16):
 
     def rel_b(u, r):                                          # per sampled episode: max over (action axis, agent)
         return ((u - r).abs() / r.abs().clamp(min=1.0)).flatten(1).max(dim=1).values
-    noise_b = rel_b(ref, exact)
+    # second witness of how well fp32 determines the result on this state: the exact evaluation of inputs moved by ONE fp32
+    # rounding (every element of S and X times (1 +- 2^-24), fixed seed) -- what a single rounding of the operands does
+    gen = torch.Generator().manual_seed(12345)
+    sgn = lambda t: (torch.randint(0, 2, t.shape, generator=gen).double() * 2.0 - 1.0) * 2.0 ** -24
+    with torch.no_grad():
+        moved = torch_port.actor_forward(X.double() * (1.0 + sgn(X)), G.double() * (1.0 + sgn(G)), [w.double() for w in Ws],
+                                         [b_.double() for b_ in bs], 0, ro.K)
+    noise_b = torch.maximum(rel_b(ref, exact), rel_b(moved, exact))
     well = noise_b <= 0.5 * PARITY_TOL                        # episodes where the fp32 reference is determined to < tol
     paths = {'two_launch': two}
     if ro.resident_supported():
@@ -348,7 +355,9 @@ def parity_gate(ro, n_check=16):
             "criterion": "per sampled episode: elementwise |gpu - cpu| / max(1, |cpu|) <= tol against the fp32 CPU reference "
                          "(paths.*.episodes_within_plain_tol counts these), or, failing that, within tol + 10 x the "
                          "episode's reference_fp32_noise of the fp64 evaluation of the same op sequence on the same fp32 "
-                         "inputs (reference_fp32_noise = how far the fp32 REFERENCE itself is from that evaluation: "
+                         "inputs (reference_fp32_noise = how far fp32 evaluations of the REFERENCE are from that evaluation -- "
+                         "the larger of two witnesses: the PyTorch-CPU fp32 op sequence, and the exact evaluation of inputs "
+                         "moved by one fp32 rounding: "
                          "colliding agents drive 1/r^4 features to 1e6, random-init wide networks amplify them, and any "
                          "two fp32 evaluations then differ by more than tol).  max_rel is over all checked episodes, "
                          "max_rel_well_conditioned over those where the reference is determined to tol/2; passed_on says "
@@ -873,7 +882,7 @@ def main():
                                     ("resident: all %d timed steps in one mgp_rollout_steps launch per GPU "
                                      "(episode state in LDS)" % args.steps) if resident else
                                     "two_launch: mgp_actor_fwd + mgp_flock_step_advance per step (HIP graph)",
-                       "step_path_rule": "by shape: resident if mgp_rollout_supported (N <= 256, widths <= 64), factored if "
+                       "step_path_rule": "by shape: resident if mgp_rollout_supported (N <= 256, widths <= 64; one hidden layer up to 128 wide at N <= 128), factored if "
                                          "N > 256 and mgp_sparse_policy_supported, else two_launch",
                        "episodes_per_gpu": B, "episodes_total": total_eps, "agents": N, "taps": K,
                        "graph_steps": gs, "weights": ro.weights, "parallelism": "episodes sharded x%d, no "

@@ -21,7 +21,8 @@ ARCH = 'gfx950'
 COMMON_FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 # flock.hip must reproduce numpy's op-by-op fp64 rounding: no fused multiply-add contraction
 PER_FILE_FLAGS = {'flock.hip': ['-ffp-contract=off'], 'rollout.hip': ['-ffp-contract=off'],
-                  'sparse_sim.hip': ['-ffp-contract=off'], 'rollout_wide.hip': ['-ffp-contract=off']}
+                  'sparse_sim.hip': ['-ffp-contract=off'], 'rollout_wide.hip': ['-ffp-contract=off'],
+                  'rollout_w128.hip': ['-ffp-contract=off']}
 
 
 def sources():

@@ -40,6 +40,9 @@
 // This translation unit is built with -ffp-contract=off (fp64 spec arithmetic); fp32 fused multiply-adds are explicit.
 #include <hip/hip_ext.h>
 #include "rollout_common.h"
+#if !defined(MGP_RO_WIDE) && !defined(MGP_RO_X128)
+#define MGP_RO_BASE 1                      // the build that owns the public entry points (layer widths <= 32)
+#endif
 
 namespace {
 
@@ -51,7 +54,9 @@ constexpr int RO_WAVES = RO_THREADS / 64;
 constexpr int RO_PIECES = RO_S1L;         // lanes per agent row in the pairwise pass S1 (adjacent lanes): 8 or 4
 constexpr int RO_MAXN = 128;              // RO_THREADS / RO_PIECES rows; membership bits of a row fit 2 x u64
 constexpr int RO_LDS_LIMIT = 160 * 1024;
-constexpr int GU = 4;                     // list entries per lane and pass in the S2 gather group (2: 4 % slower)
+// list entries per lane and pass in the S2 gather group: 4 where (N, K) are compile-time (2 measured 4 % slower there); 2 in the
+// run-time sized builds, whose S1T = 4 accumulator sets leave no registers for four entries in flight (they spilled: -20 %)
+template <int CK> struct RoGatherUnroll { static constexpr int value = CK ? 4 : 2; };
 #ifdef MGP_RO_PROFILE
 __device__ unsigned long long mgp_ro_stamps[16 * 32];     // [wave][stamp]
 #define RO_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == 5) mgp_ro_stamps[(threadIdx.x >> 6) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
@@ -275,6 +280,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     // produced this step's stage 1; steps before that (and the first step of a launch) run the stage-by-stage phase A.
     bool s1_ready = false;
     constexpr int S1T = CK ? (CK > 1 ? CK - 1 : 1) : 4;       // taps >= 1 (K <= 5)
+    constexpr int GU = RoGatherUnroll<CK>::value;
 
     for (int t = 0; t < T; ++t) {
         RO_STAMP(0);
@@ -428,14 +434,6 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 RO_STAMP(6);
             }
             const int col = wave * 16 + li;
-            // B operand of the first layer: the aggregation tile of column li, k-steps s = 0 .. RO_KS - 1, k-lane lq (channel
-            // 4 s + lq at slot rpos); taps 0 .. K - 2 were written by the previous step's S2
-            float fb0[RO_KS];
-            {
-                const float4* pb = reinterpret_cast<const float4*>(act + col * RO_CS + lq * RO_KS);
-#pragma unroll
-                for (int i = 0; i < RO_KS / 4; ++i) { const float4 tq = pb[i]; fb0[4 * i] = tq.x; fb0[4 * i + 1] = tq.y; fb0[4 * i + 2] = tq.z; fb0[4 * i + 3] = tq.w; }
-            }
             // hidden layers on MFMA, activations chained through registers (rollout_common.h): only the first layer reads its B
             // operand (the aggregation result) from LDS, only the last one stores its activations there (for the output layer)
             float zc[RO_MAXMT][4];
@@ -446,13 +444,14 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             int mtp = 0;
             for (int l = 0; l < n_layers - 1; ++l) {
                 const int cout = ro_dim(dimsA, dims8, l + 1);
-                const int MT = mtiles(cout);
+                const int MT = ro_mt(cout);
                 const float* wfrag = wl + (int)((((l < 4) ? woffA : woffB) >> (16 * (l & 3))) & 0xFFFFull);
                 float fb[RO_KS];
                 int ksteps;
                 if (l == 0) {
+                    const float4* pb = reinterpret_cast<const float4*>(act + col * RO_CS + lq * RO_KS);
 #pragma unroll
-                    for (int s_ = 0; s_ < RO_KS; ++s_) fb[s_] = fb0[s_];
+                    for (int i = 0; i < RO_KS / 4; ++i) { const float4 tq = pb[i]; fb[4 * i] = tq.x; fb[4 * i + 1] = tq.y; fb[4 * i + 2] = tq.z; fb[4 * i + 3] = tq.w; }
                     ksteps = pad4(FK) / 4;
                 } else {
 #pragma unroll
@@ -461,7 +460,8 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 }
                 const float* pw = wfrag + lane * RO_WFS;
                 const float* pbias = wfrag + MT * 64 * RO_WFS + lq * 4;
-                if (MT == 4) ro_layer_regs<(RO_MAXMT >= 4 ? 4 : 1), true>(fb, pw, pbias, ksteps, zc);
+                if (RO_MAXMT >= 8 && MT == 8) ro_layer_regs<(RO_MAXMT >= 8 ? 8 : 1), true>(fb, pw, pbias, ksteps, zc);
+                else if (MT == 4) ro_layer_regs<(RO_MAXMT >= 4 ? 4 : 1), true>(fb, pw, pbias, ksteps, zc);
                 else if (MT == 2) ro_layer_regs<2, true>(fb, pw, pbias, ksteps, zc);
                 else ro_layer_regs<1, true>(fb, pw, pbias, ksteps, zc);
                 mtp = MT;
@@ -493,7 +493,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                     }
                 }
                 u2 = u2 + u2b;
-                const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * 4 * RO_KS);
+                const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * RO_OUTC);
                 const float ux = rows_sum4(u2.x) + bb.x, uy = rows_sum4(u2.y) + bb.y;
                 RO_STAMP(14);
                 const bool agent = axis < 2 && col < N;
@@ -540,7 +540,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 ux += dpp_f<0xB1>(ux); uy += dpp_f<0xB1>(uy);
                 ux += dpp_f<0x4E>(ux); uy += dpp_f<0x4E>(uy);
                 if (agent) {
-                    const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * 4 * RO_KS);
+                    const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * RO_OUTC);
                     ux += bb.x; uy += bb.y;
                     if (CL && (unsigned long long)dagger_coin(cl.seed, coin_ep, (unsigned int)(cl.age0 + t)) < coin_thr) {
                         ux = uexp[ccol]; uy = uexp[N + ccol];
@@ -1164,7 +1164,7 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
             int mtp = 0;
             for (int l = 0; l < n_layers - 1; ++l) {
                 const int cout = ro_dim(dimsA, dims8, l + 1);
-                const int MT = mtiles(cout);
+                const int MT = ro_mt(cout);
                 const float* wfrag = wl + (int)((((l < 4) ? woffA : woffB) >> (16 * (l & 3))) & 0xFFFFull);
                 float fb[RO_KS];
                 int ksteps;
@@ -1180,7 +1180,8 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
                 }
                 const float* pw = wfrag + lane * RO_WFS;
                 const float* pbias = wfrag + MT * 64 * RO_WFS + lq * 4;
-                if (MT == 4) ro_layer_regs<(RO_MAXMT >= 4 ? 4 : 1), true>(fb, pw, pbias, ksteps, zc);
+                if (RO_MAXMT >= 8 && MT == 8) ro_layer_regs<(RO_MAXMT >= 8 ? 8 : 1), true>(fb, pw, pbias, ksteps, zc);
+                else if (MT == 4) ro_layer_regs<(RO_MAXMT >= 4 ? 4 : 1), true>(fb, pw, pbias, ksteps, zc);
                 else if (MT == 2) ro_layer_regs<2, true>(fb, pw, pbias, ksteps, zc);
                 else ro_layer_regs<1, true>(fb, pw, pbias, ksteps, zc);
                 mtp = MT;
@@ -1230,7 +1231,7 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
             RO_STAMP(14);
             float m = 0.f;
             if (agent) {
-                const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * 4 * RO_KS);
+                const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * RO_OUTC);
                 ux += bb.x; uy += bb.y;
                 if (CL && (unsigned long long)dagger_coin(cl.seed, coin_ep, (unsigned int)(cl.age0 + t)) < coin_thr) {
                     ux = uexp[ccol]; uy = uexp[N + ccol];      // the expert drives this step (gnn_dagger.py:157-158)
@@ -1451,12 +1452,19 @@ bool make_carve(const int* dims, int n_layers, int K, int N, RoParams* P, int* l
     if (dims == nullptr || n_layers < 1 || n_layers > MGP_MAX_LAYERS) return false;
     if (K < 1 || K > 5 || N < 4 || N > RB_MAXN) return false;                   // N <= 128: 2 N (K - 1) gather threads <= 1024
     if (dims[0] != 6 || dims[n_layers] != 2) return false;                      // simulator: 6 features in, 2-D action out
+#ifdef MGP_RO_X128
+    if (n_layers != 2 || N > RO_MAXN) return false;                             // this build: ONE hidden layer (up to 128 wide), N <= 128
+#endif
     int wtot = 0;
     for (int l = 0; l < n_layers; ++l) {
         const int cin = (l == 0) ? 6 * K : dims[l], cout = dims[l + 1];
-        if (cin < 1 || cout < 1 || cin > 4 * RO_KS || cout > 4 * RO_KS) return false;   // <= RO_KS k-steps
+        const bool last = l == n_layers - 1;
+        // a hidden layer reads <= RO_KS k-steps (its input comes from the aggregation tile or the previous layer's <= 4 RO_KS
+        // accumulator rows) and produces <= RO_MAXMT m-tiles; the output layer reads every row of the last hidden layer
+        if (cin < 1 || cout < 1 || cin > (last ? RO_OUTC : 4 * RO_KS) || cout > 16 * RO_MAXMT) return false;
+        if (l == 0 && cin > 4 * RO_KS) return false;
         if (P) { P->woff[l] = wtot; P->dims[l] = dims[l]; }
-        wtot += mtiles(cout) * 64 * RO_WFS + mtiles(cout) * 16;
+        wtot += last ? ((2 * RO_OUTC + 2 + 15) & ~15) : ro_mt(cout) * 64 * RO_WFS + ro_mt(cout) * 16;
     }
     if (P) { P->dims[n_layers] = dims[n_layers]; P->n_layers = n_layers; P->wtot = wtot; }
     const int total = (N > RO_MAXN ? rb_offsets(N, K).wl : ro_offsets(N, K).wl) + wtot * 4;   // N > 128: rollout_big_kernel
@@ -1591,37 +1599,49 @@ int launch_rollout_big(double* x, float* G, float* Xd, float* action, double* re
 // This file is compiled twice: as is (layer widths <= 32, MGP_RO_KS = 8: half the activation tile and weight image), and
 // through rollout_wide.hip with MGP_RO_KS = 16 for widths up to 64 (cfg/hidden_size.cfg).  The narrow build owns the
 // public entry points and forwards the shapes only the wide build covers.
-#ifdef MGP_RO_WIDE
+// Build levels: 0 = this file as is (public entry points), 1 = rollout_wide.hip, 2 = rollout_w128.hip (ONE hidden layer up to
+// 128 wide: cfg/hidden_size.cfg:58).  A level forwards the shapes it does not cover to the next one.
+#if defined(MGP_RO_X128)
+#define MGP_RO_SUPPORTED mgp_rollout_x128_supported_
+#define MGP_RO_STEPS_EX mgp_rollout_x128_steps_ex_
+#define MGP_RO_COLLECT mgp_rollout_x128_collect_
+#define MGP_RO_IMAGE_FLOATS mgp_rollout_x128_image_floats_
+#define MGP_RO_IMAGE mgp_rollout_x128_image_
+#elif defined(MGP_RO_WIDE)
 #define MGP_RO_SUPPORTED mgp_rollout_wide_supported_
 #define MGP_RO_STEPS_EX mgp_rollout_wide_steps_ex_
 #define MGP_RO_COLLECT mgp_rollout_wide_collect_
 #define MGP_RO_IMAGE_FLOATS mgp_rollout_wide_image_floats_
 #define MGP_RO_IMAGE mgp_rollout_wide_image_
+#define MGP_RO_NEXT(name) mgp_rollout_x128_##name##_
 #else
 #define MGP_RO_SUPPORTED mgp_rollout_supported
 #define MGP_RO_STEPS_EX mgp_rollout_steps_ex
 #define MGP_RO_COLLECT mgp_rollout_collect
 #define MGP_RO_IMAGE_FLOATS mgp_rollout_image_floats
 #define MGP_RO_IMAGE mgp_rollout_image
-extern "C" int mgp_rollout_wide_supported_(const int* dims, int n_layers, int K, int N);
-extern "C" int mgp_rollout_wide_steps_ex_(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
-                                          const int* dims, int n_layers, float* action, double* rewards,
-                                          const MgpFlockParams* p, int B, int K, int N, int T, const float* image,
-                                          void* carry, int flags, void* stream);
-extern "C" int mgp_rollout_wide_collect_(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
-                                         const int* dims, int n_layers, double* rewards, const MgpFlockParams* p, int B, int K,
-                                         int N, int T, const float* image, void* carry, int flags, const MgpCollect* cl,
-                                         void* stream);
-extern "C" long mgp_rollout_wide_image_floats_(const int* dims, int n_layers, int K, int N);
-extern "C" int mgp_rollout_wide_image_(const float* const* W, const float* const* b, const int* dims, int n_layers, int K, int N,
-                                       float* image, void* stream);
+#define MGP_RO_NEXT(name) mgp_rollout_wide_##name##_
+#endif
+#ifdef MGP_RO_NEXT
+extern "C" int MGP_RO_NEXT(supported)(const int* dims, int n_layers, int K, int N);
+extern "C" int MGP_RO_NEXT(steps_ex)(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
+                                     const int* dims, int n_layers, float* action, double* rewards,
+                                     const MgpFlockParams* p, int B, int K, int N, int T, const float* image,
+                                     void* carry, int flags, void* stream);
+extern "C" int MGP_RO_NEXT(collect)(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
+                                    const int* dims, int n_layers, double* rewards, const MgpFlockParams* p, int B, int K,
+                                    int N, int T, const float* image, void* carry, int flags, const MgpCollect* cl,
+                                    void* stream);
+extern "C" long MGP_RO_NEXT(image_floats)(const int* dims, int n_layers, int K, int N);
+extern "C" int MGP_RO_NEXT(image)(const float* const* W, const float* const* b, const int* dims, int n_layers, int K, int N,
+                                  float* image, void* stream);
 #endif
 
 extern "C" int MGP_RO_SUPPORTED(const int* dims, int n_layers, int K, int N)
 {
     if (make_carve(dims, n_layers, K, N, nullptr, nullptr)) return 1;
-#ifndef MGP_RO_WIDE
-    return mgp_rollout_wide_supported_(dims, n_layers, K, N);
+#ifdef MGP_RO_NEXT
+    return MGP_RO_NEXT(supported)(dims, n_layers, K, N);
 #else
     return 0;
 #endif
@@ -1631,8 +1651,8 @@ extern "C" long MGP_RO_IMAGE_FLOATS(const int* dims, int n_layers, int K, int N)
 {
     RoParams P;
     if (make_carve(dims, n_layers, K, N, &P, nullptr)) return P.wtot;
-#ifndef MGP_RO_WIDE
-    return mgp_rollout_wide_image_floats_(dims, n_layers, K, N);
+#ifdef MGP_RO_NEXT
+    return MGP_RO_NEXT(image_floats)(dims, n_layers, K, N);
 #else
     return 0;
 #endif
@@ -1644,8 +1664,8 @@ extern "C" int MGP_RO_IMAGE(const float* const* W, const float* const* b, const 
     if (W == nullptr || b == nullptr) return MGP_EINVAL;
     RoParams P;
     if (!make_carve(dims, n_layers, K, N, &P, nullptr)) {
-#ifndef MGP_RO_WIDE
-        return mgp_rollout_wide_image_(W, b, dims, n_layers, K, N, image, stream);
+#ifdef MGP_RO_NEXT
+        return MGP_RO_NEXT(image)(W, b, dims, n_layers, K, N, image, stream);
 #else
         return MGP_EUNSUPPORTED;
 #endif
@@ -1674,12 +1694,10 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
     RoParams P;
     int lds = 0;
     if (!make_carve(dims, n_layers, K, N, &P, &lds)) {
-#ifndef MGP_RO_WIDE
+#ifdef MGP_RO_NEXT
         if (cl != nullptr)
-            return mgp_rollout_wide_collect_(x, G, Xd, W, b, dims, n_layers, rewards, p, B, K, N, T, image, carry_v, flags, cl,
-                                             stream);
-        return mgp_rollout_wide_steps_ex_(x, G, Xd, W, b, dims, n_layers, action, rewards, p, B, K, N, T, image, carry_v, flags,
-                                          stream);
+            return MGP_RO_NEXT(collect)(x, G, Xd, W, b, dims, n_layers, rewards, p, B, K, N, T, image, carry_v, flags, cl, stream);
+        return MGP_RO_NEXT(steps_ex)(x, G, Xd, W, b, dims, n_layers, action, rewards, p, B, K, N, T, image, carry_v, flags, stream);
 #else
         return MGP_EUNSUPPORTED;
 #endif
@@ -1731,21 +1749,25 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
     const int wt = P.wtot;
     const bool fade = p->link_drop != 0u;   // FlockingStochastic-v0: the generic builds carry the fade hash, the others do not
 #define RB_LAUNCH(FD_, CL_) launch_rollout_big<FD_, CL_>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags, cl)
+#ifndef MGP_RO_X128
     if (N > RO_MAXN) {
         if (cl != nullptr) return fade ? RB_LAUNCH(true, true) : RB_LAUNCH(false, true);
         return fade ? RB_LAUNCH(true, false) : RB_LAUNCH(false, false);
     }
+#endif
 #undef RB_LAUNCH
 #define RO_LAUNCH(CN_, CK_, FD_, CL_) launch_rollout<CN_, CK_, FD_, CL_>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags, cl)
     if (cl != nullptr) {               // the data-collection builds (DAGGER rollouts)
-#ifndef MGP_RO_WIDE
+#ifdef MGP_RO_BASE
         if (N == 100 && K == 3 && !fade) return RO_LAUNCH(100, 3, false, true);      // cfg/dagger.cfg
 #endif
         return fade ? RO_LAUNCH(0, 0, true, true) : RO_LAUNCH(0, 0, false, true);
     }
-#ifndef MGP_RO_WIDE
+#if defined(MGP_RO_BASE) || defined(MGP_RO_X128)
     if (N == 100 && K == 3 && !fade)   // the headline shape (BASELINE.json configs[0..1]) runs a build with compile-time addresses
         return RO_LAUNCH(100, 3, false, false);
+#endif
+#ifdef MGP_RO_BASE
     if (N == 100 && K == 2 && !fade)   // cfg/default.cfg, cloning.cfg, dagger_twoflocks.cfg
         return RO_LAUNCH(100, 2, false, false);
 #endif
@@ -1770,7 +1792,7 @@ extern "C" int MGP_RO_COLLECT(double* x, float* G, float* Xd, const float* const
     return ro_run(x, G, Xd, W, b, dims, n_layers, nullptr, rewards, p, B, K, N, T, image, carry, flags, cl, stream);
 }
 
-#ifndef MGP_RO_WIDE
+#ifdef MGP_RO_BASE
 // the original entry point: dense state in, dense state out, weight image built inside the launch
 extern "C" int mgp_rollout_steps(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
                                  const int* dims, int n_layers, float* action, double* rewards,

@@ -71,7 +71,14 @@ __device__ __forceinline__ void ro_mlp_cols(float* pcol, const float* pw, const 
 // first stores its A fragments in that order (ro_chain_image_elem), so activations go from one layer's tanh straight into
 // the next layer's MFMAs: no LDS round trip between layers, and the 2-wide output layer runs as one zero-padded m-tile on the
 // same operands (rows 0, 1 of lanes lq == 0) instead of a separate VALU pass over LDS.
-constexpr int RO_MAXMT = RO_KS / 4;                            // m-tiles of the widest layer (2: widths <= 32, 4: <= 64)
+#ifndef MGP_RO_MAXMT
+#define MGP_RO_MAXMT (MGP_RO_KS / 4)
+#endif
+constexpr int RO_MAXMT = MGP_RO_MAXMT;                         // m-tiles of the widest hidden layer (2: widths <= 32, 4: <= 64;
+                                                               // rollout_w128.hip: 8 with RO_KS = 8 -- ONE hidden layer up to 128 wide)
+constexpr int RO_OUTC = 16 * RO_MAXMT;                         // channels the output layer can read (= 4 RO_KS in the chained builds)
+// m-tiles a hidden layer of `cout` rows is run with: 1, 2, 4 or 8 (padded up: few MLP code instances)
+__host__ __device__ inline int ro_mt(int cout) { const int m = pad16(cout) / 16; return m <= 2 ? m : (m <= 4 ? 4 : 8); }
 
 template <int MT, bool TANH>
 __device__ __forceinline__ void ro_layer_regs(const float (&fb)[RO_KS], const float* pw, const float* pbias, int ksteps,
@@ -114,7 +121,7 @@ __device__ __forceinline__ void ro_layer_regs(const float (&fb)[RO_KS], const fl
 __device__ __forceinline__ float ro_chain_image_elem(const float* __restrict__ src, const float* __restrict__ bias, int cin,
                                                      int cout, int layer, bool last, int e)
 {
-    const int MT = last ? 1 : mtiles(cout), tot = MT * 64 * RO_WFS;
+    const int MT = last ? 1 : ro_mt(cout), tot = MT * 64 * RO_WFS;
     if (e >= tot) { const int o = e - tot; return (o < cout) ? bias[o] : 0.f; }
     const int mt = e / (64 * RO_WFS), r1 = e - mt * (64 * RO_WFS);
     const int ln = r1 / RO_WFS, sl = r1 - ln * RO_WFS;
@@ -124,7 +131,7 @@ __device__ __forceinline__ float ro_chain_image_elem(const float* __restrict__ s
 }
 __host__ __device__ inline int ro_chain_image_size(int cout, bool last)
 {
-    const int MT = last ? 1 : mtiles(cout);
+    const int MT = last ? 1 : ro_mt(cout);
     return MT * 64 * RO_WFS + MT * 16;
 }
 
@@ -225,9 +232,9 @@ __device__ __forceinline__ float ro_weight_image_elem(const float* __restrict__ 
 {
     if (last) {
         const int c = e >> 1, o = e & 1;
-        return (c < 4 * RO_KS) ? ((c < cin) ? src[(size_t)o * cin + c] : 0.f) : bias[o];
+        return (c < RO_OUTC) ? ((c < cin) ? src[(size_t)o * cin + c] : 0.f) : bias[o];
     }
-    const int MT = mtiles(cout), tot = MT * 64 * RO_WFS;
+    const int MT = ro_mt(cout), tot = MT * 64 * RO_WFS;
     if (e >= tot) { const int o = e - tot; return (o < cout) ? bias[o] : 0.f; }
     const int mt = e / (64 * RO_WFS), r1 = e - mt * (64 * RO_WFS);
     const int ln = r1 / RO_WFS, sl = r1 - ln * RO_WFS;
@@ -236,7 +243,7 @@ __device__ __forceinline__ float ro_weight_image_elem(const float* __restrict__ 
 }
 __host__ __device__ inline int ro_weight_image_size(int cout, bool last)
 {
-    return last ? 2 * 4 * RO_KS + 2 : mtiles(cout) * 64 * RO_WFS + mtiles(cout) * 16;
+    return last ? 2 * RO_OUTC + 2 : ro_mt(cout) * 64 * RO_WFS + ro_mt(cout) * 16;
 }
 
 }  // namespace

@@ -435,7 +435,7 @@ def evaluate(learner, sim, state, n_episodes, steps):
 
 def collect_supported(learner, K, N, params=None):
     """The collecting builds of the episode-resident kernels cover the shape (mgp_rollout_collect: N <= 256, 6 features,
-    2-D actions, aggregation in front of the first layer, widths <= 64) AND the simulator's networks have symmetric
+    2-D actions, aggregation in front of the first layer, widths <= 64 or one hidden layer <= 128) AND the simulator's networks have symmetric
     membership (`params.symmetric_network`): the frame replay stores bit ROWS and rebuilds `A_t A_{t-1} ...` reading row n as
     column n, which a directed network would silently get wrong."""
     from .. import ops

@@ -102,6 +102,11 @@ CASES = [
     (100, 2, (48,), {'mean_pooling': False}),
     (75, 4, (64, 32, 16), {'n_leaders': 1}),
     (200, 3, (64, 64), {}),
+    # one hidden layer up to 128 wide (cfg/hidden_size.cfg:58): the third build (rollout_w128.hip), eight m-tiles
+    (100, 3, (128,), {}),
+    (64, 2, (96,), {'mean_pooling': False}),
+    (100, 4, (80,), {'n_leaders': 1}),
+    (128, 3, (128,), {'link_drop': 0.25, 'link_seed': 3}),
 ]
 
 
@@ -260,7 +265,7 @@ def test_rollout_ex_flag_validation():
 TOL_CHUNK = {'x': 5e-4, 'delay_gso': 1e-3, 'delay_state': 1e-3, 'last action': 1e-3, 'rewards': 1e-4}
 
 
-@pytest.mark.parametrize('N,K,hidden,variant', CASES[:3] + CASES[4:5] + CASES[7:8] + CASES[9:10] + CASES[11:12] + CASES[18:23] + CASES[28:32])
+@pytest.mark.parametrize('N,K,hidden,variant', CASES[:3] + CASES[4:5] + CASES[7:8] + CASES[9:10] + CASES[11:12] + CASES[18:23] + CASES[28:34])
 def test_rollout_in_launch_chain_matches_oracle(N, K, hidden, variant):
     """The running products inside ONE launch against the oracle forward.  With dt = 1e-7 the agents hardly move, so a
     T-step launch and T - 1 checked one-step launches reach the same state up to ~1e-6 and the last action of the long
@@ -318,7 +323,9 @@ def test_rollout_agrees_with_two_launch_path():
 def test_rollout_unsupported_shapes_fall_back():
     from multiagent_gnn_policies_amd import ops
     assert ops.rollout_supported((6, 64, 64, 2), 3, 100)          # 64-wide layers: the wide build
-    assert not ops.rollout_supported((6, 128, 2), 3, 100)         # 128-wide layers: two-launch path
+    assert ops.rollout_supported((6, 128, 2), 3, 100)             # ONE hidden layer up to 128 wide: the third build
+    assert not ops.rollout_supported((6, 128, 128, 2), 3, 100)    # two of them: two-launch path
+    assert not ops.rollout_supported((6, 128, 2), 3, 200)         # (the wide single layer is built for N <= 128)
     assert ops.rollout_supported((6, 32, 32, 2), 4, 100)          # no dense operator slice lives in LDS: K is bounded by
     assert ops.rollout_supported((6, 32, 32, 2), 5, 128)          # the 2 N (K - 1) gather threads only
     assert not ops.rollout_supported((6, 32, 32, 2), 6, 100)
