@@ -61,7 +61,7 @@ DEFAULT_STEPS = 1000      # env steps in the timed region (resident path: one la
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32 / 32x32x2 dense peak (MI355X_MICROARCH.md: = the fp32 vector rate)
 PARITY_TOL = 1e-5
-PROFILE_ROUND = 'r02'
+PROFILE_ROUND = 'r03'
 F_FEAT, N_ACT = 6, 2
 
 
@@ -84,9 +84,9 @@ def load_weights(actor):
 class Rollout(object):
     """Device-resident vectorised rollout; one `step()` = one env step for all B episodes."""
 
-    def __init__(self, device, B, N, K, hidden, seed, init_mode='auto'):
+    def __init__(self, device, B, N, K, hidden, seed, init_mode='auto', comm_radius=1.0):
         self.B, self.N, self.K = B, N, K
-        self.params = FlockParams(n_agents=N, init_mode=init_mode)
+        self.params = FlockParams(n_agents=N, init_mode=init_mode, comm_radius=comm_radius)
         self.sim = VecFlock(B, self.params, device)
         torch.manual_seed(11)
         self.actor = Actor(F_FEAT, N_ACT, hidden, K, 0).to(device)
@@ -735,6 +735,8 @@ def main():
     ap.add_argument('--init', default='auto', choices=['auto', 'disc', 'grid'],
                     help="reset distribution of the timed episodes: 'auto' = the environment's own (FlockParams.init_mode: "
                          "uniform disc up to N = 100, jittered lattice beyond); 'grid' = the lattice at any N")
+    ap.add_argument('--comm-radius', type=float, default=1.0,
+                    help='communication radius R (FlockParams.comm_radius; the mean degree of a reset state goes with R^2)')
     ap.add_argument('--dagger', action='store_true',
                     help='BASELINE configs[3]: one DAGGER round per rank -- data collection (--episodes lanes x --steps env '
                          'steps) then --updates minibatch updates of --batch-size per rank, gradients exchanged between the '
@@ -768,7 +770,7 @@ def main():
         dagger_round_bench(args, device, rank, world)
         return
 
-    ro = Rollout(device, B, N, K, hidden, seed=1000 + rank, init_mode=args.init)
+    ro = Rollout(device, B, N, K, hidden, seed=1000 + rank, init_mode=args.init, comm_radius=args.comm_radius)
     deg_start = float((ro.sim.network != 0).sum(dim=-1).double().mean().item())
     init_name = ('jittered lattice' if use_grid(ro.params) else 'uniform disc') + " (FlockParams.init_mode='%s')" % args.init
 
@@ -853,6 +855,14 @@ def main():
             run_res(n_steps)
         el_res = timed(run_res_timed)
         res_launch_ms = sum(a_.elapsed_time(b_) for a_, b_ in evs)   # the timed launches' own durations (this rank)
+    # the same launch on the jittered lattice (rounds 1-2 timed this state: sparser, mean degree 6.8 at reset against 8.5)
+    el_grid, deg_grid = None, None
+    if resident and not use_grid(ro.params):
+        ro_g = Rollout(device, B, N, K, hidden, seed=1000 + rank, init_mode='grid', comm_radius=args.comm_radius)
+        deg_grid = float((ro_g.sim.network != 0).sum(dim=-1).double().mean().item())
+        ro_g.prepare_resident([args.warmup, args.steps])
+        el_grid = timed(ro_g.run_resident)
+        del ro_g
     el_fact = None
     if ro.factored_supported() and not args.no_resident:
         ro.restart(1000 + rank)
@@ -900,6 +910,11 @@ def main():
             out["paths"]["resident"] = {"ms_per_step": 1e3 * el_res / args.steps,
                                         "value": total_eps * N * args.steps / el_res,
                                         "launch_ms_hip_events": res_launch_ms}
+            if el_grid is not None:
+                out["paths"]["resident_grid"] = {"ms_per_step": 1e3 * el_grid / args.steps,
+                                                 "value": total_eps * N * args.steps / el_grid,
+                                                 "init": "jittered lattice (FlockParams.init_mode='grid')",
+                                                 "mean_degree_at_reset": deg_grid}
     if rank == 0 and not args.no_roofline:
         res, n_sets = kernel_rooflines(device, B, N, K, ro.actor, ro.sim._c)
         fused = getattr(ro.actor, 'use_fused', False) and ro.actor.ind_agg == 0

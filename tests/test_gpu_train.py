@@ -248,7 +248,7 @@ def test_bench_dagger_round(gpus):
     assert d['dist']['world_size'] == gpus
 
 
-@pytest.mark.parametrize('n,k,paths', [(100, 3, {'two_launch', 'resident'}), (200, 4, {'two_launch', 'resident'}),
+@pytest.mark.parametrize('n,k,paths', [(100, 3, {'two_launch', 'resident', 'resident_grid'}), (200, 4, {'two_launch', 'resident'}),
                                        (300, 3, {'two_launch', 'factored'})])
 def test_bench_single_gpu_contract_and_paths(n, k, paths):
     """python bench.py: one JSON line with the contract's keys; the step implementations timed for the shape."""

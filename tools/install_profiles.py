@@ -1,10 +1,12 @@
-"""Copy the outputs of tools/regen_profiles.sh (gpurun_out/final/) into profiles/r02_* (run from the repo root)."""
+"""Copy the outputs of tools/regen_profiles.sh (gpurun_out/final/) into profiles/<round>_* (run from the repo root;
+ROUND=r03 by default)."""
 import json
 import os
 import shutil
 import sys
 sys.path.insert(0, ".")
-O, R = 'gpurun_out/final', 'r02'
+import os
+O, R = 'gpurun_out/final', os.environ.get('ROUND', 'r03')
 
 
 def last_json(path):
@@ -40,9 +42,10 @@ hdr = ("# bench.py at other shapes (B N K, hidden width x layers), 100-step laun
 open('profiles/%s_other_configs.txt' % R, 'w').write(hdr + open(O + '/other_configs.txt').read())
 open('profiles/%s_rollout_phase_stamps.txt' % R, 'w').write(
     "# tools/harness/ro_phase_prof.hip on MI355X (RO_CARRY=1: prebuilt weight image + factored hand-over, the repeated-launch form):\n"
-    "# in-kernel s_memtime stamps of workgroup 0, lane 0 of six waves, step 5 of the launch (shader cycles).  First block: regular-lattice\n"
+    "# in-kernel s_memtime stamps of workgroup 0, lane 0 of eleven waves, step 5 of the launch (shader cycles).  First block: regular-lattice\n"
     "# harness state, 200-step launch; second block: bench.py's own state 5 steps after reset (irregular degrees), 20-step launches.\n"
-    "# Fused schedule: stamp 6 = last gather stage inside the MLP waves; stage 1 rides in D2/D3 (stamp 8); 3 barriers per step.\n"
+    "# Schedule of round 3: B/C (gather stage K-1 + MLP + output layer on registers + per-axis integration, waves 0-6) | S1 (full-row\n"
+    "# membership test, lists, weights; 13 waves) | S2 (fp64 features, waves 0-6 || gather stage 1 of the next step, waves 7-13); 3 barriers.\n"
     + open(O + '/rollout_phase_stamps.txt').read())
 open('profiles/%s_rollout_launch_cost.txt' % R, 'w').write(
     "# launch length sweep, B=256 N=100 K=3, lattice harness state: dense hand-over (mgp_rollout_steps) vs [carry] = factored hand-over +\n"
@@ -57,3 +60,7 @@ open('profiles/%s_actor_fwd_phase_stamps.txt' % R, 'w').write(
     + open(O + '/actor_fwd_phase_stamps.txt').read())
 from multiagent_gnn_policies_amd import build
 print('hash ok', build.source_hash() == json.load(open('profiles/%s_pmc_traffic.json' % R))['_meta']['source_hash'])
+
+for name in ('dagger_round_1rank.json', 'dagger_round_2ranks_shared_gpu.json', 'p2p_exchange_latency.txt', 'rollout_inst_mix.txt'):
+    if os.path.exists(O + '/' + name):
+        shutil.copy(O + '/' + name, 'profiles/%s_%s' % (R, name))

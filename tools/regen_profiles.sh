@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates every round artefact under profiles/ on the GPU box (run through gpurun from the repo root):
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/regen_profiles.sh > gpurun_out/regen.log 2>&1'
-#   python tools/install_profiles.py          # copies gpurun_out/final/* into profiles/r02_*
+#   python tools/install_profiles.py          # copies gpurun_out/final/* into profiles/<round>_*  (ROUND=r03)
 # The phase harness must have been built first (it travels with the snapshot under scratch/):
 #   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -o scratch/ro_prof tools/harness/ro_phase_prof.hip
 # PMC passes use --pmc with --kernel-trace only (no sys/runtime/hip trace domains).
@@ -24,9 +24,9 @@ F=$(find $O/pmc_fetch -name "*results.db" | head -1); W=$(find $O/pmc_write -nam
 F2=$(find $O/pmc_fetch20 -name "*results.db" | head -1); W2=$(find $O/pmc_write20 -name "*results.db" | head -1)
 cd $R
 python tools/pmc_summary.py $F $W $O/pmc_traffic.json 256,100,3 $F2 $W2 20 > $O/pmc_hbm_traffic.txt 2>&1
-cp $O/pmc_traffic.json $R/profiles/r02_pmc_traffic.json
+cp $O/pmc_traffic.json $R/profiles/${ROUND:-r03}_pmc_traffic.json
 python tools/pmc_sq_summary.py $Q $O/pmc_sq.json > $O/pmc_sq.txt 2>&1
-cp $O/pmc_sq.json $R/profiles/r02_pmc_sq.json
+cp $O/pmc_sq.json $R/profiles/${ROUND:-r03}_pmc_sq.json
 # 2. bench (traffic / sq now resolved from the files just written): the driver's command line, the default, and under rocprof
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_steps20.json 2> $O/bench_steps20.err
 python bench.py > $O/bench_final.json 2> $O/bench_final.err
@@ -51,5 +51,25 @@ d = json.loads(sys.stdin.read())
 k = {a: (round(v['avg_launch_ms']*1e3,1), round(v['GBps'])) for a, v in d.get('kernels', {}).items()}
 print('$1 $2 $3 hidden $4 x $5', 'value %.3e' % d['value'], 'ms/step %.4f' % d['ms_per_step'], 'paths', {a: '%.3e' % b['value'] for a, b in d['paths'].items()}, 'parity ok', d['parity']['ok'], 'max_rel %.2e' % d['parity']['max_rel'], k, d['config']['state_finite'])
 " >> $O/other_configs.txt; done
-rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_fetch20 $O/pmc_write20 $O/trace
+# 4b. degree sweep on the environment's own (disc) resets: the communication radius sets the mean degree (~ R^2)
+for R_ in 0.83 0.95 1.0 1.05 1.15 1.3; do python bench.py --comm-radius $R_ --no-cpu-baseline --no-roofline --steps 100 --warmup 10 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print('degree sweep: comm_radius $R_', 'mean degree at reset %.2f' % d['config']['mean_degree_at_reset'], 'after the timed region %.2f' % d['config']['mean_degree'], 'value %.3e' % d['value'], 'ms/step %.4f' % d['ms_per_step'], 'paths', {a: '%.3e' % b['value'] for a, b in d['paths'].items()}, 'parity ok', d['parity']['ok'], 'max_rel %.2e' % d['parity']['max_rel'])
+" >> $O/other_configs.txt; done
+# 5. the DAGGER round (BASELINE configs[3]): one rank, and two ranks sharing this GPU (gloo carries the IPC handles; the gradient
+#    goes through the one-shot exchange), plus the exchange's own latency for 2 / 3 / 4 ranks on the one device
+python bench.py --dagger --steps 500 --warmup 20 > $O/dagger_round_1rank.json 2> $O/dagger_round_1rank.err
+MGP_DIST_BACKEND=gloo python bench.py --dagger --gpus 2 --steps 500 --warmup 20 --episodes 128 2> $O/dagger_round_2ranks.err | grep "^{" > $O/dagger_round_2ranks_shared_gpu.json
+python - > $O/p2p_exchange_latency.txt 2>&1 <<'PY'
+import sys
+sys.path.insert(0, 'tests')
+import test_gpu_p2p as t
+for w in (2, 3, 4):
+    r = t.run_ranks('allreduce', world=w)
+    print('ranks %d (one MI355X, IPC between processes): %.2f us per exchange of 1,731 floats inside a 32-exchange HIP graph (launch of the stand-alone kernel included), mailbox memory kind %d (2 = uncached), %d exchanges checked bit-exact' % (w, r['exchange_us_in_graph'], r['mem_kind'], r['exchanges']))
+PY
+# 6. instruction mix of the resident kernel (harness, bench state)
+bash tools/gpu/ro_pmc.sh > $O/rollout_inst_mix.txt 2>&1
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_fetch20 $O/pmc_write20 $O/trace gpurun_out/ro_pmc
 ls -la $O
