@@ -262,13 +262,14 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     }
     __syncthreads();
 
-    // thread roles that do not change over the steps
-    //   aggregation: thread (column gn, tap offset gt, parity gq of the list entry); stage q works on tap q + gt
-    const int gq = tid & 1, gn = (tid >> 1) % N, gt = (tid >> 1) / N;
-    const int li = lane & 15, lq = lane >> 4;
-    const int pi = tid / RO_PIECES, piece = tid % RO_PIECES;  // membership: agent row pi, piece of the row's candidates
+    // Thread roles are RE-DERIVED from the thread index at the top of every phase (ro_fresh_tid: opaque to the optimiser), not
+    // kept across the step loop: hoisted out of the loop they live through every phase, and in the run-time sized builds (which
+    // spill ~90 registers) they came back from scratch memory in every phase -- 21 scratch loads in S1 alone, 12.6k cycles
+    // where the compile-time build takes 3.4k.
+    // The compile-time sized builds of widths <= 32 keep the plain index (few spills to begin with; re-deriving cost them 3 %;
+    // the 128-wide build gains 13 % from it even there).
+#define ro_fresh_tid() ro_fresh_tid_<(CN == 0 || RO_MAXMT > 4)>()
     const int dh8 = (N + RO_PIECES - 1) / RO_PIECES;          // candidates per lane of a row in S1: the full row in RO_PIECES pieces (<= 128 / RO_PIECES)
-    const int fr = tid >> 2, fq = tid & 3;                    // lists / features: agent row fr, lane fq of 4
     const double R2 = p.comm_radius2;
     const float R2f = (float)R2, Rf = sqrtf(R2f);
     int cur = 0;                                              // ring slot of tap 0 in XT
@@ -299,6 +300,9 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         // caller's slice G_{j-hv}(t0), read from HBM.
         const int hv = min(t + t_off, K - 1);                 // networks available as lists: A_t .. A_{t-hv+1}
         const bool fused = s1_ready;                          // (implies hv == K - 1)
+        {   // ---- phase A (stage by stage; empty in the fused steady state of K <= 3)
+        const int tid = ro_fresh_tid();
+        const int fr = tid >> 2, fq = tid & 3;                //   gather stages: column fr, lane fq of 4
         // One summation order for a gather stage wherever it runs (here, inside the MLP waves, inside phase D): four lanes
         // per column, lane `part` takes list entries part, part + 4, ... in order, quad sum (l ^ 1, then l ^ 2) -- so a step
         // computes the same bits whether it is the first of a launch or deep inside one.
@@ -353,6 +357,8 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         if (hv < K - 1) {
             // taps j > hv: the product so far (x_{t-j} itself on the launch's first step) times the caller's dense slice j - hv,
             // column gn; the two parity lanes take alternate rows, ten HBM reads in flight each
+            //   dense tail: thread (column gn, tap offset gt, parity gq of the row)
+            const int gq = tid & 1, gn = (tid >> 1) % N, gt = (tid >> 1) / N;
             const bool on = gt < K - 1 && gt + 1 > hv;
             const int j = gt + 1;
             float sa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -382,7 +388,11 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             }
         }
         if (!fused) __syncthreads();                          // fused: the stages above ended with their own barrier
+        }
         RO_STAMP(1);
+        {   // ---- phase B/C
+        const int tid = ro_fresh_tid();
+        const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
         // -------------------------------------------------------------- B: filter GEMM + MLP on MFMA
         // Layer metadata comes from bit-packed scalar kernel arguments: P.dims[l] indexed dynamically is re-fetched from
         // the kernel-argument segment every layer of every step (~700 cycles each).
@@ -569,12 +579,17 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 if (it0 == 0) cl.age[fs] = cl.age0 + t;
             }
         }
+        }
         __syncthreads();
         RO_STAMP(3);
         // -------------------------------------------------------------- S1: membership bits + neighbour lists of the new state
         // reward (spec section 4: two-pass population variance of the velocities), one wave, split around the S1 barrier so
         // that its serial fp64 chain is not what the barrier waits for: the sums here, the variance pass in S2
         double rw_mx = 0.0, rw_my = 0.0;
+        {   // ---- phase S1
+        const int tid = ro_fresh_tid();
+        const int lane = tid & 63, wave = tid >> 6;
+        const int pi = tid / RO_PIECES, piece = tid % RO_PIECES;  // membership: agent row pi, piece of the row's candidates
         if (wave == RO_WAVES - 1 && (rewards != nullptr || CL)) {
             double sx = 0.0, sy = 0.0;
             for (int i = lane; i < N; i += 64) { sx += svx[i]; sy += svy[i]; }
@@ -681,6 +696,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 w_new[pi] = wtab[cnt];                          // (float)(1 / max(deg, 1)) or 1: the value the spec's row weight rounds to
             }
         }
+        }
         __syncthreads();
         RO_STAMP(7);
         // -------------------------------------------------------------- S2: fp64 feature terms  ||  gather stage 1 of step t + 1
@@ -691,6 +707,10 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         // neighbour walk, after building the list itself: 3.7 - 4.7k cycles for this phase.)
         const bool do_s1 = K >= 2 && t + 1 < T && t + 1 + t_off >= K - 1;
         const int curn = (cur + 1 == K) ? 0 : cur + 1;        // ring slot of tap 0 of step t + 1
+        {   // ---- phase S2
+        const int tid = ro_fresh_tid();
+        const int lane = tid & 63, wave = tid >> 6;
+        const int fr = tid >> 2, fq = tid & 3;                //   features: agent row fr, lane fq of 4
         if (tid == RO_THREADS - 2) { cref[0] = spx[0]; cref[1] = spy[0]; }   // next step's reference point (any point is valid)
         const int grp = 4 * ((N + 15) & ~15);                 // threads per group
         if (wave == RO_WAVES - 1 && rewards != nullptr) {     // second half of the reward (velocities change in phase C only)
@@ -816,6 +836,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             }
             RO_STAMP(23);
         }
+        }
         __syncthreads();
         RO_STAMP(4);
         cur = curn;
@@ -917,6 +938,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
 // are kept as membership BITS only (four 64-bit words per row; byte lists of three networks would be 125 KB at N = 200)
 // and every consumer -- gather stages, feature pass, exit -- walks bits; rows / gather items / pair offsets are looped
 // over instead of mapped one to a thread; everything is run-time sized.  Phases, barriers and arithmetic are the same.
+#undef ro_fresh_tid
 struct RbOff { int pos, bits, wrow, uact, xt, vb, act, sxy, mmax, uexp, wl; };
 constexpr int RB_MAXN = 256;
 constexpr int RB_NW = 4;

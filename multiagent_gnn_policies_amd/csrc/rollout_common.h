@@ -140,6 +140,16 @@ __device__ __forceinline__ int ro_dim(unsigned long long dimsA, unsigned int dim
     return (l < 8) ? (int)((dimsA >> (8 * l)) & 255ull) : (int)dims8;
 }
 
+// the thread index as a value the optimiser cannot trace back to threadIdx.x: whatever is derived from it is computed where
+// it is used instead of being hoisted out of the step loop (and, under register pressure, spilled and reloaded every phase)
+template <bool OPAQUE>
+__device__ __forceinline__ int ro_fresh_tid_()
+{
+    int t = (int)threadIdx.x;
+    if (OPAQUE) asm volatile("" : "+v"(t));
+    return t;
+}
+
 __device__ __forceinline__ int ro_slot(int cur, int k, int K) { int s = cur - k; return s < 0 ? s + K : s; }
 
 // Cross-lane adds on the DPP path (one VALU instruction per move; __shfl_xor compiles to ds_bpermute + address math).

@@ -33,7 +33,8 @@ int main(int argc, char** argv) {
         hx[((size_t)b * N + i) * 4 + 2] = 0.1 * ((i * 3) % 17) - 0.8;
         hx[((size_t)b * N + i) * 4 + 3] = 0.1 * ((i * 11) % 19) - 0.9;
     }
-    const int dims[4] = {6, 32, 32, 2};
+    const int HW = getenv("RO_HIDDEN") ? atoi(getenv("RO_HIDDEN")) : 32;      // hidden width (two layers)
+    const int dims[4] = {6, HW, HW, 2};
     std::vector<float> hw[3], hb[3];
     float *W[3], *bb[3];
     for (int l = 0; l < 3; ++l) {
