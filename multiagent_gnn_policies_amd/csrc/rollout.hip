@@ -1074,30 +1074,32 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
     }
     __syncthreads();
 
-    const int gq = tid & 1;
-    const int li = lane & 15, lq = lane >> 4;
-    const int piece = tid & 7;
+    // thread roles, re-derived at the top of every phase from an opaque thread index (see rollout_kernel: kept across the
+    // step loop they are spilled and come back from scratch memory in every phase)
+    int tidv, lanev, wavev, gq, li, lq, piece, fr, fq;
+#define RB_ROLES() do { tidv = ro_fresh_tid_<true>(); lanev = tidv & 63; wavev = tidv >> 6; gq = tidv & 1; li = lanev & 15; \
+                        lq = lanev >> 4; piece = tidv & 7; fr = tidv >> 2; fq = tidv & 3; } while (0)
     const int half = N >> 1, dh = (half + RO_PIECES - 1) / RO_PIECES;          // offsets 1..N/2, up to 16 per piece
-    const int fr = tid >> 2, fq = tid & 3;
     const double R2 = p.comm_radius2;
     const float R2f = (float)R2, Rf = sqrtf(R2f);
     const int nitems = N * (K - 1);
     int cur = 0, hs = 0;
 
     for (int t = 0; t < T; ++t) {
+        RB_ROLES();
         if (CL) {
             // file the state this step starts from: features = tap 0 of the delay line, the bit rows of its network (ring
             // slot hs, intact until phase A's end), the label phase D3 of the previous step left in uexp, its age.  All of
             // it was written before the previous step's closing barrier (or at entry): no barrier needed here.
             const size_t fs = (size_t)((cl.ring_step0 + t) % cl.ring_steps) * gridDim.x + b;
             float* ff = cl.feat + fs * 6 * N;
-            for (int e = tid; e < 6 * N; e += RO_THREADS) { const int f = e / N, n = e - f * N; ff[e] = XT[((size_t)cur * Np + n) * 8 + f]; }
+            for (int e = tidv; e < 6 * N; e += RO_THREADS) { const int f = e / N, n = e - f * N; ff[e] = XT[((size_t)cur * Np + n) * 8 + f]; }
             unsigned long long* fb = cl.bits + fs * RB_NW * N;
             const unsigned long long* cb_ = bits + (size_t)hs * N * RB_NW;
-            for (int i = tid; i < RB_NW * N; i += RO_THREADS) fb[i] = cb_[i];
+            for (int i = tidv; i < RB_NW * N; i += RO_THREADS) fb[i] = cb_[i];
             float* fl = cl.label + fs * 2 * N;
-            for (int e = tid; e < 2 * N; e += RO_THREADS) fl[e] = uexp[e];
-            if (tid == 0) cl.age[fs] = cl.age0 + t;
+            for (int e = tidv; e < 2 * N; e += RO_THREADS) fl[e] = uexp[e];
+            if (tidv == 0) cl.age[fs] = cl.age0 + t;
         }
         const int hsn = (hs + 1 == H) ? 0 : hs + 1;
         unsigned long long* rm_new = bits + (size_t)hsn * N * RB_NW;
@@ -1109,14 +1111,14 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
             const unsigned long long* bq = bits + (size_t)hq * N * RB_NW;
             const float* wq = wrow + hq * N;
             for (int it0 = 0; it0 < nitems; it0 += RO_THREADS / 2) {
-                const int item = it0 + (tid >> 1);
+                const int item = it0 + (tidv >> 1);
                 const int gt = item / N, gn = item - gt * N, j = q + gt;
                 const bool on = item < nitems && j <= K - 1;
                 float sa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (on) {
                     const float* src = (q == 1) ? XT + (size_t)ro_slot(cur, j, K) * Np * 8
                                                 : VB + ((size_t)((q - 1) & 1) * (K - 2) + (j - 2)) * Np * 8;
-                    const unsigned long long* row = bq + (size_t)gn * RB_NW + 2 * gq;      // this lane's two words
+                    const unsigned long long* row = bq + (size_t)gn * RB_NW + 2 * gq;      // this lanev's two words
                     rb_gather_word(row[0], 128 * gq, wq, src, sa);
                     rb_gather_word(row[1], 128 * gq + 64, wq, src, sa);
                 }
@@ -1137,7 +1139,7 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
         }
         if (hv < K - 1) {
             for (int it0 = 0; it0 < nitems; it0 += RO_THREADS / 2) {
-                const int item = it0 + (tid >> 1);
+                const int item = it0 + (tidv >> 1);
                 const int gt = item / N, gn = item - gt * N, j = gt + 1;
                 const bool on = item < nitems && j > hv;
                 float sa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1167,15 +1169,16 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
                 }
             }
         }
-        if (tid == RO_THREADS - 1) mmax[0] = 0u;
+        if (tidv == RO_THREADS - 1) mmax[0] = 0u;
         __syncthreads();
+        RB_ROLES();
         // the slot of the oldest network was read for the last time above: empty rows for this step's pairwise pass
-        for (int i = tid; i < N * RB_NW; i += RO_THREADS) rm_new[i] = 0ull;
+        for (int i = tidv; i < N * RB_NW; i += RO_THREADS) rm_new[i] = 0ull;
         // -------------------------------------------------------------- B: filter GEMM + MLP on MFMA
         // Layer metadata comes from bit-packed scalar kernel arguments: P.dims[l] indexed dynamically is re-fetched from
         // the kernel-argument segment every layer of every step (~700 cycles each).
-        if (wave < NT) {                                      // wave w owns columns 16 w .. 16 w + 15 through every layer
-            const int col = wave * 16 + li;
+        if (wavev < NT) {                                      // wavev w owns columns 16 w .. 16 w + 15 through every layer
+            const int col = wavev * 16 + li;
             // hidden layers on MFMA, activations chained through registers (rollout_common.h): only the first layer reads its B
             // operand (the aggregation result) from LDS, only the last one stores its activations there (for the output layer)
             float zc[RO_MAXMT][4];
@@ -1200,7 +1203,7 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
                     for (int s_ = 0; s_ < RO_KS; ++s_) fb[s_] = zc[s_ >> 2][s_ & 3];
                     ksteps = 4 * mtp;
                 }
-                const float* pw = wfrag + lane * RO_WFS;
+                const float* pw = wfrag + lanev * RO_WFS;
                 const float* pbias = wfrag + MT * 64 * RO_WFS + lq * 4;
                 if (RO_MAXMT >= 8 && MT == 8) ro_layer_regs<(RO_MAXMT >= 8 ? 8 : 1), true>(fb, pw, pbias, ksteps, zc);
                 else if (MT == 4) ro_layer_regs<(RO_MAXMT >= 4 ? 4 : 1), true>(fb, pw, pbias, ksteps, zc);
@@ -1217,17 +1220,17 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
                     for (int rr = 0; rr < 4; ++rr)
                         if (a_ < mtp) pcol[rr * RO_KS + a_ * 4 + lq] = zc[a_][rr];
             }
-            // ---------------------------------------------------------- C: output layer (VALU) + integrate, same wave
+            // ---------------------------------------------------------- C: output layer (VALU) + integrate, same wavev
             // The 2-wide output layer is a packed-FMA chain (as one zero-padded MFMA m-tile fed from the registers it measured
             // 1.5k cycles against 0.85k: eight dependent MFMAs on one accumulator).  For this part the lanes are regrouped:
-            // lane L takes agent column L >> 2 of the wave's tile and the 8 channels c = 4 s + (L & 3) (contiguous in the
-            // B-fragment layout), so the four partial sums of a column sit in one quad and are added by DPP.  The first lane of
+            // lanev L takes agent column L >> 2 of the wavev's tile and the 8 channels c = 4 s + (L & 3) (contiguous in the
+            // B-fragment layout), so the four partial sums of a column sit in one quad and are added by DPP.  The first lanev of
             // the quad then integrates the agent (spec section 1, fp64: bit-exact given the action) and publishes its fp32
-            // coordinates for D1.  No workgroup barrier since the hidden layers: the wave only reads activations it wrote
-            // itself (LDS operations of one wave are ordered).
+            // coordinates for D1.  No workgroup barrier since the hidden layers: the wavev only reads activations it wrote
+            // itself (LDS operations of one wavev are ordered).
             const int lo_ = n_layers - 1;
             const float* w2 = wl + (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull);
-            const int ccol = wave * 16 + (lane >> 2), cg = lane & 3;
+            const int ccol = wavev * 16 + (lanev >> 2), cg = lanev & 3;
             const float* zsrc = act + ccol * RO_CS + cg * RO_KS;
             float zo[RO_KS];
 #pragma unroll
@@ -1268,30 +1271,31 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
             }
             RO_STAMP(15);
             m = wave_max_to_last(m);
-            if (lane == 63) atomicMax(mmax, __float_as_uint(m));
+            if (lanev == 63) atomicMax(mmax, __float_as_uint(m));
             RO_STAMP(9);  // non-negative floats order like their bit patterns
         }
         __syncthreads();
+        RB_ROLES();
         // -------------------------------------------------------------- D1: membership bits, every unordered pair once
-        if (wave == RO_WAVES - 1 && (rewards != nullptr || CL)) {     // reward: one wave, no workgroup barrier
+        if (wavev == RO_WAVES - 1 && (rewards != nullptr || CL)) {     // reward: one wavev, no workgroup barrier
             double sx = 0.0, sy = 0.0;
-            for (int i = lane; i < N; i += 64) { sx += svx[i]; sy += svy[i]; }
+            for (int i = lanev; i < N; i += 64) { sx += svx[i]; sy += svy[i]; }
             sx = mgp_wave_sum(sx); sy = mgp_wave_sum(sy);
-            if (CL && lane == 0) { vtot[0] = sx; vtot[1] = sy; }
+            if (CL && lanev == 0) { vtot[0] = sx; vtot[1] = sy; }
             const double mx = sx / (double)N, my = sy / (double)N;
             double dv = 0.0;
-            for (int i = lane; i < N; i += 64) {
+            for (int i = lanev; i < N; i += 64) {
                 const double ex = svx[i] - mx, ey = svy[i] - my;
                 dv += ex * ex + ey * ey;
             }
             const double var = mgp_wave_sum(dv) / (double)N;
-            if (lane == 0 && rewards != nullptr) rewards[(size_t)b * T + t] = -1.0 * var * p.reward_scale;
+            if (lanev == 0 && rewards != nullptr) rewards[(size_t)b * T + t] = -1.0 * var * p.reward_scale;
         }
         {
             const float M = __uint_as_float(mmax[0]);
             const float band = Rf * (16.f * M + 16.f * Rf) * 5.9604645e-8f + R2f * 1.1920929e-7f;
             const float t_in = R2f - band, t_out = R2f + band;
-            for (int pi = tid >> 3; pi < N; pi += RO_THREADS / 8) {
+            for (int pi = tidv >> 3; pi < N; pi += RO_THREADS / 8) {
                 const float2 si = sxy[pi];
                 for (int ob = 0; ob < dh; ob += 8) {
                     const int d0 = 1 + piece * dh + ob;
@@ -1340,8 +1344,9 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
             }
         }
         __syncthreads();
+        RB_ROLES();
         // -------------------------------------------------------------- D2/D3: fp64 feature terms along the bit rows
-        if (tid < 4 * ncols16) {                              // 4 lanes per row (one 64-bit word each), whole waves
+        if (tidv < 4 * ncols16) {                              // 4 lanes per row (one 64-bit word each), whole waves
             double f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0;
             int cnt = 0;
             if (fr < N) {
@@ -1388,11 +1393,13 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
             }
         }
         __syncthreads();
-        if (tid == 0) { cref[0] = spx[0]; cref[1] = spy[0]; }
+        RB_ROLES();
+        if (tidv == 0) { cref[0] = spx[0]; cref[1] = spy[0]; }
         cur = (cur + 1 == K) ? 0 : cur + 1;
         hs = hsn;
     }
 
+#undef RB_ROLES
     // ------------------------------------------------------------------ exit (see rollout_kernel)
     if (flags & MGP_RO_EXIT_CARRY) {
         unsigned long long* cb = carry + (size_t)b * cwords;
