@@ -266,9 +266,13 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     // kept across the step loop: hoisted out of the loop they live through every phase, and in the run-time sized builds (which
     // spill ~90 registers) they came back from scratch memory in every phase -- 21 scratch loads in S1 alone, 12.6k cycles
     // where the compile-time build takes 3.4k.
-    // The compile-time sized builds of widths <= 32 keep the plain index (few spills to begin with; re-deriving cost them 3 %;
-    // the 128-wide build gains 13 % from it even there).
-#define ro_fresh_tid() ro_fresh_tid_<(CN == 0 || RO_MAXMT > 4)>()
+    // The compile-time sized builds of widths <= 32 re-derive in phase B/C only (few spills to begin with; re-deriving everywhere
+    // cost them 3 %; the 128-wide build gains 13 % from it even there).
+#ifndef RO_FRESH_MASK
+#define RO_FRESH_MASK 2                    // phases that re-derive their roles in the compile-time sized builds too (bit 0: A, 1: B/C,
+                                           // 2: S1, 3: S2).  Measured on the headline build: B/C alone -1.5 %, S1 +3 %, S2 +1 %, all +4 %
+#endif
+#define ro_fresh_tid_ph(ph) ro_fresh_tid_<(CN == 0 || RO_MAXMT > 4 || ((RO_FRESH_MASK >> (ph)) & 1))>()
     const int dh8 = (N + RO_PIECES - 1) / RO_PIECES;          // candidates per lane of a row in S1: the full row in RO_PIECES pieces (<= 128 / RO_PIECES)
     const double R2 = p.comm_radius2;
     const float R2f = (float)R2, Rf = sqrtf(R2f);
@@ -301,7 +305,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         const int hv = min(t + t_off, K - 1);                 // networks available as lists: A_t .. A_{t-hv+1}
         const bool fused = s1_ready;                          // (implies hv == K - 1)
         {   // ---- phase A (stage by stage; empty in the fused steady state of K <= 3)
-        const int tid = ro_fresh_tid();
+        const int tid = ro_fresh_tid_ph(0);
         const int fr = tid >> 2, fq = tid & 3;                //   gather stages: column fr, lane fq of 4
         // One summation order for a gather stage wherever it runs (here, inside the MLP waves, inside phase D): four lanes
         // per column, lane `part` takes list entries part, part + 4, ... in order, quad sum (l ^ 1, then l ^ 2) -- so a step
@@ -391,7 +395,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         }
         RO_STAMP(1);
         {   // ---- phase B/C
-        const int tid = ro_fresh_tid();
+        const int tid = ro_fresh_tid_ph(1);
         const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
         // -------------------------------------------------------------- B: filter GEMM + MLP on MFMA
         // Layer metadata comes from bit-packed scalar kernel arguments: P.dims[l] indexed dynamically is re-fetched from
@@ -587,7 +591,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         // that its serial fp64 chain is not what the barrier waits for: the sums here, the variance pass in S2
         double rw_mx = 0.0, rw_my = 0.0;
         {   // ---- phase S1
-        const int tid = ro_fresh_tid();
+        const int tid = ro_fresh_tid_ph(2);
         const int lane = tid & 63, wave = tid >> 6;
         const int pi = tid / RO_PIECES, piece = tid % RO_PIECES;  // membership: agent row pi, piece of the row's candidates
         if (wave == RO_WAVES - 1 && (rewards != nullptr || CL)) {
@@ -708,7 +712,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         const bool do_s1 = K >= 2 && t + 1 < T && t + 1 + t_off >= K - 1;
         const int curn = (cur + 1 == K) ? 0 : cur + 1;        // ring slot of tap 0 of step t + 1
         {   // ---- phase S2
-        const int tid = ro_fresh_tid();
+        const int tid = ro_fresh_tid_ph(3);
         const int lane = tid & 63, wave = tid >> 6;
         const int fr = tid >> 2, fq = tid & 3;                //   features: agent row fr, lane fq of 4
         if (tid == RO_THREADS - 2) { cref[0] = spx[0]; cref[1] = spy[0]; }   // next step's reference point (any point is valid)
@@ -938,7 +942,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
 // are kept as membership BITS only (four 64-bit words per row; byte lists of three networks would be 125 KB at N = 200)
 // and every consumer -- gather stages, feature pass, exit -- walks bits; rows / gather items / pair offsets are looped
 // over instead of mapped one to a thread; everything is run-time sized.  Phases, barriers and arithmetic are the same.
-#undef ro_fresh_tid
+#undef ro_fresh_tid_ph
 struct RbOff { int pos, bits, wrow, uact, xt, vb, act, sxy, mmax, uexp, wl; };
 constexpr int RB_MAXN = 256;
 constexpr int RB_NW = 4;
