@@ -313,9 +313,12 @@ def test_coverage_predicates_are_host_side():
     for h in (4, 8, 16, 32):                                       # cfg/hidden_size.cfg up to the 32-wide limit
         for layers in (1, 2, 3, 4):
             assert ops.rollout_supported((6,) + (h,) * layers + (2,), 3, 100)
-    assert ops.rollout_supported((6, 64, 2), 3, 100) and ops.rollout_supported((6, 64, 64, 64, 2), 3, 100)
-    assert not ops.rollout_supported((6, 64, 64, 64, 64, 2), 3, 100)   # four 64-wide layers: weight image + state > 160 KB
-    assert not ops.rollout_supported((6, 128, 2), 3, 100)          # 128-wide layers: two-launch path
+    assert ops.rollout_supported((6, 64, 2), 3, 100) and ops.rollout_supported((6, 64, 64, 64, 64, 2), 3, 100)
+    assert not ops.rollout_supported((6, 64, 64, 64, 64, 64, 2), 3, 100)   # five 64-wide layers: weight image + state > 160 KB
+    assert not ops.rollout_supported((6, 64, 64, 64, 64, 2), 3, 128)       # four of them at N = 128 neither
+    assert ops.rollout_supported((6, 128, 2), 3, 100)              # ONE hidden layer up to 128 wide: the third build ...
+    assert not ops.rollout_supported((6, 128, 128, 2), 3, 100)     # ... two of them, or a second hidden layer behind it:
+    assert not ops.rollout_supported((6, 128, 32, 2), 3, 100)      #     two-launch path
     assert not ops.rollout_supported((6, 32, 2), 3, 1000)          # BASELINE configs[2]: two-launch path
     assert not ops.rollout_supported((6, 32, 2), 6, 100) and not ops.rollout_supported((6, 32, 2), 3, 3)
     assert not ops.rollout_supported((5, 32, 2), 3, 100) and not ops.rollout_supported((6, 32, 3), 3, 100)
