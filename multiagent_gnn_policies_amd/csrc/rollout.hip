@@ -140,15 +140,18 @@ __host__ __device__ constexpr RoOff ro_offsets(int N, int K)
 // CL: DAGGER data collection (reference gnn_dagger.py:154-178) compiled in: every step files the state it starts from --
 // features, membership bits of its network, expert label, age -- as a compact frame, and the step is driven by the expert
 // with probability beta (a counter-based coin: mgp_device.h dagger_coin), else by the policy.
-template <int CN, int CK, bool FD, bool CL>
+// CM: the reference's policy shape compiled in -- two hidden layers of 32 (cfg/dagger.cfg: hidden_size 32, n_layers 2): the
+// layer loop unrolls, no layer metadata is decoded, the MLP's scalar control flow disappears.
+template <int CN, int CK, bool FD, bool CL, bool CM = false>
 __global__ __launch_bounds__(RO_THREADS)
 void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __restrict__ Xd, float* __restrict__ action,
                     double* __restrict__ rewards, RoParams P, MgpFlockParams p, int K_arg, int N_arg, int T,
                     unsigned long long dimsA, unsigned int dims8, unsigned long long woffA, unsigned long long woffB,
-                    int n_layers, const float* __restrict__ image, int image_floats, unsigned long long* __restrict__ carry,
+                    int n_layers_arg, const float* __restrict__ image, int image_floats, unsigned long long* __restrict__ carry,
                     int flags, MgpCollect cl)
 {
     const int N = CN ? CN : N_arg, K = CK ? CK : K_arg;
+    const int n_layers = CM ? 3 : n_layers_arg;
     const RoOff cv = ro_offsets(N, K);
     const int H = ro_hist(K);
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
@@ -272,7 +275,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
 #define RO_FRESH_MASK 2                    // phases that re-derive their roles in the compile-time sized builds too (bit 0: A, 1: B/C,
                                            // 2: S1, 3: S2).  Measured on the headline build: B/C alone -1.5 %, S1 +3 %, S2 +1 %, all +4 %
 #endif
-#define ro_fresh_tid_ph(ph) ro_fresh_tid_<(CN == 0 || RO_MAXMT > 4 || ((RO_FRESH_MASK >> (ph)) & 1))>()
+#define ro_fresh_tid_ph(ph) ro_fresh_tid_<(CN == 0 || RO_MAXMT > 4 || (((CM ? 10 : RO_FRESH_MASK) >> (ph)) & 1))>()   // (CM: B/C and S2: -2 %)
     const int dh8 = (N + RO_PIECES - 1) / RO_PIECES;          // candidates per lane of a row in S1: the full row in RO_PIECES pieces (<= 128 / RO_PIECES)
     const double R2 = p.comm_radius2;
     const float R2f = (float)R2, Rf = sqrtf(R2f);
@@ -456,10 +459,12 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) zc[a_][rr] = 0.f;
             int mtp = 0;
-            for (int l = 0; l < n_layers - 1; ++l) {
-                const int cout = ro_dim(dimsA, dims8, l + 1);
-                const int MT = ro_mt(cout);
-                const float* wfrag = wl + (int)((((l < 4) ? woffA : woffB) >> (16 * (l & 3))) & 0xFFFFull);
+#pragma unroll
+            for (int l = 0; l < (CM ? 2 : n_layers - 1); ++l) {
+                const int cout = CM ? 32 : ro_dim(dimsA, dims8, l + 1);
+                const int MT = CM ? 2 : ro_mt(cout);
+                // (CM: a 32-wide hidden layer's block is 2 m-tiles of fragments + 32 bias values)
+                const float* wfrag = wl + (CM ? l * (2 * 64 * RO_WFS + 32) : (int)((((l < 4) ? woffA : woffB) >> (16 * (l & 3))) & 0xFFFFull));
                 float fb[RO_KS];
                 int ksteps;
                 if (l == 0) {
@@ -483,8 +488,8 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             }
             // ---------------------------------------------------------- C: output layer + integration, same wave, no barrier
             const int lo_ = n_layers - 1;
-            const float* w2 = wl + (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull);
-            if (n_layers > 1) {
+            const float* w2 = wl + (CM ? 2 * (2 * 64 * RO_WFS + 32) : (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull));
+            if (CM || n_layers > 1) {
                 // The 2-wide output layer on the accumulator registers of the last hidden layer: lane (li, lq) holds channels
                 // c = 16 a + 4 lq + rr of column li, whose weight pairs (W[0][c], W[1][c]) are two 16-byte reads per m-tile;
                 // packed-FMA partials, then the four row groups (lq) of the wave are added with two lane swaps
@@ -1575,7 +1580,7 @@ static void take_launch_events(hipEvent_t* start, hipEvent_t* stop)
     mgp_tls_launch_events[0] = mgp_tls_launch_events[1] = nullptr;
 }
 
-template <int CN, int CK, bool FD, bool CL>
+template <int CN, int CK, bool FD, bool CL, bool CM = false>
 int launch_rollout(double* x, float* G, float* Xd, float* action, double* rewards, const RoParams& P,
                    const MgpFlockParams* p, int B, int K, int N, int T, unsigned long long dimsA, unsigned int dims8,
                    unsigned long long woffA, unsigned long long woffB, int n_layers, int lds, hipStream_t st,
@@ -1583,7 +1588,7 @@ int launch_rollout(double* x, float* G, float* Xd, float* action, double* reward
 {
     static thread_local int lds_set = 0;                       // the attribute sticks to the function: set it when it grows
     if (lds > lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<CN, CK, FD, CL>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<CN, CK, FD, CL, CM>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return MGP_ELAUNCH;
         lds_set = lds;
@@ -1592,11 +1597,11 @@ int launch_rollout(double* x, float* G, float* Xd, float* action, double* reward
     hipEvent_t ev0, ev1;
     take_launch_events(&ev0, &ev1);
     if (ev0 != nullptr || ev1 != nullptr)
-        hipExtLaunchKernelGGL((rollout_kernel<CN, CK, FD, CL>), dim3(B), dim3(RO_THREADS), lds, st, ev0, ev1, 0, x, G, Xd, action,
+        hipExtLaunchKernelGGL((rollout_kernel<CN, CK, FD, CL, CM>), dim3(B), dim3(RO_THREADS), lds, st, ev0, ev1, 0, x, G, Xd, action,
                               rewards, P, *p, K, N, T, dimsA, dims8, woffA, woffB, n_layers, image, image_floats, carry, flags,
                               cl ? *cl : none);
     else
-        hipLaunchKernelGGL((rollout_kernel<CN, CK, FD, CL>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K,
+        hipLaunchKernelGGL((rollout_kernel<CN, CK, FD, CL, CM>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K,
                            N, T, dimsA, dims8, woffA, woffB, n_layers, image, image_floats, carry, flags, cl ? *cl : none);
     return mgp_launch_status();
 }
@@ -1792,12 +1797,23 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
 #define RO_LAUNCH(CN_, CK_, FD_, CL_) launch_rollout<CN_, CK_, FD_, CL_>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags, cl)
     if (cl != nullptr) {               // the data-collection builds (DAGGER rollouts)
 #ifdef MGP_RO_BASE
-        if (N == 100 && K == 3 && !fade) return RO_LAUNCH(100, 3, false, true);      // cfg/dagger.cfg
+        if (N == 100 && K == 3 && !fade && n_layers == 3 && dims[1] == 32 && dims[2] == 32 && P.woff[1] == 2 * 64 * RO_WFS + 32 &&
+            P.woff[2] == 2 * (2 * 64 * RO_WFS + 32))                                  // cfg/dagger.cfg, policy shape compiled in
+            return launch_rollout<100, 3, false, true, true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB,
+                                                             n_layers, lds, st, image, wt, carry, flags, cl);
+        if (N == 100 && K == 3 && !fade) return RO_LAUNCH(100, 3, false, true);
 #endif
         return fade ? RO_LAUNCH(0, 0, true, true) : RO_LAUNCH(0, 0, false, true);
     }
+#ifdef MGP_RO_BASE
+    // the reference's own policy shape at the headline (N, K): everything compile-time (cfg/dagger.cfg; BASELINE.json configs[0..1])
+    if (N == 100 && K == 3 && !fade && n_layers == 3 && dims[1] == 32 && dims[2] == 32 && P.woff[1] == 2 * 64 * RO_WFS + 32 &&
+        P.woff[2] == 2 * (2 * 64 * RO_WFS + 32))
+        return launch_rollout<100, 3, false, false, true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers,
+                                                          lds, st, image, wt, carry, flags, cl);
+#endif
 #if defined(MGP_RO_BASE) || defined(MGP_RO_X128)
-    if (N == 100 && K == 3 && !fade)   // the headline shape (BASELINE.json configs[0..1]) runs a build with compile-time addresses
+    if (N == 100 && K == 3 && !fade)   // the headline (N, K) with any covered policy: compile-time addresses
         return RO_LAUNCH(100, 3, false, false);
 #endif
 #ifdef MGP_RO_BASE
