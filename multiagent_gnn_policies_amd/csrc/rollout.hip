@@ -435,10 +435,11 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                         }
 #pragma unroll
                         for (int u = 0; u < GU; ++u) {
-                            if (e + 4 * u < cnt) {
-                                sa[0] = fmaf(xa[u].x, g[u], sa[0]); sa[1] = fmaf(xa[u].y, g[u], sa[1]); sa[2] = fmaf(xa[u].z, g[u], sa[2]);
-                                sa[3] = fmaf(xa[u].w, g[u], sa[3]); sa[4] = fmaf(xb[u].x, g[u], sa[4]); sa[5] = fmaf(xb[u].y, g[u], sa[5]);
-                            }
+                            // entries beyond the list carry weight 0 on a valid (finite) row -- fma(x, 0, s) == s exactly -- instead
+                            // of an exec-mask change per entry (-3 % per step)
+                            const float gz = (e + 4 * u < cnt) ? g[u] : 0.f;
+                            sa[0] = fmaf(xa[u].x, gz, sa[0]); sa[1] = fmaf(xa[u].y, gz, sa[1]); sa[2] = fmaf(xa[u].z, gz, sa[2]);
+                            sa[3] = fmaf(xa[u].w, gz, sa[3]); sa[4] = fmaf(xb[u].x, gz, sa[4]); sa[5] = fmaf(xb[u].y, gz, sa[5]);
                         }
                     }
                 }
@@ -815,11 +816,10 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                             }
 #pragma unroll
                             for (int u = 0; u < GU; ++u) {
-                                if (e + 4 * u < cnt) {
-                                    s1[jj][0] = fmaf(x0[u].x, gv[u], s1[jj][0]); s1[jj][1] = fmaf(x0[u].y, gv[u], s1[jj][1]);
-                                    s1[jj][2] = fmaf(x0[u].z, gv[u], s1[jj][2]); s1[jj][3] = fmaf(x0[u].w, gv[u], s1[jj][3]);
-                                    s1[jj][4] = fmaf(x1[u].x, gv[u], s1[jj][4]); s1[jj][5] = fmaf(x1[u].y, gv[u], s1[jj][5]);
-                                }
+                                const float gz = (e + 4 * u < cnt) ? gv[u] : 0.f;
+                                s1[jj][0] = fmaf(x0[u].x, gz, s1[jj][0]); s1[jj][1] = fmaf(x0[u].y, gz, s1[jj][1]);
+                                s1[jj][2] = fmaf(x0[u].z, gz, s1[jj][2]); s1[jj][3] = fmaf(x0[u].w, gz, s1[jj][3]);
+                                s1[jj][4] = fmaf(x1[u].x, gz, s1[jj][4]); s1[jj][5] = fmaf(x1[u].y, gz, s1[jj][5]);
                             }
                         }
                     }
