@@ -84,9 +84,11 @@ def load_weights(actor):
 class Rollout(object):
     """Device-resident vectorised rollout; one `step()` = one env step for all B episodes."""
 
-    def __init__(self, device, B, N, K, hidden, seed, init_mode='auto', comm_radius=1.0):
+    def __init__(self, device, B, N, K, hidden, seed, init_mode='auto', comm_radius=1.0, **variant):
         self.B, self.N, self.K = B, N, K
-        self.params = FlockParams(n_agents=N, init_mode=init_mode, comm_radius=comm_radius)
+        # variant: FlockParams fields of the environment variants (n_leaders = 2: FlockingLeader-v0, two_flocks = True:
+        # FlockingTwoFlocks-v0, link_drop: FlockingStochastic-v0)
+        self.params = FlockParams(n_agents=N, init_mode=init_mode, comm_radius=comm_radius, **variant)
         self.sim = VecFlock(B, self.params, device)
         torch.manual_seed(11)
         self.actor = Actor(F_FEAT, N_ACT, hidden, K, 0).to(device)

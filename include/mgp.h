@@ -438,6 +438,35 @@ int  mgp_sparse_policy_step(const unsigned long long* bits, const float* wrow, c
                             int B, int K, int N, int cur, int hs, void* stream);
 int  mgp_sparse_to_dense(const unsigned long long* bits, const float* wrow, float* G, int B, int K, int N, int hs,
                          void* stream);
+/* DAGGER data collection on the factored state (reference gnn_dagger.py:154-178 per lane; the semantics of
+ * mgp_rollout_collect for N > 256): mgp_sparse_policy_step that ALSO files the frame of the state the step starts from at
+ * ring step `ring_step` of a ring laid out [ring_steps][B] -- features x_t (6,N), bit rows (N x mgp_sparse_words(N) u64) and
+ * row weights (N) of its network A_t, the expert's action for it (2,N: the label, :174-176), its age -- and writes into
+ * `action` what drives the step: the expert's action where dagger_coin(seed, episode[b], age_now) < floor(beta[b] 2^32)
+ * (:157-161; csrc/mgp_device.h, oracle/dagger_vec.py), else the policy's.  `expert` (B,N,2) is the by-product of the simulator
+ * kernel that produced the current state (mgp_flock_step_cells / _sparse).  One env step stays K launches. */
+typedef struct MgpSparseCollect {
+    float* feat;                 /* [ring_steps][B][6][N] */
+    unsigned long long* bits;    /* [ring_steps][B][N][NW] */
+    float* wrow;                 /* [ring_steps][B][N] */
+    float* label;                /* [ring_steps][B][2][N] */
+    int* age;                    /* [ring_steps][B] */
+    const float* expert;         /* (B,N,2) */
+    const float* beta;           /* (B) */
+    const unsigned int* episode; /* (B) */
+    unsigned int seed;
+    int age_now;                 /* steps since the reset (all lanes in lock step) */
+    int ring_step;
+    int ring_steps;
+} MgpSparseCollect;
+int  mgp_sparse_policy_collect(const unsigned long long* bits, const float* wrow, const float* feat, const float* image,
+                               const int* dims, int n_layers, float* scratch, float* action,
+                               int B, int K, int N, int cur, int hs, const MgpSparseCollect* collect, void* stream);
+/* mgp_replay_gather_many for frames filed by mgp_sparse_policy_collect (N > 256: NW = mgp_sparse_words(N) words per bit
+ * row, row weights stored with the frame): same outputs, the products e_i A_t A_{t-1} .. evaluated row by row from HBM. */
+int  mgp_replay_gather_rows(const float* feat, const unsigned long long* bits, const float* wrow, const float* label,
+                            const int* age, const long* idx, const int* cursor, int Bt, int nb, int lanes, int ring_steps,
+                            int K, int N, float* X, float* G, float* Y, void* stream);
 
 #ifdef __cplusplus
 }

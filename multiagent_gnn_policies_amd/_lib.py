@@ -34,6 +34,13 @@ class MgpCollect(ctypes.Structure):
                 ('seed', ctypes.c_uint), ('age0', ctypes.c_int), ('ring_step0', ctypes.c_int), ('ring_steps', ctypes.c_int)]
 
 
+class MgpSparseCollect(ctypes.Structure):
+    """Mirror of struct MgpSparseCollect (include/mgp.h): one collected step on the factored state (N > 256)."""
+    _fields_ = [('feat', ctypes.c_void_p), ('bits', ctypes.c_void_p), ('wrow', ctypes.c_void_p), ('label', ctypes.c_void_p),
+                ('age', ctypes.c_void_p), ('expert', ctypes.c_void_p), ('beta', ctypes.c_void_p), ('episode', ctypes.c_void_p),
+                ('seed', ctypes.c_uint), ('age_now', ctypes.c_int), ('ring_step', ctypes.c_int), ('ring_steps', ctypes.c_int)]
+
+
 # name -> (restype, argtypes).  Pointers are passed as raw integers (tensor.data_ptr()).
 SIGNATURES = {
     'mgp_version': (_int, []),
@@ -105,6 +112,8 @@ SIGNATURES = {
     'mgp_sparse_policy_image': (_int, [_vp, _vp, _vp, _int, _int, _vp, _vp]),
     'mgp_sparse_policy_step': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     'mgp_sparse_to_dense': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp]),
+    'mgp_sparse_policy_collect': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _int, _int, _int, _int, _int, _vp, _vp]),
+    'mgp_replay_gather_rows': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     'mgp_train_step': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _f32, _f32, _f32, _f32, _vp,
                               _vp, _vp, _int, _int, _int, _vp]),
 }

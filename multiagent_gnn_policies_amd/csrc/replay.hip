@@ -95,7 +95,101 @@ void replay_gather_kernel(const float* __restrict__ feat, const unsigned long lo
     }
 }
 
+// The same for frames of large flocks (mgp_sparse_policy_collect: N > 256, NW words per bit row, the row weights stored with
+// the frame): the history does not fit the LDS, so a wave builds ONE row i of slice j from HBM/L2 -- e_i A_t, then times
+// A_{t-1} .. A_{t-j+1} by scattering along the bit rows of the non-zero entries (symmetric membership), row vectors
+// ping-pong in LDS -- the loop of sp_to_dense_kernel (sparse_policy.hip) on ring frames.
+// grid (Bt * nb, 1 + (K - 1) * ceil(N / 4)): y = 0 copies the delay line, the label and the identity slice; else 4 rows of a slice.
+__global__ __launch_bounds__(RG_THREADS)
+void replay_gather_rows_kernel(const float* __restrict__ feat, const unsigned long long* __restrict__ bits,
+                               const float* __restrict__ wrow, const float* __restrict__ label, const int* __restrict__ age,
+                               const long* __restrict__ idx, const int* __restrict__ cursor, int Bt, int lanes,
+                               int ring_steps, int K, int N, int NW, float* __restrict__ X, float* __restrict__ G,
+                               float* __restrict__ Y)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    const int Np = (N + 3) & ~3;
+    const int b = blockIdx.x, role = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long cur = cursor != nullptr ? (long)cursor[0] : 0L;
+    const long r = idx[cur * Bt + b];
+    const long ring = (long)ring_steps * lanes;
+    const int a = age[r];
+    float* Gb = G + (size_t)b * K * N * N;
+    if (role == 0) {
+        for (int e = tid; e < K * 6 * N; e += RG_THREADS) {
+            const int k = e / (6 * N), rem = e - k * 6 * N;
+            long rk = r - (long)k * lanes; rk = rk < 0 ? rk + ring : rk;
+            X[(size_t)b * K * 6 * N + e] = (a >= k) ? feat[(size_t)rk * 6 * N + rem] : 0.f;
+        }
+        for (int e = tid; e < 2 * N; e += RG_THREADS) Y[(size_t)b * 2 * N + e] = label[(size_t)r * 2 * N + e];
+        for (int e = tid; e < N * N; e += RG_THREADS) { const int i = e / N, n = e - i * N; Gb[e] = (i == n) ? 1.f : 0.f; }
+        return;
+    }
+    const int groups = (N + 3) / 4;
+    const int j = 1 + (role - 1) / groups, i = ((role - 1) % groups) * 4 + wave;
+    if (i >= N) return;                                       // whole wave; no workgroup barrier below
+    float* Gr = Gb + ((size_t)j * N + i) * N;
+    if (a < j) {                                              // no j-step history yet: zero row (reference: zero-filled slices)
+        for (int n = lane; n < N; n += 64) Gr[n] = 0.f;
+        return;
+    }
+    float* r0 = reinterpret_cast<float*>(smraw) + (size_t)wave * 2 * Np;
+    float* r1 = r0 + Np;
+    {   // e_i . A_t
+        const unsigned long long* row = bits + ((size_t)r * N + i) * NW;
+        const float wi = wrow[(size_t)r * N + i];
+        for (int n = lane; n < N; n += 64) r0[n] = ((row[n >> 6] >> (n & 63)) & 1ull) ? wi : 0.f;
+    }
+    for (int q = 1; q < j; ++q) {                             // r1 = r0 . A_{t-q}
+        long rq = r - (long)q * lanes; rq = rq < 0 ? rq + ring : rq;
+        const unsigned long long* net = bits + (size_t)rq * N * NW;
+        const float* wn = wrow + (size_t)rq * N;
+        for (int n = lane; n < N; n += 64) r1[n] = 0.f;
+        for (int m0 = 0; m0 < N; m0 += 64) {
+            const float rv = (m0 + lane < N) ? r0[m0 + lane] : 0.f;
+            unsigned long long nz = __ballot(rv != 0.f);
+            while (nz) {                                      // wave-uniform loop over the non-zero entries, ascending m
+                const int m = m0 + __builtin_ctzll(nz);
+                nz &= nz - 1ull;
+                const float val = r0[m] * wn[m];
+                for (int wd = lane; wd < NW; wd += 64) {      // lane l walks words l, l + 64, ..: distinct columns
+                    unsigned long long w = net[(size_t)m * NW + wd];
+                    while (w) { const int n = 64 * wd + __builtin_ctzll(w); w &= w - 1ull; r1[n] += val; }
+                }
+            }
+        }
+        float* t = r0; r0 = r1; r1 = t;
+    }
+    for (int n = lane; n < N; n += 64) Gr[n] = r0[n];
+}
+
 }  // namespace
+
+extern "C" int mgp_replay_gather_rows(const float* feat, const unsigned long long* bits, const float* wrow,
+                                      const float* label, const int* age, const long* idx, const int* cursor, int Bt, int nb,
+                                      int lanes, int ring_steps, int K, int N, float* X, float* G, float* Y, void* stream)
+{
+    if (Bt < 0 || nb < 1 || lanes < 1 || ring_steps < 1 || K < 1 || K > 5 || N < 4) return MGP_EINVAL;
+    if (N > 4096) return MGP_EUNSUPPORTED;
+    if (Bt == 0) return MGP_OK;
+    if ((long)Bt * nb > 65535L * 32) return MGP_EINVAL;
+    MGP_CHECK_PTR(feat); MGP_CHECK_PTR8(bits); MGP_CHECK_PTR(wrow); MGP_CHECK_PTR(label); MGP_CHECK_PTR(age);
+    MGP_CHECK_PTR8(idx); MGP_CHECK_PTR(X); MGP_CHECK_PTR(G); MGP_CHECK_PTR(Y);
+    if (cursor != nullptr && (reinterpret_cast<uintptr_t>(cursor) & 3u)) return MGP_EALIGN;
+    const int NW = mgp_sparse_words(N), Np = (N + 3) & ~3;
+    const int lds = RG_WAVES * 2 * Np * 4;
+    const long gy = 1 + (long)(K - 1) * ((N + 3) / 4);
+    if (gy > 65535) return MGP_EUNSUPPORTED;
+    mgp_clear_error();
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(replay_gather_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            lds) != hipSuccess)
+        return MGP_ELAUNCH;
+    hipLaunchKernelGGL(replay_gather_rows_kernel, dim3(Bt * nb, (unsigned)gy), dim3(RG_THREADS), lds,
+                       static_cast<hipStream_t>(stream), feat, bits, wrow, label, age, idx, cursor, Bt, lanes, ring_steps, K, N,
+                       NW, X, G, Y);
+    return mgp_launch_status();
+}
 
 extern "C" int mgp_replay_gather_many(const float* feat, const unsigned long long* bits, const float* label, const int* age,
                                       const long* idx, const int* cursor, int Bt, int nb, int lanes, int ring_steps, int K,

@@ -14,6 +14,7 @@
 // arithmetic of rollout.hip's phases A-C) and the simulator (mgp_flock_step_sparse).  sp_to_dense_kernel rebuilds the
 // dense delayed operator slices of the reference contract from the bit rows when a caller asks for them.
 #include "mgp_common.h"
+#include "mgp_device.h"
 #include "rollout_common.h"
 
 namespace {
@@ -87,10 +88,31 @@ struct SpPolicy {
     int wtot;
 };
 
+// DAGGER data collection on the factored state (gnn_dagger.py:154-178; the semantics of rollout.hip's collecting build):
+// the policy tail also files the FRAME of the state the step starts from -- features x_t, bit rows and row weights of A_t,
+// the expert's action for x_t (the label), the age -- and hands the simulator the expert's action instead of the policy's
+// when the lane's counter-based coin says so.  Frame planes point at this step's ring slot: [B][...].
+struct SpCollect {
+    float* feat;                          // [B][6][N]
+    unsigned long long* bits;             // [B][N][NW]
+    float* wrow;                          // [B][N]
+    float* label;                         // [B][2][N]
+    int* age;                             // [B]
+    const unsigned long long* net;        // rows of A_t (ring slot hs), batch stride sNb words
+    const float* wnet;                    // its row weights, batch stride sWn
+    long sNb, sWn;
+    const float* expert;                  // (B,N,2): the expert's action for x_t (by-product of the simulator kernel)
+    const float* beta;                    // (B)
+    const unsigned int* episode;          // (B)
+    unsigned int seed;
+    int age_now;
+};
+
 // grid: x = tile of 64 columns, y = b.  LDS: act [64][RO_CS] | weight image
+template <bool CL>
 __global__ __launch_bounds__(SP_THREADS)
 void sp_policy_kernel(SpPolicy P, float* __restrict__ action, int K, int N, int NW, unsigned long long dimsA,
-                      unsigned int dims8, unsigned long long woffA, unsigned long long woffB, int n_layers)
+                      unsigned int dims8, unsigned long long woffA, unsigned long long woffB, int n_layers, SpCollect C)
 {
     extern __shared__ __attribute__((aligned(16))) float spm[];
     float* act = spm;
@@ -113,6 +135,31 @@ void sp_policy_kernel(SpPolicy P, float* __restrict__ action, int K, int N, int 
             const int c = i >> 3, f = i & 7;
             if (f < 6 && c0 + c < N) act[c * RO_CS + rpos(f * K + j)] = src[(size_t)(c0 + c) * 8 + f];
         }
+    }
+    bool expert_drives = false;
+    if (CL) {
+        const double bq = floor((double)C.beta[b] * 4294967296.0);            // P(expert drives) in units of 2^-32
+        const unsigned long long thr = bq <= 0.0 ? 0ull : (bq >= 4294967296.0 ? 4294967296ull : (unsigned long long)bq);
+        expert_drives = (unsigned long long)dagger_coin(C.seed, C.episode[b], (unsigned int)C.age_now) < thr;
+        const int cols = min(SP_COLS, N - c0);
+        // frame of x_t, this tile's columns / rows: features (6,N) from the (N,8) rows, label (2,N) from the expert's (N,2)
+        const float* xt = P.tap[0] + (size_t)b * P.ts[0];
+        float* ff = C.feat + (size_t)b * 6 * N;
+        for (int i = tid; i < 6 * SP_COLS; i += SP_THREADS) {
+            const int f = i >> 6, c = i & 63;
+            if (c < cols) ff[(size_t)f * N + c0 + c] = xt[(size_t)(c0 + c) * 8 + f];
+        }
+        const float* ex = C.expert + (size_t)b * N * 2;
+        float* lb = C.label + (size_t)b * 2 * N;
+        for (int i = tid; i < 2 * SP_COLS; i += SP_THREADS) {
+            const int a = i >> 6, c = i & 63;
+            if (c < cols) lb[(size_t)a * N + c0 + c] = ex[(size_t)(c0 + c) * 2 + a];
+        }
+        const unsigned long long* nr = C.net + (size_t)b * C.sNb + (size_t)c0 * NW;
+        unsigned long long* fb = C.bits + ((size_t)b * N + c0) * NW;
+        for (int i = tid; i < cols * NW; i += SP_THREADS) fb[i] = nr[i];
+        if (tid < cols) C.wrow[(size_t)b * N + c0 + tid] = C.wnet[(size_t)b * C.sWn + c0 + tid];
+        if (blockIdx.x == 0 && tid == 0) C.age[b] = C.age_now;
     }
     if (K >= 2) {                                              // last tap: its last factor is applied here
         const int c = tid >> 2, part = tid & 3, n = c0 + c;
@@ -158,8 +205,13 @@ void sp_policy_kernel(SpPolicy P, float* __restrict__ action, int K, int N, int 
     ux += dpp_f<0x4E>(ux); uy += dpp_f<0x4E>(uy);
     if (cg == 0 && c0 + ccol < N) {
         const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * 4 * RO_KS);
-        action[((size_t)b * 2 + 0) * N + c0 + ccol] = ux + bb.x;
-        action[((size_t)b * 2 + 1) * N + c0 + ccol] = uy + bb.y;
+        float ax = ux + bb.x, ay = uy + bb.y;
+        if (CL && expert_drives) {                             // gnn_dagger.py:157-161: the stored label drives the step
+            const float2 e2 = *reinterpret_cast<const float2*>(C.expert + ((size_t)b * N + c0 + ccol) * 2);
+            ax = e2.x; ay = e2.y;
+        }
+        action[((size_t)b * 2 + 0) * N + c0 + ccol] = ax;
+        action[((size_t)b * 2 + 1) * N + c0 + ccol] = ay;
     }
 }
 
@@ -287,9 +339,9 @@ extern "C" int mgp_sparse_policy_image(const float* const* W, const float* const
 /* One policy evaluation on the factored state: action (B,1,2,N) <- Actor(x_t .. x_{t-K+1}; A_t .. A_{t-K+2}).
  * cur = ring slot of x_t in feat (B,K,N,8); hs = ring slot of A_t in bits (B,H,N,NW) / wrow (B,H,N), H = max(K-1, 1).
  * scratch: 2 * (K-1) * B * N * 8 floats for K >= 3 (running products between stages), else unused. */
-extern "C" int mgp_sparse_policy_step(const unsigned long long* bits, const float* wrow, const float* feat,
-                                      const float* image, const int* dims, int n_layers, float* scratch, float* action,
-                                      int B, int K, int N, int cur, int hs, void* stream)
+static int sp_policy_step(const unsigned long long* bits, const float* wrow, const float* feat,
+                          const float* image, const int* dims, int n_layers, float* scratch, float* action,
+                          int B, int K, int N, int cur, int hs, const MgpSparseCollect* col, void* stream)
 {
     int woff[MGP_MAX_LAYERS], wtot = 0;
     int rc = sp_plan(dims, n_layers, K, woff, &wtot);
@@ -348,9 +400,41 @@ extern "C" int mgp_sparse_policy_step(const unsigned long long* bits, const floa
         else woffB |= (unsigned long long)woff[l] << (16 * (l - 4));
     }
     const size_t lds = ((size_t)SP_COLS * RO_CS + wtot) * sizeof(float);
-    hipLaunchKernelGGL(sp_policy_kernel, dim3(ntiles, B), dim3(SP_THREADS), lds, st, P, action, K, N, NW, dimsA, dims8,
-                       woffA, woffB, n_layers);
+    SpCollect C = {};
+    if (col != nullptr) {
+        const size_t fr = (size_t)col->ring_step * B;          // first frame of this ring step
+        C.feat = col->feat + fr * 6 * N; C.bits = col->bits + fr * N * NW; C.wrow = col->wrow + fr * N;
+        C.label = col->label + fr * 2 * N; C.age = col->age + fr;
+        C.net = bits + (size_t)hs * N * NW; C.sNb = sB; C.wnet = wrow + (size_t)hs * N; C.sWn = sW;
+        C.expert = col->expert; C.beta = col->beta; C.episode = col->episode; C.seed = col->seed; C.age_now = col->age_now;
+        hipLaunchKernelGGL(sp_policy_kernel<true>, dim3(ntiles, B), dim3(SP_THREADS), lds, st, P, action, K, N, NW, dimsA,
+                           dims8, woffA, woffB, n_layers, C);
+    } else {
+        hipLaunchKernelGGL(sp_policy_kernel<false>, dim3(ntiles, B), dim3(SP_THREADS), lds, st, P, action, K, N, NW, dimsA,
+                           dims8, woffA, woffB, n_layers, C);
+    }
     return mgp_launch_status();
+}
+
+extern "C" int mgp_sparse_policy_step(const unsigned long long* bits, const float* wrow, const float* feat,
+                                      const float* image, const int* dims, int n_layers, float* scratch, float* action,
+                                      int B, int K, int N, int cur, int hs, void* stream)
+{
+    return sp_policy_step(bits, wrow, feat, image, dims, n_layers, scratch, action, B, K, N, cur, hs, nullptr, stream);
+}
+
+/* The same evaluation as one collected DAGGER step (see SpCollect): files the frame of the current state at ring step
+ * col->ring_step and writes into `action` what drives the step -- the expert's action where the lane's coin says so. */
+extern "C" int mgp_sparse_policy_collect(const unsigned long long* bits, const float* wrow, const float* feat,
+                                         const float* image, const int* dims, int n_layers, float* scratch, float* action,
+                                         int B, int K, int N, int cur, int hs, const MgpSparseCollect* col, void* stream)
+{
+    if (col == nullptr) return MGP_EINVAL;
+    MGP_CHECK_PTR(col->feat); MGP_CHECK_PTR8(col->bits); MGP_CHECK_PTR(col->wrow); MGP_CHECK_PTR(col->label);
+    MGP_CHECK_PTR(col->age); MGP_CHECK_PTR(col->expert); MGP_CHECK_PTR(col->beta); MGP_CHECK_PTR(col->episode);
+    if (reinterpret_cast<uintptr_t>(col->expert) & 7u) return MGP_EALIGN;
+    if (col->ring_steps < 1 || col->ring_step < 0 || col->ring_step >= col->ring_steps || col->age_now < 0) return MGP_EINVAL;
+    return sp_policy_step(bits, wrow, feat, image, dims, n_layers, scratch, action, B, K, N, cur, hs, col, stream);
 }
 
 /* Dense delayed operator of the reference contract from the factored state: G (B,K,N,N) slices 1..K-1 (slice 0, the

@@ -55,7 +55,7 @@ class SparseFlockState(object):
         """Start at the simulator's current x as a freshly reset episode (no history)."""
         self.bits.zero_(); self.wrow.zero_(); self.feat.zero_()
         self.cur = self.hs = self.steps = 0
-        self._sim_call(sim, sim.x, sim._x_next, None, 0, 0, None, None)
+        self._sim_call(sim, sim.x, sim._x_next, None, 0, 0, None, sim.expert if sim.with_expert else None)
         self.owner = sim.x
 
     def step(self, sim, action):
@@ -89,11 +89,8 @@ def sparse_supported(actor, K, N):
     return actor.ind_agg == 0 and bool(_lib.lib().mgp_sparse_policy_supported(cd, len(dims) - 1, K, N))
 
 
-def sparse_policy_rollout(actor, sim, sp, T, rewards=None, action=None):
-    """T closed-loop policy steps on the factored state `sp` (SparseFlockState of `sim`).  rewards (B,T) fp64 and
-    action (B,1,2,N) as in `policy_rollout`.  K launches per step, nothing else on the device."""
+def _policy_image(actor, sim, K):
     L = _lib.lib()
-    K, B, N = sp.K, sp.B, sp.N
     dims = tuple(actor.layers)
     cd = (ctypes.c_int * len(dims))(*dims)
     nl = len(dims) - 1
@@ -102,6 +99,48 @@ def sparse_policy_rollout(actor, sim, sp, T, rewards=None, action=None):
     image = torch.empty((L.mgp_sparse_policy_image_floats(cd, nl, K),), device=sim.device, dtype=torch.float32)
     _lib.check(L.mgp_sparse_policy_image(_ptr_array(Ws), _ptr_array(bs), cd, nl, K, ops._ptr(image), ops._stream()),
                'mgp_sparse_policy_image')
+    return cd, nl, image
+
+
+def sparse_collect(actor, sim, sp, frames, beta, episode_ids, seed, age0, T, rewards=None):
+    """T DAGGER data-collection steps on the factored state (reference gnn_dagger.py:154-178 for every lane; the semantics
+    of mgp_rollout_collect for N > 256): every step files the state it starts from into `frames` (FrameReplay with .wrow)
+    at ring step frames.head, and is driven by the expert -- `sim.expert`, the by-product of the simulator kernel that
+    produced the current state -- where the lane's counter-based coin says so, else by the policy.  K launches per env step;
+    the weights are fixed for the call.  `sim` must be built with_expert; advances frames.head."""
+    L = _lib.lib()
+    K, B, N = sp.K, sp.B, sp.N
+    assert sim.with_expert and frames.wrow is not None and frames.lanes == B
+    assert beta.shape == (B,) and beta.dtype == torch.float32 and episode_ids.shape == (B,) and episode_ids.dtype == torch.int32
+    cd, nl, image = _policy_image(actor, sim, K)
+    act = torch.empty((B, 1, 2, N), device=sim.device, dtype=torch.float32)
+    rw = torch.empty((T, B), device=sim.device, dtype=torch.float64) if rewards is not None else None
+    keep = sim.reward
+    S = frames.ring_steps
+    for t in range(T):
+        cl = _lib.MgpSparseCollect(frames.feat.data_ptr(), frames.bits.data_ptr(), frames.wrow.data_ptr(),
+                                   frames.label.data_ptr(), frames.age.data_ptr(), sim.expert.data_ptr(), beta.data_ptr(),
+                                   episode_ids.data_ptr(), int(seed) & 0xFFFFFFFF, int(age0) + t, frames.head, S)
+        _lib.check(L.mgp_sparse_policy_collect(sp.bits.data_ptr(), ops._ptr(sp.wrow), ops._ptr(sp.feat), ops._ptr(image), cd, nl,
+                                               ops._ptr(sp.scratch), ops._ptr(act), B, K, N, sp.cur, sp.hs, ctypes.byref(cl),
+                                               ops._stream()), 'mgp_sparse_policy_collect')
+        if rw is not None:
+            sim.reward = rw[t]
+        sp.step(sim, act)
+        frames.advance(1)
+    sim.reward = keep
+    if rw is not None:
+        rewards.copy_(rw.t())
+        keep.copy_(rw[T - 1])
+    return True
+
+
+def sparse_policy_rollout(actor, sim, sp, T, rewards=None, action=None):
+    """T closed-loop policy steps on the factored state `sp` (SparseFlockState of `sim`).  rewards (B,T) fp64 and
+    action (B,1,2,N) as in `policy_rollout`.  K launches per step, nothing else on the device."""
+    L = _lib.lib()
+    K, B, N = sp.K, sp.B, sp.N
+    cd, nl, image = _policy_image(actor, sim, K)
     act = action if action is not None else torch.empty((B, 1, 2, N), device=sim.device, dtype=torch.float32)
     rw = torch.empty((T, B), device=sim.device, dtype=torch.float64) if rewards is not None else None
     keep = sim.reward

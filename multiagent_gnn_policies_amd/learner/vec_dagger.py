@@ -226,9 +226,13 @@ class FrameReplay(object):
         self.window_steps = max(1, (capacity + lanes - 1) // lanes)          # sampled window, in lock-step env steps
         self.ring_steps = self.window_steps + max(K - 1, 0)                  # + history guard
         S = self.ring_steps
-        self.nw = 2 if N <= 128 else 4                                       # 64-bit words per membership row
+        # 64-bit words per membership row: the collecting kernels' layouts (resident: 2 / 4; factored, N > 256: mgp_sparse_words)
+        from .. import _lib
+        self.nw = 2 if N <= 128 else (4 if N <= 256 else _lib.lib().mgp_sparse_words(N))
         self.feat = torch.zeros((S, lanes, 6, N), device=device, dtype=torch.float32)
         self.bits = torch.zeros((S, lanes, N, self.nw), device=device, dtype=torch.int64)
+        # N > 256 (mgp_sparse_policy_collect): the row weights travel with the frame (the gather works from HBM, row by row)
+        self.wrow = torch.zeros((S, lanes, N), device=device, dtype=torch.float32) if N > 256 else None
         self.label = torch.zeros((S, lanes, 2, N), device=device, dtype=torch.float32)
         self.age = torch.zeros((S, lanes), device=device, dtype=torch.int32)
         self.head = 0                 # ring step the next collected env step is filed at
@@ -245,7 +249,7 @@ class FrameReplay(object):
         return min(self.steps_written, self.window_steps) * self.lanes
 
     def bytes_per_transition(self):
-        return (6 * self.N + 2 * self.N) * 4 + self.N * 8 * self.nw + 4
+        return (6 * self.N + 2 * self.N) * 4 + self.N * 8 * self.nw + 4 + (4 * self.N if self.wrow is not None else 0)
 
     def advance(self, T):
         """The collecting launch filed T env steps starting at ring step `head`."""
@@ -441,8 +445,12 @@ def collect_supported(learner, K, N, params=None):
     from .. import ops
     if params is not None and not getattr(params, 'symmetric_network', True):
         return False
-    return (learner.actor.ind_agg == 0 and learner.n_states == 6 and N <= 256
-            and ops.rollout_supported(tuple(learner.actor.layers), K, N))
+    if learner.actor.ind_agg != 0 or learner.n_states != 6:
+        return False
+    if N > 256:                                                 # factored state in HBM: mgp_sparse_policy_collect, K launches per step
+        from .sparse_rollout import sparse_supported
+        return sparse_supported(learner.actor, K, N)
+    return ops.rollout_supported(tuple(learner.actor.layers), K, N)
 
 
 def collect_round(learner, sim, state, memory, beta, episode_ids, seed, T, chunk=None):
@@ -455,6 +463,18 @@ def collect_round(learner, sim, state, memory, beta, episode_ids, seed, T, chunk
     sim.reset(np.random)
     state.reset()
     state.push(sim.network, sim.features)                      # reset observation: all-zero operator history (carry)
+    if sim.N > 256:
+        # beyond the LDS-resident kernel: the same round on the factored state in HBM -- K launches per env step, the frame,
+        # the coin and the label inside the policy launch (mgp_sparse_policy_collect); still no host RNG, no per-step traffic
+        from .sparse_rollout import SparseFlockState, sparse_collect
+        sp = SparseFlockState(sim, state.K)
+        sp.observe_reset(sim)
+        sparse_collect(learner.actor, sim, sp, memory, beta, episode_ids, seed, 0, T)
+        sp.to_dense(sim, state)
+        state._pushes += T
+        sp.at_push = state._pushes
+        state._sparse = sp
+        return
     expert_io = sim.controller().permute(0, 2, 1).contiguous() # (B,2,N): the expert's action for the reset state
     ws, bs = _actor_params(learner.actor)
     image = ops.rollout_image(ws, bs, tuple(learner.actor.layers), state.K, sim.N)      # weights are fixed for the round
@@ -481,8 +501,10 @@ def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
 
     Where the collecting builds of the episode-resident kernels cover the shape (N <= 256: every N of the reference's
     sweeps) a round is ONE launch per GPU for the rollouts of all lanes -- no host RNG, no host<->device traffic
-    per step -- into a compact frame replay, and one HIP-graph replay per update.  Other shapes step the two-launch path from
-    the host and keep dense states in the replay (the round-1 loop)."""
+    per step -- into a compact frame replay, and one HIP-graph replay per update.  Larger flocks collect on the factored
+    state in HBM (K launches per env step, frame / coin / label inside the policy launch; frames of 160 KB at N = 1000 where
+    the dense pair is 12 MB).  Other shapes step the two-launch path from the host and keep dense states in the replay
+    (the round-1 loop)."""
     device = torch.device(device)
     p = _params_from_args(args)
     N, K, F, n_a = p.n_agents, args.getint('k'), args.getint('n_states'), args.getint('n_actions')

@@ -337,6 +337,13 @@ def replay_gather(frames, idx, X, G, Y, mean_pooling, cursor=None, nb=1):
     Bt = Bn // nb
     assert X.is_contiguous() and G.is_contiguous() and Y.is_contiguous() and G.shape == (Bn, K, N, N) and Y.numel() == Bn * 2 * N
     S, lanes = frames.feat.shape[0], frames.feat.shape[1]
+    if getattr(frames, 'wrow', None) is not None:               # frames of the factored path (N > 256): weights stored, NW words per row
+        assert frames.bits.shape[-1] == _lib.lib().mgp_sparse_words(N)
+        rc = _lib.lib().mgp_replay_gather_rows(_ptr(frames.feat), _ptr(frames.bits), _ptr(frames.wrow), _ptr(frames.label),
+                                               _ptr(frames.age), _ptr(idx), _ptr(cursor), Bt, nb, lanes, S, K, N, _ptr(X),
+                                               _ptr(G), _ptr(Y), _stream())
+        _lib.check(rc, 'mgp_replay_gather_rows')
+        return
     rc = _lib.lib().mgp_replay_gather_many(_ptr(frames.feat), _ptr(frames.bits), _ptr(frames.label), _ptr(frames.age), _ptr(idx),
                                            _ptr(cursor), Bt, nb, lanes, S, K, N, 1 if mean_pooling else 0, _ptr(X), _ptr(G),
                                            _ptr(Y), _stream())

@@ -201,3 +201,153 @@ def test_frame_updates_many_per_graph_equal_one_per_graph():
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert np.max(np.abs(outs[0][0] - outs[2][0])) <= 1e-5 and np.max(np.abs(outs[0][1] - outs[2][1])) <= 1e-5
     assert outs[0][0][-1] < outs[0][0][0]                         # and it learns
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 256: the same collection on the factored state in HBM (mgp_sparse_policy_collect, K launches per env step) and the
+# row-wise gather of its frames (mgp_replay_gather_rows)
+SPARSE_CASES = [(300, 3, (32, 32), {}), (1000, 3, (32, 32), {}), (300, 4, (32,), {'mean_pooling': False, 'n_leaders': 2}),
+                (320, 2, (16, 16), {'link_drop': 0.2, 'link_seed': 5}), (260, 1, (32,), {'centralized': False})]
+
+
+def _setup_sparse(N, K, hidden, B, variant, ring_capacity):
+    from multiagent_gnn_policies_amd.envs import VecFlock
+    from multiagent_gnn_policies_amd.learner.sparse_rollout import SparseFlockState
+    from multiagent_gnn_policies_amd.learner.vec_dagger import FrameReplay
+    rs, op, actor, sim0, st = _make(N, K, hidden, B, seed=5, **variant)
+    sim = VecFlock(B, sim0.p, 'cuda', with_expert=True)
+    sim.set_state(sim0.x.cpu().numpy())
+    st.reset(); st.push(sim.network, sim.features)
+    mem = FrameReplay(B, ring_capacity, K, N, torch.device('cuda'))
+    assert mem.wrow is not None and mem.nw % 8 == 0 and mem.nw * 64 >= N
+    sp = SparseFlockState(sim, K)
+    sp.observe_reset(sim)
+    return op, actor, sim, st, mem, sp
+
+
+@pytest.mark.parametrize('N,K,hidden,variant', SPARSE_CASES)
+def test_sparse_collect_single_steps_match_oracle(N, K, hidden, variant):
+    """Reference gnn_dagger.py:154-178 per lane, every step against the oracle: the frame (features, membership bits, row
+    weights, age), the label (FLOCK-SPEC section 5 on the state before the step), the coin (oracle/dagger_vec.py), the
+    expert-driven step bit-exact given the stored label, the policy-driven step against the oracle forward on the dense
+    state, and the network of the new state bit-exact."""
+    from multiagent_gnn_policies_amd.learner.sparse_rollout import sparse_collect
+    B, T, seed = 3, 6, 4321
+    op, actor, sim, st, mem, sp = _setup_sparse(N, K, hidden, B, variant, ring_capacity=B * T)
+    Ws, bs = _weights_np(actor)
+    beta_np = np.array([0.5, 0.8, 0.3], dtype=np.float32)
+    beta = torch.from_numpy(beta_np).cuda()
+    episode = torch.tensor([7, 1000, 123456], dtype=torch.int32, device='cuda')
+    n_expert = n_policy = 0
+    for t in range(T):
+        sp.to_dense(sim, st)
+        x0 = sim.x.cpu().numpy().copy()
+        G0 = st.delay_gso.cpu().numpy().copy(); X0 = st.delay_state.cpu().numpy().copy()
+        lab0 = sim.expert.cpu().numpy().copy()                               # (B,N,2)
+        ring_step = mem.head
+        sparse_collect(actor, sim, sp, mem, beta, episode, seed, t, 1)
+        assert mem.head == (ring_step + 1) % mem.ring_steps
+        x1 = sim.x.cpu().numpy()
+        pol = oa.forward(X0, G0, Ws, bs, 0, dtype=np.float64)               # (B,1,2,N)
+        for b in range(B):
+            h0 = ofl.helpers(x0[b], op)
+            assert np.array_equal(mem.feat[ring_step, b].cpu().numpy(), X0[b, 0])
+            assert int(mem.age[ring_step, b]) == t
+            assert np.array_equal(mem.label[ring_step, b].cpu().numpy(), lab0[b].T)
+            got_bits = _bits_dense(mem.bits[ring_step, b].cpu().numpy())
+            assert np.array_equal(got_bits, h0['network'] != 0), "membership bits of the frame's network"
+            w_ref = h0['network'].astype(np.float32).max(axis=1)
+            w_ref = np.where(w_ref == 0, np.float32(1.0), w_ref)             # isolated agents: weight 1 (1 / max(deg, 1))
+            assert np.array_equal(mem.wrow[ring_step, b].cpu().numpy(), w_ref)
+            lab_ref = ofl.controller(x0[b], op)
+            assert np.max(np.abs(lab0[b] - lab_ref) / np.maximum(1.0, np.abs(lab_ref))) <= 1e-6
+            drives = odv.expert_drives(seed, int(episode[b]), t, beta_np[b])
+            x_exp = ofl.integrate(x0[b], lab0[b].astype(np.float32), op)
+            x_pol = ofl.integrate(x0[b], pol[b, 0].T.astype(np.float32), op)
+            if drives:
+                assert np.array_equal(x1[b], x_exp), "expert-driven step: integration bit-exact given the stored label"
+                n_expert += 1
+            else:
+                assert np.max(np.abs(x1[b] - x_pol)) <= 2e-6 and np.max(np.abs(x1[b] - x_exp)) > 1e-5
+                n_policy += 1
+            net = ofl.helpers(x1[b], op)['network'].astype(np.float32)
+            from test_gpu_sparse import _bits_to_dense
+            got = _bits_to_dense(sp.bits[b, sp.hs].cpu().numpy(), sp.wrow[b, sp.hs].cpu().numpy(), N)
+            assert np.array_equal(got, net)
+    assert n_expert > 0 and n_policy > 0
+
+
+@pytest.mark.parametrize('N,K,hidden,variant', SPARSE_CASES[:1] + SPARSE_CASES[2:4])
+def test_sparse_collect_gather_rebuilds_the_states(N, K, hidden, variant):
+    """One call of T steps equals T one-step calls bit for bit (frames, state), and every stored transition's K-tap state
+    rebuilt from the ring (window shorter than the run: wraps; K - 1 guard steps) equals the dense state the factored path
+    materialises at that step: delay line and A_t exact, products 1e-6 (state_with_delay.py:44-53 on the stored history)."""
+    from multiagent_gnn_policies_amd import ops
+    from multiagent_gnn_policies_amd.learner.sparse_rollout import sparse_collect
+    B, T, seed = 3, 9, 99
+    beta = torch.tensor([0.5, 0.7, 0.2], device='cuda')
+    episode = torch.tensor([3, 4, 5], dtype=torch.int32, device='cuda')
+    runs = []
+    for chunks in ([T], [1] * T):
+        op, actor, sim, st, mem, sp = _setup_sparse(N, K, hidden, B, variant, ring_capacity=B * 6)
+        dense = []
+        t0 = 0
+        for c in chunks:
+            if c == 1:
+                sp.to_dense(sim, st)
+                dense.append((st.delay_state.cpu().numpy().copy(), st.delay_gso.cpu().numpy().copy()))
+            sparse_collect(actor, sim, sp, mem, beta, episode, seed, t0, c)
+            t0 += c
+        runs.append((sim.x.clone(), sp.bits.clone(), sp.wrow.clone(), sp.feat.clone(), sim.expert.clone(), mem.feat.clone(),
+                     mem.bits.clone(), mem.wrow.clone(), mem.label.clone(), mem.age.clone(), mem, dense))
+    for a, b_ in zip(runs[0][:10], runs[1][:10]):
+        assert torch.equal(a, b_)
+    mem, dense = runs[1][10], runs[1][11]
+    assert mem.curr_size == B * 6 and mem.bytes_per_transition() == 32 * N + 8 * mem.nw * N + 4 * N + 4
+    ids = [mem.frame_of(i) for i in range(mem.curr_size)]
+    idx = torch.tensor(ids, device='cuda', dtype=torch.long)
+    Bt = len(ids)
+    X = torch.empty((Bt, K, 6, N), device='cuda'); G = torch.empty((Bt, K, N, N), device='cuda')
+    Y = torch.empty((Bt, 1, 2, N), device='cuda')
+    ops.replay_gather(mem, idx, X, G, Y, op.mean_pooling)
+    Xn, Gn = X.cpu().numpy(), G.cpu().numpy()
+    for i in range(Bt):
+        t = T - 6 + i // B
+        b = i % B
+        Xd, Gd = dense[t]
+        assert int(mem.age.view(-1)[ids[i]]) == t
+        assert np.array_equal(Xn[i], Xd[b])
+        assert np.array_equal(Gn[i, 0], np.eye(N, dtype=np.float32))
+        if K > 1:
+            assert np.array_equal(Gn[i, 1], Gd[b, 1])            # A_t itself: exact
+        for j in range(2, K):
+            assert np.max(np.abs(Gn[i, j] - Gd[b, j])) <= 1e-6 * max(1.0, float(np.max(np.abs(Gd[b, j]))))
+            if t < j:
+                assert not Gn[i, j].any()
+    # two minibatches in one launch at a device-side cursor == two single gathers
+    idx2 = torch.tensor(ids[:4] + ids[7:11] + ids[2:6], device='cuda', dtype=torch.long)
+    cursor = torch.tensor([1], device='cuda', dtype=torch.int32)
+    X2 = torch.empty((8, K, 6, N), device='cuda'); G2 = torch.empty((8, K, N, N), device='cuda'); Y2 = torch.empty((8, 1, 2, N), device='cuda')
+    ops.replay_gather(mem, idx2, X2, G2, Y2, op.mean_pooling, cursor=cursor, nb=2)
+    sel = [7, 8, 9, 10, 2, 3, 4, 5]
+    assert torch.equal(X2, X[sel]) and torch.equal(G2, G[sel]) and torch.equal(Y2, Y[sel])
+
+
+def test_vectorised_dagger_collects_on_the_factored_state():
+    """train_dagger_vec at N = 300 (beyond the resident kernel): the rounds collect on the device (no host-stepped loop, no
+    dense replay), the updates run from the gathered frames, the losses are finite and the policy evaluation runs."""
+    import configparser
+    from multiagent_gnn_policies_amd.learner.vec_dagger import train_dagger_vec
+    cp = configparser.ConfigParser()
+    cp['DEFAULT'] = dict(env='FlockingRelative-v0', alg='dagger_vec', n_states='6', n_actions='2', k='3', hidden_size='32',
+                         gamma='0.99', tau='0.5', n_agents='300', comm_radius='1.0', v_max='3.0', actor_lr='5e-5',
+                         buffer_size='400', batch_size='8', updates_per_step='3', n_train_episodes='8', n_test_episodes='4',
+                         beta_coeff='0.993', seed='3', debug='False')
+    cp['t'] = {}
+    np.random.seed(3); torch.manual_seed(3)
+    import random
+    random.seed(3)
+    res = train_dagger_vec(cp['t'], 'cuda', n_envs=4, episode_steps=30)
+    assert res['collect'] == 'device' and res['updates'] == 2 * 3 * 4
+    assert res['replay_bytes_per_transition'] == 32 * 300 + 8 * 8 * 300 + 4 * 300 + 4
+    assert np.isfinite(res['mean']) and res['mean'] < 0
