@@ -438,6 +438,10 @@ int  mgp_sparse_policy_step(const unsigned long long* bits, const float* wrow, c
                             int B, int K, int N, int cur, int hs, void* stream);
 int  mgp_sparse_to_dense(const unsigned long long* bits, const float* wrow, float* G, int B, int K, int N, int hs,
                          void* stream);
+/* mgp_sparse_policy_step has two forms of its gather / policy launches: source rows staged in the LDS (default wherever an
+ * episode's rows fit: N <= ~2400) or gathered straight from global memory.  Test hook: on != 0 keeps the second form
+ * everywhere (process-wide); returns the previous setting. */
+int  mgp_sparse_force_direct(int on);
 /* DAGGER data collection on the factored state (reference gnn_dagger.py:154-178 per lane; the semantics of
  * mgp_rollout_collect for N > 256): mgp_sparse_policy_step that ALSO files the frame of the state the step starts from at
  * ring step `ring_step` of a ring laid out [ring_steps][B] -- features x_t (6,N), bit rows (N x mgp_sparse_words(N) u64) and

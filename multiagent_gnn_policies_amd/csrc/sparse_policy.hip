@@ -19,6 +19,13 @@
 
 namespace {
 
+#ifdef MGP_SP_PROFILE
+__device__ unsigned long long mgp_sp_stamps[2 * 16 * 16];  // [kernel][wave][stamp]
+#define SP_STAMP(k, i) do { if (blockIdx.x == 1 && blockIdx.y == 3 && (threadIdx.x & 63) == 0) mgp_sp_stamps[((k) * 16 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SP_STAMP(k, i) do { } while (0)
+#endif
+
 constexpr int SP_THREADS = 256;
 constexpr int SP_COLS = 64;               // agent columns per workgroup: 4 lanes per column / one 16-column MFMA tile per wave
 constexpr int SP_MAXTAPS = 4;             // K <= 5
@@ -215,6 +222,296 @@ void sp_policy_kernel(SpPolicy P, float* __restrict__ action, int K, int N, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-staged forms of the two kernels above: the default wherever an episode's source rows fit the LDS (N <= ~2400).
+// Measured on the direct forms (64 x 1000, K = 3): gather 10.5 us, policy tail 13.8 us for ~1 MB of useful reads -- every
+// neighbour entry is three lane-divergent global loads (weight, 16 + 8 bytes of the row), ~2.7 M cache-line lookups per
+// stage, and the L1's one-line-per-cycle tag rate is what the kernel waits for (requesting three entries of a word together
+// made it SLOWER: 2.4 x the lookups, 1.45 x the time).  Here a workgroup of 1024 threads owns 256 columns, copies the
+// episode's source rows and row weights into the LDS with coalesced 16-byte loads (68 KB for two taps at N = 1000) and gathers
+// from there: four lanes per column as before, no divergent global load left except the column's own bit words.
+constexpr int SPL_THREADS = 1024;
+constexpr int SPL_COLS = 256;             // columns per workgroup: 4 lanes per column, one 16-column MFMA tile per wave
+constexpr size_t SPL_LDS_MAX = 156 * 1024;
+
+// sum over the set bits m of `w` of lw[m] * ls[tap][m][0..5], all taps of the stage along one scan of the word
+template <int NT>
+__device__ __forceinline__ void spl_gather_word(unsigned long long w, int base, const float* lw, const float* ls, int N,
+                                                float (&sa)[NT][6])
+{
+    while (w) {
+        const int m = base + __builtin_ctzll(w);
+        w &= w - 1ull;
+        const float gv = lw[m];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float* r = ls + ((size_t)t * N + m) * 8;
+            const float4 x0 = *reinterpret_cast<const float4*>(r);
+            const float2 x1 = *reinterpret_cast<const float2*>(r + 4);
+            sa[t][0] = fmaf(x0.x, gv, sa[t][0]); sa[t][1] = fmaf(x0.y, gv, sa[t][1]); sa[t][2] = fmaf(x0.z, gv, sa[t][2]);
+            sa[t][3] = fmaf(x0.w, gv, sa[t][3]); sa[t][4] = fmaf(x1.x, gv, sa[t][4]); sa[t][5] = fmaf(x1.y, gv, sa[t][5]);
+        }
+    }
+}
+
+// the column's words of this lane (a quarter of the row): the first four from registers (requested before the staging
+// barrier; N <= 1024 has no more), the rest from global memory
+template <int NT>
+__device__ __forceinline__ void spl_gather_column(const unsigned long long (&wreg)[4], const unsigned long long* __restrict__ brow,
+                                                  int wpl, int word0, const float* lw, const float* ls, int N, bool live,
+                                                  float (&sa)[NT][6])
+{
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int f = 0; f < 6; ++f) sa[t][f] = 0.f;
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) spl_gather_word<NT>(wreg[q], 64 * (word0 + q), lw, ls, N, sa);
+        for (int q = 4; q < wpl; ++q) spl_gather_word<NT>(brow[q], 64 * (word0 + q), lw, ls, N, sa);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int f = 0; f < 6; ++f) { sa[t][f] += dpp_f<0xB1>(sa[t][f]); sa[t][f] += dpp_f<0x4E>(sa[t][f]); }
+}
+
+// grid: x = tile of 256 columns, y = b.  LDS: lw [Np] | ls [NT][N][8]
+template <int NT>
+__global__ __launch_bounds__(SPL_THREADS)
+void spl_gather_kernel(const unsigned long long* __restrict__ bits, long sBb, const float* __restrict__ wq, long sWb,
+                       SpTaps T, int N, int NW)
+{
+    extern __shared__ __attribute__((aligned(16))) float spm[];
+    const int Np = (N + 3) & ~3;
+    float* lw = spm;
+    float* ls = spm + Np;
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int n = blockIdx.x * SPL_COLS + (tid >> 2), part = tid & 3;
+    const bool live = n < N;
+    const int wpl = NW >> 2;                                   // words per lane (NW is a multiple of 8)
+    const unsigned long long* brow = bits + (size_t)b * sBb + (size_t)min(n, N - 1) * NW + part * wpl;
+    unsigned long long wreg[4];
+    SP_STAMP(0, 0);
+#ifdef MGP_SP_PROFILE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SP_STAMP(0, 5);
+#endif
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wreg[q] = (q < wpl) ? brow[q] : 0ull;
+    // every request of the copy is issued before the first LDS store (a copy loop is one memory round trip PER ITERATION:
+    // 8k cycles for five of them); N > 1024 finishes with plain loops
+    float4 rr[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float4* s4 = reinterpret_cast<const float4*>(T.src[t] + (size_t)b * T.ss[t]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = tid + q * SPL_THREADS;
+            rr[t][q] = (i < 2 * N) ? s4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float rw = (tid < N) ? wq[(size_t)b * sWb + tid] : 0.f;
+#ifdef MGP_SP_PROFILE
+    SP_STAMP(0, 6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SP_STAMP(0, 7);
+#endif
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float4* d4 = reinterpret_cast<float4*>(ls + (size_t)t * N * 8);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = tid + q * SPL_THREADS;
+            if (i < 2 * N) d4[i] = rr[t][q];
+        }
+        if (2 * N > 2 * SPL_THREADS) {
+            const float4* s4 = reinterpret_cast<const float4*>(T.src[t] + (size_t)b * T.ss[t]);
+            for (int i = tid + 2 * SPL_THREADS; i < 2 * N; i += SPL_THREADS) d4[i] = s4[i];
+        }
+    }
+    if (tid < N) lw[tid] = rw;
+    for (int i = tid + SPL_THREADS; i < N; i += SPL_THREADS) lw[i] = wq[(size_t)b * sWb + i];
+    SP_STAMP(0, 1);
+    __syncthreads();
+    SP_STAMP(0, 2);
+    float sa[NT][6];
+    spl_gather_column<NT>(wreg, brow, wpl, part * wpl, lw, ls, N, live, sa);
+    SP_STAMP(0, 3);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (live && part == (t & 3)) {
+            float* d = T.dst[t] + (size_t)b * T.ds[t] + (size_t)n * 8;
+            *reinterpret_cast<float4*>(d) = make_float4(sa[t][0], sa[t][1], sa[t][2], sa[t][3]);
+            *reinterpret_cast<float4*>(d + 4) = make_float4(sa[t][4], sa[t][5], 0.f, 0.f);
+        }
+    SP_STAMP(0, 4);
+}
+
+// grid: x = tile of 256 columns, y = b.  LDS: act [256][RO_CS] | weight image | lw [Np] | ls [N][8]
+template <bool CL>
+__global__ __launch_bounds__(SPL_THREADS)
+void spl_policy_kernel(SpPolicy P, float* __restrict__ action, int K, int N, int NW, unsigned long long dimsA,
+                       unsigned int dims8, unsigned long long woffA, unsigned long long woffB, int n_layers, SpCollect C)
+{
+    extern __shared__ __attribute__((aligned(16))) float spm[];
+    const int Np = (N + 3) & ~3, wt4 = (P.wtot + 3) & ~3;
+    float* act = spm;
+    float* wl = spm + SPL_COLS * RO_CS;
+    float* lw = wl + wt4;
+    float* ls = lw + Np;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
+    const int c0 = blockIdx.x * SPL_COLS;
+    const int FK = 6 * K;
+    const int gc = tid >> 2, part = tid & 3, gn = c0 + gc;
+    const int wpl = NW >> 2;
+    const unsigned long long* brow = P.bits + (size_t)b * P.sBb + (size_t)min(gn, N - 1) * NW + part * wpl;
+    unsigned long long wreg[4] = {0ull, 0ull, 0ull, 0ull};
+    SP_STAMP(1, 0);
+    if (K >= 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wreg[q] = (q < wpl) ? brow[q] : 0ull;
+    }
+    // every request is issued before the first LDS store of the copies (see spl_gather_kernel): the weight image, the input
+    // rows and weights of the last stage (every row of the episode), the finished taps of the own columns (tap 0 = x_t itself)
+    const int ntap = (K == 1) ? 1 : K - 1;
+    float4 rimg = make_float4(0.f, 0.f, 0.f, 0.f), rs[2] = {rimg, rimg};
+    float rw = 0.f, tv[2 * SP_MAXTAPS];
+    if (tid < wt4 / 4) rimg = reinterpret_cast<const float4*>(P.image)[tid];
+    if (K >= 2) {
+        const float4* s4 = reinterpret_cast<const float4*>(P.tap[K - 1] + (size_t)b * P.ts[K - 1]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) if (tid + q * SPL_THREADS < 2 * N) rs[q] = s4[tid + q * SPL_THREADS];
+        if (tid < N) rw = P.wq[(size_t)b * P.sWb + tid];
+    }
+#pragma unroll
+    for (int q = 0; q < 2 * SP_MAXTAPS; ++q) {                    // element e = j * 2048 + c * 8 + f of the finished taps
+        const int j = q >> 1, i = (tid + q * SPL_THREADS) & 2047, c = i >> 3, f = i & 7;
+        tv[q] = (j < ntap && f < 6 && c0 + c < N) ? P.tap[j][(size_t)b * P.ts[j] + (size_t)(c0 + c) * 8 + f] : 0.f;
+    }
+    {
+        float4* za = reinterpret_cast<float4*>(act);
+        for (int i = tid; i < SPL_COLS * RO_CS / 4; i += SPL_THREADS) za[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4* dst = reinterpret_cast<float4*>(wl);
+        if (tid < wt4 / 4) dst[tid] = rimg;
+        for (int i = tid + SPL_THREADS; i < wt4 / 4; i += SPL_THREADS) dst[i] = reinterpret_cast<const float4*>(P.image)[i];
+        if (K >= 2) {
+            const float4* s4 = reinterpret_cast<const float4*>(P.tap[K - 1] + (size_t)b * P.ts[K - 1]);
+            float4* d4 = reinterpret_cast<float4*>(ls);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) if (tid + q * SPL_THREADS < 2 * N) d4[tid + q * SPL_THREADS] = rs[q];
+            for (int i = tid + 2 * SPL_THREADS; i < 2 * N; i += SPL_THREADS) d4[i] = s4[i];
+            if (tid < N) lw[tid] = rw;
+            for (int i = tid + SPL_THREADS; i < N; i += SPL_THREADS) lw[i] = P.wq[(size_t)b * P.sWb + i];
+        }
+    }
+    SP_STAMP(1, 1);
+    __syncthreads();                                            // act is zero, the copies are complete
+    SP_STAMP(1, 2);
+    // channel (f, j) of column c -> MFMA B-fragment slot rpos(f K + j)
+#pragma unroll
+    for (int q = 0; q < 2 * SP_MAXTAPS; ++q) {
+        const int j = q >> 1, i = (tid + q * SPL_THREADS) & 2047, c = i >> 3, f = i & 7;
+        if (j < ntap && f < 6 && c0 + c < N) act[c * RO_CS + rpos(f * K + j)] = tv[q];
+    }
+    bool expert_drives = false;
+    if (CL) {
+        const double bq = floor((double)C.beta[b] * 4294967296.0);            // P(expert drives) in units of 2^-32
+        const unsigned long long thr = bq <= 0.0 ? 0ull : (bq >= 4294967296.0 ? 4294967296ull : (unsigned long long)bq);
+        expert_drives = (unsigned long long)dagger_coin(C.seed, C.episode[b], (unsigned int)C.age_now) < thr;
+        const int cols = min(SPL_COLS, N - c0);
+        const float* xt = P.tap[0] + (size_t)b * P.ts[0];
+        float* ff = C.feat + (size_t)b * 6 * N;
+        for (int i = tid; i < 6 * SPL_COLS; i += SPL_THREADS) {
+            const int f = i >> 8, c = i & 255;
+            if (c < cols) ff[(size_t)f * N + c0 + c] = xt[(size_t)(c0 + c) * 8 + f];
+        }
+        const float* ex = C.expert + (size_t)b * N * 2;
+        float* lb = C.label + (size_t)b * 2 * N;
+        for (int i = tid; i < 2 * SPL_COLS; i += SPL_THREADS) {
+            const int a = i >> 8, c = i & 255;
+            if (c < cols) lb[(size_t)a * N + c0 + c] = ex[(size_t)(c0 + c) * 2 + a];
+        }
+        const unsigned long long* nr = C.net + (size_t)b * C.sNb + (size_t)c0 * NW;
+        unsigned long long* fb = C.bits + ((size_t)b * N + c0) * NW;
+        for (int i = tid; i < cols * NW; i += SPL_THREADS) fb[i] = nr[i];
+        if (tid < cols) C.wrow[(size_t)b * N + c0 + tid] = C.wnet[(size_t)b * C.sWn + c0 + tid];
+        if (blockIdx.x == 0 && tid == 0) C.age[b] = C.age_now;
+    }
+    SP_STAMP(1, 3);
+    if (K >= 2) {                                              // last tap: its last factor is applied here
+        float sa[1][6];
+        spl_gather_column<1>(wreg, brow, wpl, part * wpl, lw, ls, N, gn < N, sa);
+        if (part == 0 && gn < N) {
+#pragma unroll
+            for (int f = 0; f < 6; ++f) act[gc * RO_CS + rpos(f * K + K - 1)] = sa[0][f];
+        }
+    }
+    SP_STAMP(1, 4);
+    __syncthreads();
+    SP_STAMP(1, 5);
+    if (c0 + wave * 16 >= N) return;                           // whole waves; no workgroup barrier below
+    // filter GEMM + tanh hidden layers: wave w owns columns 16 w .. 16 w + 15 (rollout.hip phase B)
+    const int li = lane & 15, lq = lane >> 4;
+    float* pcol = act + (wave * 16 + li) * RO_CS;
+    for (int l = 0; l < n_layers - 1; ++l) {
+        const int cin = (l == 0) ? FK : ((l < 8) ? (int)((dimsA >> (8 * l)) & 255ull) : (int)dims8);
+        const int cout = (l + 1 < 8) ? (int)((dimsA >> (8 * (l + 1))) & 255ull) : (int)dims8;
+        const int MT = mtiles(cout);
+        const float* wfrag = wl + (int)((((l < 4) ? woffA : woffB) >> (16 * (l & 3))) & 0xFFFFull);
+        if (MT == 2) ro_mlp_cols<2>(pcol, wfrag + lane * RO_WFS, wfrag + 2 * 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
+        else ro_mlp_cols<1>(pcol, wfrag + lane * RO_WFS, wfrag + 64 * RO_WFS + lq * 4, pad4(cin) / 4, lq);
+    }
+    SP_STAMP(1, 6);
+    // 2-wide output layer: lane L takes column L >> 2 of the wave's tile and 8 channels, quad sum by DPP (phase C)
+    const int lo_ = n_layers - 1;
+    const float* w2 = wl + (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull);
+    const int ccol = wave * 16 + (lane >> 2), cg = lane & 3;
+    const float* zsrc = act + ccol * RO_CS + cg * RO_KS;
+    const float4 z0 = *reinterpret_cast<const float4*>(zsrc);
+    const float4 z1 = *reinterpret_cast<const float4*>(zsrc + 4);
+    const float zc[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+    f32x2 u2 = {0.f, 0.f}, u2b = {0.f, 0.f};
+#pragma unroll
+    for (int s_ = 0; s_ < RO_KS; s_ += 2) {
+        const float2 wa = *reinterpret_cast<const float2*>(w2 + 2 * (4 * s_ + cg));
+        const float2 wb = *reinterpret_cast<const float2*>(w2 + 2 * (4 * (s_ + 1) + cg));
+        u2 = __builtin_elementwise_fma((f32x2){zc[s_], zc[s_]}, (f32x2){wa.x, wa.y}, u2);
+        u2b = __builtin_elementwise_fma((f32x2){zc[s_ + 1], zc[s_ + 1]}, (f32x2){wb.x, wb.y}, u2b);
+    }
+    u2 = u2 + u2b;
+    float ux = u2.x, uy = u2.y;
+    ux += dpp_f<0xB1>(ux); uy += dpp_f<0xB1>(uy);
+    ux += dpp_f<0x4E>(ux); uy += dpp_f<0x4E>(uy);
+    if (cg == 0 && c0 + ccol < N) {
+        const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * 4 * RO_KS);
+        float ax = ux + bb.x, ay = uy + bb.y;
+        if (CL && expert_drives) {                             // gnn_dagger.py:157-161: the stored label drives the step
+            const float2 e2 = *reinterpret_cast<const float2*>(C.expert + ((size_t)b * N + c0 + ccol) * 2);
+            ax = e2.x; ay = e2.y;
+        }
+        action[((size_t)b * 2 + 0) * N + c0 + ccol] = ax;
+        action[((size_t)b * 2 + 1) * N + c0 + ccol] = ay;
+    }
+    SP_STAMP(1, 7);
+}
+
+// dynamic LDS of a staged kernel, raised once per kernel (hipFuncSetAttribute is a driver call)
+template <typename F>
+int spl_allow_lds(F* fn, size_t lds)
+{
+    static thread_local const void* done[16];
+    static thread_local size_t done_lds[16];
+    const void* key = reinterpret_cast<const void*>(fn);
+    for (int i = 0; i < 16; ++i)
+        if (done[i] == key && done_lds[i] >= lds) return MGP_OK;
+    if (lds > 48 * 1024 && hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return MGP_ELAUNCH;
+    for (int i = 0; i < 16; ++i)
+        if (done[i] == nullptr || done[i] == key) { done[i] = key; done_lds[i] = lds; break; }
+    return MGP_OK;
+}
+
 struct SpWeights {
     const float* W[MGP_MAX_LAYERS];
     const float* b[MGP_MAX_LAYERS];
@@ -285,6 +582,8 @@ void sp_to_dense_kernel(const unsigned long long* __restrict__ bits, const float
         float* t = r0; r0 = r1; r1 = t;
     }
 }
+
+bool sp_force_direct = false;             // mgp_sparse_force_direct (tests: both forms against the oracle)
 
 int sp_plan(const int* dims, int n_layers, int K, int* woff, int* wtot)
 {
@@ -360,6 +659,7 @@ static int sp_policy_step(const unsigned long long* bits, const float* wrow, con
     // running products of taps j >= 1 between stages: V[pp][j-1], each (B, N, 8)
     auto vbuf = [&](int pp, int j) { return scratch + ((size_t)pp * (K - 1) + (j - 1)) * (size_t)B * N * 8; };
     const int ntiles = mgp_ceil_div(N, SP_COLS);
+    const int Np = (N + 3) & ~3;
     mgp_clear_error();
     SpPolicy P = {};
     P.tap[0] = fslot(0); P.ts[0] = sF;
@@ -372,8 +672,25 @@ static int sp_policy_step(const unsigned long long* bits, const float* wrow, con
             T.dst[nt] = vbuf(q & 1, j); T.ds[nt] = sV;         // tap q's product is finished here: the tail reads it from there
         }
         const int s = hslot(q);
-        hipLaunchKernelGGL(sp_gather_kernel, dim3(ntiles, nt, B), dim3(SP_THREADS), 0, st, bits + (size_t)s * N * NW, sB,
-                           wrow + (size_t)s * N, sW, T, N, NW);
+        const size_t glds = ((size_t)Np + (size_t)nt * N * 8) * sizeof(float);
+        if (!sp_force_direct && glds <= SPL_LDS_MAX) {             // staged form: source rows of all taps of the stage in LDS
+            const dim3 gg(mgp_ceil_div(N, SPL_COLS), B), gb(SPL_THREADS);
+            const unsigned long long* bq = bits + (size_t)s * N * NW;
+            const float* wq_ = wrow + (size_t)s * N;
+            switch (nt) {
+            case 1: rc = spl_allow_lds(spl_gather_kernel<1>, glds); if (rc) return rc;
+                    hipLaunchKernelGGL(spl_gather_kernel<1>, gg, gb, glds, st, bq, sB, wq_, sW, T, N, NW); break;
+            case 2: rc = spl_allow_lds(spl_gather_kernel<2>, glds); if (rc) return rc;
+                    hipLaunchKernelGGL(spl_gather_kernel<2>, gg, gb, glds, st, bq, sB, wq_, sW, T, N, NW); break;
+            case 3: rc = spl_allow_lds(spl_gather_kernel<3>, glds); if (rc) return rc;
+                    hipLaunchKernelGGL(spl_gather_kernel<3>, gg, gb, glds, st, bq, sB, wq_, sW, T, N, NW); break;
+            default: rc = spl_allow_lds(spl_gather_kernel<4>, glds); if (rc) return rc;
+                    hipLaunchKernelGGL(spl_gather_kernel<4>, gg, gb, glds, st, bq, sB, wq_, sW, T, N, NW); break;
+            }
+        } else {
+            hipLaunchKernelGGL(sp_gather_kernel, dim3(ntiles, nt, B), dim3(SP_THREADS), 0, st, bits + (size_t)s * N * NW, sB,
+                               wrow + (size_t)s * N, sW, T, N, NW);
+        }
         rc = mgp_launch_status();
         if (rc != MGP_OK) return rc;
         P.tap[q] = vbuf(q & 1, q); P.ts[q] = sV;
@@ -400,6 +717,9 @@ static int sp_policy_step(const unsigned long long* bits, const float* wrow, con
         else woffB |= (unsigned long long)woff[l] << (16 * (l - 4));
     }
     const size_t lds = ((size_t)SP_COLS * RO_CS + wtot) * sizeof(float);
+    const size_t plds = ((size_t)SPL_COLS * RO_CS + ((wtot + 3) & ~3) + (K >= 2 ? (size_t)Np + (size_t)N * 8 : 0)) * sizeof(float);
+    const bool staged = !sp_force_direct && plds <= SPL_LDS_MAX;
+    const dim3 pg(mgp_ceil_div(N, SPL_COLS), B);
     SpCollect C = {};
     if (col != nullptr) {
         const size_t fr = (size_t)col->ring_step * B;          // first frame of this ring step
@@ -407,13 +727,31 @@ static int sp_policy_step(const unsigned long long* bits, const float* wrow, con
         C.label = col->label + fr * 2 * N; C.age = col->age + fr;
         C.net = bits + (size_t)hs * N * NW; C.sNb = sB; C.wnet = wrow + (size_t)hs * N; C.sWn = sW;
         C.expert = col->expert; C.beta = col->beta; C.episode = col->episode; C.seed = col->seed; C.age_now = col->age_now;
-        hipLaunchKernelGGL(sp_policy_kernel<true>, dim3(ntiles, B), dim3(SP_THREADS), lds, st, P, action, K, N, NW, dimsA,
-                           dims8, woffA, woffB, n_layers, C);
+        if (staged) {
+            rc = spl_allow_lds(spl_policy_kernel<true>, plds); if (rc) return rc;
+            hipLaunchKernelGGL(spl_policy_kernel<true>, pg, dim3(SPL_THREADS), plds, st, P, action, K, N, NW, dimsA, dims8, woffA,
+                               woffB, n_layers, C);
+        } else {
+            hipLaunchKernelGGL(sp_policy_kernel<true>, dim3(ntiles, B), dim3(SP_THREADS), lds, st, P, action, K, N, NW, dimsA,
+                               dims8, woffA, woffB, n_layers, C);
+        }
+    } else if (staged) {
+        rc = spl_allow_lds(spl_policy_kernel<false>, plds); if (rc) return rc;
+        hipLaunchKernelGGL(spl_policy_kernel<false>, pg, dim3(SPL_THREADS), plds, st, P, action, K, N, NW, dimsA, dims8, woffA,
+                           woffB, n_layers, C);
     } else {
         hipLaunchKernelGGL(sp_policy_kernel<false>, dim3(ntiles, B), dim3(SP_THREADS), lds, st, P, action, K, N, NW, dimsA,
                            dims8, woffA, woffB, n_layers, C);
     }
     return mgp_launch_status();
+}
+
+/* Test hook: 1 = keep the direct (global-memory) gather / policy kernels even where the staged forms fit; returns the old value. */
+extern "C" int mgp_sparse_force_direct(int on)
+{
+    const int old = sp_force_direct ? 1 : 0;
+    sp_force_direct = on != 0;
+    return old;
 }
 
 extern "C" int mgp_sparse_policy_step(const unsigned long long* bits, const float* wrow, const float* feat,

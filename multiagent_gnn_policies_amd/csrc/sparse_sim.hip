@@ -5,34 +5,57 @@
 // cell members in ascending index order so that every sum has a fixed order), and a row only visits the 3 x 3 cells around
 // its own: the membership test r2 < R^2 is still the spec's own fp64 expression on every candidate, so the bit rows are
 // the all-pairs kernel's (and the oracle's) bit rows exactly; only the order of the fp64 feature sums differs (1e-16
-// relative; the tests allow 1e-11).  The cell width is chosen per episode and step as extent / g with g = min(64,
-// floor(extent / (R (1 + 1e-9)))) >= 1, i.e. never below R: a spread-out flock gets 64 x 64 cells, a collapsed one
-// degenerates gracefully to all pairs.
+// relative; the tests allow 1e-11).  The cell width is chosen per episode and step as extent / g with g = min(32,
+// floor(extent / (R (1 + 1e-9)))) >= 1, i.e. never below R: a spread-out flock gets 32 x 32 cells (about one agent per cell
+// at the N <= 2048 this kernel covers), a collapsed one degenerates gracefully to all pairs.
+//
+// [r3] One workgroup = 1024 threads = 256 rows x FOUR lanes per row (round 2: 256 threads, one per row, one wave per SIMD:
+// 53k cycles per launch at 64 x 1000 -- 8k loading the episode in four dependent round trips, 5.6k in six block reductions
+// one after the other, 7k in a per-cell insertion sort, 19-21k in the row search, 5k copying the bit rows out with an integer
+// division per word).  Now: every request of the load phase is issued before the first use; ONE block reduction of six
+// values; members ranked inside their cell in parallel (rank = members with a smaller index) instead of sorted serially; the
+// row search splits a row's candidates over its four lanes (partial fp64 sums added in a fixed order by DPP); bit words
+// are OR-ed into the LDS row by LDS atomics and leave as 32 contiguous bytes per lane.
 // Outputs are those of mgp_flock_step_sparse: bit rows, row weights, (N, 8) feature rows, reward, expert action.
 // Built with -ffp-contract=off (fp64 spec arithmetic).
 #include <math.h>
 #include "mgp_common.h"
 #include "mgp_device.h"
+#include "rollout_common.h"
 
 namespace {
 
-constexpr int SS_THREADS = 256;            // = rows per workgroup
-constexpr int SS_WAVES = SS_THREADS / 64;
-constexpr int SS_G = 64;                   // cells per axis, at most
-constexpr int SS_MAXN = 2048;              // LDS plan: 32 B of state + 4 B of lists per agent, NW + 1 words of bits per row
+#ifdef MGP_SP_PROFILE
+__device__ unsigned long long mgp_ss_stamps[16 * 16];     // [wave][stamp]
+#define SS_STAMP(i) do { if (blockIdx.x == 1 && blockIdx.y == 3 && (threadIdx.x & 63) == 0) mgp_ss_stamps[(threadIdx.x >> 6) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SS_STAMP(i) do { } while (0)
+#endif
 
-template <typename T, typename OP>
-__device__ __forceinline__ T ss_block_reduce(T v, T* sh /* [SS_WAVES] */, OP op)
+constexpr int SS_THREADS = 1024;
+constexpr int SS_WAVES = SS_THREADS / 64;
+constexpr int SS_ROWS = SS_THREADS / 4;    // rows per workgroup: four lanes per row
+constexpr int SS_G = 32;                   // cells per axis, at most
+constexpr int SS_MAXN = 2048;              // two agents per thread in the load phase; LDS plan 154 KB at N = 2048
+
+__device__ __forceinline__ double ss_first_lane(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = op(v, __shfl_xor(v, off, MGP_WAVE));
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    T t = sh[0];
-#pragma unroll
-    for (int w = 1; w < SS_WAVES; ++w) t = op(t, sh[w]);
-    return t;
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)b);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(b >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// inclusive prefix sum over the wave on the DPP path (row_shr 1, 2, 4, 8 inside rows of 16, then row_bcast15 / row_bcast31)
+__device__ __forceinline__ int ss_wave_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);     // row_shr:1 (zeros shift in)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast31 -> rows 2, 3
+    return v;
 }
 
 struct SsOut {
@@ -41,137 +64,211 @@ struct SsOut {
 };
 
 // grid: x = tile of 256 rows, y = b.
-// LDS: px, py, vx, vy [N] f64 | start [G*G + 1] int | cid [N] u16 | sorted [N] u16 | rowbits [256][NW + 1] u64
+// LDS: px, py, vx, vy [N] f64 | start [G*G + 2] int | cursor [G*G] int | cid, tmp, sorted [N4] u16 | rowbits [256][NW + 1] u64
 template <bool FD>
 __global__ __launch_bounds__(SS_THREADS)
 void sp_sim_kernel(const double* __restrict__ x, double* __restrict__ xo, const float* __restrict__ u, long su_agent,
                    long su_axis, SsOut o, MgpFlockParams p, int N, int NW)
 {
     extern __shared__ __attribute__((aligned(16))) double ssm[];
-    __shared__ double shd[SS_WAVES];
+    __shared__ double red[SS_WAVES][2];
+    __shared__ float4 redf[SS_WAVES];
+    __shared__ double red2[SS_WAVES];
     __shared__ int shi[SS_WAVES];
+    const int N4 = (N + 3) & ~3;
     double* spx = ssm; double* spy = ssm + N; double* svx = ssm + 2 * (size_t)N; double* svy = ssm + 3 * (size_t)N;
-    int* start = reinterpret_cast<int*>(ssm + 4 * (size_t)N);                   // [G*G + 1] cell -> first entry of `sorted`
-    unsigned short* cid = reinterpret_cast<unsigned short*>(start + SS_G * SS_G + 1 + 1);
-    unsigned short* sorted = cid + ((N + 3) & ~3);
+    int* start = reinterpret_cast<int*>(ssm + 4 * (size_t)N);                   // [G*G + 2] cell -> first entry of `sorted`
+    int* cursor = start + SS_G * SS_G + 2;                                      // [G*G] running fill of each cell
+    unsigned short* cid = reinterpret_cast<unsigned short*>(cursor + SS_G * SS_G);
+    unsigned short* tmp = cid + N4;                                             // cell members in arrival order
+    unsigned short* sorted = tmp + N4;                                          // ... in ascending index order
     unsigned long long* rowbits = reinterpret_cast<unsigned long long*>(
-        (reinterpret_cast<uintptr_t>(sorted + ((N + 3) & ~3)) + 7) & ~(uintptr_t)7);
-    const int tid = threadIdx.x, b = blockIdx.y;
-    const int i0 = blockIdx.x * SS_THREADS;
+        (reinterpret_cast<uintptr_t>(sorted + N4) + 7) & ~(uintptr_t)7);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
+    const int i0 = blockIdx.x * SS_ROWS;
+    const int RSW = NW + 1;                                   // odd word stride per row
     const double* xb = x + (size_t)b * N * 4;
     double* xob = xo + (size_t)b * N * 4;
 
-    // ---- every agent of the episode -> LDS, integrated (spec section 1) when an action is given; own rows -> x_out
-    double sum_vx = 0.0, sum_vy = 0.0, mnx = 1e300, mxx = -1e300, mny = 1e300, mxy = -1e300;
-    for (int i = tid; i < N; i += SS_THREADS) {
-        double px = xb[i * 4 + 0], py = xb[i * 4 + 1], vx = xb[i * 4 + 2], vy = xb[i * 4 + 3];
-        if (u != nullptr) {
-            integrate_one(px, py, vx, vy, u + (size_t)b * N * 2 + (size_t)i * su_agent, su_axis, i < p.n_leaders, p);
-            if (i >= i0 && i < i0 + SS_THREADS) {
-                xob[i * 4 + 0] = px; xob[i * 4 + 1] = py; xob[i * 4 + 2] = vx; xob[i * 4 + 3] = vy;
-            }
+    SS_STAMP(0);
+    // ---- every agent of the episode -> LDS, integrated (spec section 1) when an action is given; own rows -> x_out.
+    // Two agents per thread at most (N <= 2048); every request is issued before the first use.
+    double2 a01[2], a23[2];
+    float aux[2], auy[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = tid + q * SS_THREADS;
+        const bool in = i < N;
+        a01[q] = in ? *reinterpret_cast<const double2*>(xb + (size_t)i * 4) : make_double2(0.0, 0.0);
+        a23[q] = in ? *reinterpret_cast<const double2*>(xb + (size_t)i * 4 + 2) : make_double2(0.0, 0.0);
+        aux[q] = auy[q] = 0.f;
+        if (u != nullptr && in && i >= p.n_leaders) {
+            const float* ub = u + (size_t)b * N * 2 + (size_t)i * su_agent;
+            aux[q] = ub[0]; auy[q] = ub[su_axis];
         }
-        spx[i] = px; spy[i] = py; svx[i] = vx; svy[i] = vy;
-        sum_vx += vx; sum_vy += vy;
-        mnx = fmin(mnx, px); mxx = fmax(mxx, px); mny = fmin(mny, py); mxy = fmax(mxy, py);
     }
-    for (int c = tid; c <= SS_G * SS_G; c += SS_THREADS) start[c] = 0;
-    auto add = [](double a, double c) { return a + c; };
-    auto mn = [](double a, double c) { return fmin(a, c); };
-    auto mx = [](double a, double c) { return fmax(a, c); };
-    const double tot_vx = ss_block_reduce(sum_vx, shd, add);
-    const double tot_vy = ss_block_reduce(sum_vy, shd, add);
-    mnx = ss_block_reduce(mnx, shd, mn); mxx = ss_block_reduce(mxx, shd, mx);
-    mny = ss_block_reduce(mny, shd, mn); mxy = ss_block_reduce(mxy, shd, mx);
-    if (o.reward != nullptr && blockIdx.x == 0) {           // spec section 4: population variance, two passes
+    for (int c = tid; c < SS_G * SS_G + 2; c += SS_THREADS) start[c] = 0;
+    for (int e = tid; e < SS_ROWS * RSW; e += SS_THREADS) rowbits[e] = 0ull;
+    // bounding box in fp32 (minima negated: one kind of reduction for all four), widened below: the cell grid is private to
+    // this workgroup and only has to CONTAIN every agent -- the membership test stays the spec's fp64 expression
+    double sum_vx = 0.0, sum_vy = 0.0;
+    float bnx = -3e38f, bxx = -3e38f, bny = -3e38f, bxy = -3e38f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = tid + q * SS_THREADS;
+        if (i < N) {
+            double px = a01[q].x, py = a01[q].y, vx = a23[q].x, vy = a23[q].y;
+            if (u != nullptr) {                               // spec section 1 (integrate_one, the action already in registers)
+                const double ux = clipd((double)aux[q], -p.max_accel, p.max_accel) * p.action_gain;
+                const double uy = clipd((double)auy[q], -p.max_accel, p.max_accel) * p.action_gain;
+                px = (px + vx * p.dt) + ((ux * p.dt) * p.dt) * 0.5;
+                py = (py + vy * p.dt) + ((uy * p.dt) * p.dt) * 0.5;
+                vx = vx + ux * p.dt;
+                vy = vy + uy * p.dt;
+                if (i >= i0 && i < i0 + SS_ROWS) {
+                    *reinterpret_cast<double2*>(xob + (size_t)i * 4) = make_double2(px, py);
+                    *reinterpret_cast<double2*>(xob + (size_t)i * 4 + 2) = make_double2(vx, vy);
+                }
+            }
+            spx[i] = px; spy[i] = py; svx[i] = vx; svy[i] = vy;
+            sum_vx += vx; sum_vy += vy;
+            bnx = fmaxf(bnx, -(float)px); bxx = fmaxf(bxx, (float)px); bny = fmaxf(bny, -(float)py); bxy = fmaxf(bxy, (float)py);
+        }
+    }
+    SS_STAMP(1);
+    // ---- one block reduction of the six values (fixed order: lanes by DPP, then the sixteen wave partials over a DPP row)
+    {
+        const double s0 = wave_sum_d(sum_vx), s1 = wave_sum_d(sum_vy);
+        const float m0 = wave_max_to_last(bnx), m1 = wave_max_to_last(bxx), m2 = wave_max_to_last(bny), m3 = wave_max_to_last(bxy);
+        if (lane == 63) { red[wave][0] = s0; red[wave][1] = s1; redf[wave] = make_float4(m0, m1, m2, m3); }
+    }
+    __syncthreads();
+    double tot_vx, tot_vy, mnx, mxx, mny, mxy;
+    {
+        const int wl = lane & 15;
+        double t0 = red[wl][0], t1 = red[wl][1];
+        float4 m = redf[wl];
+        t0 += dpp_d<0xB1>(t0); t0 += dpp_d<0x4E>(t0); t0 += dpp_d<0x141>(t0); t0 += dpp_d<0x140>(t0);
+        t1 += dpp_d<0xB1>(t1); t1 += dpp_d<0x4E>(t1); t1 += dpp_d<0x141>(t1); t1 += dpp_d<0x140>(t1);
+        m.x = fmaxf(m.x, dpp_f<0xB1>(m.x)); m.x = fmaxf(m.x, dpp_f<0x4E>(m.x)); m.x = fmaxf(m.x, dpp_f<0x141>(m.x)); m.x = fmaxf(m.x, dpp_f<0x140>(m.x));
+        m.y = fmaxf(m.y, dpp_f<0xB1>(m.y)); m.y = fmaxf(m.y, dpp_f<0x4E>(m.y)); m.y = fmaxf(m.y, dpp_f<0x141>(m.y)); m.y = fmaxf(m.y, dpp_f<0x140>(m.y));
+        m.z = fmaxf(m.z, dpp_f<0xB1>(m.z)); m.z = fmaxf(m.z, dpp_f<0x4E>(m.z)); m.z = fmaxf(m.z, dpp_f<0x141>(m.z)); m.z = fmaxf(m.z, dpp_f<0x140>(m.z));
+        m.w = fmaxf(m.w, dpp_f<0xB1>(m.w)); m.w = fmaxf(m.w, dpp_f<0x4E>(m.w)); m.w = fmaxf(m.w, dpp_f<0x141>(m.w)); m.w = fmaxf(m.w, dpp_f<0x140>(m.w));
+        tot_vx = ss_first_lane(t0); tot_vy = ss_first_lane(t1);
+        const float nx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m.x)));
+        const float xx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m.y)));
+        const float ny = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m.z)));
+        const float xy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m.w)));
+        // widened by more than the fp32 rounding of the conversions: every fp64 position lies inside
+        mnx = -((double)nx + 2.4e-7 * fabs((double)nx) + 1e-30); mxx = (double)xx + 2.4e-7 * fabs((double)xx) + 1e-30;
+        mny = -((double)ny + 2.4e-7 * fabs((double)ny) + 1e-30); mxy = (double)xy + 2.4e-7 * fabs((double)xy) + 1e-30;
+    }
+    SS_STAMP(2);
+    const bool does_reward = o.reward != nullptr && blockIdx.x == 0;
+    if (does_reward) {                                        // spec section 4: population variance, two passes
         const double mvx = tot_vx / (double)N, mvy = tot_vy / (double)N;
         double dv = 0.0;
-        for (int i = tid; i < N; i += SS_THREADS) {
-            const double ex = svx[i] - mvx, ey = svy[i] - mvy;
-            dv += ex * ex + ey * ey;
-        }
-        const double var = ss_block_reduce(dv, shd, add) / (double)N;
-        if (tid == 0) o.reward[b] = -1.0 * var * p.reward_scale;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (tid + q * SS_THREADS < N) {
+                const double ex = svx[tid + q * SS_THREADS] - mvx, ey = svy[tid + q * SS_THREADS] - mvy;
+                dv += ex * ex + ey * ey;
+            }
+        dv = wave_sum_d(dv);
+        if (lane == 0) red2[wave] = dv;                       // summed by thread 0 after the next barrier
     }
-    // ---- cell grid: width >= R (1 + 1e-9) on each axis, at most 64 x 64 cells
+    SS_STAMP(3);
+    // ---- cell grid: width >= R (1 + 1e-9) on each axis, at most 32 x 32 cells
     const double R = sqrt(p.comm_radius2) * (1.0 + 1e-9);
     const double ex_ = mxx - mnx, ey_ = mxy - mny;
     const int gx = max(1, (int)fmin((double)SS_G, floor(ex_ / R)));
     const int gy = max(1, (int)fmin((double)SS_G, floor(ey_ / R)));
     const double iwx = (ex_ > 0.0) ? (double)gx / ex_ : 0.0, iwy = (ey_ > 0.0) ? (double)gy / ey_ : 0.0;
     // NaN positions (a diverged episode) land in cell 0: every index stays valid, the outputs are garbage as they would be
-    for (int i = tid; i < N; i += SS_THREADS) {
-        int cx = (int)((spx[i] - mnx) * iwx), cy = (int)((spy[i] - mny) * iwy);
-        cx = min(max(cx, 0), gx - 1); cy = min(max(cy, 0), gy - 1);
-        const int c = cy * gx + cx;
-        cid[i] = (unsigned short)c;
-        atomicAdd(&start[c + 1], 1);                        // histogram, shifted by one: the scan below turns it into starts
-    }
-    __syncthreads();
-    // ---- inclusive scan of the counts (16 cells per thread, then across threads)
-    const int ncell = gx * gy;
-    {
-        int loc[16], run = 0;
+    int myc[2];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { const int c = tid * 16 + q + 1; loc[q] = (c <= ncell) ? start[c] : 0; run += loc[q]; }
-        // exclusive prefix of `run` over the 256 threads
-        int inc = run;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off, MGP_WAVE); if ((tid & 63) >= off) inc += t; }
-        if ((tid & 63) == 63) shi[tid >> 6] = inc;
-        __syncthreads();
-        int base = 0;
-        for (int w = 0; w < (tid >> 6); ++w) base += shi[w];
-        int acc = base + inc - run;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { const int c = tid * 16 + q + 1; acc += loc[q]; if (c <= ncell) start[c] = acc; }
-    }
-    __syncthreads();
-    // ---- scatter by cell (arrival order), then every cell's members into ascending index order (fixed summation order)
-    {
-        int* cursor = reinterpret_cast<int*>(rowbits);       // [ncell] running fill of each cell (rowbits is not live yet)
-        for (int c = tid; c < ncell; c += SS_THREADS) cursor[c] = start[c];
-        __syncthreads();
-        for (int i = tid; i < N; i += SS_THREADS) sorted[atomicAdd(&cursor[cid[i]], 1)] = (unsigned short)i;
-        __syncthreads();
-        for (int c = tid; c < ncell; c += SS_THREADS) {
-            const int s0 = start[c], s1 = start[c + 1];
-            for (int a = s0 + 1; a < s1; ++a) {               // insertion sort: cells hold a handful of agents
-                const unsigned short v = sorted[a];
-                int k = a - 1;
-                while (k >= s0 && sorted[k] > v) { sorted[k + 1] = sorted[k]; --k; }
-                sorted[k + 1] = v;
-            }
+    for (int q = 0; q < 2; ++q) {
+        const int i = tid + q * SS_THREADS;
+        myc[q] = 0;
+        if (i < N) {
+            int cx = (int)((spx[i] - mnx) * iwx), cy = (int)((spy[i] - mny) * iwy);
+            cx = min(max(cx, 0), gx - 1); cy = min(max(cy, 0), gy - 1);
+            const int c = cy * gx + cx;
+            myc[q] = c;
+            cid[i] = (unsigned short)c;
+            atomicAdd(&start[c + 1], 1);                    // histogram, shifted by one: the scan below turns it into starts
         }
-        __syncthreads();
     }
-    // ---- this thread's row: the 3 x 3 cells around its own
-    const int i = i0 + tid;
-    const int RSW = NW + 1;                                   // odd word stride per row
-    unsigned long long* myrow = rowbits + (size_t)tid * RSW;
-    for (int wd = 0; wd < NW; ++wd) myrow[wd] = 0ull;
+    __syncthreads();
+    SS_STAMP(4);
+    if (does_reward && tid == 0) {
+        double var = 0.0;
+#pragma unroll
+        for (int w = 0; w < SS_WAVES; ++w) var += red2[w];
+        o.reward[b] = -1.0 * (var / (double)N) * p.reward_scale;
+    }
+    // ---- inclusive scan of the counts: thread t owns index t + 1 (= the count of cell t)
+    {
+        const int cnt = start[tid + 1];                        // (zero beyond the grid)
+        const int inc = ss_wave_scan(cnt);
+        if (lane == 63) shi[wave] = inc;
+        __syncthreads();
+        int base = (lane < wave) ? shi[lane & 15] : 0;          // waves before this one, summed over lanes 0..15
+        base += (int)dpp_u<0xB1>((unsigned int)base); base += (int)dpp_u<0x4E>((unsigned int)base);
+        base += (int)dpp_u<0x141>((unsigned int)base); base += (int)dpp_u<0x140>((unsigned int)base);
+        base = __builtin_amdgcn_readfirstlane(base);
+        start[tid + 1] = base + inc;                           // cells <= t hold this many agents
+        cursor[tid] = base + inc - cnt;                        // first slot of cell t
+    }
+    __syncthreads();
+    SS_STAMP(5);
+    // ---- scatter by cell (arrival order), then every member to its rank inside the cell: the number of members with a
+    // smaller index -- ascending index order (a fixed summation order) without a serial sort
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = tid + q * SS_THREADS;
+        if (i < N) tmp[atomicAdd(&cursor[myc[q]], 1)] = (unsigned short)i;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = tid + q * SS_THREADS;
+        if (i < N) {
+            const int s0 = start[myc[q]], s1 = start[myc[q] + 1];
+            int rank = 0;
+            for (int a = s0; a < s1; ++a) rank += (tmp[a] < i) ? 1 : 0;
+            sorted[s0 + rank] = (unsigned short)i;
+        }
+    }
+    __syncthreads();
+    SS_STAMP(6);
+    // ---- row r = tid >> 2 on four lanes: the candidates of the 3 x 3 cells around its own, every fourth one per lane
+    const int r = tid >> 2, part = tid & 3;
+    const int i = i0 + r;
     if (i < N) {
         const double xi = spx[i], yi = spy[i], vxi = svx[i], vyi = svy[i];
         const double R2 = p.comm_radius2;
         const unsigned int wi = (FD && p.link_drop != 0u) ? fade_word(xi, yi) : 0u;
         const int c = cid[i], cy = c / gx, cx = c - cy * gx;
-        double deg = 0.0, f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0;
+        unsigned long long* myrow = rowbits + (size_t)r * RSW;
+        int deg = 0;
+        double f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0;
+        const int xa = max(cx - 1, 0), xz = min(cx + 1, gx - 1);
         for (int dy = -1; dy <= 1; ++dy) {
             const int yy = cy + dy;
             if (yy < 0 || yy >= gy) continue;
-            const int xa = max(cx - 1, 0), xz = min(cx + 1, gx - 1);
             // the (up to) three cells of a grid row are contiguous in `sorted`
             const int s0 = start[yy * gx + xa], s1 = start[yy * gx + xz + 1];
-            for (int a = s0; a < s1; ++a) {
+            for (int a = s0 + part; a < s1; a += 4) {
                 const int j = sorted[a];
                 const double dx = xi - spx[j], dyy = yi - spy[j];
                 const double r2 = dx * dx + dyy * dyy;
                 if (j == i || !(r2 < R2)) continue;
                 if (FD && p.link_drop != 0u && !link_up(p, i, j, N, wi, fade_word(spx[j], spy[j]))) continue;
-                myrow[j >> 6] |= 1ull << (j & 63);
+                atomicOr(&myrow[j >> 6], 1ull << (j & 63));
                 const double q = 1.0 / r2;
                 const double qq = q * q;
-                deg += 1.0;
+                deg += 1;
                 f0 += vxi - svx[j];
                 f1 += dx * qq;
                 f2 += dx * q;
@@ -180,30 +277,39 @@ void sp_sim_kernel(const double* __restrict__ x, double* __restrict__ xo, const 
                 f5 += dyy * q;
             }
         }
-        const double w = p.mean_pooling ? 1.0 / (deg == 0.0 ? 1.0 : deg) : 1.0;
-        o.wq[(size_t)b * o.sWb + i] = (float)w;
-        float* ft = o.featT + (size_t)b * o.sTb + (size_t)i * 8;
-        *reinterpret_cast<float4*>(ft) = make_float4((float)f0, (float)f1, (float)f2, (float)f3);
-        *reinterpret_cast<float4*>(ft + 4) = make_float4((float)f4, (float)f5, 0.f, 0.f);
-        if (o.expert != nullptr) {                            // spec section 5
-            double tvx = f0, tvy = f3;
-            if (p.centralized) { tvx = (double)N * vxi - tot_vx; tvy = (double)N * vyi - tot_vy; }
-            const double ux = clipd(-tvx - (2.0 * f2 - 2.0 * f1), -p.ctrl_clip, p.ctrl_clip) * p.ctrl_gain;
-            const double uy = clipd(-tvy - (2.0 * f5 - 2.0 * f4), -p.ctrl_clip, p.ctrl_clip) * p.ctrl_gain;
-            o.expert[((size_t)b * N + i) * 2 + 0] = (float)ux;
-            o.expert[((size_t)b * N + i) * 2 + 1] = (float)uy;
+        // the four partial sums of the row, fixed order (lanes 0+1, 2+3, then the pairs)
+        deg += (int)dpp_u<0xB1>((unsigned int)deg); deg += (int)dpp_u<0x4E>((unsigned int)deg);
+        f0 += dpp_d<0xB1>(f0); f0 += dpp_d<0x4E>(f0); f1 += dpp_d<0xB1>(f1); f1 += dpp_d<0x4E>(f1);
+        f2 += dpp_d<0xB1>(f2); f2 += dpp_d<0x4E>(f2); f3 += dpp_d<0xB1>(f3); f3 += dpp_d<0x4E>(f3);
+        f4 += dpp_d<0xB1>(f4); f4 += dpp_d<0x4E>(f4); f5 += dpp_d<0xB1>(f5); f5 += dpp_d<0x4E>(f5);
+        SS_STAMP(7);
+        if (part == 0) {
+            const double dg = (double)deg;
+            const double w = p.mean_pooling ? 1.0 / (dg == 0.0 ? 1.0 : dg) : 1.0;
+            o.wq[(size_t)b * o.sWb + i] = (float)w;
+            float* ft = o.featT + (size_t)b * o.sTb + (size_t)i * 8;
+            *reinterpret_cast<float4*>(ft) = make_float4((float)f0, (float)f1, (float)f2, (float)f3);
+            *reinterpret_cast<float4*>(ft + 4) = make_float4((float)f4, (float)f5, 0.f, 0.f);
+            if (o.expert != nullptr) {                        // spec section 5
+                double tvx = f0, tvy = f3;
+                if (p.centralized) { tvx = (double)N * vxi - tot_vx; tvy = (double)N * vyi - tot_vy; }
+                const double ux = clipd(-tvx - (2.0 * f2 - 2.0 * f1), -p.ctrl_clip, p.ctrl_clip) * p.ctrl_gain;
+                const double uy = clipd(-tvy - (2.0 * f5 - 2.0 * f4), -p.ctrl_clip, p.ctrl_clip) * p.ctrl_gain;
+                *reinterpret_cast<float2*>(o.expert + ((size_t)b * N + i) * 2) = make_float2((float)ux, (float)uy);
+            }
         }
     }
     __syncthreads();
-    // ---- bit rows of this tile -> HBM, coalesced
-    {
-        const int rows = min(SS_THREADS, N - i0);
-        unsigned long long* gb = o.bits + (size_t)b * o.sBb + (size_t)i0 * NW;
-        for (int idx = tid; idx < rows * NW; idx += SS_THREADS) {
-            const int r = idx / NW, wd = idx - r * NW;
-            gb[idx] = rowbits[(size_t)r * RSW + wd];
-        }
+    SS_STAMP(8);
+    // ---- bit rows of this tile -> HBM: lane `part` of a row writes its quarter (NW / 4 contiguous words)
+    if (i < N) {
+        const int wpl = NW >> 2;                              // NW is a multiple of 8
+        unsigned long long* gb = o.bits + (size_t)b * o.sBb + (size_t)i * NW + part * wpl;
+        const unsigned long long* lr = rowbits + (size_t)r * RSW + part * wpl;
+        for (int k = 0; k < wpl; k += 2)
+            *reinterpret_cast<ulonglong2*>(gb + k) = make_ulonglong2(lr[k], lr[k + 1]);
     }
+    SS_STAMP(9);
 }
 
 }  // namespace
@@ -220,13 +326,16 @@ extern "C" int mgp_flock_step_cells(const double* x, double* x_out, const float*
     MGP_CHECK_PTR8(x); MGP_CHECK_PTR8(x_out); MGP_CHECK_PTR8(bits); MGP_CHECK_PTR(wrow); MGP_CHECK_PTR(featT);
     if (x_out == x) return MGP_EINVAL;
     if (!mgp_aligned16(featT) || (sTb & 3)) return MGP_EALIGN;
+    if (!mgp_aligned16(x) || !mgp_aligned16(x_out) || !mgp_aligned16(bits) || (sBb & 1)) return MGP_EALIGN;
+    if (expert != nullptr && (reinterpret_cast<uintptr_t>(expert) & 7u)) return MGP_EALIGN;
     const int NW = mgp_sparse_words(N);
-    const size_t lds = (size_t)4 * N * 8 + (size_t)(SS_G * SS_G + 2) * 4 + (size_t)2 * ((N + 3) & ~3) * 2 + 8
-                       + (size_t)SS_THREADS * (NW + 1) * 8;
+    const int N4 = (N + 3) & ~3;
+    const size_t lds = (size_t)4 * N * 8 + (size_t)(SS_G * SS_G + 2 + SS_G * SS_G) * 4 + (size_t)3 * N4 * 2 + 8
+                       + (size_t)SS_ROWS * (NW + 1) * 8;
     SsOut o = {bits, wrow, featT, sBb, sWb, sTb, reward, expert};
     mgp_clear_error();
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid(mgp_ceil_div(N, SS_THREADS), B);
+    const dim3 grid(mgp_ceil_div(N, SS_ROWS), B);
     const bool fade = p->link_drop != 0u;
     const void* fn = fade ? reinterpret_cast<const void*>(sp_sim_kernel<true>) : reinterpret_cast<const void*>(sp_sim_kernel<false>);
     if (lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

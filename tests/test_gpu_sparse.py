@@ -135,3 +135,29 @@ def test_cell_list_simulator_equals_the_all_pairs_kernel(N, spread, variant):
     assert relerr(a[3], b[3]) <= 1e-6 and relerr(a[5], b[5]) <= 1e-6
     assert np.max(np.abs(a[4] - b[4]) / np.maximum(1.0, np.abs(b[4]))) <= 1e-12
     assert a[1].any()
+
+
+@pytest.mark.parametrize('N,K,hidden', [(300, 3, (32, 32)), (1000, 3, (32, 32)), (400, 4, (32,)), (260, 2, (16, 16)), (320, 5, (16,))])
+def test_staged_and_direct_gather_forms_agree(N, K, hidden):
+    """mgp_sparse_policy_step has two forms of its gather / policy launches -- source rows staged in the LDS (the default
+    where they fit) and gathered straight from global memory (the fallback for very large flocks).  Same four-lanes-per-
+    column summation order: the actions of a rollout from a reset must agree bit for bit."""
+    from multiagent_gnn_policies_amd import _lib
+    from multiagent_gnn_policies_amd.learner.sparse_rollout import SparseFlockState, sparse_policy_rollout
+    outs = []
+    for direct in (0, 1):
+        old = _lib.lib().mgp_sparse_force_direct(direct)
+        try:
+            rs, op, actor, sim, st = _make(N, K, hidden, 2, seed=N + K)
+            sp = SparseFlockState(sim, K)
+            sp.observe_reset(sim)
+            action = torch.zeros((2, 1, 2, N), device='cuda')
+            acts = []
+            for _ in range(K + 2):
+                sparse_policy_rollout(actor, sim, sp, 1, action=action)
+                acts.append(action.clone())
+            outs.append((torch.stack(acts), sim.x.clone()))
+        finally:
+            _lib.lib().mgp_sparse_force_direct(old)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.isfinite(outs[0][0]).all() and float(outs[0][0].abs().max()) > 0
