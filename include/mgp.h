@@ -466,6 +466,16 @@ typedef struct MgpSparseCollect {
 int  mgp_sparse_policy_collect(const unsigned long long* bits, const float* wrow, const float* feat, const float* image,
                                const int* dims, int n_layers, float* scratch, float* action,
                                int B, int K, int N, int cur, int hs, const MgpSparseCollect* collect, void* stream);
+/* T closed-loop steps on the factored state enqueued by ONE call (reference test_model.py:38-44 / gnn_dagger.py:154-178 for
+ * every lane): per step mgp_sparse_policy_step (or _collect when `collect` is given), then the simulator (cell list up to
+ * N = 2048, all pairs beyond) into the next ring slots.  x_a holds the state on entry; x_a / x_b ping-pong: the final state
+ * is in x_b if T is odd, else x_a.  rewards (T,B) fp64 or NULL; expert (B,N,2) or NULL (required with collect: the label /
+ * the expert's action of every visited state).  collect->ring_step / age_now describe the FIRST step and advance per step.
+ * *cur / *hs: ring slots of x_t / A_t on entry, of the final state on return. */
+int  mgp_sparse_rollout(unsigned long long* bits, float* wrow, float* feat, const float* image, const int* dims,
+                        int n_layers, float* scratch, float* action, double* x_a, double* x_b, double* rewards,
+                        float* expert, const MgpFlockParams* p, int B, int K, int N, int T, int* cur, int* hs,
+                        const MgpSparseCollect* collect, void* stream);
 /* mgp_replay_gather_many for frames filed by mgp_sparse_policy_collect (N > 256: NW = mgp_sparse_words(N) words per bit
  * row, row weights stored with the frame): same outputs, the products e_i A_t A_{t-1} .. evaluated row by row from HBM. */
 int  mgp_replay_gather_rows(const float* feat, const unsigned long long* bits, const float* wrow, const float* label,

@@ -775,6 +775,48 @@ extern "C" int mgp_sparse_policy_collect(const unsigned long long* bits, const f
     return sp_policy_step(bits, wrow, feat, image, dims, n_layers, scratch, action, B, K, N, cur, hs, col, stream);
 }
 
+/* T closed-loop steps on the factored state, enqueued from one call (the loop of learner/sparse_rollout.py without a host
+ * round trip per launch): per step mgp_sparse_policy_step / _collect, then the simulator (cell list up to N = 2048, all
+ * pairs beyond) into the next ring slots; x_a holds the state on entry, x_a / x_b ping-pong.  rewards (T,B) or NULL;
+ * expert (B,N,2) or NULL (required with collect).  collect: ring_step / age_now of the FIRST step, advanced per step (ring
+ * step modulo ring_steps).  On return *cur / *hs are the ring slots of the final state and the state is in (T odd ? x_b : x_a). */
+extern "C" int mgp_sparse_rollout(unsigned long long* bits, float* wrow, float* feat, const float* image, const int* dims,
+                                  int n_layers, float* scratch, float* action, double* x_a, double* x_b, double* rewards,
+                                  float* expert, const MgpFlockParams* p, int B, int K, int N, int T, int* cur, int* hs,
+                                  const MgpSparseCollect* collect, void* stream)
+{
+    if (cur == nullptr || hs == nullptr || T < 0 || p == nullptr) return MGP_EINVAL;
+    if (collect != nullptr && expert == nullptr) return MGP_EINVAL;
+    const int H = K > 2 ? K - 1 : 1;
+    const int NW = mgp_sparse_words(N);
+    int c = *cur, h = *hs;
+    MgpSparseCollect col = {};
+    if (collect != nullptr) col = *collect;
+    double* xs[2] = {x_a, x_b};
+    for (int t = 0; t < T; ++t) {
+        int rc = (collect != nullptr)
+            ? mgp_sparse_policy_collect(bits, wrow, feat, image, dims, n_layers, scratch, action, B, K, N, c, h, &col, stream)
+            : mgp_sparse_policy_step(bits, wrow, feat, image, dims, n_layers, scratch, action, B, K, N, c, h, stream);
+        if (rc != MGP_OK) return rc;
+        const int nh = (h + 1) % H, nc = (c + 1) % K;
+        double* rw = rewards != nullptr ? rewards + (size_t)t * B : nullptr;
+        unsigned long long* bq = bits + (size_t)nh * N * NW;
+        float* wq = wrow + (size_t)nh * N;
+        float* fq = feat + (size_t)nc * N * 8;
+        // the Actor's output layout (B,1,2,N): agent stride 1, axis stride N
+        rc = (N <= 2048)
+            ? mgp_flock_step_cells(xs[t & 1], xs[(t & 1) ^ 1], action, 1, N, bq, (long)H * N * NW, wq, (long)H * N, fq,
+                                   (long)K * N * 8, rw, expert, p, B, N, stream)
+            : mgp_flock_step_sparse(xs[t & 1], xs[(t & 1) ^ 1], action, 1, N, bq, (long)H * N * NW, wq, (long)H * N, fq,
+                                    (long)K * N * 8, rw, expert, p, B, N, stream);
+        if (rc != MGP_OK) return rc;
+        h = nh; c = nc;
+        if (collect != nullptr) { col.ring_step = (col.ring_step + 1) % col.ring_steps; col.age_now += 1; }
+    }
+    *cur = c; *hs = h;
+    return MGP_OK;
+}
+
 /* Dense delayed operator of the reference contract from the factored state: G (B,K,N,N) slices 1..K-1 (slice 0, the
  * identity, is left alone).  hs = ring slot of the newest network. */
 extern "C" int mgp_sparse_to_dense(const unsigned long long* bits, const float* wrow, float* G, int B, int K, int N, int hs,

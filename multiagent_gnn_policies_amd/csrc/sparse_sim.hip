@@ -64,11 +64,12 @@ struct SsOut {
 };
 
 // grid: x = tile of 256 rows, y = b.
-// LDS: px, py, vx, vy [N] f64 | start [G*G + 2] int | cursor [G*G] int | cid, tmp, sorted [N4] u16 | rowbits [256][NW + 1] u64
-template <bool FD>
+// LDS: px, py, vx, vy [N] f64 | start [G*G + 2] int | cursor [G*G] int | cid, tmp, sorted [N4] u16 | rowbits [256][NW + 1] u64 | sub [1024][subcap] u16
+//      | PRE: posf [N] float2 (fp32 positions in `sorted` order)
+template <bool FD, bool PRE>
 __global__ __launch_bounds__(SS_THREADS)
 void sp_sim_kernel(const double* __restrict__ x, double* __restrict__ xo, const float* __restrict__ u, long su_agent,
-                   long su_axis, SsOut o, MgpFlockParams p, int N, int NW)
+                   long su_axis, SsOut o, MgpFlockParams p, int N, int NW, int subcap)
 {
     extern __shared__ __attribute__((aligned(16))) double ssm[];
     __shared__ double red[SS_WAVES][2];
@@ -84,6 +85,8 @@ void sp_sim_kernel(const double* __restrict__ x, double* __restrict__ xo, const 
     unsigned short* sorted = tmp + N4;                                          // ... in ascending index order
     unsigned long long* rowbits = reinterpret_cast<unsigned long long*>(
         (reinterpret_cast<uintptr_t>(sorted + N4) + 7) & ~(uintptr_t)7);
+    unsigned short* sub = reinterpret_cast<unsigned short*>(rowbits + (size_t)SS_ROWS * (NW + 1));   // [1024][subcap] hits of a lane
+    float2* posf = reinterpret_cast<float2*>((reinterpret_cast<uintptr_t>(sub + (size_t)SS_THREADS * subcap) + 7) & ~(uintptr_t)7);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
     const int i0 = blockIdx.x * SS_ROWS;
     const int RSW = NW + 1;                                   // odd word stride per row
@@ -238,6 +241,7 @@ void sp_sim_kernel(const double* __restrict__ x, double* __restrict__ xo, const 
             int rank = 0;
             for (int a = s0; a < s1; ++a) rank += (tmp[a] < i) ? 1 : 0;
             sorted[s0 + rank] = (unsigned short)i;
+            if (PRE) posf[s0 + rank] = make_float2((float)spx[i], (float)spy[i]);
         }
     }
     __syncthreads();
@@ -254,6 +258,31 @@ void sp_sim_kernel(const double* __restrict__ x, double* __restrict__ xo, const 
         int deg = 0;
         double f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0;
         const int xa = max(cx - 1, 0), xz = min(cx + 1, gx - 1);
+        auto terms = [&](int j, double dx, double dyy, double r2) {
+            const double q = 1.0 / r2;
+            const double qq = q * q;
+            deg += 1;
+            f0 += vxi - svx[j];
+            f1 += dx * qq;
+            f2 += dx * q;
+            f3 += vyi - svy[j];
+            f4 += dyy * qq;
+            f5 += dyy * q;
+        };
+        // Pass 1: the membership tests only; a lane notes its hits in its own short list.  (With the feature terms inside
+        // this loop a wave executes them on EVERY candidate -- some lane always has a hit -- ~10 times per row; the hits
+        // themselves are ~2 per lane.)
+        SS_STAMP(11);
+        unsigned short* mine = sub + (size_t)tid * subcap;
+        int cnt = 0;
+        // PRE: the candidates' positions in fp32, in candidate order (contiguous reads, no dependent index load -- this loop
+        // was bound by the LDS pipe: three scattered reads per candidate and lane).  fp32 decides wherever it provably
+        // agrees with the spec's fp64 test -- |r2_f32 - R^2| beyond `band`, four times the worst-case rounding of the fp32
+        // evaluation for candidates of the 3 x 3 cells -- and the fp64 expression decides inside the band.
+        const float xif = (float)xi, yif = (float)yi, R2f = (float)R2;
+        const float cwf = (float)fmax(ex_ / (double)gx, ey_ / (double)gy);
+        const float Rf = (float)R;
+        const float band = 2.384185791015625e-07f * 4.f * Rf * (2.f * fmaxf(fabsf(xif), fabsf(yif)) + 3.f * cwf + Rf) + 1e-30f;
         for (int dy = -1; dy <= 1; ++dy) {
             const int yy = cy + dy;
             if (yy < 0 || yy >= gy) continue;
@@ -261,20 +290,54 @@ void sp_sim_kernel(const double* __restrict__ x, double* __restrict__ xo, const 
             const int s0 = start[yy * gx + xa], s1 = start[yy * gx + xz + 1];
             for (int a = s0 + part; a < s1; a += 4) {
                 const int j = sorted[a];
-                const double dx = xi - spx[j], dyy = yi - spy[j];
-                const double r2 = dx * dx + dyy * dyy;
-                if (j == i || !(r2 < R2)) continue;
+                if (PRE) {
+                    const float2 pj = posf[a];
+                    const float dxf = xif - pj.x, dyf = yif - pj.y;
+                    const float r2f = dxf * dxf + dyf * dyf;
+                    if (j == i || !(r2f < R2f + band)) continue;
+                    if (r2f > R2f - band) {                       // too close to call in fp32
+                        const double dx = xi - spx[j], dyy = yi - spy[j];
+                        if (!(dx * dx + dyy * dyy < R2)) continue;
+                    }
+                } else {
+                    const double dx = xi - spx[j], dyy = yi - spy[j];
+                    const double r2 = dx * dx + dyy * dyy;
+                    if (j == i || !(r2 < R2)) continue;
+                }
                 if (FD && p.link_drop != 0u && !link_up(p, i, j, N, wi, fade_word(spx[j], spy[j]))) continue;
                 atomicOr(&myrow[j >> 6], 1ull << (j & 63));
-                const double q = 1.0 / r2;
-                const double qq = q * q;
-                deg += 1;
-                f0 += vxi - svx[j];
-                f1 += dx * qq;
-                f2 += dx * q;
-                f3 += vyi - svy[j];
-                f4 += dyy * qq;
-                f5 += dyy * q;
+                if (cnt < subcap) mine[cnt] = (unsigned short)j;
+                ++cnt;
+            }
+        }
+        SS_STAMP(10);
+        // Pass 2: the row's hits -- the four lists one after the other -- dealt round-robin to the four lanes
+        const int c0 = (int)dpp_u<0x00>((unsigned int)cnt), c1 = (int)dpp_u<0x55>((unsigned int)cnt);
+        const int c2 = (int)dpp_u<0xAA>((unsigned int)cnt), c3 = (int)dpp_u<0xFF>((unsigned int)cnt);
+        if (max(max(c0, c1), max(c2, c3)) <= subcap) {
+            const int tot = c0 + c1 + c2 + c3;
+            const unsigned short* rowsub = sub + (size_t)(tid & ~3) * subcap;
+            for (int e = part; e < tot; e += 4) {
+                int k = e, sl = 0;
+                if (k >= c0) { k -= c0; sl = 1; if (k >= c1) { k -= c1; sl = 2; if (k >= c2) { k -= c2; sl = 3; } } }
+                const int j = rowsub[sl * subcap + k];
+                const double dx = xi - spx[j], dyy = yi - spy[j];
+                terms(j, dx, dyy, dx * dx + dyy * dyy);
+            }
+        } else {
+            // a list overflowed (a dense flock, or no room for lists at this N): every lane walks its candidates again
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = cy + dy;
+                if (yy < 0 || yy >= gy) continue;
+                const int s0 = start[yy * gx + xa], s1 = start[yy * gx + xz + 1];
+                for (int a = s0 + part; a < s1; a += 4) {
+                    const int j = sorted[a];
+                    const double dx = xi - spx[j], dyy = yi - spy[j];
+                    const double r2 = dx * dx + dyy * dyy;
+                    if (j == i || !(r2 < R2)) continue;
+                    if (FD && p.link_drop != 0u && !link_up(p, i, j, N, wi, fade_word(spx[j], spy[j]))) continue;
+                    terms(j, dx, dyy, r2);
+                }
             }
         }
         // the four partial sums of the row, fixed order (lanes 0+1, 2+3, then the pairs)
@@ -330,19 +393,30 @@ extern "C" int mgp_flock_step_cells(const double* x, double* x_out, const float*
     if (expert != nullptr && (reinterpret_cast<uintptr_t>(expert) & 7u)) return MGP_EALIGN;
     const int NW = mgp_sparse_words(N);
     const int N4 = (N + 3) & ~3;
-    const size_t lds = (size_t)4 * N * 8 + (size_t)(SS_G * SS_G + 2 + SS_G * SS_G) * 4 + (size_t)3 * N4 * 2 + 8
-                       + (size_t)SS_ROWS * (NW + 1) * 8;
+    const size_t lds0 = (size_t)4 * N * 8 + (size_t)(SS_G * SS_G + 2 + SS_G * SS_G) * 4 + (size_t)3 * N4 * 2 + 8
+                        + (size_t)SS_ROWS * (NW + 1) * 8;
+    // per-lane hit lists of the row search: 16 entries where the LDS has room, else 8, else none (single-pass fallback);
+    // fp32 positions for the pre-filter of the membership tests where they fit besides
+    const size_t cap_lds = 160 * 1024;
+    const int subcap = (lds0 + (size_t)SS_THREADS * 16 * 2 <= cap_lds) ? 16 : ((lds0 + (size_t)SS_THREADS * 8 * 2 <= cap_lds) ? 8 : 0);
+    const size_t lds1 = lds0 + (size_t)SS_THREADS * subcap * 2 + 8;
+    const bool pre = lds1 + (size_t)N * 8 <= cap_lds;
+    const size_t lds = lds1 + (pre ? (size_t)N * 8 : 0);
     SsOut o = {bits, wrow, featT, sBb, sWb, sTb, reward, expert};
     mgp_clear_error();
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(mgp_ceil_div(N, SS_ROWS), B);
     const bool fade = p->link_drop != 0u;
-    const void* fn = fade ? reinterpret_cast<const void*>(sp_sim_kernel<true>) : reinterpret_cast<const void*>(sp_sim_kernel<false>);
-    if (lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return MGP_ELAUNCH;
-    if (fade)
-        hipLaunchKernelGGL(sp_sim_kernel<true>, grid, dim3(SS_THREADS), lds, st, x, x_out, u, su_agent, su_axis, o, *p, N, NW);
-    else
-        hipLaunchKernelGGL(sp_sim_kernel<false>, grid, dim3(SS_THREADS), lds, st, x, x_out, u, su_agent, su_axis, o, *p, N, NW);
+    auto go = [&](auto kern) -> int {
+        if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)lds) != hipSuccess)
+            return MGP_ELAUNCH;
+        hipLaunchKernelGGL(kern, grid, dim3(SS_THREADS), lds, st, x, x_out, u, su_agent, su_axis, o, *p, N, NW, subcap);
+        return MGP_OK;
+    };
+    int rc;
+    if (fade) rc = pre ? go(sp_sim_kernel<true, true>) : go(sp_sim_kernel<true, false>);
+    else rc = pre ? go(sp_sim_kernel<false, true>) : go(sp_sim_kernel<false, false>);
+    if (rc != MGP_OK) return rc;
     return mgp_launch_status();
 }

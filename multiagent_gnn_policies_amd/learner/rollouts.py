@@ -220,8 +220,10 @@ def policy_rollout(actor, sim, state, T, rewards=None, action=None, resident=Tru
                     sp = SparseFlockState(sim, state.K)
                     sp.observe_reset(sim)
             if sp is not None:
+                if state._dense_from is not None:              # a pending lazy rebuild refers to the rings about to move; the
+                    state._dense_from, state._dense_stale = None, False       # dense slices are rebuilt from the NEW state on demand
                 sparse_policy_rollout(actor, sim, sp, T, rewards=rewards, action=action)
-                sp.to_dense(sim, state)
+                sp.to_dense(sim, state, lazy=lazy_dense)
                 state._pushes += T
                 sp.at_push = state._pushes
                 state._sparse = sp

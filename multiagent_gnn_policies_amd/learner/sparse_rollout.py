@@ -68,18 +68,30 @@ class SparseFlockState(object):
         self.steps += 1
         self.owner = sim.x
 
-    def to_dense(self, sim, state):
-        """Materialise the reference's dense state into `state` (BatchedDelayState): delay_gso slices 1..K-1 from the bit
-        rows, delay_state from the feature ring, and point the simulator's observation views at them."""
-        G, X = state.delay_gso, state.delay_state
-        rc = _lib.lib().mgp_sparse_to_dense(self.bits.data_ptr(), ops._ptr(self.wrow), ops._ptr(G), self.B, self.K, self.N,
-                                            self.hs, ops._stream())
-        _lib.check(rc, 'mgp_sparse_to_dense')
-        for k in range(self.K):
-            X[:, k].copy_(self.feat[:, (self.cur - k) % self.K, :, :6].transpose(1, 2))
+    def to_dense(self, sim, state, lazy=False):
+        """Materialise the reference's dense state into `state` (BatchedDelayState): delay_state from the feature ring now,
+        delay_gso slices 1..K-1 from the bit rows now or -- lazy -- when somebody reads them (state.delay_gso /
+        sim.network: 12 MB per episode at N = 1000, 180 us for 64 episodes), and point the simulator's observation views at them."""
+        X = state._X[state._cur]
+        slots = torch.tensor([(self.cur - k) % self.K for k in range(self.K)], device=X.device)
+        X.copy_(self.feat.index_select(1, slots)[:, :, :, :6].transpose(2, 3))
+        hs, bits, wrow = self.hs, self.bits, self.wrow
+
+        def build():
+            rc = _lib.lib().mgp_sparse_to_dense(bits.data_ptr(), ops._ptr(wrow), ops._ptr(state._G[state._cur]), self.B,
+                                                self.K, self.N, hs, ops._stream())
+            _lib.check(rc, 'mgp_sparse_to_dense')
         state._has_prev = True
+        state._carry_valid = False
+        if lazy:
+            # the rings move on with the next step: the closure is only valid until then, which is exactly as long as
+            # `state` describes this state (any later transition goes through _ensure_dense first)
+            state._dense_stale, state._dense_from = True, build
+        else:
+            state._dense_stale, state._dense_from = False, None
+            build()
         if self.K > 1:
-            sim.network = G[:, 1]
+            sim._network, sim._network_lazy = None, (lambda: state.delay_gso[:, 1])
         sim.features = X[:, 0]
 
 
@@ -102,6 +114,23 @@ def _policy_image(actor, sim, K):
     return cd, nl, image
 
 
+def _run_steps(sim, sp, cd, nl, image, act, T, rw, collect):
+    """T steps enqueued by one library call (mgp_sparse_rollout); keeps `sp` / `sim` in step with the rings and the ping-pong."""
+    cur, hs = ctypes.c_int(sp.cur), ctypes.c_int(sp.hs)
+    assert sim.with_expert or collect is None
+    rc = _lib.lib().mgp_sparse_rollout(
+        sp.bits.data_ptr(), ops._ptr(sp.wrow), ops._ptr(sp.feat), ops._ptr(image), cd, nl, ops._ptr(sp.scratch), ops._ptr(act),
+        ops._ptr(sim.x), ops._ptr(sim._x_next), ops._ptr(rw), ops._ptr(sim.expert if sim.with_expert else None),
+        ctypes.byref(sim._c), sp.B, sp.K, sp.N, int(T), ctypes.byref(cur), ctypes.byref(hs),
+        ctypes.byref(collect) if collect is not None else None, ops._stream())
+    _lib.check(rc, 'mgp_sparse_rollout')
+    if T & 1:
+        sim.x, sim._x_next = sim._x_next, sim.x
+    sp.cur, sp.hs = cur.value, hs.value
+    sp.steps += T
+    sp.owner = sim.x
+
+
 def sparse_collect(actor, sim, sp, frames, beta, episode_ids, seed, age0, T, rewards=None):
     """T DAGGER data-collection steps on the factored state (reference gnn_dagger.py:154-178 for every lane; the semantics
     of mgp_rollout_collect for N > 256): every step files the state it starts from into `frames` (FrameReplay with .wrow)
@@ -115,23 +144,14 @@ def sparse_collect(actor, sim, sp, frames, beta, episode_ids, seed, age0, T, rew
     cd, nl, image = _policy_image(actor, sim, K)
     act = torch.empty((B, 1, 2, N), device=sim.device, dtype=torch.float32)
     rw = torch.empty((T, B), device=sim.device, dtype=torch.float64) if rewards is not None else None
-    keep = sim.reward
-    S = frames.ring_steps
-    for t in range(T):
-        cl = _lib.MgpSparseCollect(frames.feat.data_ptr(), frames.bits.data_ptr(), frames.wrow.data_ptr(),
-                                   frames.label.data_ptr(), frames.age.data_ptr(), sim.expert.data_ptr(), beta.data_ptr(),
-                                   episode_ids.data_ptr(), int(seed) & 0xFFFFFFFF, int(age0) + t, frames.head, S)
-        _lib.check(L.mgp_sparse_policy_collect(sp.bits.data_ptr(), ops._ptr(sp.wrow), ops._ptr(sp.feat), ops._ptr(image), cd, nl,
-                                               ops._ptr(sp.scratch), ops._ptr(act), B, K, N, sp.cur, sp.hs, ctypes.byref(cl),
-                                               ops._stream()), 'mgp_sparse_policy_collect')
-        if rw is not None:
-            sim.reward = rw[t]
-        sp.step(sim, act)
-        frames.advance(1)
-    sim.reward = keep
+    cl = _lib.MgpSparseCollect(frames.feat.data_ptr(), frames.bits.data_ptr(), frames.wrow.data_ptr(),
+                               frames.label.data_ptr(), frames.age.data_ptr(), sim.expert.data_ptr(), beta.data_ptr(),
+                               episode_ids.data_ptr(), int(seed) & 0xFFFFFFFF, int(age0), frames.head, frames.ring_steps)
+    _run_steps(sim, sp, cd, nl, image, act, T, rw, cl)
+    frames.advance(T)
     if rw is not None:
         rewards.copy_(rw.t())
-        keep.copy_(rw[T - 1])
+        sim.reward.copy_(rw[T - 1])
     return True
 
 
@@ -143,16 +163,8 @@ def sparse_policy_rollout(actor, sim, sp, T, rewards=None, action=None):
     cd, nl, image = _policy_image(actor, sim, K)
     act = action if action is not None else torch.empty((B, 1, 2, N), device=sim.device, dtype=torch.float32)
     rw = torch.empty((T, B), device=sim.device, dtype=torch.float64) if rewards is not None else None
-    keep = sim.reward
-    for t in range(T):
-        _lib.check(L.mgp_sparse_policy_step(sp.bits.data_ptr(), ops._ptr(sp.wrow), ops._ptr(sp.feat), ops._ptr(image), cd, nl,
-                                            ops._ptr(sp.scratch), ops._ptr(act), B, K, N, sp.cur, sp.hs, ops._stream()),
-                   'mgp_sparse_policy_step')
-        if rw is not None:
-            sim.reward = rw[t]                 # the simulator writes this step's rewards straight into row t
-        sp.step(sim, act)
-    sim.reward = keep
+    _run_steps(sim, sp, cd, nl, image, act, T, rw, None)
     if rw is not None:
         rewards.copy_(rw.t())
-        keep.copy_(rw[T - 1])
+        sim.reward.copy_(rw[T - 1])
     return True

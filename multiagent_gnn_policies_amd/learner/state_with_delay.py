@@ -95,12 +95,14 @@ class BatchedDelayState(object):
         self._carry = None
         self._carry_valid = False
         self._dense_stale = False
+        self._dense_from = None                   # factored state in HBM (N > 256): callable that rebuilds the dense slices
 
     def reset(self):
         self._has_prev = False
         self._pushes = 0
         self._carry_valid = False
         self._dense_stale = False
+        self._dense_from = None
 
     def carry_buffer(self):
         """(B, mgp_rollout_carry_bytes) uint8 device buffer, or None when the resident kernel does not cover (K, N)."""
@@ -113,8 +115,12 @@ class BatchedDelayState(object):
 
     def _ensure_dense(self):
         if self._dense_stale:
-            ops.rollout_carry_to_dense(self._carry, self._G[self._cur], self.K)
             self._dense_stale = False
+            if self._dense_from is not None:      # left by a rollout on the factored state (sparse_rollout.py)
+                fn, self._dense_from = self._dense_from, None
+                fn()
+            else:
+                ops.rollout_carry_to_dense(self._carry, self._G[self._cur], self.K)
 
     def push(self, A, X_t):
         """A (B,N,N) fp32, X_t (B,F,N) fp32 on the device.  mgp_gso_update reads both with batch strides N*N and F*N, so

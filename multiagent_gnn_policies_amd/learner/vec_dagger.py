@@ -470,7 +470,7 @@ def collect_round(learner, sim, state, memory, beta, episode_ids, seed, T, chunk
         sp = SparseFlockState(sim, state.K)
         sp.observe_reset(sim)
         sparse_collect(learner.actor, sim, sp, memory, beta, episode_ids, seed, 0, T)
-        sp.to_dense(sim, state)
+        sp.to_dense(sim, state, lazy=True)
         state._pushes += T
         sp.at_push = state._pushes
         state._sparse = sp

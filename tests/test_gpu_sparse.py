@@ -137,7 +137,7 @@ def test_cell_list_simulator_equals_the_all_pairs_kernel(N, spread, variant):
     assert a[1].any()
 
 
-@pytest.mark.parametrize('N,K,hidden', [(300, 3, (32, 32)), (1000, 3, (32, 32)), (400, 4, (32,)), (260, 2, (16, 16)), (320, 5, (16,))])
+@pytest.mark.parametrize('N,K,hidden', [(300, 3, (32, 32)), (1000, 3, (32, 32)), (400, 4, (32,)), (260, 2, (16, 16)), (320, 5, (16,)), (2600, 3, (32, 32))])
 def test_staged_and_direct_gather_forms_agree(N, K, hidden):
     """mgp_sparse_policy_step has two forms of its gather / policy launches -- source rows staged in the LDS (the default
     where they fit) and gathered straight from global memory (the fallback for very large flocks).  Same four-lanes-per-

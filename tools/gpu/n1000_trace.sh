@@ -7,5 +7,7 @@ cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_n1000 -o n1000 -- pytho
 cd "$GRAFT_REPO_ROOT"
 T=$(find /tmp/prof_n1000 -name "*results.db" | head -1)
 python tools/rocpd_stats.py $T > gpurun_out/n1000/kernel_stats.csv 2>&1
+python tools/rocpd_gaps.py $T 'sp_|spl_' > gpurun_out/n1000/gaps.txt 2>&1
+cat gpurun_out/n1000/gaps.txt
 cat gpurun_out/n1000/bench.json | cut -c1-600
 cat gpurun_out/n1000/kernel_stats.csv | cut -c1-200

@@ -9,6 +9,8 @@
 #include <cmath>
 thread_local int mgp_tls_hip_error = 0;
 thread_local void* mgp_tls_launch_events[2] = {nullptr, nullptr};
+extern "C" int mgp_flock_step_sparse(const double*, double*, const float*, long, long, unsigned long long*, long, float*, long, float*, long,
+                                     double*, float*, const MgpFlockParams*, int, int, void*) { return MGP_EUNSUPPORTED; }   // (flock.hip is not linked here)
 extern "C" int mgp_sparse_words(int N) { return N <= 0 ? 0 : 8 * (((((N + 7) / 8) + 63) & ~63) / 64); }
 int main(int argc, char** argv) {
     int B = argc > 1 ? atoi(argv[1]) : 64, N = argc > 2 ? atoi(argv[2]) : 1000, K = argc > 3 ? atoi(argv[3]) : 3;
@@ -88,7 +90,7 @@ int main(int argc, char** argv) {
         unsigned long long st[256];
         hipMemcpyFromSymbol(st, HIP_SYMBOL(mgp_ss_stamps), sizeof(st));
         const char* names[] = {"start", "loaded + integrated", "block reductions done", "reward done", "histogram done (barrier)", "scan done (barrier)",
-                               "scatter + sort done", "row search done", "outputs written (barrier)", "bit rows written"};
+                               "scatter + sort done", "row search done", "outputs written (barrier)", "bit rows written", "row search: pass 1 (tests) done", "row search: row data loaded"};
         {
             unsigned long long sq[512];
             hipMemcpyFromSymbol(sq, HIP_SYMBOL(mgp_sp_stamps), sizeof(sq));
@@ -101,7 +103,7 @@ int main(int argc, char** argv) {
             for (int i = 0; i < 8; ++i) { printf("  stamp %d :", i); for (int w = 0; w < 4; ++w) printf(" %7lld", (long long)(sq[(1 * 16 + wv[w]) * 16 + i] - sq[16 * 16])); printf("  %s\n", pn[i]); }
         }
         printf("sp_sim_kernel, workgroup (1,3): cycles since start, lane 0 of waves 0 5 10 15\n");
-        for (int i = 0; i < 10; ++i) {
+        for (int i = 0; i < 12; ++i) {
             printf("  stamp %d :", i);
             for (int w = 0; w < 4; ++w) printf(" %7lld", (long long)(st[(5 * w) * 16 + i] - st[0]));
             printf("  %s\n", names[i]);
