@@ -640,7 +640,27 @@ def dagger_round_bench(args, device, rank, world):
     # ---- collection: reset sampling (host, once per round) is outside the timed region, the launch inside
     from multiagent_gnn_policies_amd.learner.rollouts import _actor_params
 
+    def collect_factored(steps):
+        """N > 256: the same round on the factored state in HBM (K launches per env step enqueued by one library call;
+        frame, label and coin inside the policy launch: mgp_sparse_policy_collect)."""
+        from multiagent_gnn_policies_amd.learner.sparse_rollout import SparseFlockState, sparse_collect
+        sim.reset(np.random)
+        state.reset()
+        state.push(sim.network, sim.features)
+        sp = SparseFlockState(sim, K)
+        sp.observe_reset(sim)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sparse_collect(learner.actor, sim, sp, memory, beta, eps, 11, 0, steps)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        barrier()
+        return max_over_ranks(el)
+
     def collect(steps):
+        if N > 256:
+            return collect_factored(steps)
         sim.reset(np.random)
         state.reset()
         state.push(sim.network, sim.features)
@@ -694,7 +714,8 @@ def dagger_round_bench(args, device, rank, world):
             "warmup": args.warmup, "ms_per_step": 1e3 * t_collect / T, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DAGGER round (BASELINE.json configs[3]): %d lanes x %d steps of data collection per rank "
-                                   "(mgp_rollout_collect: policy forward, expert label, beta coin, sim step, frame insert), "
+                                   "(" + ("mgp_rollout_collect" if N <= 256 else "factored state, mgp_sparse_policy_collect") +
+                                   ": policy forward, expert label, beta coin, sim step, frame insert), "
                                    "then %d updates of %d samples per rank with the gradient exchanged between %d rank(s)"
                                    % (lanes, T, U, Bt, world),
                        "episodes_per_gpu": lanes, "agents": N, "taps": K, "hidden": [args.hidden] * args.layers,

@@ -73,8 +73,8 @@ class SparseFlockState(object):
         delay_gso slices 1..K-1 from the bit rows now or -- lazy -- when somebody reads them (state.delay_gso /
         sim.network: 12 MB per episode at N = 1000, 180 us for 64 episodes), and point the simulator's observation views at them."""
         X = state._X[state._cur]
-        slots = torch.tensor([(self.cur - k) % self.K for k in range(self.K)], device=X.device)
-        X.copy_(self.feat.index_select(1, slots)[:, :, :, :6].transpose(2, 3))
+        for k in range(self.K):                                 # (K small strided copies; no index tensor: that would be an H2D)
+            X[:, k].copy_(self.feat[:, (self.cur - k) % self.K, :, :6].transpose(1, 2))
         hs, bits, wrow = self.hs, self.bits, self.wrow
 
         def build():
@@ -102,6 +102,8 @@ def sparse_supported(actor, K, N):
 
 
 def _policy_image(actor, sim, K):
+    """(dims, n_layers, weight image) of `actor` for the factored policy kernels.  Rebuilt on every call: the optimiser's
+    kernels write the parameters through raw pointers, so torch's version counters do not see a training update."""
     L = _lib.lib()
     dims = tuple(actor.layers)
     cd = (ctypes.c_int * len(dims))(*dims)
