@@ -310,6 +310,17 @@ void sp_sim_kernel(const double* __restrict__ x, double* __restrict__ xo, const 
                 ++cnt;
             }
         }
+        // the row's bit words are final once its four lanes -- one wave -- have issued their LDS atomics: lane `part` writes its
+        // quarter (NW / 4 contiguous words) to HBM now, under pass 2, without a workgroup barrier
+        {
+            __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): the wave's LDS atomics have completed
+            __builtin_amdgcn_wave_barrier();
+            const int wpl = NW >> 2;                              // NW is a multiple of 8
+            unsigned long long* gb = o.bits + (size_t)b * o.sBb + (size_t)i * NW + part * wpl;
+            const unsigned long long* lr = rowbits + (size_t)r * RSW + part * wpl;
+            for (int k = 0; k < wpl; k += 2)
+                *reinterpret_cast<ulonglong2*>(gb + k) = make_ulonglong2(lr[k], lr[k + 1]);
+        }
         SS_STAMP(10);
         // Pass 2: the row's hits -- the four lists one after the other -- dealt round-robin to the four lanes
         const int c0 = (int)dpp_u<0x00>((unsigned int)cnt), c1 = (int)dpp_u<0x55>((unsigned int)cnt);
@@ -362,16 +373,7 @@ void sp_sim_kernel(const double* __restrict__ x, double* __restrict__ xo, const 
             }
         }
     }
-    __syncthreads();
     SS_STAMP(8);
-    // ---- bit rows of this tile -> HBM: lane `part` of a row writes its quarter (NW / 4 contiguous words)
-    if (i < N) {
-        const int wpl = NW >> 2;                              // NW is a multiple of 8
-        unsigned long long* gb = o.bits + (size_t)b * o.sBb + (size_t)i * NW + part * wpl;
-        const unsigned long long* lr = rowbits + (size_t)r * RSW + part * wpl;
-        for (int k = 0; k < wpl; k += 2)
-            *reinterpret_cast<ulonglong2*>(gb + k) = make_ulonglong2(lr[k], lr[k + 1]);
-    }
     SS_STAMP(9);
 }
 

@@ -71,5 +71,19 @@ for w in (2, 3, 4):
 PY
 # 6. instruction mix of the resident kernel (harness, bench state)
 bash tools/gpu/ro_pmc.sh > $O/rollout_inst_mix.txt 2>&1
-rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_fetch20 $O/pmc_write20 $O/trace gpurun_out/ro_pmc
+# 7. the factored path (N > 256; cfg-3 shape 64 x 1000, K = 3): harness stamps of its three kernels, their kernel trace, the
+#    bench at 100 / 500 steps per call, and DAGGER rounds collecting on the factored state (N = 1000, N = 300)
+#    (harness: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DMGP_SP_PROFILE] -o scratch/sp_prof[_stamps] tools/harness/sp_step_prof.hip)
+{ ./scratch/sp_prof_stamps 64 1000 3 200; ./scratch/sp_prof 64 1000 3 200; ./scratch/sp_prof 256 300 3 200; ./scratch/sp_prof 64 1000 4 200; } > $O/factored_step_stamps.txt 2>&1
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $O/trace_sp -o sp -- $R/scratch/sp_prof 64 1000 3 200 > /dev/null 2>&1)
+TS=$(find $O/trace_sp -name "*results.db" | head -1)
+python tools/rocpd_stats.py $TS | head -8 > $O/factored_kernel_trace.txt 2>&1
+for st in 100 500; do python bench.py --episodes 64 --agents 1000 --taps 3 --no-cpu-baseline --no-roofline --steps $st --warmup 10 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print('64 1000 3 hidden 32 x 2, $st steps per call:', 'value %.3e' % d['value'], 'us/step %.2f' % (1e3 * d['ms_per_step']), 'paths', {a: '%.3e' % b['value'] for a, b in d['paths'].items()}, 'parity ok', d['parity']['ok'], 'max_rel %.2e' % d['parity']['max_rel'], 'mean degree %.2f' % d['config']['mean_degree'])
+" >> $O/factored_kernel_trace.txt; done
+python bench.py --dagger --episodes 64 --agents 1000 --steps 200 --warmup 10 --updates 64 2> $O/dagger_round_n1000.err | grep "^{" > $O/dagger_round_n1000.json
+python bench.py --dagger --episodes 256 --agents 300 --steps 200 --warmup 10 --updates 256 2> $O/dagger_round_n300.err | grep "^{" > $O/dagger_round_n300.json
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_fetch20 $O/pmc_write20 $O/trace $O/trace_sp gpurun_out/ro_pmc
 ls -la $O
