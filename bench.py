@@ -714,10 +714,10 @@ def dagger_round_bench(args, device, rank, world):
             "warmup": args.warmup, "ms_per_step": 1e3 * t_collect / T, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DAGGER round (BASELINE.json configs[3]): %d lanes x %d steps of data collection per rank "
-                                   "(" + ("mgp_rollout_collect" if N <= 256 else "factored state, mgp_sparse_policy_collect") +
-                                   ": policy forward, expert label, beta coin, sim step, frame insert), "
+                                   "(%s: policy forward, expert label, beta coin, sim step, frame insert), "
                                    "then %d updates of %d samples per rank with the gradient exchanged between %d rank(s)"
-                                   % (lanes, T, U, Bt, world),
+                                   % (lanes, T, "mgp_rollout_collect" if N <= 256 else "factored state, mgp_sparse_policy_collect",
+                                      U, Bt, world),
                        "episodes_per_gpu": lanes, "agents": N, "taps": K, "hidden": [args.hidden] * args.layers,
                        "init": args.init, "beta": 0.75,
                        "parallelism": "episodes sharded x%d; one exchange of %d floats per update"
