@@ -39,6 +39,7 @@ says so (N <= 256, widths <= 64; one hidden layer up to 128 wide at N <= 128), f
 names it and paths.* carries every implementation that was timed.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -649,12 +650,14 @@ def dagger_round_bench(args, device, rank, world):
         state.push(sim.network, sim.features)
         sp = SparseFlockState(sim, K)
         sp.observe_reset(sim)
+        gc.disable()                                             # (see timed(): no interpreter GC pass inside the timed region)
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         sparse_collect(learner.actor, sim, sp, memory, beta, eps, 11, 0, steps)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        gc.enable()
         barrier()
         return max_over_ranks(el)
 
@@ -668,6 +671,7 @@ def dagger_round_bench(args, device, rank, world):
         ws, bs = _actor_params(learner.actor)
         image = ops.rollout_image(ws, bs, tuple(learner.actor.layers), K, N)
         carry = state.carry_buffer()
+        gc.disable()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -676,25 +680,30 @@ def dagger_round_bench(args, device, rank, world):
                                  flags=ops.RO_ENTER_CARRY | ops.RO_EXIT_CARRY | ops.RO_SKIP_DENSE, image=image)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        gc.enable()
         barrier()
         assert ok
         memory.advance(steps)
         state._pushes += steps
         state._dense_stale = True
         return max_over_ranks(el)
+    gc.freeze()
     collect(max(args.warmup, K))
     t_collect = collect(T)
     # ---- updates
     fu = FrameUpdates(learner, memory, Bt, max(U, 64), p.mean_pooling)
     learner.begin_updates()
+    gc.freeze()
     fu.run_sampled(64)                                           # warm-up: captures both graphs
     learner.end_updates()
+    gc.disable()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     loss_sum = fu.run_sampled(U)
     torch.cuda.synchronize()
     t_upd = time.perf_counter() - t0
+    gc.enable()
     barrier()
     t_upd = max_over_ranks(t_upd)
     learner.end_updates()
@@ -831,13 +840,24 @@ def main():
         """warm-up, then EXACTLY args.steps steps bracketed by barrier + synchronize on both sides; the clock is read
         between the closing synchronize and the closing barrier (the collective's own latency is not part of a step),
         and the MAX over ranks is taken below."""
-        fn(args.warmup)
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        fn(args.steps)
-        torch.cuda.synchronize()
-        el_ = time.perf_counter() - t0
+        # no cyclic-GC pass of the interpreter inside the timed region: a generation-2 collection over torch's ~10^6 objects
+        # takes 35-55 ms, and WHERE it lands is a deterministic function of the allocation count -- it sat inside the 3.4 ms
+        # timed call of one build of this file and outside it in the previous one (12x on the reported figure).  Collected
+        # gc.freeze() moves everything allocated so far out of the collector's reach (no traversal: a gc.collect() here
+        # instead cost the 20-step launch +13 to +55 us of host time after 40 ms of GPU idling), and the collector stays off
+        # until the region is over.
+        gc.freeze()
+        gc.disable()
+        try:
+            fn(args.warmup)
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn(args.steps)
+            torch.cuda.synchronize()
+            el_ = time.perf_counter() - t0
+        finally:
+            gc.enable()
         barrier()
         if world > 1:
             t = torch.tensor([el_], device=device, dtype=torch.float64)

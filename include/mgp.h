@@ -439,9 +439,10 @@ int  mgp_sparse_policy_step(const unsigned long long* bits, const float* wrow, c
 int  mgp_sparse_to_dense(const unsigned long long* bits, const float* wrow, float* G, int B, int K, int N, int hs,
                          void* stream);
 /* mgp_sparse_policy_step has two forms of its gather / policy launches: source rows staged in the LDS (default wherever an
- * episode's rows fit: N <= ~2400) or gathered straight from global memory.  Test hook: on != 0 keeps the second form
- * everywhere (process-wide); returns the previous setting. */
-int  mgp_sparse_force_direct(int on);
+ * episode's rows fit: N <= ~2400) or gathered straight from global memory.  Test hook (process-wide): mode 1 keeps the second
+ * form everywhere, mode 2 the staged form on bit rows only (ignores the neighbour lists of mgp_sparse_rollout), 0 restores the
+ * default; returns the previous mode. */
+int  mgp_sparse_force_direct(int mode);
 /* DAGGER data collection on the factored state (reference gnn_dagger.py:154-178 per lane; the semantics of
  * mgp_rollout_collect for N > 256): mgp_sparse_policy_step that ALSO files the frame of the state the step starts from at
  * ring step `ring_step` of a ring laid out [ring_steps][B] -- features x_t (6,N), bit rows (N x mgp_sparse_words(N) u64) and
@@ -475,7 +476,16 @@ int  mgp_sparse_policy_collect(const unsigned long long* bits, const float* wrow
 int  mgp_sparse_rollout(unsigned long long* bits, float* wrow, float* feat, const float* image, const int* dims,
                         int n_layers, float* scratch, float* action, double* x_a, double* x_b, double* rewards,
                         float* expert, const MgpFlockParams* p, int B, int K, int N, int T, int* cur, int* hs,
-                        const MgpSparseCollect* collect, void* stream);
+                        const MgpSparseCollect* collect, unsigned short* nbr, void* stream);
+/* nbr (B,H,N,16) u16 or NULL: the networks of the bit-row ring once more as compact neighbour LISTS, kept in step with it by
+ * the cell-list simulator (mgp_flock_step_cells_nbr; N <= 2048) and read by the gather / policy launches instead of the bit rows
+ * (32 instead of 128 bytes per row to request at N = 1000, entries dealt evenly over a column's four lanes).  Row layout: up
+ * to 15 neighbour indices, entry e at position (e & 3) * 4 + (e >> 2); position 15 = the count, 0xFFFF = use the bit row.
+ * The ring slot of the current network must have been written by mgp_flock_step_cells_nbr (e.g. the reset observation). */
+int  mgp_flock_step_cells_nbr(const double* x, double* x_out, const float* u, long su_agent, long su_axis,
+                              unsigned long long* bits, long sBb, float* wrow, long sWb, float* featT, long sTb,
+                              unsigned short* nbr, long sNb, double* reward, float* expert, const MgpFlockParams* p,
+                              int B, int N, void* stream);
 /* mgp_replay_gather_many for frames filed by mgp_sparse_policy_collect (N > 256: NW = mgp_sparse_words(N) words per bit
  * row, row weights stored with the frame): same outputs, the products e_i A_t A_{t-1} .. evaluated row by row from HBM. */
 int  mgp_replay_gather_rows(const float* feat, const unsigned long long* bits, const float* wrow, const float* label,

@@ -114,7 +114,9 @@ SIGNATURES = {
     'mgp_sparse_to_dense': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     'mgp_sparse_force_direct': (_int, [_int]),
     'mgp_sparse_rollout': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int,
-                                  ctypes.POINTER(_int), ctypes.POINTER(_int), _vp, _vp]),
+                                  ctypes.POINTER(_int), ctypes.POINTER(_int), _vp, _vp, _vp]),
+    'mgp_flock_step_cells_nbr': (_int, [_vp, _vp, _vp, _long, _long, _vp, _long, _vp, _long, _vp, _long, _vp, _long, _vp, _vp,
+                                        _vp, _int, _int, _vp]),
     'mgp_sparse_policy_collect': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _int, _int, _int, _int, _int, _vp, _vp]),
     'mgp_replay_gather_rows': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     'mgp_train_step': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _f32, _f32, _f32, _f32, _vp,

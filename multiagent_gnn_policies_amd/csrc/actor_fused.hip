@@ -882,10 +882,7 @@ int launch_fwd_mfma(const float* X, const float* G, float* out, float* saved, co
                     int B, int K, int N, hipStream_t st)
 {
     const size_t lds = (size_t)pm.cv.total * sizeof(float);
-    if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(actor_fwd_mfma_kernel<S, FH>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return MGP_ELAUNCH;
+    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(actor_fwd_mfma_kernel<S, FH>), lds) != hipSuccess) return MGP_ELAUNCH;
     hipLaunchKernelGGL((actor_fwd_mfma_kernel<S, FH>), dim3((unsigned)B), dim3(AF_THREADS), lds, st,
                        X, G, out, saved, P, pm.wc, pm.cv, B, K, N, pm.nblk);
     return mgp_launch_status();
@@ -896,10 +893,7 @@ int launch_fwd(const float* X, const float* G, float* out, float* saved, const A
                int B, int K, int N, hipStream_t st)
 {
     const size_t lds = (size_t)pl.cv.total * sizeof(float);
-    if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(actor_fwd_kernel<CT, V>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return MGP_ELAUNCH;
+    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(actor_fwd_kernel<CT, V>), lds) != hipSuccess) return MGP_ELAUNCH;
     hipLaunchKernelGGL((actor_fwd_kernel<CT, V>), dim3((unsigned)(((B + 7) / 8) * 8 * pl.ntiles)), dim3(AF_THREADS), lds, st,
                        X, G, out, saved, P, pl.cv, B, K, N, pl.tw, pl.ntiles, pl.R, pl.MC, pl.ncp);
     return mgp_launch_status();
@@ -1042,8 +1036,7 @@ extern "C" int mgp_actor_bwd(const float* dOut, const float* saved, const float*
     mgp_clear_error();
     const void* kfn = (cols == 64) ? reinterpret_cast<const void*>(actor_bwd_kernel<64>)
                                    : reinterpret_cast<const void*>(actor_bwd_kernel<16>);
-    if (lds > 48 * 1024 && hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return MGP_ELAUNCH;
+    if (mgp_allow_dyn_lds(kfn, lds) != hipSuccess) return MGP_ELAUNCH;
     const int ntx = (N + cols - 1) / cols;
     if (cols == 64)
         hipLaunchKernelGGL(actor_bwd_kernel<64>, dim3(ntx, B), dim3(AB_THREADS), lds, st, dOut, saved, workspace, P, Ptot, K, N,

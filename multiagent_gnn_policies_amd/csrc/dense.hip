@@ -202,11 +202,7 @@ extern "C" int mgp_dense_bwd(const float* dOut, const float* out, const float* i
     dim3 grid(ntx, T, B);
     const size_t lds = ((size_t)Cout * 65 + (size_t)DN_CC * 65) * sizeof(float);
     if (lds > 150 * 1024) return MGP_EUNSUPPORTED;
-    if (lds > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dense_bwd_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return MGP_ELAUNCH;
-    }
+    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(dense_bwd_kernel), lds) != hipSuccess) return MGP_ELAUNCH;
     hipLaunchKernelGGL(dense_bwd_kernel, grid, dim3(DN_THREADS), lds, st, dOut, out, in, W, workspace, dIn,
                        Cin, Cout, T, N, sib, sic, sit, act);
     int rc = mgp_launch_status();

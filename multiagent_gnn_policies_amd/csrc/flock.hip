@@ -416,9 +416,7 @@ int launch_step(const double* x, double* xo, const float* u, long su_agent, long
     const int jh = (o.bits != nullptr) ? ((((N + PIECES - 1) / PIECES) + 63) & ~63) : (N + PIECES - 1) / PIECES;
     const size_t lds = ((size_t)4 * N + PIECES * ROWS * 8 + ROWS + (size_t)ROWS * PIECES * ((jh + 63) / 64)) *
                            sizeof(double) + (o.adv ? (((size_t)ROWS * N + 15) & ~(size_t)15) : 0);     // + one byte-indexed neighbour list per row
-    if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(flock_step_kernel<FUSE, THREADS, ROWS, PIECES>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(flock_step_kernel<FUSE, THREADS, ROWS, PIECES>), lds) != hipSuccess)
         return MGP_ELAUNCH;
     dim3 grid(mgp_ceil_div(N, ROWS) + ((o.sep_reward || o.adv) ? 1 : 0), B);
     FlockOut ov = o;

@@ -256,17 +256,11 @@ int launch_gso(const float* A, long sAb, int mode, const float* src, float* dst,
     const int nslots = nrt + extra;
     dim3 grid((unsigned)(((B + 7) / 8) * 8 * nslots));
     if (vec) {
-        if (lds > 48 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(gso_rows_kernel<4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return MGP_ELAUNCH;
+        if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(gso_rows_kernel<4>), lds) != hipSuccess) return MGP_ELAUNCH;
         hipLaunchKernelGGL((gso_rows_kernel<4>), grid, dim3(GSO_THREADS), lds, st, A, src, dst, sAb, mode, B, K, N,
                            j_lo, j_hi, write_base, has_prev, nrt, nslots, X_t, Xd_prev, Xd_next, F);
     } else {
-        if (lds > 48 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(gso_rows_kernel<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return MGP_ELAUNCH;
+        if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(gso_rows_kernel<1>), lds) != hipSuccess) return MGP_ELAUNCH;
         hipLaunchKernelGGL((gso_rows_kernel<1>), grid, dim3(GSO_THREADS), lds, st, A, src, dst, sAb, mode, B, K, N,
                            j_lo, j_hi, write_base, has_prev, nrt, nslots, X_t, Xd_prev, Xd_next, F);
     }

@@ -68,3 +68,24 @@ __device__ __forceinline__ void mgp_adam_elem(float& p, float& m, float& v, floa
     m = mi;
     v = vi;
 }
+
+// Raise a kernel's dynamic-LDS limit ONCE per (kernel, size) and thread: hipFuncSetAttribute is a driver call -- measured at up
+// to 0.35 ms per call in some processes, during which the runtime also held back the submission of launches already enqueued
+// (a 100-step loop of launches with one call each sat on the host for 35 ms before the first kernel started).
+inline hipError_t mgp_allow_dyn_lds(const void* fn, size_t lds)
+{
+    struct Entry { const void* fn; size_t lds; };
+    static thread_local Entry tab[96];
+    static thread_local int used = 0;
+    if (lds <= 48 * 1024) return hipSuccess;
+    for (int i = 0; i < used; ++i)
+        if (tab[i].fn == fn) {
+            if (tab[i].lds >= lds) return hipSuccess;
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) tab[i].lds = lds;
+            return e;
+        }
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess && used < 96) { tab[used].fn = fn; tab[used].lds = lds; ++used; }
+    return e;
+}

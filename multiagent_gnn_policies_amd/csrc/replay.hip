@@ -181,10 +181,7 @@ extern "C" int mgp_replay_gather_rows(const float* feat, const unsigned long lon
     const long gy = 1 + (long)(K - 1) * ((N + 3) / 4);
     if (gy > 65535) return MGP_EUNSUPPORTED;
     mgp_clear_error();
-    if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(replay_gather_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            lds) != hipSuccess)
-        return MGP_ELAUNCH;
+    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(replay_gather_rows_kernel), (size_t)lds) != hipSuccess) return MGP_ELAUNCH;
     hipLaunchKernelGGL(replay_gather_rows_kernel, dim3(Bt * nb, (unsigned)gy), dim3(RG_THREADS), lds,
                        static_cast<hipStream_t>(stream), feat, bits, wrow, label, age, idx, cursor, Bt, lanes, ring_steps, K, N,
                        NW, X, G, Y);

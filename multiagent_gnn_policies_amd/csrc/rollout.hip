@@ -1869,10 +1869,10 @@ extern "C" int mgp_rollout_carry_to_dense(const void* carry, float* G, int B, in
     hipStream_t st = static_cast<hipStream_t>(stream);
     const unsigned long long* c = static_cast<const unsigned long long*>(carry);
     if (NW == 2) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(carry_to_dense_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MGP_ELAUNCH;
+        if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(carry_to_dense_kernel<2>), (size_t)lds) != hipSuccess) return MGP_ELAUNCH;
         hipLaunchKernelGGL((carry_to_dense_kernel<2>), dim3(B), dim3(RO_THREADS), lds, st, c, G, K, N);
     } else {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(carry_to_dense_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MGP_ELAUNCH;
+        if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(carry_to_dense_kernel<4>), (size_t)lds) != hipSuccess) return MGP_ELAUNCH;
         hipLaunchKernelGGL((carry_to_dense_kernel<4>), dim3(B), dim3(RO_THREADS), lds, st, c, G, K, N);
     }
     return mgp_launch_status();

@@ -93,6 +93,8 @@ struct SpPolicy {
     const float* wq; long sWb;
     const float* image;                   // weight image (sp_weight_image_kernel), wtot floats
     int wtot;
+    const unsigned short* nbr;            // compact neighbour rows of the last stage's network (staged form with lists), or NULL
+    long sNbr;
 };
 
 // DAGGER data collection on the factored state (gnn_dagger.py:154-178; the semantics of rollout.hip's collecting build):
@@ -254,6 +256,50 @@ __device__ __forceinline__ void spl_gather_word(unsigned long long w, int base, 
     }
 }
 
+// one neighbour entry m: lw[m] * ls[tap][m][0..5] for all taps of the stage
+template <int NT>
+__device__ __forceinline__ void spl_gather_entry(int m, const float* lw, const float* ls, int N, float (&sa)[NT][6])
+{
+    const float gv = lw[m];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float* r = ls + ((size_t)t * N + m) * 8;
+        const float4 x0 = *reinterpret_cast<const float4*>(r);
+        const float2 x1 = *reinterpret_cast<const float2*>(r + 4);
+        sa[t][0] = fmaf(x0.x, gv, sa[t][0]); sa[t][1] = fmaf(x0.y, gv, sa[t][1]); sa[t][2] = fmaf(x0.z, gv, sa[t][2]);
+        sa[t][3] = fmaf(x0.w, gv, sa[t][3]); sa[t][4] = fmaf(x1.x, gv, sa[t][4]); sa[t][5] = fmaf(x1.y, gv, sa[t][5]);
+    }
+}
+
+// The column from its compact LIST (mgp_flock_step_cells_nbr: 32 bytes per row instead of the 128-byte bit row at N = 1000
+// to request, and the entries dealt evenly): `lst` = this lane's 8 bytes of the row = entries part, part + 4, part + 8,
+// part + 12; the count sits in the last u16 of lane 3.  Count 0xFFFF (more than 15 neighbours): the bit row, from global.
+template <int NT>
+__device__ __forceinline__ void spl_gather_list(uint2 lst, int part, const unsigned long long* __restrict__ brow, int wpl,
+                                                const float* lw, const float* ls, int N, bool live, float (&sa)[NT][6])
+{
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int f = 0; f < 6; ++f) sa[t][f] = 0.f;
+    const unsigned int cntw = dpp_u<0xFF>(lst.y) >> 16;
+    if (live) {
+        if (cntw != 0xFFFFu) {
+            const int mine = ((int)cntw - part + 3) >> 2;
+            for (int k = 0; k < mine; ++k) {
+                const unsigned int pair = (k < 2) ? lst.x : lst.y;
+                spl_gather_entry<NT>((int)((k & 1) ? (pair >> 16) : (pair & 0xFFFFu)), lw, ls, N, sa);
+            }
+        } else {
+            for (int q = 0; q < wpl; ++q) spl_gather_word<NT>(brow[q], 64 * (part * wpl + q), lw, ls, N, sa);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int f = 0; f < 6; ++f) { sa[t][f] += dpp_f<0xB1>(sa[t][f]); sa[t][f] += dpp_f<0x4E>(sa[t][f]); }
+}
+
 // the column's words of this lane (a quarter of the row): the first four from registers (requested before the staging
 // barrier; N <= 1024 has no more), the rest from global memory
 template <int NT>
@@ -277,10 +323,10 @@ __device__ __forceinline__ void spl_gather_column(const unsigned long long (&wre
 }
 
 // grid: x = tile of 256 columns, y = b.  LDS: lw [Np] | ls [NT][N][8]
-template <int NT>
+template <int NT, bool LS>
 __global__ __launch_bounds__(SPL_THREADS)
 void spl_gather_kernel(const unsigned long long* __restrict__ bits, long sBb, const float* __restrict__ wq, long sWb,
-                       SpTaps T, int N, int NW)
+                       SpTaps T, int N, int NW, const unsigned short* __restrict__ nbr, long sNb)
 {
     extern __shared__ __attribute__((aligned(16))) float spm[];
     const int Np = (N + 3) & ~3;
@@ -297,8 +343,12 @@ void spl_gather_kernel(const unsigned long long* __restrict__ bits, long sBb, co
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     SP_STAMP(0, 5);
 #endif
+    uint2 lst = make_uint2(0u, 0u);
+    if (LS) lst = *reinterpret_cast<const uint2*>(nbr + (size_t)b * sNb + (size_t)min(n, N - 1) * 16 + 4 * part);
+    else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) wreg[q] = (q < wpl) ? brow[q] : 0ull;
+        for (int q = 0; q < 4; ++q) wreg[q] = (q < wpl) ? brow[q] : 0ull;
+    }
     // every request of the copy is issued before the first LDS store (a copy loop is one memory round trip PER ITERATION:
     // 8k cycles for five of them); N > 1024 finishes with plain loops
     float4 rr[NT][2];
@@ -336,7 +386,8 @@ void spl_gather_kernel(const unsigned long long* __restrict__ bits, long sBb, co
     __syncthreads();
     SP_STAMP(0, 2);
     float sa[NT][6];
-    spl_gather_column<NT>(wreg, brow, wpl, part * wpl, lw, ls, N, live, sa);
+    if (LS) spl_gather_list<NT>(lst, part, brow, wpl, lw, ls, N, live, sa);
+    else spl_gather_column<NT>(wreg, brow, wpl, part * wpl, lw, ls, N, live, sa);
     SP_STAMP(0, 3);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -349,7 +400,7 @@ void spl_gather_kernel(const unsigned long long* __restrict__ bits, long sBb, co
 }
 
 // grid: x = tile of 256 columns, y = b.  LDS: act [256][RO_CS] | weight image | lw [Np] | ls [N][8]
-template <bool CL>
+template <bool CL, bool LS>
 __global__ __launch_bounds__(SPL_THREADS)
 void spl_policy_kernel(SpPolicy P, float* __restrict__ action, int K, int N, int NW, unsigned long long dimsA,
                        unsigned int dims8, unsigned long long woffA, unsigned long long woffB, int n_layers, SpCollect C)
@@ -368,9 +419,13 @@ void spl_policy_kernel(SpPolicy P, float* __restrict__ action, int K, int N, int
     const unsigned long long* brow = P.bits + (size_t)b * P.sBb + (size_t)min(gn, N - 1) * NW + part * wpl;
     unsigned long long wreg[4] = {0ull, 0ull, 0ull, 0ull};
     SP_STAMP(1, 0);
+    uint2 lst = make_uint2(0u, 0u);
     if (K >= 2) {
+        if (LS) lst = *reinterpret_cast<const uint2*>(P.nbr + (size_t)b * P.sNbr + (size_t)min(gn, N - 1) * 16 + 4 * part);
+        else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wreg[q] = (q < wpl) ? brow[q] : 0ull;
+            for (int q = 0; q < 4; ++q) wreg[q] = (q < wpl) ? brow[q] : 0ull;
+        }
     }
     // every request is issued before the first LDS store of the copies (see spl_gather_kernel): the weight image, the input
     // rows and weights of the last stage (every row of the episode), the finished taps of the own columns (tap 0 = x_t itself)
@@ -441,7 +496,8 @@ void spl_policy_kernel(SpPolicy P, float* __restrict__ action, int K, int N, int
     SP_STAMP(1, 3);
     if (K >= 2) {                                              // last tap: its last factor is applied here
         float sa[1][6];
-        spl_gather_column<1>(wreg, brow, wpl, part * wpl, lw, ls, N, gn < N, sa);
+        if (LS) spl_gather_list<1>(lst, part, brow, wpl, lw, ls, N, gn < N, sa);
+        else spl_gather_column<1>(wreg, brow, wpl, part * wpl, lw, ls, N, gn < N, sa);
         if (part == 0 && gn < N) {
 #pragma unroll
             for (int f = 0; f < 6; ++f) act[gc * RO_CS + rpos(f * K + K - 1)] = sa[0][f];
@@ -496,20 +552,10 @@ void spl_policy_kernel(SpPolicy P, float* __restrict__ action, int K, int N, int
     SP_STAMP(1, 7);
 }
 
-// dynamic LDS of a staged kernel, raised once per kernel (hipFuncSetAttribute is a driver call)
 template <typename F>
 int spl_allow_lds(F* fn, size_t lds)
 {
-    static thread_local const void* done[16];
-    static thread_local size_t done_lds[16];
-    const void* key = reinterpret_cast<const void*>(fn);
-    for (int i = 0; i < 16; ++i)
-        if (done[i] == key && done_lds[i] >= lds) return MGP_OK;
-    if (lds > 48 * 1024 && hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return MGP_ELAUNCH;
-    for (int i = 0; i < 16; ++i)
-        if (done[i] == nullptr || done[i] == key) { done[i] = key; done_lds[i] = lds; break; }
-    return MGP_OK;
+    return mgp_allow_dyn_lds(reinterpret_cast<const void*>(fn), lds) == hipSuccess ? MGP_OK : MGP_ELAUNCH;
 }
 
 struct SpWeights {
@@ -583,7 +629,7 @@ void sp_to_dense_kernel(const unsigned long long* __restrict__ bits, const float
     }
 }
 
-bool sp_force_direct = false;             // mgp_sparse_force_direct (tests: both forms against the oracle)
+int sp_mode = 0;                          // mgp_sparse_force_direct: 0 default, 1 direct kernels, 2 staged kernels on bit rows only
 
 int sp_plan(const int* dims, int n_layers, int K, int* woff, int* wtot)
 {
@@ -640,8 +686,11 @@ extern "C" int mgp_sparse_policy_image(const float* const* W, const float* const
  * scratch: 2 * (K-1) * B * N * 8 floats for K >= 3 (running products between stages), else unused. */
 static int sp_policy_step(const unsigned long long* bits, const float* wrow, const float* feat,
                           const float* image, const int* dims, int n_layers, float* scratch, float* action,
-                          int B, int K, int N, int cur, int hs, const MgpSparseCollect* col, void* stream)
+                          int B, int K, int N, int cur, int hs, const MgpSparseCollect* col, const unsigned short* nbr,
+                          void* stream)
 {
+    if (sp_mode != 0) nbr = nullptr;
+    const long sN = (long)(K > 2 ? K - 1 : 1) * N * 16;
     int woff[MGP_MAX_LAYERS], wtot = 0;
     int rc = sp_plan(dims, n_layers, K, woff, &wtot);
     if (rc != MGP_OK) return rc;
@@ -673,20 +722,23 @@ static int sp_policy_step(const unsigned long long* bits, const float* wrow, con
         }
         const int s = hslot(q);
         const size_t glds = ((size_t)Np + (size_t)nt * N * 8) * sizeof(float);
-        if (!sp_force_direct && glds <= SPL_LDS_MAX) {             // staged form: source rows of all taps of the stage in LDS
+        if (sp_mode != 1 && glds <= SPL_LDS_MAX) {                  // staged form: source rows of all taps of the stage in LDS
             const dim3 gg(mgp_ceil_div(N, SPL_COLS), B), gb(SPL_THREADS);
             const unsigned long long* bq = bits + (size_t)s * N * NW;
             const float* wq_ = wrow + (size_t)s * N;
+            const unsigned short* nq = nbr != nullptr ? nbr + (size_t)s * N * 16 : nullptr;
+#define SPL_GO(NT_)                                                                                                              \
+            if (nq != nullptr) { rc = spl_allow_lds(spl_gather_kernel<NT_, true>, glds); if (rc) return rc;                       \
+                hipLaunchKernelGGL((spl_gather_kernel<NT_, true>), gg, gb, glds, st, bq, sB, wq_, sW, T, N, NW, nq, sN); }        \
+            else { rc = spl_allow_lds(spl_gather_kernel<NT_, false>, glds); if (rc) return rc;                                    \
+                hipLaunchKernelGGL((spl_gather_kernel<NT_, false>), gg, gb, glds, st, bq, sB, wq_, sW, T, N, NW, nq, sN); }
             switch (nt) {
-            case 1: rc = spl_allow_lds(spl_gather_kernel<1>, glds); if (rc) return rc;
-                    hipLaunchKernelGGL(spl_gather_kernel<1>, gg, gb, glds, st, bq, sB, wq_, sW, T, N, NW); break;
-            case 2: rc = spl_allow_lds(spl_gather_kernel<2>, glds); if (rc) return rc;
-                    hipLaunchKernelGGL(spl_gather_kernel<2>, gg, gb, glds, st, bq, sB, wq_, sW, T, N, NW); break;
-            case 3: rc = spl_allow_lds(spl_gather_kernel<3>, glds); if (rc) return rc;
-                    hipLaunchKernelGGL(spl_gather_kernel<3>, gg, gb, glds, st, bq, sB, wq_, sW, T, N, NW); break;
-            default: rc = spl_allow_lds(spl_gather_kernel<4>, glds); if (rc) return rc;
-                    hipLaunchKernelGGL(spl_gather_kernel<4>, gg, gb, glds, st, bq, sB, wq_, sW, T, N, NW); break;
+            case 1: SPL_GO(1) break;
+            case 2: SPL_GO(2) break;
+            case 3: SPL_GO(3) break;
+            default: SPL_GO(4) break;
             }
+#undef SPL_GO
         } else {
             hipLaunchKernelGGL(sp_gather_kernel, dim3(ntiles, nt, B), dim3(SP_THREADS), 0, st, bits + (size_t)s * N * NW, sB,
                                wrow + (size_t)s * N, sW, T, N, NW);
@@ -703,6 +755,7 @@ static int sp_policy_step(const unsigned long long* bits, const float* wrow, con
         const int s = hslot(K - 1);
         P.bits = bits + (size_t)s * N * NW; P.sBb = sB;
         P.wq = wrow + (size_t)s * N; P.sWb = sW;
+        P.nbr = nbr != nullptr ? nbr + (size_t)s * N * 16 : nullptr; P.sNbr = sN;
     }
     P.image = image; P.wtot = wtot;
     unsigned long long dimsA = 0ull, woffA = 0ull, woffB = 0ull;
@@ -718,7 +771,8 @@ static int sp_policy_step(const unsigned long long* bits, const float* wrow, con
     }
     const size_t lds = ((size_t)SP_COLS * RO_CS + wtot) * sizeof(float);
     const size_t plds = ((size_t)SPL_COLS * RO_CS + ((wtot + 3) & ~3) + (K >= 2 ? (size_t)Np + (size_t)N * 8 : 0)) * sizeof(float);
-    const bool staged = !sp_force_direct && plds <= SPL_LDS_MAX;
+    const bool staged = sp_mode != 1 && plds <= SPL_LDS_MAX;
+    const bool lists = staged && K >= 2 && P.nbr != nullptr;
     const dim3 pg(mgp_ceil_div(N, SPL_COLS), B);
     SpCollect C = {};
     if (col != nullptr) {
@@ -727,18 +781,26 @@ static int sp_policy_step(const unsigned long long* bits, const float* wrow, con
         C.label = col->label + fr * 2 * N; C.age = col->age + fr;
         C.net = bits + (size_t)hs * N * NW; C.sNb = sB; C.wnet = wrow + (size_t)hs * N; C.sWn = sW;
         C.expert = col->expert; C.beta = col->beta; C.episode = col->episode; C.seed = col->seed; C.age_now = col->age_now;
-        if (staged) {
-            rc = spl_allow_lds(spl_policy_kernel<true>, plds); if (rc) return rc;
-            hipLaunchKernelGGL(spl_policy_kernel<true>, pg, dim3(SPL_THREADS), plds, st, P, action, K, N, NW, dimsA, dims8, woffA,
-                               woffB, n_layers, C);
+        if (staged && lists) {
+            rc = spl_allow_lds(spl_policy_kernel<true, true>, plds); if (rc) return rc;
+            hipLaunchKernelGGL((spl_policy_kernel<true, true>), pg, dim3(SPL_THREADS), plds, st, P, action, K, N, NW, dimsA, dims8,
+                               woffA, woffB, n_layers, C);
+        } else if (staged) {
+            rc = spl_allow_lds(spl_policy_kernel<true, false>, plds); if (rc) return rc;
+            hipLaunchKernelGGL((spl_policy_kernel<true, false>), pg, dim3(SPL_THREADS), plds, st, P, action, K, N, NW, dimsA, dims8,
+                               woffA, woffB, n_layers, C);
         } else {
             hipLaunchKernelGGL(sp_policy_kernel<true>, dim3(ntiles, B), dim3(SP_THREADS), lds, st, P, action, K, N, NW, dimsA,
                                dims8, woffA, woffB, n_layers, C);
         }
+    } else if (staged && lists) {
+        rc = spl_allow_lds(spl_policy_kernel<false, true>, plds); if (rc) return rc;
+        hipLaunchKernelGGL((spl_policy_kernel<false, true>), pg, dim3(SPL_THREADS), plds, st, P, action, K, N, NW, dimsA, dims8,
+                           woffA, woffB, n_layers, C);
     } else if (staged) {
-        rc = spl_allow_lds(spl_policy_kernel<false>, plds); if (rc) return rc;
-        hipLaunchKernelGGL(spl_policy_kernel<false>, pg, dim3(SPL_THREADS), plds, st, P, action, K, N, NW, dimsA, dims8, woffA,
-                           woffB, n_layers, C);
+        rc = spl_allow_lds(spl_policy_kernel<false, false>, plds); if (rc) return rc;
+        hipLaunchKernelGGL((spl_policy_kernel<false, false>), pg, dim3(SPL_THREADS), plds, st, P, action, K, N, NW, dimsA, dims8,
+                           woffA, woffB, n_layers, C);
     } else {
         hipLaunchKernelGGL(sp_policy_kernel<false>, dim3(ntiles, B), dim3(SP_THREADS), lds, st, P, action, K, N, NW, dimsA,
                            dims8, woffA, woffB, n_layers, C);
@@ -747,10 +809,10 @@ static int sp_policy_step(const unsigned long long* bits, const float* wrow, con
 }
 
 /* Test hook: 1 = keep the direct (global-memory) gather / policy kernels even where the staged forms fit; returns the old value. */
-extern "C" int mgp_sparse_force_direct(int on)
+extern "C" int mgp_sparse_force_direct(int mode)
 {
-    const int old = sp_force_direct ? 1 : 0;
-    sp_force_direct = on != 0;
+    const int old = sp_mode;
+    sp_mode = (mode == 1 || mode == 2) ? mode : 0;
     return old;
 }
 
@@ -758,7 +820,7 @@ extern "C" int mgp_sparse_policy_step(const unsigned long long* bits, const floa
                                       const float* image, const int* dims, int n_layers, float* scratch, float* action,
                                       int B, int K, int N, int cur, int hs, void* stream)
 {
-    return sp_policy_step(bits, wrow, feat, image, dims, n_layers, scratch, action, B, K, N, cur, hs, nullptr, stream);
+    return sp_policy_step(bits, wrow, feat, image, dims, n_layers, scratch, action, B, K, N, cur, hs, nullptr, nullptr, stream);
 }
 
 /* The same evaluation as one collected DAGGER step (see SpCollect): files the frame of the current state at ring step
@@ -772,7 +834,7 @@ extern "C" int mgp_sparse_policy_collect(const unsigned long long* bits, const f
     MGP_CHECK_PTR(col->age); MGP_CHECK_PTR(col->expert); MGP_CHECK_PTR(col->beta); MGP_CHECK_PTR(col->episode);
     if (reinterpret_cast<uintptr_t>(col->expert) & 7u) return MGP_EALIGN;
     if (col->ring_steps < 1 || col->ring_step < 0 || col->ring_step >= col->ring_steps || col->age_now < 0) return MGP_EINVAL;
-    return sp_policy_step(bits, wrow, feat, image, dims, n_layers, scratch, action, B, K, N, cur, hs, col, stream);
+    return sp_policy_step(bits, wrow, feat, image, dims, n_layers, scratch, action, B, K, N, cur, hs, col, nullptr, stream);
 }
 
 /* T closed-loop steps on the factored state, enqueued from one call (the loop of learner/sparse_rollout.py without a host
@@ -783,9 +845,10 @@ extern "C" int mgp_sparse_policy_collect(const unsigned long long* bits, const f
 extern "C" int mgp_sparse_rollout(unsigned long long* bits, float* wrow, float* feat, const float* image, const int* dims,
                                   int n_layers, float* scratch, float* action, double* x_a, double* x_b, double* rewards,
                                   float* expert, const MgpFlockParams* p, int B, int K, int N, int T, int* cur, int* hs,
-                                  const MgpSparseCollect* collect, void* stream)
+                                  const MgpSparseCollect* collect, unsigned short* nbr, void* stream)
 {
     if (cur == nullptr || hs == nullptr || T < 0 || p == nullptr) return MGP_EINVAL;
+    if (N > 2048) nbr = nullptr;                               // (the all-pairs simulator does not write lists)
     if (collect != nullptr && expert == nullptr) return MGP_EINVAL;
     const int H = K > 2 ? K - 1 : 1;
     const int NW = mgp_sparse_words(N);
@@ -794,9 +857,13 @@ extern "C" int mgp_sparse_rollout(unsigned long long* bits, float* wrow, float* 
     if (collect != nullptr) col = *collect;
     double* xs[2] = {x_a, x_b};
     for (int t = 0; t < T; ++t) {
-        int rc = (collect != nullptr)
-            ? mgp_sparse_policy_collect(bits, wrow, feat, image, dims, n_layers, scratch, action, B, K, N, c, h, &col, stream)
-            : mgp_sparse_policy_step(bits, wrow, feat, image, dims, n_layers, scratch, action, B, K, N, c, h, stream);
+        if (collect != nullptr) {
+            MGP_CHECK_PTR(col.feat); MGP_CHECK_PTR8(col.bits); MGP_CHECK_PTR(col.wrow); MGP_CHECK_PTR(col.label);
+            MGP_CHECK_PTR(col.age); MGP_CHECK_PTR(col.expert); MGP_CHECK_PTR(col.beta); MGP_CHECK_PTR(col.episode);
+            if (col.ring_steps < 1 || col.ring_step < 0 || col.ring_step >= col.ring_steps || col.age_now < 0) return MGP_EINVAL;
+        }
+        int rc = sp_policy_step(bits, wrow, feat, image, dims, n_layers, scratch, action, B, K, N, c, h,
+                                collect != nullptr ? &col : nullptr, nbr, stream);
         if (rc != MGP_OK) return rc;
         const int nh = (h + 1) % H, nc = (c + 1) % K;
         double* rw = rewards != nullptr ? rewards + (size_t)t * B : nullptr;
@@ -805,8 +872,9 @@ extern "C" int mgp_sparse_rollout(unsigned long long* bits, float* wrow, float* 
         float* fq = feat + (size_t)nc * N * 8;
         // the Actor's output layout (B,1,2,N): agent stride 1, axis stride N
         rc = (N <= 2048)
-            ? mgp_flock_step_cells(xs[t & 1], xs[(t & 1) ^ 1], action, 1, N, bq, (long)H * N * NW, wq, (long)H * N, fq,
-                                   (long)K * N * 8, rw, expert, p, B, N, stream)
+            ? mgp_flock_step_cells_nbr(xs[t & 1], xs[(t & 1) ^ 1], action, 1, N, bq, (long)H * N * NW, wq, (long)H * N, fq,
+                                       (long)K * N * 8, nbr != nullptr ? nbr + (size_t)nh * N * 16 : nullptr, (long)H * N * 16,
+                                       rw, expert, p, B, N, stream)
             : mgp_flock_step_sparse(xs[t & 1], xs[(t & 1) ^ 1], action, 1, N, bq, (long)H * N * NW, wq, (long)H * N, fq,
                                     (long)K * N * 8, rw, expert, p, B, N, stream);
         if (rc != MGP_OK) return rc;
@@ -830,10 +898,7 @@ extern "C" int mgp_sparse_to_dense(const unsigned long long* bits, const float* 
     const int NW = mgp_sparse_words(N);
     const size_t lds = (size_t)4 * 2 * ((N + 3) & ~3) * sizeof(float);
     mgp_clear_error();
-    if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(sp_to_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-        return MGP_ELAUNCH;
+    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(sp_to_dense_kernel), lds) != hipSuccess) return MGP_ELAUNCH;
     hipLaunchKernelGGL(sp_to_dense_kernel, dim3(mgp_ceil_div(N, 4), B), dim3(SP_THREADS), lds, static_cast<hipStream_t>(stream),
                        bits, wrow, G, K, H, N, NW, hs);
     return mgp_launch_status();

@@ -61,6 +61,8 @@ __device__ __forceinline__ int ss_wave_scan(int v)
 struct SsOut {
     unsigned long long* bits; float* wq; float* featT; long sBb, sWb, sTb;
     double* reward; float* expert;
+    unsigned short* nbr; long sNb;          // optional compact neighbour rows (see mgp_flock_step_cells_nbr), batch stride in u16
+    int nbl_on;                             // LDS room for assembling them
 };
 
 // grid: x = tile of 256 rows, y = b.
@@ -87,6 +89,7 @@ void sp_sim_kernel(const double* __restrict__ x, double* __restrict__ xo, const 
         (reinterpret_cast<uintptr_t>(sorted + N4) + 7) & ~(uintptr_t)7);
     unsigned short* sub = reinterpret_cast<unsigned short*>(rowbits + (size_t)SS_ROWS * (NW + 1));   // [1024][subcap] hits of a lane
     float2* posf = reinterpret_cast<float2*>((reinterpret_cast<uintptr_t>(sub + (size_t)SS_THREADS * subcap) + 7) & ~(uintptr_t)7);
+    unsigned short* nbl = reinterpret_cast<unsigned short*>(posf + (PRE ? N : 0));                    // [256][16] list rows being assembled
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
     const int i0 = blockIdx.x * SS_ROWS;
     const int RSW = NW + 1;                                   // odd word stride per row
@@ -325,6 +328,29 @@ void sp_sim_kernel(const double* __restrict__ x, double* __restrict__ xo, const 
         // Pass 2: the row's hits -- the four lists one after the other -- dealt round-robin to the four lanes
         const int c0 = (int)dpp_u<0x00>((unsigned int)cnt), c1 = (int)dpp_u<0x55>((unsigned int)cnt);
         const int c2 = (int)dpp_u<0xAA>((unsigned int)cnt), c3 = (int)dpp_u<0xFF>((unsigned int)cnt);
+        if (o.nbr != nullptr) {
+            // the row as a compact LIST for the gather launches of the policy step (32 bytes to stage instead of the 128-byte
+            // bit row at N = 1000, and evenly dealt entries): entry e of the concatenated lists at u16 position
+            // (e & 3) * 4 + (e >> 2) -- lane q of a gathering quad reads entries q, q + 4, q + 8, q + 12 as one 8-byte word --
+            // and the count at position 15; 0xFFFF there: more than 15 neighbours (or no list memory), use the bit row
+            const int tot = c0 + c1 + c2 + c3;
+            const bool fits = tot <= 15 && max(max(c0, c1), max(c2, c3)) <= subcap;
+            if (!o.nbl_on) {                                      // no LDS left for the assembly (N near 2048): bit rows only
+                if (part == 3) o.nbr[(size_t)b * o.sNb + (size_t)i * 16 + 15] = (unsigned short)0xFFFF;
+            } else {
+            unsigned short* lrow = nbl + (size_t)r * 16;
+            *reinterpret_cast<uint2*>(lrow + 4 * part) = make_uint2(0u, part == 3 ? ((fits ? (unsigned int)tot : 0xFFFFu) << 16) : 0u);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            if (fits) {
+                const int off = part == 0 ? 0 : (part == 1 ? c0 : (part == 2 ? c0 + c1 : c0 + c1 + c2));
+                for (int k = 0; k < cnt; ++k) { const int e = off + k; lrow[(e & 3) * 4 + (e >> 2)] = mine[k]; }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            *reinterpret_cast<uint2*>(o.nbr + (size_t)b * o.sNb + (size_t)i * 16 + 4 * part) = *reinterpret_cast<const uint2*>(lrow + 4 * part);
+            }
+        }
         if (max(max(c0, c1), max(c2, c3)) <= subcap) {
             const int tot = c0 + c1 + c2 + c3;
             const unsigned short* rowsub = sub + (size_t)(tid & ~3) * subcap;
@@ -379,10 +405,13 @@ void sp_sim_kernel(const double* __restrict__ x, double* __restrict__ xo, const 
 
 }  // namespace
 
-/* mgp_flock_step_sparse with a cell list (see the top of this file).  Same arguments and outputs; N <= 2048. */
-extern "C" int mgp_flock_step_cells(const double* x, double* x_out, const float* u, long su_agent, long su_axis,
-                                    unsigned long long* bits, long sBb, float* wrow, long sWb, float* featT, long sTb,
-                                    double* reward, float* expert, const MgpFlockParams* p, int B, int N, void* stream)
+/* mgp_flock_step_cells that also writes every row as a compact neighbour list (nbr: (N,16) u16 per episode, batch stride sNb):
+ * up to 15 neighbour indices -- entry e at position (e & 3) * 4 + (e >> 2) -- and the count at position 15 (0xFFFF: use the bit
+ * row).  The order of a row's entries is a deterministic function of the state.  nbr may be NULL. */
+extern "C" int mgp_flock_step_cells_nbr(const double* x, double* x_out, const float* u, long su_agent, long su_axis,
+                                        unsigned long long* bits, long sBb, float* wrow, long sWb, float* featT, long sTb,
+                                        unsigned short* nbr, long sNb, double* reward, float* expert, const MgpFlockParams* p,
+                                        int B, int N, void* stream)
 {
     if (B < 0 || N <= 0 || p == nullptr) return MGP_EINVAL;
     if (!(p->comm_radius2 > 0.0) || !(p->dt > 0.0) || p->n_leaders < 0) return MGP_EINVAL;
@@ -401,18 +430,19 @@ extern "C" int mgp_flock_step_cells(const double* x, double* x_out, const float*
     // fp32 positions for the pre-filter of the membership tests where they fit besides
     const size_t cap_lds = 160 * 1024;
     const int subcap = (lds0 + (size_t)SS_THREADS * 16 * 2 <= cap_lds) ? 16 : ((lds0 + (size_t)SS_THREADS * 8 * 2 <= cap_lds) ? 8 : 0);
-    const size_t lds1 = lds0 + (size_t)SS_THREADS * subcap * 2 + 8;
+    const size_t lds1a = lds0 + (size_t)SS_THREADS * subcap * 2 + 8;
+    const bool nbl_on = nbr != nullptr && subcap > 0 && lds1a + (size_t)SS_ROWS * 16 * 2 <= cap_lds;
+    const size_t lds1 = lds1a + (nbl_on ? (size_t)SS_ROWS * 16 * 2 : 0);
     const bool pre = lds1 + (size_t)N * 8 <= cap_lds;
     const size_t lds = lds1 + (pre ? (size_t)N * 8 : 0);
-    SsOut o = {bits, wrow, featT, sBb, sWb, sTb, reward, expert};
+    if (nbr != nullptr && ((reinterpret_cast<uintptr_t>(nbr) & 7u) || (sNb & 3))) return MGP_EALIGN;
+    SsOut o = {bits, wrow, featT, sBb, sWb, sTb, reward, expert, nbr, sNb, nbl_on ? 1 : 0};
     mgp_clear_error();
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(mgp_ceil_div(N, SS_ROWS), B);
     const bool fade = p->link_drop != 0u;
     auto go = [&](auto kern) -> int {
-        if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   (int)lds) != hipSuccess)
-            return MGP_ELAUNCH;
+        if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return MGP_ELAUNCH;
         hipLaunchKernelGGL(kern, grid, dim3(SS_THREADS), lds, st, x, x_out, u, su_agent, su_axis, o, *p, N, NW, subcap);
         return MGP_OK;
     };
@@ -421,4 +451,13 @@ extern "C" int mgp_flock_step_cells(const double* x, double* x_out, const float*
     else rc = pre ? go(sp_sim_kernel<false, true>) : go(sp_sim_kernel<false, false>);
     if (rc != MGP_OK) return rc;
     return mgp_launch_status();
+}
+
+/* mgp_flock_step_sparse with a cell list (see the top of this file).  Same arguments and outputs; N <= 2048. */
+extern "C" int mgp_flock_step_cells(const double* x, double* x_out, const float* u, long su_agent, long su_axis,
+                                    unsigned long long* bits, long sBb, float* wrow, long sWb, float* featT, long sTb,
+                                    double* reward, float* expert, const MgpFlockParams* p, int B, int N, void* stream)
+{
+    return mgp_flock_step_cells_nbr(x, x_out, u, su_agent, su_axis, bits, sBb, wrow, sWb, featT, sTb, nullptr, 0, reward, expert,
+                                    p, B, N, stream);
 }

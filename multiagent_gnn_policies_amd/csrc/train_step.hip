@@ -479,10 +479,7 @@ int launch_train(const float* X, const float* G, const float* target, const floa
     const int Pstride = pl.Ptot + 1;
     const long n_out = (long)B * dims[n_layers] * N;
     mgp_clear_error();
-    if (pl.lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(train_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)pl.lds) != hipSuccess)
-        return MGP_ELAUNCH;
+    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(train_tile_kernel), pl.lds) != hipSuccess) return MGP_ELAUNCH;
     hipLaunchKernelGGL(train_tile_kernel, dim3(pl.ntx, B), dim3(TS_THREADS), pl.lds, st, X, G, target, workspace, P, Pstride,
                        K, dims[0], N, pl.MP, pl.MC, pl.acts_floats, pl.maxw, 2.0f / (float)n_out);
     int rc = mgp_launch_status();

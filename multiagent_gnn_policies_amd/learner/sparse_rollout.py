@@ -19,6 +19,10 @@ from .. import _lib, ops
 from .actor_fused import _ptr_array
 
 
+import os
+_NOLISTS = os.environ.get('MGP_SP_NOLISTS', '0') == '1'        # debugging aid: keep the gather launches on the bit rows
+
+
 class SparseFlockState(object):
     """Bit rows / row weights / features of B episodes of `sim` (VecFlock), ring-indexed over time."""
 
@@ -31,6 +35,11 @@ class SparseFlockState(object):
         self.wrow = torch.zeros((self.B, self.H, self.N), device=dev, dtype=torch.float32)
         self.feat = torch.zeros((self.B, K, self.N, 8), device=dev, dtype=torch.float32)
         self.scratch = torch.zeros((max(1, 2 * (K - 1) * self.B * self.N * 8),), device=dev, dtype=torch.float32)
+        # the same networks once more as compact neighbour lists (mgp_flock_step_cells_nbr; the gather launches read these
+        # instead of the bit rows).  Valid while every network of the ring was written by the cell-list simulator.
+        self.nbr = (torch.zeros((self.B, self.H, self.N, 16), device=dev, dtype=torch.int16)
+                    if (self.N <= 2048 and not _NOLISTS) else None)
+        self._nbr_ok = False
         self.cur = 0            # ring slot of x_t in feat
         self.hs = 0             # ring slot of A_t in bits / wrow
         self.steps = 0          # simulator steps since the reset this state was started at
@@ -41,19 +50,31 @@ class SparseFlockState(object):
         L = _lib.lib()
         su_agent, su_axis = (1, self.N) if u is not None else (2, 1)          # the Actor's output layout (B,1,2,N)
         # cell-list simulator up to N = 2048 (identical bit rows), the all-pairs kernel beyond
-        fn, name = (L.mgp_flock_step_cells, 'mgp_flock_step_cells') if self.N <= 2048 and self.use_cells else \
-                   (L.mgp_flock_step_sparse, 'mgp_flock_step_sparse')
-        rc = fn(
+        if self.N <= 2048 and self.use_cells:
+            rc = L.mgp_flock_step_cells_nbr(
+                ops._ptr(x_in), ops._ptr(x_out), ops._ptr(u), su_agent, su_axis,
+                self.bits.data_ptr() + h * self.N * self.NW * 8, self.H * self.N * self.NW,
+                self.wrow.data_ptr() + h * self.N * 4, self.H * self.N,
+                self.feat.data_ptr() + c * self.N * 8 * 4, self.K * self.N * 8,
+                (self.nbr.data_ptr() + h * self.N * 16 * 2) if self.nbr is not None else None, self.H * self.N * 16,
+                ops._ptr(reward), ops._ptr(expert), ctypes.byref(sim._c), self.B, self.N, ops._stream())
+            _lib.check(rc, 'mgp_flock_step_cells_nbr')
+            return
+        self._nbr_ok = False                                     # the all-pairs kernel writes bit rows only
+        rc = L.mgp_flock_step_sparse(
             ops._ptr(x_in), ops._ptr(x_out), ops._ptr(u), su_agent, su_axis,
             self.bits.data_ptr() + h * self.N * self.NW * 8, self.H * self.N * self.NW,
             self.wrow.data_ptr() + h * self.N * 4, self.H * self.N,
             self.feat.data_ptr() + c * self.N * 8 * 4, self.K * self.N * 8,
             ops._ptr(reward), ops._ptr(expert), ctypes.byref(sim._c), self.B, self.N, ops._stream())
-        _lib.check(rc, name)
+        _lib.check(rc, 'mgp_flock_step_sparse')
 
     def observe_reset(self, sim):
         """Start at the simulator's current x as a freshly reset episode (no history)."""
         self.bits.zero_(); self.wrow.zero_(); self.feat.zero_()
+        if self.nbr is not None:
+            self.nbr.zero_()                                     # count 0: a network that does not exist yet has no neighbours
+            self._nbr_ok = self.use_cells
         self.cur = self.hs = self.steps = 0
         self._sim_call(sim, sim.x, sim._x_next, None, 0, 0, None, sim.expert if sim.with_expert else None)
         self.owner = sim.x
@@ -124,7 +145,8 @@ def _run_steps(sim, sp, cd, nl, image, act, T, rw, collect):
         sp.bits.data_ptr(), ops._ptr(sp.wrow), ops._ptr(sp.feat), ops._ptr(image), cd, nl, ops._ptr(sp.scratch), ops._ptr(act),
         ops._ptr(sim.x), ops._ptr(sim._x_next), ops._ptr(rw), ops._ptr(sim.expert if sim.with_expert else None),
         ctypes.byref(sim._c), sp.B, sp.K, sp.N, int(T), ctypes.byref(cur), ctypes.byref(hs),
-        ctypes.byref(collect) if collect is not None else None, ops._stream())
+        ctypes.byref(collect) if collect is not None else None,
+        sp.nbr.data_ptr() if (sp.nbr is not None and sp._nbr_ok and not _NOLISTS) else None, ops._stream())
     _lib.check(rc, 'mgp_sparse_rollout')
     if T & 1:
         sim.x, sim._x_next = sim._x_next, sim.x

@@ -58,17 +58,15 @@ int main(int argc, char** argv) {
     if (mgp_sparse_policy_image(W, bb, dims, 3, K, image, nullptr)) { printf("image failed\n"); return 1; }
     MgpFlockParams p = {1.0, 0.01, 10.0, 1.0, 0.1, 10.0, 1.0, 1, 0, 1, 0};
     int cur = 0, hs = 0, xi = 0, rc;
-    rc = mgp_flock_step_cells(x[0], x[1], nullptr, 2, 1, bits, (long)H * N * NW, wrow, (long)H * N, feat, (long)K * N * 8, nullptr, expert, &p, B, N, nullptr);
+    unsigned short* nbr = nullptr;
+    if (!getenv("SP_NOLISTS")) { hipMalloc(&nbr, (size_t)B * H * N * 16 * 2); hipMemset(nbr, 0, (size_t)B * H * N * 16 * 2); }
+    rc = mgp_flock_step_cells_nbr(x[0], x[1], nullptr, 2, 1, bits, (long)H * N * NW, wrow, (long)H * N, feat, (long)K * N * 8, nbr, (long)H * N * 16, nullptr, expert, &p, B, N, nullptr);
     if (rc) { printf("observe rc %d\n", rc); return 1; }
     const char* only = getenv("SP_ONLY");                       // "policy": gather + policy launches only (no producer before the gather)
     auto step = [&]() {
-        int r = mgp_sparse_policy_step(bits, wrow, feat, image, dims, 3, scratch, act, B, K, N, cur, hs, nullptr);
-        if (r) return r;
-        if (only && only[0] == 'p') return 0;
-        const int nh = (hs + 1) % H, nc = (cur + 1) % K;
-        r = mgp_flock_step_cells(x[xi], x[xi ^ 1], act, 1, N, bits + (size_t)nh * N * NW, (long)H * N * NW, wrow + (size_t)nh * N, (long)H * N,
-                                 feat + (size_t)nc * N * 8, (long)K * N * 8, rew, expert, &p, B, N, nullptr);
-        xi ^= 1; hs = nh; cur = nc;
+        if (only && only[0] == 'p') return mgp_sparse_policy_step(bits, wrow, feat, image, dims, 3, scratch, act, B, K, N, cur, hs, nullptr);
+        const int r = mgp_sparse_rollout(bits, wrow, feat, image, dims, 3, scratch, act, x[xi], x[xi ^ 1], rew, expert, &p, B, K, N, 1, &cur, &hs, nullptr, nbr, nullptr);
+        xi ^= 1;
         return r;
     };
     for (int t = 0; t < 10; ++t) if ((rc = step())) { printf("step rc %d\n", rc); return 1; }
