@@ -293,6 +293,65 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
             while (m) { rlist[(size_t)rl * N + pos++] = (unsigned char)(jbase + __builtin_ctzll(m)); m &= m - 1ull; }
         }
     }
+    // The product rows come BEFORE the network rows: loads and stores of a wave complete in issue order, so gathers issued behind
+    // the 12.8 KB store burst of the network rows would wait for its acknowledgements as well; the network rows need nothing back
+    // and drain while the workgroup retires.
+    if (o.adv && o.K > 2) {
+    __syncthreads();                                              // neighbour lists complete
+    // ---- fused delayed-GSO product for this workgroup's rows: Gn[b,j,i,:] = sum_{p in N(i)} w_i * Gp[b,j-1,p,:], j >= 2.
+    //      Same arithmetic, order and weights as gso_rows_half_kernel (bit-identical), but the neighbour list comes from
+    //      the membership bits instead of re-reading and compacting the dense row of A.  One half-wave per row.
+    {
+        constexpr int HW = FL_THREADS / 32;                       // half-waves in the workgroup
+        const int lane = tid & 63, hw = tid >> 5, hl = lane & 31;
+        const size_t NN = (size_t)N * N;
+        const int nwords = FL_SPLIT * nch, n4 = N / 4;
+        // a half-wave's rows (<= FL_ROWS / HW) are all accumulated before the first of them is stored: a gather issued behind
+        // a store would wait for that store's acknowledgement too
+        constexpr int RPH = (FL_ROWS + HW - 1) / HW;
+        for (int j = 2; j < o.K; ++j) {
+            float4 accs[RPH];
+#pragma unroll
+            for (int ri = 0; ri < RPH; ++ri) {
+                const int r0 = hw + ri * HW;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r0 < rows && hl < n4 && o.has_prev) {
+                    const unsigned char* mylist = rlist + (size_t)r0 * N;
+                    int cnt = 0;
+                    for (int t = 0; t < nwords; ++t) cnt += __popcll(adjw[(size_t)r0 * nwords + t]);
+                    const float w = (float)wrow[r0];
+                    const float* sj = o.Gp + (size_t)b * o.K * NN + (size_t)(j - 1) * NN + hl * 4;
+                    // chunks of 8 source rows, all 8 loads issued before the first FMA (one L2 round trip per chunk,
+                    // typical degree <= 8); entries past the list end re-read row 0 with weight 0 (adds exact zeros)
+                    for (int e = 0; e < cnt; e += 8) {
+                        float4 g[8];
+                        float wv[8];
+#pragma unroll
+                        for (int d = 0; d < 8; ++d) {
+                            const bool ok = (e + d) < cnt;
+                            const int m = ok ? mylist[e + d] : 0;
+                            g[d] = *reinterpret_cast<const float4*>(sj + (size_t)m * N);
+                            wv[d] = ok ? w : 0.f;
+                        }
+#pragma unroll
+                        for (int d = 0; d < 8; ++d) {
+                            acc.x = fmaf(wv[d], g[d].x, acc.x); acc.y = fmaf(wv[d], g[d].y, acc.y);
+                            acc.z = fmaf(wv[d], g[d].z, acc.z); acc.w = fmaf(wv[d], g[d].w, acc.w);
+                        }
+                    }
+                }
+                accs[ri] = acc;
+            }
+#pragma unroll
+            for (int ri = 0; ri < RPH; ++ri) {
+                const int r0 = hw + ri * HW;
+                if (r0 < rows && hl < n4)
+                    *reinterpret_cast<float4*>(o.Gn + (size_t)b * o.K * NN + (size_t)j * NN + (size_t)(i0 + r0) * N + hl * 4) = accs[ri];
+            }
+        }
+    }
+    }
+    FL_STAMP(6);
     // ---- network rows i0..i0+rows-1: one flat coalesced sweep; membership comes from the phase-1 bit masks
     const size_t base = ((size_t)b * N + i0) * N;
     const size_t baseA = (size_t)b * o.sAb + (size_t)i0 * N;
@@ -351,52 +410,6 @@ void flock_step_kernel(const double* __restrict__ x, double* __restrict__ xo, co
             }
         }
     }
-    }
-    FL_STAMP(6);
-    if (!o.adv || o.K <= 2) return;
-    __syncthreads();                                              // neighbour lists complete
-    // ---- fused delayed-GSO product for this workgroup's rows: Gn[b,j,i,:] = sum_{p in N(i)} w_i * Gp[b,j-1,p,:], j >= 2.
-    //      Same arithmetic, order and weights as gso_rows_half_kernel (bit-identical), but the neighbour list comes from
-    //      the membership bits instead of re-reading and compacting the dense row of A.  One half-wave per row.
-    {
-        constexpr int HW = FL_THREADS / 32;                       // half-waves in the workgroup
-        const int lane = tid & 63, hw = tid >> 5, hl = lane & 31;
-        const size_t NN = (size_t)N * N;
-        const int nwords = FL_SPLIT * nch, n4 = N / 4;
-        for (int r0 = hw; r0 < rows; r0 += HW) {
-            if (hl >= n4) continue;
-            const int gi = i0 + r0;
-            const unsigned char* mylist = rlist + (size_t)r0 * N;
-            int cnt = 0;
-            for (int t = 0; t < nwords; ++t) cnt += __popcll(adjw[(size_t)r0 * nwords + t]);
-            const float w = (float)wrow[r0];
-            for (int j = 2; j < o.K; ++j) {
-                float* orow = o.Gn + (size_t)b * o.K * NN + (size_t)j * NN + (size_t)gi * N + hl * 4;
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (o.has_prev) {
-                    const float* sj = o.Gp + (size_t)b * o.K * NN + (size_t)(j - 1) * NN + hl * 4;
-                    // chunks of 8 source rows, all 8 loads issued before the first FMA (one L2 round trip per chunk,
-                    // typical degree <= 8); entries past the list end re-read row 0 with weight 0 (adds exact zeros)
-                    for (int e = 0; e < cnt; e += 8) {
-                        float4 g[8];
-                        float wv[8];
-#pragma unroll
-                        for (int d = 0; d < 8; ++d) {
-                            const bool ok = (e + d) < cnt;
-                            const int m = ok ? mylist[e + d] : 0;
-                            g[d] = *reinterpret_cast<const float4*>(sj + (size_t)m * N);
-                            wv[d] = ok ? w : 0.f;
-                        }
-#pragma unroll
-                        for (int d = 0; d < 8; ++d) {
-                            acc.x = fmaf(wv[d], g[d].x, acc.x); acc.y = fmaf(wv[d], g[d].y, acc.y);
-                            acc.z = fmaf(wv[d], g[d].z, acc.z); acc.w = fmaf(wv[d], g[d].w, acc.w);
-                        }
-                    }
-                }
-                *reinterpret_cast<float4*>(orow) = acc;
-            }
-        }
     }
     FL_STAMP(7);
 }

@@ -47,7 +47,7 @@ int main(int argc, char** argv) {
     }
     unsigned long long st[32];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(mgp_fl_stamps), sizeof(st));
-    const char* names[] = {"start", "x/u loaded + integrated (barrier)", "reward sums done (wg 0)", "pairwise phases done", "partials combined, features/expert written", "barrier before sweep", "network rows written", "delayed-GSO rows written"};
+    const char* names[] = {"start", "x/u loaded + integrated (barrier)", "reward sums done (wg 0)", "pairwise phases done", "partials combined, features/expert written", "barrier before the row phases", "delayed-GSO rows written", "network rows written"};
     for (int i = 0; i < 8; ++i) printf("  stamp %d : %8llu  %s\n", i, st[i] - st[0], names[i]);
     return 0;
 }
