@@ -806,6 +806,14 @@ def main():
     deg_start = float((ro.sim.network != 0).sum(dim=-1).double().mean().item())
     init_name = ('jittered lattice' if use_grid(ro.params) else 'uniform disc') + " (FlockParams.init_mode='%s')" % args.init
 
+    executed = [0]                                               # env steps actually run since the reset (a graph capture runs none)
+    _t_trace = [time.perf_counter()]
+
+    def trace(msg):                                              # MGP_BENCH_TRACE=1: where the wall time of a bench run goes (stderr)
+        if os.environ.get('MGP_BENCH_TRACE'):
+            now = time.perf_counter()
+            sys.stderr.write('[bench %7.2f s] %s\n' % (now - _t_trace[0], msg))
+            _t_trace[0] = now
     # ---- capture `gs` consecutive env steps into one HIP graph (even count: ping-pong buffers realign)
     gs = args.graph_steps
     if gs > 0:
@@ -815,6 +823,7 @@ def main():
         with torch.cuda.stream(side):
             for _ in range(2):
                 ro.step()
+        executed[0] += 2
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
@@ -827,10 +836,12 @@ def main():
                 graph.replay()
             for _ in range(n_steps % gs):
                 ro.step()
+            executed[0] += n_steps
     else:
         def run(n_steps):
             for _ in range(n_steps):
                 ro.step()
+            executed[0] += n_steps
 
     def barrier():
         if world > 1:
@@ -865,7 +876,9 @@ def main():
             el_ = float(t.item())
         return el_
 
+    trace('setup + graph capture')
     el_two = timed(run)
+    trace('two-launch pass')
     resident = ro.resident_supported() and not args.no_resident
     el_res, res_launch_ms = None, None
     if resident:
@@ -879,8 +892,15 @@ def main():
         for a_, b_ in evs:
             a_.record(); b_.record()                             # creates the underlying hipEvent_t handles (outside the timed region)
         torch.cuda.synchronize()
-        ro.prepare_resident([args.warmup, args.steps])
+        ro.prepare_resident([args.warmup, args.steps, max(executed[0], 1)])
         timing_on = [False]
+        pre_roll = executed[0]                                   # both resident passes time the SAME steps of the SAME episodes:
+
+        def rewind():                                            # back to the reset, forward to where the two-launch pass ended
+            ro.restart(1000 + rank)
+            if pre_roll > 0:
+                ro.run_resident(pre_roll)
+            torch.cuda.synchronize()
 
         def run_res(n_steps):
             if not timing_on[0]:
@@ -896,7 +916,18 @@ def main():
         def run_res_timed(n_steps):
             timing_on[0] = (n_steps == args.steps)
             run_res(n_steps)
-        el_res = timed(run_res_timed)
+        # pass 1 (`value`): the launch as a caller issues it.  pass 2: the identical region with HIP events stamped by the launch
+        # (roofline.avg_launch_ms) -- the stamped form costs the launch ~11 us of wall time (5 on the host before the doorbell, 6
+        # until the completion is seen: tools/gpu/launch_probe.py), a fifteenth of a 20-step region, so it is not what `value` times
+        rewind()
+        trace('rewind')
+        el_res = timed(ro.run_resident)
+        trace('resident pass 1')
+        rewind()
+        trace('rewind')
+        el_res_ev = timed(run_res_timed)
+        trace('resident pass 2')
+        executed[0] = pre_roll + args.warmup + args.steps
         res_launch_ms = sum(a_.elapsed_time(b_) for a_, b_ in evs)   # the timed launches' own durations (this rank)
     # the same launch on the jittered lattice (rounds 1-2 timed this state: sparser, mean degree 6.8 at reset against 8.5)
     el_grid, deg_grid = None, None
@@ -905,6 +936,7 @@ def main():
         deg_grid = float((ro_g.sim.network != 0).sum(dim=-1).double().mean().item())
         ro_g.prepare_resident([args.warmup, args.steps])
         el_grid = timed(ro_g.run_resident)
+        trace('lattice pass')
         del ro_g
     el_fact = None
     if ro.factored_supported() and not args.no_resident:
@@ -941,7 +973,7 @@ def main():
                        "graph_steps": gs, "weights": ro.weights, "parallelism": "episodes sharded x%d, no "
                        "data-path collective" % world, "state_finite": finite,
                        "mean_degree": deg, "mean_degree_at_reset": deg_start,
-                       "init": "%s, %d steps since reset at the end of the timed region" % (init_name, ro.state._pushes)},
+                       "init": "%s, %d steps since reset at the end of the timed region" % (init_name, executed[0])},
             "dist": dist_record(),
             "paths": {"two_launch": {"ms_per_step": 1e3 * el_two / args.steps,
                                      "value": total_eps * N * args.steps / el_two, "graph_steps": gs}},
@@ -952,14 +984,20 @@ def main():
         if timed_resident:
             out["paths"]["resident"] = {"ms_per_step": 1e3 * el_res / args.steps,
                                         "value": total_eps * N * args.steps / el_res,
-                                        "launch_ms_hip_events": res_launch_ms}
+                                        "launch_ms_hip_events": res_launch_ms,
+                                        "ms_per_step_event_pass": 1e3 * el_res_ev / args.steps,
+                                        "passes": "value: the plain launch; launch_ms_hip_events: a second pass over the same %d steps "
+                                                  "of the same episodes with kernel-stamped HIP events (mgp_set_launch_events), whose "
+                                                  "wall time is ms_per_step_event_pass" % args.steps}
             if el_grid is not None:
                 out["paths"]["resident_grid"] = {"ms_per_step": 1e3 * el_grid / args.steps,
                                                  "value": total_eps * N * args.steps / el_grid,
                                                  "init": "jittered lattice (FlockParams.init_mode='grid')",
                                                  "mean_degree_at_reset": deg_grid}
     if rank == 0 and not args.no_roofline:
+        trace('-')
         res, n_sets = kernel_rooflines(device, B, N, K, ro.actor, ro.sim._c)
+        trace('kernel_rooflines')
         fused = getattr(ro.actor, 'use_fused', False) and ro.actor.ind_agg == 0
 
         def hbm_block(key, kname, pmc_names):
@@ -1021,7 +1059,9 @@ def main():
                           for k, v in res.items()}
     parity = None
     if rank == 0 and not args.no_parity:
+        trace('roofline blocks')
         parity = parity_gate(ro)
+        trace('parity gate')
         out["parity"] = parity
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, K, hidden, init_mode=args.init)
