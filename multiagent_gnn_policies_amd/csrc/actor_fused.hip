@@ -426,6 +426,11 @@ struct WLayout {
     int lw[MGP_MAX_LAYERS], lstride[MGP_MAX_LAYERS];     // per layer: LDS offset and row stride of its weights
     int osplit[MGP_MAX_LAYERS], bias_owner[MGP_MAX_LAYERS];   // rows < osplit[l] and the biases with owner 0: staging wave 0
     int split;                                           // the cut (floats from the start of the weight area, % 4 == 0)
+    // the same per-layer facts bit-packed into scalars for the MLP waves: an array member of a kernel argument indexed with a
+    // run-time layer number is re-fetched from the kernel-argument segment at every use (~700 cycles each, on the MLP's
+    // critical path: three layers paid 2-3k cycles for them); shifts of a scalar that was loaded with the other arguments cost
+    // nothing.  dimsP: dims[1..8], 8 bits each; lwA / lwB: lw[0..3] / lw[4..7], 16 bits each; strideP: lstride[0..7], 8 bits each
+    unsigned long long dimsP, lwA, lwB, strideP;
 };
 
 // ---- register-chained MLP of the MFMA aggregation kernel (weights in LDS in natural order, see above).  A layer's
@@ -460,6 +465,7 @@ __device__ __forceinline__ void chain_tiles(const ChainArgs& a, int h, int nkc, 
         acc[m] = f32x4{bv.x, bv.y, bv.z, bv.w};
         r[m] = a.w + (16 * (h + m) + a.li) * a.stride + 4 * a.lq;
     }
+    if (FIRST) AF_STAMP(20);
 #pragma unroll
     for (int kc = 0; kc < NC; ++kc) {
         if (kc < nkc) {                                     // uniform
@@ -476,6 +482,7 @@ __device__ __forceinline__ void chain_tiles(const ChainArgs& a, int h, int nkc, 
 #pragma unroll
                 for (int m = 0; m < NT; ++m)
                     acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][j], bb[j], acc[m], 0, 0, 0);
+            if (FIRST) AF_STAMP(21 + kc);
         }
     }
 }
@@ -498,6 +505,7 @@ __device__ __forceinline__ void chain_layer(const ChainArgs& a, const float (&fb
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
                 zout[h + m][rr] = (h + m < MT) ? (a.last ? acc[m][rr] : tanh_fast(acc[m][rr])) : 0.f;
+        if (FIRST) AF_STAMP(30 + h);
     }
 #pragma unroll
     for (int mt = NC; mt < AM_MAXMT; ++mt)
@@ -626,19 +634,22 @@ void actor_fwd_mfma_kernel(const float* __restrict__ X, const float* __restrict_
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) { za[mt][rr] = 0.f; zb[mt][rr] = 0.f; }
         size_t soff = (size_t)B * FK * N;
-        for (int l = 0; l < P.n_layers; l += 2) {            // two layers per trip: the ping-pong stays in registers
+        const int n_layers = P.n_layers;
+        const unsigned long long dimsP = WC.dimsP, lwA = WC.lwA, lwB = WC.lwB, strideP = WC.strideP;
+        auto dimv = [&](int i) { return (int)((dimsP >> (8 * (i - 1))) & 255ull); };                      // dims[i], i >= 1
+        auto lwv = [&](int l) { return (int)(((l < 4 ? lwA : lwB) >> (16 * (l & 3))) & 0xFFFFull); };
+        auto stv = [&](int l) { return (int)((strideP >> (8 * l)) & 255ull); };
+        for (int l = 0; l < n_layers; l += 2) {              // two layers per trip: the ping-pong stays in registers
             {
-                const int cin = (l == 0) ? FK : P.dims[l], cout = P.dims[l + 1];
-                ChainArgs ca = {wl + WC.lw[l], WC.lstride[l], cin, cout, out, saved, soff, b, N, col, li, lq,
-                                l == P.n_layers - 1};
+                const int cin = (l == 0) ? FK : dimv(l), cout = dimv(l + 1);
+                ChainArgs ca = {wl + lwv(l), stv(l), cin, cout, out, saved, soff, b, N, col, li, lq, l == n_layers - 1};
                 if (l == 0) chain_layer_any<true>(ca, fb0, zb, za); else chain_layer_any<false>(ca, fb0, zb, za);
                 soff += (size_t)B * cout * N;
                 AF_STAMP(6 + l);
             }
-            if (l + 1 < P.n_layers) {
-                const int cin = P.dims[l + 1], cout = P.dims[l + 2];
-                ChainArgs ca = {wl + WC.lw[l + 1], WC.lstride[l + 1], cin, cout, out, saved, soff, b, N, col, li, lq,
-                                l + 1 == P.n_layers - 1};
+            if (l + 1 < n_layers) {
+                const int cin = dimv(l + 1), cout = dimv(l + 2);
+                ChainArgs ca = {wl + lwv(l + 1), stv(l + 1), cin, cout, out, saved, soff, b, N, col, li, lq, l + 1 == n_layers - 1};
                 chain_layer_any<false>(ca, fb0, za, zb);
                 soff += (size_t)B * cout * N;
                 AF_STAMP(7 + l);
@@ -859,6 +870,13 @@ bool make_plan_mfma(const float* const* W, const float* const* bias, const int* 
         wtot = (wtot + 3) & ~3;
         rows_total += cout;
     }
+    wc.dimsP = wc.lwA = wc.lwB = wc.strideP = 0ull;
+    for (int l = 0; l < n_layers; ++l) {
+        wc.dimsP |= (unsigned long long)(dims[l + 1] & 255) << (8 * l);
+        (l < 4 ? wc.lwA : wc.lwB) |= (unsigned long long)(wc.lw[l] & 0xFFFF) << (16 * (l & 3));
+        wc.strideP |= (unsigned long long)(wc.lstride[l] & 255) << (8 * l);
+    }
+    if (wtot > 0xFFFF) return false;
     // cut the area where half of the weight rows (one LDS-DMA each) lie below
     wc.split = wtot;
     for (int l = 0, seen = 0; l < n_layers; ++l) {
