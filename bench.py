@@ -21,12 +21,16 @@ PER GPU (weak scaling: episodes are independent, ranks never communicate in the 
 value = (episodes * agents * steps * ranks) / max-over-ranks wall time.
 
 Also reported on the same JSON line:
-  roofline      the dominant kernel of the timed region.  Resident path: algorithmic bytes of the dense-contract
-                aggregation (4KN^2 + 8KFN per episode-step) x episode-steps per launch / launch duration
-                (HIP events over the timed region) -- an EQUIVALENT rate: the operator never leaves LDS, `traffic` is
-                what HBM really moved.  `dense_kernels` holds the HBM-roofline figures of the kernels that do stream
-                the dense operator from HBM (fused Actor forward, aggregation alone), measured live on rotating
-                input sets larger than the 256 MiB Infinity Cache.
+  roofline      the dominant kernel of the timed region.  Resident path: rollout_kernel, bound = "mfma" -- algorithmic flops of
+                the MFMA-run layers x episode-steps per launch / launch duration (fp32 MFMA peak; nothing streams from HBM, the
+                `sq` fractions say what bounds it) with `traffic` = what HBM really moved (PMC) and `equivalent_hbm` = the
+                dense-contract bytes (4KN^2 + 8KFN per episode-step) over the same duration, labelled as NOT a
+                roofline fraction.  The duration comes from HIP events the launch stamps itself (mgp_set_launch_events); they
+                cost a launch ~11 us of wall time, so the resident region is timed TWICE over the same steps of the same
+                episodes (rewind to the reset, roll forward): the plain pass is `value`, the stamped pass is the roofline's
+                duration (paths.resident.ms_per_step_event_pass is its wall time).  `dense_kernels` holds the HBM-roofline
+                figures of the kernels that do stream the dense operator from HBM (fused Actor forward, aggregation alone, fused
+                sim + state step), measured live on rotating input sets larger than the 256 MiB Infinity Cache.
   kernels       same measurement for the other stand-alone kernels.
   cpu_baseline  the PyTorch-CPU port of the reference op sequence (oracle/torch_port.py, "kind": "port"),
                 reference-style B=1 loop, timed on this host for a bounded sample (rank 0, N=1 only).
@@ -1043,6 +1047,9 @@ def main():
                 "frac": flops / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, "traffic": tr, "traffic_source": tr_note,
                 "algorithmic_flops_per_launch": flops, "algorithmic_flops_per_episode_step": flops_unit,
                 "avg_launch_ms": ms, "steps_per_launch": spl, "resident": True,
+                "launch_timing": "HIP events stamped by the launch itself (mgp_set_launch_events) in a second pass over the same "
+                                 "steps of the same episodes (paths.resident.ms_per_step_event_pass); the pass `value` is taken "
+                                 "from carries no events",
                 "limiter": "instruction issue / LDS latency / workgroup barriers: one workgroup per CU, the episode's state "
                            "in LDS; neither HBM (traffic = state in/out + 8 B of reward per step) nor the matrix pipe "
                            "(sq.mfma_busy) is saturated -- the fractions in `sq` are the evidence",

@@ -269,6 +269,12 @@ def test_bench_single_gpu_contract_and_paths(n, k, paths):
     assert d['value'] == d['paths'][headline]['value']
     assert d['parity']['ok'] and d['parity']['tol'] == 1e-5 and {'max_abs', 'max_rel'} <= set(d['parity'])
     assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(d['roofline'])
+    if 'resident' in paths:
+        # the resident region is timed twice over the same steps: plain launch = value, event-stamped pass = the roofline's duration
+        r_ = d['paths']['resident']
+        assert r_['ms_per_step'] == d['ms_per_step'] and r_['ms_per_step_event_pass'] > 0
+        assert 0 < r_['launch_ms_hip_events'] <= 1.05 * r_['ms_per_step_event_pass'] * d['steps']
+        assert abs(d['roofline']['avg_launch_ms'] - r_['launch_ms_hip_events']) <= 1e-9 + 1e-6 * r_['launch_ms_hip_events']
 
 
 def test_device_replay_ring_and_sampling():

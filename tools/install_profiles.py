@@ -32,8 +32,9 @@ open('profiles/%s_bench_default_1000steps.json' % R, 'w').write(json.dumps(d) + 
 open('profiles/%s_bench_steps20_under_rocprof.json' % R, 'w').write(json.dumps(d2) + '\n')
 kt = open(O + '/bench_kernel_trace.txt').read().splitlines(True)
 note = ("# rocprofv3 --kernel-trace --stats of `python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's command line).\n"
-        "# rollout_kernel<100,3,..>: the 5-step warm-up launch (min_us), the 20-step TIMED launch (max_us) and the parity gate's one-step launch;\n"
-        "#      bench.py's roofline.avg_launch_ms (HIP events around the timed launch) is the max_us figure.  The other kernels belong to the\n"
+        "# rollout_kernel<100,3,..>: bench.py times the resident region twice over the same steps (rewind to the reset + pre-roll launch, 5-step\n"
+        "#      warm-up launch, 20-step TIMED launch; the first pass is `value`, the second carries the kernel-stamped HIP events behind\n"
+        "#      roofline.avg_launch_ms), then the same on the jittered lattice, then the parity gate's one-step launch.  The other kernels belong to the\n"
         "#      two-launch path (timed in the same run) and to the stand-alone dense-kernel roofline leg.\n")
 open('profiles/%s_bench_kernel_trace.txt' % R, 'w').write(''.join(kt[:2]) + note + ''.join(kt[2:]))
 shutil.copy(O + '/dagger_update.json', 'profiles/%s_dagger_update.json' % R)
