@@ -1050,9 +1050,11 @@ def main():
                 "launch_timing": "HIP events stamped by the launch itself (mgp_set_launch_events) in a second pass over the same "
                                  "steps of the same episodes (paths.resident.ms_per_step_event_pass); the pass `value` is taken "
                                  "from carries no events",
-                "limiter": "instruction issue / LDS latency / workgroup barriers: one workgroup per CU, the episode's state "
-                           "in LDS; neither HBM (traffic = state in/out + 8 B of reward per step) nor the matrix pipe "
-                           "(sq.mfma_busy) is saturated -- the fractions in `sq` are the evidence",
+                "limiter": "vector-ALU instruction issue: sq.valu_issue (>= 0.6: SQ_INSTS_VALU x 4 cycles over the four SIMDs' busy "
+                           "cycles, a lower bound -- fp64, transcendental and MFMA instructions hold the pipe longer) is the "
+                           "resource nearest its ceiling; the rest of a step is LDS latency and workgroup barriers with one "
+                           "workgroup per CU.  Neither HBM (traffic = state in/out + 8 B of reward per step) nor the matrix "
+                           "pipe (sq.mfma_busy) is saturated -- the fractions in `sq` are the evidence",
                 "sq": pmc_sq('rollout_kernel'),
                 "equivalent_hbm": {"GBps": alg / ms / 1e6, "frac_of_peak": alg / ms / 1e6 / HBM_PEAK_GBS,
                                    "algorithmic_bytes_per_launch": alg,

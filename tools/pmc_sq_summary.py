@@ -49,6 +49,9 @@ def main(path):
             # one matrix pipe per SIMD, four SIMDs per CU: busy cycles are summed over the SIMDs
             print("    %-28s %15.1f%%  of (busy CU cycles x 4 SIMDs)" % ('matrix pipe busy', 100.0 * v['SQ_VALU_MFMA_BUSY_CYCLES'] /
                                                                         (4.0 * v['SQ_BUSY_CU_CYCLES'])))
+        if v.get('SQ_INSTS_VALU') and v.get('SQ_BUSY_CU_CYCLES'):
+            print("    %-28s %15.1f%%  of (busy CU cycles x 4 SIMDs), at 4 cycles per wave instruction: a lower bound" %
+                  ('vector pipes issuing', 100.0 * v['SQ_INSTS_VALU'] / v['SQ_BUSY_CU_CYCLES']))
 
 
     if len(sys.argv) > 2:                                       # machine-readable fractions for bench.py's roofline.sq
@@ -63,9 +66,14 @@ def main(path):
                  "avg_launch_us": v.get('_us'), "valu_insts": v.get('SQ_INSTS_VALU'), "mfma_f32_insts": v.get('SQ_INSTS_VALU_MFMA_F32')}
             if v.get('SQ_BUSY_CU_CYCLES'):
                 o["mfma_busy"] = v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (4.0 * v['SQ_BUSY_CU_CYCLES'])
+                # a wave64 VALU instruction occupies its SIMD's vector pipe for >= 4 cycles (fp64 / transcendental / MFMA longer):
+                # SQ_INSTS_VALU x 4 / (4 SIMDs x busy CU cycles) is a LOWER bound on how busy the vector pipes are
+                o["valu_issue"] = v.get('SQ_INSTS_VALU', 0.0) / v['SQ_BUSY_CU_CYCLES']
+                o["busy_cu_cycles"] = v['SQ_BUSY_CU_CYCLES']
             out[k] = o
         out['_meta'] = {"units": "fractions of SQ_WAVE_CYCLES (wave residency); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / "
-                                 "(4 SIMDs x SQ_BUSY_CU_CYCLES)", "probe_T": __import__('os').environ.get('PROBE_T', '1000')}
+                                 "(4 SIMDs x SQ_BUSY_CU_CYCLES); valu_issue = SQ_INSTS_VALU x 4 cycles / (4 SIMDs x SQ_BUSY_CU_CYCLES), a lower bound on "
+                                 "the vector pipes' busy share", "probe_T": __import__('os').environ.get('PROBE_T', '1000')}
         with open(sys.argv[2], 'w') as f:
             json.dump(out, f, indent=1)
 
