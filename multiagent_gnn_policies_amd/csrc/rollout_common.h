@@ -114,6 +114,103 @@ __device__ __forceinline__ void ro_layer_regs(const float (&fb)[RO_KS], const fl
     }
 }
 
+// ---- split-bf16 form of a 32-wide hidden layer (the compiled-in policy shape of the headline build).  The fp32 matrix pipe
+// multiplies 16x16x4 per 8 passes; v_mfma_f32_16x16x32_bf16 multiplies 16x16x32 per 4.  With every fp32 operand written as
+// x = x1 + x2 + x3 (three bf16 pieces: 24 significand bits, the split is exact) the products that matter at fp32 accuracy are
+// w1 x1, w1 x2, w2 x1, w2 x2, w1 x3, w3 x1 (each exact in the fp32 accumulator's inputs; what is dropped is below 2^-24 of the
+// product): six instructions of 16 cycles per m-tile cover K = 32, against five / eight of 32 cycles.  A lane's block record is
+// the same 12 floats (48 bytes) as the fp32 fragments: [piece][8 bf16]; element j of k-group lq <-> channel 4 j + lq for the
+// first layer (its B operand is the aggregation's LDS tile), 4 lq + j | 16 + 4 lq + (j - 4) for the second (B operand = the
+// first layer's accumulator registers).
+#ifndef MGP_RO_BF16
+#define MGP_RO_BF16 1                    // 0: the fp32-MFMA form everywhere (A/B builds of the harness)
+#endif
+// which builds: layer widths <= 32 (RO_KS = 8 input k-steps, two m-tiles) -- rollout.hip itself; the wider builds keep fp32
+constexpr bool RO_BF16_CHAIN = MGP_RO_BF16 && RO_KS == 8 && RO_MAXMT == 2;
+typedef __attribute__((ext_vector_type(8))) __bf16 ro_bf16x8;
+
+__device__ __forceinline__ void ro_split3(const float* x /* [8] */, ro_bf16x8& h1, ro_bf16x8& h2, ro_bf16x8& h3)
+{
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 a = (__bf16)x[j];
+        const float r = x[j] - (float)a;
+        const __bf16 b = (__bf16)r;
+        const float r2 = r - (float)b;
+        h1[j] = a; h2[j] = b; h3[j] = (__bf16)r2;
+    }
+}
+
+template <int MT, bool TANH>
+__device__ __forceinline__ void ro_layer_bf16(const float* x /* [8] */, const float* pw /* this lane's record of m-tile 0 */,
+                                              const float* pbias, float (&zn)[RO_MAXMT][4])
+{
+    static_assert(MT <= RO_MAXMT, "m-tiles");
+    ro_bf16x8 b1, b2, b3;
+    ro_split3(x, b1, b2, b3);
+    f32x4 acc[MT];
+    ro_bf16x8 a1[MT], a2[MT], a3[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const float4* pa = reinterpret_cast<const float4*>(pw + mt * 64 * RO_WFS);
+        const float4 u1 = pa[0], u2 = pa[1], u3 = pa[2];
+        a1[mt] = *reinterpret_cast<const ro_bf16x8*>(&u1);
+        a2[mt] = *reinterpret_cast<const ro_bf16x8*>(&u2);
+        a3[mt] = *reinterpret_cast<const ro_bf16x8*>(&u3);
+        const float4 bv = *reinterpret_cast<const float4*>(pbias + mt * 16);
+        acc[mt][0] = bv.x; acc[mt][1] = bv.y; acc[mt][2] = bv.z; acc[mt][3] = bv.w;
+    }
+    // smallest products first; the two m-tiles alternate (two independent accumulator chains)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b3, acc[mt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[mt], b1, acc[mt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[mt], b2, acc[mt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b2, acc[mt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[mt], b1, acc[mt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b1, acc[mt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) zn[mt][rr] = TANH ? tanh_fast(acc[mt][rr]) : acc[mt][rr];
+#pragma unroll
+    for (int mt = MT; mt < RO_MAXMT; ++mt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) zn[mt][rr] = 0.f;
+}
+
+// element e (a float slot = two bf16) of a hidden layer's block in that form; same block size as the fp32 fragments
+__device__ __forceinline__ float ro_chain_image_elem_bf(const float* __restrict__ src, const float* __restrict__ bias, int cin,
+                                                        int cout, int layer, int e)
+{
+    const int MT = ro_mt(cout), tot = MT * 64 * RO_WFS;
+    if (e >= tot) { const int o = e - tot; return (o < cout) ? bias[o] : 0.f; }
+    const int mt = e / (64 * RO_WFS), r1 = e - mt * (64 * RO_WFS);
+    const int ln = r1 / RO_WFS, sl = r1 - ln * RO_WFS;
+    const int piece = sl >> 2, pr = sl & 3;
+    const int lqq = ln >> 4, o = mt * 16 + (ln & 15);
+    unsigned int word = 0u;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int j = 2 * pr + t;
+        const int c = (layer == 0) ? 4 * j + lqq : (j < 4 ? 4 * lqq + j : 16 + 4 * lqq + (j - 4));
+        const float w = (piece < 3 && o < cout && c < cin) ? src[(size_t)o * cin + c] : 0.f;
+        const __bf16 a = (__bf16)w;
+        const float r = w - (float)a;
+        const __bf16 b = (__bf16)r;
+        const float r2 = r - (float)b;
+        const __bf16 h = piece == 0 ? a : (piece == 1 ? b : (__bf16)r2);
+        unsigned short bits;
+        __builtin_memcpy(&bits, &h, 2);
+        word |= (unsigned int)bits << (16 * t);
+    }
+    return __uint_as_float(word);
+}
+
 // element e of layer `layer`'s block in the chained weight image: A fragments [MT][64][RO_WFS] (lane = lq * 16 + (o & 15), slot
 // s) + bias [MT * 16]; channel of (slot s, k-lane lq): 4 s + lq for the first layer (its B operand comes from the aggregation's
 // LDS tile), 16 (s >> 2) + 4 lq + (s & 3) for the others (B operand = the previous layer's accumulator registers).  The output
@@ -121,6 +218,7 @@ __device__ __forceinline__ void ro_layer_regs(const float (&fb)[RO_KS], const fl
 __device__ __forceinline__ float ro_chain_image_elem(const float* __restrict__ src, const float* __restrict__ bias, int cin,
                                                      int cout, int layer, bool last, int e)
 {
+    if (RO_BF16_CHAIN && !last) return ro_chain_image_elem_bf(src, bias, cin, cout, layer, e);
     const int MT = last ? 1 : ro_mt(cout), tot = MT * 64 * RO_WFS;
     if (e >= tot) { const int o = e - tot; return (o < cout) ? bias[o] : 0.f; }
     const int mt = e / (64 * RO_WFS), r1 = e - mt * (64 * RO_WFS);
