@@ -482,7 +482,9 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 const float* pbias = wfrag + MT * 64 * RO_WFS + lq * 4;
                 if constexpr (RO_BF16_CHAIN) {
                     // widths <= 32: split-bf16 MFMA (rollout_common.h), the whole K = 32 in one instruction per product (no k-step count)
-                    if (MT == 2) ro_layer_bf16<(RO_MAXMT >= 2 ? 2 : 1), true>(fb, pw, pbias, zc);
+                    if (RO_MAXMT >= 8 && MT == 8) ro_layer_bf16<(RO_MAXMT >= 8 ? 8 : 1), true>(fb, pw, pbias, zc);
+                    else if (RO_MAXMT >= 4 && MT == 4) ro_layer_bf16<(RO_MAXMT >= 4 ? 4 : 1), true>(fb, pw, pbias, zc);
+                    else if (MT == 2) ro_layer_bf16<(RO_MAXMT >= 2 ? 2 : 1), true>(fb, pw, pbias, zc);
                     else ro_layer_bf16<1, true>(fb, pw, pbias, zc);
                 } else {
                 if (RO_MAXMT >= 8 && MT == 8) ro_layer_regs<(RO_MAXMT >= 8 ? 8 : 1), true>(fb, pw, pbias, ksteps, zc);
@@ -1222,7 +1224,9 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
                 const float* pbias = wfrag + MT * 64 * RO_WFS + lq * 4;
                 if constexpr (RO_BF16_CHAIN) {
                     // widths <= 32: split-bf16 MFMA (rollout_common.h), the whole K = 32 in one instruction per product (no k-step count)
-                    if (MT == 2) ro_layer_bf16<(RO_MAXMT >= 2 ? 2 : 1), true>(fb, pw, pbias, zc);
+                    if (RO_MAXMT >= 8 && MT == 8) ro_layer_bf16<(RO_MAXMT >= 8 ? 8 : 1), true>(fb, pw, pbias, zc);
+                    else if (RO_MAXMT >= 4 && MT == 4) ro_layer_bf16<(RO_MAXMT >= 4 ? 4 : 1), true>(fb, pw, pbias, zc);
+                    else if (MT == 2) ro_layer_bf16<(RO_MAXMT >= 2 ? 2 : 1), true>(fb, pw, pbias, zc);
                     else ro_layer_bf16<1, true>(fb, pw, pbias, zc);
                 } else {
                 if (RO_MAXMT >= 8 && MT == 8) ro_layer_regs<(RO_MAXMT >= 8 ? 8 : 1), true>(fb, pw, pbias, ksteps, zc);

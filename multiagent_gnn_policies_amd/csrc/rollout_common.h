@@ -125,8 +125,9 @@ __device__ __forceinline__ void ro_layer_regs(const float (&fb)[RO_KS], const fl
 #ifndef MGP_RO_BF16
 #define MGP_RO_BF16 1                    // 0: the fp32-MFMA form everywhere (A/B builds of the harness)
 #endif
-// which builds: layer widths <= 32 (RO_KS = 8 input k-steps, two m-tiles) -- rollout.hip itself; the wider builds keep fp32
-constexpr bool RO_BF16_CHAIN = MGP_RO_BF16 && RO_KS == 8 && RO_MAXMT == 2;
+// which builds: layer INPUTS of at most 32 channels (RO_KS = 8 k-steps: one K = 32 instruction per product) -- rollout.hip itself
+// (widths <= 32) and rollout_w128.hip (one hidden layer up to 128 wide: eight m-tiles); the 64-wide build keeps fp32
+constexpr bool RO_BF16_CHAIN = MGP_RO_BF16 && RO_KS == 8;
 typedef __attribute__((ext_vector_type(8))) __bf16 ro_bf16x8;
 
 __device__ __forceinline__ void ro_split3(const float* x /* [8] */, ro_bf16x8& h1, ro_bf16x8& h2, ro_bf16x8& h3)
@@ -146,37 +147,41 @@ __device__ __forceinline__ void ro_layer_bf16(const float* x /* [8] */, const fl
                                               const float* pbias, float (&zn)[RO_MAXMT][4])
 {
     static_assert(MT <= RO_MAXMT, "m-tiles");
+    constexpr int CH = MT > 2 ? 2 : MT;                       // m-tiles in flight (two accumulator chains; their A pieces: 24 registers)
     ro_bf16x8 b1, b2, b3;
     ro_split3(x, b1, b2, b3);
-    f32x4 acc[MT];
-    ro_bf16x8 a1[MT], a2[MT], a3[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const float4* pa = reinterpret_cast<const float4*>(pw + mt * 64 * RO_WFS);
-        const float4 u1 = pa[0], u2 = pa[1], u3 = pa[2];
-        a1[mt] = *reinterpret_cast<const ro_bf16x8*>(&u1);
-        a2[mt] = *reinterpret_cast<const ro_bf16x8*>(&u2);
-        a3[mt] = *reinterpret_cast<const ro_bf16x8*>(&u3);
-        const float4 bv = *reinterpret_cast<const float4*>(pbias + mt * 16);
-        acc[mt][0] = bv.x; acc[mt][1] = bv.y; acc[mt][2] = bv.z; acc[mt][3] = bv.w;
+    for (int h = 0; h < MT; h += CH) {
+        f32x4 acc[CH];
+        ro_bf16x8 a1[CH], a2[CH], a3[CH];
+#pragma unroll
+        for (int mt = 0; mt < CH; ++mt) {
+            const float4* pa = reinterpret_cast<const float4*>(pw + (h + mt) * 64 * RO_WFS);
+            const float4 u1 = pa[0], u2 = pa[1], u3 = pa[2];
+            a1[mt] = *reinterpret_cast<const ro_bf16x8*>(&u1);
+            a2[mt] = *reinterpret_cast<const ro_bf16x8*>(&u2);
+            a3[mt] = *reinterpret_cast<const ro_bf16x8*>(&u3);
+            const float4 bv = *reinterpret_cast<const float4*>(pbias + (h + mt) * 16);
+            acc[mt][0] = bv.x; acc[mt][1] = bv.y; acc[mt][2] = bv.z; acc[mt][3] = bv.w;
+        }
+        // smallest products first; the m-tiles of a chunk alternate (independent accumulator chains)
+#pragma unroll
+        for (int mt = 0; mt < CH; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b3, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < CH; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[mt], b1, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < CH; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[mt], b2, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < CH; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b2, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < CH; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[mt], b1, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < CH; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b1, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < CH; ++mt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) zn[h + mt][rr] = TANH ? tanh_fast(acc[mt][rr]) : acc[mt][rr];
     }
-    // smallest products first; the two m-tiles alternate (two independent accumulator chains)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b3, acc[mt], 0, 0, 0);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[mt], b1, acc[mt], 0, 0, 0);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[mt], b2, acc[mt], 0, 0, 0);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b2, acc[mt], 0, 0, 0);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[mt], b1, acc[mt], 0, 0, 0);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b1, acc[mt], 0, 0, 0);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) zn[mt][rr] = TANH ? tanh_fast(acc[mt][rr]) : acc[mt][rr];
 #pragma unroll
     for (int mt = MT; mt < RO_MAXMT; ++mt)
 #pragma unroll
