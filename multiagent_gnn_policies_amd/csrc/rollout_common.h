@@ -23,9 +23,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // accumulators, tanh on the accumulator registers.  The wave reads all its B fragments before it stores anything and
 // therefore works in place; no other wave touches these columns, so hidden layers need no workgroup barrier between
 // them.  (Splitting the m-tiles over two waves with ping-pong buffers and a barrier per layer measured the same.)
+template <int MT> __device__ __forceinline__ bool ro_mlp_cols_bf16(float* pcol, const float* pw, const float* pbias, int lq);
+
 template <int MT>
 __device__ __forceinline__ void ro_mlp_cols(float* pcol, const float* pw, const float* pbias, int ksteps, int lq)
 {
+    if (ro_mlp_cols_bf16<MT>(pcol, pw, pbias, lq)) return;    // builds with <= 32 input channels per layer: split-bf16 MFMA (below)
     constexpr int CH = MT > 2 ? 2 : MT;                       // m-tiles in flight: two chains hide the MFMA latency, four spill
     float fb[RO_KS];
     const float4* pb = reinterpret_cast<const float4*>(pcol + lq * RO_KS);
@@ -216,6 +219,29 @@ __device__ __forceinline__ float ro_chain_image_elem_bf(const float* __restrict_
     return __uint_as_float(word);
 }
 
+// the LDS-tile form of a hidden layer (ro_mlp_cols: every layer reads its B operand from the wave's activation columns, slot
+// j of k-lane lq <-> channel 4 j + lq, and writes its output there) on the same instructions; its weight blocks are the
+// first-layer enumeration of ro_chain_image_elem_bf for every layer (ro_weight_image_elem)
+template <int MT>
+__device__ __forceinline__ bool ro_mlp_cols_bf16(float* pcol, const float* pw, const float* pbias, int lq)
+{
+    if constexpr (RO_BF16_CHAIN && MT <= RO_MAXMT) {
+        float fb[8];
+        const float4* pb = reinterpret_cast<const float4*>(pcol + lq * RO_KS);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const float4 t = pb[i]; fb[4 * i] = t.x; fb[4 * i + 1] = t.y; fb[4 * i + 2] = t.z; fb[4 * i + 3] = t.w; }
+        float zn[RO_MAXMT][4];
+        ro_layer_bf16<MT, true>(fb, pw, pbias, zn);           // (every B fragment is in registers before the first store)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) pcol[rr * RO_KS + mt * 4 + lq] = zn[mt][rr];     // slot rpos(16 mt + 4 lq + rr)
+        return true;
+    } else {
+        return false;
+    }
+}
+
 // element e of layer `layer`'s block in the chained weight image: A fragments [MT][64][RO_WFS] (lane = lq * 16 + (o & 15), slot
 // s) + bias [MT * 16]; channel of (slot s, k-lane lq): 4 s + lq for the first layer (its B operand comes from the aggregation's
 // LDS tile), 16 (s >> 2) + 4 lq + (s & 3) for the others (B operand = the previous layer's accumulator registers).  The output
@@ -347,6 +373,7 @@ __device__ __forceinline__ float ro_weight_image_elem(const float* __restrict__ 
         const int c = e >> 1, o = e & 1;
         return (c < RO_OUTC) ? ((c < cin) ? src[(size_t)o * cin + c] : 0.f) : bias[o];
     }
+    if (RO_BF16_CHAIN) return ro_chain_image_elem_bf(src, bias, cin, cout, 0, e);       // (every layer: the LDS-tile enumeration)
     const int MT = ro_mt(cout), tot = MT * 64 * RO_WFS;
     if (e >= tot) { const int o = e - tot; return (o < cout) ? bias[o] : 0.f; }
     const int mt = e / (64 * RO_WFS), r1 = e - mt * (64 * RO_WFS);
