@@ -64,6 +64,7 @@ from multiagent_gnn_policies_amd.learner.state_with_delay import BatchedDelaySta
 
 DEFAULT_STEPS = 1000      # env steps in the timed region (resident path: one launch; ~10 ms)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+MFMA_BF16_PEAK_TFLOPS = 2500.0                     # dense bf16 (MI355X_MICROARCH.md: ~2.5 PFLOP/s; no sparsity)
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32 / 32x32x2 dense peak (MI355X_MICROARCH.md: = the fp32 vector rate)
 PARITY_TOL = 1e-5
 PROFILE_ROUND = 'r03'
@@ -1039,6 +1040,18 @@ def main():
             flops = flops_unit * B * spl
             ms = res_launch_ms / n_launch
             alg = (4 * K * N * N + 8 * K * F_FEAT * N) * B * spl
+            # which instructions run those flops: layers whose inputs have <= 32 channels run on split-bf16 MFMA (three bf16
+            # pieces per fp32 operand, six 16x16x32 products per fp32 product: rollout_common.h ro_layer_bf16), the 64-wide
+            # build on fp32 MFMA 16x16x4.  `frac` above stays against the fp32 matrix peak -- the rate a plain fp32
+            # implementation of the same flops is bounded by; the bf16 figures are here for the pipe's own occupancy
+            split = max(hidden) <= 32 or (len(hidden) == 1 and 64 < hidden[0] <= 128)     # base build / the 128-wide build
+            matrix_note = ({"form": "split-bf16: v_mfma_f32_16x16x32_bf16, 6 bf16 products per fp32 product, K padded to 32",
+                            "bf16_flops_per_episode_step": 6.0 * 2.0 * N * sum(32 * 16 * ((b_ + 15) // 16) for b_ in dims[1:]),
+                            "bf16_peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS}
+                           if split else {"form": "fp32: v_mfma_f32_16x16x4_f32"})
+            if split:
+                matrix_note["frac_of_bf16_peak"] = (matrix_note["bf16_flops_per_episode_step"] * B * spl / ms / 1e9 /
+                                                    MFMA_BF16_PEAK_TFLOPS)
             tr, tr_note = pmc_traffic('rollout_kernel', B, N, K, steps_per_launch=spl)
             out["roofline"] = {
                 "kernel": "rollout_kernel (episode-resident: power-iterated aggregation along neighbour lists + fp32-MFMA "
@@ -1047,6 +1060,7 @@ def main():
                 "frac": flops / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, "traffic": tr, "traffic_source": tr_note,
                 "algorithmic_flops_per_launch": flops, "algorithmic_flops_per_episode_step": flops_unit,
                 "avg_launch_ms": ms, "steps_per_launch": spl, "resident": True,
+                "matrix_instructions": matrix_note,
                 "launch_timing": "HIP events stamped by the launch itself (mgp_set_launch_events) in a second pass over the same "
                                  "steps of the same episodes (paths.resident.ms_per_step_event_pass); the pass `value` is taken "
                                  "from carries no events",
