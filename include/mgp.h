@@ -236,9 +236,7 @@ int mgp_rollout_steps(double* x, float* G, float* Xd, const float* const* W, con
 /* The same launch for callers that launch REPEATEDLY (the chunked evaluation loops of gnn_dagger.py:190-232, test_model.py,
  * bench.py): what a launch costs besides its steps is then handed over instead of recomputed.
  *   image   prebuilt weight image (mgp_rollout_image: the MFMA fragment layout the kernel otherwise derives from W, b at
- *           every launch -- opaque: fp32 fragments, or for layers with at most 32 input channels three bf16 pieces per
- *           weight for the split-bf16 products the kernel multiplies with, same size either way; rebuild it whenever the
- *           weights change), 16-byte aligned, or NULL (then W, b are read; with an image W and b may be NULL)
+ *           every launch), 16-byte aligned, or NULL (then W, b are read; with an image W and b may be NULL)
  *   carry   B x mgp_rollout_carry_bytes(K, N) bytes: the operator history in FACTORED form -- per episode the membership
  *           bits (row-major, 2 x u64 per row for N <= 128, 4 beyond) and row weights of the last max(K-1, 1) networks
  *           A_t, A_{t-1}, ... (newest first).  An all-zero carry is the history of a reset observation.
