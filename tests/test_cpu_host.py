@@ -391,3 +391,35 @@ def test_frame_replay_ring_positions_and_sampling():
     with pytest.raises(ValueError):
         m.sample_ids(13)
     assert m.bytes_per_transition() == 4 * 8 * N + 16 * N + 4
+
+
+def test_split_bf16_pieces_carry_an_fp32_product():
+    """The arithmetic behind the resident kernels' hidden layers (csrc/rollout_common.h: ro_split3 / ro_layer_bf16), restated in
+    numpy: an fp32 value is the EXACT sum of three bf16 pieces (round-to-nearest-even at each stage: 24 significand bits), and
+    the six products the kernel multiplies -- w1 x1, w1 x2, w2 x1, w2 x2, w1 x3, w3 x1 -- miss the exact dot product by less than
+    2^-22 of sum |w x| (what is dropped: w2 x3, w3 x2, w3 x3)."""
+    import numpy as np
+
+    def bf16_rne(v):                                           # fp32 -> nearest bf16 (ties to even), returned as fp32
+        u = np.asarray(v, np.float32).view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+        return u.astype(np.uint32).view(np.float32)
+
+    def split3(v):
+        v = np.asarray(v, np.float32)
+        a = bf16_rne(v); r = (v - a).astype(np.float32)
+        b = bf16_rne(r); r2 = (r - b).astype(np.float32)
+        return a, b, bf16_rne(r2)
+
+    rs = np.random.RandomState(0)
+    for scale in (1.0, 1e-3, 1e5):
+        x = (rs.standard_normal((64, 32)) * scale).astype(np.float32)
+        w = rs.standard_normal((64, 32)).astype(np.float32)
+        x1, x2, x3 = split3(x); w1, w2, w3 = split3(w)
+        assert np.array_equal((x1.astype(np.float64) + x2 + x3), x.astype(np.float64))       # the split is exact
+        assert np.array_equal((w1.astype(np.float64) + w2 + w3), w.astype(np.float64))
+        f = lambda a_, b_: (a_.astype(np.float64) * b_.astype(np.float64)).sum(axis=1)
+        six = f(w1, x3) + f(w3, x1) + f(w2, x2) + f(w1, x2) + f(w2, x1) + f(w1, x1)
+        exact = f(w, x)
+        bound = 2.0 ** -22 * (np.abs(w.astype(np.float64)) * np.abs(x.astype(np.float64))).sum(axis=1)
+        assert np.all(np.abs(six - exact) <= bound)
