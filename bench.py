@@ -745,13 +745,26 @@ def dagger_round_bench(args, device, rank, world):
             "weights_bit_identical_across_ranks": identical,
             "dist": dist_record(),
         }
-        print(json.dumps(out))
+        emit_json(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if not identical:
         sys.stderr.write("bench.py --dagger: the ranks' weights differ\n")
         sys.exit(4)
+
+
+_JSON_FD = [None]
+
+
+def emit_json(obj):
+    """The result line, on the process's ORIGINAL stdout (see main: fd 1 is pointed at stderr while the bench runs)."""
+    line = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD[0] is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        sys.stdout.flush()
+        os.write(_JSON_FD[0], line)
 
 
 def main():
@@ -793,6 +806,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args.gpus))                         # `python bench.py --gpus N` starts its own N ranks
+    # ONE line on stdout: libraries that print there from C (gloo's "[Gloo] Rank 0 is connected ..." when several ranks share
+    # a GPU in tests) are sent to stderr for the rest of the process; the JSON line goes to the saved descriptor (emit_json)
+    sys.stdout.flush()
+    _JSON_FD[0] = os.dup(1)
+    os.dup2(2, 1)
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: one rank per GPU, launch with --nproc-per-node %d (or without a "
@@ -1089,7 +1107,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, K, hidden, init_mode=args.init)
     if rank == 0:
-        print(json.dumps(out))
+        emit_json(out)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
