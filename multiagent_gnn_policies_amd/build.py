@@ -7,6 +7,7 @@ shared library lands next to this file so it travels with the repo snapshot to t
 """
 import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -70,12 +71,32 @@ def build(force=False, verbose=True):
         try:
             if not force and is_current():               # another process built it while we waited
                 return LIB_PATH
-            return _build_locked(verbose)
+            return _build_locked(verbose, force)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build_locked(verbose):
+_INCLUDE_RE = re.compile(rb'^[ \t]*#[ \t]*include[ \t]*"([^"]+)"', re.M)
+
+
+def _tu_bytes(src, seen=None):
+    """The bytes a translation unit is built from besides the headers: its own text plus, recursively, every file it
+    pulls in with #include "..." (rollout_wide.hip / rollout_w128.hip are wrappers around rollout.hip: editing
+    rollout.hip must rebuild all three objects)."""
+    seen = set() if seen is None else seen
+    path = os.path.normpath(os.path.join(CSRC, src))
+    if path in seen or not os.path.exists(path):
+        return b''
+    seen.add(path)
+    with open(path, 'rb') as f:
+        text = f.read()
+    out = src.encode() + b'\0' + text
+    for inc in _INCLUDE_RE.findall(text):
+        out += _tu_bytes(os.path.join(os.path.dirname(src), inc.decode()), seen)
+    return out
+
+
+def _build_locked(verbose, force=False):
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build libmgp.so (ROCm toolchain required)")
@@ -91,11 +112,10 @@ def _build_locked(verbose):
     for src in sources():
         obj = os.path.join(OBJ_DIR, src[:-4] + '.o')
         flags = COMMON_FLAGS + PER_FILE_FLAGS.get(src, [])
-        with open(os.path.join(CSRC, src), 'rb') as f:
-            key = hashlib.sha256(hdr.digest() + f.read() + ' '.join(flags).encode()).hexdigest()
+        key = hashlib.sha256(hdr.digest() + _tu_bytes(src) + ' '.join(flags).encode()).hexdigest()
         stamp = obj + '.key'
         objs.append(obj)
-        if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == key:
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == key:
             continue
         cmd = [hipcc] + flags + ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:

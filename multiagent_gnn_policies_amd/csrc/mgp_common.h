@@ -69,23 +69,29 @@ __device__ __forceinline__ void mgp_adam_elem(float& p, float& m, float& v, floa
     v = vi;
 }
 
-// Raise a kernel's dynamic-LDS limit ONCE per (kernel, size) and thread: hipFuncSetAttribute is a driver call -- measured at up
-// to 0.35 ms per call in some processes, during which the runtime also held back the submission of launches already enqueued
-// (a 100-step loop of launches with one call each sat on the host for 35 ms before the first kernel started).
+// Raise a kernel's dynamic-LDS limit ONCE per (device, kernel, size) and thread: hipFuncSetAttribute is a driver call -- measured
+// at up to 0.35 ms per call in some processes, during which the runtime also held back the submission of launches already
+// enqueued (a 100-step loop of launches with one call each sat on the host for 35 ms before the first kernel started).
+// The attribute belongs to the CURRENT device's function object, so the device is part of the key (a process that drives a
+// second GPU from the same thread must set it there too); a full table falls back to the plain driver call, never to a skip.
 inline hipError_t mgp_allow_dyn_lds(const void* fn, size_t lds)
 {
-    struct Entry { const void* fn; size_t lds; };
-    static thread_local Entry tab[96];
+    struct Entry { const void* fn; size_t lds; int dev; };
+    constexpr int CAP = 192;
+    static thread_local Entry tab[CAP];
     static thread_local int used = 0;
     if (lds <= 48 * 1024) return hipSuccess;
-    for (int i = 0; i < used; ++i)
-        if (tab[i].fn == fn) {
-            if (tab[i].lds >= lds) return hipSuccess;
-            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess) tab[i].lds = lds;
-            return e;
-        }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
+    if (dev >= 0)
+        for (int i = 0; i < used; ++i)
+            if (tab[i].fn == fn && tab[i].dev == dev) {
+                if (tab[i].lds >= lds) return hipSuccess;
+                const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e == hipSuccess) tab[i].lds = lds;
+                return e;
+            }
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess && used < 96) { tab[used].fn = fn; tab[used].lds = lds; ++used; }
+    if (e == hipSuccess && dev >= 0 && used < CAP) { tab[used].fn = fn; tab[used].lds = lds; tab[used].dev = dev; ++used; }
     return e;
 }

@@ -39,7 +39,8 @@ struct MgpP2P {
     hipIpcMemHandle_t handle;
 };
 
-__device__ __forceinline__ float p2p_exchange_mean(const P2PDev& X, int i, float mine, unsigned seq)
+// `late` (optional): set to true when this entry's poll gave up -- the caller must not apply the result as a gradient.
+__device__ __forceinline__ float p2p_exchange_mean(const P2PDev& X, int i, float mine, unsigned seq, bool* late = nullptr)
 {
     const int slot = (int)(seq & 1u);
     const unsigned long long pkt = ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(mine);
@@ -66,6 +67,7 @@ __device__ __forceinline__ float p2p_exchange_mean(const P2PDev& X, int i, float
         if (all) break;
         if (wall_clock64() - t0 > X.timeout) {
             atomicOr(X.ctl + 2, 1);
+            if (late != nullptr) *late = true;
 #pragma unroll
             for (int q = 0; q < MGP_P2P_MAX_WORLD; ++q)
                 if ((unsigned)(p[q] >> 32) != seq) p[q] = 0ull;   // late peers contribute 0

@@ -365,7 +365,11 @@ void train_reduce_kernel(const float* __restrict__ part, int ntiles, int Pstride
                          float* __restrict__ loss, float inv_n, AdamArgs A, P2PDev X)
 {
     unsigned xseq = 0;
-    if (P2P) xseq = (unsigned)X.ctl[0] + 1u;
+    bool bad = false;                                    // P2P: an exchange timed out, now or earlier (sticky status word):
+    if (P2P) {                                           // the weights stay as they are -- a late peer's share counted as 0
+        xseq = (unsigned)X.ctl[0] + 1u;                  // would be a wrong, rank-divergent step -- and the host raises at its
+        bad = X.ctl[2] != 0;                             // next status check (P2PExchange.check)
+    }
     __shared__ float sh[TR_GROUPS][64];
     __shared__ float shc[2];
     const int pl = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -397,13 +401,13 @@ void train_reduce_kernel(const float* __restrict__ part, int ntiles, int Pstride
 #pragma unroll
         for (int q = 0; q < TR_GROUPS; ++q) s += sh[q][pl];
         if (i == Ptot) s *= inv_n;
-        if (P2P) s = p2p_exchange_mean(X, i, s, xseq);
+        if (P2P) s = p2p_exchange_mean(X, i, s, xseq, &bad);
         if (i == Ptot) {
             if (loss != nullptr) loss[0] = s;
             if (A.loss_hist != nullptr) A.loss_hist[*A.cursor % A.hist_cap] = s;   // (the cursor moves after every
         } else {                                                                         //  workgroup is through: ticket below)
             flat_grad[i] = s;
-            if (A.p != nullptr) {                        // torch.optim.Adam defaults, same expressions as mgp_adam_step_dev
+            if (A.p != nullptr && !bad) {                // torch.optim.Adam defaults, same expressions as mgp_adam_step_dev
                 const float one_m_b1 = (float)(1.0 - (double)A.b1), one_m_b2 = (float)(1.0 - (double)A.b2);
                 mgp_adam_elem(A.p[i], A.m[i], A.v[i], s, one_m_b1, A.b2, one_m_b2, shc[0], shc[1], A.eps);
             }

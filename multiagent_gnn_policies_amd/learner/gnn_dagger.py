@@ -236,6 +236,14 @@ class DAGGER(object):
         if self.p2p is not None:
             self.p2p.check()
 
+    def _checked_step(self):
+        """Adam after an eager all-reduce.  When that all-reduce was the one-shot exchange (stand-alone kernel,
+        FlatGradSync), its status is read BEFORE the step is enqueued: a late peer's share counted as zero must never
+        reach the weights (costs one stream synchronisation per update; the graph paths check inside the kernel)."""
+        if self.p2p is not None and parallel.is_distributed():
+            self.p2p.check()
+        self.actor_optim.step()
+
     def __del__(self):
         try:
             if getattr(self, 'p2p', None) is not None:
@@ -300,11 +308,15 @@ class DAGGER(object):
             if gu is None:
                 gu = self._graphed[B] = GraphedUpdate(self, B)
             loss = gu.run(delay_state_batch, delay_gso_batch, optimal_action_batch)
-            return loss.item() if sync else loss.clone()
+            if not sync:
+                return loss.clone()
+            value = loss.item()
+            self.end_updates()                     # the stream is idle anyway: a timed-out exchange raises HERE, per update
+            return value
         loss = self._train_grads(delay_state_batch, delay_gso_batch, optimal_action_batch)
         if loss is not None:                       # two launches wrote the flat gradient; (all-reduce,) Adam
             self.grad_sync.all_reduce_mean_(self.actor_optim.flat_grad)
-            self.actor_optim.step()
+            self._checked_step()
             return loss.item() if sync else loss
         self.actor_optim.zero_grad()
         actor_batch = self.actor(delay_state_batch, delay_gso_batch)
@@ -312,7 +324,7 @@ class DAGGER(object):
         policy_loss.backward()
         flat_grad = self.actor_optim.gather_grads()
         self.grad_sync.all_reduce_mean_(flat_grad)
-        self.actor_optim.step()
+        self._checked_step()
         return policy_loss.item()
 
     def _train_grads(self, X, G, Y):

@@ -570,6 +570,7 @@ def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
                 bufs = tuple(torch.empty(sh, device=device) for sh in ((batch_size, K, F, N), (batch_size, K, N, N),
                                                                        (batch_size, 1, n_a, N)))
             loss_dev = torch.zeros((1,), device=device)
+            learner.begin_updates()                               # as above: aligned ranks, then the status of the exchanges
             for _ in range(n_updates):
                 if on_device:
                     xs, gs, ys = memory.sample(batch_size, bufs, mean_pooling=p.mean_pooling)
@@ -581,6 +582,7 @@ def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
                     loss_sum += learner.gradient_step_tensors(xs, gs, ys)
                 updates += 1
             loss_sum += float(loss_dev.item())
+            learner.end_updates()
         if debug and rank == 0:
             print("Round: {}, episodes: {}, updates: {}, policy loss: {}".format(rd, (rd + 1) * n_envs * world,
                                                                                    updates, loss_sum))

@@ -143,23 +143,32 @@ class P2PExchange(object):
     def create(cls, n_floats, device=None, self_test=True):
         import ctypes
         from . import _lib
-        if not is_distributed() or os.environ.get('MGP_P2P', '1') == '0' or not torch.cuda.is_available():
+        if not is_distributed():                      # a property of the process group: the same answer on every rank
             return None
         world, rk = dist.get_world_size(), dist.get_rank()
-        if world < 2:
-            return None
         L = _lib.lib()
         cdev = _comm_device()
         ok = torch.ones((1,), dtype=torch.int32, device=cdev)
         ptr, comm = ctypes.c_void_p(), None
         hb = L.mgp_p2p_handle_bytes()
         mine = torch.zeros((hb,), dtype=torch.uint8)
-        if world > 8 or L.mgp_p2p_create(world, rk, int(n_floats), ctypes.byref(ptr)) != 0:
-            ok.zero_()
-        else:
+        # rank-LOCAL preconditions (environment, device, allocation, handle export) only clear this rank's `ok`; every rank
+        # then still walks through every collective below and the MIN all-reduce turns one refusal into everyone's None
+        local_ok = os.environ.get('MGP_P2P', '1') != '0' and torch.cuda.is_available() and world <= 8
+        if local_ok:
+            # the mailbox and the control words are allocated on the CURRENT HIP device: that must be the rank's own
+            want = torch.device(device).index if device is not None and torch.device(device).index is not None \
+                else torch.cuda.current_device()
+            with torch.cuda.device(want):
+                local_ok = L.mgp_p2p_create(world, rk, int(n_floats), ctypes.byref(ptr)) == 0
+        if local_ok:
             raw = (ctypes.c_ubyte * hb)()
-            _lib.check(L.mgp_p2p_handle(ptr, raw), 'mgp_p2p_handle')
-            mine = torch.tensor(list(raw), dtype=torch.uint8)
+            if L.mgp_p2p_handle(ptr, raw) == 0:
+                mine = torch.tensor(list(raw), dtype=torch.uint8)
+            else:
+                local_ok = False
+        if not local_ok:
+            ok.zero_()
         # every rank takes part in every collective below, whatever happened locally (no rank may be left waiting)
         parts = [torch.zeros((hb,), dtype=torch.uint8, device=cdev) for _ in range(world)]
         dist.all_gather(parts, mine.to(cdev))

@@ -46,6 +46,21 @@ def test_library_is_in_tree_and_built_for_gfx950():
     assert b'gfx950' in blob, "libmgp.so carries no gfx950 code object"
 
 
+def test_build_keys_follow_included_sources():
+    """A wrapper translation unit (rollout_wide.hip / rollout_w128.hip: `#include "rollout.hip"` under other macros) must
+    be rebuilt when the file it wraps changes: its per-object key covers the included sources, recursively."""
+    from multiagent_gnn_policies_amd import build
+    with open(os.path.join(build.CSRC, 'rollout.hip'), 'rb') as f:
+        body = f.read()
+    wrappers = [s for s in build.sources() if s != 'rollout.hip' and b'"rollout.hip"' in open(os.path.join(build.CSRC, s), 'rb').read()]
+    assert wrappers, "the wide / 128-wide builds are expected to wrap rollout.hip"
+    for w in wrappers:
+        assert body in build._tu_bytes(w)
+    assert body in build._tu_bytes('rollout.hip') and build._tu_bytes('agg.hip').count(body) == 0
+    # the shipped library is the one these sources produce
+    assert build.is_current()
+
+
 def test_c_abi_argument_validation_without_gpu():
     """Entry points validate sizes/pointers before touching the device."""
     from multiagent_gnn_policies_amd import _lib
