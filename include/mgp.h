@@ -302,6 +302,19 @@ int mgp_replay_gather_many(const float* feat, const unsigned long long* bits, co
 long mgp_rollout_image_floats(const int* dims, int n_layers, int K, int N);      /* 0: shape not covered */
 int mgp_rollout_image(const float* const* W, const float* const* b, const int* dims, int n_layers, int K, int N,
                       float* image, void* stream);
+/* CHECKER build of the same kernels (csrc/rollout_f32ref.hip): hidden layers of <= 32 input channels on fp32 MFMA 16x16x4 -- a
+ * k-ordered fp32 fmaf chain, the arithmetic the product build's split-bf16 layers (three bf16 pieces per operand, six of
+ * the nine cross products) stand in for.  Same arguments, same state layout, same carry; layer widths <= 32 only (no
+ * forwarding to the wide builds); `image` must come from mgp_rollout_f32ref_image (fp32 fragments), or be NULL.  Used by
+ * tests/test_gpu_headline_parity.py to hold the product build to it on the same episodes; not a fast path. */
+int mgp_rollout_f32ref_supported(const int* dims, int n_layers, int K, int N);
+int mgp_rollout_f32ref_steps_ex(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
+                                const int* dims, int n_layers, float* action, double* rewards,
+                                const MgpFlockParams* p, int B, int K, int N, int T, const float* image, void* carry,
+                                int flags, void* stream);
+long mgp_rollout_f32ref_image_floats(const int* dims, int n_layers, int K, int N);
+int mgp_rollout_f32ref_image(const float* const* W, const float* const* b, const int* dims, int n_layers, int K, int N,
+                             float* image, void* stream);
 long mgp_rollout_carry_bytes(int K, int N);                                       /* per episode; 0: shape not covered */
 /* G[:,j] = A_t A_{t-1} .. A_{t-j+1} for j = 1..K-1 from a carry (slice 0, the identity, is not touched). */
 int mgp_rollout_carry_to_dense(const void* carry, float* G, int B, int K, int N, void* stream);

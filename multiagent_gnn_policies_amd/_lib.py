@@ -79,6 +79,11 @@ SIGNATURES = {
     'mgp_replay_gather_many': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     'mgp_rollout_image_floats': (_long, [_vp, _int, _int, _int]),
     'mgp_rollout_image': (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
+    'mgp_rollout_f32ref_supported': (_int, [_vp, _int, _int, _int]),
+    'mgp_rollout_f32ref_steps_ex': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, ctypes.POINTER(MgpFlockParams),
+                                          _int, _int, _int, _int, _vp, _vp, _int, _vp]),
+    'mgp_rollout_f32ref_image_floats': (_long, [_vp, _int, _int, _int]),
+    'mgp_rollout_f32ref_image': (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
     'mgp_rollout_carry_bytes': (_long, [_int, _int]),
     'mgp_rollout_carry_to_dense': (_int, [_vp, _vp, _int, _int, _int, _vp]),
     'mgp_flock_controller': (_int, [_vp, _vp, _vp, ctypes.POINTER(MgpFlockParams), _int, _int, _int, _vp]),

@@ -23,7 +23,7 @@ COMMON_FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall',
 # flock.hip must reproduce numpy's op-by-op fp64 rounding: no fused multiply-add contraction
 PER_FILE_FLAGS = {'flock.hip': ['-ffp-contract=off'], 'rollout.hip': ['-ffp-contract=off'],
                   'sparse_sim.hip': ['-ffp-contract=off'], 'rollout_wide.hip': ['-ffp-contract=off'],
-                  'rollout_w128.hip': ['-ffp-contract=off']}
+                  'rollout_w128.hip': ['-ffp-contract=off'], 'rollout_f32ref.hip': ['-ffp-contract=off']}
 
 
 def sources():

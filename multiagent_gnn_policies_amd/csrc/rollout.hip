@@ -61,7 +61,12 @@ template <int CK> struct RoGatherUnroll { static constexpr int value = CK ? 4 : 
 __device__ unsigned long long mgp_ro_stamps[16 * 32];     // [wave][stamp]
 #define RO_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == 5) mgp_ro_stamps[(threadIdx.x >> 6) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
 #define RO_STAMPX(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) mgp_ro_stamps[(threadIdx.x >> 6) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+// launch anatomy: the 100 MHz wall clock of EVERY workgroup at kernel begin / entry done / first steps / loop end / kernel end
+// (tools/harness/ro_launch_prof.hip: dispatch ramp, entry, cold first step, exit -- what a launch costs beyond its steps)
+__device__ long long mgp_ro_wall[4096 * 8];
+#define RO_WALL(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) mgp_ro_wall[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 #else
+#define RO_WALL(i) do { } while (0)
 #define RO_STAMP(i) do { } while (0)
 #define RO_STAMPX(i) do { } while (0)
 #endif
@@ -150,6 +155,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                     int n_layers_arg, const float* __restrict__ image, int image_floats, unsigned long long* __restrict__ carry,
                     int flags, MgpCollect cl)
 {
+    RO_WALL(0);
     const int N = CN ? CN : N_arg, K = CK ? CK : K_arg;
     const int n_layers = CM ? 3 : n_layers_arg;
     const RoOff cv = ro_offsets(N, K);
@@ -289,6 +295,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     bool s1_ready = false;
     constexpr int S1T = CK ? (CK > 1 ? CK - 1 : 1) : 4;       // taps >= 1 (K <= 5)
     constexpr int GU = RoGatherUnroll<CK>::value;
+    RO_WALL(1);
 
     for (int t = 0; t < T; ++t) {
         RO_STAMP(0);
@@ -860,7 +867,9 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         hs = hsn;
         s1_ready = do_s1;
         RO_STAMP(5);
+        if (t < 3) RO_WALL(2 + t);
     }
+    RO_WALL(5);
 
     // ------------------------------------------------------------------ exit: LDS -> the caller's buffers
     // Dense operator slices of the final state, one row per wave at a time:
@@ -947,6 +956,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     if (CL)
         for (int e = tid; e < 2 * N; e += RO_THREADS) cl.expert_io[(size_t)b * 2 * N + e] = uexp[e];
     RO_STAMPX(2);
+    RO_WALL(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1602,13 +1612,8 @@ int launch_rollout(double* x, float* G, float* Xd, float* action, double* reward
                    unsigned long long woffA, unsigned long long woffB, int n_layers, int lds, hipStream_t st,
                    const float* image, int image_floats, unsigned long long* carry, int flags, const MgpCollect* cl)
 {
-    static thread_local int lds_set = 0;                       // the attribute sticks to the function: set it when it grows
-    if (lds > lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<CN, CK, FD, CL, CM>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return MGP_ELAUNCH;
-        lds_set = lds;
-    }
+    // (the attribute sticks to the function object of the CURRENT device: cached per (device, kernel), mgp_common.h)
+    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(rollout_kernel<CN, CK, FD, CL, CM>), (size_t)lds) != hipSuccess) return MGP_ELAUNCH;
     MgpCollect none = {};
     hipEvent_t ev0, ev1;
     take_launch_events(&ev0, &ev1);
@@ -1628,13 +1633,7 @@ int launch_rollout_big(double* x, float* G, float* Xd, float* action, double* re
                        unsigned long long woffA, unsigned long long woffB, int n_layers, int lds, hipStream_t st,
                        const float* image, int image_floats, unsigned long long* carry, int flags, const MgpCollect* cl)
 {
-    static thread_local int lds_set = 0;
-    if (lds > lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_big_kernel<FD, CL>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return MGP_ELAUNCH;
-        lds_set = lds;
-    }
+    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(rollout_big_kernel<FD, CL>), (size_t)lds) != hipSuccess) return MGP_ELAUNCH;
     MgpCollect none = {};
     hipEvent_t ev0, ev1;
     take_launch_events(&ev0, &ev1);
@@ -1655,7 +1654,15 @@ int launch_rollout_big(double* x, float* G, float* Xd, float* action, double* re
 // public entry points and forwards the shapes only the wide build covers.
 // Build levels: 0 = this file as is (public entry points), 1 = rollout_wide.hip, 2 = rollout_w128.hip (ONE hidden layer up to
 // 128 wide: cfg/hidden_size.cfg:58).  A level forwards the shapes it does not cover to the next one.
-#if defined(MGP_RO_X128)
+#if defined(MGP_RO_F32REF)
+// rollout_f32ref.hip: this build once more with the hidden layers on fp32 MFMA 16x16x4 (MGP_RO_BF16 = 0) -- the arithmetic the
+// split-bf16 layers stand in for; entry points of their own (include/mgp.h), nothing forwarded
+#define MGP_RO_SUPPORTED mgp_rollout_f32ref_supported
+#define MGP_RO_STEPS_EX mgp_rollout_f32ref_steps_ex
+#define MGP_RO_COLLECT mgp_rollout_f32ref_collect_
+#define MGP_RO_IMAGE_FLOATS mgp_rollout_f32ref_image_floats
+#define MGP_RO_IMAGE mgp_rollout_f32ref_image
+#elif defined(MGP_RO_X128)
 #define MGP_RO_SUPPORTED mgp_rollout_x128_supported_
 #define MGP_RO_STEPS_EX mgp_rollout_x128_steps_ex_
 #define MGP_RO_COLLECT mgp_rollout_x128_collect_
@@ -1857,7 +1864,7 @@ extern "C" int MGP_RO_COLLECT(double* x, float* G, float* Xd, const float* const
     return ro_run(x, G, Xd, W, b, dims, n_layers, nullptr, rewards, p, B, K, N, T, image, carry, flags, cl, stream);
 }
 
-#ifdef MGP_RO_BASE
+#if defined(MGP_RO_BASE) && !defined(MGP_RO_F32REF)
 // the original entry point: dense state in, dense state out, weight image built inside the launch
 extern "C" int mgp_rollout_steps(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
                                  const int* dims, int n_layers, float* action, double* rewards,

@@ -257,8 +257,10 @@ def rollout_supported(dims, K, N):
 RO_ENTER_CARRY, RO_EXIT_CARRY, RO_SKIP_DENSE = 1, 2, 4          # include/mgp.h: MGP_RO_*
 
 
-def rollout_steps(x, G, Xd, weights, biases, dims, params, T, action=None, rewards=None, image=None, carry=None, flags=0):
+def rollout_steps(x, G, Xd, weights, biases, dims, params, T, action=None, rewards=None, image=None, carry=None, flags=0,
+                  f32ref=False):
     """T closed-loop policy steps for every episode in ONE launch, state updated in place (mgp_rollout_steps_ex).
+    f32ref: the checker build with the hidden layers on fp32 MFMA (mgp_rollout_f32ref_steps_ex; tests only).
     x (B,N,4) f64 | G (B,K,N,N) | Xd (B,K,6,N) | weights[l] (out, in*step) / biases[l] fp32 | rewards (B,T) f64.
     image: prebuilt weight image (rollout_image), or None (built from weights / biases inside the launch);
     carry (B, rollout_carry_bytes) uint8 + flags (RO_*): factored hand-over of the operator history, see include/mgp.h.
@@ -283,9 +285,9 @@ def rollout_steps(x, G, Xd, weights, biases, dims, params, T, action=None, rewar
         ba = (ctypes.c_void_p * len(bs))(*[b_.data_ptr() for b_ in bs])
     else:
         _dev(image, 'image')
-    rc = _lib.lib().mgp_rollout_steps_ex(_ptr(x), _ptr(G), _ptr(Xd), wa, ba, cd, len(dims) - 1, _ptr(action), _ptr(rewards),
-                                         ctypes.byref(params), B, K, N, int(T), _ptr(image), _ptr(carry), int(flags),
-                                         _stream())
+    entry = _lib.lib().mgp_rollout_f32ref_steps_ex if f32ref else _lib.lib().mgp_rollout_steps_ex
+    rc = entry(_ptr(x), _ptr(G), _ptr(Xd), wa, ba, cd, len(dims) - 1, _ptr(action), _ptr(rewards),
+               ctypes.byref(params), B, K, N, int(T), _ptr(image), _ptr(carry), int(flags), _stream())
     if rc == -5:
         return False
     _lib.check(rc, 'mgp_rollout_steps_ex')

@@ -136,6 +136,8 @@ class P2PExchange(object):
     `P2PExchange.create(n_floats)` returns None when the exchange cannot be brought up (MGP_P2P=0, world > 8, IPC refused,
     or the self-test failing on any rank): callers then keep the torch.distributed collective."""
 
+    last_bringup = None   # why the last create() on this rank returned what it did: {'ok', 'stage', 'local_ok', 'world'}
+
     def __init__(self, handle, world, rank, n_floats, mem_kind):
         self.handle, self.world, self.rank, self.n_floats, self.mem_kind = handle, world, rank, n_floats, mem_kind
 
@@ -146,6 +148,8 @@ class P2PExchange(object):
         if not is_distributed():                      # a property of the process group: the same answer on every rank
             return None
         world, rk = dist.get_world_size(), dist.get_rank()
+        if world < 2:
+            return None
         L = _lib.lib()
         cdev = _comm_device()
         ok = torch.ones((1,), dtype=torch.int32, device=cdev)
@@ -167,6 +171,8 @@ class P2PExchange(object):
                 mine = torch.tensor(list(raw), dtype=torch.uint8)
             else:
                 local_ok = False
+        stage = 'local preconditions / mailbox allocation / handle export'
+        cls.last_bringup = dict(ok=False, stage=stage, local_ok=bool(local_ok), world=world)
         if not local_ok:
             ok.zero_()
         # every rank takes part in every collective below, whatever happened locally (no rank may be left waiting)
@@ -174,21 +180,32 @@ class P2PExchange(object):
         dist.all_gather(parts, mine.to(cdev))
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 1:
+            stage = 'hipIpcOpenMemHandle of the peers\' mailboxes (mgp_p2p_connect)'
             blob = bytes(torch.cat([p_.cpu() for p_ in parts]).tolist())
-            if L.mgp_p2p_connect(ptr, blob) != 0:
+            local_ok = L.mgp_p2p_connect(ptr, blob) == 0
+            if not local_ok:
                 ok.zero_()
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 1:
+            stage = 'self-test (two exchanges of known values)'
             kind = ctypes.c_int()
             L.mgp_p2p_info(ptr, None, None, None, ctypes.byref(kind))
             comm = cls(ptr, world, rk, int(n_floats), kind.value)
-            if self_test and not comm._self_test(device):
+            local_ok = (not self_test) or comm._self_test(device)
+            if not local_ok:
                 ok.zero_()
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) != 1:
+            # refused somewhere: say so ONCE per rank that saw it locally (callers keep the torch.distributed collective)
+            cls.last_bringup = dict(ok=False, stage=stage, local_ok=bool(local_ok), world=world)
+            if not local_ok and os.environ.get('MGP_P2P', '1') != '0':
+                import warnings
+                warnings.warn("one-shot gradient exchange not available on rank %d of %d: failed at %s; falling back to the "
+                              "torch.distributed all-reduce" % (rk, world, stage), RuntimeWarning)
             if ptr.value:
                 L.mgp_p2p_destroy(ptr)
             return None
+        cls.last_bringup = dict(ok=True, stage='up', local_ok=True, world=world)
         return comm
 
     def _self_test(self, device=None):

@@ -68,7 +68,7 @@ def _check_bound(u, ref, noise_refs, what, plain_everywhere, factor=1.0):
     elsewhere (agents about to collide: 1/r^4 features of 1e4 and more) within 1e-5 + the reference's own distance to the
     exact result, factor one -- the triangle-inequality form of "within 1e-5 of the fp32 reference".  The reference's distance
     is the larger of its two fp32 evaluations' (numpy and PyTorch-CPU op order: on such states they differ from each other by
-    several 1e-5).  `factor` = 1 on the lattice states; 3 on the environment's own disc resets, where in the first steps MOST
+    several 1e-5).  `factor` = 1 on the lattice states; 2 (round 3: 3) on the environment's own disc resets, where in the first steps MOST
     episodes are ill-conditioned (agents start as close as 0.1 R: 1/r^4 = 1e4; the reference's fp32 evaluations are up to 1.5e-3
     from exact) and the kernel's error is another draw from that distribution, not a fraction of one witness's draw."""
     err = elem_err_per_episode(u, ref)
@@ -113,7 +113,7 @@ def test_resident_last_action_elementwise_1e5_full_batch(T, init):
     # the lattice states of this test except around step 20, where the freshly reset lattice has collapsed locally (1/r^4
     # features reach 1e4) and the reference's own fp32 evaluations -- numpy vs torch op order -- differ by 4e-5 from each other
     _check_bound(u, ref, _reference_fp32(G, X, Ws, bs, SAMPLED), 'resident kernel, last action of a %d-step launch, B=%d, %s resets' % (T, B_FULL, init),
-                 plain_everywhere=(init == 'grid' and T != 20), factor=1.0 if init == 'grid' else 3.0)
+                 plain_everywhere=(init == 'grid' and T != 20), factor=1.0 if init == 'grid' else 2.0)
     # the step itself: integration bit-exact given that action, network bit-exact (oracle/flock.py: FLOCK-SPEC v1)
     x_before = ro.sim.x.cpu().numpy(); x_after = ro2.sim.x.cpu().numpy()
     G_after = ro2.state.delay_gso.cpu().numpy()
@@ -137,8 +137,51 @@ def test_two_launch_actor_elementwise_1e5_full_batch(init):
             out = ro.actor(ro.state.delay_state, ro.state.delay_gso).cpu().numpy()
         _check_bound(out[SAMPLED], _oracle_action(G, X, Ws, bs, SAMPLED), _reference_fp32(G, X, Ws, bs, SAMPLED),
                      'mgp_actor_fwd, state %d after a %s reset, B=256' % (t, init), plain_everywhere=(init == 'grid'),
-                     factor=1.0 if init == 'grid' else 3.0)
+                     factor=1.0 if init == 'grid' else 2.0)
         ro.step()
+
+
+@pytest.mark.parametrize('init', ['grid', 'disc'])
+def test_split_bf16_layers_against_the_fp32_mfma_build(init):
+    """The product build runs the hidden layers as split-bf16 MFMAs (three bf16 pieces per fp32 operand, six of the nine
+    cross products; csrc/rollout_common.h::ro_layer_bf16) and declares `dtype: f32`.  The SAME kernel built with the layers on
+    fp32 MFMA 16x16x4 (csrc/rollout_f32ref.hip: a k-ordered fp32 fmaf chain) is run on the same 256 episodes -- one step from
+    the same state, and a 20-step closed loop -- and the two are held to 2e-6 of each other elementwise (what is dropped is
+    3 x 2^-24 of a product; the accumulation orders differ).  Everything outside the layers is the same code: integration,
+    membership bits, carry bit-identical given the action."""
+    from multiagent_gnn_policies_amd import ops
+    ro = _fresh(init=init)
+    assert 'reference checkpoint' in ro.weights
+    ro.run_resident(5)
+    Ws = [c.weight.detach().reshape(c.weight.shape[0], -1).contiguous() for c in ro.actor.conv_layers]
+    bs = [c.bias.detach().contiguous() for c in ro.actor.conv_layers]
+    dims = tuple(ro.actor.layers)
+    assert ops._lib.lib().mgp_rollout_f32ref_supported((__import__('ctypes').c_int * len(dims))(*dims), len(dims) - 1, K, N)
+    G0 = ro.state.delay_gso.clone(); X0 = ro.state.delay_state.clone(); x0 = ro.sim.x.clone()
+    out = {}
+    for T in (1, 20):
+        for ref in (False, True):
+            x, G, Xd = x0.clone(), G0.clone(), X0.clone()
+            action = torch.zeros((B_FULL, 1, 2, N), device='cuda')
+            rewards = torch.zeros((B_FULL, T), device='cuda', dtype=torch.float64)
+            assert ops.rollout_steps(x, G, Xd, Ws, bs, dims, ro.sim._c, T, action=action, rewards=rewards, f32ref=ref)
+            out[(T, ref)] = (action.cpu().numpy().astype(np.float64), x.cpu().numpy(), G.cpu().numpy())
+    # one step from the identical state: the actions differ by the layers' arithmetic only
+    u, v = out[(1, False)][0], out[(1, True)][0]
+    d1 = np.abs(u - v) / np.maximum(1.0, np.abs(v))
+    print('split-bf16 vs fp32-MFMA layers, %s resets, one step, 256 episodes: worst elementwise difference %.3g (max |u| %.3g)'
+          % (init, d1.max(), np.abs(v).max()))
+    assert d1.max() <= 2e-6
+    # given (almost) the same action the simulator halves agree: same network, positions to the action's difference x dt^2
+    assert np.mean(out[(1, False)][2][:, 1] != out[(1, True)][2][:, 1]) <= 1e-5
+    assert np.max(np.abs(out[(1, False)][1] - out[(1, True)][1])) <= 1e-9
+    # 20-step closed loop: the two builds stay together (a closed loop amplifies a rounding; this is a sanity bound, the
+    # elementwise statement is the one-step one above)
+    u20, v20 = out[(20, False)][0], out[(20, True)][0]
+    d20 = np.abs(u20 - v20) / np.maximum(1.0, np.abs(v20))
+    print('  ... last action of a 20-step closed loop: worst difference %.3g, median over episodes %.3g'
+          % (d20.max(), np.median(d20.reshape(B_FULL, -1).max(axis=1))))
+    assert np.median(d20.reshape(B_FULL, -1).max(axis=1)) <= 2e-5
 
 
 def test_reset_push_after_strided_steps_reads_the_reset_observation():

@@ -55,6 +55,19 @@ def test_three_ranks_on_one_device():
     assert r['exchanges'] > 0
 
 
+def test_eight_ranks_on_one_device():
+    """MGP_P2P_MAX_WORLD = 8 = the node north_star names: eight processes, each with its own mailbox of 8 x 2 x 1,731 packets
+    (216 KB), every rank pushing into seven peers and polling seven sources per entry.  On the one-GPU box the eight ranks'
+    kernels share the device (an upper bound on the exchange's latency, a real check of its protocol at full width)."""
+    r = run_ranks('allreduce', world=8, timeout=900)
+    assert r['exchanges'] >= 40 + 6 + 32 * 13 and r['exchange_us_in_graph'] < 400.0, r
+
+
+def test_data_parallel_update_at_eight_ranks_is_bit_identical_on_every_rank():
+    r = run_ranks('train', world=8, timeout=900)
+    assert r['max_weight_diff_vs_single_process'] <= 1e-7
+
+
 def test_missing_peer_is_a_status_not_a_hang():
     r = run_ranks('timeout')
     assert r['status'] == 1

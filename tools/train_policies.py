@@ -1,0 +1,152 @@
+"""Train the policies the non-headline shapes are benched and parity-gated on (run on the GPU box).
+
+The reference ships ONE checkpoint (models/actor_FlockingRelative-v0_dagger_k3: K = 3, hidden [32, 32]).  Every other
+shape of its sweeps (cfg/k.cfg, cfg/hidden_size.cfg, cfg/n_twoflocks.cfg, cfg/dagger_leader.cfg, cfg/dagger_twoflocks.cfg)
+used to run on default-init weights, and a random network drives a freshly reset flock into itself: 1/r^4 features of 1e4
+and more, an ill-conditioned forward, parity checked on a relaxed bound.  This script trains those policies with the
+package's own vectorised DAGGER loop (learner/vec_dagger.py::train_dagger_vec: the reference's schedule -- cfg/dagger.cfg:
+400 episodes, 200 updates per episode, batch 20, beta_coeff 0.993 -- with 64 episodes side by side per round) and stores
+them as plain arrays (data, like tests/golden/ckpt_dagger_k3.npz):
+
+    python tools/train_policies.py [--out gpurun_out/policies] [--only NAME ...]
+    -> <out>/policy_<env>_k<K>_h<H>x<L>_n<N>.npz   conv_layers__{i}__weight / __bias  + meta (JSON string)
+    -> <out>/summary.json                           reward of the trained policy next to idle agents and the expert
+
+`bench.load_weights` / `tests` pick a file by (environment, K, hidden sizes), nearest N.
+"""
+import argparse
+import configparser
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+# (name suffix, env id, N, K, hidden width, hidden layers)
+SHAPES = [
+    ('FlockingRelative-v0', 200, 4, 32, 2),      # BASELINE configs[4] shape on the plain environment (cfg/n_twoflocks.cfg:114-116 is K=4 N=200)
+    ('FlockingLeader-v0', 200, 4, 32, 2),        # configs[4]
+    ('FlockingTwoFlocks-v0', 200, 4, 32, 2),     # configs[4]
+    ('FlockingRelative-v0', 100, 4, 32, 2),      # cfg/k.cfg
+    ('FlockingRelative-v0', 100, 2, 32, 2),
+    ('FlockingRelative-v0', 100, 1, 32, 2),
+    ('FlockingRelative-v0', 100, 3, 64, 2),      # cfg/hidden_size.cfg
+    ('FlockingRelative-v0', 100, 3, 128, 1),
+    ('FlockingRelative-v0', 100, 3, 128, 2),
+    ('FlockingRelative-v0', 100, 3, 64, 1),
+    ('FlockingRelative-v0', 100, 3, 32, 1),
+    ('FlockingRelative-v0', 100, 3, 32, 3),
+    ('FlockingLeader-v0', 100, 1, 32, 2),        # cfg/dagger_leader.cfg (k = 1)
+    ('FlockingTwoFlocks-v0', 100, 2, 32, 2),     # cfg/dagger_twoflocks.cfg (k = 2)
+    ('FlockingStochastic-v0', 100, 3, 32, 2),    # cfg/dagger_stoch.cfg
+]
+
+
+def policy_name(env, N, K, H, L):
+    return 'policy_%s_k%d_h%dx%d_n%d' % (env.replace('Flocking', '').replace('-v0', '').lower(), K, H, L, N)
+
+
+def section(env, N, K, H, L, lr, seed, episodes, updates_per_step):
+    cp = configparser.ConfigParser()
+    cp['DEFAULT'] = dict(alg='dagger_vec', batch_size='20', buffer_size='10000', updates_per_step=str(updates_per_step),
+                         seed=str(seed), actor_lr=repr(lr), n_train_episodes=str(episodes), beta_coeff='0.993',
+                         test_interval='40', n_test_episodes='64', k=str(K), hidden_size=str(H), n_layers=str(L),
+                         gamma='0.99', tau='0.5', env=env, v_max='3.0', comm_radius='1.0', n_agents=str(N),
+                         n_actions='2', n_states='6', debug='False', dt='0.01')
+    cp['t'] = {}
+    return cp['t']
+
+
+def scripted_reward(params, device, steps, mode, lanes=32, seed=77):
+    """Per-episode reward of idle agents ('idle') or of the spec's teacher ('expert') from the same reset distribution."""
+    from multiagent_gnn_policies_amd.envs import VecFlock
+    sim = VecFlock(lanes, params, device, with_expert=True)
+    sim.reset(np.random.RandomState(seed))
+    total = torch.zeros((lanes,), device=device, dtype=torch.float64)
+    zero = torch.zeros((lanes, params.n_agents, 2), device=device)
+    for _ in range(steps):
+        u = sim.controller().clone() if mode == 'expert' else zero
+        sim.step(u)
+        total += sim.reward
+    return float(total.mean().item())
+
+
+def train_one(env, N, K, H, L, device, lrs, episodes, updates_per_step, n_envs, steps):
+    from multiagent_gnn_policies_amd.learner.vec_dagger import train_dagger_vec, _params_from_args
+    best = None
+    tried = []
+    for lr in lrs:
+        sec = section(env, N, K, H, L, lr, 11, episodes, updates_per_step)
+        random.seed(11); np.random.seed(11); torch.manual_seed(11)
+        t0 = time.time()
+        stats = train_dagger_vec(sec, device, n_envs=n_envs, episode_steps=steps)
+        el = time.time() - t0
+        tried.append(dict(lr=lr, mean=stats['mean'], std=stats['std'], updates=stats['updates'], seconds=el,
+                          collect=stats['collect']))
+        print('  lr %g: reward %.1f +- %.1f, %d updates, %.1f s, collection on %s' % (
+            lr, stats['mean'], stats['std'], stats['updates'], el, stats['collect']), flush=True)
+        if np.isfinite(stats['mean']) and (best is None or stats['mean'] > best[0]['mean']):
+            sd = {k: v.detach().cpu().numpy().copy() for k, v in stats['learner'].actor.state_dict().items()}
+            best = (tried[-1], sd)
+        del stats
+        torch.cuda.empty_cache()
+    params = _params_from_args(section(env, N, K, H, L, lrs[0], 11, episodes, updates_per_step))
+    return best, tried, params
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'policies'))
+    ap.add_argument('--only', nargs='*', default=None, help='policy names (policy_<env>_k.._h..x.._n..) to train')
+    ap.add_argument('--lrs', nargs='*', type=float, default=[5e-5, 2e-4, 6e-4])
+    ap.add_argument('--episodes', type=int, default=448, help='cfg/dagger.cfg: 400; 7 rounds of 64 lanes')
+    ap.add_argument('--updates-per-step', type=int, default=200)
+    ap.add_argument('--envs', type=int, default=64)
+    ap.add_argument('--steps', type=int, default=500, help='episode length (FLOCK-SPEC item 6)')
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    device = torch.device('cuda:0')
+    summary = {}
+    for env, N, K, H, L in SHAPES:
+        name = policy_name(env, N, K, H, L)
+        if args.only and name not in args.only:
+            continue
+        print(name, flush=True)
+        try:
+            best, tried, params = train_one(env, N, K, H, L, device, args.lrs, args.episodes, args.updates_per_step,
+                                            args.envs, args.steps)
+            idle = scripted_reward(params, device, args.steps, 'idle')
+            expert = scripted_reward(params, device, args.steps, 'expert')
+        except Exception as e:                                        # keep going: one shape must not cost the others
+            import traceback
+            traceback.print_exc()
+            summary[name] = dict(error=repr(e))
+            continue
+        if best is None:
+            summary[name] = dict(error='no finite result', tried=tried)
+            continue
+        meta = dict(name=name, env=env, n_agents=N, k=K, hidden=[H] * L, trained_with='tools/train_policies.py '
+                    '(learner/vec_dagger.py::train_dagger_vec, %d lanes x %d steps per round)' % (args.envs, args.steps),
+                    schedule=dict(episodes=args.episodes, updates_per_step=args.updates_per_step, batch_size=20,
+                                  beta_coeff=0.993, actor_lr=best[0]['lr'], seed=11),
+                    reward_per_episode=dict(policy=best[0]['mean'], policy_std=best[0]['std'], idle_agents=idle,
+                                            spec_teacher=expert, episode_steps=args.steps),
+                    tried=tried)
+        arrays = {k.replace('.', '__'): v for k, v in best[1].items()}
+        arrays['meta'] = np.array(json.dumps(meta))
+        np.savez(os.path.join(args.out, name + '.npz'), **arrays)
+        summary[name] = meta
+        print('  -> %s: policy %.1f | teacher %.1f | idle %.1f  (lr %g)' % (name, best[0]['mean'], expert, idle, best[0]['lr']),
+              flush=True)
+    with open(os.path.join(args.out, 'summary.json'), 'w') as f:
+        json.dump(summary, f, indent=1, sort_keys=True)
+
+
+if __name__ == '__main__':
+    main()
