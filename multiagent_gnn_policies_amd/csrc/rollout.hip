@@ -51,6 +51,10 @@ constexpr int RO_WAVES = RO_THREADS / 64;
 #ifndef RO_S1L
 #define RO_S1L 8                          // (4 lanes per row -- 7 waves instead of 13, 25 candidates each -- measured 1 % slower)
 #endif
+#ifndef RO_S1_DOT
+#define RO_S1_DOT 0                       // 1: the pair test in dot-product form (six instructions per candidate instead of eight, but a
+                                          // cancellation error ~ M^2 instead of M R: a 40x wider band; measured 0.8k cycles SLOWER per step)
+#endif
 constexpr int RO_PIECES = RO_S1L;         // lanes per agent row in the pairwise pass S1 (adjacent lanes): 8 or 4
 constexpr int RO_MAXN = 128;              // RO_THREADS / RO_PIECES rows; membership bits of a row fit 2 x u64
 constexpr int RO_LDS_LIMIT = 160 * 1024;
@@ -94,7 +98,7 @@ struct RoOff {
     int act;                              // float [ncols16][RO_CS] activations (in place through the layers); row buffers on exit
     int rlist;                            // u8 [H][N][RS] ascending neighbour lists (RS = ro_list_stride(N))
     int rcnt;                             // int [H][N] list lengths
-    int sxy;                              // float2 [N] fp32 coordinates relative to the reference point
+    int sxy;                              // float4 [N] fp32 coordinates relative to the reference point: {sx, sy, sx^2 + sy^2, -}
     int mmax;                             // float [8]: max |relative coordinate| of the step, one slot per MLP wave
     int wtab;                             // float [N + 1]: row weight of a network row by its degree (1/max(deg,1) or 1)
     int uexp;                             // float [2][N] expert action of the current state (data collection) + double [2] velocity sums
@@ -131,7 +135,7 @@ __host__ __device__ constexpr RoOff ro_offsets(int N, int K)
     c.act = ro_take(off, ((N + 15) & ~15) * RO_CS * 4);
     c.rlist = ro_take(off, H * N * ro_list_stride(N));
     c.rcnt = ro_take(off, H * N * 4);
-    c.sxy = ro_take(off, N * 8);
+    c.sxy = ro_take(off, N * 16);
     c.mmax = ro_take(off, 32);
     c.wtab = ro_take(off, (N + 1) * 4);
     c.uexp = ro_take(off, 2 * N * 4 + 16);
@@ -173,7 +177,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     float* act = reinterpret_cast<float*>(smraw + cv.act);
     unsigned char* rlist = smraw + cv.rlist;
     int* rcnt = reinterpret_cast<int*>(smraw + cv.rcnt);
-    float2* sxy = reinterpret_cast<float2*>(smraw + cv.sxy);
+    float4* sxy = reinterpret_cast<float4*>(smraw + cv.sxy);
     float* wtab = reinterpret_cast<float*>(smraw + cv.wtab);
     float* uexp = reinterpret_cast<float*>(smraw + cv.uexp);                 // [2][N]
     double* vtot = reinterpret_cast<double*>(smraw + cv.uexp + ((2 * N * 4 + 7) & ~7));
@@ -189,27 +193,43 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
 
     // ------------------------------------------------------------------ entry: the episode's state -> LDS
     // (the caller's dense operator slices stay in HBM: they are read by the first K - 1 steps only, see phase A)
-    for (int i = tid; i < 2 * N; i += RO_THREADS) rowmask[i] = 0ull;
-    for (int e = tid; e < K * Np * 8; e += RO_THREADS) {                       // tap k -> ring slot (K - k) % K, cur = 0
-        const int f = e & 7, mk = e >> 3, k = mk / Np, m = mk - k * Np;
-        const int slot = (k == 0) ? 0 : K - k;
-        XT[(slot * Np + m) * 8 + f] = (f < 6 && m < N) ? Xb[((size_t)k * 6 + f) * N + m] : 0.f;
+    // Every global read of the entry is REQUESTED before the first one is consumed, and each request is coalesced: the delay
+    // line is read in its memory order (the transposing index math is on the LDS side), the agent states as one double per
+    // thread, the carried history (bits + row weights) before the barrier it is needed behind.  (Round 3 read the delay line
+    // element by element in LDS order -- 38 wave-loads that touched 64 cache lines each -- and fetched the carry after the
+    // first barrier: 3.3 us from kernel begin to the first step, tools/harness/ro_launch_prof.hip.)
+    constexpr int XTP = 4;                                    // delay-line elements per thread (K 6 N <= 5 * 6 * 128 = 3840)
+    constexpr int CYP = 2;                                    // (network, row, quarter) items per thread (H N 4 <= 2048)
+    const int nXT = K * 6 * N;
+    float xtv[XTP];
+#pragma unroll
+    for (int r = 0; r < XTP; ++r) { const int e = tid + r * RO_THREADS; xtv[r] = (e < nXT) ? Xb[e] : 0.f; }
+    const double posv = (tid < 4 * N) ? xb[tid] : 0.0;        // thread 4 i + c: component c of agent i
+    const size_t cwords = ro_carry_words(K, N);
+    const bool enter_carry = (flags & MGP_RO_ENTER_CARRY) != 0;
+    unsigned long long cy_lo[CYP] = {0ull, 0ull}, cy_hi[CYP] = {0ull, 0ull};
+    float cy_w[CYP] = {0.f, 0.f};
+    if (enter_carry) {
+        const unsigned long long* cb = carry + (size_t)b * cwords;
+        const float* cw = reinterpret_cast<const float*>(cb + (size_t)H * N * 2);
+#pragma unroll
+        for (int r = 0; r < CYP; ++r) {
+            const int it = tid + r * RO_THREADS;
+            if (it < H * N * 4) {
+                const int rq = it >> 2;
+                cy_lo[r] = cb[(size_t)rq * 2]; cy_hi[r] = cb[(size_t)rq * 2 + 1];
+                cy_w[r] = cw[rq];
+            }
+        }
     }
-    for (int i = tid; i < N; i += RO_THREADS) {
-        spx[i] = xb[i * 4 + 0]; spy[i] = xb[i * 4 + 1]; svx[i] = xb[i * 4 + 2]; svy[i] = xb[i * 4 + 3];
-    }
-    if (tid == 0) { cref[0] = xb[0]; cref[1] = xb[1]; }
     unsigned long long coin_thr = 0ull;
     unsigned int coin_ep = 0u;
+    float uexv = 0.f;
+    float betav = 0.f;
     if (CL) {
-        for (int e = tid; e < 2 * N; e += RO_THREADS) uexp[e] = cl.expert_io[(size_t)b * 2 * N + e];
-        const double bq = floor((double)cl.beta[b] * 4294967296.0);       // P(expert drives) in units of 2^-32
-        coin_thr = bq <= 0.0 ? 0ull : (bq >= 4294967296.0 ? 4294967296ull : (unsigned long long)bq);
+        if (tid < 2 * N) uexv = cl.expert_io[(size_t)b * 2 * N + tid];
+        betav = cl.beta[b];
         coin_ep = cl.episode[b];
-    }
-    for (int c = tid; c <= N; c += RO_THREADS) {              // the expression of phase D3, tabulated by degree
-        const double deg = (double)c;
-        wtab[c] = (float)(p.mean_pooling ? 1.0 / (deg == 0.0 ? 1.0 : deg) : 1.0);
     }
     // weights in MFMA A-fragment order (see actor_fused.hip): wfrag[mt][lane][RO_WFS], lane = (c & 3) * 16 + (o & 15),
     // slot s = c >> 2, zero padded; then the bias of the layer's MT*16 rows.  A caller that launches repeatedly with the
@@ -229,6 +249,19 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 dst[e] = last ? ro_weight_image_elem(P.W[l], P.b[l], cin, cout, true, e) : ro_chain_image_elem(P.W[l], P.b[l], cin, cout, l, false, e);
         }
     }
+    // ---- LDS regions no load fills (while the requests are in flight)
+    for (int i = tid; i < 2 * N; i += RO_THREADS) rowmask[i] = 0ull;
+    for (int e = tid; e < K * Np; e += RO_THREADS)                               // the two pad floats of every delay-line row
+        *reinterpret_cast<float2*>(XT + (size_t)e * 8 + 6) = make_float2(0.f, 0.f);
+    if (Np > N)
+        for (int e = tid; e < K * (Np - N) * 6; e += RO_THREADS) {               // rows N .. Np - 1 (N % 4 != 0)
+            const int f = e % 6, mk = e / 6, k = mk / (Np - N), m = N + mk - k * (Np - N);
+            XT[((size_t)k * Np + m) * 8 + f] = 0.f;
+        }
+    for (int c = tid; c <= N; c += RO_THREADS) {              // the expression of phase D3, tabulated by degree
+        const double deg = (double)c;
+        wtab[c] = (float)(p.mean_pooling ? 1.0 / (deg == 0.0 ? 1.0 : deg) : 1.0);
+    }
     {
         float4* za = reinterpret_cast<float4*>(act);
         for (int i = tid; i < ncols16 * RO_CS / 4; i += RO_THREADS) za[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -236,32 +269,51 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         for (int i = tid; i < H * N * RS / 4; i += RO_THREADS) zl[i] = 0u;
         for (int i = tid; i < H * N; i += RO_THREADS) { rcnt[i] = 0; wrow[i] = 0.f; }
     }
+    // ---- the requested values -> LDS
+#pragma unroll
+    for (int r = 0; r < XTP; ++r) {                           // tap k -> ring slot (K - k) % K, cur = 0; row m, feature f
+        const int e = tid + r * RO_THREADS;
+        if (e < nXT) {
+            const int kf = e / N, m = e - kf * N, k = kf / 6, f = kf - k * 6;
+            const int slot = (k == 0) ? 0 : K - k;
+            XT[((size_t)slot * Np + m) * 8 + f] = xtv[r];
+        }
+    }
+    if (tid < 4 * N) spx[(tid & 3) * N + (tid >> 2)] = posv;
+    if (tid < 2) cref[tid] = posv;                            // agent 0's position: the reference point of the fp32 membership test
+    if (CL) {
+        if (tid < 2 * N) uexp[tid] = uexv;
+        const double bq = floor((double)betav * 4294967296.0);            // P(expert drives) in units of 2^-32
+        coin_thr = bq <= 0.0 ? 0ull : (bq >= 4294967296.0 ? 4294967296ull : (unsigned long long)bq);
+    }
     __syncthreads();
+    RO_WALL(7);
     // history networks handed over in factored form (MGP_RO_ENTER_CARRY): bits -> ascending neighbour lists, four lanes per
     // (network, row) as in phase D2; carry slot q = A_{t0 - q} goes to ring slot (H - q) % H, i.e. hs = 0 is the current
     // network and every tap's product is available as lists from the first step on (t_off): the dense slices are not read
     int t_off = 0;
-    const size_t cwords = ro_carry_words(K, N);
-    if (flags & MGP_RO_ENTER_CARRY) {
+    if (enter_carry) {
         t_off = K - 1;
-        const unsigned long long* cb = carry + (size_t)b * cwords;
-        const float* cw = reinterpret_cast<const float*>(cb + (size_t)H * N * 2);
-        for (int it = tid; it < H * N * 4; it += RO_THREADS) {
-            const int cq = it & 3, rq = it >> 2, q = rq / N, row = rq - q * N;
-            const int slot = (q == 0) ? 0 : H - q;
-            const unsigned long long lo = cb[(size_t)rq * 2], hi = cb[(size_t)rq * 2 + 1];
-            const int cnt = __popcll(lo) + __popcll(hi);
-            unsigned int chunk; int pos;
-            if (cq == 0) { chunk = (unsigned int)lo; pos = 0; }
-            else if (cq == 1) { chunk = (unsigned int)(lo >> 32); pos = __popc((unsigned int)lo); }
-            else if (cq == 2) { chunk = (unsigned int)hi; pos = __popcll(lo); }
-            else { chunk = (unsigned int)(hi >> 32); pos = __popcll(lo) + __popc((unsigned int)hi); }
-            unsigned char* lp = rlist + ((size_t)slot * N + row) * RS;
-            while (chunk) { lp[pos++] = (unsigned char)(32 * cq + __builtin_ctz(chunk)); chunk &= chunk - 1u; }
-            if (cq == 0) {
-                rcnt[slot * N + row] = cnt;
-                wrow[slot * N + row] = cw[rq];
-                if (q == 0) { rowmask[2 * row] = lo; rowmask[2 * row + 1] = hi; }
+#pragma unroll
+        for (int r = 0; r < CYP; ++r) {
+            const int it = tid + r * RO_THREADS;
+            if (it < H * N * 4) {
+                const int cq = it & 3, rq = it >> 2, q = rq / N, row = rq - q * N;
+                const int slot = (q == 0) ? 0 : H - q;
+                const unsigned long long lo = cy_lo[r], hi = cy_hi[r];
+                const int cnt = __popcll(lo) + __popcll(hi);
+                unsigned int chunk; int pos;
+                if (cq == 0) { chunk = (unsigned int)lo; pos = 0; }
+                else if (cq == 1) { chunk = (unsigned int)(lo >> 32); pos = __popc((unsigned int)lo); }
+                else if (cq == 2) { chunk = (unsigned int)hi; pos = __popcll(lo); }
+                else { chunk = (unsigned int)(hi >> 32); pos = __popcll(lo) + __popc((unsigned int)hi); }
+                unsigned char* lp = rlist + ((size_t)slot * N + row) * RS;
+                while (chunk) { lp[pos++] = (unsigned char)(32 * cq + __builtin_ctz(chunk)); chunk &= chunk - 1u; }
+                if (cq == 0) {
+                    rcnt[slot * N + row] = cnt;
+                    wrow[slot * N + row] = cy_w[r];
+                    if (q == 0) { rowmask[2 * row] = lo; rowmask[2 * row + 1] = hi; }
+                }
             }
         }
     }
@@ -295,6 +347,80 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     bool s1_ready = false;
     constexpr int S1T = CK ? (CK > 1 ? CK - 1 : 1) : 4;       // taps >= 1 (K <= 5)
     constexpr int GU = RoGatherUnroll<CK>::value;
+    // Gather stage 1 of a step: x_{t-j} . A_t for every tap j >= 1, A_t given as ascending lists (rc_, rl_) with row weights wv_;
+    // `curn_` = ring slot tap 0 of that step sits in.  One summation order wherever it runs (S2 of the previous step, or the
+    // entry of a launch that is handed the history in factored form): lane `part` of the column's four takes list entries
+    // part, part + 4, ... in order, then the quad sum (l ^ 1, l ^ 2).
+    auto gather_stage1 = [&](const int gtid, const int curn, const int* rc_new, const unsigned char* rl_new, const float* w_new) {
+            // one summation order for a gather stage wherever it runs: lane `part` of the column's four takes list entries
+            // part, part + 4, ... in order, then the quad sum (l ^ 1, l ^ 2)
+            const int c4 = gtid >> 2, part = gtid & 3;
+            float s1[S1T][6];
+#pragma unroll
+            for (int jj = 0; jj < S1T; ++jj)
+#pragma unroll
+                for (int f = 0; f < 6; ++f) s1[jj][f] = 0.f;
+            if (c4 < N) {
+                const int cnt = rc_new[c4];
+                const unsigned char* lp = rl_new + c4 * RS;
+                // four entries per lane per pass (lists of up to 16 neighbours in ONE pass): the list bytes without waiting for
+                // the length, then every operand read of the pass in flight together, then the multiply-adds in list order
+                // (entries beyond the list are masked; every list byte is a valid row index)
+                for (int e = part; e == part || e < cnt; e += 4 * GU) {
+                    int jn[GU]; float gv[GU];
+#pragma unroll
+                    for (int u = 0; u < GU; ++u) jn[u] = lp[min(e + 4 * u, RS - 1)];
+#pragma unroll
+                    for (int u = 0; u < GU; ++u) gv[u] = w_new[jn[u]];
+#pragma unroll
+                    for (int jj = 0; jj < S1T; ++jj) {
+                        if (jj < K - 1) {
+                            // tap jj + 1 of step t + 1 = tap jj of step t: ring slot ro_slot(curn, jj + 1) = ro_slot(cur, jj)
+                            const float* src = XT + (size_t)ro_slot(curn, jj + 1, K) * Np * 8;
+                            float4 x0[GU]; float2 x1[GU];
+#pragma unroll
+                            for (int u = 0; u < GU; ++u) {
+                                x0[u] = *reinterpret_cast<const float4*>(src + jn[u] * 8);
+                                x1[u] = *reinterpret_cast<const float2*>(src + jn[u] * 8 + 4);
+                            }
+#pragma unroll
+                            for (int u = 0; u < GU; ++u) {
+                                const float gz = (e + 4 * u < cnt) ? gv[u] : 0.f;
+                                s1[jj][0] = fmaf(x0[u].x, gz, s1[jj][0]); s1[jj][1] = fmaf(x0[u].y, gz, s1[jj][1]);
+                                s1[jj][2] = fmaf(x0[u].z, gz, s1[jj][2]); s1[jj][3] = fmaf(x0[u].w, gz, s1[jj][3]);
+                                s1[jj][4] = fmaf(x1[u].x, gz, s1[jj][4]); s1[jj][5] = fmaf(x1[u].y, gz, s1[jj][5]);
+                            }
+                        }
+                    }
+                }
+            }
+            
+#pragma unroll
+            for (int jj = 0; jj < S1T; ++jj) {
+                if (jj < K - 1) {
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) { s1[jj][f] += dpp_f<0xB1>(s1[jj][f]); s1[jj][f] += dpp_f<0x4E>(s1[jj][f]); }
+                    if (part == 0 && c4 < N) {
+                        if (jj == 0) {                        // tap 1: stage 1 is its only factor -> B-fragment slot
+#pragma unroll
+                            for (int f = 0; f < 6; ++f) act[c4 * RO_CS + rpos(f * K + 1)] = s1[0][f];
+                        } else {                              // taps >= 2: running product for stage 2 (buffer parity of q = 1)
+                            float* dst = VB + ((size_t)(K - 2) + (jj - 1)) * Np * 8 + c4 * 8;
+                            *reinterpret_cast<float4*>(dst) = make_float4(s1[jj][0], s1[jj][1], s1[jj][2], s1[jj][3]);
+                            *reinterpret_cast<float2*>(dst + 4) = make_float2(s1[jj][4], s1[jj][5]);
+                        }
+                    }
+                }
+            }
+    };
+    if (enter_carry && K >= 2) {
+        // a launch that is handed the history in factored form runs gather stage 1 of its FIRST step here, from the lists the
+        // entry has just built (slot 0 = the current network), and so starts in the fused schedule: no stage-by-stage phase A,
+        // two barriers less on the first step (round 3: 7.8 us for the first step of a launch, 5.0 us for the others)
+        if (tid < 4 * ((N + 15) & ~15)) gather_stage1(tid, 0, rcnt, rlist, wrow);
+        s1_ready = true;
+        __syncthreads();
+    }
     RO_WALL(1);
 
     for (int t = 0; t < T; ++t) {
@@ -532,6 +658,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 const float ux = rows_sum4(u2.x) + bb.x, uy = rows_sum4(u2.y) + bb.y;
                 RO_STAMP(14);
                 const bool agent = axis < 2 && col < N;
+                float sc = 0.f;                                 // fp32 coordinate relative to cref (this lane's axis)
                 if (agent) {
                     float ua = axis ? uy : ux;
                     if (CL && (unsigned long long)dagger_coin(cl.seed, coin_ep, (unsigned int)(cl.age0 + t)) < coin_thr)
@@ -544,8 +671,15 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                     pp = (pp + vv * p.dt) + ((ue * p.dt) * p.dt) * 0.5;      // integrate_one, one axis
                     vv = vv + ue * p.dt;
                     spx[axis * N + col] = pp; spx[(2 + axis) * N + col] = vv;
-                    const float sc = (float)(pp - cc);          // fp32 coordinate relative to cref
-                    reinterpret_cast<float*>(sxy)[2 * col + axis] = sc;
+                    sc = (float)(pp - cc);
+                    reinterpret_cast<float*>(sxy)[4 * col + axis] = sc;
+                }
+                if (RO_S1_DOT) {   // squared norm of the relative position for S1's dot-product form: the x lane (row 0 of the wave) and the y
+                    // lane (row 1) of a column add their squares through one v_permlane16_swap (every lane executes it)
+                    const float sq = sc * sc;
+                    unsigned int qa = __float_as_uint(sq), qb = qa;
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(qa), "+v"(qb));
+                    if (agent && axis == 0) reinterpret_cast<float*>(sxy)[4 * col + 2] = __uint_as_float(qa) + __uint_as_float(qb);
                 }
                 RO_STAMP(15);
             } else {
@@ -585,7 +719,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                     integrate_one(px, py, vx, vy, ub, 1, ccol < p.n_leaders, p);
                     spx[ccol] = px; spy[ccol] = py; svx[ccol] = vx; svy[ccol] = vy;
                     const float sx = (float)(px - cx), sy = (float)(py - cy);
-                    sxy[ccol] = make_float2(sx, sy);
+                    sxy[ccol] = make_float4(sx, sy, sx * sx + sy * sy, 0.f);
                 }
             }
         } else {
@@ -638,36 +772,86 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             // each other (farther ones miss R^2 by a wide margin): |s_j| <= |s_i| + 2R there, so M = |s_i|_inf + 2R is sound for
             // every candidate of this row -- no maximum over the flock, and a sound band gives the same final bits whatever
             // its width (pairs it cannot certify go to the exact test).
-            const float2 si = sxy[pi];
+#if RO_S1_DOT
+            // (experiment, off by default: measured slower) The distance test in DOT-PRODUCT form: |s_i - s_j|^2 = n_i + (n_j - 2 s_i . s_j) with n = |s|^2 stored next to the
+            // coordinates (phase C), n_i folded into the two thresholds: per candidate two fused multiply-adds and two sign tests
+            // (six vector instructions; the difference form took eight), and exactly dh8 candidates per lane in the sized builds
+            // (13 at N = 100; two groups of eight tested 16).  Soundness of the band: with u = 2^-24 and P = max(|s_i|, |s_j|)
+            // the stored n are within 3 u P^2 of |s|^2, each fused multiply-add rounds a value below 3 P^2, the folded thresholds
+            // round once: |computed - |s_i - s_j|^2| <= 15 u P^2 <= 30 u M^2 for every pair within 2R of each other (M bounds
+            // the max-norm of both agents, P^2 <= 2 M^2); 64 u M^2 is added to the band.  Pairs farther than 2R stay at least
+            // 3.9 R^2 - 60 u M^2 above R^2: never "clearly inside" while the band is below R^2 / 2 -- a wider band (a flock spread
+            // over hundreds of radii, or a NaN) sends every pair to the exact fp64 test.  A sound band gives the oracle's bits
+            // whatever its width, so the two rows of a pair agree although neither the bands nor the expressions are symmetric.
+            const float4 si = sxy[pi];
+            const int j0 = piece * dh8, nd = max(0, min(dh8, N - j0));          // this lane's candidates j0 .. j0 + nd - 1
+            const float M = fmaxf(fabsf(si.x), fabsf(si.y)) + 2.0f * Rf;
+            const float band = Rf * (16.f * M + 16.f * Rf) * 5.9604645e-8f + R2f * 1.1920929e-7f + (64.f * 5.9604645e-8f) * M * M;
+            const bool wide = !(band < 0.5f * R2f);
+            const float t_in = (wide ? -__builtin_huge_valf() : R2f - band) - si.z;
+            const float t_out = (wide ? __builtin_huge_valf() : R2f + band) - si.z;
+            const float m2x = -2.f * si.x, m2y = -2.f * si.y;
+            unsigned int im = 0u, om = 0u;
+            // tests executed by every lane: dh8 in the sized builds, one or two groups of eight otherwise (candidates beyond the
+            // piece re-test row N - 1 and are masked below)
+            const int nt = CN ? dh8 : ((dh8 + 7) & ~7);
+#pragma unroll
+            for (int c0 = 0; c0 < 128 / RO_PIECES; c0 += 8) {
+                if (c0 < nt) {
+                    float4 sj[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (c0 + q < nt) sj[q] = sxy[min(j0 + c0 + q, N - 1)];
+                    // sign bits instead of compare / select pairs (a v_cmp -> v_cndmask pair costs wait states on gfx9): the
+                    // sign of r2 - t_in says "clearly inside", the sign of t_out - r2 says "clearly outside"; v_alignbit shifts
+                    // each into a mask (test k ends in bit nt - 1 - k).  A NaN distance (diverged episode) classifies arbitrarily --
+                    // the state is garbage by then, and every index stays valid.
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (c0 + q < nt) {
+                            const float bq = fmaf(m2y, sj[q].y, fmaf(m2x, sj[q].x, sj[q].z));
+                            im = __builtin_amdgcn_alignbit(im, __float_as_uint(bq - t_in), 31);
+                            om = __builtin_amdgcn_alignbit(om, __float_as_uint(t_out - bq), 31);
+                        }
+                    }
+                }
+            }
+#else
+            const float4 si = sxy[pi];
             const int j0 = piece * dh8, nd = max(0, min(dh8, N - j0));          // this lane's candidates j0 .. j0 + nd - 1
             const float M = fmaxf(fabsf(si.x), fabsf(si.y)) + 2.0f * Rf;
             const float band = Rf * (16.f * M + 16.f * Rf) * 5.9604645e-8f + R2f * 1.1920929e-7f;
             const float t_in = R2f - band, t_out = R2f + band;
-            unsigned int in_m = 0u, unc_m = 0u;
+            unsigned int im = 0u, om = 0u;
+            // tests executed by every lane: EXACTLY dh8 in the sized builds (13 at N = 100: round 3 ran two groups of eight), one or
+            // two groups of eight otherwise (candidates beyond the piece re-test row N - 1 and are masked below)
+            const int nt = CN ? dh8 : ((dh8 + 7) & ~7);
 #pragma unroll
             for (int c0 = 0; c0 < 128 / RO_PIECES; c0 += 8) {
-                if (c0 < dh8) {
+                if (c0 < nt) {
                     float2 sj[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) sj[q] = sxy[min(j0 + c0 + q, N - 1)];
+                    for (int q = 0; q < 8; ++q)
+                        if (c0 + q < nt) sj[q] = *reinterpret_cast<const float2*>(&sxy[min(j0 + c0 + q, N - 1)]);
                     // sign bits instead of compare / select pairs (a v_cmp -> v_cndmask pair costs wait states on gfx9): the
                     // sign of r2 - t_in says "clearly inside", the sign of t_out - r2 says "clearly outside"; v_alignbit shifts
-                    // each into a mask (first test ends in bit 7).  A NaN distance (diverged episode) classifies arbitrarily --
+                    // each into a mask (test k ends in bit nt - 1 - k).  A NaN distance (diverged episode) classifies arbitrarily --
                     // the state is garbage by then, and every index stays valid.
-                    unsigned int im = 0u, om = 0u;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        const float dx = si.x - sj[q].x, dy = si.y - sj[q].y;
-                        const float r2 = fmaf(dy, dy, dx * dx);
-                        im = __builtin_amdgcn_alignbit(im, __float_as_uint(r2 - t_in), 31);
-                        om = __builtin_amdgcn_alignbit(om, __float_as_uint(t_out - r2), 31);
+                        if (c0 + q < nt) {
+                            const float dx = si.x - sj[q].x, dy = si.y - sj[q].y;
+                            const float r2 = fmaf(dy, dy, dx * dx);
+                            im = __builtin_amdgcn_alignbit(im, __float_as_uint(r2 - t_in), 31);
+                            om = __builtin_amdgcn_alignbit(om, __float_as_uint(t_out - r2), 31);
+                        }
                     }
-                    im = __builtin_bitreverse32(im) >> 24;        // test q -> bit q
-                    om = __builtin_bitreverse32(om) >> 24;
-                    in_m |= im << c0;
-                    unc_m |= (~om & ~im & 0xFFu) << c0;
                 }
             }
+#endif
+            const unsigned int tmask = (nt >= 32) ? 0xFFFFFFFFu : ((1u << nt) - 1u);
+            unsigned int in_m = __builtin_bitreverse32(im) >> (32 - nt);          // test k -> bit k
+            unsigned int unc_m = ~(__builtin_bitreverse32(om) >> (32 - nt)) & ~in_m & tmask;
             RO_STAMP(16);
             unsigned int valid = (nd >= 32) ? 0xFFFFFFFFu : ((1u << nd) - 1u);   // candidates beyond the piece re-tested row N - 1
             const int self = pi - j0;
@@ -798,66 +982,8 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             }
             RO_STAMP(22);
         } else if (do_s1 && gtid >= 0 && gtid < grp) {
-            // one summation order for a gather stage wherever it runs: lane `part` of the column's four takes list entries
-            // part, part + 4, ... in order, then the quad sum (l ^ 1, l ^ 2)
-            const int c4 = gtid >> 2, part = gtid & 3;
-            float s1[S1T][6];
-#pragma unroll
-            for (int jj = 0; jj < S1T; ++jj)
-#pragma unroll
-                for (int f = 0; f < 6; ++f) s1[jj][f] = 0.f;
-            if (c4 < N) {
-                const int cnt = rc_new[c4];
-                const unsigned char* lp = rl_new + c4 * RS;
-                // four entries per lane per pass (lists of up to 16 neighbours in ONE pass): the list bytes without waiting for
-                // the length, then every operand read of the pass in flight together, then the multiply-adds in list order
-                // (entries beyond the list are masked; every list byte is a valid row index)
-                for (int e = part; e == part || e < cnt; e += 4 * GU) {
-                    int jn[GU]; float gv[GU];
-#pragma unroll
-                    for (int u = 0; u < GU; ++u) jn[u] = lp[min(e + 4 * u, RS - 1)];
-#pragma unroll
-                    for (int u = 0; u < GU; ++u) gv[u] = w_new[jn[u]];
-#pragma unroll
-                    for (int jj = 0; jj < S1T; ++jj) {
-                        if (jj < K - 1) {
-                            // tap jj + 1 of step t + 1 = tap jj of step t: ring slot ro_slot(curn, jj + 1) = ro_slot(cur, jj)
-                            const float* src = XT + (size_t)ro_slot(curn, jj + 1, K) * Np * 8;
-                            float4 x0[GU]; float2 x1[GU];
-#pragma unroll
-                            for (int u = 0; u < GU; ++u) {
-                                x0[u] = *reinterpret_cast<const float4*>(src + jn[u] * 8);
-                                x1[u] = *reinterpret_cast<const float2*>(src + jn[u] * 8 + 4);
-                            }
-#pragma unroll
-                            for (int u = 0; u < GU; ++u) {
-                                const float gz = (e + 4 * u < cnt) ? gv[u] : 0.f;
-                                s1[jj][0] = fmaf(x0[u].x, gz, s1[jj][0]); s1[jj][1] = fmaf(x0[u].y, gz, s1[jj][1]);
-                                s1[jj][2] = fmaf(x0[u].z, gz, s1[jj][2]); s1[jj][3] = fmaf(x0[u].w, gz, s1[jj][3]);
-                                s1[jj][4] = fmaf(x1[u].x, gz, s1[jj][4]); s1[jj][5] = fmaf(x1[u].y, gz, s1[jj][5]);
-                            }
-                        }
-                    }
-                }
-            }
+            gather_stage1(gtid, curn, rc_new, rl_new, w_new);
             RO_STAMP(20);
-#pragma unroll
-            for (int jj = 0; jj < S1T; ++jj) {
-                if (jj < K - 1) {
-#pragma unroll
-                    for (int f = 0; f < 6; ++f) { s1[jj][f] += dpp_f<0xB1>(s1[jj][f]); s1[jj][f] += dpp_f<0x4E>(s1[jj][f]); }
-                    if (part == 0 && c4 < N) {
-                        if (jj == 0) {                        // tap 1: stage 1 is its only factor -> B-fragment slot
-#pragma unroll
-                            for (int f = 0; f < 6; ++f) act[c4 * RO_CS + rpos(f * K + 1)] = s1[0][f];
-                        } else {                              // taps >= 2: running product for stage 2 (buffer parity of q = 1)
-                            float* dst = VB + ((size_t)(K - 2) + (jj - 1)) * Np * 8 + c4 * 8;
-                            *reinterpret_cast<float4*>(dst) = make_float4(s1[jj][0], s1[jj][1], s1[jj][2], s1[jj][3]);
-                            *reinterpret_cast<float2*>(dst + 4) = make_float2(s1[jj][4], s1[jj][5]);
-                        }
-                    }
-                }
-            }
             RO_STAMP(23);
         }
         }

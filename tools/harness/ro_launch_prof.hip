@@ -137,6 +137,30 @@ int main(int argc, char** argv)
         }
         printf("%3d | %8.2f | %8.2f | %6.2f | %6.2f | %6.2f %6.2f %6.2f | %6.2f | %6.2f | %6.2f\n", T, med(ker), med(wall), med(ramp), med(entry),
                med(s0), med(s1), med(s2), med(rest), med(ex), med(endsp));
+        if (const char* dump = getenv("RO_WG_DUMP")) {
+            // per workgroup (= episode) of the LAST launch of this length: begin-to-end duration, next to the episode's mean and
+            // largest degree at the state the harness was handed -- which episodes set a launch's duration
+            if (T == (getenv("RO_WG_DUMP_T") ? atoi(getenv("RO_WG_DUMP_T")) : 20)) {
+                FILE* f = fopen(dump, "w");
+                if (!f) { printf("cannot write %s\n", dump); return 1; }
+                fprintf(f, "# episode  duration_us (T = %d)  mean_degree  max_degree  first_entry_us\n", T);
+                for (int b = 0; b < B; ++b) {
+                    int dsum = 0, dmax = 0;
+                    for (int i = 0; i < N; ++i) {
+                        int d = 0;
+                        for (int j = 0; j < N; ++j) {
+                            if (j == i) continue;
+                            const double dx = hx[((size_t)b * N + i) * 4] - hx[((size_t)b * N + j) * 4], dy = hx[((size_t)b * N + i) * 4 + 1] - hx[((size_t)b * N + j) * 4 + 1];
+                            d += dx * dx + dy * dy < 1.0;
+                        }
+                        dsum += d; dmax = d > dmax ? d : dmax;
+                    }
+                    const long long* w = &hwall[(size_t)b * 8];
+                    fprintf(f, "%d %.2f %.2f %d %.2f\n", b, 0.01 * (w[6] - w[0]), (double)dsum / N, dmax, 0.01 * (w[7] - w[0]));
+                }
+                fclose(f);
+            }
+        }
     }
     return 0;
 }
