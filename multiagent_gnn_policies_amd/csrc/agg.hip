@@ -9,6 +9,7 @@
 //     the rows with stride R = 256/colgroups; the X[b,k] tile is staged TRANSPOSED in LDS ([m][c]) so the
 //     CT multipliers of one row come from one or two wide, mostly-broadcast ds_reads;
 //   * the R row-phases are combined through LDS in a fixed order (deterministic, no atomics).
+#include <cstdlib>
 #include "mgp_common.h"
 #include "agg_mfma.h"
 
@@ -256,6 +257,65 @@ int launch_agg_fwd_mfma(const float* X, const float* G, float* Y, int B, int K, 
     return mgp_launch_status();
 }
 
+// ---- the same aggregation with FOUR waves per (episode, tap): wave = (column block, row part); a wave holds a quarter of the
+// operator share of the eight-wave kernel above (14 float4 instead of 28 at N = 100: <= 128 VGPRs), so three to four
+// workgroups share a CU and, beyond one workgroup per CU (B K > 256), one workgroup's row sums, part combine and stores
+// overlap the next one's stream -- the eight-wave kernel holds 240 VGPRs per wave: ONE workgroup per CU, every launch phase
+// exposed once per episode (4.15 TB/s at B = 2048 against 3.4 at B = 256).  Parts are added in fixed order through LDS.
+template <int S, int FH, int NH, int NBLK, bool NT>   // S row steps per wave, NH row parts, NBLK column blocks: 64 NH NBLK threads
+__global__ __launch_bounds__(64 * NH * NBLK)         // (forcing <= 128 VGPRs for a fourth wave per SIMD spills and measured 7 % slower)
+void agg_fwd_mfma4_kernel(const float* __restrict__ X, const float* __restrict__ G, float* __restrict__ Y,
+                          int K, int C, int N, long sxb, long sxk, long sxc, long syb, long syk, long syc)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NW = NH * NBLK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int b = blockIdx.x / K, k = blockIdx.x - b * K;
+    const int blk = wave / NH, part = wave - blk * NH;
+    const int gtot = N >> 2, g0 = (NBLK == 2) ? ((gtot + 1) >> 1) : gtot;
+    const int ng = blk ? gtot - g0 : g0;
+    const int g = blk * g0 + min(li, ng - 1);
+    f32x4* red = reinterpret_cast<f32x4*>(smem) + wave * (4 * 64);
+    f32x4* comb = reinterpret_cast<f32x4*>(smem) + NW * (4 * 64);           // [wave][FH][64]
+    const float* Gk = G + ((size_t)b * K + k) * (size_t)N * N + 4 * g;
+    const float* Xk = X + (size_t)b * sxb + (size_t)k * sxk;
+    f32x4 mine[FH];
+    auto keep = [&](int h, const f32x4& tot) { mine[h] = tot; };
+    if (part == 0) agg_mfma_rows<S, 0, FH, NT>(Gk, Xk, sxc, C, N, lane, red, keep);
+    else if (part == 1) agg_mfma_rows<S, S, FH, NT>(Gk, Xk, sxc, C, N, lane, red, keep);
+    else if (NH == 4 && part == 2) agg_mfma_rows<S, (NH == 4 ? 2 * S : 0), FH, NT>(Gk, Xk, sxc, C, N, lane, red, keep);
+    else agg_mfma_rows<S, (NH == 4 ? 3 * S : 0), FH, NT>(Gk, Xk, sxc, C, N, lane, red, keep);
+    if (part != 0) {
+#pragma unroll
+        for (int h = 0; h < FH; ++h) comb[(wave * FH + h) * 64 + lane] = mine[h];
+    }
+    __syncthreads();
+    if (part == 0 && li < ng) {
+        float* Yk = Y + (size_t)b * syb + (size_t)k * syk + 4 * g + lq;
+#pragma unroll
+        for (int h = 0; h < FH; ++h) {
+            f32x4 tot = mine[h];
+#pragma unroll
+            for (int q = 1; q < NH; ++q) tot += comb[((wave + q) * FH + h) * 64 + lane];     // fixed order: part 1, 2, 3
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (4 * h + i < C) Yk[(size_t)(4 * h + i) * syc] = tot[i];
+        }
+    }
+}
+
+template <int S, int FH, int NH, int NBLK, bool NT = true>
+int launch_agg_fwd_mfma4(const float* X, const float* G, float* Y, int B, int K, int C, int N,
+                         long sxb, long sxk, long sxc, long syb, long syk, long syc, hipStream_t st)
+{
+    constexpr int NW = NH * NBLK;
+    const size_t lds = (size_t)(NW * 4 * 64 + NW * FH * 64) * 16;
+    hipLaunchKernelGGL((agg_fwd_mfma4_kernel<S, FH, NH, NBLK, NT>), dim3((unsigned)(B * K)), dim3(64 * NW), lds, st,
+                       X, G, Y, K, C, N, sxb, sxk, sxc, syb, syk, syc);
+    return mgp_launch_status();
+}
+
 template <int V>
 int dispatch_agg_fwd(const float* X, const float* G, float* Y, int B, int K, int C, int N,
                      long sxb, long sxk, long sxc, long syb, long syk, long syc, hipStream_t st)
@@ -297,8 +357,21 @@ extern "C" int mgp_agg_fwd(const float* X, const float* G, float* Y, int B, int 
     mgp_clear_error();
     const bool vec = (N % 4 == 0) && mgp_aligned16(G);
     const int nblk = N > 64 ? 2 : 1;
-    if (vec && N >= 16 && N <= 128 && C <= 8 && K * nblk <= AGM_THREADS / 64 && mgp_aligned16(X) && sxb % 4 == 0 &&
-        sxk % 4 == 0 && sxc % 4 == 0) {                        // X quads are aligned float4 loads
+    const bool quads = mgp_aligned16(X) && sxb % 4 == 0 && sxk % 4 == 0 && sxc % 4 == 0;     // X quads are aligned float4 loads
+    static const int agg_form = getenv("MGP_AGG_FORM") ? atoi(getenv("MGP_AGG_FORM")) : 4;   // 8: the eight-wave kernel (A/B switch)
+    if (vec && N >= 16 && N <= 128 && C <= 8 && quads && agg_form != 8 && (size_t)B * K <= 0x7FFFFFFFull) {
+#define MGP_AG4_CASE(S_, NH_, NB_, NT_) return C <= 4 ? launch_agg_fwd_mfma4<S_, 1, NH_, NB_, NT_>(X, G, Y, B, K, C, N, sxb, sxk, sxc, syb, syk, syc, st) \
+                                                      : launch_agg_fwd_mfma4<S_, 2, NH_, NB_, NT_>(X, G, Y, B, K, C, N, sxb, sxk, sxc, syb, syk, syc, st)
+        if (N <= 64) MGP_AG4_CASE(4, 4, 1, true);              // one column block, four row parts of 4 steps (16 rows each)
+        if (N <= 112) {
+            if (agg_form == 41) MGP_AG4_CASE(14, 2, 2, false); // (A/B: default cache policy)
+            if (agg_form == 42) MGP_AG4_CASE(7, 4, 2, true);   // (A/B: eight waves of 7 steps)
+            MGP_AG4_CASE(14, 2, 2, true);                      // two column blocks, two row parts of 14 steps
+        }
+        MGP_AG4_CASE(16, 2, 2, true);
+#undef MGP_AG4_CASE
+    }
+    if (vec && N >= 16 && N <= 128 && C <= 8 && K * nblk <= AGM_THREADS / 64 && quads) {
 #define MGP_AGM_CASE(S_) return C <= 4 ? launch_agg_fwd_mfma<S_, 1>(X, G, Y, B, K, C, N, nblk, sxb, sxk, sxc, syb, syk, syc, st) \
                                        : launch_agg_fwd_mfma<S_, 2>(X, G, Y, B, K, C, N, nblk, sxb, sxk, sxc, syb, syk, syc, st)
         if (N <= 64) MGP_AGM_CASE(16);

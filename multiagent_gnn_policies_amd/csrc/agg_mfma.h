@@ -73,4 +73,62 @@ __device__ __forceinline__ void agg_mfma_unit(const float* __restrict__ Gk, cons
     }
 }
 
+// The same unit for a PART of the contraction rows: row steps S0 .. S0 + S - 1 of the enumeration above (a wave of the
+// four-wave kernel of agg.hip owns half -- or, with one column block, a quarter -- of the rows of its columns: a quarter of
+// the registers, so that several workgroups share a CU and one workgroup's row sums and stores overlap the next one's
+// stream).  `part(h, tot)` receives the wave's partial sums in the layout of emit(); the caller adds the parts in fixed order.
+#ifndef AGG_NT
+#define AGG_NT 1                          // operator loads with the non-temporal hint (read once, never again)
+#endif
+template <int S, int S0, int FH, bool NT = (AGG_NT != 0), class Part>
+__device__ __forceinline__ void agg_mfma_rows(const float* __restrict__ Gk, const float* __restrict__ Xk, long sxc, int F,
+                                              int N, int lane, f32x4* red, Part part)
+{
+    const int li = lane & 15, lq = lane >> 4;
+    constexpr int T0 = S0 >> 2, TQ = ((S0 + S + 3) >> 2) - T0;       // X quads (16 rows each) the steps touch
+    f32x4 xa[FH][TQ];
+    f32x4 gv[S];
+#pragma unroll
+    for (int h = 0; h < FH; ++h) {
+        const float* xr = Xk + (size_t)min(4 * h + (li & 3), F - 1) * sxc;
+#pragma unroll
+        for (int t4 = 0; t4 < TQ; ++t4)
+            xa[h][t4] = *reinterpret_cast<const f32x4*>(xr + min(16 * (T0 + t4) + 4 * lq, N - 4));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const f32x4* gp = reinterpret_cast<const f32x4*>(Gk + (size_t)min(16 * ((S0 + s) >> 2) + 4 * lq + ((S0 + s) & 3), N - 1) * N);
+        gv[s] = NT ? __builtin_nontemporal_load(gp) : *gp;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x4 acc[4][FH];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int h = 0; h < FH; ++h) acc[t][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S; ++s) {                             // rows past N: clamped addresses times a = 0
+        const bool rok = 16 * ((S0 + s) >> 2) + 4 * lq + ((S0 + s) & 3) < N;
+#pragma unroll
+        for (int h = 0; h < FH; ++h) {
+            const float a = (rok && 4 * h + (li & 3) < F) ? xa[h][((S0 + s) >> 2) - T0][(S0 + s) & 3] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[t][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, gv[s][t], acc[t][h], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int h = 0; h < FH; ++h) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) red[t * 64 + lane] = acc[t][h];
+        const f32x4* p = red + lq * 64 + li;
+        f32x4 tot = p[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) tot += p[16 * q];
+        part(h, tot);
+    }
+}
+
 }  // namespace
