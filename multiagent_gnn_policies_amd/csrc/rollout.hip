@@ -615,10 +615,11 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 const float* pbias = wfrag + MT * 64 * RO_WFS + lq * 4;
                 if constexpr (RO_BF16_CHAIN) {
                     // widths <= 32: split-bf16 MFMA (rollout_common.h), the whole K = 32 in one instruction per product (no k-step count)
-                    if (RO_MAXMT >= 8 && MT == 8) ro_layer_bf16<(RO_MAXMT >= 8 ? 8 : 1), true>(fb, pw, pbias, zc);
-                    else if (RO_MAXMT >= 4 && MT == 4) ro_layer_bf16<(RO_MAXMT >= 4 ? 4 : 1), true>(fb, pw, pbias, zc);
-                    else if (MT == 2) ro_layer_bf16<(RO_MAXMT >= 2 ? 2 : 1), true>(fb, pw, pbias, zc);
-                    else ro_layer_bf16<1, true>(fb, pw, pbias, zc);
+                    const int nkb = (RO_KB == 2 && l > 0 && ro_dim(dimsA, dims8, l) > 32) ? 2 : 1;   // K blocks of this layer's input
+                    if (RO_MAXMT >= 8 && MT == 8) ro_layer_bf16<(RO_MAXMT >= 8 ? 8 : 1), true>(fb, pw, pbias, zc, nkb);
+                    else if (RO_MAXMT >= 4 && MT == 4) ro_layer_bf16<(RO_MAXMT >= 4 ? 4 : 1), true>(fb, pw, pbias, zc, nkb);
+                    else if (MT == 2) ro_layer_bf16<(RO_MAXMT >= 2 ? 2 : 1), true>(fb, pw, pbias, zc, nkb);
+                    else ro_layer_bf16<1, true>(fb, pw, pbias, zc, nkb);
                 } else {
                 if (RO_MAXMT >= 8 && MT == 8) ro_layer_regs<(RO_MAXMT >= 8 ? 8 : 1), true>(fb, pw, pbias, ksteps, zc);
                 else if (MT == 4) ro_layer_regs<(RO_MAXMT >= 4 ? 4 : 1), true>(fb, pw, pbias, ksteps, zc);
@@ -1092,6 +1093,10 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
 // and every consumer -- gather stages, feature pass, exit -- walks bits; rows / gather items / pair offsets are looped
 // over instead of mapped one to a thread; everything is run-time sized.  Phases, barriers and arithmetic are the same.
 #undef ro_fresh_tid_ph
+// layers of the N > 128 kernel: split-bf16 where a layer's input is ONE K block (widths <= 32, the 128-wide build); the 64-wide
+// build keeps fp32 fragments here (rollout_common.h: ro_wfs)
+constexpr bool RB_BF = RO_BF16_CHAIN && RO_KB == 1;
+constexpr int RB_WFS = ro_wfs(RB_BF);
 struct RbOff { int pos, bits, wrow, uact, xt, vb, act, sxy, mmax, uexp, wl; };
 constexpr int RB_MAXN = 256;
 constexpr int RB_NW = 4;
@@ -1192,10 +1197,10 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
             const int cin = (l == 0) ? FK : P.dims[l];
             const int cout = P.dims[l + 1];
             const bool last = l == P.n_layers - 1;
-            const int tot = last ? ro_weight_image_size(cout, true) : ro_chain_image_size(cout, false);
+            const int tot = last ? ro_weight_image_size(cout, true) : ro_chain_image_size(cout, false, RB_BF);
             float* dst = wl + P.woff[l];
             for (int e = tid; e < tot; e += RO_THREADS)
-                dst[e] = last ? ro_weight_image_elem(P.W[l], P.b[l], cin, cout, true, e) : ro_chain_image_elem(P.W[l], P.b[l], cin, cout, l, false, e);
+                dst[e] = last ? ro_weight_image_elem(P.W[l], P.b[l], cin, cout, true, e) : ro_chain_image_elem(P.W[l], P.b[l], cin, cout, l, false, e, RB_BF);
         }
     }
     // factored hand-over of the history networks (see rollout_kernel): carry slot q -> ring slot (H - q) % H, hs = 0
@@ -1356,14 +1361,15 @@ void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __
                     for (int s_ = 0; s_ < RO_KS; ++s_) fb[s_] = zc[s_ >> 2][s_ & 3];
                     ksteps = 4 * mtp;
                 }
-                const float* pw = wfrag + lanev * RO_WFS;
-                const float* pbias = wfrag + MT * 64 * RO_WFS + lq * 4;
-                if constexpr (RO_BF16_CHAIN) {
+                const float* pw = wfrag + lanev * RB_WFS;
+                const float* pbias = wfrag + MT * 64 * RB_WFS + lq * 4;
+                if constexpr (RB_BF) {
                     // widths <= 32: split-bf16 MFMA (rollout_common.h), the whole K = 32 in one instruction per product (no k-step count)
-                    if (RO_MAXMT >= 8 && MT == 8) ro_layer_bf16<(RO_MAXMT >= 8 ? 8 : 1), true>(fb, pw, pbias, zc);
-                    else if (RO_MAXMT >= 4 && MT == 4) ro_layer_bf16<(RO_MAXMT >= 4 ? 4 : 1), true>(fb, pw, pbias, zc);
-                    else if (MT == 2) ro_layer_bf16<(RO_MAXMT >= 2 ? 2 : 1), true>(fb, pw, pbias, zc);
-                    else ro_layer_bf16<1, true>(fb, pw, pbias, zc);
+                    const int nkb = (RO_KB == 2 && l > 0 && ro_dim(dimsA, dims8, l) > 32) ? 2 : 1;   // K blocks of this layer's input
+                    if (RO_MAXMT >= 8 && MT == 8) ro_layer_bf16<(RO_MAXMT >= 8 ? 8 : 1), true>(fb, pw, pbias, zc, nkb);
+                    else if (RO_MAXMT >= 4 && MT == 4) ro_layer_bf16<(RO_MAXMT >= 4 ? 4 : 1), true>(fb, pw, pbias, zc, nkb);
+                    else if (MT == 2) ro_layer_bf16<(RO_MAXMT >= 2 ? 2 : 1), true>(fb, pw, pbias, zc, nkb);
+                    else ro_layer_bf16<1, true>(fb, pw, pbias, zc, nkb);
                 } else {
                 if (RO_MAXMT >= 8 && MT == 8) ro_layer_regs<(RO_MAXMT >= 8 ? 8 : 1), true>(fb, pw, pbias, ksteps, zc);
                 else if (MT == 4) ro_layer_regs<(RO_MAXMT >= 4 ? 4 : 1), true>(fb, pw, pbias, ksteps, zc);
@@ -1654,7 +1660,7 @@ bool make_carve(const int* dims, int n_layers, int K, int N, RoParams* P, int* l
         if (cin < 1 || cout < 1 || cin > (last ? RO_OUTC : 4 * RO_KS) || cout > 16 * RO_MAXMT) return false;
         if (l == 0 && cin > 4 * RO_KS) return false;
         if (P) { P->woff[l] = wtot; P->dims[l] = dims[l]; }
-        wtot += last ? ((2 * RO_OUTC + 2 + 15) & ~15) : ro_mt(cout) * 64 * RO_WFS + ro_mt(cout) * 16;
+        wtot += last ? ((2 * RO_OUTC + 2 + 15) & ~15) : ro_mt(cout) * 64 * ro_wfs(N > RO_MAXN ? RB_BF : RO_BF16_CHAIN) + ro_mt(cout) * 16;
     }
     if (P) { P->dims[n_layers] = dims[n_layers]; P->n_layers = n_layers; P->wtot = wtot; }
     const int total = (N > RO_MAXN ? rb_offsets(N, K).wl : ro_offsets(N, K).wl) + wtot * 4;   // N > 128: rollout_big_kernel
@@ -1709,16 +1715,16 @@ void carry_to_dense_kernel(const unsigned long long* __restrict__ carry, float* 
     }
 }
 
-__global__ void rollout_image_kernel(RoParams P, int K, float* __restrict__ image)
+__global__ void rollout_image_kernel(RoParams P, int K, float* __restrict__ image, bool bf)
 {
     for (int l = 0; l < P.n_layers; ++l) {
         const int cin = (l == 0) ? 6 * K : P.dims[l], cout = P.dims[l + 1];
         const bool last = l == P.n_layers - 1;
-        const int tot = last ? ro_weight_image_size(cout, true) : ro_chain_image_size(cout, false);
+        const int tot = last ? ro_weight_image_size(cout, true) : ro_chain_image_size(cout, false, bf);
         const int span = (l + 1 < P.n_layers ? P.woff[l + 1] : P.wtot) - P.woff[l];
         for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < span; e += gridDim.x * blockDim.x)
             image[P.woff[l] + e] = (e >= tot) ? 0.f : (last ? ro_weight_image_elem(P.W[l], P.b[l], cin, cout, true, e)
-                                                             : ro_chain_image_elem(P.W[l], P.b[l], cin, cout, l, false, e));
+                                                             : ro_chain_image_elem(P.W[l], P.b[l], cin, cout, l, false, e, bf));
     }
 }
 
@@ -1865,7 +1871,8 @@ extern "C" int MGP_RO_IMAGE(const float* const* W, const float* const* b, const 
         P.W[l] = W[l]; P.b[l] = b[l];
     }
     mgp_clear_error();
-    hipLaunchKernelGGL(rollout_image_kernel, dim3(8), dim3(256), 0, static_cast<hipStream_t>(stream), P, K, image);
+    hipLaunchKernelGGL(rollout_image_kernel, dim3(8), dim3(256), 0, static_cast<hipStream_t>(stream), P, K, image,
+                       N > RO_MAXN ? RB_BF : RO_BF16_CHAIN);
     return mgp_launch_status();
 }
 
@@ -1950,8 +1957,8 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
             P.woff[2] == 2 * (2 * 64 * RO_WFS + 32))                                  // cfg/dagger.cfg, policy shape compiled in
             return launch_rollout<100, 3, false, true, true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB,
                                                              n_layers, lds, st, image, wt, carry, flags, cl);
-        if (N == 100 && K == 3 && !fade) return RO_LAUNCH(100, 3, false, true);
 #endif
+        if (N == 100 && K == 3 && !fade) return RO_LAUNCH(100, 3, false, true);
         return fade ? RO_LAUNCH(0, 0, true, true) : RO_LAUNCH(0, 0, false, true);
     }
 #ifdef MGP_RO_BASE
@@ -1961,10 +1968,8 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
         return launch_rollout<100, 3, false, false, true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers,
                                                           lds, st, image, wt, carry, flags, cl);
 #endif
-#if defined(MGP_RO_BASE) || defined(MGP_RO_X128)
-    if (N == 100 && K == 3 && !fade)   // the headline (N, K) with any covered policy: compile-time addresses
+    if (N == 100 && K == 3 && !fade)   // the headline (N, K) with any covered policy, every build: compile-time addresses
         return RO_LAUNCH(100, 3, false, false);
-#endif
 #ifdef MGP_RO_BASE
     if (N == 100 && K == 2 && !fade)   // cfg/default.cfg, cloning.cfg, dagger_twoflocks.cfg
         return RO_LAUNCH(100, 2, false, false);

@@ -14,7 +14,20 @@ namespace {
 #endif
 constexpr int RO_KS = MGP_RO_KS;
 constexpr int RO_CS = 4 * RO_KS + 4;
-constexpr int RO_WFS = RO_KS + 4;
+#ifndef MGP_RO_BF16
+#define MGP_RO_BF16 1                    // 0: the fp32-MFMA form everywhere (rollout_f32ref.hip, A/B builds of the harness)
+#endif
+// Hidden layers on split-bf16 MFMA (ro_layer_bf16 below): layer inputs of up to 32 channels are ONE K block of
+// v_mfma_f32_16x16x32_bf16 (RO_KS = 8: rollout.hip, rollout_w128.hip), up to 64 channels TWO (RO_KS = 16: rollout_wide.hip).
+constexpr bool RO_BF16_CHAIN = MGP_RO_BF16 && (RO_KS == 8 || RO_KS == 16);
+constexpr int RO_KB = RO_KS / 8;          // K blocks of 32 input channels
+// floats per lane in a weight fragment block: fp32 k-steps + pad, or [K block][piece][8 bf16] = 12 floats per block; 12 and 28
+// words per lane keep a 16-lane ds_read_b128 group on disjoint banks (24 would put lanes 0 and 8 on the same four)
+constexpr int RO_WFS = (RO_BF16_CHAIN && RO_KB == 2) ? 28 : RO_KS + 4;
+// the N > 128 kernel of the 64-wide build keeps fp32 fragments (its state leaves no room for the 40 % larger image of the
+// two-block form: N = 200 with [64, 64] would no longer fit 160 KB): `bf` selects the layout of an image
+constexpr int RO_WFS_F32 = RO_KS + 4;
+__host__ __device__ constexpr int ro_wfs(bool bf) { return bf ? RO_WFS : RO_WFS_F32; }
 __host__ __device__ inline int rpos(int c) { return (c & 3) * RO_KS + (c >> 2); }   // channel -> slot (B-fragment order)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -83,7 +96,7 @@ constexpr int RO_OUTC = 16 * RO_MAXMT;                         // channels the o
 // m-tiles a hidden layer of `cout` rows is run with: 1, 2, 4 or 8 (padded up: few MLP code instances)
 __host__ __device__ inline int ro_mt(int cout) { const int m = pad16(cout) / 16; return m <= 2 ? m : (m <= 4 ? 4 : 8); }
 
-template <int MT, bool TANH>
+template <int MT, bool TANH, int WFS = RO_WFS_F32>            // WFS: floats per lane and m-tile of the fp32 fragment image
 __device__ __forceinline__ void ro_layer_regs(const float (&fb)[RO_KS], const float* pw, const float* pbias, int ksteps,
                                               float (&zn)[RO_MAXMT][4])
 {
@@ -94,7 +107,7 @@ __device__ __forceinline__ void ro_layer_regs(const float (&fb)[RO_KS], const fl
         f32x4 acc[CH];
 #pragma unroll
         for (int mt = 0; mt < CH; ++mt) {
-            const float4* pa = reinterpret_cast<const float4*>(pw + (h + mt) * 64 * RO_WFS);
+            const float4* pa = reinterpret_cast<const float4*>(pw + (h + mt) * 64 * WFS);
 #pragma unroll
             for (int i = 0; i < RO_KS / 4; ++i) { const float4 u = pa[i]; fa[mt][4 * i] = u.x; fa[mt][4 * i + 1] = u.y; fa[mt][4 * i + 2] = u.z; fa[mt][4 * i + 3] = u.w; }
             const float4 bv = *reinterpret_cast<const float4*>(pbias + (h + mt) * 16);
@@ -125,12 +138,6 @@ __device__ __forceinline__ void ro_layer_regs(const float (&fb)[RO_KS], const fl
 // the same 12 floats (48 bytes) as the fp32 fragments: [piece][8 bf16]; element j of k-group lq <-> channel 4 j + lq for the
 // first layer (its B operand is the aggregation's LDS tile), 4 lq + j | 16 + 4 lq + (j - 4) for the second (B operand = the
 // first layer's accumulator registers).
-#ifndef MGP_RO_BF16
-#define MGP_RO_BF16 1                    // 0: the fp32-MFMA form everywhere (A/B builds of the harness)
-#endif
-// which builds: layer INPUTS of at most 32 channels (RO_KS = 8 k-steps: one K = 32 instruction per product) -- rollout.hip itself
-// (widths <= 32) and rollout_w128.hip (one hidden layer up to 128 wide: eight m-tiles); the 64-wide build keeps fp32
-constexpr bool RO_BF16_CHAIN = MGP_RO_BF16 && RO_KS == 8;
 typedef __attribute__((ext_vector_type(8))) __bf16 ro_bf16x8;
 
 __device__ __forceinline__ void ro_split3(const float* x /* [8] */, ro_bf16x8& h1, ro_bf16x8& h2, ro_bf16x8& h3)
@@ -145,11 +152,62 @@ __device__ __forceinline__ void ro_split3(const float* x /* [8] */, ro_bf16x8& h
     }
 }
 
+// Two K blocks (layer inputs of up to 64 channels: rollout_wide.hip).  x[8 kb + j] <-> channel 16 (2 kb) + 4 lq + j for j < 4,
+// 16 (2 kb + 1) + 4 lq + (j - 4) beyond (the accumulator registers of m-tiles 2 kb, 2 kb + 1 of the previous layer; layer 0
+// reads its <= 32 aggregation channels as block 0 alone: nkb = 1).  One m-tile at a time, the two blocks as two independent
+// accumulator chains (six dependent MFMAs each, smallest products first) added at the end: 24 registers of A pieces in flight.
+// 12 MFMAs of 16 cycles per m-tile against 16 fp32 k-steps of 32.
 template <int MT, bool TANH>
-__device__ __forceinline__ void ro_layer_bf16(const float* x /* [8] */, const float* pw /* this lane's record of m-tile 0 */,
-                                              const float* pbias, float (&zn)[RO_MAXMT][4])
+__device__ __forceinline__ void ro_layer_bf16_kb2(const float* x /* [16] */, const float* pw, const float* pbias,
+                                                  float (&zn)[RO_MAXMT][4], int nkb)
 {
     static_assert(MT <= RO_MAXMT, "m-tiles");
+    ro_bf16x8 b1[2], b2[2], b3[2];
+    ro_split3(x, b1[0], b2[0], b3[0]);
+    if (nkb > 1) ro_split3(x + 8, b1[1], b2[1], b3[1]);       // (uniform)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const float4* pa = reinterpret_cast<const float4*>(pw + mt * 64 * RO_WFS);
+        const float4 bv = *reinterpret_cast<const float4*>(pbias + mt * 16);
+        f32x4 acc0 = f32x4{bv.x, bv.y, bv.z, bv.w}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const float4 u1 = pa[0], u2 = pa[1], u3 = pa[2];
+            const ro_bf16x8 a1 = *reinterpret_cast<const ro_bf16x8*>(&u1), a2 = *reinterpret_cast<const ro_bf16x8*>(&u2),
+                            a3 = *reinterpret_cast<const ro_bf16x8*>(&u3);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3[0], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1[0], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2[0], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2[0], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1[0], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1[0], acc0, 0, 0, 0);
+        }
+        if (nkb > 1) {
+            const float4 u1 = pa[3], u2 = pa[4], u3 = pa[5];
+            const ro_bf16x8 a1 = *reinterpret_cast<const ro_bf16x8*>(&u1), a2 = *reinterpret_cast<const ro_bf16x8*>(&u2),
+                            a3 = *reinterpret_cast<const ro_bf16x8*>(&u3);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3[1], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1[1], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2[1], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2[1], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1[1], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1[1], acc1, 0, 0, 0);
+            acc0 += acc1;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) zn[mt][rr] = TANH ? tanh_fast(acc0[rr]) : acc0[rr];
+    }
+#pragma unroll
+    for (int mt = MT; mt < RO_MAXMT; ++mt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) zn[mt][rr] = 0.f;
+}
+
+template <int MT, bool TANH>
+__device__ __forceinline__ void ro_layer_bf16(const float* x /* [8 RO_KB] */, const float* pw /* this lane's record of m-tile 0 */,
+                                              const float* pbias, float (&zn)[RO_MAXMT][4], int nkb = 1)
+{
+    static_assert(MT <= RO_MAXMT, "m-tiles");
+    if constexpr (RO_KB == 2) { ro_layer_bf16_kb2<MT, TANH>(x, pw, pbias, zn, nkb); return; }
     constexpr int CH = MT > 2 ? 2 : MT;                       // m-tiles in flight (two accumulator chains; their A pieces: 24 registers)
     ro_bf16x8 b1, b2, b3;
     ro_split3(x, b1, b2, b3);
@@ -199,14 +257,18 @@ __device__ __forceinline__ float ro_chain_image_elem_bf(const float* __restrict_
     if (e >= tot) { const int o = e - tot; return (o < cout) ? bias[o] : 0.f; }
     const int mt = e / (64 * RO_WFS), r1 = e - mt * (64 * RO_WFS);
     const int ln = r1 / RO_WFS, sl = r1 - ln * RO_WFS;
-    const int piece = sl >> 2, pr = sl & 3;
+    const int kb = sl / 12, sb = sl - kb * 12;                // K block (32 input channels), slot inside its 12-float record
+    const int piece = sb >> 2, pr = sb & 3;
     const int lqq = ln >> 4, o = mt * 16 + (ln & 15);
     unsigned int word = 0u;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int j = 2 * pr + t;
-        const int c = (layer == 0) ? 4 * j + lqq : (j < 4 ? 4 * lqq + j : 16 + 4 * lqq + (j - 4));
-        const float w = (piece < 3 && o < cout && c < cin) ? src[(size_t)o * cin + c] : 0.f;
+        // element j of k-group lq of block kb: the first layer reads the aggregation tile (channel 4 j + lq, block 0 only),
+        // the others the accumulator registers of m-tiles 2 kb (j < 4) and 2 kb + 1 of the previous layer
+        const int c = (layer == 0) ? (kb == 0 ? 4 * j + lqq : cin)
+                                   : (j < 4 ? 32 * kb + 4 * lqq + j : 32 * kb + 16 + 4 * lqq + (j - 4));
+        const float w = (kb < RO_KB && piece < 3 && o < cout && c < cin) ? src[(size_t)o * cin + c] : 0.f;
         const __bf16 a = (__bf16)w;
         const float r = w - (float)a;
         const __bf16 b = (__bf16)r;
@@ -247,21 +309,22 @@ __device__ __forceinline__ bool ro_mlp_cols_bf16(float* pcol, const float* pw, c
 // LDS tile), 16 (s >> 2) + 4 lq + (s & 3) for the others (B operand = the previous layer's accumulator registers).  The output
 // layer is one m-tile padded with zero rows.
 __device__ __forceinline__ float ro_chain_image_elem(const float* __restrict__ src, const float* __restrict__ bias, int cin,
-                                                     int cout, int layer, bool last, int e)
+                                                     int cout, int layer, bool last, int e, bool bf = RO_BF16_CHAIN)
 {
-    if (RO_BF16_CHAIN && !last) return ro_chain_image_elem_bf(src, bias, cin, cout, layer, e);
-    const int MT = last ? 1 : ro_mt(cout), tot = MT * 64 * RO_WFS;
+    if (bf && !last) return ro_chain_image_elem_bf(src, bias, cin, cout, layer, e);
+    const int WFS = ro_wfs(false);
+    const int MT = last ? 1 : ro_mt(cout), tot = MT * 64 * WFS;
     if (e >= tot) { const int o = e - tot; return (o < cout) ? bias[o] : 0.f; }
-    const int mt = e / (64 * RO_WFS), r1 = e - mt * (64 * RO_WFS);
-    const int ln = r1 / RO_WFS, sl = r1 - ln * RO_WFS;
+    const int mt = e / (64 * WFS), r1 = e - mt * (64 * WFS);
+    const int ln = r1 / WFS, sl = r1 - ln * WFS;
     const int lqq = ln >> 4, o = mt * 16 + (ln & 15);
     const int c = (layer == 0) ? 4 * sl + lqq : 16 * (sl >> 2) + 4 * lqq + (sl & 3);
     return (sl < RO_KS && o < cout && c < cin) ? src[(size_t)o * cin + c] : 0.f;
 }
-__host__ __device__ inline int ro_chain_image_size(int cout, bool last)
+__host__ __device__ inline int ro_chain_image_size(int cout, bool last, bool bf = RO_BF16_CHAIN)
 {
     const int MT = last ? 1 : ro_mt(cout);
-    return MT * 64 * RO_WFS + MT * 16;
+    return MT * 64 * ro_wfs(bf) + MT * 16;
 }
 
 __device__ __forceinline__ int ro_dim(unsigned long long dimsA, unsigned int dims8, int l)

@@ -185,9 +185,9 @@ def test_split_bf16_layers_against_the_fp32_mfma_build(init):
     assert np.all(d_all[SAMPLED] <= 1e-6 + 2.0 * noise)
     assert d_all.max() <= 5e-5 and np.median(d_all) <= 2e-6
     assert np.all(e_b <= e_f + 2e-6)
-    # given (almost) the same action the simulator halves agree: same network, positions to the action's difference x dt^2
+    # given (almost) the same action the simulator halves agree: same network, velocities to the action's difference x gain x dt
     assert np.mean(out[False][2][:, 1] != out[True][2][:, 1]) <= 1e-5
-    assert np.max(np.abs(out[False][1] - out[True][1])) <= 1e-9
+    assert np.max(np.abs(out[False][1] - out[True][1])) <= 0.2 * max(d_all.max() * np.abs(v).max(), 1e-6)
 
 
 def test_reset_push_after_strided_steps_reads_the_reset_observation():

@@ -27,8 +27,14 @@ def _run(code, timeout=300, **extra_env):
                MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
     env.pop('MGP_DIST_BACKEND', None)
     env.update(extra_env)
-    return subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                          text=True, timeout=timeout)
+    for attempt in range(2):
+        r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=timeout)
+        # a process killed by a SIGNAL (seen once in ~10 full-suite runs: SIGABRT inside RCCL's teardown of the world-1 group, after
+        # the script's own checks had passed or before they ran) is run once more; a Python error / failed assertion (rc > 0) never is
+        if r.returncode >= 0:
+            break
+    return r
 
 
 BRINGUP = r'''
