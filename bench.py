@@ -68,7 +68,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0                     # dense bf16 (MI355X_MICROARC
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32 / 32x32x2 dense peak (MI355X_MICROARCH.md: = the fp32 vector rate)
 PARITY_TOL = 1e-5
 NOISE_FACTOR = 2.0          # allowance on ill-conditioned episodes: tol + NOISE_FACTOR x the reference's own fp32 noise (round 3: 10)
-PROFILE_ROUND = 'r03'
+PROFILE_ROUND = 'r04'
 F_FEAT, N_ACT = 6, 2
 
 
@@ -379,6 +379,24 @@ def pmc_traffic(kernel, B, N, K, steps_per_launch=None):
             m['fixed_bytes'], m['bytes_per_step'])
     except KeyError:
         return None, 'kernel not in the committed PMC pass'
+
+
+def pmc_traffic_factored(B, N, K):
+    """HBM bytes per ENV STEP of the factored path (simulator + gather stage(s) + policy tail) from the committed PMC passes
+    (profiles/<round>_pmc_traffic_factored.json: tools/pmc_probe.py with PROBE_FACTORED=1), or (None, why)."""
+    d = _profile_json('pmc_traffic_factored.json')
+    if d is None:
+        return None, 'no committed PMC pass of the factored kernels'
+    if d.get('_meta', {}).get('shape') != [B, N, K]:
+        return None, 'committed PMC pass is for shape %s' % (d.get('_meta', {}).get('shape'),)
+    tot, parts = 0.0, []
+    for k, per_step in (('sp_sim_kernel', 1), ('spl_gather_kernel', max(K - 2, 0)), ('spl_policy_kernel', 1)):
+        if per_step and k in d:
+            tot += d[k]['total_bytes'] * per_step
+            parts.append('%s %.2f MB' % (k, d[k]['total_bytes'] / 1e6))
+    if not parts:
+        return None, 'kernels not in the committed PMC pass'
+    return tot, 'profiles/%s_pmc_traffic_factored.json (per launch: %s)' % (PROFILE_ROUND, ', '.join(parts))
 
 
 def pmc_sq(kernel):
@@ -1205,8 +1223,9 @@ def main():
             "actor_fwd": hbm_block('actor_fwd', "mgp_actor_fwd: actor_fwd_mfma_kernel for N <= 128 (aggregation X.G AND filter/"
                                    "MLP on fp32 MFMA, fused), actor_fwd_kernel otherwise: 4KN^2 + 4KFN + 4 nA N bytes per "
                                    "episode", ('actor_fwd_mfma_kernel', 'actor_fwd_kernel')),
-            "agg_fwd": hbm_block('agg_fwd', "mgp_agg_fwd: agg_fwd_mfma_kernel for N <= 128, agg_fwd_kernel otherwise (aggregation "
-                                 "X.G alone): 4KN^2 + 8KFN bytes per episode", ('agg_fwd_mfma_kernel', 'agg_fwd_kernel')),
+            "agg_fwd": hbm_block('agg_fwd', "mgp_agg_fwd: agg_fwd_mfma4_kernel for N <= 128 (four waves per (episode, tap): a wave "
+                                 "streams half the rows of its column block), agg_fwd_kernel otherwise (aggregation "
+                                 "X.G alone): 4KN^2 + 8KFN bytes per episode", ('agg_fwd_mfma4_kernel', 'agg_fwd_mfma_kernel', 'agg_fwd_kernel')),
             "sim_state_step": hbm_block('sim_state_step', "flock_step_kernel<advance> (sim step + delayed-GSO / delay-line "
                                         "transition, fused)", ('flock_step_kernel',)),
             "rotating_input_sets": n_sets,
@@ -1226,7 +1245,7 @@ def main():
             # pieces per fp32 operand, six 16x16x32 products per fp32 product: rollout_common.h ro_layer_bf16), the 64-wide
             # build on fp32 MFMA 16x16x4.  `frac` above stays against the fp32 matrix peak -- the rate a plain fp32
             # implementation of the same flops is bounded by; the bf16 figures are here for the pipe's own occupancy
-            split = max(hidden) <= 32 or (len(hidden) == 1 and 64 < hidden[0] <= 128)     # base build / the 128-wide build
+            split = N <= 128 or max(hidden) <= 32        # every build of the N <= 128 kernel; beyond, widths <= 32 only
             matrix_note = ({"form": "split-bf16: v_mfma_f32_16x16x32_bf16, 6 bf16 products per fp32 product, K padded to 32",
                             "bf16_flops_per_episode_step": 6.0 * 2.0 * N * sum(32 * 16 * ((b_ + 15) // 16) for b_ in dims[1:]),
                             "bf16_peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS}
@@ -1257,6 +1276,33 @@ def main():
                                    "note": "NOT a roofline fraction: the bytes the dense-contract aggregation (4KN^2 + 8KFN "
                                            "per episode-step, SURVEY.md 8d) WOULD stream for these steps / launch time; "
                                            "inside the launch the operator exists only as neighbour lists in LDS"},
+                "dense_kernels": dense}
+        elif factored:
+            # N > 256: the factored state in HBM, K launches per env step (simulator, K - 2 gather stages, policy tail).  No
+            # dense operator exists; the bytes a step REQUIRES (each array once) per episode:
+            #   simulator    x in + out (2 x 32 N), bit rows (8 NW N), row weights (4 N), feature rows (32 N), lists (32 N)
+            #   gather q     lists of A_{t-q+1} (32 N) + row weights (4 N), source rows of taps >= q in (32 N each) and out
+            #   policy tail  lists + weights of the last factor, its source rows, the K finished taps (32 N each), action (8 N)
+            NW = (N + 63) // 64
+            sim_b = (64 + 8 * NW + 4 + 32 + 32) * N
+            gather_b = sum((36 + 64 * (K - q)) * N for q in range(1, K - 1))          # stages 1 .. K-2: taps q .. K-1 in and out
+            policy_b = ((36 + 32) * (1 if K >= 2 else 0) + 32 * K + 8) * N
+            req = (sim_b + gather_b + policy_b) * B
+            ms_step = 1e3 * el_fact / args.steps
+            trf, trf_note = pmc_traffic_factored(B, N, K)
+            out["roofline"] = {
+                "kernel": "factored step: sp_sim_kernel + %d x spl_gather_kernel + spl_policy_kernel (%d launches per env step)"
+                          % (max(K - 2, 0), max(K, 2)),
+                "bound": "hbm", "achieved": req / ms_step / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": req / ms_step / 1e6 / HBM_PEAK_GBS, "traffic": trf, "traffic_source": trf_note,
+                "required_bytes_per_step": req,
+                "required_bytes_per_episode_step": {"simulator": sim_b, "gather_stages": gather_b, "policy_tail": policy_b},
+                "avg_step_ms": ms_step,
+                "note": "bytes the factored state REQUIRES per env step (bit rows, lists, row weights, feature rings, agent "
+                        "states: each array once) / wall time per step of the timed region / 8 TB/s.  The path is latency-, not "
+                        "bandwidth-bound: every launch starts with the wait for the rows the previous launch wrote on other "
+                        "XCDs (profiles/%s_factored_step_stamps.txt); the dense-contract bytes of this shape would be %.0f MB "
+                        "per step" % (PROFILE_ROUND, (4 * K * N * N + 8 * K * F_FEAT * N) * B / 1e6),
                 "dense_kernels": dense}
         else:
             out["roofline"] = dict(dense["actor_fwd" if fused else "agg_fwd"], dense_kernels=dense)

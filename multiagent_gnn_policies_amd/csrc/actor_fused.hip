@@ -18,7 +18,9 @@
 //   Y and Z never touch HBM unless `saved` is requested (training).
 // Backward: one workgroup per 64-column tile walks the layers in LDS and emits per-tile parameter-gradient
 // partials; a second kernel adds the partials in tile order (deterministic).
+#include <cstdlib>
 #include "mgp_device.h"
+#include "rollout_common.h"               // the split-bf16 hidden layer of the resident kernels (MGP_RO_KS = 8: widths <= 32)
 
 namespace {
 
@@ -658,6 +660,135 @@ void actor_fwd_mfma_kernel(const float* __restrict__ X, const float* __restrict_
     }
 }
 
+// ---- The reference's own policy shape compiled in: [6 K -> 32 -> 32 -> 2], inference (no saved activations).  Same stream,
+// same single barrier; what differs is the MLP tail (7k of this kernel's 25k cycles in the generic form: fp32 MFMA 16x16x4,
+// 16 instructions of 32 cycles per m-tile and layer, run-time layer metadata): the hidden layers run as split-bf16 MFMA
+// (rollout_common.h::ro_layer_bf16 -- three bf16 pieces per fp32 operand, six 16x16x32 products of 16 cycles, the form the
+// episode-resident kernel runs these layers in), the 2-wide output layer on the accumulator registers with two lane swaps.
+// The two staging waves build the piece records in LDS themselves, one layer each: a lane loads the 16 weights of its two
+// records (requests in flight together, in the shadow of the operator stream), splits them and stores 2 x 48 bytes.
+// The aggregation tile is written in the bf16 layer's channel enumeration (slot rpos(c) of a 36-float column).
+constexpr int AP_IMG = 2 * 64 * RO_WFS + 32;        // floats of one hidden layer's block: fragments of 2 m-tiles + 32 biases
+constexpr int AP_OUT = 2 * 32 + 16;                 // output layer: pairs (W[0][c], W[1][c]) of 32 channels, the bias pair, pad
+
+template <int S, int FH>
+__global__ __launch_bounds__(AF_THREADS)
+void actor_fwd_pol_kernel(const float* __restrict__ X, const float* __restrict__ G, float* __restrict__ out, ActorParams P,
+                          int B, int K, int N, int nblk)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int b = blockIdx.x;
+    const int F = 6, FK = F * K;
+    const int ncols16 = pad16(N);
+    float* ys = smem;                                             // [ncols16][RO_CS]
+    float* wimg = smem + ncols16 * RO_CS;                         // layer 0 | layer 1 | output layer
+    f32x4* red = reinterpret_cast<f32x4*>(wimg + 2 * AP_IMG + AP_OUT);
+    const int nstream = K * nblk;
+    AF_STAMP(0);
+    if (wave < nstream) {
+        const int gtot = N >> 2, g0 = (nblk == 2) ? ((gtot + 1) >> 1) : gtot;
+        const int k = wave / nblk, blk = wave - k * nblk;
+        const int ng = blk ? gtot - g0 : g0;
+        const int g = blk * g0 + min(li, ng - 1);
+        agg_mfma_unit<S, FH>(G + ((size_t)b * K + k) * (size_t)N * N + 4 * g, X + ((size_t)b * K + k) * (size_t)F * N, N, F, N,
+                             lane, red + wave * (4 * 64),
+                             [&](int h, const f32x4& tot) {
+                                 if (li < ng) {
+#pragma unroll
+                                     for (int i = 0; i < 4; ++i) {
+                                         const int c = 4 * h + i;
+                                         if (c < F) ys[(4 * g + lq) * RO_CS + rpos(c * K + k)] = tot[i];
+                                     }
+                                 }
+                             });
+        AF_STAMP(3);
+    } else if (wave < nstream + 2) {
+        const int sw = __builtin_amdgcn_readfirstlane(wave) - nstream;     // staging wave 0: layer 0, 1: layer 1 + output layer
+        const int cin = sw ? 32 : FK;
+        const float* Wl = P.W[sw];
+        // this lane's two records (m-tiles 0, 1): row o = 16 mt + li, element j of k-group lq <-> channel 4 j + lq (layer 0:
+        // the aggregation tile) or 4 lq + j | 16 + 4 lq + (j - 4) (layer 1: the first layer's accumulator registers)
+        float wv[2][8];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = sw ? (j < 4 ? 4 * lq + j : 16 + 4 * lq + (j - 4)) : 4 * j + lq;
+                wv[mt][j] = Wl[(size_t)(16 * mt + li) * cin + min(c, cin - 1)];     // (clamped address, masked below)
+            }
+        const float bias_v = (lane < 32) ? P.b[sw][lane] : 0.f;
+        float w2v = 0.f, b2v = 0.f;
+        if (sw) { w2v = P.W[2][(size_t)(lane & 1) * 32 + (lane >> 1)]; b2v = P.b[2][lane & 1]; }
+        // padding channels FK .. 31 of the aggregation tile (the streaming waves write the others): columns 64 sw .. 64 sw + 63
+        {
+            const int st = lane + 64 * sw;
+            if (st < ncols16)
+                for (int q = FK; q < 32; ++q) ys[st * RO_CS + rpos(q)] = 0.f;
+        }
+        float* img = wimg + sw * AP_IMG;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float wm[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = sw ? (j < 4 ? 4 * lq + j : 16 + 4 * lq + (j - 4)) : 4 * j + lq;
+                wm[j] = (c < cin) ? wv[mt][j] : 0.f;
+            }
+            ro_bf16x8 a1, a2, a3;
+            ro_split3(wm, a1, a2, a3);
+            float4* dst = reinterpret_cast<float4*>(img + (mt * 64 + lane) * RO_WFS);
+            dst[0] = *reinterpret_cast<const float4*>(&a1);
+            dst[1] = *reinterpret_cast<const float4*>(&a2);
+            dst[2] = *reinterpret_cast<const float4*>(&a3);
+        }
+        if (lane < 32) img[2 * 64 * RO_WFS + lane] = bias_v;
+        if (sw) {
+            float* w2 = wimg + 2 * AP_IMG;
+            w2[lane] = w2v;                                        // float 2 c + o = W[o][c], c = lane >> 1, o = lane & 1
+            if (lane < 2) w2[64 + lane] = b2v;
+        }
+        AF_STAMP_T(19, 64 * nstream);
+    }
+    __syncthreads();
+    AF_STAMP(4);
+    const int NT = ncols16 / 16;
+    if (wave < NT) {
+        const int col = wave * 16 + li;
+        float fb[8];
+        {
+            const float4* pb = reinterpret_cast<const float4*>(ys + col * RO_CS + lq * RO_KS);
+            const float4 t0 = pb[0], t1 = pb[1];
+            fb[0] = t0.x; fb[1] = t0.y; fb[2] = t0.z; fb[3] = t0.w; fb[4] = t1.x; fb[5] = t1.y; fb[6] = t1.z; fb[7] = t1.w;
+        }
+        float zc[RO_MAXMT][4];
+        ro_layer_bf16<2, true>(fb, wimg + lane * RO_WFS, wimg + 2 * 64 * RO_WFS + lq * 4, zc);
+        AF_STAMP(6);
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) fb[s_] = zc[s_ >> 2][s_ & 3];
+        ro_layer_bf16<2, true>(fb, wimg + AP_IMG + lane * RO_WFS, wimg + AP_IMG + 2 * 64 * RO_WFS + lq * 4, zc);
+        AF_STAMP(7);
+        // output layer on the accumulator registers: lane (li, lq) holds channels 16 a + 4 lq + rr of column li
+        const float* w2 = wimg + 2 * AP_IMG;
+        f32x2 u2 = {0.f, 0.f}, u2b = {0.f, 0.f};
+#pragma unroll
+        for (int a_ = 0; a_ < 2; ++a_) {
+            const float4 wa = *reinterpret_cast<const float4*>(w2 + 2 * (16 * a_ + 4 * lq));
+            const float4 wb = *reinterpret_cast<const float4*>(w2 + 2 * (16 * a_ + 4 * lq) + 4);
+            u2 = __builtin_elementwise_fma((f32x2){zc[a_][0], zc[a_][0]}, (f32x2){wa.x, wa.y}, u2);
+            u2b = __builtin_elementwise_fma((f32x2){zc[a_][1], zc[a_][1]}, (f32x2){wa.z, wa.w}, u2b);
+            u2 = __builtin_elementwise_fma((f32x2){zc[a_][2], zc[a_][2]}, (f32x2){wb.x, wb.y}, u2);
+            u2b = __builtin_elementwise_fma((f32x2){zc[a_][3], zc[a_][3]}, (f32x2){wb.z, wb.w}, u2b);
+        }
+        u2 = u2 + u2b;
+        const float2 bb = *reinterpret_cast<const float2*>(w2 + 64);
+        const float ux = rows_sum4(u2.x) + bb.x, uy = rows_sum4(u2.y) + bb.y;
+        if (lq < 2 && col < N) out[((size_t)b * 2 + lq) * N + col] = lq ? uy : ux;
+        AF_STAMP(8);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Backward (parameters only).  Workgroup per (b, 64-column tile).  LDS: delta ping-pong [maxw][65],
 // input tile [maxin][65].  Partials: part[tile][P] with P = sum_l cout*cin + cout, layer-major (W then b).
@@ -906,6 +1037,16 @@ int launch_fwd_mfma(const float* X, const float* G, float* out, float* saved, co
     return mgp_launch_status();
 }
 
+template <int S, int FH>
+int launch_fwd_pol(const float* X, const float* G, float* out, const ActorParams& P, const PlanM& pm, int B, int K, int N,
+                   hipStream_t st)
+{
+    const size_t lds = ((size_t)pad16(N) * RO_CS + 2 * AP_IMG + AP_OUT + (size_t)K * pm.nblk * 4 * 64 * 4) * sizeof(float);
+    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(actor_fwd_pol_kernel<S, FH>), lds) != hipSuccess) return MGP_ELAUNCH;
+    hipLaunchKernelGGL((actor_fwd_pol_kernel<S, FH>), dim3((unsigned)B), dim3(AF_THREADS), lds, st, X, G, out, P, B, K, N, pm.nblk);
+    return mgp_launch_status();
+}
+
 template <int CT, int V>
 int launch_fwd(const float* X, const float* G, float* out, float* saved, const ActorParams& P, const Plan& pl,
                int B, int K, int N, hipStream_t st)
@@ -956,6 +1097,14 @@ extern "C" int mgp_actor_fwd(const float* X, const float* G, const float* const*
     mgp_clear_error();
     PlanM pm;
     if (make_plan_mfma(W, b, dims, n_layers, K, N, mgp_aligned16(G) && mgp_aligned16(X), &pm)) {   // G, X: float4 loads
+        // the reference's policy shape (cfg/dagger.cfg: two hidden layers of 32), inference: its layers compiled in
+        static const bool pol_off = getenv("MGP_ACTOR_POL") != nullptr && atoi(getenv("MGP_ACTOR_POL")) == 0;   // (A/B switch)
+        if (saved == nullptr && !pol_off && n_layers == 3 && dims[0] == 6 && dims[1] == 32 && dims[2] == 32 && dims[3] == 2 &&
+            6 * K <= 32) {
+            if (pm.S <= 16) return launch_fwd_pol<16, 2>(X, G, out, P, pm, B, K, N, st);
+            if (pm.S <= 28) return launch_fwd_pol<28, 2>(X, G, out, P, pm, B, K, N, st);
+            return launch_fwd_pol<32, 2>(X, G, out, P, pm, B, K, N, st);
+        }
 #define MGP_AM_CASE(S_) return dims[0] <= 4 ? launch_fwd_mfma<S_, 1>(X, G, out, saved, P, pm, B, K, N, st) \
                                              : launch_fwd_mfma<S_, 2>(X, G, out, saved, P, pm, B, K, N, st)
         if (pm.S <= 16) MGP_AM_CASE(16);

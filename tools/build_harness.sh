@@ -1,0 +1,12 @@
+#!/bin/bash
+# Builds the stand-alone profiling harnesses into scratch/ (they travel to the GPU box with the snapshot; hipcc cross-compiles here).
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p scratch
+F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w"
+hipcc $F -o scratch/ro_prof tools/harness/ro_phase_prof.hip &
+hipcc $F -o scratch/ro_launch tools/harness/ro_launch_prof.hip &
+hipcc $F -o scratch/sp_prof tools/harness/sp_step_prof.hip &
+hipcc $F -DMGP_SP_PROFILE -o scratch/sp_prof_stamps tools/harness/sp_step_prof.hip &
+wait
+ls -la scratch/ro_prof scratch/ro_launch scratch/sp_prof scratch/sp_prof_stamps

@@ -1,12 +1,12 @@
 """Copy the outputs of tools/regen_profiles.sh (gpurun_out/final/) into profiles/<round>_* (run from the repo root;
-ROUND=r03 by default)."""
+ROUND=r04 by default)."""
 import json
 import os
 import shutil
 import sys
 sys.path.insert(0, ".")
 import os
-O, R = 'gpurun_out/final', os.environ.get('ROUND', 'r03')
+O, R = 'gpurun_out/final', os.environ.get('ROUND', 'r04')
 
 
 def last_json(path):
@@ -38,8 +38,10 @@ note = ("# rocprofv3 --kernel-trace --stats of `python bench.py --gpus 1 --steps
         "#      two-launch path (timed in the same run) and to the stand-alone dense-kernel roofline leg.\n")
 open('profiles/%s_bench_kernel_trace.txt' % R, 'w').write(''.join(kt[:2]) + note + ''.join(kt[2:]))
 shutil.copy(O + '/dagger_update.json', 'profiles/%s_dagger_update.json' % R)
-hdr = ("# bench.py at other shapes (B N K, hidden width x layers), 100-step launches right after reset: value, per-path throughput, in-run parity gate, per-kernel\n"
-       "# (avg launch us, GB/s), state finite.  `resident` = mgp_rollout_steps_ex (N <= 256); `factored` = HBM bit-row state (N > 256)\n")
+hdr = ("# tools/gpu/other_cfgs.sh: bench.py at the non-headline shapes, each on a TRAINED policy (tests/golden/policies, tools/train_policies.py;\n"
+       "# the reference's shipped checkpoint where its shape fits) and the environment's own reset distribution, 100-step launches right after\n"
+       "# reset: value, per-path throughput; second line: the in-run parity gate -- well-conditioned episodes of the 16 checked, the\n"
+       "# reference's own fp32 noise, and per path max_rel and the bound it passed on.  Then B = 1 / B = 2048 with per-kernel (us, GB/s), then the degree sweep.\n")
 open('profiles/%s_other_configs.txt' % R, 'w').write(hdr + open(O + '/other_configs.txt').read())
 open('profiles/%s_rollout_phase_stamps.txt' % R, 'w').write(
     "# tools/harness/ro_phase_prof.hip on MI355X (RO_CARRY=1: prebuilt weight image + factored hand-over, the repeated-launch form):\n"
@@ -49,9 +51,14 @@ open('profiles/%s_rollout_phase_stamps.txt' % R, 'w').write(
     "# membership test, lists, weights; 13 waves) | S2 (fp64 features, waves 0-6 || gather stage 1 of the next step, waves 7-13); 3 barriers.\n"
     + open(O + '/rollout_phase_stamps.txt').read())
 open('profiles/%s_rollout_launch_cost.txt' % R, 'w').write(
-    "# launch length sweep, B=256 N=100 K=3, lattice harness state: dense hand-over (mgp_rollout_steps) vs [carry] = factored hand-over +\n"
-    "# prebuilt weight image + dense slices on demand (mgp_rollout_steps_ex); us per launch averaged over 20 back-to-back launches\n"
+    "# tools/harness/ro_launch_prof.hip: anatomy of a resident launch (prebuilt weight image, factored hand-over), B=256 N=100 K=3.  Every launch\n"
+    "# of a row starts from the SAME saved state; kernel us = the launch's own begin/end events; the other columns from the 100 MHz wall clock every\n"
+    "# workgroup stamps (medians over workgroups and 30 launches): dispatch ramp, entry (state -> LDS, lists from the carry, gather stage 1 of the\n"
+    "# first step), the first three steps, the later steps, exit, and the spread of the workgroups' END times (the launch lasts as long as its\n"
+    "# slowest episode).  First block: bench.py's state 5 steps after a disc reset; second: the regular lattice of the harness.\n"
     + open(O + '/rollout_launch_cost.txt').read())
+if os.path.exists(O + '/rollout_wg_times.txt'):
+    shutil.copy(O + '/rollout_wg_times.txt', 'profiles/%s_rollout_wg_times.txt' % R)
 open('profiles/%s_actor_fwd_phase_stamps.txt' % R, 'w').write(
     "# tools/harness/af_phase_prof.hip on MI355X: in-kernel s_memtime stamps of workgroup 0 of actor_fwd_mfma_kernel<28, 2> (shader cycles),\n"
     "# B = 256 (one workgroup per CU) and B = 1.  Thread 0 (a streaming wave): 1 = its X + G requests issued | 2 = its 4x4x1 MFMAs done\n"
@@ -62,7 +69,8 @@ open('profiles/%s_actor_fwd_phase_stamps.txt' % R, 'w').write(
 from multiagent_gnn_policies_amd import build
 print('hash ok', build.source_hash() == json.load(open('profiles/%s_pmc_traffic.json' % R))['_meta']['source_hash'])
 
-for name in ('dagger_round_1rank.json', 'dagger_round_2ranks_shared_gpu.json', 'p2p_exchange_latency.txt', 'rollout_inst_mix.txt'):
+for name in ('dagger_round_1rank.json', 'dagger_round_2ranks_shared_gpu.json', 'p2p_exchange_latency.txt', 'rollout_inst_mix.txt',
+             'agg_forms.txt', 'first_multi_gpu_dry.json', 'pmc_traffic_factored.json', 'pmc_hbm_traffic_factored.txt'):
     if os.path.exists(O + '/' + name):
         shutil.copy(O + '/' + name, 'profiles/%s_%s' % (R, name))
 

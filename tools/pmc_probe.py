@@ -21,6 +21,15 @@ def main():
     N = int(os.environ.get('PROBE_N', '100'))
     K = 3
     dev = torch.device('cuda:0')
+    if os.environ.get('PROBE_FACTORED'):
+        # the factored path (N > 256): simulator + gather + policy launches of 200 env steps at BASELINE configs[2]'s shape
+        ro = bench.Rollout(dev, B, N, K, [32, 32], seed=1000)
+        assert ro.factored_supported()
+        ro.run_resident(20)
+        ro.run_resident(200)
+        torch.cuda.synchronize()
+        print('factored path: 200 env steps at', B, 'x', N)
+        return
     actor = Actor(6, 2, [32, 32], K, 0).to(dev)
     bench.load_weights(actor)
     actor.eval()

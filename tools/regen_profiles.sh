@@ -1,9 +1,8 @@
 #!/bin/bash
 # Regenerates every round artefact under profiles/ on the GPU box (run through gpurun from the repo root):
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/regen_profiles.sh > gpurun_out/regen.log 2>&1'
-#   python tools/install_profiles.py          # copies gpurun_out/final/* into profiles/<round>_*  (ROUND=r03)
-# The phase harness must have been built first (it travels with the snapshot under scratch/):
-#   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -o scratch/ro_prof tools/harness/ro_phase_prof.hip
+#   python tools/install_profiles.py          # copies gpurun_out/final/* into profiles/<round>_*  (ROUND=r04)
+# The harnesses must have been built first (they travel with the snapshot under scratch/):  bash tools/build_harness.sh
 # PMC passes use --pmc with --kernel-trace only (no sys/runtime/hip trace domains).
 set -x
 R=$GRAFT_REPO_ROOT
@@ -20,13 +19,19 @@ export PROBE_T=20
 PROBE_ROLLOUT_ONLY=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch20 -o fetch -- python $R/tools/pmc_probe.py > $O/pmc_fetch20.log 2>&1
 PROBE_ROLLOUT_ONLY=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write20 -o write -- python $R/tools/pmc_probe.py > $O/pmc_write20.log 2>&1
 export PROBE_T=1000
+# the factored path (BASELINE configs[2]: 64 x 1000): bytes per launch of its three kernels
+PROBE_FACTORED=1 PROBE_B=64 PROBE_N=1000 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_f -o fetch -- python $R/tools/pmc_probe.py > $O/pmc_fetch_f.log 2>&1
+PROBE_FACTORED=1 PROBE_B=64 PROBE_N=1000 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write_f -o write -- python $R/tools/pmc_probe.py > $O/pmc_write_f.log 2>&1
 F=$(find $O/pmc_fetch -name "*results.db" | head -1); W=$(find $O/pmc_write -name "*results.db" | head -1); Q=$(find $O/pmc_sq -name "*results.db" | head -1)
 F2=$(find $O/pmc_fetch20 -name "*results.db" | head -1); W2=$(find $O/pmc_write20 -name "*results.db" | head -1)
 cd $R
 python tools/pmc_summary.py $F $W $O/pmc_traffic.json 256,100,3 $F2 $W2 20 > $O/pmc_hbm_traffic.txt 2>&1
-cp $O/pmc_traffic.json $R/profiles/${ROUND:-r03}_pmc_traffic.json
+cp $O/pmc_traffic.json $R/profiles/${ROUND:-r04}_pmc_traffic.json
+FF=$(find $O/pmc_fetch_f -name "*results.db" | head -1); WF=$(find $O/pmc_write_f -name "*results.db" | head -1)
+python tools/pmc_summary.py $FF $WF $O/pmc_traffic_factored.json 64,1000,3 > $O/pmc_hbm_traffic_factored.txt 2>&1
+cp $O/pmc_traffic_factored.json $R/profiles/${ROUND:-r04}_pmc_traffic_factored.json
 python tools/pmc_sq_summary.py $Q $O/pmc_sq.json > $O/pmc_sq.txt 2>&1
-cp $O/pmc_sq.json $R/profiles/${ROUND:-r03}_pmc_sq.json
+cp $O/pmc_sq.json $R/profiles/${ROUND:-r04}_pmc_sq.json
 # 2. bench (traffic / sq now resolved from the files just written): the driver's command line, the default, and under rocprof
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_steps20.json 2> $O/bench_steps20.err
 python bench.py > $O/bench_final.json 2> $O/bench_final.err
@@ -39,18 +44,20 @@ python tools/rocpd_stats.py $T > $O/bench_kernel_trace.txt 2>&1
 RO_CARRY=1 ./scratch/ro_prof 256 100 3 200 > $O/rollout_phase_stamps.txt 2>&1
 python tools/dump_rollout_state.py /tmp/ro_state5.bin 5 > /dev/null 2>&1
 RO_STATE=/tmp/ro_state5.bin RO_CARRY=1 ./scratch/ro_prof 256 100 3 20 20 >> $O/rollout_phase_stamps.txt 2>&1
-for T in 1 2 5 20 200; do ./scratch/ro_prof 256 100 3 $T 20 | head -1; RO_CARRY=1 ./scratch/ro_prof 256 100 3 $T 20 | head -1; done 2>/dev/null > $O/rollout_launch_cost.txt
+{ RO_STATE=/tmp/ro_state5.bin RO_WG_DUMP=$O/rollout_wg_times.txt ./scratch/ro_launch 256 100 3 "1 2 3 5 10 20 40 100" 30; ./scratch/ro_launch 256 100 3 "1 2 5 20" 30; } > $O/rollout_launch_cost.txt 2>&1
 # 3b. phase stamps of the fused Actor forward (MFMA aggregation variant), B = 256 and B = 1
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -w -o /tmp/af_prof tools/harness/af_phase_prof.hip 2>/dev/null
 { /tmp/af_prof 256 100; /tmp/af_prof 1 100; } > $O/actor_fwd_phase_stamps.txt 2>&1
 # 4. DAGGER update / collection + other configs
 python tools/bench_update.py > $O/dagger_update.json 2> $O/dagger_update.err
-for cfg in "64 1000 3 32 2" "256 200 4 32 2" "1 100 3 32 2" "2048 100 3 32 2" "256 100 4 32 2" "256 100 2 32 2" "256 125 3 32 2" "256 50 2 32 2" "256 100 3 64 2" "256 100 3 128 1" "256 100 3 128 2"; do set -- $cfg; python bench.py --episodes $1 --agents $2 --taps $3 --hidden $4 --layers $5 --no-cpu-baseline --steps 100 --warmup 10 2>/dev/null | python -c "
+bash tools/gpu/other_cfgs.sh > $O/other_configs.txt 2>&1
+for cfg in "1 100 3 32 2" "2048 100 3 32 2"; do set -- $cfg; python bench.py --episodes $1 --agents $2 --taps $3 --hidden $4 --layers $5 --no-cpu-baseline --steps 100 --warmup 10 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 k = {a: (round(v['avg_launch_ms']*1e3,1), round(v['GBps'])) for a, v in d.get('kernels', {}).items()}
-print('$1 $2 $3 hidden $4 x $5', 'value %.3e' % d['value'], 'ms/step %.4f' % d['ms_per_step'], 'paths', {a: '%.3e' % b['value'] for a, b in d['paths'].items()}, 'parity ok', d['parity']['ok'], 'max_rel %.2e' % d['parity']['max_rel'], k, d['config']['state_finite'])
+print('$1 x N=$2 K=$3 hidden $4 x $5', 'value %.3e' % d['value'], 'ms/step %.4f' % d['ms_per_step'], 'paths', {a: '%.3e' % b['value'] for a, b in d['paths'].items()}, 'parity', d['parity']['ok'], d['parity']['passed_on'], 'kernels (us, GB/s)', k)
 " >> $O/other_configs.txt; done
+for f in 8 4; do MGP_AGG_FORM=$f python tools/gpu/agg_ab.py 2>/dev/null; done > $O/agg_forms.txt
 # 4b. degree sweep on the environment's own (disc) resets: the communication radius sets the mean degree (~ R^2)
 for R_ in 0.83 0.95 1.0 1.05 1.15 1.3; do python bench.py --comm-radius $R_ --no-cpu-baseline --no-roofline --steps 100 --warmup 10 2>/dev/null | python -c "
 import sys, json
@@ -65,10 +72,11 @@ python - > $O/p2p_exchange_latency.txt 2>&1 <<'PY'
 import sys
 sys.path.insert(0, 'tests')
 import test_gpu_p2p as t
-for w in (2, 3, 4):
-    r = t.run_ranks('allreduce', world=w)
+for w in (2, 3, 4, 8):
+    r = t.run_ranks('allreduce', world=w, timeout=900)
     print('ranks %d (one MI355X, IPC between processes): %.2f us per exchange of 1,731 floats inside a 32-exchange HIP graph (launch of the stand-alone kernel included), mailbox memory kind %d (2 = uncached), %d exchanges checked bit-exact' % (w, r['exchange_us_in_graph'], r['mem_kind'], r['exchanges']))
 PY
+DRY=1 python tools/first_multi_gpu.py > $O/first_multi_gpu_dry.json 2> $O/first_multi_gpu_dry.err
 # 6. instruction mix of the resident kernel (harness, bench state)
 bash tools/gpu/ro_pmc.sh > $O/rollout_inst_mix.txt 2>&1
 # 7. the factored path (N > 256; cfg-3 shape 64 x 1000, K = 3): harness stamps of its three kernels, their kernel trace, the
@@ -85,5 +93,5 @@ print('64 1000 3 hidden 32 x 2, $st steps per call:', 'value %.3e' % d['value'],
 " >> $O/factored_kernel_trace.txt; done
 python bench.py --dagger --episodes 64 --agents 1000 --steps 200 --warmup 10 --updates 64 2> $O/dagger_round_n1000.err | grep "^{" > $O/dagger_round_n1000.json
 python bench.py --dagger --episodes 256 --agents 300 --steps 200 --warmup 10 --updates 256 2> $O/dagger_round_n300.err | grep "^{" > $O/dagger_round_n300.json
-rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_fetch20 $O/pmc_write20 $O/trace $O/trace_sp gpurun_out/ro_pmc
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_fetch20 $O/pmc_write20 $O/pmc_fetch_f $O/pmc_write_f $O/trace $O/trace_sp gpurun_out/ro_pmc
 ls -la $O
