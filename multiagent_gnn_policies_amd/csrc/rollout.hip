@@ -1134,14 +1134,17 @@ __device__ __forceinline__ void rb_gather_word(unsigned long long w, int base, c
     }
 }
 
-template <bool FD, bool CL>
+// CN / CK: compile-time (N, K) of a sized instantiation (0 = run-time arguments), as in rollout_kernel: BASELINE configs[4]'s
+// shape (N = 200, K = 4) runs with constant LDS addresses, loop bounds and divisors.
+template <bool FD, bool CL, int CN = 0, int CK = 0>
 __global__ __launch_bounds__(RO_THREADS)
 void rollout_big_kernel(double* __restrict__ x, float* __restrict__ G, float* __restrict__ Xd, float* __restrict__ action,
-                        double* __restrict__ rewards, RoParams P, MgpFlockParams p, int K, int N, int T,
+                        double* __restrict__ rewards, RoParams P, MgpFlockParams p, int K_arg, int N_arg, int T,
                         unsigned long long dimsA, unsigned int dims8, unsigned long long woffA, unsigned long long woffB,
                         int n_layers, const float* __restrict__ image, int image_floats, unsigned long long* __restrict__ carry,
                         int flags, MgpCollect cl)
 {
+    const int N = CN ? CN : N_arg, K = CK ? CK : K_arg;
     const RbOff cv = rb_offsets(N, K);
     const int H = ro_hist(K);
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
@@ -1759,22 +1762,22 @@ int launch_rollout(double* x, float* G, float* Xd, float* action, double* reward
     return mgp_launch_status();
 }
 
-template <bool FD, bool CL>
+template <bool FD, bool CL, int CN = 0, int CK = 0>
 int launch_rollout_big(double* x, float* G, float* Xd, float* action, double* rewards, const RoParams& P,
                        const MgpFlockParams* p, int B, int K, int N, int T, unsigned long long dimsA, unsigned int dims8,
                        unsigned long long woffA, unsigned long long woffB, int n_layers, int lds, hipStream_t st,
                        const float* image, int image_floats, unsigned long long* carry, int flags, const MgpCollect* cl)
 {
-    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(rollout_big_kernel<FD, CL>), (size_t)lds) != hipSuccess) return MGP_ELAUNCH;
+    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(rollout_big_kernel<FD, CL, CN, CK>), (size_t)lds) != hipSuccess) return MGP_ELAUNCH;
     MgpCollect none = {};
     hipEvent_t ev0, ev1;
     take_launch_events(&ev0, &ev1);
     if (ev0 != nullptr || ev1 != nullptr)
-        hipExtLaunchKernelGGL((rollout_big_kernel<FD, CL>), dim3(B), dim3(RO_THREADS), lds, st, ev0, ev1, 0, x, G, Xd, action, rewards,
+        hipExtLaunchKernelGGL((rollout_big_kernel<FD, CL, CN, CK>), dim3(B), dim3(RO_THREADS), lds, st, ev0, ev1, 0, x, G, Xd, action, rewards,
                               P, *p, K, N, T, dimsA, dims8, woffA, woffB, n_layers, image, image_floats, carry, flags,
                               cl ? *cl : none);
     else
-        hipLaunchKernelGGL((rollout_big_kernel<FD, CL>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K, N, T,
+        hipLaunchKernelGGL((rollout_big_kernel<FD, CL, CN, CK>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K, N, T,
                            dimsA, dims8, woffA, woffB, n_layers, image, image_floats, carry, flags, cl ? *cl : none);
     return mgp_launch_status();
 }
@@ -1945,6 +1948,15 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
 #define RB_LAUNCH(FD_, CL_) launch_rollout_big<FD_, CL_>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags, cl)
 #ifndef MGP_RO_X128
     if (N > RO_MAXN) {
+#ifdef MGP_RO_BASE
+        if (N == 200 && K == 4 && !fade) {                   // BASELINE configs[4] (cfg/n_twoflocks.cfg:114-116): sized instantiation
+            if (cl != nullptr)
+                return launch_rollout_big<false, true, 200, 4>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB,
+                                                               n_layers, lds, st, image, wt, carry, flags, cl);
+            return launch_rollout_big<false, false, 200, 4>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB,
+                                                            n_layers, lds, st, image, wt, carry, flags, cl);
+        }
+#endif
         if (cl != nullptr) return fade ? RB_LAUNCH(true, true) : RB_LAUNCH(false, true);
         return fade ? RB_LAUNCH(true, false) : RB_LAUNCH(false, false);
     }
@@ -1973,6 +1985,10 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
 #ifdef MGP_RO_BASE
     if (N == 100 && K == 2 && !fade)   // cfg/default.cfg, cloning.cfg, dagger_twoflocks.cfg
         return RO_LAUNCH(100, 2, false, false);
+    if (N == 100 && K == 4 && !fade)   // cfg/k.cfg
+        return RO_LAUNCH(100, 4, false, false);
+    if (N == 100 && K == 1 && !fade)   // cfg/dagger_leader.cfg, k.cfg
+        return RO_LAUNCH(100, 1, false, false);
 #endif
     return fade ? RO_LAUNCH(0, 0, true, false) : RO_LAUNCH(0, 0, false, false);
 #undef RO_LAUNCH
