@@ -23,9 +23,11 @@
 extern "C" {
 #endif
 
-#define MGP_VERSION 300            /* 0.2.0: + mgp_rollout_steps_ex / _image / _carry_*, mgp_rollout_collect, mgp_replay_gather;
+#define MGP_VERSION 310            /* 0.2.0: + mgp_rollout_steps_ex / _image / _carry_*, mgp_rollout_collect, mgp_replay_gather;
                                       0.2.1: + mgp_replay_gather_many; mgp_actor_fwd covers layer widths up to 128 at N <= 128;
-                                      0.3.0: + mgp_p2p_* (one-shot gradient exchange), mgp_train_step_p2p, mgp_adam_step_filed */
+                                      0.3.0: + mgp_p2p_* (one-shot gradient exchange), mgp_train_step_p2p, mgp_adam_step_filed;
+                                      0.3.1: + mgp_rollout_f32ref_* (checker build of the resident kernels); a timed-out exchange
+                                             leaves the weights untouched (mgp_train_step_p2p) */
 
 #define MGP_OK            0
 #define MGP_EINVAL       -1        /* bad size / null pointer / unsupported combination */

@@ -82,6 +82,7 @@ struct RoParams {
     int woff[MGP_MAX_LAYERS];             // offset (floats) of layer l's fragment block inside the weight image
     int n_layers;
     int wtot;                             // floats in the weight image
+    int bf;                               // hidden-layer blocks of the image hold split-bf16 pieces (else fp32 fragments)
 };
 
 // LDS layout (byte offsets).  Every region except the weight image depends on (N, K) only, and the weight image comes
@@ -151,7 +152,10 @@ __host__ __device__ constexpr RoOff ro_offsets(int N, int K)
 // with probability beta (a counter-based coin: mgp_device.h dagger_coin), else by the policy.
 // CM: the reference's policy shape compiled in -- two hidden layers of 32 (cfg/dagger.cfg: hidden_size 32, n_layers 2): the
 // layer loop unrolls, no layer metadata is decoded, the MLP's scalar control flow disappears.
-template <int CN, int CK, bool FD, bool CL, bool CM = false>
+// WBF: the hidden layers run on split-bf16 MFMA from piece records (rollout_common.h) -- every build but the checker; the
+// 64-wide build falls back to fp32 fragments (WBF = false) for policies whose 40 % larger piece image does not fit the LDS
+// (four 64-wide layers at N = 100: cfg/hidden_size.cfg [4, 64]).
+template <int CN, int CK, bool FD, bool CL, bool CM = false, bool WBF = RO_BF16_CHAIN>
 __global__ __launch_bounds__(RO_THREADS)
 void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __restrict__ Xd, float* __restrict__ action,
                     double* __restrict__ rewards, RoParams P, MgpFlockParams p, int K_arg, int N_arg, int T,
@@ -161,6 +165,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
 {
     RO_WALL(0);
     const int N = CN ? CN : N_arg, K = CK ? CK : K_arg;
+    constexpr int WFS = ro_wfs(WBF);                          // floats per lane and m-tile of a hidden layer's block
     const int n_layers = CM ? 3 : n_layers_arg;
     const RoOff cv = ro_offsets(N, K);
     const int H = ro_hist(K);
@@ -243,10 +248,10 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             const int cin = (l == 0) ? FK : P.dims[l];
             const int cout = P.dims[l + 1];
             const bool last = l == P.n_layers - 1;
-            const int tot = last ? ro_weight_image_size(cout, true) : ro_chain_image_size(cout, false);
+            const int tot = last ? ro_weight_image_size(cout, true) : ro_chain_image_size(cout, false, WBF);
             float* dst = wl + P.woff[l];
             for (int e = tid; e < tot; e += RO_THREADS)
-                dst[e] = last ? ro_weight_image_elem(P.W[l], P.b[l], cin, cout, true, e) : ro_chain_image_elem(P.W[l], P.b[l], cin, cout, l, false, e);
+                dst[e] = last ? ro_weight_image_elem(P.W[l], P.b[l], cin, cout, true, e) : ro_chain_image_elem(P.W[l], P.b[l], cin, cout, l, false, e, WBF);
         }
     }
     // ---- LDS regions no load fills (while the requests are in flight)
@@ -598,7 +603,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 const int cout = CM ? 32 : ro_dim(dimsA, dims8, l + 1);
                 const int MT = CM ? 2 : ro_mt(cout);
                 // (CM: a 32-wide hidden layer's block is 2 m-tiles of fragments + 32 bias values)
-                const float* wfrag = wl + (CM ? l * (2 * 64 * RO_WFS + 32) : (int)((((l < 4) ? woffA : woffB) >> (16 * (l & 3))) & 0xFFFFull));
+                const float* wfrag = wl + (CM ? l * (2 * 64 * WFS + 32) : (int)((((l < 4) ? woffA : woffB) >> (16 * (l & 3))) & 0xFFFFull));
                 float fb[RO_KS];
                 int ksteps;
                 if (l == 0) {
@@ -611,9 +616,9 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                     for (int s_ = 0; s_ < RO_KS; ++s_) fb[s_] = zc[s_ >> 2][s_ & 3];
                     ksteps = 4 * mtp;
                 }
-                const float* pw = wfrag + lane * RO_WFS;
-                const float* pbias = wfrag + MT * 64 * RO_WFS + lq * 4;
-                if constexpr (RO_BF16_CHAIN) {
+                const float* pw = wfrag + lane * WFS;
+                const float* pbias = wfrag + MT * 64 * WFS + lq * 4;
+                if constexpr (WBF) {
                     // widths <= 32: split-bf16 MFMA (rollout_common.h), the whole K = 32 in one instruction per product (no k-step count)
                     const int nkb = (RO_KB == 2 && l > 0 && ro_dim(dimsA, dims8, l) > 32) ? 2 : 1;   // K blocks of this layer's input
                     if (RO_MAXMT >= 8 && MT == 8) ro_layer_bf16<(RO_MAXMT >= 8 ? 8 : 1), true>(fb, pw, pbias, zc, nkb);
@@ -631,7 +636,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             }
             // ---------------------------------------------------------- C: output layer + integration, same wave, no barrier
             const int lo_ = n_layers - 1;
-            const float* w2 = wl + (CM ? 2 * (2 * 64 * RO_WFS + 32) : (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull));
+            const float* w2 = wl + (CM ? 2 * (2 * 64 * WFS + 32) : (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull));
             if (CM || n_layers > 1) {
                 // The 2-wide output layer on the accumulator registers of the last hidden layer: lane (li, lq) holds channels
                 // c = 16 a + 4 lq + rr of column li, whose weight pairs (W[0][c], W[1][c]) are two 16-byte reads per m-tile;
@@ -1654,19 +1659,27 @@ bool make_carve(const int* dims, int n_layers, int K, int N, RoParams* P, int* l
 #ifdef MGP_RO_X128
     if (n_layers != 2 || N > RO_MAXN) return false;                             // this build: ONE hidden layer (up to 128 wide), N <= 128
 #endif
-    int wtot = 0;
-    for (int l = 0; l < n_layers; ++l) {
-        const int cin = (l == 0) ? 6 * K : dims[l], cout = dims[l + 1];
-        const bool last = l == n_layers - 1;
-        // a hidden layer reads <= RO_KS k-steps (its input comes from the aggregation tile or the previous layer's <= 4 RO_KS
-        // accumulator rows) and produces <= RO_MAXMT m-tiles; the output layer reads every row of the last hidden layer
-        if (cin < 1 || cout < 1 || cin > (last ? RO_OUTC : 4 * RO_KS) || cout > 16 * RO_MAXMT) return false;
-        if (l == 0 && cin > 4 * RO_KS) return false;
-        if (P) { P->woff[l] = wtot; P->dims[l] = dims[l]; }
-        wtot += last ? ((2 * RO_OUTC + 2 + 15) & ~15) : ro_mt(cout) * 64 * ro_wfs(N > RO_MAXN ? RB_BF : RO_BF16_CHAIN) + ro_mt(cout) * 16;
+    // layout of the hidden layers' blocks: split-bf16 pieces wherever this build runs them (RB_BF beyond N = 128); the 64-wide
+    // build retries with fp32 fragments when the larger piece image does not fit
+    bool bf = N > RO_MAXN ? RB_BF : RO_BF16_CHAIN;
+    int wtot = 0, total = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        wtot = 0;
+        for (int l = 0; l < n_layers; ++l) {
+            const int cin = (l == 0) ? 6 * K : dims[l], cout = dims[l + 1];
+            const bool last = l == n_layers - 1;
+            // a hidden layer reads <= RO_KS k-steps (its input comes from the aggregation tile or the previous layer's <= 4 RO_KS
+            // accumulator rows) and produces <= RO_MAXMT m-tiles; the output layer reads every row of the last hidden layer
+            if (cin < 1 || cout < 1 || cin > (last ? RO_OUTC : 4 * RO_KS) || cout > 16 * RO_MAXMT) return false;
+            if (l == 0 && cin > 4 * RO_KS) return false;
+            if (P) { P->woff[l] = wtot; P->dims[l] = dims[l]; }
+            wtot += last ? ((2 * RO_OUTC + 2 + 15) & ~15) : ro_mt(cout) * 64 * ro_wfs(bf) + ro_mt(cout) * 16;
+        }
+        total = (N > RO_MAXN ? rb_offsets(N, K).wl : ro_offsets(N, K).wl) + wtot * 4;   // N > 128: rollout_big_kernel
+        if (total <= RO_LDS_LIMIT || !(bf && RO_KB == 2 && N <= RO_MAXN)) break;
+        bf = false;
     }
-    if (P) { P->dims[n_layers] = dims[n_layers]; P->n_layers = n_layers; P->wtot = wtot; }
-    const int total = (N > RO_MAXN ? rb_offsets(N, K).wl : ro_offsets(N, K).wl) + wtot * 4;   // N > 128: rollout_big_kernel
+    if (P) { P->dims[n_layers] = dims[n_layers]; P->n_layers = n_layers; P->wtot = wtot; P->bf = bf ? 1 : 0; }
     if (total > RO_LDS_LIMIT) return false;
     if (lds_bytes) *lds_bytes = total;
     return true;
@@ -1741,23 +1754,23 @@ static void take_launch_events(hipEvent_t* start, hipEvent_t* stop)
     mgp_tls_launch_events[0] = mgp_tls_launch_events[1] = nullptr;
 }
 
-template <int CN, int CK, bool FD, bool CL, bool CM = false>
+template <int CN, int CK, bool FD, bool CL, bool CM = false, bool WBF = RO_BF16_CHAIN>
 int launch_rollout(double* x, float* G, float* Xd, float* action, double* rewards, const RoParams& P,
                    const MgpFlockParams* p, int B, int K, int N, int T, unsigned long long dimsA, unsigned int dims8,
                    unsigned long long woffA, unsigned long long woffB, int n_layers, int lds, hipStream_t st,
                    const float* image, int image_floats, unsigned long long* carry, int flags, const MgpCollect* cl)
 {
     // (the attribute sticks to the function object of the CURRENT device: cached per (device, kernel), mgp_common.h)
-    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(rollout_kernel<CN, CK, FD, CL, CM>), (size_t)lds) != hipSuccess) return MGP_ELAUNCH;
+    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(rollout_kernel<CN, CK, FD, CL, CM, WBF>), (size_t)lds) != hipSuccess) return MGP_ELAUNCH;
     MgpCollect none = {};
     hipEvent_t ev0, ev1;
     take_launch_events(&ev0, &ev1);
     if (ev0 != nullptr || ev1 != nullptr)
-        hipExtLaunchKernelGGL((rollout_kernel<CN, CK, FD, CL, CM>), dim3(B), dim3(RO_THREADS), lds, st, ev0, ev1, 0, x, G, Xd, action,
+        hipExtLaunchKernelGGL((rollout_kernel<CN, CK, FD, CL, CM, WBF>), dim3(B), dim3(RO_THREADS), lds, st, ev0, ev1, 0, x, G, Xd, action,
                               rewards, P, *p, K, N, T, dimsA, dims8, woffA, woffB, n_layers, image, image_floats, carry, flags,
                               cl ? *cl : none);
     else
-        hipLaunchKernelGGL((rollout_kernel<CN, CK, FD, CL, CM>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K,
+        hipLaunchKernelGGL((rollout_kernel<CN, CK, FD, CL, CM, WBF>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K,
                            N, T, dimsA, dims8, woffA, woffB, n_layers, image, image_floats, carry, flags, cl ? *cl : none);
     return mgp_launch_status();
 }
@@ -1874,8 +1887,7 @@ extern "C" int MGP_RO_IMAGE(const float* const* W, const float* const* b, const 
         P.W[l] = W[l]; P.b[l] = b[l];
     }
     mgp_clear_error();
-    hipLaunchKernelGGL(rollout_image_kernel, dim3(8), dim3(256), 0, static_cast<hipStream_t>(stream), P, K, image,
-                       N > RO_MAXN ? RB_BF : RO_BF16_CHAIN);
+    hipLaunchKernelGGL(rollout_image_kernel, dim3(8), dim3(256), 0, static_cast<hipStream_t>(stream), P, K, image, P.bf != 0);
     return mgp_launch_status();
 }
 
@@ -1962,7 +1974,12 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
     }
 #endif
 #undef RB_LAUNCH
-#define RO_LAUNCH(CN_, CK_, FD_, CL_) launch_rollout<CN_, CK_, FD_, CL_>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags, cl)
+#define RO_LAUNCH_(CN_, CK_, FD_, CL_, WBF_) launch_rollout<CN_, CK_, FD_, CL_, false, WBF_>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags, cl)
+#ifdef MGP_RO_WIDE
+#define RO_LAUNCH(CN_, CK_, FD_, CL_) (P.bf ? RO_LAUNCH_(CN_, CK_, FD_, CL_, RO_BF16_CHAIN) : RO_LAUNCH_(CN_, CK_, FD_, CL_, false))
+#else
+#define RO_LAUNCH(CN_, CK_, FD_, CL_) RO_LAUNCH_(CN_, CK_, FD_, CL_, RO_BF16_CHAIN)
+#endif
     if (cl != nullptr) {               // the data-collection builds (DAGGER rollouts)
 #ifdef MGP_RO_BASE
         if (N == 100 && K == 3 && !fade && n_layers == 3 && dims[1] == 32 && dims[2] == 32 && P.woff[1] == 2 * 64 * RO_WFS + 32 &&
@@ -1992,6 +2009,7 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
 #endif
     return fade ? RO_LAUNCH(0, 0, true, false) : RO_LAUNCH(0, 0, false, false);
 #undef RO_LAUNCH
+#undef RO_LAUNCH_
 }
 }  // namespace
 

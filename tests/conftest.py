@@ -15,6 +15,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The allowance log (check_parity below) describes ONE run of the suite."""
+    try:
+        os.remove(os.path.join(ROOT, 'gpurun_out', 'parity_allowances.jsonl'))
+    except OSError:
+        pass
+
+
 def load_golden(name):
     path = os.path.join(GOLDEN, name if name.endswith('.npz') else name + '.npz')
     with np.load(path) as z:

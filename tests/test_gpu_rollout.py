@@ -101,6 +101,7 @@ CASES = [
     (100, 2, (48,), {'mean_pooling': False}),
     (75, 4, (64, 32, 16), {'n_leaders': 1}),
     (200, 3, (64, 64), {}),
+    (100, 3, (64, 64, 64, 64), {}),        # cfg/hidden_size.cfg [4, 64]: the piece image does not fit -- fp32 fragments in the same build
     # one hidden layer up to 128 wide (cfg/hidden_size.cfg:58): the third build (rollout_w128.hip), eight m-tiles
     (100, 3, (128,), {}),
     (64, 2, (96,), {'mean_pooling': False}),
