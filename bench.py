@@ -1220,9 +1220,11 @@ def main():
         # north_star's "fraction of HBM roofline for the S^k X aggregation" -- measured live with HIP events on the
         # launch stream over rotating input sets larger than the Infinity Cache; algorithmic bytes per SURVEY.md 8(d)
         dense = {
-            "actor_fwd": hbm_block('actor_fwd', "mgp_actor_fwd: actor_fwd_mfma_kernel for N <= 128 (aggregation X.G AND filter/"
-                                   "MLP on fp32 MFMA, fused), actor_fwd_kernel otherwise: 4KN^2 + 4KFN + 4 nA N bytes per "
-                                   "episode", ('actor_fwd_mfma_kernel', 'actor_fwd_kernel')),
+            "actor_fwd": hbm_block('actor_fwd', "mgp_actor_fwd: for N <= 128 actor_fwd_pol_kernel (the reference's policy shape [32, 32] compiled in: "
+                                   "aggregation on 4x4x1 fp32 MFMA, hidden layers on split-bf16 MFMA) or actor_fwd_mfma_kernel (any "
+                                   "widths <= 128, fp32 MFMA), actor_fwd_kernel otherwise: 4KN^2 + 4KFN + 4 nA N bytes per "
+                                   "episode", ('actor_fwd_pol_kernel', 'actor_fwd_mfma_kernel', 'actor_fwd_kernel')
+                                   if hidden == [32, 32] else ('actor_fwd_mfma_kernel', 'actor_fwd_kernel')),
             "agg_fwd": hbm_block('agg_fwd', "mgp_agg_fwd: agg_fwd_mfma4_kernel for N <= 128 (four waves per (episode, tap): a wave "
                                  "streams half the rows of its column block), agg_fwd_kernel otherwise (aggregation "
                                  "X.G alone): 4KN^2 + 8KFN bytes per episode", ('agg_fwd_mfma4_kernel', 'agg_fwd_mfma_kernel', 'agg_fwd_kernel')),

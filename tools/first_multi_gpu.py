@@ -53,6 +53,10 @@ def main():
     W = worlds[-1]
     rec["dagger"] = {}
     for tag, p2p in (("p2p", "1"), ("collective", "0")):
+        if dry and p2p == "0":
+            rec["dagger"][tag] = {"skipped": "the torch.distributed leg captures an RCCL all-reduce in the update graph; on one device "
+                                             "the ranks talk gloo (host), which cannot be captured -- runs on a multi-GPU node only"}
+            continue
         d = run_json([sys.executable, 'bench.py', '--dagger', '--gpus', str(W), '--steps', '200', '--warmup', '20',
                       '--episodes', '128' if dry else '256', '--updates', '1024'], env=dict(share, MGP_P2P=p2p))
         if "updates" in d:
