@@ -16,10 +16,12 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """The allowance log (check_parity below) describes ONE run of the suite."""
+    """The allowance log (check_parity below) describes ONE run of the GPU suite."""
     try:
-        os.remove(os.path.join(ROOT, 'gpurun_out', 'parity_allowances.jsonl'))
-    except OSError:
+        import torch
+        if torch.cuda.is_available():
+            os.remove(os.path.join(ROOT, 'gpurun_out', 'parity_allowances.jsonl'))
+    except (OSError, ImportError):
         pass
 
 
