@@ -367,7 +367,8 @@ class DAGGER(object):
             if str(actor_path).endswith('.npz'):   # weight fixture: keys with '.' spelled '__' (tests/golden/gen_golden.py)
                 import numpy as np
                 with np.load(actor_path) as z:
-                    sd = {k_.replace('__', '.'): torch.from_numpy(z[k_]) for k_ in z.files}
+                    sd = {k_.replace('__', '.'): torch.from_numpy(z[k_]) for k_ in z.files if k_ != 'meta'}   # ('meta': how a
+                    #                                                  policy of tests/golden/policies was trained -- a JSON string)
             else:
                 sd = torch.load(actor_path, map_location)
             own = self.actor.state_dict()

@@ -438,3 +438,31 @@ def test_split_bf16_pieces_carry_an_fp32_product():
         exact = f(w, x)
         bound = 2.0 ** -22 * (np.abs(w.astype(np.float64)) * np.abs(x.astype(np.float64))).sum(axis=1)
         assert np.all(np.abs(six - exact) <= bound)
+
+
+def test_trained_policies_are_data_and_load_by_shape():
+    """tests/golden/policies: one policy per non-headline shape of the reference's sweeps (tools/train_policies.py: this package's
+    DAGGER loop on the reference's schedule), stored as plain arrays in the state_dict layout + a JSON `meta`.  Each loads into an
+    Actor of its shape (bench.load_weights picks it by (environment, K, hidden sizes); DAGGER.load_model reads the same file), and
+    its recorded reward shows a policy that flocks: far from idle agents, within a factor of five of the spec's teacher."""
+    import glob
+    import json
+    import bench
+    from multiagent_gnn_policies_amd.learner import Actor
+    files = sorted(glob.glob(os.path.join(ROOT, 'tests', 'golden', 'policies', 'policy_*.npz')))
+    assert len(files) >= 15
+    envs = {v: k for k, v in bench.ENV_TAGS.items()}
+    for f in files:
+        with np.load(f) as z:
+            meta = json.loads(str(z['meta']))
+            assert all(z[k].dtype == np.float32 for k in z.files if k != 'meta')
+        actor = Actor(6, 2, meta['hidden'], meta['k'], 0)
+        assert bench._load_npz_policy(actor, f)
+        tag = os.path.basename(f).split('_')[1]
+        got = bench.load_weights(Actor(6, 2, meta['hidden'], meta['k'], 0), envs[tag], meta['n_agents'])
+        if not (tag == 'relative' and meta['k'] == 3 and meta['hidden'] == [32, 32]):     # (that shape: the shipped checkpoint)
+            assert os.path.basename(f) in got, (f, got)
+        r = meta['reward_per_episode']
+        assert r['policy'] > 0.25 * r['idle_agents'] and r['policy'] > 5.0 * r['spec_teacher'], (f, r)
+    # a shape nobody trained says so
+    assert bench.load_weights(Actor(6, 2, [16, 16], 5, 0), 'FlockingRelative-v0', 100) == 'default init (seed 11)'
