@@ -315,3 +315,35 @@ def test_fused_sim_state_kernel_equals_two_kernel_protocol(cfg):
     sims[1].step_advance(dev(np.zeros((B, 1, 2, N), np.float32)), st)
     assert float(st.delay_gso[:, 1:].abs().max()) == 0.0 and float(st.delay_state[:, 1:].abs().max()) == 0.0
     assert torch.equal(st.delay_gso[:, 0], torch.eye(N, device='cuda').expand(B, N, N))
+
+
+@pytest.mark.parametrize('hidden', [(8,), (32, 32)])
+def test_tanh_fast_absolute_error(hidden):
+    """The hidden layers evaluate tanh as 1 - 2 / (1 + exp2(2 x log2 e)) on v_exp_f32 / v_rcp_f32 (mgp_device.h::tanh_fast: five
+    instructions, no branches) -- the approximation SURVEY section 7 warns about.  With identity-like weights the fused Actor
+    forward returns tanh_fast(x) itself (one hidden layer of 8: the generic fp32-MFMA chain) or tanh_fast(tanh_fast(x)) (the
+    reference's policy shape [32, 32]: actor_fwd_pol_kernel, whose layers are the resident kernel's ro_layer_bf16 -- a unit
+    weight times x is exact in both forms), so its ABSOLUTE error against np.tanh in fp64 is measured directly, over 20 decades
+    of |x| incl. the saturated ends (exp2 overflows to inf -> rcp 0 -> 1) and signed zeros: <= 3e-7 per evaluation (measured
+    1.2e-7: the parity budget is 1e-5)."""
+    from multiagent_gnn_policies_amd.learner.actor import Actor
+    N, K, B = 128, 1, 8
+    mags = np.concatenate([[0.0], np.logspace(-12, 2.2, B * N // 2 - 3), [88.0, 1e4, 1e38]])
+    xs = np.concatenate([mags, -mags]).astype(np.float32)[:B * N].reshape(B, N)
+    X = np.zeros((B, K, 6, N), dtype=np.float32)
+    X[:, 0, 0] = xs
+    X[:, 0, 1] = xs[:, ::-1]
+    G = np.broadcast_to(np.eye(N, dtype=np.float32), (B, K, N, N)).copy()
+    actor = Actor(6, 2, list(hidden), K, 0).cuda()
+    with torch.no_grad():
+        for conv in actor.conv_layers:
+            conv.weight.zero_(); conv.bias.zero_()
+        for conv in actor.conv_layers:                       # channel 0 -> 0, 1 -> 1 through every layer
+            conv.weight[0, 0, 0, 0] = 1.0; conv.weight[1, 1, 0, 0] = 1.0
+        out = actor(torch.from_numpy(X).cuda(), torch.from_numpy(G).cuda()).cpu().numpy().astype(np.float64)
+    ref0, ref1 = xs.astype(np.float64), xs[:, ::-1].astype(np.float64)
+    for _ in hidden:
+        ref0, ref1 = np.tanh(ref0), np.tanh(ref1)
+    err = max(np.max(np.abs(out[:, 0, 0] - ref0)), np.max(np.abs(out[:, 0, 1] - ref1)))
+    print('tanh_fast through %d hidden layer(s): max abs error %.3g' % (len(hidden), err))
+    assert np.all(np.isfinite(out)) and err <= 3e-7 * len(hidden)
