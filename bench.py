@@ -860,7 +860,10 @@ def dagger_round_bench(args, device, rank, world):
                         "exchange": (fu.dp or "none (single process)"),
                         "exchange_mem_kind": getattr(learner.p2p, 'mem_kind', None),
                         "exchange_bringup": parallel.P2PExchange.last_bringup,
-                        "updates_per_graph": 32},
+                        "updates_per_graph": 32,
+                        # aggregated: mgp_replay_aggregate + mgp_train_step_agg (the K-hop products along the frames' bit rows,
+                        # operator slices never formed); dense: mgp_replay_gather_many / _rows + mgp_train_step_indexed
+                        "slots": "aggregated" if fu.aggregated else "dense"},
             "round_s": t_collect + t_upd,
             "weights_bit_identical_across_ranks": identical,
             "dist": dist_record(),

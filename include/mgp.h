@@ -23,11 +23,13 @@
 extern "C" {
 #endif
 
-#define MGP_VERSION 310            /* 0.2.0: + mgp_rollout_steps_ex / _image / _carry_*, mgp_rollout_collect, mgp_replay_gather;
+#define MGP_VERSION 320            /* 0.2.0: + mgp_rollout_steps_ex / _image / _carry_*, mgp_rollout_collect, mgp_replay_gather;
                                       0.2.1: + mgp_replay_gather_many; mgp_actor_fwd covers layer widths up to 128 at N <= 128;
                                       0.3.0: + mgp_p2p_* (one-shot gradient exchange), mgp_train_step_p2p, mgp_adam_step_filed;
                                       0.3.1: + mgp_rollout_f32ref_* (checker build of the resident kernels); a timed-out exchange
-                                             leaves the weights untouched (mgp_train_step_p2p) */
+                                             leaves the weights untouched (mgp_train_step_p2p);
+                                      0.3.2: + mgp_replay_aggregate, mgp_train_step_agg / _grads_agg / _agg_supported (DAGGER updates on
+                                             the aggregated first-layer input, operator slices never formed) */
 
 #define MGP_OK            0
 #define MGP_EINVAL       -1        /* bad size / null pointer / unsupported combination */
@@ -506,6 +508,36 @@ int  mgp_flock_step_cells_nbr(const double* x, double* x_out, const float* u, lo
 int  mgp_replay_gather_rows(const float* feat, const unsigned long long* bits, const float* wrow, const float* label,
                             const int* age, const long* idx, const int* cursor, int Bt, int nb, int lanes, int ring_steps,
                             int K, int N, float* X, float* G, float* Y, void* stream);
+
+/* ---- DAGGER updates without the dense operator slices -------------------------------------------------------------------
+ * The reference's update (gnn_dagger.py:76-96) evaluates actor(delay_state, delay_gso): actor.py:64-75 multiplies tap k of the
+ * delay line by slice k of delay_gso (K N^2 floats per sample: 12 MB at N = 1000) and concatenates the K results into the
+ * (F K, N) input of the first filter layer.  Parameters are the only leaves, so nothing flows back through that product: the
+ * update needs only its RESULT, and the frame ring holds every factor of every slice as bit rows.
+ *   mgp_replay_aggregate   Z[s, f K + k, n] = (x_{t-k} . A_t A_{t-1} .. A_{t-k+1})[f, n] for nb minibatches of Bt frames (same
+ *                          indexing, history rule -- zero for k > age -- and symmetric-membership requirement as
+ *                          mgp_replay_gather_many / _rows), evaluated left to right as k sparse products along the bit rows,
+ *                          set bits in ascending order; Y = the labels.  Z (nb Bt, 6 K, N), Y (nb Bt, 2, N) fp32.  Rows of Z are
+ *                          in the column order of the first layer's weight (conv_layers.0.weight viewed (out, F K)).
+ *                          wrow: the row weights stored with the frames of the factored path (required for N > 256, where
+ *                          NW = mgp_sparse_words(N) words per bit row); N <= 256: 2 (N <= 128) or 4 words per row, weights
+ *                          (float)(1 / max(deg, 1)) from the row populations (mean_pooling) or 1, wrow ignored.  N <= 2048.
+ *   mgp_train_grads_agg    mgp_train_grads on Z instead of (X, G)
+ *   mgp_train_step_agg     mgp_train_step / _indexed / _p2p on Z: idx, cursor, loss_hist all NULL or all given; comm NULL or
+ *                          the exchange; loss may be NULL
+ *   mgp_train_agg_supported  shapes the two above cover (the dense forms also hold K F N floats of X per tile in LDS; these
+ *                          do not: any N).  Workspace: mgp_train_workspace. */
+int  mgp_replay_aggregate(const float* feat, const unsigned long long* bits, const float* wrow, const float* label,
+                          const int* age, const long* idx, const int* cursor, int Bt, int nb, int lanes, int ring_steps,
+                          int K, int N, int mean_pooling, float* Z, float* Y, void* stream);
+int  mgp_train_agg_supported(const int* dims, int n_layers, int B, int K, int N);
+int  mgp_train_grads_agg(const float* Z, const float* target, const float* const* W, const float* const* b,
+                         const int* dims, int n_layers, float* flat_grad, float* loss, float* workspace, int B, int K, int N,
+                         void* stream);
+int  mgp_train_step_agg(const float* Z, const float* target, const long* idx, int* cursor, float* loss_hist, int hist_cap,
+                        float* flat_param, float* flat_grad, float* m, float* v, const int* dims, int n_layers,
+                        float lr, float beta1, float beta2, float eps, int* step_dev, float* loss, float* workspace,
+                        int B, int K, int N, MgpP2P* comm, void* stream);
 
 #ifdef __cplusplus
 }

@@ -124,6 +124,11 @@ SIGNATURES = {
                                         _vp, _int, _int, _vp]),
     'mgp_sparse_policy_collect': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _int, _int, _int, _int, _int, _vp, _vp]),
     'mgp_replay_gather_rows': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    'mgp_replay_aggregate': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
+    'mgp_train_agg_supported': (_int, [_vp, _int, _int, _int, _int]),
+    'mgp_train_grads_agg': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _int, _int, _vp]),
+    'mgp_train_step_agg': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _int,
+                                  _f32, _f32, _f32, _f32, _vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
     'mgp_train_step': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _f32, _f32, _f32, _f32, _vp,
                               _vp, _vp, _int, _int, _int, _vp]),
 }

@@ -163,7 +163,135 @@ void replay_gather_rows_kernel(const float* __restrict__ feat, const unsigned lo
     for (int n = lane; n < N; n += 64) Gr[n] = r0[n];
 }
 
+// The aggregated first-layer input of a minibatch straight from the frame ring -- the operator slices are never formed:
+//     Z[s, f K + k, n] = (x_{t-k} . A_t A_{t-1} .. A_{t-k+1})[f, n]      (reference actor.py:64-75 on the state of
+//                                                                         state_with_delay.py:44-53; zero for k > age)
+// evaluated left to right as k sparse products along the bit rows (symmetric membership: bit row n is column n),
+// (v . A)[f, n] = sum over the set bits m of row n, ascending, of v[f, m] w[m] -- the power iteration of the rollout kernels
+// (rollout.hip phase A, sparse_policy.hip spl_gather_kernel) on ring frames.  The dense gather above writes K N^2 floats per
+// sample for the update kernel to read back (12 MB at N = 1000, 240 MB per minibatch of 20); this one reads K - 1 bit matrices
+// (128 KB each at N = 1000) and writes 6 K N floats (72 KB).  Row order f K + k = the column order of the first layer's weight.
+// grid (samples, K): workgroup (s, k) owns tap k -- tap 0 copies x_t and the label.
+// LDS: v0, v1 [Np][8] floats (feature vectors per agent, ping-pong) | sw [Np] row weights of the product's network
+constexpr int RA_THREADS = 512;
+
+template <int NWC>                                            // words per bit row: 2 / 4 (N <= 256, weights from the row populations) or 0: NW words, weights stored
+__global__ __launch_bounds__(RA_THREADS)
+void replay_aggregate_kernel(const float* __restrict__ feat, const unsigned long long* __restrict__ bits,
+                             const float* __restrict__ wrow, const float* __restrict__ label, const int* __restrict__ age,
+                             const long* __restrict__ idx, const int* __restrict__ cursor, int Bt, int lanes, int ring_steps,
+                             int K, int N, int NWr, int mean_pooling, float* __restrict__ Z, float* __restrict__ Y)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    const int Np = (N + 3) & ~3;
+    const int NW = NWC ? NWC : NWr;
+    float* v0 = reinterpret_cast<float*>(smraw);
+    float* v1 = v0 + (size_t)Np * 8;
+    float* sw = v1 + (size_t)Np * 8;
+    const int s = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
+    const long cur = cursor != nullptr ? (long)cursor[0] : 0L;
+    const long r = idx[cur * Bt + s];
+    const long ring = (long)ring_steps * lanes;
+    const int a = age[r];
+    float* Zs = Z + (size_t)s * 6 * K * N;
+    if (k == 0) {                                             // tap 0: G_0 = I; and the label
+        for (int e = tid; e < 6 * N; e += RA_THREADS) { const int f = e / N, n = e - f * N; Zs[(size_t)f * K * N + n] = feat[(size_t)r * 6 * N + e]; }
+        for (int e = tid; e < 2 * N; e += RA_THREADS) Y[(size_t)s * 2 * N + e] = label[(size_t)r * 2 * N + e];
+        return;
+    }
+    if (a < k) {                                              // no k-step history yet (reference: zero-filled slices)
+        for (int e = tid; e < 6 * N; e += RA_THREADS) { const int f = e / N, n = e - f * N; Zs[((size_t)f * K + k) * N + n] = 0.f; }
+        return;
+    }
+    {
+        long rk = r - (long)k * lanes; rk = rk < 0 ? rk + ring : rk;
+        for (int e = tid; e < 6 * N; e += RA_THREADS) { const int f = e / N, n = e - f * N; v0[n * 8 + f] = feat[(size_t)rk * 6 * N + e]; }
+    }
+    for (int q = 0; q < k; ++q) {                             // v1 = v0 . A_{t-q}
+        long rq = r - (long)q * lanes; rq = rq < 0 ? rq + ring : rq;
+        const unsigned long long* net = bits + (size_t)rq * N * NW;
+        unsigned long long mine[NWC ? NWC : 1];               // N <= 256 <= threads: the row this thread owns stays in registers
+        if (NWC) {
+            int cnt = 0;
+#pragma unroll
+            for (int wd = 0; wd < NWC; ++wd) { mine[wd] = net[(size_t)min(tid, N - 1) * NWC + wd]; cnt += __popcll(mine[wd]); }
+            const double deg = (double)cnt;
+            if (tid < N) sw[tid] = (float)(mean_pooling ? 1.0 / (deg == 0.0 ? 1.0 : deg) : 1.0);
+        } else {
+            for (int n = tid; n < N; n += RA_THREADS) sw[n] = wrow[(size_t)rq * N + n];
+        }
+        __syncthreads();                                      // v0 and sw complete
+        const bool last = q == k - 1;
+        for (int n = tid; n < N; n += RA_THREADS) {
+            float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            auto walk = [&](unsigned long long w, int wd) {
+                while (w) {
+                    const int m = 64 * wd + __builtin_ctzll(w);
+                    w &= w - 1ull;
+                    const float g = sw[m];
+                    const float4 x0 = *reinterpret_cast<const float4*>(v0 + m * 8);
+                    const float2 x1 = *reinterpret_cast<const float2*>(v0 + m * 8 + 4);
+                    acc[0] = fmaf(x0.x, g, acc[0]); acc[1] = fmaf(x0.y, g, acc[1]); acc[2] = fmaf(x0.z, g, acc[2]);
+                    acc[3] = fmaf(x0.w, g, acc[3]); acc[4] = fmaf(x1.x, g, acc[4]); acc[5] = fmaf(x1.y, g, acc[5]);
+                }
+            };
+            if (NWC) {
+#pragma unroll
+                for (int wd = 0; wd < NWC; ++wd) walk(mine[wd], wd);
+            } else {
+                const unsigned long long* row = net + (size_t)n * NW;
+                for (int wd0 = 0; wd0 < NW; wd0 += 8) {       // eight words requested together
+                    unsigned long long w[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) w[u] = row[min(wd0 + u, NW - 1)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) if (wd0 + u < NW) walk(w[u], wd0 + u);
+                }
+            }
+            if (last) {
+#pragma unroll
+                for (int f = 0; f < 6; ++f) Zs[((size_t)f * K + k) * N + n] = acc[f];
+            } else {
+                *reinterpret_cast<float4*>(v1 + n * 8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                *reinterpret_cast<float2*>(v1 + n * 8 + 4) = make_float2(acc[4], acc[5]);
+            }
+        }
+        if (!last) __syncthreads();                           // v1 complete, sw and v0 free
+        float* t = v0; v0 = v1; v1 = t;
+    }
+}
+
 }  // namespace
+
+extern "C" int mgp_replay_aggregate(const float* feat, const unsigned long long* bits, const float* wrow, const float* label,
+                                    const int* age, const long* idx, const int* cursor, int Bt, int nb, int lanes,
+                                    int ring_steps, int K, int N, int mean_pooling, float* Z, float* Y, void* stream)
+{
+    if (Bt < 0 || nb < 1 || lanes < 1 || ring_steps < 1 || K < 1 || K > 5 || N < 4) return MGP_EINVAL;
+    if (N > 2048) return MGP_EUNSUPPORTED;
+    if (Bt == 0) return MGP_OK;
+    if ((long)Bt * nb > 2147483647L / 64) return MGP_EINVAL;
+    MGP_CHECK_PTR(feat); MGP_CHECK_PTR8(bits); MGP_CHECK_PTR(label); MGP_CHECK_PTR(age); MGP_CHECK_PTR8(idx);
+    MGP_CHECK_PTR(Z); MGP_CHECK_PTR(Y);
+    if (N > 256) MGP_CHECK_PTR(wrow);                         // frames of the factored path carry their row weights
+    if (cursor != nullptr && (reinterpret_cast<uintptr_t>(cursor) & 3u)) return MGP_EALIGN;
+    const int Np = (N + 3) & ~3;
+    const size_t lds = (size_t)Np * (8 + 8 + 1) * sizeof(float);
+    const dim3 grid(Bt * nb, K);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    mgp_clear_error();
+#define MGP_RA_LAUNCH(NWC_, NW_)                                                                                          \
+    do {                                                                                                                  \
+        if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(replay_aggregate_kernel<NWC_>), lds) != hipSuccess) return MGP_ELAUNCH; \
+        hipLaunchKernelGGL(replay_aggregate_kernel<NWC_>, grid, dim3(RA_THREADS), lds, st, feat, bits, wrow, label, age, idx, \
+                           cursor, Bt, lanes, ring_steps, K, N, NW_, mean_pooling, Z, Y);                                 \
+    } while (0)
+    if (N <= 128) MGP_RA_LAUNCH(2, 2);
+    else if (N <= 256) MGP_RA_LAUNCH(4, 4);
+    else MGP_RA_LAUNCH(0, mgp_sparse_words(N));
+#undef MGP_RA_LAUNCH
+    return mgp_launch_status();
+}
 
 extern "C" int mgp_replay_gather_rows(const float* feat, const unsigned long long* bits, const float* wrow,
                                       const float* label, const int* age, const long* idx, const int* cursor, int Bt, int nb,

@@ -128,6 +128,10 @@ __device__ __forceinline__ f32x4 ts_mfma_tile(int kmax, const TsOperand& A, cons
     return acc;
 }
 
+// PRE: X is the AGGREGATED first-layer input Z (B, F K, N), rows in W_0's column order f K + k (mgp_replay_aggregate builds it
+// from the frame ring along the bit rows; G unused): the tile's F K x 16 block goes straight into `acts`, no xs / gs / red areas
+// (LDS: acts | d0 | d1 | wall -- 17 KB for 18-32-32-2, so several workgroups share a CU), no aggregation phase.
+template <bool PRE>
 __global__ __launch_bounds__(TS_THREADS)
 void train_tile_kernel(const float* __restrict__ X, const float* __restrict__ G, const float* __restrict__ target,
                        float* __restrict__ part, TrainParams P, int Pstride, int K, int F, int N, int MP, int MC,
@@ -140,9 +144,9 @@ void train_tile_kernel(const float* __restrict__ X, const float* __restrict__ G,
     const int L = P.n_layers;
     const int nA = P.dims[L];
     float* xs = smem;                                         // [K*F][N]
-    float* gs = xs + (size_t)FK * N;                          // [K][MC][16]   one chunk of G rows, this tile's columns
-    float* red = gs + (size_t)K * MC * TS_COLS;               // [MP][FK][16]
-    float* acts = red + (size_t)MP * FK * TS_COLS;
+    float* gs = xs + (PRE ? (size_t)0 : (size_t)FK * N);      // [K][MC][16]   one chunk of G rows, this tile's columns
+    float* red = gs + (PRE ? (size_t)0 : (size_t)K * MC * TS_COLS);   // [MP][FK][16]
+    float* acts = red + (PRE ? (size_t)0 : (size_t)MP * FK * TS_COLS);
     float* d0 = acts + acts_floats;
     float* d1 = d0 + (size_t)maxw * TS_CS;
     float* wall = d1 + (size_t)maxw * TS_CS;
@@ -155,7 +159,36 @@ void train_tile_kernel(const float* __restrict__ X, const float* __restrict__ G,
 
     // ---- every first-round global read goes out before the first LDS write: G tile (20 per thread), X, parameters
     //      (8 each), the targets -- one exposed memory latency for the whole workgroup
-    {
+    if (PRE) {
+        const int nz = FK * TS_COLS, nw = Pstride - 1;          // F K <= 64: at most four tile elements per thread
+        float rz[4], rw[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = min(q * TS_THREADS + tid, nz - 1), r = e >> TS_CSH, c = e & (TS_COLS - 1);
+            rz[q] = xb[(size_t)r * N + min(n0 + c, N - 1)];
+        }
+        if (P.flat != nullptr) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rw[q] = P.flat[min(q * TS_THREADS + tid, nw - 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = q * TS_THREADS + tid, r = e >> TS_CSH, c = e & (TS_COLS - 1);
+            if (e < nz) acts[r * TS_CS + c] = (n0 + c < N) ? rz[q] : 0.f;
+        }
+        if (P.flat != nullptr) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int i = q * TS_THREADS + tid; if (i < nw) wall[i] = rw[q]; }
+            stage_lds(wall, P.flat, nw, tid, 8 * TS_THREADS);
+        } else {
+            for (int l = 0; l < L; ++l) {
+                const int cin = (l == 0) ? FK : P.dims[l], cout = P.dims[l + 1];
+                stage_lds(wall + P.poff[l], P.W[l], cout * cin, tid);
+                stage_lds(wall + P.poff[l] + cout * cin, P.b[l], cout, tid);
+            }
+        }
+    } else {
         const int mcn = min(MC, N), ne = K * mcn * TS_COLS, nx = FK * N, nw = Pstride - 1;
         float rg[TS_GB], rx[8], rw[8];
 #pragma unroll
@@ -193,6 +226,7 @@ void train_tile_kernel(const float* __restrict__ X, const float* __restrict__ G,
         tgt[rr] = (o < nA && n0 + (tid & 15) < N) ? target[(src * nA + o) * N + n0 + (tid & 15)] : 0.f;
     }
 
+    if (!PRE) {
     // ---- aggregation y[k,f,col] = sum_m X[b,k,f,m] G[b,k,m,n0+col]: thread = (col, tap k, piece mp of the chunk's rows).
     //      Eight accumulators whatever F is (feature index clamped, surplus results dropped): no branch in the row loop.
     const bool agg_on = g < K * MP;
@@ -246,6 +280,7 @@ void train_tile_kernel(const float* __restrict__ X, const float* __restrict__ G,
         acts[r * TS_CS + c] = s;
     }
 
+    }
     // ---- filter + tanh MLP on the 16 columns, on the matrix pipe: out (cout x 16) = W (cout x cin) . in (cin x 16), one
     //      16-row m-tile per wave and trip; the input of every layer stays in LDS for the backward pass
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
@@ -434,7 +469,7 @@ struct TrainPlan {
     int poff[MGP_MAX_LAYERS], ioff[MGP_MAX_LAYERS];
 };
 
-bool make_train_plan(const int* dims, int n_layers, int B, int K, int N, TrainPlan* pl)
+bool make_train_plan(const int* dims, int n_layers, int B, int K, int N, TrainPlan* pl, bool pre = false)
 {
     if (dims == nullptr || n_layers <= 0 || n_layers > MGP_MAX_LAYERS || K <= 0 || K > TS_GROUPS || N <= 0 || B <= 0) return false;
     const int F = dims[0];
@@ -455,17 +490,17 @@ bool make_train_plan(const int* dims, int n_layers, int B, int K, int N, TrainPl
     pl->acts_floats = ioff; pl->maxw = maxw; pl->maxin = maxin; pl->Ptot = poff;
     pl->ntx = (N + TS_COLS - 1) / TS_COLS;
     if ((long)B * pl->ntx > 8192 || B > 65535) return false;             // partials: tiles x (Ptot + 1) floats
-    pl->lds = ((size_t)FK * N + (size_t)K * pl->MC * TS_COLS + (size_t)pl->MP * FK * TS_COLS + ioff + (size_t)2 * maxw * TS_CS
-               + (size_t)poff) * sizeof(float);
+    pl->lds = ((pre ? (size_t)0 : (size_t)FK * N + (size_t)K * pl->MC * TS_COLS + (size_t)pl->MP * FK * TS_COLS) + ioff
+               + (size_t)2 * maxw * TS_CS + (size_t)poff) * sizeof(float);
     return pl->lds <= TS_LDS_LIMIT;
 }
 
 int launch_train(const float* X, const float* G, const float* target, const float* const* W, const float* const* b,
                  const int* dims, int n_layers, float* flat_grad, float* loss, float* workspace, const AdamArgs& A,
-                 int B, int K, int N, hipStream_t st, const long* idx = nullptr, const MgpP2P* comm = nullptr)
+                 int B, int K, int N, hipStream_t st, const long* idx = nullptr, const MgpP2P* comm = nullptr, bool pre = false)
 {
     TrainPlan pl;
-    if (!make_train_plan(dims, n_layers, B, K, N, &pl)) return MGP_EUNSUPPORTED;
+    if (!make_train_plan(dims, n_layers, B, K, N, &pl, pre)) return MGP_EUNSUPPORTED;
     TrainParams P;
     P.n_layers = n_layers;
     for (int i = 0; i <= n_layers; ++i) P.dims[i] = dims[i];
@@ -483,9 +518,15 @@ int launch_train(const float* X, const float* G, const float* target, const floa
     const int Pstride = pl.Ptot + 1;
     const long n_out = (long)B * dims[n_layers] * N;
     mgp_clear_error();
-    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(train_tile_kernel), pl.lds) != hipSuccess) return MGP_ELAUNCH;
-    hipLaunchKernelGGL(train_tile_kernel, dim3(pl.ntx, B), dim3(TS_THREADS), pl.lds, st, X, G, target, workspace, P, Pstride,
-                       K, dims[0], N, pl.MP, pl.MC, pl.acts_floats, pl.maxw, 2.0f / (float)n_out);
+    if (pre) {
+        if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(train_tile_kernel<true>), pl.lds) != hipSuccess) return MGP_ELAUNCH;
+        hipLaunchKernelGGL(train_tile_kernel<true>, dim3(pl.ntx, B), dim3(TS_THREADS), pl.lds, st, X, G, target, workspace, P,
+                           Pstride, K, dims[0], N, pl.MP, pl.MC, pl.acts_floats, pl.maxw, 2.0f / (float)n_out);
+    } else {
+        if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(train_tile_kernel<false>), pl.lds) != hipSuccess) return MGP_ELAUNCH;
+        hipLaunchKernelGGL(train_tile_kernel<false>, dim3(pl.ntx, B), dim3(TS_THREADS), pl.lds, st, X, G, target, workspace, P,
+                           Pstride, K, dims[0], N, pl.MP, pl.MC, pl.acts_floats, pl.maxw, 2.0f / (float)n_out);
+    }
     int rc = mgp_launch_status();
     if (rc != MGP_OK) return rc;
     if (comm != nullptr) {
@@ -512,7 +553,7 @@ extern "C" int mgp_train_supported(const int* dims, int n_layers, int B, int K, 
 extern "C" long mgp_train_workspace(const int* dims, int n_layers, int B, int K, int N)
 {
     TrainPlan pl;
-    if (!make_train_plan(dims, n_layers, B, K, N, &pl)) return 0;
+    if (!make_train_plan(dims, n_layers, B, K, N, &pl) && !make_train_plan(dims, n_layers, B, K, N, &pl, true)) return 0;
     return (long)B * pl.ntx * (pl.Ptot + 1) + 1;                         // + the ticket word of mgp_train_step
 }
 
@@ -532,15 +573,16 @@ extern "C" int mgp_train_grads(const float* X, const float* G, const float* targ
 static int train_step_impl(const float* X, const float* G, const float* target, const long* idx, int* cursor, float* loss_hist,
                            int hist_cap, float* flat_param, float* flat_grad, float* m, float* v, const int* dims,
                            int n_layers, float lr, float beta1, float beta2, float eps, int* step_dev, float* loss,
-                           float* workspace, int B, int K, int N, void* stream, const MgpP2P* comm = nullptr)
+                           float* workspace, int B, int K, int N, void* stream, const MgpP2P* comm = nullptr, bool pre = false)
 {
     if (dims == nullptr) return MGP_EINVAL;
     if (B <= 0 || K <= 0 || N <= 0 || n_layers <= 0 || n_layers > MGP_MAX_LAYERS) return MGP_EINVAL;
-    MGP_CHECK_PTR(X); MGP_CHECK_PTR(G); MGP_CHECK_PTR(target); MGP_CHECK_PTR(flat_param); MGP_CHECK_PTR(flat_grad);
+    MGP_CHECK_PTR(X); MGP_CHECK_PTR(target); MGP_CHECK_PTR(flat_param); MGP_CHECK_PTR(flat_grad);
+    if (!pre) MGP_CHECK_PTR(G);
     MGP_CHECK_PTR(m); MGP_CHECK_PTR(v); MGP_CHECK_PTR(step_dev); MGP_CHECK_PTR(workspace);
     if (loss != nullptr && (reinterpret_cast<uintptr_t>(loss) & 3u)) return MGP_EALIGN;
     TrainPlan pl;
-    if (!make_train_plan(dims, n_layers, B, K, N, &pl)) return MGP_EUNSUPPORTED;
+    if (!make_train_plan(dims, n_layers, B, K, N, &pl, pre)) return MGP_EUNSUPPORTED;
     const float* W[MGP_MAX_LAYERS];
     const float* b[MGP_MAX_LAYERS];
     for (int l = 0; l < n_layers; ++l) {
@@ -551,7 +593,7 @@ static int train_step_impl(const float* X, const float* G, const float* target, 
     int* ticket = reinterpret_cast<int*>(workspace + (size_t)B * pl.ntx * (pl.Ptot + 1));
     AdamArgs A = {flat_param, m, v, step_dev, ticket, lr, beta1, beta2, eps, cursor, loss_hist, hist_cap};
     return launch_train(X, G, target, W, b, dims, n_layers, flat_grad, loss, workspace, A, B, K, N,
-                        static_cast<hipStream_t>(stream), idx, comm);
+                        static_cast<hipStream_t>(stream), idx, comm, pre);
 }
 
 extern "C" int mgp_train_step(const float* X, const float* G, const float* target, float* flat_param, float* flat_grad,
@@ -590,4 +632,44 @@ extern "C" int mgp_train_step_p2p(const float* X, const float* G, const float* t
     }
     return train_step_impl(X, G, target, idx, cursor, loss_hist, hist_cap, flat_param, flat_grad, m, v, dims, n_layers, lr, beta1,
                            beta2, eps, step_dev, loss, workspace, B, K, N, stream, comm);
+}
+
+
+// The same update on the AGGREGATED first-layer input Z (B, F K, N), rows f K + k in W_0's column order -- what
+// mgp_replay_aggregate builds from the frame ring without forming the operator slices (reference gnn_dagger.py:85-93 with
+// actor.py:64-75's aggregation already applied; parameters are the only leaves, so nothing flows back through it).
+extern "C" int mgp_train_agg_supported(const int* dims, int n_layers, int B, int K, int N)
+{
+    TrainPlan pl;
+    return make_train_plan(dims, n_layers, B, K, N, &pl, true) ? 1 : 0;
+}
+
+extern "C" int mgp_train_grads_agg(const float* Z, const float* target, const float* const* W, const float* const* b,
+                                   const int* dims, int n_layers, float* flat_grad, float* loss, float* workspace, int B, int K,
+                                   int N, void* stream)
+{
+    if (dims == nullptr || W == nullptr || b == nullptr) return MGP_EINVAL;
+    if (B <= 0 || K <= 0 || N <= 0 || n_layers <= 0 || n_layers > MGP_MAX_LAYERS) return MGP_EINVAL;
+    MGP_CHECK_PTR(Z); MGP_CHECK_PTR(target); MGP_CHECK_PTR(flat_grad); MGP_CHECK_PTR(workspace);
+    if (loss != nullptr && (reinterpret_cast<uintptr_t>(loss) & 3u)) return MGP_EALIGN;
+    AdamArgs A = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, 0};
+    return launch_train(Z, nullptr, target, W, b, dims, n_layers, flat_grad, loss, workspace, A, B, K, N,
+                        static_cast<hipStream_t>(stream), nullptr, nullptr, true);
+}
+
+// idx / cursor / loss_hist: all NULL (mgp_train_step semantics, loss -> loss[0]) or all given (mgp_train_step_indexed
+// semantics: batch item i reads row idx[cursor[0] * B + i] of Z / target); comm: NULL or the data-parallel exchange
+// (mgp_train_step_p2p semantics).
+extern "C" int mgp_train_step_agg(const float* Z, const float* target, const long* idx, int* cursor, float* loss_hist,
+                                  int hist_cap, float* flat_param, float* flat_grad, float* m, float* v, const int* dims,
+                                  int n_layers, float lr, float beta1, float beta2, float eps, int* step_dev, float* loss,
+                                  float* workspace, int B, int K, int N, MgpP2P* comm, void* stream)
+{
+    const bool indexed = idx != nullptr || cursor != nullptr || loss_hist != nullptr;
+    if (indexed) {
+        if (idx == nullptr || cursor == nullptr || loss_hist == nullptr || hist_cap <= 0) return MGP_EINVAL;
+        if ((reinterpret_cast<uintptr_t>(idx) & 7u) || (reinterpret_cast<uintptr_t>(cursor) & 3u)) return MGP_EALIGN;
+    }
+    return train_step_impl(Z, nullptr, target, idx, cursor, loss_hist, hist_cap, flat_param, flat_grad, m, v, dims, n_layers, lr,
+                           beta1, beta2, eps, step_dev, loss, workspace, B, K, N, stream, comm, true);
 }

@@ -293,10 +293,17 @@ class FrameUpdates(object):
     device-side cursor) and the two launches of mgp_train_step_indexed on the gathered buffers (forward + MSE + backward per
     tile; reduction + Adam, which advances the cursor and files the loss).  The gathers do not depend on the weights: the
     graph of UPDATES_PER_GRAPH updates starts with ONE launch that gathers all of its minibatches (mgp_replay_gather_many,
-    ~1 us per update instead of 9) into UPDATES_PER_GRAPH slots and each update reads its slot."""
+    ~1 us per update instead of 9) into UPDATES_PER_GRAPH slots and each update reads its slot.
 
-    def __init__(self, learner, memory, batch_size, max_updates, mean_pooling):
+    `aggregated` (default wherever mgp_train_agg_supported says so; MGP_FRAME_AGG=0 or aggregated=False selects the dense
+    form): the slots hold the AGGREGATED first-layer input Z (6 K, N) per sample instead of (X, G) -- mgp_replay_aggregate
+    runs the K-hop products along the frames' bit rows, mgp_train_step_agg trains on the result.  Parameters are the only
+    leaves of the reference's update (gnn_dagger.py:85-93), so the product's result is all it needs; the dense slices cost
+    K N^2 floats per sample to write and read back (240 MB per minibatch at N = 1000)."""
+
+    def __init__(self, learner, memory, batch_size, max_updates, mean_pooling, aggregated=None):
         import ctypes
+        import os
         from .. import _lib
         actor, opt = learner.actor, learner.actor_optim
         dev = opt.flat.device
@@ -305,9 +312,18 @@ class FrameUpdates(object):
         self.nl, self.K, self.N, self.B = actor.n_layers, actor.k, learner.n_agents, batch_size
         self.learner, self.memory, self.cap, self.mean_pooling = learner, memory, max_updates, mean_pooling
         L = _lib.lib()
+        can_agg = bool(L.mgp_train_agg_supported(self.cdims, self.nl, batch_size, self.K, self.N)) and self.N <= 2048 and dims[0] == 6
+        if aggregated is None:
+            aggregated = can_agg and os.environ.get('MGP_FRAME_AGG', '1') != '0'
+        assert can_agg or not aggregated
+        self.aggregated = bool(aggregated)
         slots = UPDATES_PER_GRAPH * batch_size                      # one slot of batch_size samples per update of a graph
-        self.X = torch.zeros((slots, self.K, 6, self.N), device=dev)
-        self.G = torch.zeros((slots, self.K, self.N, self.N), device=dev)
+        if self.aggregated:
+            self.Z = torch.zeros((slots, 6 * self.K, self.N), device=dev)
+            self.X = self.G = None
+        else:
+            self.X = torch.zeros((slots, self.K, 6, self.N), device=dev)
+            self.G = torch.zeros((slots, self.K, self.N, self.N), device=dev)
         self.Y = torch.zeros((slots, 1, actor.n_a, self.N), device=dev)
         self.idx = torch.zeros((max_updates + UPDATES_PER_GRAPH, batch_size), device=dev, dtype=torch.long)   # frame indices
         self.ident = torch.arange(batch_size, device=dev, dtype=torch.long).repeat(max_updates, 1).contiguous()
@@ -329,13 +345,52 @@ class FrameUpdates(object):
 
     @staticmethod
     def supported(learner, batch_size, N):
-        return IndexedUpdates.supported(learner, batch_size, N, frames=True)
+        import ctypes
+        import os
+        from .. import _lib
+        if IndexedUpdates.supported(learner, batch_size, N, frames=True):
+            return True
+        # shapes only the aggregated form covers (the dense tile kernel also keeps K F N floats of X in LDS)
+        if not (learner.use_graphed_update and learner.use_train_step) or os.environ.get('MGP_FRAME_AGG', '1') == '0':
+            return False
+        if parallel.is_distributed() and _dp_mode(learner, True) is None:
+            return False
+        dims = tuple(learner.actor.layers)
+        cd = (ctypes.c_int * len(dims))(*dims)
+        return (learner.actor.ind_agg == 0 and dims[0] == 6 and N <= 2048
+                and bool(_lib.lib().mgp_train_agg_supported(cd, learner.actor.n_layers, batch_size, learner.actor.k, N)))
+
+    def _train_agg(self, ident, slot):
+        from .. import _lib, ops
+        L, o = _lib.lib(), self.learner.actor_optim
+        if self.dp == 'rccl':
+            import torch.distributed as dist
+            B, P = self.B, o.flat.numel()
+            lo = slot * B
+            _lib.check(L.mgp_train_grads_agg(ops._ptr(self.Z[lo:lo + B]), ops._ptr(self.Y[lo:lo + B]), self.Wp, self.bp,
+                                             self.cdims, self.nl, ops._ptr(self.xbuf), ops._ptr(self.xbuf[P:]),
+                                             ops._ptr(self.ws), B, self.K, self.N, ops._stream()), 'mgp_train_grads_agg')
+            dist.all_reduce(self.xbuf, op=dist.ReduceOp.SUM)
+            self.xbuf.div_(parallel.world_size())
+            _lib.check(L.mgp_adam_step_filed(ops._ptr(o.flat), ops._ptr(self.xbuf), ops._ptr(o.m), ops._ptr(o.v), P, o.lr,
+                                             o.betas[0], o.betas[1], o.eps, self.step_dev.data_ptr(), ops._ptr(self.xbuf[P:]),
+                                             ops._ptr(self.loss_hist), self.cap, self.cursor.data_ptr(), ops._stream()),
+                       'mgp_adam_step_filed')
+            return
+        comm = self.learner.p2p.handle if self.dp == 'p2p' else None
+        _lib.check(L.mgp_train_step_agg(
+            ops._ptr(self.Z), ops._ptr(self.Y), ident.data_ptr(), self.cursor.data_ptr(), ops._ptr(self.loss_hist), self.cap,
+            ops._ptr(o.flat), ops._ptr(o.flat_grad), ops._ptr(o.m), ops._ptr(o.v), self.cdims, self.nl, o.lr, o.betas[0],
+            o.betas[1], o.eps, self.step_dev.data_ptr(), None, ops._ptr(self.ws), self.B, self.K, self.N, comm,
+            ops._stream()), 'mgp_train_step_agg')
 
     def _train(self, ident, slot=0):
         """One update on the gathered slots: `ident` maps (update cursor, batch item) to a row of X / G / Y; `slot` is the
         slot this update of the captured sequence reads (only the 'rccl' form needs it spelled out)."""
         from .. import _lib, ops
         L, o = _lib.lib(), self.learner.actor_optim
+        if self.aggregated:
+            return self._train_agg(ident, slot)
         if self.dp == 'p2p':
             _lib.check(L.mgp_train_step_p2p(
                 ops._ptr(self.X), ops._ptr(self.G), ops._ptr(self.Y), ident.data_ptr(), self.cursor.data_ptr(),
@@ -369,14 +424,20 @@ class FrameUpdates(object):
         """one update: gather into slot 0, train on it"""
         from .. import ops
         B = self.B
-        ops.replay_gather(self.memory, self.idx, self.X[:B], self.G[:B], self.Y[:B], self.mean_pooling, cursor=self.cursor)
+        if self.aggregated:
+            ops.replay_aggregate(self.memory, self.idx, self.Z[:B], self.Y[:B], self.mean_pooling, cursor=self.cursor)
+        else:
+            ops.replay_gather(self.memory, self.idx, self.X[:B], self.G[:B], self.Y[:B], self.mean_pooling, cursor=self.cursor)
         self._train(self.ident)
 
     def _enqueue_many(self, n):
         """n updates starting at a cursor that is a multiple of n: one gather for all of them, then the n train steps"""
         from .. import ops
         assert n == UPDATES_PER_GRAPH
-        ops.replay_gather(self.memory, self.idx, self.X, self.G, self.Y, self.mean_pooling, cursor=self.cursor, nb=n)
+        if self.aggregated:
+            ops.replay_aggregate(self.memory, self.idx, self.Z, self.Y, self.mean_pooling, cursor=self.cursor, nb=n)
+        else:
+            ops.replay_gather(self.memory, self.idx, self.X, self.G, self.Y, self.mean_pooling, cursor=self.cursor, nb=n)
         for i in range(n):
             self._train(self.ident_many, slot=i)
 

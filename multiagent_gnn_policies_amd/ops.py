@@ -352,6 +352,24 @@ def replay_gather(frames, idx, X, G, Y, mean_pooling, cursor=None, nb=1):
     _lib.check(rc, 'mgp_replay_gather_many')
 
 
+def replay_aggregate(frames, idx, Z, Y, mean_pooling, cursor=None, nb=1):
+    """The aggregated first-layer input of `nb` minibatches straight from the frame ring (mgp_replay_aggregate):
+    Z[s, f K + k] = x_{t-k} . A_t A_{t-1} .. A_{t-k+1} (reference actor.py:64-75 on the frame history, the operator slices never
+    formed), Y = the labels.  Z (nb Bt, 6 K, N), Y (nb Bt, 1, 2, N); idx / cursor as in replay_gather."""
+    _dev(Z, 'Z'); _dev(Y, 'Y'); _dev(idx, 'idx', torch.int64)
+    Bn, FK, N = Z.shape
+    K = frames.K
+    assert FK == 6 * K and Bn % nb == 0 and Z.is_contiguous() and Y.is_contiguous() and Y.numel() == Bn * 2 * N
+    S, lanes = frames.feat.shape[0], frames.feat.shape[1]
+    wrow = getattr(frames, 'wrow', None)
+    if wrow is not None:
+        assert frames.bits.shape[-1] == _lib.lib().mgp_sparse_words(N)
+    rc = _lib.lib().mgp_replay_aggregate(_ptr(frames.feat), _ptr(frames.bits), _ptr(wrow), _ptr(frames.label), _ptr(frames.age),
+                                         _ptr(idx), _ptr(cursor), Bn // nb, nb, lanes, S, K, N, 1 if mean_pooling else 0,
+                                         _ptr(Z), _ptr(Y), _stream())
+    _lib.check(rc, 'mgp_replay_aggregate')
+
+
 def rollout_image(weights, biases, dims, K, N):
     """Weight image of the episode-resident kernel for this policy (MFMA fragment order), built once by a tiny kernel:
     pass it to rollout_steps(image=...) for as long as the weights do not change.  None when the shape is not covered."""

@@ -200,11 +200,17 @@ def scenario_vec(comm, dev, rk, world):
     wa, wb = a.actor_optim.flat.clone(), b.actor_optim.flat.clone()
     assert int(a.actor_optim.step_dev.item()) == U == int(b.actor_optim.step_dev.item())
     err = float((wa - wb).abs().max())
-    assert err <= 1e-7, err
+    # dense slots: the same kernels on the same operands as the one-by-one path.  Aggregated slots (the default): the K-hop
+    # products are summed along the bit rows instead of over the dense slices -- fp32 re-association of the first layer's
+    # input (1e-7 on a gradient entry), carried through U = 70 Adam steps of 1e-3: an entry whose gradient is itself of that
+    # size moves by a fraction of a step either way (measured 6.5e-5 = 0.07 steps on the worst entry of 1,730)
+    assert fu.aggregated == (os.environ.get('MGP_FRAME_AGG', '1') != '0')
+    assert err <= (2e-4 if fu.aggregated else 1e-7), err
     assert abs(loss_a - loss_b) <= 1e-4 * max(1.0, abs(loss_b)), (loss_a, loss_b)
     parts = gather_cpu(wa)
     assert all(torch.equal(parts[0], q) for q in parts[1:]), "weights must be bit-identical on every rank"
-    return {"updates": U, "loss_sum": loss_a, "graph_vs_single_updates_max_weight_diff": err, "bit_identical_paths": err == 0.0}
+    return {"updates": U, "loss_sum": loss_a, "graph_vs_single_updates_max_weight_diff": err, "bit_identical_paths": err == 0.0,
+            "aggregated": fu.aggregated}
 
 
 def main():

@@ -20,6 +20,73 @@ def _bits_dense(bits_row):
     return ((b[:, cols >> 6] >> (cols & 63).astype(np.uint64)) & np.uint64(1)).astype(bool)
 
 
+def _check_aggregate_and_its_update(mem, idx, X, G, Y, K, N, mean_pooling, hidden):
+    """mgp_replay_aggregate against the dense gather of the same frames -- Z[s, f K + k] = X[s, k] . G[s, k] (reference
+    actor.py:64-75), evaluated in fp64 from the gathered fp32 operands: 1e-6 of the row scale, zero taps exactly zero, labels
+    identical -- and the update on it (mgp_train_grads_agg) against the update on (X, G) (mgp_train_grads): loss and every
+    gradient entry to fp32 re-association of the aggregation."""
+    import ctypes
+    from multiagent_gnn_policies_amd import _lib, ops
+    Bt = idx.numel()
+    Z = torch.full((Bt, 6 * K, N), float('nan'), device='cuda')
+    Yz = torch.full((Bt, 1, 2, N), float('nan'), device='cuda')
+    ops.replay_aggregate(mem, idx, Z, Yz, mean_pooling)
+    assert torch.equal(Yz, Y)
+    ref = torch.einsum('skfm,skmn->sfkn', X.double(), G.double()).reshape(Bt, 6 * K, N)
+    scale = ref.abs().amax(dim=2, keepdim=True).clamp_min(1.0)
+    assert float(((Z.double() - ref).abs() / scale).max()) <= 1e-6
+    ages = mem.age.view(-1)[idx]
+    for k in range(K):
+        young = ages < k
+        if bool(young.any()):
+            assert not bool(Z.view(Bt, 6, K, N)[young][:, :, k].any())
+        assert torch.equal(Z.view(Bt, 6, K, N)[:, :, 0], X[:, 0])     # tap 0 is the frame's own feature block
+    # two minibatches in one launch at a device-side cursor == single launches
+    if Bt >= 12:
+        idx2 = torch.cat([idx[:4], idx[7:11], idx[2:6]])
+        Z2 = torch.empty((8, 6 * K, N), device='cuda'); Y2 = torch.empty((8, 1, 2, N), device='cuda')
+        ops.replay_aggregate(mem, idx2, Z2, Y2, mean_pooling, cursor=torch.tensor([1], device='cuda', dtype=torch.int32), nb=2)
+        sel = [7, 8, 9, 10, 2, 3, 4, 5]
+        assert torch.equal(Z2, Z[sel]) and torch.equal(Y2, Y[sel])
+    # the update
+    L = _lib.lib()
+    dims = (6,) + tuple(hidden) + (2,)
+    cd = (ctypes.c_int * len(dims))(*dims)
+    nl = len(dims) - 1
+    Bu = min(Bt, 20)
+    assert L.mgp_train_agg_supported(cd, nl, Bu, K, N)
+    g = torch.Generator(device='cpu'); g.manual_seed(11)
+    Ws, bs = [], []
+    for l in range(nl):
+        cin = dims[0] * K if l == 0 else dims[l]
+        Ws.append((torch.randn((dims[l + 1], cin), generator=g) / np.sqrt(cin)).cuda())
+        bs.append((0.1 * torch.randn((dims[l + 1],), generator=g)).cuda())
+    P = sum(w.numel() + b_.numel() for w, b_ in zip(Ws, bs))
+    wa = (ctypes.c_void_p * nl)(*[w.data_ptr() for w in Ws]); ba = (ctypes.c_void_p * nl)(*[b_.data_ptr() for b_ in bs])
+    ws = torch.zeros((L.mgp_train_workspace(cd, nl, Bu, K, N),), device='cuda')
+    ga, la = torch.zeros((P,), device='cuda'), torch.zeros((1,), device='cuda')
+    _lib.check(L.mgp_train_grads_agg(ops._ptr(Z[:Bu].contiguous()), ops._ptr(Y[:Bu].contiguous()), wa, ba, cd, nl, ops._ptr(ga),
+                                     ops._ptr(la), ops._ptr(ws), Bu, K, N, ops._stream()), 'mgp_train_grads_agg')
+    if L.mgp_train_supported(cd, nl, Bu, K, N):
+        gd, ld = torch.zeros((P,), device='cuda'), torch.zeros((1,), device='cuda')
+        _lib.check(L.mgp_train_grads(ops._ptr(X[:Bu].contiguous()), ops._ptr(G[:Bu].contiguous()), ops._ptr(Y[:Bu].contiguous()), wa, ba,
+                                     cd, nl, ops._ptr(gd), ops._ptr(ld), ops._ptr(ws), Bu, K, N, ops._stream()), 'mgp_train_grads')
+        assert abs(float(la) - float(ld)) <= 1e-6 * max(1.0, abs(float(ld)))
+        assert float((ga - gd).abs().max()) <= 1e-5 * max(1.0, float(gd.abs().max()))   # (measured: <= 6e-6 without mean pooling at K = 4, 5e-7 with)
+    # and against autograd in fp64 on the aggregated input (reference gnn_dagger.py:85-93: mse_loss(actor(state), target))
+    Wd = [w.double().requires_grad_(True) for w in Ws]; bd = [b_.double().requires_grad_(True) for b_ in bs]
+    h = ref[:Bu]
+    for l in range(nl):
+        h = torch.einsum('oc,scn->son', Wd[l], h) + bd[l][None, :, None]
+        if l < nl - 1:
+            h = torch.tanh(h)
+    loss = torch.nn.functional.mse_loss(h, Y[:Bu, 0].double())
+    loss.backward()
+    flat = torch.cat([torch.cat([w.grad.reshape(-1), b_.grad.reshape(-1)]) for w, b_ in zip(Wd, bd)])
+    assert abs(float(la) - float(loss.detach())) <= 1e-5 * max(1.0, float(loss.detach()))
+    assert float((ga.double() - flat).abs().max()) <= 1e-5 * max(1.0, float(flat.abs().max()))
+
+
 def _setup(N, K, hidden, B, variant, ring_capacity):
     from multiagent_gnn_policies_amd.envs import VecFlock
     from multiagent_gnn_policies_amd.learner.vec_dagger import FrameReplay
@@ -139,6 +206,7 @@ def test_collect_chunking_is_bit_identical_and_gather_rebuilds_the_states(N, K, 
         if K > 1:
             assert np.array_equal(Gn[i, 1], Gd[b, 1])            # A_t itself: exact
         assert np.max(np.abs(Gn[i] - Gd[b])) <= 1e-6             # products: fp32 re-association only
+    _check_aggregate_and_its_update(mem, idx, X, G, Y, K, N, op.mean_pooling, hidden)
     # device-side cursor form (what FrameUpdates replays): minibatch 1 of a (2, 4) index table
     tbl = torch.tensor([ids[:4], ids[5:9]], device='cuda', dtype=torch.long)
     X2 = torch.empty((4, K, 6, N), device='cuda'); G2 = torch.empty((4, K, N, N), device='cuda'); Y2 = torch.empty((4, 1, 2, N), device='cuda')
@@ -147,9 +215,11 @@ def test_collect_chunking_is_bit_identical_and_gather_rebuilds_the_states(N, K, 
     assert torch.equal(Y.view(Bt, 2, N), mem.label.view(-1, 2, N)[idx])
 
 
-def test_frame_updates_many_per_graph_equal_one_per_graph():
+@pytest.mark.parametrize('aggregated', [True, False], ids=['aggregated', 'dense'])
+def test_frame_updates_many_per_graph_equal_one_per_graph(aggregated):
     """A round of updates replayed 32-per-graph (device cursor, device step counter) is bit-identical to the same round replayed
-    one update per graph, and to the eager path on gathered minibatches within fp32 rounding."""
+    one update per graph, and to the eager path on gathered minibatches within fp32 rounding -- on the aggregated slots
+    (mgp_replay_aggregate + mgp_train_step_agg, the default) and on the dense ones."""
     import configparser
     import random
     from multiagent_gnn_policies_amd.learner import vec_dagger as vd
@@ -172,7 +242,8 @@ def test_frame_updates_many_per_graph_equal_one_per_graph():
         learner = DAGGER('cuda:0', cp['t'])
         if per_graph:
             vd.UPDATES_PER_GRAPH = per_graph if per_graph < 10 ** 6 else 32
-            fu = vd.FrameUpdates(learner, mem, Bt, U, True)
+            fu = vd.FrameUpdates(learner, mem, Bt, U, True, aggregated=aggregated)
+            assert fu.aggregated == aggregated
             if per_graph == 10 ** 6:                             # one update per replay
                 fu.idx[:U].copy_(torch.tensor(ids)); fu.cursor.zero_()
                 torch.cuda.synchronize()
@@ -324,6 +395,7 @@ def test_sparse_collect_gather_rebuilds_the_states(N, K, hidden, variant):
             assert np.max(np.abs(Gn[i, j] - Gd[b, j])) <= 1e-6 * max(1.0, float(np.max(np.abs(Gd[b, j]))))
             if t < j:
                 assert not Gn[i, j].any()
+    _check_aggregate_and_its_update(mem, idx, X, G, Y, K, N, op.mean_pooling, hidden)
     # two minibatches in one launch at a device-side cursor == two single gathers
     idx2 = torch.tensor(ids[:4] + ids[7:11] + ids[2:6], device='cuda', dtype=torch.long)
     cursor = torch.tensor([1], device='cuda', dtype=torch.int32)
