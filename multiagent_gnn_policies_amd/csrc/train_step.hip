@@ -417,17 +417,19 @@ void train_reduce_kernel(const float* __restrict__ part, int ntiles, int Pstride
     }
     float s = 0.f;
     if (i < Pstride) {
-        // the first TR_BATCH tiles of this group are requested together (the partials come from the other XCDs' tile
-        // workgroups, i.e. from memory: nine dependent round trips otherwise) and added in the same order as before
-        float v[TR_BATCH];
+        // TR_BATCH tiles of this group are requested together (the partials come from the other XCDs' tile workgroups, i.e.
+        // from memory: one dependent round trip per tile otherwise -- 79 of them at B = 20, N = 1000, 23.6 us for this kernel)
+        // and added in ascending tile order, batch after batch
+        for (int t0 = g; t0 < ntiles; t0 += TR_GROUPS * TR_BATCH) {
+            float v[TR_BATCH];
 #pragma unroll
-        for (int q = 0; q < TR_BATCH; ++q) {
-            const int t = g + TR_GROUPS * q;
-            v[q] = part[(size_t)min(t, ntiles - 1) * Pstride + i];
+            for (int q = 0; q < TR_BATCH; ++q) {
+                const int t = t0 + TR_GROUPS * q;
+                v[q] = part[(size_t)min(t, ntiles - 1) * Pstride + i];
+            }
+#pragma unroll
+            for (int q = 0; q < TR_BATCH; ++q) s += (t0 + TR_GROUPS * q < ntiles) ? v[q] : 0.f;
         }
-#pragma unroll
-        for (int q = 0; q < TR_BATCH; ++q) s += (g + TR_GROUPS * q < ntiles) ? v[q] : 0.f;
-        for (int t = g + TR_GROUPS * TR_BATCH; t < ntiles; t += TR_GROUPS) s += part[(size_t)t * Pstride + i];
     }
     sh[g][pl] = s;
     __syncthreads();
