@@ -394,7 +394,9 @@ constexpr int TR_BATCH = 10;               // tiles per group fetched in one bat
 // P2P: data-parallel update -- the entry this thread owns (gradient element or squared error) is exchanged with the other
 // ranks' (p2p_device.h: pushed into every peer's mailbox, the W values added in rank order, / W) between the local
 // reduction and Adam, so the whole data-parallel update stays two launches and every rank applies bit-identical steps.
-template <bool P2P>
+// EPW entries per workgroup (x 1024 / EPW interleaved groups of tiles): 64 for the reference's batch (140 tiles: 28 workgroups);
+// 16 when there are many tiles (B = 20, N = 1000: 1,260 tiles, 8.7 MB of partials -- 109 workgroups instead of 28 pull them in)
+template <bool P2P, int EPW>
 __global__ __launch_bounds__(64 * TR_GROUPS)
 void train_reduce_kernel(const float* __restrict__ part, int ntiles, int Pstride, float* __restrict__ flat_grad,
                          float* __restrict__ loss, float inv_n, AdamArgs A, P2PDev X)
@@ -405,10 +407,11 @@ void train_reduce_kernel(const float* __restrict__ part, int ntiles, int Pstride
         xseq = (unsigned)X.ctl[0] + 1u;                  // would be a wrong, rank-divergent step -- and the host raises at its
         bad = X.ctl[2] != 0;                             // next status check (P2PExchange.check)
     }
-    __shared__ float sh[TR_GROUPS][64];
+    constexpr int NG = 64 * TR_GROUPS / EPW;          // groups of tiles
+    __shared__ float sh[NG][EPW];
     __shared__ float shc[2];
-    const int pl = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + pl;
+    const int pl = threadIdx.x % EPW, g = threadIdx.x / EPW;
+    const int i = blockIdx.x * EPW + pl;
     const int Ptot = Pstride - 1;
     if (A.p != nullptr && threadIdx.x == 64) {          // bias corrections once per workgroup (fp64 pow), off wave 0
         const double step = (double)(*A.step_dev + 1);
@@ -420,15 +423,15 @@ void train_reduce_kernel(const float* __restrict__ part, int ntiles, int Pstride
         // TR_BATCH tiles of this group are requested together (the partials come from the other XCDs' tile workgroups, i.e.
         // from memory: one dependent round trip per tile otherwise -- 79 of them at B = 20, N = 1000, 23.6 us for this kernel)
         // and added in ascending tile order, batch after batch
-        for (int t0 = g; t0 < ntiles; t0 += TR_GROUPS * TR_BATCH) {
+        for (int t0 = g; t0 < ntiles; t0 += NG * TR_BATCH) {
             float v[TR_BATCH];
 #pragma unroll
             for (int q = 0; q < TR_BATCH; ++q) {
-                const int t = t0 + TR_GROUPS * q;
+                const int t = t0 + NG * q;
                 v[q] = part[(size_t)min(t, ntiles - 1) * Pstride + i];
             }
 #pragma unroll
-            for (int q = 0; q < TR_BATCH; ++q) s += (t0 + TR_GROUPS * q < ntiles) ? v[q] : 0.f;
+            for (int q = 0; q < TR_BATCH; ++q) s += (t0 + NG * q < ntiles) ? v[q] : 0.f;
         }
     }
     sh[g][pl] = s;
@@ -436,7 +439,7 @@ void train_reduce_kernel(const float* __restrict__ part, int ntiles, int Pstride
     if (g == 0 && i < Pstride) {
         s = 0.f;
 #pragma unroll
-        for (int q = 0; q < TR_GROUPS; ++q) s += sh[q][pl];
+        for (int q = 0; q < NG; ++q) s += sh[q][pl];
         if (i == Ptot) s *= inv_n;
         if (P2P) s = p2p_exchange_mean(X, i, s, xseq, &bad);
         if (i == Ptot) {
@@ -531,16 +534,25 @@ int launch_train(const float* X, const float* G, const float* target, const floa
     }
     int rc = mgp_launch_status();
     if (rc != MGP_OK) return rc;
+    const bool wide = (long)B * pl.ntx > 512;                 // many tiles: narrower workgroups, more of them (see the kernel)
     if (comm != nullptr) {
         if (!comm->connected || comm->dev.n < Pstride || A.p == nullptr) return MGP_EINVAL;
-        hipLaunchKernelGGL(train_reduce_kernel<true>, dim3((unsigned)((Pstride + 63) / 64)), dim3(64 * TR_GROUPS), 0, st,
-                           workspace, B * pl.ntx, Pstride, flat_grad, loss, (float)(1.0 / (double)n_out), A, comm->dev);
+        if (wide)
+            hipLaunchKernelGGL((train_reduce_kernel<true, 16>), dim3((unsigned)((Pstride + 15) / 16)), dim3(64 * TR_GROUPS), 0, st,
+                               workspace, B * pl.ntx, Pstride, flat_grad, loss, (float)(1.0 / (double)n_out), A, comm->dev);
+        else
+            hipLaunchKernelGGL((train_reduce_kernel<true, 64>), dim3((unsigned)((Pstride + 63) / 64)), dim3(64 * TR_GROUPS), 0, st,
+                               workspace, B * pl.ntx, Pstride, flat_grad, loss, (float)(1.0 / (double)n_out), A, comm->dev);
         return mgp_launch_status();
     }
     P2PDev none;
     memset(&none, 0, sizeof(none));
-    hipLaunchKernelGGL(train_reduce_kernel<false>, dim3((unsigned)((Pstride + 63) / 64)), dim3(64 * TR_GROUPS), 0, st, workspace,
-                       B * pl.ntx, Pstride, flat_grad, loss, (float)(1.0 / (double)n_out), A, none);
+    if (wide)
+        hipLaunchKernelGGL((train_reduce_kernel<false, 16>), dim3((unsigned)((Pstride + 15) / 16)), dim3(64 * TR_GROUPS), 0, st,
+                           workspace, B * pl.ntx, Pstride, flat_grad, loss, (float)(1.0 / (double)n_out), A, none);
+    else
+        hipLaunchKernelGGL((train_reduce_kernel<false, 64>), dim3((unsigned)((Pstride + 63) / 64)), dim3(64 * TR_GROUPS), 0, st,
+                           workspace, B * pl.ntx, Pstride, flat_grad, loss, (float)(1.0 / (double)n_out), A, none);
     return mgp_launch_status();
 }
 
