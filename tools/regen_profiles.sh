@@ -58,6 +58,7 @@ k = {a: (round(v['avg_launch_ms']*1e3,1), round(v['GBps'])) for a, v in d.get('k
 print('$1 x N=$2 K=$3 hidden $4 x $5', 'value %.3e' % d['value'], 'ms/step %.4f' % d['ms_per_step'], 'paths', {a: '%.3e' % b['value'] for a, b in d['paths'].items()}, 'parity', d['parity']['ok'], d['parity']['passed_on'], 'kernels (us, GB/s)', k)
 " >> $O/other_configs.txt; done
 for f in 8 4; do MGP_AGG_FORM=$f python tools/gpu/agg_ab.py 2>/dev/null; done > $O/agg_forms.txt
+bash tools/gpu/update_slots_ab.sh > $O/dagger_update_slots.txt 2>&1
 # 4b. degree sweep on the environment's own (disc) resets: the communication radius sets the mean degree (~ R^2)
 for R_ in 0.83 0.95 1.0 1.05 1.15 1.3; do python bench.py --comm-radius $R_ --no-cpu-baseline --no-roofline --steps 100 --warmup 10 2>/dev/null | python -c "
 import sys, json
