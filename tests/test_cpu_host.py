@@ -349,6 +349,14 @@ def test_coverage_predicates_are_host_side():
     assert not L.mgp_actor_supported(d128x3, 4, 3, 100)            # three 128-wide layers: weights > 160 KB of LDS
     assert L.mgp_train_supported(d128, 2, 20, 3, 100)                  # one-launch update: widths <= 128 too
     assert not L.mgp_train_supported(d128x3, 4, 20, 3, 100)
+    # the update on the aggregated input keeps no X / G tile in LDS: every N, and wider nets at large N than the dense form
+    d128x2 = (ctypes.c_int * 4)(6, 128, 128, 2)
+    for n in (100, 1000, 2048):
+        assert L.mgp_train_agg_supported(d, 3, 20, 3, n)
+    assert L.mgp_train_agg_supported(d128x2, 3, 20, 3, 1000) and not L.mgp_train_supported(d128x2, 3, 20, 3, 1000)
+    assert L.mgp_train_workspace(d128x2, 3, 20, 3, 1000) == 20 * 63 * (18 * 128 + 128 + 128 * 128 + 128 + 2 * 128 + 2 + 1) + 1
+    assert not L.mgp_train_agg_supported(d128x3, 4, 20, 3, 100)    # weights + activations of three 128-wide layers > 150 KB
+    assert not L.mgp_train_agg_supported(d, 3, 20000, 3, 100)
 
 
 def test_beta_schedule_is_the_reference_running_product():
