@@ -19,6 +19,7 @@
 // microseconds of kernel time in the five-launch graph.
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 #include "mgp_common.h"
 #include "p2p_device.h"
 #include "mgp_device.h"
@@ -131,18 +132,28 @@ __device__ __forceinline__ f32x4 ts_mfma_tile(int kmax, const TsOperand& A, cons
 // PRE: X is the AGGREGATED first-layer input Z (B, F K, N), rows in W_0's column order f K + k (mgp_replay_aggregate builds it
 // from the frame ring along the bit rows; G unused): the tile's F K x 16 block goes straight into `acts`, no xs / gs / red areas
 // (LDS: acts | d0 | d1 | wall -- 17 KB for 18-32-32-2, so several workgroups share a CU), no aggregation phase.
-template <bool PRE>
+// CW > 0: the reference's policy shapes compiled in (cfg/dagger.cfg, cfg/k.cfg: F K = CFK inputs, two hidden layers of CW, two outputs) --
+// layer count, widths, LDS offsets and every MFMA tile's k-range are constants, the layer loops are unrolled (the generic form
+// computes clamped operand addresses with run-time strides per load: most of a phase's instructions).
+template <bool PRE, int CW = 0, int CFK = 18>
 __global__ __launch_bounds__(TS_THREADS)
 void train_tile_kernel(const float* __restrict__ X, const float* __restrict__ G, const float* __restrict__ target,
-                       float* __restrict__ part, TrainParams P, int Pstride, int K, int F, int N, int MP, int MC,
-                       int acts_floats, int maxw, float grad_scale)
+                       float* __restrict__ part, TrainParams P, int Pstride_, int K, int F, int N, int MP, int MC,
+                       int acts_floats_, int maxw_, float grad_scale)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr bool CS = CW > 0;
     const int tid = threadIdx.x;
     const int n0 = blockIdx.x * TS_COLS, b = blockIdx.y;
-    const int FK = F * K;
-    const int L = P.n_layers;
-    const int nA = P.dims[L];
+    const int FK = CS ? CFK : F * K;
+    const int L = CS ? 3 : P.n_layers;
+    auto dim_ = [&](int l) -> int { return CS ? (l == 0 ? 6 : (l == 3 ? 2 : CW)) : P.dims[l]; };
+    auto poff_ = [&](int l) -> int { return CS ? (l == 0 ? 0 : (l == 1 ? (CFK + 1) * CW : (CFK + 1) * CW + CW * CW + CW)) : P.poff[l]; };
+    auto ioff_ = [&](int l) -> int { return CS ? (l == 0 ? 0 : (l == 1 ? CFK * TS_CS : (CFK + CW) * TS_CS)) : P.ioff[l]; };
+    const int Pstride = CS ? (CFK + 1) * CW + CW * CW + CW + 2 * CW + 2 + 1 : Pstride_;
+    const int acts_floats = CS ? (CFK + 2 * CW) * TS_CS : acts_floats_;
+    const int maxw = CS ? CW : maxw_;
+    const int nA = dim_(L);
     float* xs = smem;                                         // [K*F][N]
     float* gs = xs + (PRE ? (size_t)0 : (size_t)FK * N);      // [K][MC][16]   one chunk of G rows, this tile's columns
     float* red = gs + (PRE ? (size_t)0 : (size_t)K * MC * TS_COLS);   // [MP][FK][16]
@@ -183,9 +194,9 @@ void train_tile_kernel(const float* __restrict__ X, const float* __restrict__ G,
             stage_lds(wall, P.flat, nw, tid, 8 * TS_THREADS);
         } else {
             for (int l = 0; l < L; ++l) {
-                const int cin = (l == 0) ? FK : P.dims[l], cout = P.dims[l + 1];
-                stage_lds(wall + P.poff[l], P.W[l], cout * cin, tid);
-                stage_lds(wall + P.poff[l] + cout * cin, P.b[l], cout, tid);
+                const int cin = (l == 0) ? FK : dim_(l), cout = dim_(l + 1);
+                stage_lds(wall + poff_(l), P.W[l], cout * cin, tid);
+                stage_lds(wall + poff_(l) + cout * cin, P.b[l], cout, tid);
             }
         }
     } else {
@@ -210,9 +221,9 @@ void train_tile_kernel(const float* __restrict__ X, const float* __restrict__ G,
             stage_lds(wall, P.flat, nw, tid, 8 * TS_THREADS);
         } else {
             for (int l = 0; l < L; ++l) {
-                const int cin = (l == 0) ? FK : P.dims[l], cout = P.dims[l + 1];
-                stage_lds(wall + P.poff[l], P.W[l], cout * cin, tid);
-                stage_lds(wall + P.poff[l] + cout * cin, P.b[l], cout, tid);
+                const int cin = (l == 0) ? FK : dim_(l), cout = dim_(l + 1);
+                stage_lds(wall + poff_(l), P.W[l], cout * cin, tid);
+                stage_lds(wall + poff_(l) + cout * cin, P.b[l], cout, tid);
             }
         }
         stage_lds(xs, xb, nx, tid, 8 * TS_THREADS);
@@ -287,11 +298,11 @@ void train_tile_kernel(const float* __restrict__ X, const float* __restrict__ G,
     float* dcur = d0;
     float* dnext = d1;
     float sq = 0.f;
-    for (int l = 0; l < L; ++l) {
-        const int cin = (l == 0) ? FK : P.dims[l];
-        const int cout = P.dims[l + 1];
-        const float* in = acts + P.ioff[l];
-        const float* wl = wall + P.poff[l];
+    auto forward_layer = [&](const int l) __attribute__((always_inline)) {
+        const int cin = (l == 0) ? FK : dim_(l);
+        const int cout = dim_(l + 1);
+        const float* in = acts + ioff_(l);
+        const float* wl = wall + poff_(l);
         __syncthreads();                                            // inputs complete
         TS_STAMP(3 + l);
         for (int mt = wave; 16 * mt < cout; mt += TS_THREADS / 64) {
@@ -304,7 +315,7 @@ void train_tile_kernel(const float* __restrict__ X, const float* __restrict__ G,
                 const int o = 16 * mt + 4 * lq + rr;
                 if (o < cout) {
                     if (l < L - 1) {
-                        acts[P.ioff[l + 1] + o * TS_CS + li] = tanh_fast(acc[rr]);
+                        acts[ioff_(l + 1) + o * TS_CS + li] = tanh_fast(acc[rr]);
                     } else {
                         // d loss / d pred = 2 (pred - target) / n  (reference F.mse_loss, mean over every element)
                         float d = 0.f;
@@ -315,7 +326,9 @@ void train_tile_kernel(const float* __restrict__ X, const float* __restrict__ G,
                 }
             }
         }
-    }
+    };
+    if (CS) { forward_layer(0); forward_layer(1); forward_layer(2); }
+    else for (int l = 0; l < L; ++l) forward_layer(l);
     // squared-error share of this workgroup (fixed order: wave sums, then the four added pairwise)
     {
         __shared__ float shq[TS_THREADS / 64];
@@ -329,14 +342,14 @@ void train_tile_kernel(const float* __restrict__ X, const float* __restrict__ G,
     // ---- backward, parameters only (ind_agg = 0: nothing flows into X or G -- reference actor.py:64-71 inputs are leaves)
     //      dW (cout x cin) = delta (cout x 16) . in^T (16 x cin) and, for the layer below, W^T (cin x cout) . delta (cout x 16):
     //      16 x 16 tiles dealt to the four waves
-    for (int l = L - 1; l >= 0; --l) {
-        const int cin = (l == 0) ? FK : P.dims[l];
-        const int cout = P.dims[l + 1];
-        const float* in = acts + P.ioff[l];
-        const float* wl = wall + P.poff[l];
+    auto backward_layer = [&](const int l) __attribute__((always_inline)) {
+        const int cin = (l == 0) ? FK : dim_(l);
+        const int cout = dim_(l + 1);
+        const float* in = acts + ioff_(l);
+        const float* wl = wall + poff_(l);
         if (l < L - 1) __syncthreads();                             // dcur complete (the loss block synchronised l = L-1)
         TS_STAMP(9 + (L - 1 - l));
-        float* myl = my + P.poff[l];
+        float* myl = my + poff_(l);
         for (int o = tid; o < cout; o += TS_THREADS) {
             float s = 0.f;
 #pragma unroll
@@ -372,7 +385,9 @@ void train_tile_kernel(const float* __restrict__ X, const float* __restrict__ G,
             }
             float* t = dcur; dcur = dnext; dnext = t;
         }
-    }
+    };
+    if (CS) { backward_layer(2); backward_layer(1); backward_layer(0); }
+    else for (int l = L - 1; l >= 0; --l) backward_layer(l);
     TS_STAMP(14);
 }
 
@@ -413,11 +428,22 @@ void train_reduce_kernel(const float* __restrict__ part, int ntiles, int Pstride
     const int pl = threadIdx.x % EPW, g = threadIdx.x / EPW;
     const int i = blockIdx.x * EPW + pl;
     const int Ptot = Pstride - 1;
-    if (A.p != nullptr && threadIdx.x == 64) {          // bias corrections once per workgroup (fp64 pow), off wave 0
-        const double step = (double)(*A.step_dev + 1);
+    // bias corrections once per workgroup (two fp64 pow: ~0.7 us), by one thread off wave 0 -- computed between the issue of
+    // that wave's partial loads and their first use (in front of them it delayed the wave, and so the barrier, by its length)
+    const bool corr = A.p != nullptr && threadIdx.x == 64;
+    int step_now = 0;
+    if (corr) step_now = *A.step_dev;
+    // the parameter and its moments are requested together with the first partials (they do not depend on the gradient: one
+    // memory round trip less between the reduction and the step)
+    float pp = 0.f, pm = 0.f, pv = 0.f;
+    const bool owner = A.p != nullptr && g == 0 && i < Ptot;
+    if (owner) { pp = A.p[i]; pm = A.m[i]; pv = A.v[i]; }
+    auto bias_corrections = [&]() {
+        const double step = (double)(step_now + 1);
         shc[0] = (float)((double)A.lr / (1.0 - pow((double)A.b1, step)));
         shc[1] = (float)sqrt(1.0 - pow((double)A.b2, step));
-    }
+    };
+    if (corr && g >= ntiles) bias_corrections();        // (fewer tiles than groups: this thread's loop below is empty)
     float s = 0.f;
     if (i < Pstride) {
         // TR_BATCH tiles of this group are requested together (the partials come from the other XCDs' tile workgroups, i.e.
@@ -429,6 +455,11 @@ void train_reduce_kernel(const float* __restrict__ part, int ntiles, int Pstride
             for (int q = 0; q < TR_BATCH; ++q) {
                 const int t = t0 + NG * q;
                 v[q] = part[(size_t)min(t, ntiles - 1) * Pstride + i];
+            }
+            if (corr && t0 == g) {
+                __builtin_amdgcn_sched_barrier(0);
+                bias_corrections();
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int q = 0; q < TR_BATCH; ++q) s += (t0 + NG * q < ntiles) ? v[q] : 0.f;
@@ -449,7 +480,8 @@ void train_reduce_kernel(const float* __restrict__ part, int ntiles, int Pstride
             flat_grad[i] = s;
             if (A.p != nullptr && !bad) {                // torch.optim.Adam defaults, same expressions as mgp_adam_step_dev
                 const float one_m_b1 = (float)(1.0 - (double)A.b1), one_m_b2 = (float)(1.0 - (double)A.b2);
-                mgp_adam_elem(A.p[i], A.m[i], A.v[i], s, one_m_b1, A.b2, one_m_b2, shc[0], shc[1], A.eps);
+                mgp_adam_elem(pp, pm, pv, s, one_m_b1, A.b2, one_m_b2, shc[0], shc[1], A.eps);
+                A.p[i] = pp; A.m[i] = pm; A.v[i] = pv;
             }
         }
     }
@@ -523,7 +555,23 @@ int launch_train(const float* X, const float* G, const float* target, const floa
     const int Pstride = pl.Ptot + 1;
     const long n_out = (long)B * dims[n_layers] * N;
     mgp_clear_error();
-    if (pre) {
+    static const bool no_cs = getenv("MGP_TRAIN_CS") != nullptr && atoi(getenv("MGP_TRAIN_CS")) == 0;      // (A/B switch)
+    const bool cs_shape = pre && !no_cs && n_layers == 3 && dims[0] == 6 && dims[3] == 2 && dims[1] == dims[2] && K >= 1 && K <= 4
+                          && (dims[1] == 32 || (dims[1] == 64 && K == 3));
+#define MGP_TS_CS(CW_, CFK_)                                                                                                      \
+    do {                                                                                                                          \
+        if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(train_tile_kernel<true, CW_, CFK_>), pl.lds) != hipSuccess) return MGP_ELAUNCH; \
+        hipLaunchKernelGGL((train_tile_kernel<true, CW_, CFK_>), dim3(pl.ntx, B), dim3(TS_THREADS), pl.lds, st, X, G, target, workspace, \
+                           P, Pstride, K, dims[0], N, pl.MP, pl.MC, pl.acts_floats, pl.maxw, 2.0f / (float)n_out);               \
+    } while (0)
+    if (cs_shape) {                                           // cfg/dagger.cfg, cfg/k.cfg (K = 1..4), hidden_size 64
+        if (dims[1] == 64) MGP_TS_CS(64, 18);
+        else if (K == 1) MGP_TS_CS(32, 6);
+        else if (K == 2) MGP_TS_CS(32, 12);
+        else if (K == 3) MGP_TS_CS(32, 18);
+        else MGP_TS_CS(32, 24);
+#undef MGP_TS_CS
+    } else if (pre) {
         if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(train_tile_kernel<true>), pl.lds) != hipSuccess) return MGP_ELAUNCH;
         hipLaunchKernelGGL(train_tile_kernel<true>, dim3(pl.ntx, B), dim3(TS_THREADS), pl.lds, st, X, G, target, workspace, P,
                            Pstride, K, dims[0], N, pl.MP, pl.MC, pl.acts_floats, pl.maxw, 2.0f / (float)n_out);

@@ -170,6 +170,58 @@ def test_train_grads_random_configuration(seed):
         first = got.copy()
     assert relerr(got, flat_ref) <= 2e-5, (B, K, F, N, hidden, n_a)
     assert abs(loss.item() - od.mse_loss(ref, target)) <= 1e-5 * max(1.0, od.mse_loss(ref, target))
+    # the same update on the aggregated first-layer input (mgp_train_grads_agg): Z[b, f K + k] = X[b, k, f] . G[b, k]
+    assert L.mgp_train_agg_supported(cd, len(Ws), B, K, N)
+    Z = np.einsum('bkfm,bkmn->bfkn', X.astype(np.float64), G.astype(np.float64)).reshape(B, F * K, N).astype(np.float32)
+    flat_a = torch.full((flat_ref.size,), float('nan'), device='cuda')
+    loss_a = torch.zeros((1,), device='cuda')
+    _lib.check(L.mgp_train_grads_agg(ops._ptr(torch.from_numpy(Z).cuda()), ops._ptr(Td), _ptr_array(Wd), _ptr_array(bd), cd, len(Ws),
+                                     ops._ptr(flat_a), ops._ptr(loss_a), ops._ptr(ws), B, K, N, ops._stream()), 'mgp_train_grads_agg')
+    assert relerr(flat_a.cpu().numpy(), flat_ref) <= 2e-5, (B, K, F, N, hidden, n_a)
+    assert abs(loss_a.item() - od.mse_loss(ref, target)) <= 1e-5 * max(1.0, od.mse_loss(ref, target))
+
+
+@pytest.mark.parametrize('K,hidden', [(1, (32, 32)), (2, (32, 32)), (3, (32, 32)), (4, (32, 32)), (3, (64, 64)), (3, (32, 32, 32)), (3, (16, 16))])
+@pytest.mark.parametrize('B,N', [(20, 100), (3, 37), (20, 1000)])
+def test_train_grads_agg_compiled_policy_shapes(K, hidden, B, N):
+    """mgp_train_grads_agg on the shapes whose tile kernel has the policy compiled in (two hidden layers of 32 at K = 1..4,
+    of 64 at K = 3: train_tile_kernel<true, CW, CFK>) and two generic neighbours, ragged N included, against fp64 autograd of
+    mse_loss(MLP(Z), target) (reference gnn_dagger.py:85-93 behind actor.py:64-75's aggregation); a second call on the
+    same workspace is bit-identical."""
+    import ctypes
+    from multiagent_gnn_policies_amd import _lib, ops
+    from multiagent_gnn_policies_amd.learner.actor_fused import _ptr_array
+    g = torch.Generator().manual_seed(100 * K + N + len(hidden))
+    dims = (6,) + tuple(hidden) + (2,)
+    nl = len(dims) - 1
+    L = _lib.lib()
+    cd = (ctypes.c_int * len(dims))(*dims)
+    assert L.mgp_train_agg_supported(cd, nl, B, K, N)
+    Z = torch.randn((B, 6 * K, N), generator=g)
+    T = torch.randn((B, 2, N), generator=g)
+    Ws = [torch.randn((dims[l + 1], 6 * K if l == 0 else dims[l]), generator=g) / np.sqrt(6 * K if l == 0 else dims[l]) for l in range(nl)]
+    bs = [0.1 * torch.randn((dims[l + 1],), generator=g) for l in range(nl)]
+    Wd = [w.double().requires_grad_(True) for w in Ws]; bd = [b_.double().requires_grad_(True) for b_ in bs]
+    h = Z.double()
+    for l in range(nl):
+        h = torch.einsum('oc,scn->son', Wd[l], h) + bd[l][None, :, None]
+        if l < nl - 1:
+            h = torch.tanh(h)
+    loss_ref = torch.nn.functional.mse_loss(h, T.double())
+    loss_ref.backward()
+    flat_ref = torch.cat([torch.cat([w.grad.reshape(-1), b_.grad.reshape(-1)]) for w, b_ in zip(Wd, bd)]).numpy()
+    Wc = [w.cuda().contiguous() for w in Ws]; bc = [b_.cuda() for b_ in bs]
+    ws = torch.zeros((L.mgp_train_workspace(cd, nl, B, K, N),), device='cuda')
+    Zc, Tc = Z.cuda(), T.cuda()
+    outs = []
+    for rep in range(2):
+        flat = torch.full((flat_ref.size,), float('nan'), device='cuda'); loss = torch.zeros((1,), device='cuda')
+        _lib.check(L.mgp_train_grads_agg(ops._ptr(Zc), ops._ptr(Tc), _ptr_array(Wc), _ptr_array(bc), cd, nl, ops._ptr(flat),
+                                         ops._ptr(loss), ops._ptr(ws), B, K, N, ops._stream()), 'mgp_train_grads_agg')
+        outs.append((flat.cpu().numpy(), float(loss)))
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+    assert relerr(outs[0][0], flat_ref) <= 2e-5
+    assert abs(outs[0][1] - float(loss_ref.detach())) <= 1e-5 * max(1.0, float(loss_ref.detach()))
 
 
 @pytest.mark.parametrize('seed', range(40))
