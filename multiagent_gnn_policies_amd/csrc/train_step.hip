@@ -575,6 +575,11 @@ int launch_train(const float* X, const float* G, const float* target, const floa
         if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(train_tile_kernel<true>), pl.lds) != hipSuccess) return MGP_ELAUNCH;
         hipLaunchKernelGGL(train_tile_kernel<true>, dim3(pl.ntx, B), dim3(TS_THREADS), pl.lds, st, X, G, target, workspace, P,
                            Pstride, K, dims[0], N, pl.MP, pl.MC, pl.acts_floats, pl.maxw, 2.0f / (float)n_out);
+    } else if (!no_cs && n_layers == 3 && dims[0] == 6 && K == 3 && dims[1] == 32 && dims[2] == 32 && dims[3] == 2) {
+        // the dense form (callers that hand over delay_state / delay_gso: the reference's gradient_step signature) at cfg/dagger.cfg
+        if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(train_tile_kernel<false, 32, 18>), pl.lds) != hipSuccess) return MGP_ELAUNCH;
+        hipLaunchKernelGGL((train_tile_kernel<false, 32, 18>), dim3(pl.ntx, B), dim3(TS_THREADS), pl.lds, st, X, G, target, workspace, P,
+                           Pstride, K, dims[0], N, pl.MP, pl.MC, pl.acts_floats, pl.maxw, 2.0f / (float)n_out);
     } else {
         if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(train_tile_kernel<false>), pl.lds) != hipSuccess) return MGP_ELAUNCH;
         hipLaunchKernelGGL(train_tile_kernel<false>, dim3(pl.ntx, B), dim3(TS_THREADS), pl.lds, st, X, G, target, workspace, P,
