@@ -59,6 +59,10 @@ print('$1 x N=$2 K=$3 hidden $4 x $5', 'value %.3e' % d['value'], 'ms/step %.4f'
 " >> $O/other_configs.txt; done
 for f in 8 4; do MGP_AGG_FORM=$f python tools/gpu/agg_ab.py 2>/dev/null; done > $O/agg_forms.txt
 bash tools/gpu/update_slots_ab.sh > $O/dagger_update_slots.txt 2>&1
+{ echo '# tools/harness/train_phase_prof.hip on MI355X: the two-launch DAGGER update, B = 20, 6-32-32-2, K = 3 -- wall time per update (back to back, no graph) and in-kernel'
+  echo '# cycle stamps of workgroup (0,0) of train_tile_kernel.  Blocks: dense (X, G) at N = 100 | aggregated input at N = 100 | the same with the generic'
+  echo '# kernel (MGP_TRAIN_CS=0: run-time widths) | aggregated input at N = 1000'
+  ./scratch/ts_prof 20 100 3 0; ./scratch/ts_prof 20 100 3 1; MGP_TRAIN_CS=0 ./scratch/ts_prof 20 100 3 1; ./scratch/ts_prof 20 1000 3 1; } > $O/train_phase_stamps.txt 2>&1
 # 4b. degree sweep on the environment's own (disc) resets: the communication radius sets the mean degree (~ R^2)
 for R_ in 0.83 0.95 1.0 1.05 1.15 1.3; do python bench.py --comm-radius $R_ --no-cpu-baseline --no-roofline --steps 100 --warmup 10 2>/dev/null | python -c "
 import sys, json
