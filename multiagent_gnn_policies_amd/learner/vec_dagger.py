@@ -110,7 +110,7 @@ def _replay_updates(obj, U):
         obj.graph.replay()
 
 
-def _run_sampled(obj, U, sampler):
+def _run_sampled(obj, U, sampler, batch_sampler=None):
     """U updates whose minibatch indices come from `sampler()` (one list of batch_size indices per call: the reference's
     `random.sample` per update), pipelined: while the GPU replays one graph of UPDATES_PER_GRAPH updates the host draws the
     indices of the next one into a pinned staging buffer and enqueues their upload -- a round of updates costs max(host
@@ -128,7 +128,10 @@ def _run_sampled(obj, U, sampler):
         buf = obj._stage[turn]
         if obj._stage_done[turn] is not None:
             obj._stage_done[turn].synchronize()                   # its previous upload has been consumed
-        buf[:n] = torch.tensor([sampler() for _ in range(n)], dtype=torch.long)
+        if batch_sampler is not None:                         # (n, B) int64 array in one call (sample_batch: same stream, same values)
+            buf[:n] = torch.from_numpy(batch_sampler(n))
+        else:
+            buf[:n] = torch.tensor([sampler() for _ in range(n)], dtype=torch.long)
         obj.idx[done:done + n].copy_(buf[:n], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -140,6 +143,62 @@ def _run_sampled(obj, U, sampler):
         turn ^= 1
     obj.learner.actor_optim.step_count += U
     return obj.loss_hist[:U].sum()
+
+
+def sample_batch(n, k, count):
+    """`count` consecutive draws of random.sample(range(n), k) -- the reference's minibatch sampler (replay_buffer.py:40) -- as one
+    (count, k) int64 array: the SAME values from the SAME stream of Python's global generator, which is left in the state
+    `count` calls of random.sample would leave it in.  A round of updates draws thousands of minibatches; at ~10 us per
+    random.sample call the host was as slow as the GPU's 11.7 us per update.  How: random.sample (n larger than its set-size
+    threshold) is k draws of _randbelow(n) with repeats inside a minibatch rejected, _randbelow is getrandbits(bits(n)) until
+    the value is below n, and getrandbits(b <= 32) is the top b bits of one MT19937 word -- so a block of words fetched at
+    once (getrandbits(32 M): M successive words, little end first) holds every value the calls would see, in order; the block
+    is filtered with numpy, and the generator is rewound and advanced by exactly the number of words the calls would have
+    consumed.  Minibatches with an internal repeat (rare: k^2 / 2n) are finished by the sequential rule on the same stream."""
+    import math
+    setsize = 21 + (4 ** math.ceil(math.log(k * 3, 4)) if k > 5 else 0)
+    if count <= 0 or k <= 0 or n <= setsize or n >= (1 << 32):
+        return np.array([random.sample(range(n), k) for _ in range(count)], dtype=np.int64).reshape(max(count, 0), k)
+    bits = n.bit_length()
+    need = count * k
+    state = random.getstate()
+    M = int(need * ((1 << bits) / n) * 1.05) + 64
+    while True:
+        words = np.frombuffer(random.getrandbits(32 * M).to_bytes(4 * M, 'little'), dtype='<u4')
+        r = words >> np.uint32(32 - bits)
+        ok = np.flatnonzero(r < n)
+        out = None
+        if ok.size >= need:
+            acc = r[ok[:need]].astype(np.int64).reshape(count, k)
+            srt = np.sort(acc, axis=1)
+            dup = np.flatnonzero((srt[:, 1:] == srt[:, :-1]).any(axis=1))
+            if dup.size == 0:
+                out, consumed = acc, int(ok[need - 1]) + 1
+            else:
+                # sequential rule from the first minibatch with a repeat on: accepted values in stream order, repeats skipped
+                g0 = int(dup[0])
+                vals = r[ok].tolist()
+                ptr, rows, short = g0 * k, [], False
+                for _ in range(g0, count):
+                    seen, row = set(), []
+                    while len(row) < k:
+                        if ptr >= len(vals):
+                            short = True
+                            break
+                        v = vals[ptr]; ptr += 1
+                        if v not in seen:
+                            seen.add(v); row.append(v)
+                    if short:
+                        break
+                    rows.append(row)
+                if not short:
+                    out = np.concatenate([acc[:g0], np.array(rows, dtype=np.int64).reshape(-1, k)], axis=0)
+                    consumed = int(ok[ptr - 1]) + 1
+        random.setstate(state)
+        if out is not None:
+            random.getrandbits(32 * consumed)                    # advance by exactly the words the calls would have drawn
+            return out
+        M *= 2
 
 
 class IndexedUpdates(object):
@@ -198,7 +257,9 @@ class IndexedUpdates(object):
         """U updates, indices drawn per update by `sampler` (default: the reference's random.sample over the replay rows),
         host sampling overlapped with the GPU (see _run_sampled)."""
         m = self.memory
-        return _run_sampled(self, U, sampler or (lambda: random.sample(range(m.curr_size), self.B)))
+        if sampler is None:
+            return _run_sampled(self, U, None, batch_sampler=lambda n_: sample_batch(m.curr_size, self.B, n_))
+        return _run_sampled(self, U, sampler)
 
     def run(self, ids):
         """ids: one list of `batch_size` replay rows per update.  Returns the sum of the updates' losses (device tensor)."""
@@ -271,10 +332,19 @@ class FrameReplay(object):
         if self._table_key != key:
             n_valid = min(self.steps_written, self.window_steps)
             steps = (self.head - n_valid + np.arange(n_valid)) % self.ring_steps
-            self._table = (steps[:, None] * self.lanes + np.arange(self.lanes)[None, :]).reshape(-1).tolist()
+            self._table_np = (steps[:, None] * self.lanes + np.arange(self.lanes)[None, :]).reshape(-1).astype(np.int64)
+            self._table = self._table_np.tolist()
             self._table_key = key
         tbl = self._table
         return [tbl[i] for i in random.sample(range(len(tbl)), num_samples)]
+
+    def sample_ids_many(self, num_samples, count):
+        """`count` consecutive sample_ids(num_samples) as one (count, num_samples) int64 array: same values, same generator
+        state afterwards (sample_batch)."""
+        if count > 0:
+            self.sample_ids(0)                                   # (re)builds the position -> frame table; draws nothing
+        pos = sample_batch(len(self._table), num_samples, count)
+        return self._table_np[pos]
 
     def sample(self, num_samples, out, mean_pooling=True):
         """Gather one minibatch into `out` = (X, G, Y) (the eager / data-parallel update path: one small H2D per update)."""
@@ -445,7 +515,9 @@ class FrameUpdates(object):
         """U updates, frame indices drawn per update by `sampler` (default: FrameReplay.sample_ids -- the reference's
         random.sample over the buffer positions), host sampling overlapped with the GPU (see _run_sampled)."""
         m = self.memory
-        return _run_sampled(self, U, sampler or (lambda: m.sample_ids(self.B)))
+        if sampler is None:
+            return _run_sampled(self, U, None, batch_sampler=lambda n_: m.sample_ids_many(self.B, n_))
+        return _run_sampled(self, U, sampler)
 
     def run(self, ids):
         """ids: one list of `batch_size` frame indices per update.  Returns the sum of the updates' losses (device tensor)."""

@@ -474,3 +474,31 @@ def test_trained_policies_are_data_and_load_by_shape():
         assert r['policy'] > 0.25 * r['idle_agents'] and r['policy'] > 5.0 * r['spec_teacher'], (f, r)
     # a shape nobody trained says so
     assert bench.load_weights(Actor(6, 2, [16, 16], 5, 0), 'FlockingRelative-v0', 100) == 'default init (seed 11)'
+
+
+def test_batched_minibatch_sampler_is_random_sample_exactly():
+    """vec_dagger.sample_batch(n, k, count) == [random.sample(range(n), k) for _ in range(count)] (reference
+    replay_buffer.py:40) value for value, and leaves Python's generator in the same state -- for populations above and below
+    random.sample's set-size threshold, populations where most minibatches contain rejected repeats, power-of-two edges, and
+    through FrameReplay.sample_ids_many (position -> frame table, wrapped ring)."""
+    import random
+    import torch
+    from multiagent_gnn_policies_amd.learner.vec_dagger import FrameReplay, sample_batch
+    for n, k, count in [(128000, 20, 32), (128000, 20, 700), (100, 20, 50), (90, 20, 7), (60, 20, 5), (5000, 5, 40),
+                        (2 ** 17, 20, 64), (2 ** 17 + 1, 3, 10), (1000, 1, 5), (300, 20, 200), (64, 20, 3), (50, 0, 2), (50, 5, 0)]:
+        for seed in range(3):
+            random.seed(seed)
+            ref = [random.sample(range(n), k) for _ in range(count)]
+            tail = random.random()
+            random.seed(seed)
+            got = sample_batch(n, k, count)
+            assert got.shape == (count, k) and got.dtype == np.int64 and got.tolist() == ref, (n, k, count, seed)
+            assert random.random() == tail, (n, k, count, seed)
+    mem = FrameReplay(8, 8 * 30, 3, 16, torch.device('cpu'))
+    mem.advance(47)                                              # the ring (30 + 2 guard steps) has wrapped
+    random.seed(5)
+    ref = [mem.sample_ids(20) for _ in range(40)]
+    tail = random.random()
+    random.seed(5)
+    got = mem.sample_ids_many(20, 40)
+    assert got.tolist() == ref and random.random() == tail
