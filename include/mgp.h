@@ -29,7 +29,7 @@ extern "C" {
                                       0.3.1: + mgp_rollout_f32ref_* (checker build of the resident kernels); a timed-out exchange
                                              leaves the weights untouched (mgp_train_step_p2p);
                                       0.3.2: + mgp_replay_aggregate, mgp_train_step_agg / _grads_agg / _agg_supported (DAGGER updates on
-                                             the aggregated first-layer input, operator slices never formed) */
+                                             the aggregated first-layer input, operator slices never formed), mgp_flock_reset_check */
 
 #define MGP_OK            0
 #define MGP_EINVAL       -1        /* bad size / null pointer / unsupported combination */
@@ -323,6 +323,12 @@ long mgp_rollout_carry_bytes(int K, int N);                                     
 /* G[:,j] = A_t A_{t-1} .. A_{t-j+1} for j = 1..K-1 from a carry (slice 0, the identity, is not touched). */
 int mgp_rollout_carry_to_dense(const void* carry, float* G, int B, int K, int N, void* stream);
 
+/* Acceptance statistics of M reset candidates (FLOCK-SPEC v1 section 3; gym_flock's reset loop -- draw until the flock is
+ * connected enough and nobody overlaps -- is host control flow in the reference): pos (M,N,2) fp64 positions ->
+ * min_degree[m] = min over agents of the number of others within the radius, r2_min[m] = smallest squared pair distance,
+ * both exactly what numpy's fp64 evaluation gives (r2 = dx dx + dy dy, unfused).  The caller keeps the RNG stream, the draw
+ * order and the accept rule (envs/flocking.py::sample_initial_states); N <= 8192. */
+int mgp_flock_reset_check(const double* pos, int M, int N, double comm_radius2, int* min_degree, double* r2_min, void* stream);
 /* Expert controller on the current x: u (B,N,2) fp32 and/or u64 (B,N,2) fp64 (either may be NULL). */
 int mgp_flock_controller(const double* x, float* u, double* u64, const MgpFlockParams* p,
                          int centralized, int B, int N, void* stream);

@@ -124,6 +124,7 @@ SIGNATURES = {
                                         _vp, _int, _int, _vp]),
     'mgp_sparse_policy_collect': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _int, _int, _int, _int, _int, _vp, _vp]),
     'mgp_replay_gather_rows': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    'mgp_flock_reset_check': (_int, [_vp, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
     'mgp_replay_aggregate': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
     'mgp_train_agg_supported': (_int, [_vp, _int, _int, _int, _int]),
     'mgp_train_grads_agg': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _int, _int, _vp]),

@@ -462,7 +462,67 @@ int launch_flock(double* x, double* x_out, const float* u, long su_agent, long s
     return launch_step<false, FP_THREADS, FP_ROWS, FP_PIECES>(x, x, u, su_agent, su_axis, os, p, B, N, st);
 }
 
+// Acceptance test of reset candidates (FLOCK-SPEC v1 section 3: an episode starts from the first draw whose minimum degree is
+// >= min_degree and whose closest pair is >= min_dist_thresh apart -- at N = 100 about one draw in 140 passes, and the host's
+// numpy test of one draw, a 100 x 100 fp64 distance matrix, took 130 us: 19 ms per episode reset, 8.4 of the 10.9 s of a whole
+// training run).  One workgroup per candidate: min over rows of |{j != i : r2_ij < R^2}| and min over pairs of r2, with
+// r2 = dx dx + dy dy evaluated exactly as numpy does (two rounded products, one rounded sum: this file is built with
+// -ffp-contract=off), so the host's decision -- deg >= min_degree and sqrt(r2_min) >= thresh -- is the sequential sampler's.
+constexpr int RC_THREADS = 256;
+__global__ __launch_bounds__(RC_THREADS)
+void reset_check_kernel(const double* __restrict__ pos, int N, double R2, int* __restrict__ min_degree, double* __restrict__ r2_min)
+{
+    extern __shared__ __attribute__((aligned(16))) double rcs[];   // px [N] | py [N]
+    __shared__ int sdeg[RC_THREADS / 64];
+    __shared__ double smin[RC_THREADS / 64];
+    double* px = rcs;
+    double* py = rcs + N;
+    const double* pc = pos + (size_t)blockIdx.x * N * 2;
+    for (int i = threadIdx.x; i < N; i += RC_THREADS) { px[i] = pc[2 * i]; py[i] = pc[2 * i + 1]; }
+    __syncthreads();
+    int dmin = 0x7FFFFFFF;
+    double rmin = __builtin_huge_val();
+    for (int i = threadIdx.x; i < N; i += RC_THREADS) {
+        const double xi = px[i], yi = py[i];
+        int deg = 0;
+        for (int j = 0; j < N; ++j) {
+            const double dx = xi - px[j], dy = yi - py[j];
+            const double r2 = dx * dx + dy * dy;
+            if (j != i) {
+                deg += (r2 < R2) ? 1 : 0;
+                rmin = fmin(rmin, r2);
+            }
+        }
+        dmin = min(dmin, deg);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        dmin = min(dmin, __shfl_xor(dmin, o));
+        rmin = fmin(rmin, __shfl_xor(rmin, o));
+    }
+    if ((threadIdx.x & 63) == 0) { sdeg[threadIdx.x >> 6] = dmin; smin[threadIdx.x >> 6] = rmin; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < RC_THREADS / 64; ++w) { dmin = min(dmin, sdeg[w]); rmin = fmin(rmin, smin[w]); }
+        min_degree[blockIdx.x] = dmin;
+        r2_min[blockIdx.x] = rmin;
+    }
+}
+
 }  // namespace
+
+extern "C" int mgp_flock_reset_check(const double* pos, int M, int N, double comm_radius2, int* min_degree, double* r2_min,
+                                     void* stream)
+{
+    if (M < 0 || N < 2 || N > 8192) return MGP_EINVAL;
+    if (M == 0) return MGP_OK;
+    MGP_CHECK_PTR8(pos); MGP_CHECK_PTR(min_degree); MGP_CHECK_PTR8(r2_min);
+    const size_t lds = (size_t)2 * N * sizeof(double);
+    mgp_clear_error();
+    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(reset_check_kernel), lds) != hipSuccess) return MGP_ELAUNCH;
+    hipLaunchKernelGGL(reset_check_kernel, dim3((unsigned)M), dim3(RC_THREADS), lds, static_cast<hipStream_t>(stream), pos, N,
+                       comm_radius2, min_degree, r2_min);
+    return mgp_launch_status();
+}
 
 extern "C" int mgp_flock_step(double* x, double* x_out, const float* u, long su_agent, long su_axis,
                               float* A, double* A64, float* feat, double* feat64,

@@ -502,3 +502,19 @@ def test_batched_minibatch_sampler_is_random_sample_exactly():
     random.seed(5)
     got = mem.sample_ids_many(20, 40)
     assert got.tolist() == ref and random.random() == tail
+
+
+def test_reset_candidates_from_a_block_of_uniforms_are_the_sequential_draws():
+    """envs/flocking.py::_candidates_from_uniforms (the host half of the batched reset sampler: a block of the generator's raw
+    uniforms -> candidates) against _sample_candidate drawn one by one from the same seed: every value identical, the stream
+    consumed identically -- plain, two-flock and leader variants, other speed limits."""
+    from multiagent_gnn_policies_amd.envs import FlockParams, flocking as fl
+    for kw in (dict(n_agents=100), dict(n_agents=100, two_flocks=True), dict(n_agents=37, n_leaders=2),
+               dict(n_agents=64, v_max=1.5, v_bias=0.7, comm_radius=1.3)):
+        p = FlockParams(**kw)
+        r = np.random.RandomState(3)
+        seq = np.stack([fl._sample_candidate(r, p) for _ in range(200)])
+        tail = r.random_sample()
+        r = np.random.RandomState(3)
+        U = r.random_sample((200, 4 * p.n_agents + 2))
+        assert np.array_equal(fl._candidates_from_uniforms(U, p), seq) and r.random_sample() == tail
