@@ -178,6 +178,23 @@ def _candidates_from_uniforms(U, p):
     return x
 
 
+def _candidate_positions(U, p):
+    """The position half of _candidates_from_uniforms: (M, n, 2), contiguous."""
+    n = p.n_agents
+    area = p.r_max * (0.5 if p.two_flocks else 1.0)
+    length = np.sqrt((0 + (p.r_max - 0) * U[:, 0:n]) * (area / p.r_max))
+    angle = np.pi * (0 + (2 - 0) * U[:, n:2 * n])
+    pos = np.empty((U.shape[0], n, 2), dtype=np.float64)
+    pos[:, :, 0] = length * np.cos(angle)
+    pos[:, :, 1] = length * np.sin(angle)
+    if p.two_flocks:
+        half = n // 2
+        shift = np.sqrt(area) + 0.5 * p.comm_radius
+        pos[:, :half, 0] -= shift
+        pos[:, half:, 0] += shift
+    return pos
+
+
 def sample_initial_states(rng, p, B, device, max_tries=100000):
     """B consecutive sample_initial_state(rng, p) draws -- the same states from the same stream, the generator left where B
     sequential calls would leave it -- with the acceptance test of the candidates on the device (mgp_flock_reset_check).
@@ -198,15 +215,15 @@ def sample_initial_states(rng, p, B, device, max_tries=100000):
     while True:
         state = rng.get_state()
         U = rng.random_sample((M, per))
-        x = _candidates_from_uniforms(U, p)
-        pos = torch.from_numpy(np.ascontiguousarray(x[:, :, 0:2])).to(device)
+        pos = torch.from_numpy(_candidate_positions(U, p)).to(device)        # (velocities: only for the accepted rows, below)
         deg = torch.empty((M,), device=device, dtype=torch.int32)
         r2m = torch.empty((M,), device=device, dtype=torch.float64)
         _lib.check(L.mgp_flock_reset_check(pos.data_ptr(), M, n, ctypes.c_double(p.comm_radius2), deg.data_ptr(), r2m.data_ptr(),
                                            ops._stream()), 'mgp_flock_reset_check')
         ok = np.flatnonzero((deg.cpu().numpy() >= p.min_degree) & (np.sqrt(r2m.cpu().numpy()) >= p.min_dist_thresh))
         take = ok[:B - len(out)]
-        out += [x[j] for j in take]
+        if take.size:
+            out += list(_candidates_from_uniforms(U[take], p))
         if len(out) == B:
             used = int(take[-1]) + 1                              # candidates of this block the sequential loop would have drawn
             rng.set_state(state)
