@@ -70,7 +70,7 @@ from multiagent_gnn_policies_amd import build
 print('hash ok', build.source_hash() == json.load(open('profiles/%s_pmc_traffic.json' % R))['_meta']['source_hash'])
 
 for name in ('dagger_round_1rank.json', 'dagger_round_2ranks_shared_gpu.json', 'p2p_exchange_latency.txt', 'rollout_inst_mix.txt',
-             'agg_forms.txt', 'dagger_update_slots.txt', 'train_phase_stamps.txt', 'stream_floor.txt', 'first_multi_gpu_dry.json', 'pmc_traffic_factored.json', 'pmc_hbm_traffic_factored.txt'):
+             'agg_forms.txt', 'dagger_update_slots.txt', 'train_phase_stamps.txt', 'stream_floor.txt', 'train_wall.json', 'train_wall_n200_k4.json', 'first_multi_gpu_dry.json', 'pmc_traffic_factored.json', 'pmc_hbm_traffic_factored.txt'):
     if os.path.exists(O + '/' + name):
         shutil.copy(O + '/' + name, 'profiles/%s_%s' % (R, name))
 

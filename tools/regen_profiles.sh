@@ -60,6 +60,8 @@ print('$1 x N=$2 K=$3 hidden $4 x $5', 'value %.3e' % d['value'], 'ms/step %.4f'
 for f in 8 4; do MGP_AGG_FORM=$f python tools/gpu/agg_ab.py 2>/dev/null; done > $O/agg_forms.txt
 bash tools/gpu/update_slots_ab.sh > $O/dagger_update_slots.txt 2>&1
 ./scratch/stream_floor > $O/stream_floor.txt 2>&1
+python tools/gpu/train_wall.py 2>/dev/null | tail -1 > $O/train_wall.json
+python tools/gpu/train_wall.py --agents 200 --taps 4 2>/dev/null | tail -1 > $O/train_wall_n200_k4.json
 { echo '# tools/harness/train_phase_prof.hip on MI355X: the two-launch DAGGER update, B = 20, 6-32-32-2, K = 3 -- wall time per update (back to back, no graph) and in-kernel'
   echo '# cycle stamps of workgroup (0,0) of train_tile_kernel.  Blocks: dense (X, G) at N = 100 | aggregated input at N = 100 | the same with the generic'
   echo '# kernel (MGP_TRAIN_CS=0: run-time widths) | aggregated input at N = 1000'
