@@ -248,7 +248,7 @@ def policy_episode_rewards(env, learner, device, args, n_episodes):
     up to the closed-loop amplification of fp32 rounding (the summation order of the aggregation differs).
     Any other environment object falls back to the sequential loop."""
     import torch
-    from ..envs.flocking import FlockingRelativeEnv, VecFlock, sample_initial_state
+    from ..envs.flocking import FlockingRelativeEnv, VecFlock
     from .state_with_delay import BatchedDelayState
     raw = getattr(env, 'env', None)
     steps = getattr(env, '_max_episode_steps', None)
@@ -258,7 +258,7 @@ def policy_episode_rewards(env, learner, device, args, n_episodes):
         return [policy_episode_reward(env, learner, device, args) for _ in range(n_episodes)]
     p = raw.params
     sim = VecFlock(n_episodes, p, device)
-    sim.set_state(np.stack([sample_initial_state(raw._rng, p) for _ in range(n_episodes)]))
+    sim.reset(raw._rng)                                          # the sequential sampler's states (sample_initial_states)
     state = BatchedDelayState(device, n_episodes, learner.actor.k, learner.n_states, p.n_agents)
     state.push(sim.network, sim.features)
     per_step = torch.zeros((n_episodes, steps), device=sim.device, dtype=torch.float64)
