@@ -54,7 +54,6 @@ def py_only():
 
 state, sim = plan.state, plan.sim
 rw = ro._rws[T]
-import ctypes
 fn = L.mgp_rollout_steps_ex
 flags = ops.RO_ENTER_CARRY | ops.RO_EXIT_CARRY | ops.RO_SKIP_DENSE
 a = (sim.x.data_ptr(), state._G[state._cur].data_ptr(), state._X[state._cur].data_ptr(), None, None, plan._cd, plan._nl, None,
