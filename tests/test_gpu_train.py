@@ -534,3 +534,34 @@ def test_batched_reset_sampler_is_the_sequential_one(kw, B):
     sim = VecFlock(B, p, 'cuda')
     sim.reset(np.random)
     assert np.array_equal(sim.x.cpu().numpy(), seq) and np.random.random_sample() == tail
+
+
+@pytest.mark.parametrize('N', [2, 3, 17, 100, 257, 1000])
+def test_reset_check_statistics_equal_numpy(N):
+    """mgp_flock_reset_check against the numpy evaluation of the spec's acceptance statistics (envs/flocking.py::_candidate_ok):
+    min over agents of |{j != i : r2_ij < R^2}| and min over pairs of r2, with r2 = dx dx + dy dy unfused -- bit-equal, on
+    random candidates, candidates with coincident agents (r2 = 0), pairs exactly at the radius, and M = 0."""
+    import ctypes
+    from multiagent_gnn_policies_amd import _lib, ops
+    L = _lib.lib()
+    rs = np.random.RandomState(N)
+    M = 37
+    pos = rs.uniform(-3.0, 3.0, size=(M, N, 2))
+    pos[1, N - 1] = pos[1, 0]                                     # coincident agents
+    pos[2, 0] = (0.0, 0.0); pos[2, 1] = (0.6, 0.8)                # r2 = 1 up to rounding: the strict inequality decides
+    R2 = 1.0
+    d = pos[:, :, None, :] - pos[:, None, :, :]
+    r2 = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]
+    idx = np.arange(N)
+    r2[:, idx, idx] = np.inf
+    deg_ref = (r2 < R2).sum(axis=2).min(axis=1)
+    r2_ref = r2.reshape(M, -1).min(axis=1)
+    pd = torch.from_numpy(pos).cuda()
+    deg = torch.full((M,), -7, device='cuda', dtype=torch.int32)
+    r2m = torch.full((M,), float('nan'), device='cuda', dtype=torch.float64)
+    _lib.check(L.mgp_flock_reset_check(pd.data_ptr(), M, N, ctypes.c_double(R2), deg.data_ptr(), r2m.data_ptr(), ops._stream()),
+               'mgp_flock_reset_check')
+    assert np.array_equal(deg.cpu().numpy(), deg_ref) and np.array_equal(r2m.cpu().numpy(), r2_ref)
+    assert r2_ref[1] == 0.0
+    assert L.mgp_flock_reset_check(pd.data_ptr(), 0, N, ctypes.c_double(R2), deg.data_ptr(), r2m.data_ptr(), ops._stream()) == 0
+    assert L.mgp_flock_reset_check(pd.data_ptr(), M, 1, ctypes.c_double(R2), deg.data_ptr(), r2m.data_ptr(), ops._stream()) != 0
