@@ -18,7 +18,7 @@ import torch
 
 from .. import parallel
 from ..envs import FlockParams, VecFlock
-from ..envs.flocking import _REGISTRY
+from ..envs.flocking import _REGISTRY, sample_initial_states, use_grid
 from .rollouts import policy_rollout
 from .gnn_dagger import DAGGER, BetaSchedule
 from .state_with_delay import BatchedDelayState
@@ -112,35 +112,37 @@ def _replay_updates(obj, U):
 
 def _run_sampled(obj, U, sampler, batch_sampler=None):
     """U updates whose minibatch indices come from `sampler()` (one list of batch_size indices per call: the reference's
-    `random.sample` per update), pipelined: while the GPU replays one graph of UPDATES_PER_GRAPH updates the host draws the
-    indices of the next one into a pinned staging buffer and enqueues their upload -- a round of updates costs max(host
-    sampling, GPU) per update instead of their sum.  Returns the sum of the losses (device tensor)."""
+    `random.sample` per update) or `batch_sampler(n)` ((n, batch_size) int64 array: the same draws, sample_batch), pipelined:
+    the host draws the indices of a graph of UPDATES_PER_GRAPH updates into its own rows of a pinned staging table, enqueues
+    their upload and the graph's replay, and goes on to the next graph without waiting for anything -- every graph has its own
+    staging rows, so the host is through the whole round (about 1.5 us per update) long before the GPU is, and whatever it
+    does next (train_dagger_vec: drawing the next round's reset states) runs under the GPU's updates.  Returns the sum of
+    the losses (device tensor; reading it is the caller's synchronisation point)."""
     assert 0 < U <= obj.cap
     assert obj.idx.shape[0] >= min(obj.cap, U) and obj.idx.shape[1] == obj.B
-    if getattr(obj, '_stage', None) is None:
-        obj._stage = [torch.empty((UPDATES_PER_GRAPH, obj.B), dtype=torch.long).pin_memory() for _ in range(2)]
-        obj._stage_done = [None, None]
+    rows = ((obj.cap + UPDATES_PER_GRAPH - 1) // UPDATES_PER_GRAPH) * UPDATES_PER_GRAPH
+    if getattr(obj, '_stage', None) is None or obj._stage.shape[0] < rows:
+        obj._stage = torch.empty((rows, obj.B), dtype=torch.long).pin_memory()
+        obj._stage_done = None
+    if obj._stage_done is not None:
+        obj._stage_done.synchronize()                             # the previous round's uploads have left the staging table
     obj.cursor.zero_()
     _replay_updates(obj, 0)                                       # make sure both graphs exist
-    done, turn = 0, 0
+    done = 0
     while done < U:
         n = min(UPDATES_PER_GRAPH, U - done)
-        buf = obj._stage[turn]
-        if obj._stage_done[turn] is not None:
-            obj._stage_done[turn].synchronize()                   # its previous upload has been consumed
-        if batch_sampler is not None:                         # (n, B) int64 array in one call (sample_batch: same stream, same values)
-            buf[:n] = torch.from_numpy(batch_sampler(n))
+        buf = obj._stage[done:done + n]
+        if batch_sampler is not None:                             # (n, B) int64 array in one call (sample_batch: same stream, same values)
+            buf.copy_(torch.from_numpy(batch_sampler(n)))
         else:
-            buf[:n] = torch.tensor([sampler() for _ in range(n)], dtype=torch.long)
-        obj.idx[done:done + n].copy_(buf[:n], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        obj._stage_done[turn] = ev
+            buf.copy_(torch.tensor([sampler() for _ in range(n)], dtype=torch.long))
+        obj.idx[done:done + n].copy_(buf, non_blocking=True)
         # a graph of UPDATES_PER_GRAPH updates maps update c to gather slot c % UPDATES_PER_GRAPH: it must start on a multiple
         assert done % UPDATES_PER_GRAPH == 0
         _replay_updates(obj, n)
         done += n
-        turn ^= 1
+    obj._stage_done = torch.cuda.Event()
+    obj._stage_done.record()
     obj.learner.actor_optim.step_count += U
     return obj.loss_hist[:U].sum()
 
@@ -586,14 +588,18 @@ def collect_supported(learner, K, N, params=None):
     return ops.rollout_supported(tuple(learner.actor.layers), K, N)
 
 
-def collect_round(learner, sim, state, memory, beta, episode_ids, seed, T, chunk=None):
+def collect_round(learner, sim, state, memory, beta, episode_ids, seed, T, chunk=None, x0=None):
     """One lock-step round of DAGGER data collection ON THE DEVICE (reference gnn_dagger.py:150-178 for every lane): reset,
     then T steps inside mgp_rollout_collect launches -- policy forward, expert label, beta coin, simulator step, state
     transition and the filing of every visited state into the frame ring all happen in the kernel; the host draws the reset
-    states and launches.  `beta` (n_envs,) float32 and `episode_ids` (n_envs,) int32 on the device."""
+    states (or is handed them: `x0` (n_envs, N, 4), drawn ahead from the same generator) and launches.  `beta` (n_envs,)
+    float32 and `episode_ids` (n_envs,) int32 on the device."""
     from .. import ops
     from .rollouts import _actor_params
-    sim.reset(np.random)
+    if x0 is None:
+        sim.reset(np.random)
+    else:
+        sim.set_state(x0)                                       # reset states drawn ahead (train_dagger_vec): the same draws, earlier
     state.reset()
     state.push(sim.network, sim.features)                      # reset observation: all-zero operator history (carry)
     if sim.N > 256:
@@ -665,12 +671,14 @@ def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
     rounds = (n_train_episodes + n_envs * world - 1) // (n_envs * world)
     updates = 0
     indexed = None
+    next_x0, side = None, None
     for rd in range(rounds):
         e0 = (rd * world + rank) * n_envs
         beta = np.array([beta_of(e) for e in range(e0, e0 + n_envs)], dtype=np.float64)   # reference schedule per global episode
         if on_device:
             collect_round(learner, sim, state, memory, torch.tensor(beta, dtype=torch.float32, device=device),
-                          torch.arange(e0, e0 + n_envs, dtype=torch.int32, device=device), seed, T)
+                          torch.arange(e0, e0 + n_envs, dtype=torch.int32, device=device), seed, T, x0=next_x0)
+            next_x0 = None
         else:
             sim.reset(np.random)
             state.reset()
@@ -693,7 +701,16 @@ def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
                 indexed = (FrameUpdates(learner, memory, batch_size, n_updates, p.mean_pooling) if on_device
                            else IndexedUpdates(learner, memory, batch_size, n_updates))
             learner.begin_updates()                                     # data parallel: ranks aligned before the exchanges
-            loss_sum = float(indexed.run_sampled(n_updates).item())     # random.sample per update, overlapped with the GPU
+            loss_dev = indexed.run_sampled(n_updates)                   # random.sample per update; enqueued, not waited for
+            if on_device and rd + 1 < rounds and not use_grid(p):
+                # the next round's reset states, drawn while the GPU runs this round's updates: the rejection sampler costs
+                # ~1 ms of host time per disc reset (MT19937 + libm for ~140 candidates), nothing between here and the next
+                # collect_round draws from numpy's generator, and the acceptance launches go to a stream of their own
+                if side is None:
+                    side = torch.cuda.Stream(device)
+                with torch.cuda.stream(side):
+                    next_x0 = sample_initial_states(np.random, p, n_envs, device)
+            loss_sum = float(loss_dev.item())
             learner.end_updates()
             updates += n_updates
         elif n_updates > 0 and memory.curr_size > batch_size:

@@ -43,7 +43,7 @@ def main():
     cp['t'] = {}
     dev = torch.device('cuda:0')
     torch.zeros(1, device=dev)
-    spent = {'collect_round (host reset sampling + collection launches)': 0.0, 'update rounds': 0.0, 'test episodes': 0.0}
+    spent = {'collect_round (host reset sampling + collection launches)': 0.0, 'update rounds': 0.0, 'test episodes': 0.0}   # 'update rounds' include the next round's reset sampling, drawn under them
     counts = {'rounds': 0, 'updates': 0}
 
     def timed(fn, key, sync=True):
@@ -58,17 +58,26 @@ def main():
         return wrapped
     vd.collect_round = timed(vd.collect_round, 'collect_round (host reset sampling + collection launches)')
     vd.evaluate = timed(vd.evaluate, 'test episodes')
+    # an update round = from the entry of FrameUpdates.run_sampled to the learner's end_updates() behind the loss read-out: the
+    # host enqueues the round, draws the NEXT round's reset states while the GPU works (train_dagger_vec), then reads the loss
     orig_run = vd.FrameUpdates.run_sampled
+    t_round = [None]
 
     def run_sampled(self, U, sampler=None):
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        out = orig_run(self, U, sampler)
-        torch.cuda.synchronize()
-        spent['update rounds'] += time.perf_counter() - t0
+        t_round[0] = time.perf_counter()
         counts['rounds'] += 1; counts['updates'] += U
-        return out
+        return orig_run(self, U, sampler)
     vd.FrameUpdates.run_sampled = run_sampled
+    orig_end = vd.DAGGER.end_updates
+
+    def end_updates(self):
+        if t_round[0] is not None:
+            torch.cuda.synchronize()
+            spent['update rounds'] += time.perf_counter() - t_round[0]
+            t_round[0] = None
+        return orig_end(self)
+    vd.DAGGER.end_updates = end_updates
     random.seed(11); np.random.seed(11); torch.manual_seed(11)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -84,6 +93,7 @@ def main():
                      "batch_size": 20, "lr": a.lr, "episodes_side_by_side": a.n_envs, "test_episodes": 20},
         "wall_s": wall,
         "wall_s_by_part": spent,
+        "note_parts": "update rounds: enqueue + the next round's reset states drawn on the host while the GPU runs the updates + loss read-out",
         "wall_s_unaccounted": wall - sum(spent.values()),
         "rounds": counts['rounds'], "updates": counts['updates'],
         "us_per_update_incl_round_overheads": 1e6 * spent['update rounds'] / max(counts['updates'], 1),
