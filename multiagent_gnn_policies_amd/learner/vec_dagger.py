@@ -672,6 +672,8 @@ def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
     updates = 0
     indexed = None
     next_x0, side = None, None
+    import os
+    prefetch_resets = os.environ.get('MGP_PREFETCH_RESETS', '1') != '0'        # (0: every round draws its resets when it starts)
     for rd in range(rounds):
         e0 = (rd * world + rank) * n_envs
         beta = np.array([beta_of(e) for e in range(e0, e0 + n_envs)], dtype=np.float64)   # reference schedule per global episode
@@ -702,7 +704,7 @@ def train_dagger_vec(args, device, n_envs=64, episode_steps=None):
                            else IndexedUpdates(learner, memory, batch_size, n_updates))
             learner.begin_updates()                                     # data parallel: ranks aligned before the exchanges
             loss_dev = indexed.run_sampled(n_updates)                   # random.sample per update; enqueued, not waited for
-            if on_device and rd + 1 < rounds and not use_grid(p):
+            if on_device and rd + 1 < rounds and not use_grid(p) and prefetch_resets:
                 # the next round's reset states, drawn while the GPU runs this round's updates: the rejection sampler costs
                 # ~1 ms of host time per disc reset (MT19937 + libm for ~140 candidates), nothing between here and the next
                 # collect_round draws from numpy's generator, and the acceptance launches go to a stream of their own

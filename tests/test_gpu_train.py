@@ -565,3 +565,25 @@ def test_reset_check_statistics_equal_numpy(N):
     assert r2_ref[1] == 0.0
     assert L.mgp_flock_reset_check(pd.data_ptr(), 0, N, ctypes.c_double(R2), deg.data_ptr(), r2m.data_ptr(), ops._stream()) == 0
     assert L.mgp_flock_reset_check(pd.data_ptr(), M, 1, ctypes.c_double(R2), deg.data_ptr(), r2m.data_ptr(), ops._stream()) != 0
+
+
+def test_resets_drawn_under_the_updates_leave_the_run_unchanged(monkeypatch):
+    """train_dagger_vec draws the next round's reset states while the GPU runs the current round's updates (disc resets).  The
+    same run with MGP_PREFETCH_RESETS=0 -- every round draws its resets when it starts -- must end with the same weights bit
+    for bit, the same test statistics, and numpy's / Python's generators in the same state."""
+    import random
+    from multiagent_gnn_policies_amd.learner.vec_dagger import train_dagger_vec
+    cp = configparser.ConfigParser()
+    cp['DEFAULT'] = dict(alg='dagger_vec', batch_size='20', buffer_size='2000', updates_per_step='3', seed='1', actor_lr='1e-3',
+                         n_train_episodes='24', beta_coeff='0.993', test_interval='40', n_test_episodes='4', k='3',
+                         hidden_size='32', gamma='0.99', tau='0.5', env='FlockingRelative-v0', v_max='3.0', comm_radius='1.0',
+                         n_agents='60', n_actions='2', n_states='6', debug='False', dt='0.01', init_mode='disc')
+    cp['t'] = {}
+    outs = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('MGP_PREFETCH_RESETS', flag)
+        random.seed(2); np.random.seed(2); torch.manual_seed(2)
+        st = train_dagger_vec(cp['t'], 'cuda:0', n_envs=8, episode_steps=30)
+        outs.append((st['learner'].actor_optim.flat.clone(), st['mean'], st['std'], st['updates'], np.random.random_sample(),
+                     random.random()))
+    assert outs[0][3] == 3 * 3 * 8 and torch.equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:]
