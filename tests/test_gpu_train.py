@@ -587,3 +587,18 @@ def test_resets_drawn_under_the_updates_leave_the_run_unchanged(monkeypatch):
         outs.append((st['learner'].actor_optim.flat.clone(), st['mean'], st['std'], st['updates'], np.random.random_sample(),
                      random.random()))
     assert outs[0][3] == 3 * 3 * 8 and torch.equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:]
+
+
+def test_train_py_jobs_runs_sections_side_by_side_with_the_sequential_output():
+    """`python train.py <cfg> --jobs 3`: the three sections of cfg/smoke_vec_sweep.cfg as three worker processes on the one GPU --
+    the printed lines (header, then `section, mean, std` in file order) are those of the sequential run, digit for digit
+    (every section seeds its own streams: reference train.py:24-28)."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    outs = []
+    for extra in ([], ['--jobs', '3']):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'train.py'), 'cfg/smoke_vec_sweep.cfg'] + extra, cwd=ROOT, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append([l for l in r.stdout.strip().splitlines() if l.strip()])
+    assert outs[0] == outs[1], outs
+    assert outs[0][0] == 'alg, reward' and [l.split(',')[0] for l in outs[0][1:]] == ['k3', 'k2', 'n40']

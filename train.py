@@ -5,7 +5,8 @@
 Every section of the INI file is one experiment (inheriting `[DEFAULT]`); the `header` key is printed once, then one
 line `section, mean, std` per experiment.  Environments come from this package's registry instead of gym / gym_flock and
 all learning runs on the MI355X kernels.  Under torchrun (one process per GPU) episodes are sharded over the ranks and
-rank 0 prints.  Extension: `alg = dagger_vec` (device-resident vectorised DAGGER, `n_envs` episodes per GPU).
+rank 0 prints.  Extensions: `alg = dagger_vec` (device-resident vectorised DAGGER, `n_envs` episodes per GPU);
+`python3 train.py <cfg> --jobs J` runs J sections of the file side by side (same output, file order).
 """
 import configparser
 import os
@@ -104,6 +105,50 @@ def iter_experiments(config):
         yield name, config[name]
 
 
+def run_sections_concurrently(path, names, jobs):
+    """Extension (`python3 train.py <cfg> --jobs J`): the experiments of a cfg file are independent (every section seeds its own
+    streams, reference train.py:24-28), so on a node with several GPUs J sections run side by side, one worker process each
+    (`--section NAME`), dealt round-robin to the visible devices (LOCAL_RANK), and their result lines are printed in file order
+    exactly as the sequential run prints them.  NOT a gain on ONE GPU: the four full trainings of
+    cfg/flocking_dagger_vec_k_sweep.cfg take 6.8 s in one process and 15.0 s as four processes sharing the MI355X (each
+    worker pays the framework start-up, and chains of short dependent launches from different processes interleave badly)."""
+    import subprocess
+    import tempfile
+    import time
+    results, running, order = {}, {}, list(names)
+    pending = list(enumerate(order))
+    try:
+        while pending or running:
+            while pending and len(running) < jobs:
+                i, name = pending.pop(0)
+                env = dict(os.environ, LOCAL_RANK=str(i % max(1, jobs)), MGP_TRAIN_WORKER='1')
+                fo, fe = tempfile.TemporaryFile('w+'), tempfile.TemporaryFile('w+')   # (files, not pipes: a debug run prints a lot)
+                proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), path, '--section', name], env=env,
+                                        stdout=fo, stderr=fe, text=True)
+                running[name] = (proc, fo, fe)
+            finished = [n for n, (pr, _, _) in running.items() if pr.poll() is not None]
+            if not finished:
+                time.sleep(0.02)
+                continue
+            for name in finished:
+                proc, fo, fe = running.pop(name)
+                fo.seek(0); fe.seek(0)
+                out, err = fo.read(), fe.read()
+                fo.close(); fe.close()
+                if proc.returncode != 0:
+                    raise RuntimeError("section %r failed:\n%s" % (name, err[-4000:]))
+                lines = [ln for ln in out.splitlines() if ln.startswith(name + ", ")]
+                results[name] = lines[-1] if lines else (out.strip().splitlines() or [''])[-1]
+                extra = [ln for ln in out.splitlines() if ln != results[name]]
+                if extra:                                         # a section's own progress lines (debug = True), kept together
+                    sys.stdout.write("\n".join(extra) + "\n")
+                sys.stderr.write(err)
+    finally:
+        for proc, fo, fe in running.values():
+            proc.kill()
+    return [results[n] for n in order]
+
+
 def main(argv=None):
     argv = sys.argv if argv is None else argv
     fname = argv[1]
@@ -113,7 +158,19 @@ def main(argv=None):
     config.read(path)
     is_root = int(os.environ.get('RANK', '0')) == 0
     header_done = False
+    only = argv[argv.index('--section') + 1] if '--section' in argv else None
+    jobs = int(argv[argv.index('--jobs') + 1]) if '--jobs' in argv else 1
+    if jobs > 1 and only is None and config.sections() and int(os.environ.get('WORLD_SIZE', '1')) == 1:
+        names = config.sections()
+        print(config[names[0]].get('header'))
+        for line in run_sections_concurrently(path, names, min(jobs, len(names))):
+            print(line)
+        return
     for name, section in iter_experiments(config):
+        if only is not None:
+            if name != only:
+                continue
+            header_done = True                               # a worker prints its result line only
         if name is not None and not header_done and is_root:
             print(section.get('header'))
             header_done = True
