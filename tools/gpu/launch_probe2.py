@@ -74,12 +74,24 @@ def sync_only():
 
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); e1.record(); sync()
-g = []
-for _ in range(30):
-    L.mgp_set_launch_events(e0.cuda_event, e1.cuda_event)
-    fn(*a); sync()
-    g.append(e0.elapsed_time(e1) * 1e3)
-print('T=%d  kernel (launch-stamped events) %.1f us' % (T, float(np.median(g))))
-print('bench path: launch + synchronize %.1f us | enqueue returns after %.1f us | Python above the C ABI %.1f us' % (med(full), med(full_enqueue), med(py_only)))
-print('bare ctypes call, arguments pre-converted: launch + synchronize %.1f us | call returns after %.1f us' % (med(raw), med(raw_enqueue)))
+
+
+def overhead(call, n=60):
+    """median over n launches of (wall time of launch + synchronize) - (the SAME launch's own begin -> end, stamped by the launch:
+    mgp_set_launch_events): the flock keeps evolving from launch to launch, so only differences within one launch compare"""
+    ov, kn, en = [], [], []
+    for _ in range(n):
+        sync()
+        L.mgp_set_launch_events(e0.cuda_event, e1.cuda_event)
+        t0 = time.perf_counter(); call(); t1 = time.perf_counter(); sync(); t2 = time.perf_counter()
+        k = e0.elapsed_time(e1) * 1e3
+        ov.append(1e6 * (t2 - t0) - k); kn.append(k); en.append(1e6 * (t1 - t0))
+    return float(np.median(ov[5:])), float(np.median(kn[5:])), float(np.median(en[5:]))
+
+
+ob, kb, eb = overhead(lambda: ep.advance(ro.run_resident, T))
+orw, kr, er = overhead(lambda: fn(*a))
+print('T=%d  kernel (launch-stamped events) %.1f us' % (T, kb))
+print('bench path (Episodes.advance -> Rollout.run_resident -> ResidentPlan.run): wall - kernel = %.1f us per launch | the call returns after %.1f us | Python above the C ABI %.1f us' % (ob, eb, med(py_only)))
+print('bare ctypes call, arguments pre-converted: wall - kernel = %.1f us per launch | the call returns after %.1f us' % (orw, er))
 print('synchronize on an idle device %.1f us' % med(sync_only))
