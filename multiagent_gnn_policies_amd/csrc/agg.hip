@@ -262,7 +262,7 @@ int launch_agg_fwd_mfma(const float* X, const float* G, float* Y, int B, int K, 
 // workgroups share a CU and, beyond one workgroup per CU (B K > 256), one workgroup's row sums, part combine and stores
 // overlap the next one's stream -- the eight-wave kernel holds 240 VGPRs per wave: ONE workgroup per CU, every launch phase
 // exposed once per episode (4.15 TB/s at B = 2048 against 3.4 at B = 256).  Parts are added in fixed order through LDS.
-template <int S, int FH, int NH, int NBLK, bool NT>   // S row steps per wave, NH row parts, NBLK column blocks: 64 NH NBLK threads
+template <int S, int FH, int NH, int NBLK, bool NT, bool NTS = false>   // S row steps per wave, NH row parts, NBLK column blocks: 64 NH NBLK threads; NTS: non-temporal stores
 __global__ __launch_bounds__(64 * NH * NBLK)         // (forcing <= 128 VGPRs for a fourth wave per SIMD spills and measured 7 % slower)
 void agg_fwd_mfma4_kernel(const float* __restrict__ X, const float* __restrict__ G, float* __restrict__ Y,
                           int K, int C, int N, long sxb, long sxk, long sxc, long syb, long syk, long syc)
@@ -300,7 +300,10 @@ void agg_fwd_mfma4_kernel(const float* __restrict__ X, const float* __restrict__
             for (int q = 1; q < NH; ++q) tot += comb[((wave + q) * FH + h) * 64 + lane];     // fixed order: part 1, 2, 3
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (4 * h + i < C) Yk[(size_t)(4 * h + i) * syc] = tot[i];
+                if (4 * h + i < C) {
+                    if (NTS) __builtin_nontemporal_store(tot[i], Yk + (size_t)(4 * h + i) * syc);
+                    else Yk[(size_t)(4 * h + i) * syc] = tot[i];
+                }
         }
     }
 }
@@ -311,8 +314,15 @@ int launch_agg_fwd_mfma4(const float* X, const float* G, float* Y, int B, int K,
 {
     constexpr int NW = NH * NBLK;
     const size_t lds = (size_t)(NW * 4 * 64 + NW * FH * 64) * 16;
-    hipLaunchKernelGGL((agg_fwd_mfma4_kernel<S, FH, NH, NBLK, NT>), dim3((unsigned)(B * K)), dim3(64 * NW), lds, st,
-                       X, G, Y, K, C, N, sxb, sxk, sxc, syb, syk, syc);
+    // results with the non-temporal hint once the launch is several workgroups per CU deep (B K >= 3072: 15 MB of results in a
+    // 246 MB read stream at B = 2048 -- 50.8 -> 48.4 us in the harness; at B = 256 the plain stores are the faster ones: 8.5 vs 8.9)
+    static const int nts_from = getenv("MGP_AGG_NTS") ? atoi(getenv("MGP_AGG_NTS")) : 3072;
+    if ((long)B * K >= nts_from)
+        hipLaunchKernelGGL((agg_fwd_mfma4_kernel<S, FH, NH, NBLK, NT, true>), dim3((unsigned)(B * K)), dim3(64 * NW), lds, st,
+                           X, G, Y, K, C, N, sxb, sxk, sxc, syb, syk, syc);
+    else
+        hipLaunchKernelGGL((agg_fwd_mfma4_kernel<S, FH, NH, NBLK, NT>), dim3((unsigned)(B * K)), dim3(64 * NW), lds, st,
+                           X, G, Y, K, C, N, sxb, sxk, sxc, syb, syk, syc);
     return mgp_launch_status();
 }
 
