@@ -21,9 +21,13 @@ STAMP = os.path.join(OBJ_DIR, 'libmgp.srchash')
 ARCH = 'gfx950'
 COMMON_FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 # flock.hip must reproduce numpy's op-by-op fp64 rounding: no fused multiply-add contraction
-PER_FILE_FLAGS = {'flock.hip': ['-ffp-contract=off'], 'rollout.hip': ['-ffp-contract=off'],
-                  'sparse_sim.hip': ['-ffp-contract=off'], 'rollout_wide.hip': ['-ffp-contract=off'],
-                  'rollout_w128.hip': ['-ffp-contract=off'], 'rollout_f32ref.hip': ['-ffp-contract=off']}
+# -fno-slp-vectorize (the resident rollout kernels): under plain -O3 the compiler packs adjacent scalar fp32 adds / multiplies of
+# the pair tests into v_pk_*_f32 behind register shuffles and s_nops; measured on the headline build: one-step launches 15.6 ->
+# 14.0 us with the packing off, longer launches 1 % (profiles/r05_rollout_ab.txt)
+_RO = ['-ffp-contract=off', '-fno-slp-vectorize']
+PER_FILE_FLAGS = {'flock.hip': ['-ffp-contract=off'], 'rollout.hip': _RO,
+                  'sparse_sim.hip': ['-ffp-contract=off'], 'rollout_wide.hip': _RO,
+                  'rollout_w128.hip': _RO, 'rollout_f32ref.hip': _RO}
 
 
 def sources():

@@ -51,23 +51,117 @@ constexpr int RO_WAVES = RO_THREADS / 64;
 #ifndef RO_S1L
 #define RO_S1L 8                          // (4 lanes per row -- 7 waves instead of 13, 25 candidates each -- measured 1 % slower)
 #endif
-#ifndef RO_S1_DOT
-#define RO_S1_DOT 0                       // 1: the pair test in dot-product form (six instructions per candidate instead of eight, but a
-                                          // cancellation error ~ M^2 instead of M R: a 40x wider band; measured 0.8k cycles SLOWER per step)
-#endif
+// (The pair test in dot-product form -- |s_i - s_j|^2 = n_i + (n_j - 2 s_i . s_j), six instructions per candidate instead of
+//  eight -- was measured in round 4: a cancellation error ~ M^2 instead of M R widens the band 40x, one to three lanes per step
+//  take the fp64 fallback, 0.8k cycles SLOWER per step.  Removed in round 5; LAB_NOTES.md "Pair test (S1)".)
 constexpr int RO_PIECES = RO_S1L;         // lanes per agent row in the pairwise pass S1 (adjacent lanes): 8 or 4
 constexpr int RO_MAXN = 128;              // RO_THREADS / RO_PIECES rows; membership bits of a row fit 2 x u64
 constexpr int RO_LDS_LIMIT = 160 * 1024;
+__host__ __device__ constexpr int ro_take(int& off, int bytes) { const int o = off; off += (bytes + 15) & ~15; return o; }
 // list entries per lane and pass in the S2 gather group: 4 where (N, K) are compile-time (2 measured 4 % slower there); 2 in the
 // run-time sized builds, whose S1T = 4 accumulator sets leave no registers for four entries in flight (they spilled: -20 %)
 template <int CK> struct RoGatherUnroll { static constexpr int value = CK ? 4 : 2; };
+
+// ---- [r5] Verlet candidate lists for the membership phase S1 (temporal coherence: agents move <= a few % of the radius per step).
+// Every RO_VSKIN-dependent quantity is a pure accelerator: the bits S1 produces are the exact test's (fp32 band + fp64
+// fallback) on every step; the candidate list only says which pairs CANNOT be within R and need no test.
+//   rebuild (step t_r): row i lists every j with |x_i - x_j| < RV = R (1 + RO_VSKIN)  (fp32 test, widened by the proven error
+//       band: conservative), ascending, up to RO_VCAP entries; the helper wave stores the positions p(t_r) and a frame velocity V.
+//   later steps: D_i(t) = p_i(t) - p_i(t_r) - V dt (t - t_r) for ANY common V; |x_i - x_j|(t_r) <= |x_i - x_j|(t) + |D_i| + |D_j|,
+//       so while 2 max_i |D_i| <= skin - margin every pair within R at step t is on the list of step t_r.  The helper wave
+//       evaluates the bound ONE STEP AHEAD (from p, v of the current state and the acceleration clip: |ue| <= max_accel *
+//       action_gain per axis), off the critical path, and leaves next step's mode in LDS:
+//         CHEAP   test the listed candidates only (eight lanes per row take entries piece, piece + 8, ...: ballots give the
+//                 row's hit mask, hits are compacted into the ascending neighbour list)
+//         REBUILD full-row pass that writes the candidate lists, then the cheap pass on them
+//         FULL    the all-pairs exact pass (round 4's S1): one-step launches, flocks whose relative motion would outrun the
+//                 skin within RO_VMINLIFE steps, rows with more than RO_VCAP candidates (per row)
+#ifndef RO_VERLET
+#define RO_VERLET 1
+#endif
+#ifndef MGP_RO_VL_BUILD
+#if defined(MGP_RO_WIDE) || defined(MGP_RO_X128)
+#define MGP_RO_VL_BUILD 0                 // (the 64- and 128-wide builds: lists not enabled yet)
+#else
+#define MGP_RO_VL_BUILD 1
+#endif
+#endif
+#ifndef RO_VSKIN
+#define RO_VSKIN 0.3f                     // skin in units of the communication radius (<= 1: the error band is proven for pairs within 2R)
+#endif
+#ifndef RO_VPU
+#define RO_VPU 2                          // candidate passes (of eight lanes) per trip of the cheap pass
+#endif
+#ifndef RO_VTRIPS
+#define RO_VTRIPS 4                       // trips a row's list may take: capacity RO_VPU * 8 * RO_VTRIPS candidates
+#endif
+#ifndef RO_VMINLIFE
+#define RO_VMINLIFE 2                     // a rebuild (the exact pass + ~0.4k cycles) is worth it if the list is expected to serve this many steps
+#endif
+constexpr int RO_VCAP = 8 * RO_VPU * RO_VTRIPS;               // candidates a row's list holds
+constexpr int RO_VSTR = 4 * ((RO_VCAP / 4) | 1);              // row stride in bytes: an odd word count (neighbouring rows on other banks)
+enum { RO_VM_CHEAP = 0, RO_VM_REBUILD = 1, RO_VM_FULL = 2 };
+struct RoVOff { int list, cnt, pref, gap, flag, total; };          // byte offsets relative to the end of the weight image
+__host__ __device__ constexpr RoVOff ro_voffsets(int N)
+{
+    RoVOff v = {};
+    int off = 0;
+    v.list = ro_take(off, N * RO_VSTR);
+    v.cnt = ro_take(off, N * 4);
+    v.pref = ro_take(off, 2 * N * 8);
+    v.gap = ro_take(off, N * 4);                              // float [N]: distance to the nearest agent at the rebuild - R, agents without candidates
+    v.flag = ro_take(off, 64);                                // int [0] next step's mode, [1] steps the lists have served, [2] steps of backoff;
+                                                              // double [4] at +16: frame offset (x, y), frame velocity (x, y); bytes 48..55: target
+                                                              // of masked list writes
+    v.total = off;
+    return v;
+}
+
+// Pair tests of one S1 lane: candidates j0 .. j0 + nt - 1 of row `si` (fp32 coordinates relative to the reference point);
+// sign bits instead of compare / select pairs (a v_cmp -> v_cndmask pair costs wait states on gfx9): the sign of r2 - t_in says
+// "clearly inside", the sign of t_out - r2 says "clearly outside"; v_alignbit shifts each into a mask (test k ends in bit
+// nt - 1 - k).  A NaN distance (diverged episode) classifies arbitrarily -- the state is garbage by then, and every index
+// stays valid.  WANT_V: a third threshold in the same pass (the candidate-list build of a rebuild step).
+template <int NTC, bool WANT_V>
+__device__ __forceinline__ void ro_s1_masks(const float4* sxy, const float six, const float siy, const int j0, const int N,
+                                            const int nt_rt, const float t_in, const float t_out, unsigned int& im, unsigned int& om,
+                                            const float t_v = 0.f, unsigned int* vm_ = nullptr)
+{
+    const int nt = NTC ? NTC : nt_rt;
+    im = 0u; om = 0u;
+    unsigned int vm = 0u;                                     // WANT_V: a third mask -- "clearly farther than the candidate radius"
+#pragma unroll
+    for (int c0 = 0; c0 < 128 / RO_PIECES; c0 += 8) {
+        if (c0 < nt) {
+            float2 sj[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (c0 + q < nt) sj[q] = *reinterpret_cast<const float2*>(&sxy[min(j0 + c0 + q, N - 1)]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (c0 + q < nt) {
+                    const float dx = six - sj[q].x, dy = siy - sj[q].y;
+                    const float r2 = fmaf(dy, dy, dx * dx);
+                    im = __builtin_amdgcn_alignbit(im, __float_as_uint(r2 - t_in), 31);
+                    om = __builtin_amdgcn_alignbit(om, __float_as_uint(t_out - r2), 31);
+                    if (WANT_V) vm = __builtin_amdgcn_alignbit(vm, __float_as_uint(t_v - r2), 31);
+                }
+            }
+        }
+    }
+    if (WANT_V) *vm_ = vm;
+}
 #ifdef MGP_RO_PROFILE
 __device__ unsigned long long mgp_ro_stamps[16 * 32];     // [wave][stamp]
-#define RO_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == 5) mgp_ro_stamps[(threadIdx.x >> 6) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#ifndef RO_STAMP_T
+#define RO_STAMP_T 5
+#endif
+#define RO_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == RO_STAMP_T) mgp_ro_stamps[(threadIdx.x >> 6) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
 #define RO_STAMPX(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) mgp_ro_stamps[(threadIdx.x >> 6) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
 // launch anatomy: the 100 MHz wall clock of EVERY workgroup at kernel begin / entry done / first steps / loop end / kernel end
 // (tools/harness/ro_launch_prof.hip: dispatch ramp, entry, cold first step, exit -- what a launch costs beyond its steps)
 __device__ long long mgp_ro_wall[4096 * 8];
+__device__ unsigned int mgp_ro_vstat[4096 * 4];             // S1 modes chosen per workgroup: cheap / rebuild / full
 #define RO_WALL(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) mgp_ro_wall[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define RO_WALL(i) do { } while (0)
@@ -106,7 +200,6 @@ struct RoOff {
     int wl;                               // float weight image: per layer fragments [MT][64][RO_WFS] + bias [MT*16]
 };
 
-__host__ __device__ constexpr int ro_take(int& off, int bytes) { const int o = off; off += (bytes + 15) & ~15; return o; }
 __host__ __device__ constexpr int ro_hist(int K) { return K > 2 ? K - 1 : 1; }
 // list row stride in bytes: room for N - 1 entries, a multiple of 4 with an ODD word count -- neighbouring lanes walk
 // neighbouring rows, and an even word stride put them 8 to a bank
@@ -155,7 +248,8 @@ __host__ __device__ constexpr RoOff ro_offsets(int N, int K)
 // WBF: the hidden layers run on split-bf16 MFMA from piece records (rollout_common.h) -- every build but the checker; the
 // 64-wide build falls back to fp32 fragments (WBF = false) for policies whose 40 % larger piece image does not fit the LDS
 // (four 64-wide layers at N = 100: cfg/hidden_size.cfg [4, 64]).
-template <int CN, int CK, bool FD, bool CL, bool CM = false, bool WBF = RO_BF16_CHAIN>
+// VL: Verlet candidate lists in S1 (above; the launcher selects it when the lists fit the LDS next to the weight image).
+template <int CN, int CK, bool FD, bool CL, bool CM = false, bool WBF = RO_BF16_CHAIN, bool VL = false>
 __global__ __launch_bounds__(RO_THREADS)
 void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __restrict__ Xd, float* __restrict__ action,
                     double* __restrict__ rewards, RoParams P, MgpFlockParams p, int K_arg, int N_arg, int T,
@@ -187,6 +281,14 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     float* uexp = reinterpret_cast<float*>(smraw + cv.uexp);                 // [2][N]
     double* vtot = reinterpret_cast<double*>(smraw + cv.uexp + ((2 * N * 4 + 7) & ~7));
     const int RS = ro_list_stride(N);                         // list row stride (bytes)
+    // Verlet regions behind the weight image (VL builds; the launcher has checked that they fit)
+    const RoVOff vo = ro_voffsets(N);
+    unsigned char* vbase = smraw + cv.wl + (CM ? (2 * (2 * 64 * WFS + 32) + ((2 * RO_OUTC + 2 + 15) & ~15)) * 4 : ((image_floats * 4 + 15) & ~15));
+    unsigned char* vlist = vbase + vo.list;
+    int* vcnt = reinterpret_cast<int*>(vbase + vo.cnt);
+    double* vpref = reinterpret_cast<double*>(vbase + vo.pref);
+    float* vgap = reinterpret_cast<float*>(vbase + vo.gap);
+    int* vflag = reinterpret_cast<int*>(vbase + vo.flag);
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Np = (N + 3) & ~3;                              // delay-line rows: N rounded up to a multiple of 4
@@ -286,6 +388,13 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     }
     if (tid < 4 * N) spx[(tid & 3) * N + (tid >> 2)] = posv;
     if (tid < 2) cref[tid] = posv;                            // agent 0's position: the reference point of the fp32 membership test
+    if (VL && tid == RO_THREADS - 1) {
+        // the first step builds the candidate lists unless the launch is too short to use them; sxy[N] (the unused 32 bytes
+        // behind the coordinates) is the SENTINEL the padding entries of a candidate list point at: far outside every radius
+        vflag[0] = (T >= RO_VMINLIFE) ? RO_VM_REBUILD : RO_VM_FULL;
+        vflag[1] = 0; vflag[2] = 0;
+        sxy[N] = make_float4(3.0e18f, 3.0e18f, 0.f, 0.f);
+    }
     if (CL) {
         if (tid < 2 * N) uexp[tid] = uexv;
         const double bq = floor((double)betav * 4294967296.0);            // P(expert drives) in units of 2^-32
@@ -352,6 +461,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     bool s1_ready = false;
     constexpr int S1T = CK ? (CK > 1 ? CK - 1 : 1) : 4;       // taps >= 1 (K <= 5)
     constexpr int GU = RoGatherUnroll<CK>::value;
+    constexpr bool GTAIL = GU == 4;                           // gather passes: one of GU entries per lane, then single entries
     // Gather stage 1 of a step: x_{t-j} . A_t for every tap j >= 1, A_t given as ascending lists (rc_, rl_) with row weights wv_;
     // `curn_` = ring slot tap 0 of that step sits in.  One summation order wherever it runs (S2 of the previous step, or the
     // entry of a launch that is handed the history in factored form): lane `part` of the column's four takes list entries
@@ -371,7 +481,9 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 // four entries per lane per pass (lists of up to 16 neighbours in ONE pass): the list bytes without waiting for
                 // the length, then every operand read of the pass in flight together, then the multiply-adds in list order
                 // (entries beyond the list are masked; every list byte is a valid row index)
-                for (int e = part; e == part || e < cnt; e += 4 * GU) {
+                // (sized builds: ONE pass of four entries per lane -- sixteen neighbours --, then the rare longer lists one entry per
+                //  lane and trip: a second full pass cost a wave ~90 instructions for its one row of 17+ neighbours.  Same order.)
+                for (int e = part; e == part || (!GTAIL && e < cnt); e += 4 * GU) {
                     int jn[GU]; float gv[GU];
 #pragma unroll
                     for (int u = 0; u < GU; ++u) jn[u] = lp[min(e + 4 * u, RS - 1)];
@@ -394,6 +506,23 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                                 s1[jj][0] = fmaf(x0[u].x, gz, s1[jj][0]); s1[jj][1] = fmaf(x0[u].y, gz, s1[jj][1]);
                                 s1[jj][2] = fmaf(x0[u].z, gz, s1[jj][2]); s1[jj][3] = fmaf(x0[u].w, gz, s1[jj][3]);
                                 s1[jj][4] = fmaf(x1[u].x, gz, s1[jj][4]); s1[jj][5] = fmaf(x1[u].y, gz, s1[jj][5]);
+                            }
+                        }
+                    }
+                }
+                if (GTAIL) {
+                    for (int e = part + 4 * GU; e < cnt; e += 4) {
+                        const int jn = lp[e];
+                        const float gz = w_new[jn];
+#pragma unroll
+                        for (int jj = 0; jj < S1T; ++jj) {
+                            if (jj < K - 1) {
+                                const float* src = XT + (size_t)ro_slot(curn, jj + 1, K) * Np * 8 + jn * 8;
+                                const float4 x0 = *reinterpret_cast<const float4*>(src);
+                                const float2 x1 = *reinterpret_cast<const float2*>(src + 4);
+                                s1[jj][0] = fmaf(x0.x, gz, s1[jj][0]); s1[jj][1] = fmaf(x0.y, gz, s1[jj][1]);
+                                s1[jj][2] = fmaf(x0.z, gz, s1[jj][2]); s1[jj][3] = fmaf(x0.w, gz, s1[jj][3]);
+                                s1[jj][4] = fmaf(x1.x, gz, s1[jj][4]); s1[jj][5] = fmaf(x1.y, gz, s1[jj][5]);
                             }
                         }
                     }
@@ -560,7 +689,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                     // round trips per pass instead of two per entry (entries beyond the list: weight 0 on a valid row)
                     // (the first pass reads its list bytes without waiting for the length: every list byte is a valid row index,
                     //  entries beyond the list are masked at the multiply-add -- one LDS round trip less on the critical path)
-                    for (int e = part; e == part || e < cnt; e += 4 * GU) {
+                    for (int e = part; e == part || (!GTAIL && e < cnt); e += 4 * GU) {
                         int m[4];
 #pragma unroll
                         for (int u = 0; u < GU; ++u) m[u] = lp[min(e + 4 * u, RS - 1)];
@@ -578,6 +707,16 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                             const float gz = (e + 4 * u < cnt) ? g[u] : 0.f;
                             sa[0] = fmaf(xa[u].x, gz, sa[0]); sa[1] = fmaf(xa[u].y, gz, sa[1]); sa[2] = fmaf(xa[u].z, gz, sa[2]);
                             sa[3] = fmaf(xa[u].w, gz, sa[3]); sa[4] = fmaf(xb[u].x, gz, sa[4]); sa[5] = fmaf(xb[u].y, gz, sa[5]);
+                        }
+                    }
+                    if (GTAIL) {
+                        for (int e = part + 4 * GU; e < cnt; e += 4) {       // lists beyond sixteen entries: one entry per lane and trip
+                            const int m1 = lp[e];
+                            const float gz = wq[m1];
+                            const float4 xa = *reinterpret_cast<const float4*>(src + m1 * 8);
+                            const float2 xb = *reinterpret_cast<const float2*>(src + m1 * 8 + 4);
+                            sa[0] = fmaf(xa.x, gz, sa[0]); sa[1] = fmaf(xa.y, gz, sa[1]); sa[2] = fmaf(xa.z, gz, sa[2]);
+                            sa[3] = fmaf(xa.w, gz, sa[3]); sa[4] = fmaf(xb.x, gz, sa[4]); sa[5] = fmaf(xb.y, gz, sa[5]);
                         }
                     }
                 }
@@ -680,13 +819,6 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                     sc = (float)(pp - cc);
                     reinterpret_cast<float*>(sxy)[4 * col + axis] = sc;
                 }
-                if (RO_S1_DOT) {   // squared norm of the relative position for S1's dot-product form: the x lane (row 0 of the wave) and the y
-                    // lane (row 1) of a column add their squares through one v_permlane16_swap (every lane executes it)
-                    const float sq = sc * sc;
-                    unsigned int qa = __float_as_uint(sq), qb = qa;
-                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(qa), "+v"(qb));
-                    if (agent && axis == 0) reinterpret_cast<float*>(sxy)[4 * col + 2] = __uint_as_float(qa) + __uint_as_float(qb);
-                }
                 RO_STAMP(15);
             } else {
                 // no hidden layer: the output layer reads the aggregation tile from LDS; lane L takes agent column L >> 2 of the
@@ -729,6 +861,13 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 }
             }
         } else {
+            if (VL && __builtin_amdgcn_readfirstlane(vflag[0]) == RO_VM_REBUILD) {
+                // S1 of this step rebuilds the candidate lists: the waves without columns pad every row with the sentinel index
+                const int it0 = tid - NT * 64, nth = RO_THREADS - NT * 64;
+                const unsigned int sw = 0x01010101u * (unsigned int)N;
+                uint4* vz = reinterpret_cast<uint4*>(vlist);
+                for (int i = it0; i < (N * RO_VSTR + 15) / 16; i += nth) vz[i] = make_uint4(sw, sw, sw, sw);
+            }
             if (CL) {
                 // meanwhile the other waves file the state this step starts from (reference gnn_dagger.py:178: the transition
                 // stores the state BEFORE the step and the expert's action for it): features = tap 0 of the delay line, the
@@ -738,6 +877,16 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 float* ff = cl.feat + fs * 6 * N;
                 for (int e = it0; e < 6 * N; e += nth) { const int f = e / N, n = e - f * N; ff[e] = XT[((size_t)cur * Np + n) * 8 + f]; }
                 unsigned long long* fb = cl.bits + fs * 2 * N;
+                if (VL) {
+                    // (the cheap pass of S1 writes lists only: the bits of the current network are folded back from its list)
+                    for (int row = it0; row < N; row += nth) {
+                        const unsigned char* lq_ = rlist + ((size_t)hs * N + row) * RS;
+                        const int cq_ = rcnt[hs * N + row];
+                        unsigned long long lo = 0ull, hi = 0ull;
+                        for (int e = 0; e < cq_; ++e) { const int m = lq_[e]; if (m < 64) lo |= 1ull << m; else hi |= 1ull << (m - 64); }
+                        fb[2 * row] = lo; fb[2 * row + 1] = hi;
+                    }
+                } else
                 for (int i = it0; i < 2 * N; i += nth) fb[i] = rowmask[i];
                 float* fl = cl.label + fs * 2 * N;
                 for (int e = it0; e < 2 * N; e += nth) fl[e] = uexp[e];
@@ -745,12 +894,16 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             }
         }
         }
+        // how S1 of this step finds the new network (VL builds; written in S2 of the previous step): requested in front of the
+        // barrier, so that the round trip is not the first thing S1 waits for
+        const int vmode_raw = VL ? vflag[0] : (int)RO_VM_FULL;
         __syncthreads();
         RO_STAMP(3);
         // -------------------------------------------------------------- S1: membership bits + neighbour lists of the new state
         // reward (spec section 4: two-pass population variance of the velocities), one wave, split around the S1 barrier so
         // that its serial fp64 chain is not what the barrier waits for: the sums here, the variance pass in S2
         double rw_mx = 0.0, rw_my = 0.0;
+        const int vmode = VL ? __builtin_amdgcn_readfirstlane(vmode_raw) : (int)RO_VM_FULL;
         {   // ---- phase S1
         const int tid = ro_fresh_tid_ph(2);
         const int lane = tid & 63, wave = tid >> 6;
@@ -778,90 +931,73 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             // each other (farther ones miss R^2 by a wide margin): |s_j| <= |s_i| + 2R there, so M = |s_i|_inf + 2R is sound for
             // every candidate of this row -- no maximum over the flock, and a sound band gives the same final bits whatever
             // its width (pairs it cannot certify go to the exact test).
-#if RO_S1_DOT
-            // (experiment, off by default: measured slower) The distance test in DOT-PRODUCT form: |s_i - s_j|^2 = n_i + (n_j - 2 s_i . s_j) with n = |s|^2 stored next to the
-            // coordinates (phase C), n_i folded into the two thresholds: per candidate two fused multiply-adds and two sign tests
-            // (six vector instructions; the difference form took eight), and exactly dh8 candidates per lane in the sized builds
-            // (13 at N = 100; two groups of eight tested 16).  Soundness of the band: with u = 2^-24 and P = max(|s_i|, |s_j|)
-            // the stored n are within 3 u P^2 of |s|^2, each fused multiply-add rounds a value below 3 P^2, the folded thresholds
-            // round once: |computed - |s_i - s_j|^2| <= 15 u P^2 <= 30 u M^2 for every pair within 2R of each other (M bounds
-            // the max-norm of both agents, P^2 <= 2 M^2); 64 u M^2 is added to the band.  Pairs farther than 2R stay at least
-            // 3.9 R^2 - 60 u M^2 above R^2: never "clearly inside" while the band is below R^2 / 2 -- a wider band (a flock spread
-            // over hundreds of radii, or a NaN) sends every pair to the exact fp64 test.  A sound band gives the oracle's bits
-            // whatever its width, so the two rows of a pair agree although neither the bands nor the expressions are symmetric.
-            const float4 si = sxy[pi];
-            const int j0 = piece * dh8, nd = max(0, min(dh8, N - j0));          // this lane's candidates j0 .. j0 + nd - 1
-            const float M = fmaxf(fabsf(si.x), fabsf(si.y)) + 2.0f * Rf;
-            const float band = Rf * (16.f * M + 16.f * Rf) * 5.9604645e-8f + R2f * 1.1920929e-7f + (64.f * 5.9604645e-8f) * M * M;
-            const bool wide = !(band < 0.5f * R2f);
-            const float t_in = (wide ? -__builtin_huge_valf() : R2f - band) - si.z;
-            const float t_out = (wide ? __builtin_huge_valf() : R2f + band) - si.z;
-            const float m2x = -2.f * si.x, m2y = -2.f * si.y;
-            unsigned int im = 0u, om = 0u;
-            // tests executed by every lane: dh8 in the sized builds, one or two groups of eight otherwise (candidates beyond the
-            // piece re-test row N - 1 and are masked below)
-            const int nt = CN ? dh8 : ((dh8 + 7) & ~7);
-#pragma unroll
-            for (int c0 = 0; c0 < 128 / RO_PIECES; c0 += 8) {
-                if (c0 < nt) {
-                    float4 sj[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        if (c0 + q < nt) sj[q] = sxy[min(j0 + c0 + q, N - 1)];
-                    // sign bits instead of compare / select pairs (a v_cmp -> v_cndmask pair costs wait states on gfx9): the
-                    // sign of r2 - t_in says "clearly inside", the sign of t_out - r2 says "clearly outside"; v_alignbit shifts
-                    // each into a mask (test k ends in bit nt - 1 - k).  A NaN distance (diverged episode) classifies arbitrarily --
-                    // the state is garbage by then, and every index stays valid.
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        if (c0 + q < nt) {
-                            const float bq = fmaf(m2y, sj[q].y, fmaf(m2x, sj[q].x, sj[q].z));
-                            im = __builtin_amdgcn_alignbit(im, __float_as_uint(bq - t_in), 31);
-                            om = __builtin_amdgcn_alignbit(om, __float_as_uint(t_out - bq), 31);
-                        }
-                    }
-                }
-            }
-#else
             const float4 si = sxy[pi];
             const int j0 = piece * dh8, nd = max(0, min(dh8, N - j0));          // this lane's candidates j0 .. j0 + nd - 1
             const float M = fmaxf(fabsf(si.x), fabsf(si.y)) + 2.0f * Rf;
             const float band = Rf * (16.f * M + 16.f * Rf) * 5.9604645e-8f + R2f * 1.1920929e-7f;
             const float t_in = R2f - band, t_out = R2f + band;
-            unsigned int im = 0u, om = 0u;
-            // tests executed by every lane: EXACTLY dh8 in the sized builds (13 at N = 100: round 3 ran two groups of eight), one or
-            // two groups of eight otherwise (candidates beyond the piece re-test row N - 1 and are masked below)
+            // tests executed by every lane of a full-row pass: EXACTLY dh8 in the sized builds (13 at N = 100: round 3 ran two groups
+            // of eight), one or two groups of eight otherwise (candidates beyond the piece re-test row N - 1 and are masked below)
             const int nt = CN ? dh8 : ((dh8 + 7) & ~7);
-#pragma unroll
-            for (int c0 = 0; c0 < 128 / RO_PIECES; c0 += 8) {
-                if (c0 < nt) {
-                    float2 sj[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        if (c0 + q < nt) sj[q] = *reinterpret_cast<const float2*>(&sxy[min(j0 + c0 + q, N - 1)]);
-                    // sign bits instead of compare / select pairs (a v_cmp -> v_cndmask pair costs wait states on gfx9): the
-                    // sign of r2 - t_in says "clearly inside", the sign of t_out - r2 says "clearly outside"; v_alignbit shifts
-                    // each into a mask (test k ends in bit nt - 1 - k).  A NaN distance (diverged episode) classifies arbitrarily --
-                    // the state is garbage by then, and every index stays valid.
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        if (c0 + q < nt) {
-                            const float dx = si.x - sj[q].x, dy = si.y - sj[q].y;
-                            const float r2 = fmaf(dy, dy, dx * dx);
-                            im = __builtin_amdgcn_alignbit(im, __float_as_uint(r2 - t_in), 31);
-                            om = __builtin_amdgcn_alignbit(om, __float_as_uint(t_out - r2), 31);
-                        }
-                    }
-                }
-            }
-#endif
+            constexpr int NTC = CN ? (CN + RO_PIECES - 1) / RO_PIECES : 0;
             const unsigned int tmask = (nt >= 32) ? 0xFFFFFFFFu : ((1u << nt) - 1u);
-            unsigned int in_m = __builtin_bitreverse32(im) >> (32 - nt);          // test k -> bit k
-            unsigned int unc_m = ~(__builtin_bitreverse32(om) >> (32 - nt)) & ~in_m & tmask;
-            RO_STAMP(16);
             unsigned int valid = (nd >= 32) ? 0xFFFFFFFFu : ((1u << nd) - 1u);   // candidates beyond the piece re-tested row N - 1
             const int self = pi - j0;
             if (self >= 0 && self < nd) valid &= ~(1u << self);                // (r2 = 0 is "inside": the diagonal is not a link)
+            // a lane's bits -> the row's 128-bit word, OR-combined over the row's eight lanes on the DPP path (every lane gets it)
+            auto row_word = [&](const unsigned int bits_, unsigned long long& flo_, unsigned long long& fhi_) {
+                unsigned long long lo = 0ull, hi = 0ull;
+                if (j0 < 64) {
+                    lo = (unsigned long long)bits_ << j0;
+                    if (j0 > 32) hi = (unsigned long long)bits_ >> (64 - j0);
+                } else {
+                    hi = (unsigned long long)bits_ << (j0 - 64);
+                }
+                unsigned int w0 = (unsigned int)lo, w1 = (unsigned int)(lo >> 32), w2_ = (unsigned int)hi, w3 = (unsigned int)(hi >> 32);
+                w0 |= dpp_u<0xB1>(w0); w1 |= dpp_u<0xB1>(w1); w2_ |= dpp_u<0xB1>(w2_); w3 |= dpp_u<0xB1>(w3);       // lane ^ 1
+                w0 |= dpp_u<0x4E>(w0); w1 |= dpp_u<0x4E>(w1); w2_ |= dpp_u<0x4E>(w2_); w3 |= dpp_u<0x4E>(w3);       // lane ^ 2
+                if (RO_PIECES == 8) { w0 |= dpp_u<0x141>(w0); w1 |= dpp_u<0x141>(w1); w2_ |= dpp_u<0x141>(w2_); w3 |= dpp_u<0x141>(w3); }   // i -> 7 - i
+                flo_ = ((unsigned long long)w1 << 32) | w0; fhi_ = ((unsigned long long)w3 << 32) | w2_;
+            };
+            // entries of the row's ascending list in front of this lane's piece
+            auto piece_pos = [&](const unsigned long long flo_, const unsigned long long fhi_) -> int {
+                if (j0 < 64) return __popcll(flo_ & ((1ull << j0) - 1ull));
+                return __popcll(flo_) + __popcll(fhi_ & ((1ull << (j0 - 64)) - 1ull));
+            };
+            // VL builds keep no bit words in S1 (the bits of a network are folded back from its list where somebody needs them):
+            // list positions come from an inclusive prefix sum of the lanes' hit counts over the row's eight lanes -- three DPP
+            // steps on one register (pairs, quads, halves), two counts packed into it on rebuild steps
+            auto seg8_scan = [&](const unsigned int x) -> unsigned int {
+                unsigned int sc = x;
+                sc += dpp_u<0xA0>(sc) & (0u - (unsigned int)(piece & 1));                  // quad_perm [0,0,2,2]: odd lanes += left neighbour
+                sc += dpp_u<0x55>(sc) & (0u - (unsigned int)((piece >> 1) & 1));           // quad_perm [1,1,1,1]: lanes 2, 3 of a quad += its first pair
+                const unsigned int q3 = dpp_u<0xFF>(sc);                                   // quad_perm [3,3,3,3]: the quad's total
+                sc += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)q3, 0x114, 0xF, 0xA, false);   // row_shr:4 into banks 1, 3: upper quad += lower quad
+                return sc;
+            };
+            bool exact_row = true;                            // this row takes the all-pairs exact pass
+            int vc = 0;                                       // else: candidates on its Verlet list
+            unsigned int im = 0u, om = 0u, cand = 0u;
+            const bool vbuild = VL && vmode == RO_VM_REBUILD;
+            if (vbuild) {
+                static_assert(!VL || (RO_PIECES == 8 && !FD), "the candidate lists ride on the eight-lane difference-form pass");
+                // the all-pairs exact pass with a third threshold: the candidate list of the row = every j that is not CLEARLY
+                // farther than RV = R (1 + skin).  For pairs within 2R of each other |r2_fp32 - r2| <= band (above), RV <= 2R, and
+                // RVf^2 is RV^2 to three roundings; a pair that may be within RV at this step stays on the list: r2_fp32 <= r2 + band
+                // < RV^2 + band <= tv.  (A NaN / infinite band keeps every pair: the row overflows and takes the exact pass.)
+                const float RVf = Rf * (1.0f + RO_VSKIN);
+                const float tv = fmaf(RVf, RVf, 4.f * band + RVf * RVf * 4.e-7f);
+                unsigned int omv;
+                ro_s1_masks<NTC, true>(sxy, si.x, si.y, j0, N, nt, t_in, t_out, im, om, tv, &omv);
+                cand = ~(__builtin_bitreverse32(omv) >> (32 - nt)) & tmask & valid;
+            } else {
+                if (VL && vmode == RO_VM_CHEAP) { vc = vcnt[pi]; exact_row = vc > RO_VCAP; }
+                if (exact_row) ro_s1_masks<NTC, false>(sxy, si.x, si.y, j0, N, nt, t_in, t_out, im, om);
+            }
+            if (exact_row) {
+            unsigned int in_m = __builtin_bitreverse32(im) >> (32 - nt);          // test k -> bit k
+            unsigned int unc_m = ~(__builtin_bitreverse32(om) >> (32 - nt)) & ~in_m & tmask;
+            RO_STAMP(16);
             in_m &= valid;
             unc_m &= valid;
             while (unc_m) {                                   // rare: the spec's own fp64 expression decides
@@ -883,23 +1019,35 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 }
             }
             RO_STAMP(17);
-            // this lane's bits at their place in the row's 128-bit word
-            unsigned long long lo = 0ull, hi = 0ull;
-            if (j0 < 64) {
-                lo = (unsigned long long)in_m << j0;
-                if (j0 > 32) hi = (unsigned long long)in_m >> (64 - j0);
+            if (VL) {
+                const unsigned int own = (unsigned int)__popc(in_m) | (vbuild ? (unsigned int)__popc(cand) << 16 : 0u);
+                const unsigned int incl = seg8_scan(own);
+                RO_STAMP(18);
+                int pos = (int)((incl - own) & 0xFFFFu);
+                unsigned char* lp = rl_new + pi * RS;
+                unsigned int mq = in_m;
+                while (mq) { lp[pos++] = (unsigned char)(j0 + __builtin_ctz(mq)); mq &= mq - 1u; }
+                if (vbuild) {
+                    // the candidate list, ascending; a row beyond the capacity keeps a truncated list nobody reads (its count says so:
+                    // exact pass every step)
+                    int vpos = (int)((incl - own) >> 16);
+                    unsigned char* vp = vlist + pi * RO_VSTR;
+                    unsigned int cq = cand;
+                    while (cq) { if (vpos < RO_VCAP) vp[vpos] = (unsigned char)(j0 + __builtin_ctz(cq)); ++vpos; cq &= cq - 1u; }
+                }
+                RO_STAMP(19);
+                if (piece == RO_PIECES - 1) {                 // the last lane of the row holds the totals
+                    const int cnt = (int)(incl & 0xFFFFu);
+                    rc_new[pi] = cnt;
+                    w_new[pi] = wtab[cnt];
+                    if (vbuild) vcnt[pi] = (int)(incl >> 16);
+                }
             } else {
-                hi = (unsigned long long)in_m << (j0 - 64);
-            }
-            unsigned int w0 = (unsigned int)lo, w1 = (unsigned int)(lo >> 32), w2_ = (unsigned int)hi, w3 = (unsigned int)(hi >> 32);
-            w0 |= dpp_u<0xB1>(w0); w1 |= dpp_u<0xB1>(w1); w2_ |= dpp_u<0xB1>(w2_); w3 |= dpp_u<0xB1>(w3);       // lane ^ 1
-            w0 |= dpp_u<0x4E>(w0); w1 |= dpp_u<0x4E>(w1); w2_ |= dpp_u<0x4E>(w2_); w3 |= dpp_u<0x4E>(w3);       // lane ^ 2
-            if (RO_PIECES == 8) { w0 |= dpp_u<0x141>(w0); w1 |= dpp_u<0x141>(w1); w2_ |= dpp_u<0x141>(w2_); w3 |= dpp_u<0x141>(w3); }   // i -> 7 - i
-            const unsigned long long flo = ((unsigned long long)w1 << 32) | w0, fhi = ((unsigned long long)w3 << 32) | w2_;
+            // this lane's bits at their place in the row's 128-bit word
+            unsigned long long flo, fhi;
+            row_word(in_m, flo, fhi);
             RO_STAMP(18);
-            int pos;
-            if (j0 < 64) pos = __popcll(flo & ((1ull << j0) - 1ull));
-            else pos = __popcll(flo) + __popcll(fhi & ((1ull << (j0 - 64)) - 1ull));
+            int pos = piece_pos(flo, fhi);
             unsigned char* lp = rl_new + pi * RS;
             unsigned int mq = in_m;
             while (mq) { lp[pos++] = (unsigned char)(j0 + __builtin_ctz(mq)); mq &= mq - 1u; }
@@ -909,6 +1057,64 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 rm_new[2 * pi] = flo; rm_new[2 * pi + 1] = fhi;
                 rc_new[pi] = cnt;
                 w_new[pi] = wtab[cnt];                          // (float)(1 / max(deg, 1)) or 1: the value the spec's row weight rounds to
+            }
+            }
+            } else {
+                // ---- cheap pass: the row's listed candidates only.  Lane `piece` of the row takes entries piece, piece + 8, ... (the
+                // padding entries point at the sentinel: clearly outside); a ballot per pass holds the hits of the wave's eight rows,
+                // one byte per row, so the row's hit mask over list positions needs no cross-lane moves; a hit goes to position
+                // (hits in front of it) of the ascending neighbour list -- the candidate list is ascending, so is every subset.
+                // The bits are the exact pass's: same fp32 expression, same band, same fp64 fallback.
+                const unsigned char* vl = vlist + pi * RO_VSTR + piece;
+                unsigned char* lp = rl_new + pi * RS;
+                unsigned char* dummy = reinterpret_cast<unsigned char*>(vflag) + 48 + piece;  // masked writes land here
+                int base = 0;
+                const bool rowhi = (tid & 32) != 0;           // this row's byte: in the high half of a ballot?
+                const int shb = tid & 24;                     // ... and its bit offset inside that half
+                for (int e0 = 0; e0 < vc; e0 += 8 * RO_VPU) {
+                    int jv[RO_VPU]; float2 sj[RO_VPU];
+                    unsigned long long bin[RO_VPU], bunc = 0ull;
+#pragma unroll
+                    for (int u = 0; u < RO_VPU; ++u) jv[u] = vl[e0 + 8 * u];
+#pragma unroll
+                    for (int u = 0; u < RO_VPU; ++u) sj[u] = *reinterpret_cast<const float2*>(&sxy[jv[u]]);
+#pragma unroll
+                    for (int u = 0; u < RO_VPU; ++u) {
+                        const float dx = si.x - sj[u].x, dy = si.y - sj[u].y;
+                        const float r2 = fmaf(dy, dy, dx * dx);
+                        bin[u] = __builtin_amdgcn_ballot_w64(r2 < t_in);
+                        bunc |= __builtin_amdgcn_ballot_w64(!(r2 > t_out)) & ~bin[u];     // (a NaN goes to the fp64 expression: "no link")
+                    }
+                    if (bunc != 0ull) {                       // rare, wave-uniform: the spec's own fp64 expression decides
+#pragma unroll
+                        for (int u = 0; u < RO_VPU; ++u) {
+                            const int j = min(jv[u], N - 1);   // (sentinel entries are clearly outside: never uncertain)
+                            const float dxf = si.x - sj[u].x, dyf = si.y - sj[u].y;
+                            const float r2f = fmaf(dyf, dyf, dxf * dxf);
+                            const double dx = spx[pi] - spx[j], dy = spy[pi] - spy[j];
+                            const double r2 = dx * dx + dy * dy;
+                            const bool unc = !(r2f < t_in) && !(r2f > t_out);
+                            bin[u] |= __builtin_amdgcn_ballot_w64(unc && r2 < R2);
+                        }
+                    }
+                    unsigned int mw = 0u;                     // hits of this trip over list positions 8 u + piece
+#pragma unroll
+                    for (int u = 0; u < RO_VPU; ++u) {
+                        const unsigned int half = rowhi ? (unsigned int)(bin[u] >> 32) : (unsigned int)bin[u];
+                        mw |= ((half >> shb) & 0xFFu) << (8 * u);
+                    }
+#pragma unroll
+                    for (int u = 0; u < RO_VPU; ++u) {
+                        const int pos = base + __popc(mw & ((1u << (8 * u + piece)) - 1u));
+                        unsigned char* dst = ((mw >> (8 * u + piece)) & 1u) ? lp + pos : dummy;
+                        *dst = (unsigned char)jv[u];
+                    }
+                    base += __popc(mw);
+                }
+                if (piece == 0) {
+                    rc_new[pi] = base;
+                    w_new[pi] = wtab[base];
+                }
             }
         }
         }
@@ -928,6 +1134,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         const int fr = tid >> 2, fq = tid & 3;                //   features: agent row fr, lane fq of 4
         if (tid == RO_THREADS - 2) { cref[0] = spx[0]; cref[1] = spy[0]; }   // next step's reference point (any point is valid)
         const int grp = 4 * ((N + 15) & ~15);                 // threads per group
+        const int vl_wave = (N <= 112) ? RO_WAVES - 2 : RO_WAVES - 1;   // the wave that keeps the Verlet books (VL builds)
         if (wave == RO_WAVES - 1 && rewards != nullptr) {     // second half of the reward (velocities change in phase C only)
             double dv = 0.0;
             for (int i = lane; i < N; i += 64) {
@@ -937,6 +1144,100 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             const double var = wave_sum_d(dv) / (double)N;
             if (lane == 0) rewards[(size_t)b * T + t] = -1.0 * var * p.reward_scale;
             RO_STAMP(21);
+        }
+        if (VL && wave == vl_wave && t + 1 < T) {
+            // ---- Verlet bookkeeping (header of this file), one step AHEAD and off the critical path, by a wave that has no rows
+            // in this phase (N <= 112; the reward wave otherwise): is every pair that can be within R after the NEXT integration
+            // still on the candidate lists?  D_i = p_i - pref_i - c with c = V dt (steps since the rebuild) for the frame
+            // velocity V chosen at the rebuild (any common vector is sound); the next state adds v_i dt - V dt and at most
+            // hacc = |max_accel action_gain| dt^2 / 2 per axis.
+            // A pair that was farther apart than RV at the rebuild is safe while D_i + D_j <= skin.  An ESCAPER -- an agent that has
+            // left the flock and keeps its course -- outruns that bound within a few steps although it is nowhere near anybody; for
+            // an agent that had NO candidate at the rebuild the wave therefore keeps gap_o = (distance to its nearest agent then)
+            // - R, and every pair of o is safe while D_o + D_j <= gap_o.  Sufficient for the step: every agent has D_i <= skin / 2, or
+            // D_i + max_j D_j <= gap_i (gap = 0 for agents that had candidates).
+            double* vst = reinterpret_cast<double*>(vflag) + 2;    // frame offset (x, y), frame velocity (x, y): state of this wave, kept in LDS
+            const double hacc = fabs(p.max_accel * p.action_gain) * p.dt * p.dt * 0.5;
+            const float skin = RO_VSKIN * Rf;
+            const float vmarg = 1.e-3f * Rf;                  // margin: the fp32 / fp64 roundings of these bounds are ~1e-6 R
+            bool vl_ok = false;
+            float dd[2] = {0.f, 0.f};                         // upper bounds of |D_i| after the next integration, agents lane, lane + 64
+            if (vmode == RO_VM_REBUILD) {                     // S1 of this step listed the candidates of THESE positions:
+                // they become the reference, the frame moves with the flock's mean velocity (any common vector is sound)
+                double sx = 0.0, sy = 0.0;
+                for (int i = lane; i < N; i += 64) { sx += svx[i]; sy += svy[i]; }
+                const double fvx = wave_sum_d(sx) * p.dt / (double)N, fvy = wave_sum_d(sy) * p.dt / (double)N;
+                unsigned long long iso[2];
+#pragma unroll
+                for (int a_ = 0; a_ < 2; ++a_) {
+                    const int i = lane + 64 * a_;
+                    bool lonely = false;
+                    if (i < N) {
+                        const double xi = spx[i], yi = spy[i];
+                        vpref[i] = xi; vpref[N + i] = yi;
+                        const double ex = fabs(svx[i] * p.dt - fvx) + hacc, ey = fabs(svy[i] * p.dt - fvy) + hacc;
+                        dd[a_] = sqrtf((float)(ex * ex + ey * ey) * 1.000001f) * 1.000001f;
+                        vgap[i] = 0.f;
+                        lonely = vcnt[i] == 0;
+                    }
+                    iso[a_] = __builtin_amdgcn_ballot_w64(lonely);
+                }
+                for (int a_ = 0, budget = 8; a_ < 2; ++a_) {  // (wave-uniform loops; a handful of agents at most)
+                    unsigned long long mk = iso[a_];
+                    while (mk != 0ull && budget > 0) {
+                        const int o = 64 * a_ + __builtin_ctzll(mk);
+                        mk &= mk - 1ull; --budget;
+                        const double xo = spx[o], yo = spy[o];
+                        float nm = __builtin_huge_valf();
+                        for (int j = lane; j < N; j += 64) {
+                            const double dx = xo - spx[j], dy = yo - spy[j];
+                            const float r2 = (float)(dx * dx + dy * dy) * 0.999999f;
+                            if (j != o) nm = fminf(nm, r2);
+                        }
+                        nm = -wave_max_to_last(-nm);
+                        if (lane == 63) vgap[o] = sqrtf(nm) * 0.999999f - Rf - vmarg;
+                    }
+                }
+                if (lane == 0) { vst[0] = fvx; vst[1] = fvy; vst[2] = fvx; vst[3] = fvy; }
+                vl_ok = true;
+            } else if (vmode == RO_VM_CHEAP) {
+                const double fvx = vst[2], fvy = vst[3];
+                const double cx = vst[0] + fvx, cy = vst[1] + fvy;
+#pragma unroll
+                for (int a_ = 0; a_ < 2; ++a_) {
+                    const int i = lane + 64 * a_;
+                    if (i < N) {
+                        const double ex = fabs((spx[i] + svx[i] * p.dt) - vpref[i] - cx) + hacc;
+                        const double ey = fabs((spy[i] + svy[i] * p.dt) - vpref[N + i] - cy) + hacc;
+                        dd[a_] = sqrtf((float)(ex * ex + ey * ey) * 1.000001f) * 1.000001f;
+                    }
+                }
+                if (lane == 0) { vst[0] = cx; vst[1] = cy; }
+                vl_ok = true;
+            }
+            const float dmx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max_to_last(fmaxf(dd[0], dd[1]))), 63));
+            bool bad = false;                                 // (comparisons written so that a NaN -- diverged episode -- falls to the exact pass)
+#pragma unroll
+            for (int a_ = 0; a_ < 2; ++a_) {
+                const int i = lane + 64 * a_;
+                if (i < N) bad = bad || !((dd[a_] <= 0.5f * (skin - vmarg)) || (dd[a_] + dmx <= vgap[i]));
+            }
+            const bool cheap_ok = vl_ok && __builtin_amdgcn_ballot_w64(bad) == 0ull;
+            // Next step's mode.  A list that did not serve RO_VMINLIFE steps was not worth its rebuild (~0.4k cycles on top of the
+            // exact pass): the flock moves too fast for this skin -- exact passes for a while, then another try.
+            int age = (vmode == RO_VM_CHEAP) ? vflag[1] + 1 : 0, backoff = vflag[2];
+            int next = RO_VM_CHEAP;
+            if (!cheap_ok) {                                  // (wave-uniform)
+                if (vl_ok && age < RO_VMINLIFE) backoff = 8;
+                const bool rebuild = backoff == 0 && (T - (t + 1) >= RO_VMINLIFE);
+                if (backoff > 0) --backoff;
+                next = rebuild ? RO_VM_REBUILD : RO_VM_FULL;
+            }
+            if (lane == 0) { vflag[1] = age; vflag[2] = backoff; }
+            if (lane == 0) vflag[0] = next;
+#ifdef MGP_RO_PROFILE
+            if (blockIdx.x < 4096 && lane == 0) atomicAdd(&mgp_ro_vstat[blockIdx.x * 4 + next], 1u);
+#endif
         }
         const int gtid = tid - grp;                           // (the groups swapped -- gather on the older waves -- measured the same)
         if (tid < grp) {
@@ -1009,6 +1310,17 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     // Slices are produced in descending j (a slice that is still an input -- j - hv < j -- is overwritten later), with a
     // workgroup barrier between slices.  Row vectors ping-pong in the activation area (no longer needed).
     RO_STAMPX(10);
+    if (VL && T > 0 && K >= 2 && !(flags & MGP_RO_SKIP_DENSE)) {
+        // the cheap pass of S1 writes lists only: fold the newest network's bits back from its list for the dense exit below
+        for (int row = tid; row < N; row += RO_THREADS) {
+            const unsigned char* lq_ = rlist + ((size_t)hs * N + row) * RS;
+            const int cq_ = rcnt[hs * N + row];
+            unsigned long long lo = 0ull, hi = 0ull;
+            for (int e = 0; e < cq_; ++e) { const int m = lq_[e]; if (m < 64) lo |= 1ull << m; else hi |= 1ull << (m - 64); }
+            rowmask[2 * row] = lo; rowmask[2 * row + 1] = hi;
+        }
+        __syncthreads();
+    }
     // Factored hand-over (MGP_RO_EXIT_CARRY): bits + row weights of the last H networks, newest first.  The newest network's
     // bits are still in rowmask (cleared in phase B only); older ones are folded back from their lists.
     if (flags & MGP_RO_EXIT_CARRY) {
@@ -1018,8 +1330,8 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             const int q = it / N, row = it - q * N;
             int hq = hs - q; hq = hq < 0 ? hq + H : hq;
             unsigned long long lo = 0ull, hi = 0ull;
-            if (q == 0) { lo = rowmask[2 * row]; hi = rowmask[2 * row + 1]; }
-            else {
+            if (q == 0 && !VL) { lo = rowmask[2 * row]; hi = rowmask[2 * row + 1]; }
+            else {                                            // (VL: the newest network's bits exist as its list only)
                 const unsigned char* lp = rlist + ((size_t)hq * N + row) * RS;
                 const int cnt = rcnt[hq * N + row];
                 for (int e = 0; e < cnt; ++e) {
@@ -1754,23 +2066,24 @@ static void take_launch_events(hipEvent_t* start, hipEvent_t* stop)
     mgp_tls_launch_events[0] = mgp_tls_launch_events[1] = nullptr;
 }
 
-template <int CN, int CK, bool FD, bool CL, bool CM = false, bool WBF = RO_BF16_CHAIN>
+template <int CN, int CK, bool FD, bool CL, bool CM = false, bool WBF = RO_BF16_CHAIN, bool VL = false>
 int launch_rollout(double* x, float* G, float* Xd, float* action, double* rewards, const RoParams& P,
                    const MgpFlockParams* p, int B, int K, int N, int T, unsigned long long dimsA, unsigned int dims8,
                    unsigned long long woffA, unsigned long long woffB, int n_layers, int lds, hipStream_t st,
                    const float* image, int image_floats, unsigned long long* carry, int flags, const MgpCollect* cl)
 {
+    if (VL) lds = ro_offsets(N, K).wl + ((image_floats * 4 + 15) & ~15) + ro_voffsets(N).total;   // candidate lists behind the image
     // (the attribute sticks to the function object of the CURRENT device: cached per (device, kernel), mgp_common.h)
-    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(rollout_kernel<CN, CK, FD, CL, CM, WBF>), (size_t)lds) != hipSuccess) return MGP_ELAUNCH;
+    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(rollout_kernel<CN, CK, FD, CL, CM, WBF, VL>), (size_t)lds) != hipSuccess) return MGP_ELAUNCH;
     MgpCollect none = {};
     hipEvent_t ev0, ev1;
     take_launch_events(&ev0, &ev1);
     if (ev0 != nullptr || ev1 != nullptr)
-        hipExtLaunchKernelGGL((rollout_kernel<CN, CK, FD, CL, CM, WBF>), dim3(B), dim3(RO_THREADS), lds, st, ev0, ev1, 0, x, G, Xd, action,
+        hipExtLaunchKernelGGL((rollout_kernel<CN, CK, FD, CL, CM, WBF, VL>), dim3(B), dim3(RO_THREADS), lds, st, ev0, ev1, 0, x, G, Xd, action,
                               rewards, P, *p, K, N, T, dimsA, dims8, woffA, woffB, n_layers, image, image_floats, carry, flags,
                               cl ? *cl : none);
     else
-        hipLaunchKernelGGL((rollout_kernel<CN, CK, FD, CL, CM, WBF>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K,
+        hipLaunchKernelGGL((rollout_kernel<CN, CK, FD, CL, CM, WBF, VL>), dim3(B), dim3(RO_THREADS), lds, st, x, G, Xd, action, rewards, P, *p, K,
                            N, T, dimsA, dims8, woffA, woffB, n_layers, image, image_floats, carry, flags, cl ? *cl : none);
     return mgp_launch_status();
 }
@@ -1974,7 +2287,10 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
     }
 #endif
 #undef RB_LAUNCH
-#define RO_LAUNCH_(CN_, CK_, FD_, CL_, WBF_) launch_rollout<CN_, CK_, FD_, CL_, false, WBF_>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags, cl)
+#define RO_LAUNCH_(CN_, CK_, FD_, CL_, WBF_) launch_rollout<CN_, CK_, FD_, CL_, false, WBF_, ((CN_) != 0 && !(FD_) && RO_VERLET && MGP_RO_VL_BUILD)>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags, cl)
+    // sized instantiations keep Verlet candidate lists behind the weight image (S1): where they would not fit the LDS, the
+    // run-time sized build (no lists) takes the shape
+    const bool vfit = !(RO_VERLET && MGP_RO_VL_BUILD) || lds + ro_voffsets(N).total + 16 <= RO_LDS_LIMIT;
 #ifdef MGP_RO_WIDE
 #define RO_LAUNCH(CN_, CK_, FD_, CL_) (P.bf ? RO_LAUNCH_(CN_, CK_, FD_, CL_, RO_BF16_CHAIN) : RO_LAUNCH_(CN_, CK_, FD_, CL_, false))
 #else
@@ -1984,27 +2300,27 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
 #ifdef MGP_RO_BASE
         if (N == 100 && K == 3 && !fade && n_layers == 3 && dims[1] == 32 && dims[2] == 32 && P.woff[1] == 2 * 64 * RO_WFS + 32 &&
             P.woff[2] == 2 * (2 * 64 * RO_WFS + 32))                                  // cfg/dagger.cfg, policy shape compiled in
-            return launch_rollout<100, 3, false, true, true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB,
+            return launch_rollout<100, 3, false, true, true, RO_BF16_CHAIN, RO_VERLET != 0>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB,
                                                              n_layers, lds, st, image, wt, carry, flags, cl);
 #endif
-        if (N == 100 && K == 3 && !fade) return RO_LAUNCH(100, 3, false, true);
+        if (N == 100 && K == 3 && !fade && vfit) return RO_LAUNCH(100, 3, false, true);
         return fade ? RO_LAUNCH(0, 0, true, true) : RO_LAUNCH(0, 0, false, true);
     }
 #ifdef MGP_RO_BASE
     // the reference's own policy shape at the headline (N, K): everything compile-time (cfg/dagger.cfg; BASELINE.json configs[0..1])
     if (N == 100 && K == 3 && !fade && n_layers == 3 && dims[1] == 32 && dims[2] == 32 && P.woff[1] == 2 * 64 * RO_WFS + 32 &&
         P.woff[2] == 2 * (2 * 64 * RO_WFS + 32))
-        return launch_rollout<100, 3, false, false, true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers,
+        return launch_rollout<100, 3, false, false, true, RO_BF16_CHAIN, RO_VERLET != 0>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers,
                                                           lds, st, image, wt, carry, flags, cl);
 #endif
-    if (N == 100 && K == 3 && !fade)   // the headline (N, K) with any covered policy, every build: compile-time addresses
+    if (N == 100 && K == 3 && !fade && vfit)   // the headline (N, K) with any covered policy, every build: compile-time addresses
         return RO_LAUNCH(100, 3, false, false);
 #ifdef MGP_RO_BASE
-    if (N == 100 && K == 2 && !fade)   // cfg/default.cfg, cloning.cfg, dagger_twoflocks.cfg
+    if (N == 100 && K == 2 && !fade && vfit)   // cfg/default.cfg, cloning.cfg, dagger_twoflocks.cfg
         return RO_LAUNCH(100, 2, false, false);
-    if (N == 100 && K == 4 && !fade)   // cfg/k.cfg
+    if (N == 100 && K == 4 && !fade && vfit)   // cfg/k.cfg
         return RO_LAUNCH(100, 4, false, false);
-    if (N == 100 && K == 1 && !fade)   // cfg/dagger_leader.cfg, k.cfg
+    if (N == 100 && K == 1 && !fade && vfit)   // cfg/dagger_leader.cfg, k.cfg
         return RO_LAUNCH(100, 1, false, false);
 #endif
     return fade ? RO_LAUNCH(0, 0, true, false) : RO_LAUNCH(0, 0, false, false);

@@ -216,6 +216,48 @@ def test_rollout_factored_handover_makes_chunkings_bit_identical(N, K, hidden, v
             assert np.array_equal(a, b), name
 
 
+@pytest.mark.parametrize("K", [1, 2, 3, 4])
+def test_rollout_candidate_lists_keep_the_exact_network(K):
+    """[r5] The sized builds find a step's network among Verlet candidates (csrc/rollout.hip, header: lists rebuilt when the
+    predicted displacements could bring an unlisted pair within the radius; exact pass for rows beyond the list capacity and
+    when the flock outruns the skin).  Whatever the lists do, the bits are the exact pass's: a long launch equals the same
+    steps taken ONE PER LAUNCH (a one-step launch never uses a list) bit for bit -- on a disc reset, with an escaper that
+    leaves the flock and comes back through it, with a clump of 80 agents inside one radius (rows beyond the capacity), and at
+    ten times the reset speed (lists that do not pay)."""
+    from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
+    N, B, T = 100, 4, 70
+    outs = []
+    for chunks in ([T], [1] * T, [33, 37], [2, 3, T - 5]):
+        rs, op, actor, sim, st = _make(N, K, (32, 32), B, seed=21)
+        rs = np.random.RandomState(5)
+        xs = np.stack([ofl.reset(rs, ofl.FlockParams(n_agents=N, init_mode='disc')) for _ in range(B)])
+        xs[1, 7, 0:2] = (9.0, 0.5); xs[1, 7, 2:4] = (-25.0, 0.3)          # an escaper far out, heading back through the flock
+        ang = rs.uniform(0, 2 * np.pi, 80); rad = 0.45 * np.sqrt(rs.uniform(0, 1, 80))
+        xs[2, :80, 0] = rad * np.cos(ang); xs[2, :80, 1] = rad * np.sin(ang)  # 80 agents inside one radius
+        xs[3, :, 2:4] *= 10.0                                                  # relative speeds the skin cannot follow
+        sim.set_state(xs)
+        st = type(st)('cuda', B, K, 6, N)
+        st.push(sim.network, sim.features)
+        rewards = torch.zeros((B, T), device='cuda', dtype=torch.float64)
+        action = torch.zeros((B, 1, 2, N), device='cuda')
+        t0 = 0
+        for c in chunks:
+            rw = torch.zeros((B, c), device='cuda', dtype=torch.float64)
+            assert policy_rollout(actor, sim, st, c, rewards=rw, action=action)
+            rewards[:, t0:t0 + c] = rw
+            t0 += c
+        outs.append(_snapshot(sim, st) + (action.cpu().numpy().copy(), rewards.cpu().numpy().copy(), sim.network.cpu().numpy()))
+    assert np.isfinite(outs[0][0]).all()
+    for other in outs[1:]:
+        for name, a, b in zip(('x', 'delay_gso', 'delay_state', 'last action', 'rewards', 'network'), outs[0], other):
+            assert np.array_equal(a, b), name
+    # and the network of the final state is the oracle's for the final positions (bit rows, row weights)
+    x_end = outs[0][0]
+    for b in range(B):
+        h = ofl.helpers(x_end[b], op)
+        assert K == 1 or np.array_equal(outs[0][5][b], h["network"].astype(np.float32)), b   # (K = 1 keeps no operator slice)
+
+
 def test_resident_plan_equals_policy_rollout():
     """ResidentPlan (the host side of a repeated launch bound once) launches the same kernel with the same arguments."""
     from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout, ResidentPlan

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p scratch
-F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w"
+F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -w"
 hipcc $F -o scratch/ro_prof tools/harness/ro_phase_prof.hip &
 hipcc $F -o scratch/ro_launch tools/harness/ro_launch_prof.hip &
 hipcc $F -o scratch/sp_prof tools/harness/sp_step_prof.hip &

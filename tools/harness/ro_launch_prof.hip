@@ -113,6 +113,7 @@ int main(int argc, char** argv)
             hipMemcpyAsync(carry, carry0, cb, hipMemcpyDeviceToDevice, nullptr);
             hipDeviceSynchronize();
             mgp_tls_launch_events[0] = e0; mgp_tls_launch_events[1] = e1;
+            { static std::vector<unsigned int> z(4096 * 4, 0u); hipMemcpyToSymbol(HIP_SYMBOL(mgp_ro_vstat), z.data(), z.size() * 4); }
             rc = mgp_rollout_steps_ex(x, G, Xd, W, bb, dims, 3, act, rew, &p, B, K, N, T, image, carry, fl, nullptr);
             if (rc) { printf("rc %d\n", rc); return 1; }
             hipDeviceSynchronize();
@@ -143,7 +144,9 @@ int main(int argc, char** argv)
             if (T == (getenv("RO_WG_DUMP_T") ? atoi(getenv("RO_WG_DUMP_T")) : 20)) {
                 FILE* f = fopen(dump, "w");
                 if (!f) { printf("cannot write %s\n", dump); return 1; }
-                fprintf(f, "# episode  duration_us (T = %d)  mean_degree  max_degree  first_entry_us\n", T);
+                std::vector<unsigned int> vs(4096 * 4);
+                hipMemcpyFromSymbol(vs.data(), HIP_SYMBOL(mgp_ro_vstat), vs.size() * 4);
+                fprintf(f, "# episode  duration_us (T = %d)  mean_degree  max_degree  first_entry_us  S1 modes decided inside the launch: cheap rebuild full\n", T);
                 for (int b = 0; b < B; ++b) {
                     int dsum = 0, dmax = 0;
                     for (int i = 0; i < N; ++i) {
@@ -156,7 +159,7 @@ int main(int argc, char** argv)
                         dsum += d; dmax = d > dmax ? d : dmax;
                     }
                     const long long* w = &hwall[(size_t)b * 8];
-                    fprintf(f, "%d %.2f %.2f %d %.2f\n", b, 0.01 * (w[6] - w[0]), (double)dsum / N, dmax, 0.01 * (w[7] - w[0]));
+                    fprintf(f, "%d %.2f %.2f %d %.2f  %u %u %u\n", b, 0.01 * (w[6] - w[0]), (double)dsum / N, dmax, 0.01 * (w[7] - w[0]), vs[b * 4], vs[b * 4 + 1], vs[b * 4 + 2]);
                 }
                 fclose(f);
             }

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #include <cmath>
 thread_local int mgp_tls_hip_error = 0;
 thread_local void* mgp_tls_launch_events[2] = {nullptr, nullptr};
@@ -84,6 +85,17 @@ int main(int argc, char** argv) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("%sB=%d N=%d K=%d T=%d resident rollout: %.1f us per launch, %.2f us per step -> %.3e agent-steps/s\n", use_carry ? "[carry] " : "", B, N, K, T,
            1e3 * ms / IT, 1e3 * ms / IT / T, (double)B * N * T / (1e-3 * ms / IT));
+    std::vector<unsigned int> vs(4096 * 4);
+    hipMemcpyFromSymbol(vs.data(), HIP_SYMBOL(mgp_ro_vstat), vs.size() * 4);
+    {
+        unsigned long long tot[3] = {0, 0, 0}; unsigned int mxr = 0, mxf = 0;
+        for (int b = 0; b < B && b < 4096; ++b) {
+            for (int m = 0; m < 3; ++m) tot[m] += vs[b * 4 + m];
+            mxr = std::max(mxr, vs[b * 4 + 1]); mxf = std::max(mxf, vs[b * 4 + 2]);
+        }
+        printf("S1 modes over all launches (cheap / rebuild / full): workgroup 0 %u / %u / %u; all workgroups %llu / %llu / %llu; most rebuilds in one workgroup %u, most full steps %u\n",
+               vs[0], vs[1], vs[2], tot[0], tot[1], tot[2], mxr, mxf);
+    }
     unsigned long long st[512];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(mgp_ro_stamps), sizeof(st));
     const char* names[] = {"step start", "A done (barrier)", "B hidden layers (waves 0-6) + G_1 expansion (waves 7-15) done (barrier)", "B+C: hidden layers, output layer, integration (waves 0-6) / bit clearing (waves 7-15) done (barrier)",
