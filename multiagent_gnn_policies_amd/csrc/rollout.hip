@@ -79,6 +79,13 @@ template <int CK> struct RoGatherUnroll { static constexpr int value = CK ? 4 : 
 #ifndef RO_VERLET
 #define RO_VERLET 1
 #endif
+#ifndef RO_FEAT_PAIR
+#define RO_FEAT_PAIR 0                    // feature pass of S2: two list entries per trip with their LDS reads in flight together
+                                          // (measured: the feature waves end 0.2k cycles earlier, the phase -- bound by the gather waves -- does not)
+#endif
+#ifndef RO_FEAT_FMA
+#define RO_FEAT_FMA 1
+#endif
 #ifndef MGP_RO_VL_BUILD
 #if defined(MGP_RO_WIDE) || defined(MGP_RO_X128)
 #define MGP_RO_VL_BUILD 0                 // (the 64- and 128-wide builds: lists not enabled yet)
@@ -1235,6 +1242,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             }
             if (lane == 0) { vflag[1] = age; vflag[2] = backoff; }
             if (lane == 0) vflag[0] = next;
+            RO_STAMP(24);
 #ifdef MGP_RO_PROFILE
             if (blockIdx.x < 4096 && lane == 0) atomicAdd(&mgp_ro_vstat[blockIdx.x * 4 + next], 1u);
 #endif
@@ -1247,24 +1255,58 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 cnt = rc_new[fr];
                 const unsigned char* lp = rl_new + fr * RS;
                 const double xi = spx[fr], yi = spy[fr], vxi = svx[fr], vyi = svy[fr];
-                for (int e = fq; e < cnt; e += 4) {
-                    const int j = lp[e];
-                    const double dx = xi - spx[j], dy = yi - spy[j];
+                // one neighbour's terms.  q = 1 / r2 to within an ulp: fp32 reciprocal seed (1 ulp of fp32), two Newton steps in fp64
+                // -- five instructions where the correctly rounded division takes eleven (measured: 1 % of the step); the feature
+                // sums already differ from the oracle's by their summation order (1e-11), the tests hold them to 1e-6
+                auto term = [&](const double xj, const double yj, const double vxj, const double vyj) {
+                    const double dx = xi - xj, dy = yi - yj;
                     const double r2 = dx * dx + dy * dy;
-                    // q = 1 / r2 to within an ulp: fp32 reciprocal seed (1 ulp of fp32), two Newton steps in fp64 -- five
-                    // instructions where the correctly rounded division takes eleven (measured: 1 % of the step); the feature
-                    // sums already differ from the oracle's by their summation order (1e-11), the tests hold them to 1e-6
                     double q = (double)__builtin_amdgcn_rcpf((float)r2);
                     q = __builtin_fma(q, __builtin_fma(-r2, q, 1.0), q);
                     q = __builtin_fma(q, __builtin_fma(-r2, q, 1.0), q);
                     const double qq = q * q;
-                    f0 += vxi - svx[j];
+#if RO_FEAT_FMA
+                    // [r5] fused multiply-adds for the four potential terms, and the velocity term as deg v_i - sum v_j (formed behind
+                    // the loop): 23 instead of 29 fp64 instructions per neighbour; the sums move by ~1e-16 of their terms (tests: 1e-6)
+                    f0 += vxj;
+                    f1 = __builtin_fma(dx, qq, f1);
+                    f2 = __builtin_fma(dx, q, f2);
+                    f3 += vyj;
+                    f4 = __builtin_fma(dy, qq, f4);
+                    f5 = __builtin_fma(dy, q, f5);
+#else
+                    f0 += vxi - vxj;
                     f1 += dx * qq;
                     f2 += dx * q;
-                    f3 += vyi - svy[j];
+                    f3 += vyi - vyj;
                     f4 += dy * qq;
                     f5 += dy * q;
+#endif
+                };
+                int e = fq;
+#if RO_FEAT_PAIR
+                // [r5] two entries per trip with both entries' LDS reads in flight together (a trip is a chain of two LDS round trips
+                // and thirteen dependent fp64 instructions: the phase waits on latency as much as on issue); the lane's entries are
+                // still added in list order
+                for (; e + 4 < cnt; e += 8) {
+                    const int ja = lp[e], jb = lp[e + 4];
+                    const double xa = spx[ja], ya = spy[ja], vxa = svx[ja], vya = svy[ja];
+                    const double xb2 = spx[jb], yb2 = spy[jb], vxb = svx[jb], vyb = svy[jb];
+                    term(xa, ya, vxa, vya);
+                    term(xb2, yb2, vxb, vyb);
                 }
+#endif
+                for (; e < cnt; e += 4) {
+                    const int j = lp[e];
+                    term(spx[j], spy[j], svx[j], svy[j]);
+                }
+#if RO_FEAT_FMA
+                {   // this lane's share of sum_j (v_i - v_j): (its entries) v_i - sum v_j
+                    const double mine = (double)((cnt - fq + 3) >> 2);          // entries fq, fq + 4, ... < cnt
+                    f0 = __builtin_fma(mine, vxi, -f0);
+                    f3 = __builtin_fma(mine, vyi, -f3);
+                }
+#endif
             }
             RO_STAMP(8);
             f0 += dpp_d<0xB1>(f0); f1 += dpp_d<0xB1>(f1); f2 += dpp_d<0xB1>(f2);

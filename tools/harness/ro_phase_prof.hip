@@ -100,14 +100,14 @@ int main(int argc, char** argv) {
     hipMemcpyFromSymbol(st, HIP_SYMBOL(mgp_ro_stamps), sizeof(st));
     const char* names[] = {"step start", "A done (barrier)", "B hidden layers (waves 0-6) + G_1 expansion (waves 7-15) done (barrier)", "B+C: hidden layers, output layer, integration (waves 0-6) / bit clearing (waves 7-15) done (barrier)",
                            "D2/D3 done (barrier)", "step done", "A: first gather stage of this wave done", "D1: membership bits done (barrier)",
-                           "D2/D3: lists + neighbour feature terms done (waves 0-6)", "C: max published (atomic issued)", "D: lists written", "E: rows of slices >= 2 done (barrier)", "B: layer 0 tile done (before barrier)", "B: layer 1 tile done", "C: output layer + quad sums done", "C: integrated, coordinates stored", "S1: pair tests done", "S1: fallback / fading done", "S1: row word combined", "S1: list written", "S2: gather group loop done", "S2: reward wave done", "S2: features group done", "S2: gather group done"};
-    const int order[] = {0, 6, 1, 12, 13, 14, 15, 3, 16, 17, 18, 19, 7, 8, 22, 20, 23, 21, 4, 5};
-    printf("cycles since step start, lane 0 of waves 0 1 2 3 4 5 6 | 7 9 13 15\n");
-    const int wv[] = {0, 1, 2, 3, 4, 5, 6, 7, 9, 13, 15};
-    for (int oi = 0; oi < 20; ++oi) {
+                           "D2/D3: lists + neighbour feature terms done (waves 0-6)", "C: max published (atomic issued)", "D: lists written", "E: rows of slices >= 2 done (barrier)", "B: layer 0 tile done (before barrier)", "B: layer 1 tile done", "C: output layer + quad sums done", "C: integrated, coordinates stored", "S1: pair tests done", "S1: fallback / fading done", "S1: row word combined", "S1: list written", "S2: gather group loop done", "S2: reward wave done", "S2: features group done", "S2: gather group done", "S2: Verlet helper wave done"};
+    const int order[] = {0, 6, 1, 12, 13, 14, 15, 3, 16, 17, 18, 19, 7, 8, 22, 20, 23, 21, 24, 4, 5};
+    printf("cycles since step start, lane 0 of waves 0 1 2 3 4 5 6 | 7 9 12 13 14 15\n");
+    const int wv[] = {0, 1, 2, 3, 4, 5, 6, 7, 9, 12, 13, 14, 15};
+    for (int oi = 0; oi < 21; ++oi) {
         const int i = order[oi];
         printf("  stamp %2d :", i);
-        for (int w = 0; w < 11; ++w) {
+        for (int w = 0; w < 13; ++w) {
             const long long d = (long long)(st[wv[w] * 32 + i] - st[0]);
             if (d > -100000 && d < 10000000) printf(" %6lld", d); else printf("      -");
         }
