@@ -15,6 +15,7 @@
 // workgroup writes its rows of the network matrix in one flat, coalesced sweep.  For N <= 128 the double
 // integrator and the velocity-variance reward are fused in front (one workgroup == one episode);
 // larger N runs flock_integrate first.
+#include <cstdlib>
 #include "mgp_device.h"
 
 namespace {
@@ -462,6 +463,346 @@ int launch_flock(double* x, double* x_out, const float* u, long su_agent, long s
     return launch_step<false, FP_THREADS, FP_ROWS, FP_PIECES>(x, x, u, su_agent, su_axis, os, p, B, N, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// [r5] mgp_flock_step_advance for N <= 128: ONE 1024-thread workgroup per episode.
+// The row-tiled kernel above runs five workgroups per episode (four row tiles + the reward), each of which loads and integrates
+// the whole episode, tests its rows against every agent in fp64, meets its j-pieces in LDS and then gathers the product rows
+// G_j = A_t . G_{j-1}(prev) from L2 one dependent round trip per four rows: 21 us per 256 episodes at N = 100, 0.21 of the HBM
+// rate on its 35.8 MB, for four rounds.  Here the episode's chain runs once -- integration, the membership test of the resident
+// kernel (an fp32 test on coordinates relative to agent 0 decides every pair that clears the radius by a proven error band, the
+// spec's fp64 expression the rest: the bits are the oracle's), fp64 feature terms of actual neighbours -- while the source
+// slice G_{j-1}(prev) streams into LDS with coalesced 16-byte loads; the product rows are then gathered from LDS, and all
+// stores (network rows, product rows, features, delay line, agent states) are flat coalesced sweeps.
+// Bit-identical to the row-tiled kernel (tests/test_gpu_kernels.py::test_fused_sim_state_kernel_equals_two_kernel_protocol):
+// same per-axis integration, the same j-pieces (eight per row, ceil(N / 8) candidates each) summed in ascending order, one true
+// division per neighbour, the same reduction tree for the velocity sums, product rows accumulated along the ascending list.
+// (Measured and dropped, LAB_NOTES.md round 5: two 512-thread workgroups per episode, each with half the rows -- both stage the
+//  whole source slice, 20 MB instead of 10 through the CUs' memory pipelines in front of the agent states: 15.9 us against 13.4.)
+constexpr int FA_THREADS = 1024;
+constexpr int FA_WAVES = FA_THREADS / 64;
+
+struct FaOff { int pos, sxy, bits, wrow, rcnt, rlist, stage, total; };
+__host__ __device__ inline int fa_take(int& off, int bytes) { const int o = off; off += (bytes + 15) & ~15; return o; }
+__host__ __device__ inline int fa_list_stride(int N) { const int w = (N + 3) >> 2; return 4 * (w | 1); }
+__host__ __device__ inline FaOff fa_offsets(int N, int K)
+{
+    FaOff c = {};
+    int off = 0;
+    c.pos = fa_take(off, (4 * N + 2) * 8);                  // double px, py, vx, vy [4][N] + reference point
+    c.sxy = fa_take(off, N * 8);                            // float2 [N] coordinates relative to the reference point
+    c.bits = fa_take(off, N * 16);                          // u64 [N][2] membership bits of the new network
+    c.wrow = fa_take(off, N * 8);                           // double [N] row weights
+    c.rcnt = fa_take(off, N * 4);
+    c.rlist = fa_take(off, N * fa_list_stride(N));          // u8 [N][RS] ascending neighbour lists
+    c.stage = fa_take(off, K > 2 ? N * N * 4 : 0);          // float [N][N]: one source slice G_{j-1}(prev)
+    c.total = off;
+    return c;
+}
+
+// 16 bytes per active lane straight into LDS: LDS[dst_uniform + 16 * lane] = *src (global_load_lds_dwordx4; M0 carries the LDS
+// base; asm rather than the builtin, see actor_fused.hip).  hipcc does not count it: the caller waits (s_waitcnt vmcnt(0)) before
+// the barrier in front of the first read, and issues it BEHIND the last load whose data it waits for itself (loads return in order).
+__device__ __forceinline__ void fa_lds_dma16(const void* src, const void* dst_uniform)
+{
+    const unsigned int base = __builtin_amdgcn_readfirstlane((unsigned int)reinterpret_cast<uintptr_t>(dst_uniform));
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(base), "v"(src) : "memory", "m0");
+}
+
+// four entries per trip: the list bytes, then the four source rows in flight together, then the multiply-adds in list order
+// (entries past the end re-read a valid row with weight 0: fma(0, g, acc) == acc; a row's list bytes are valid row indices)
+__device__ __forceinline__ void fa_gather(float4& acc, const float w, const int cnt, const unsigned char* lp, const float4* stage4,
+                                          const int n4, const int c4)
+{
+    for (int q = 0; q < cnt; q += 4) {
+        int m[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) m[d] = (q + d < cnt) ? (int)lp[q + d] : 0;
+        float4 g[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) g[d] = stage4[m[d] * n4 + c4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const float wd = (q + d < cnt) ? w : 0.f;
+            acc.x = fmaf(wd, g[d].x, acc.x); acc.y = fmaf(wd, g[d].y, acc.y); acc.z = fmaf(wd, g[d].z, acc.z); acc.w = fmaf(wd, g[d].w, acc.w);
+        }
+    }
+}
+
+__global__ __launch_bounds__(FA_THREADS)
+void flock_advance_kernel(const double* __restrict__ x, double* __restrict__ xo, const float* __restrict__ u, long su_agent,
+                          long su_axis, FlockOut o, MgpFlockParams p, int N)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+    __shared__ double tot_sh[2];
+    const int K = o.K;
+    const FaOff cv = fa_offsets(N, K);
+    double* spx = reinterpret_cast<double*>(fsm + cv.pos);
+    double* spy = spx + N; double* svx = spx + 2 * N; double* svy = spx + 3 * N;
+    float2* sxy = reinterpret_cast<float2*>(fsm + cv.sxy);
+    unsigned long long* rowmask = reinterpret_cast<unsigned long long*>(fsm + cv.bits);
+    double* wrow = reinterpret_cast<double*>(fsm + cv.wrow);
+    int* rcnt = reinterpret_cast<int*>(fsm + cv.rcnt);
+    unsigned char* rlist = fsm + cv.rlist;
+    unsigned char* stage = fsm + cv.stage;
+    const float4* stage4 = reinterpret_cast<const float4*>(stage);
+    const int RS = fa_list_stride(N);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t NN = (size_t)N * N;
+    const int n4 = N >> 2, nn4 = N * n4;                    // float4 per row / per slice
+    const double* xb = x + (size_t)b * N * 4;
+    double* xob = xo + (size_t)b * N * 4;
+    const float* Gp = o.Gp + (size_t)b * K * NN;
+    float* Gn = o.Gn + (size_t)b * K * NN;
+    const bool prod = K > 2 && o.has_prev;
+    // source slice `sl` of G_prev -> LDS, 1 KB per wave and request, no registers, nothing to wait for until it is read; by the
+    // UPPER eight waves: hipcc does not count these requests, loads return in order, so a wave that waited for a load of its own
+    // behind them would wait for the whole slice -- the upper waves load nothing else
+    constexpr int FA_DMA_WAVES = 8, FA_DMA_W0 = FA_WAVES - FA_DMA_WAVES;
+    auto stage_slice = [&](const int sl) {
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(Gp + (size_t)sl * NN);
+        const int bytes = (int)NN * 4;
+        if (wave >= FA_DMA_W0 && wave < FA_DMA_W0 + FA_DMA_WAVES)
+            for (int c = (wave - FA_DMA_W0) * 1024; c < bytes; c += FA_DMA_WAVES * 1024)
+                if (c + lane * 16 < bytes) fa_lds_dma16(src + c + lane * 16, stage + c);
+    };
+
+    FL_STAMP(8);
+    if (prod) stage_slice(1);                               // first thing: the slice streams in behind everything below
+    // ---- agent states and the delay line's taps are requested together (the lower eight waves); thread i owns agent i (the
+    //      expression tree of integrate_one: bit-exact given the action)
+    double px = 0.0, py = 0.0, vx = 0.0, vy = 0.0, cx = 0.0, cy = 0.0;
+    if (tid < N) {
+        const double2 pa = *reinterpret_cast<const double2*>(xb + tid * 4), pb = *reinterpret_cast<const double2*>(xb + tid * 4 + 2);
+        px = pa.x; py = pa.y; vx = pb.x; vy = pb.y;
+        // reference point of the fp32 membership test: agent 0's position BEFORE the step (any point is valid; this one needs no
+        // exchange between threads: rollout.hip "Exact membership from an fp32 test")
+        const double2 pc = *reinterpret_cast<const double2*>(xb);
+        cx = pc.x; cy = pc.y;
+    }
+    const long tap = 6L * N, per = (long)K * tap;
+    constexpr int XT_ = 64 * FA_DMA_W0;                     // threads that copy the delay line: the waves below the DMA waves
+    constexpr int XP = 3072 / XT_;                          // elements per thread: (K - 1) 6 N <= 4 * 6 * 128 = 3072
+    float xpv[XP];
+#pragma unroll
+    for (int r = 0; r < XP; ++r) {
+        const long e = tap + tid + (long)r * XT_;
+        xpv[r] = (K > 1 && o.has_prev && tid < XT_ && e < per) ? o.Xp[(long)b * per + e - tap] : 0.f;
+    }
+    if (tid < N) {
+        integrate_one(px, py, vx, vy, u + (size_t)b * N * 2 + (size_t)tid * su_agent, su_axis, tid < p.n_leaders, p);
+        xob[tid * 4 + 0] = px; xob[tid * 4 + 1] = py; xob[tid * 4 + 2] = vx; xob[tid * 4 + 3] = vy;
+        spx[tid] = px; spy[tid] = py; svx[tid] = vx; svy[tid] = vy;
+        sxy[tid] = make_float2((float)(px - cx), (float)(py - cy));
+    }
+    if (K > 1) {                                            // delay line: taps 1..K-1 <- previous taps 0..K-2
+#pragma unroll
+        for (int r = 0; r < XP; ++r) {
+            const long e = tap + tid + (long)r * XT_;
+            if (tid < XT_ && e < per) o.Xn[(long)b * per + e] = xpv[r];
+        }
+    }
+    __syncthreads();
+    FL_STAMP(9);
+    FL_STAMP(10);
+    // ---- membership + features: eight lanes per row, lane `piece` owns candidates j0 .. j0 + jh - 1 (the row-tiled kernel's
+    //      pieces).  Meanwhile the last wave forms the episode sums in the reduction tree of the row-tiled kernel (256 threads
+    //      there: agent i in lane i % 64 of wave i / 64, butterfly inside the wave, wave sums added in order).
+    const int pi = tid >> 3, piece = tid & 7;
+    const int jh = (N + 7) >> 3;
+    const double R2 = p.comm_radius2;
+    const float R2f = (float)R2, Rf = sqrtf(R2f);
+    const bool need_cent = o.centralized && o.expert != nullptr;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;    // the row's feature sums (piece-0 lanes)
+    if (wave == FA_WAVES - 1 && (o.reward != nullptr || need_cent)) {
+        double sx[4], sy[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int i = lane + 64 * w;
+            sx[w] = mgp_wave_sum(i < N ? svx[i] : 0.0);
+            sy[w] = mgp_wave_sum(i < N ? svy[i] : 0.0);
+        }
+        double tvx = 0.0, tvy = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { tvx += sx[w]; tvy += sy[w]; }
+        if (lane == 0) { tot_sh[0] = tvx; tot_sh[1] = tvy; }
+        if (o.reward != nullptr) {
+            const double mx = tvx / (double)N, my = tvy / (double)N;
+            double dsum = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int i = lane + 64 * w;
+                double dv = 0.0;
+                if (i < N) { const double ex = svx[i] - mx, ey = svy[i] - my; dv += ex * ex + ey * ey; }
+                dsum += mgp_wave_sum(dv);
+            }
+            if (lane == 0) o.reward[b] = -1.0 * (dsum / (double)N) * p.reward_scale;
+        }
+    }
+    if (pi < N) {
+        const float2 si = sxy[pi];
+        const int j0 = piece * jh, nd = max(0, min(jh, N - j0));
+        const float M = fmaxf(fabsf(si.x), fabsf(si.y)) + 2.0f * Rf;
+        const float band = Rf * (16.f * M + 16.f * Rf) * 5.9604645e-8f + R2f * 1.1920929e-7f;
+        const float t_in = R2f - band, t_out = R2f + band;
+        // sign bits instead of compare / select pairs: the sign of r2 - t_in says "clearly inside", the sign of t_out - r2 "clearly
+        // outside"; v_alignbit shifts each into a mask (test k ends in bit 15 - k of a 16-test pass; rollout.hip ro_s1_masks)
+        unsigned int im = 0u, om = 0u;
+#pragma unroll
+        for (int c0 = 0; c0 < 16; c0 += 8) {                // jh <= 16: two groups of eight, every read of a group in flight together
+            float2 sj[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sj[q] = sxy[min(j0 + c0 + q, N - 1)];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float dx = si.x - sj[q].x, dy = si.y - sj[q].y;
+                const float r2 = fmaf(dy, dy, dx * dx);
+                im = __builtin_amdgcn_alignbit(im, __float_as_uint(r2 - t_in), 31);
+                om = __builtin_amdgcn_alignbit(om, __float_as_uint(t_out - r2), 31);
+            }
+        }
+        unsigned int in_m = __builtin_bitreverse32(im) >> 16;                 // test k -> bit k
+        unsigned int unc_m = ~(__builtin_bitreverse32(om) >> 16) & ~in_m & 0xFFFFu;
+        unsigned int valid = (1u << nd) - 1u;               // (candidates beyond the piece re-tested row N - 1)
+        const int self = pi - j0;
+        if (self >= 0 && self < nd) valid &= ~(1u << self);
+        in_m &= valid; unc_m &= valid;
+        const double xi = spx[pi], yi = spy[pi], vxi = svx[pi], vyi = svy[pi];
+        while (unc_m) {                                     // rare: the spec's own fp64 expression decides
+            const int q = __builtin_ctz(unc_m);
+            unc_m &= unc_m - 1u;
+            const double dx = xi - spx[j0 + q], dy = yi - spy[j0 + q];
+            if (dx * dx + dy * dy < R2) in_m |= 1u << q;
+        }
+        if (p.link_drop != 0u) {                            // FlockingStochastic-v0: faded links leave the mask
+            unsigned int mq = in_m;
+            const unsigned int wi = fade_word(xi, yi);
+            while (mq) {
+                const int q = __builtin_ctz(mq);
+                mq &= mq - 1u;
+                if (!link_up(p, pi, j0 + q, N, wi, fade_word(spx[j0 + q], spy[j0 + q]))) in_m &= ~(1u << q);
+            }
+        }
+        // the piece's feature terms, ascending j, one true division per neighbour (the row-tiled kernel's expression)
+        double f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0;
+        {
+            unsigned int mq = in_m;
+            while (mq) {
+                const int j = j0 + __builtin_ctz(mq);
+                mq &= mq - 1u;
+                const double dx = xi - spx[j], dy = yi - spy[j];
+                const double r2 = dx * dx + dy * dy;
+                const double q = 1.0 / r2;
+                const double qq = q * q;
+                f0 += vxi - svx[j];
+                f1 += dx * qq;
+                f2 += dx * q;
+                f3 += vyi - svy[j];
+                f4 += dy * qq;
+                f5 += dy * q;
+            }
+        }
+        // the row's 128-bit word, OR-combined over its eight lanes on the DPP path (every lane gets it)
+        unsigned long long lo = 0ull, hi = 0ull;
+        if (j0 < 64) {
+            lo = (unsigned long long)in_m << j0;
+            if (j0 > 32) hi = (unsigned long long)in_m >> (64 - j0);
+        } else {
+            hi = (unsigned long long)in_m << (j0 - 64);
+        }
+        unsigned int w0 = (unsigned int)lo, w1 = (unsigned int)(lo >> 32), w2 = (unsigned int)hi, w3 = (unsigned int)(hi >> 32);
+#define FA_OR(c) w0 |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)w0, c, 0xF, 0xF, true); w1 |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)w1, c, 0xF, 0xF, true); \
+                 w2 |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)w2, c, 0xF, 0xF, true); w3 |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)w3, c, 0xF, 0xF, true);
+        FA_OR(0xB1) FA_OR(0x4E) FA_OR(0x141)
+#undef FA_OR
+        const unsigned long long flo = ((unsigned long long)w1 << 32) | w0, fhi = ((unsigned long long)w3 << 32) | w2;
+        int pos;
+        if (j0 < 64) pos = __popcll(flo & ((1ull << j0) - 1ull));
+        else pos = __popcll(flo) + __popcll(fhi & ((1ull << (j0 - 64)) - 1ull));
+        unsigned char* lp = rlist + pi * RS;
+        {
+            unsigned int mq = in_m;
+            while (mq) { lp[pos++] = (unsigned char)(j0 + __builtin_ctz(mq)); mq &= mq - 1u; }
+        }
+        // pieces 1 .. 7 are added to piece 0's sums in ascending order (row_shl:s brings lane + s's value; the sums of the
+        // other lanes are not used)
+#define FA_DSHL(v, c) __builtin_bit_cast(double, ((unsigned long long)(unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(__builtin_bit_cast(unsigned long long, v) >> 32), c, 0xF, 0xF, true) << 32) | \
+                                                  (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)__builtin_bit_cast(unsigned long long, v), c, 0xF, 0xF, true))
+#define FA_CHAIN(a, f) a = f; a += FA_DSHL(f, 0x101); a += FA_DSHL(f, 0x102); a += FA_DSHL(f, 0x103); a += FA_DSHL(f, 0x104); \
+                       a += FA_DSHL(f, 0x105); a += FA_DSHL(f, 0x106); a += FA_DSHL(f, 0x107);
+        FA_CHAIN(a0, f0) FA_CHAIN(a1, f1) FA_CHAIN(a2, f2) FA_CHAIN(a3, f3) FA_CHAIN(a4, f4) FA_CHAIN(a5, f5)
+#undef FA_CHAIN
+#undef FA_DSHL
+        if (piece == 0) {
+            const int cnt = __popcll(flo) + __popcll(fhi);
+            const double deg = (double)cnt;
+            wrow[pi] = p.mean_pooling ? 1.0 / (deg == 0.0 ? 1.0 : deg) : 1.0;
+            rcnt[pi] = cnt;
+            rowmask[2 * pi] = flo; rowmask[2 * pi + 1] = fhi;
+            if (o.feat != nullptr) {
+                float* fb = o.feat + (size_t)b * o.sFb + pi;
+                fb[0 * (size_t)N] = (float)a0; fb[1 * (size_t)N] = (float)a1; fb[2 * (size_t)N] = (float)a2;
+                fb[3 * (size_t)N] = (float)a3; fb[4 * (size_t)N] = (float)a4; fb[5 * (size_t)N] = (float)a5;
+            }
+        }
+    }
+    if (prod) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the source slice has landed
+    __syncthreads();
+    FL_STAMP(11);
+    // expert action, a closed form of the observation (the centralised form needs the episode's velocity sums: behind the barrier)
+    if (o.expert != nullptr && pi < N && piece == 0) {
+        double tvx = a0, tvy = a3;
+        if (o.centralized) {
+            tvx = (double)N * svx[pi] - tot_sh[0];
+            tvy = (double)N * svy[pi] - tot_sh[1];
+        }
+        const double ux = clipd(-tvx - (2.0 * a2 - 2.0 * a1), -p.ctrl_clip, p.ctrl_clip) * p.ctrl_gain;
+        const double uy = clipd(-tvy - (2.0 * a5 - 2.0 * a4), -p.ctrl_clip, p.ctrl_clip) * p.ctrl_gain;
+        o.expert[((size_t)b * N + pi) * 2 + 0] = (float)ux; o.expert[((size_t)b * N + pi) * 2 + 1] = (float)uy;
+    }
+    // ---- network rows (slice 1 of G_next) from the bit words, and the product rows G_next[j] = A_t . G_prev[j - 1], j >= 2:
+    //      row i = w_i x (sum over i's ascending list of the source rows), one fused multiply-add per entry in list order (the
+    //      arithmetic of gso_rows_half_kernel), source rows in LDS.  One flat sweep of float4 items (row, four columns) per slice.
+    for (int j = 1; j < K; ++j) {
+        float* Gj = Gn + (size_t)j * NN;
+        for (int e = tid; e < nn4; e += FA_THREADS) {
+            const int ri = e / n4, c4 = e - ri * n4;
+            const float w = o.has_prev ? (float)wrow[ri] : 0.f;    // (an episode's first state: taps >= 1 read zero)
+            if (j == 1) {
+                const int c0 = c4 << 2;
+                const unsigned long long wb = rowmask[2 * ri + (c0 >> 6)];
+                const unsigned int nib = (unsigned int)(wb >> (c0 & 63)) & 0xFu;     // (c0 is a multiple of 4: the nibble does not straddle words)
+                *reinterpret_cast<float4*>(Gj + (size_t)e * 4) = make_float4((nib & 1u) ? w : 0.f, (nib & 2u) ? w : 0.f, (nib & 4u) ? w : 0.f, (nib & 8u) ? w : 0.f);
+                if (K > 2) {                                // the same item of the first product row right behind it
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (prod) fa_gather(acc, w, rcnt[ri], rlist + ri * RS, stage4, n4, c4);
+                    *reinterpret_cast<float4*>(Gj + NN + (size_t)e * 4) = acc;
+                }
+            } else if (j > 2) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (prod) fa_gather(acc, w, rcnt[ri], rlist + ri * RS, stage4, n4, c4);
+                *reinterpret_cast<float4*>(Gj + (size_t)e * 4) = acc;
+            }
+        }
+        if (j == 1) FL_STAMP(12);
+        if (prod && j >= 2 && j + 1 < K) {                  // the next source slice (K >= 4): product j + 1 reads G_prev[j]
+            __syncthreads();                                // every gather of this slice done
+            stage_slice(j);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    FL_STAMP(13);
+}
+
+int launch_advance_episode(const double* x, double* xo, const float* u, long su_agent, long su_axis, const FlockOut& o,
+                           const MgpFlockParams* p, int B, int N, hipStream_t st)
+{
+    const int lds = fa_offsets(N, o.K).total;
+    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(flock_advance_kernel), (size_t)lds) != hipSuccess) return MGP_ELAUNCH;
+    hipLaunchKernelGGL(flock_advance_kernel, dim3(B), dim3(FA_THREADS), lds, st, x, xo, u, su_agent, su_axis, o, *p, N);
+    return mgp_launch_status();
+}
+
 // Acceptance test of reset candidates (FLOCK-SPEC v1 section 3: an episode starts from the first draw whose minimum degree is
 // >= min_degree and whose closest pair is >= min_dist_thresh apart -- at N = 100 about one draw in 140 passes, and the host's
 // numpy test of one draw, a 100 x 100 fp64 distance matrix, took 130 us: 19 ms per episode reset, 8.4 of the 10.9 s of a whole
@@ -587,6 +928,10 @@ extern "C" int mgp_flock_step_advance(double* x, double* x_out, const float* u, 
                   reward != nullptr ? 1 : 0,
                   (long)K * NN, (long)K * 6 * N, 1, K, has_prev ? 1 : 0, G_prev, G_next, Xd_prev, Xd_next, 0};
     mgp_clear_error();
+    // one workgroup per episode (flock_advance_kernel) unless MGP_FLOCK_ADVANCE_TILED asks for the row-tiled kernel of rounds 1-4
+    static const bool tiled = getenv("MGP_FLOCK_ADVANCE_TILED") != nullptr && getenv("MGP_FLOCK_ADVANCE_TILED")[0] == '1';
+    if (!tiled && fa_offsets(N, K).total <= 160 * 1024 && mgp_aligned16(x))      // (the agent states are read as 16-byte pairs)
+        return launch_advance_episode(x, x_out, u, su_agent, su_axis, o, p, B, N, static_cast<hipStream_t>(stream));
     return launch_step<true, FP_THREADS, FP_ROWS, FP_PIECES>(x, x_out, u, su_agent, su_axis, o, p, B, N,
                                                   static_cast<hipStream_t>(stream));
 }

@@ -264,6 +264,8 @@ def test_bench_single_gpu_contract_and_paths(n, k, paths):
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                 'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
         assert key in d, key
+    if 'resident' in paths:
+        paths = paths | {'resident_dense_exit'}
     assert set(d['paths']) == paths and d['config']['state_finite']
     headline = 'factored' if 'factored' in paths else ('resident' if 'resident' in paths else 'two_launch')   # by shape
     assert d['value'] == d['paths'][headline]['value']
@@ -275,6 +277,14 @@ def test_bench_single_gpu_contract_and_paths(n, k, paths):
         assert r_['ms_per_step'] == d['ms_per_step'] and r_['ms_per_step_event_pass'] > 0
         assert 0 < r_['launch_ms_hip_events'] <= 1.05 * r_['ms_per_step_event_pass'] * d['steps']
         assert abs(d['roofline']['avg_launch_ms'] - r_['launch_ms_hip_events']) <= 1e-9 + 1e-6 * r_['launch_ms_hip_events']
+        # [r5] the line says what the timed kernel defers and what bounds it: the dense slices (RO_SKIP_DENSE) with the same region
+        # timed with them rebuilt inside the launch, vector-issue as the bound with the matrix figure beside it, a median of repeats
+        assert 'MGP_RO_SKIP_DENSE' in d['config']['step_path'] and 'resident_dense_exit' in d['config']['step_path']
+        assert d['paths']['resident_dense_exit']['ms_per_step'] > 0.9 * r_['ms_per_step']
+        assert d['roofline']['bound'] == 'valu' and {'achieved', 'peak', 'frac'} <= set(d['roofline']['mfma'])
+        vm = d['value_median_of']
+        assert vm['n'] >= 3 and len(vm['samples_ms_per_step']) == vm['n'] and vm['samples_ms_per_step'][0] == d['ms_per_step']
+        assert min(vm['samples_ms_per_step']) <= vm['ms_per_step'] <= max(vm['samples_ms_per_step'])
 
 
 def test_device_replay_ring_and_sampling():

@@ -49,5 +49,8 @@ int main(int argc, char** argv) {
     hipMemcpyFromSymbol(st, HIP_SYMBOL(mgp_fl_stamps), sizeof(st));
     const char* names[] = {"start", "x/u loaded + integrated (barrier)", "reward sums done (wg 0)", "pairwise phases done", "partials combined, features/expert written", "barrier before the row phases", "delayed-GSO rows written", "network rows written"};
     for (int i = 0; i < 8; ++i) printf("  stamp %d : %8llu  %s\n", i, st[i] - st[0], names[i]);
+    const char* names2[] = {"start", "agents integrated, source slice in LDS (barrier)", "episode sums, relative coordinates (barrier)", "membership, features, lists (barrier)", "network rows stored", "product rows stored"};
+    printf("flock_advance_kernel (one workgroup per episode), workgroup 0:\n");
+    for (int i = 8; i < 14; ++i) printf("  stamp %d : %8lld  %s\n", i, (long long)(st[i] - st[8]), names2[i - 8]);
     return 0;
 }

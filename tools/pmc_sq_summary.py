@@ -73,7 +73,11 @@ def main(path):
             out[k] = o
         out['_meta'] = {"units": "fractions of SQ_WAVE_CYCLES (wave residency); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / "
                                  "(4 SIMDs x SQ_BUSY_CU_CYCLES); valu_issue = SQ_INSTS_VALU x 4 cycles / (4 SIMDs x SQ_BUSY_CU_CYCLES), a lower bound on "
-                                 "the vector pipes' busy share", "probe_T": __import__('os').environ.get('PROBE_T', '1000')}
+                                 "the vector pipes' busy share", "probe_T": __import__('os').environ.get('PROBE_T', '1000'),
+                        # tools/pmc_probe.py: one 3-step launch, then five of PROBE_T steps, B = PROBE_B episodes: the average launch
+                        # of the pass covers this many episode-steps (bench.py: VALU instructions per episode-step)
+                        "rollout_episode_steps_per_launch": int(__import__('os').environ.get('PROBE_B', '256')) *
+                        (3 + 5 * int(__import__('os').environ.get('PROBE_T', '1000'))) / 6.0}
         with open(sys.argv[2], 'w') as f:
             json.dump(out, f, indent=1)
 
