@@ -87,11 +87,14 @@ template <int CK> struct RoGatherUnroll { static constexpr int value = CK ? 4 : 
 #define RO_FEAT_FMA 1
 #endif
 #ifndef MGP_RO_VL_BUILD
-#if defined(MGP_RO_WIDE) || defined(MGP_RO_X128)
-#define MGP_RO_VL_BUILD 0                 // (the 64- and 128-wide builds: lists not enabled yet)
-#else
 #define MGP_RO_VL_BUILD 1
 #endif
+// The 64- and 128-wide builds also keep the sized instantiation WITHOUT lists: their weight images leave less LDS (four 64-wide
+// layers at N = 100 fit only without the lists), and a shape must not fall to the run-time sized build for that.
+#if defined(MGP_RO_WIDE) || defined(MGP_RO_X128)
+#define MGP_RO_VL_BOTH 1
+#else
+#define MGP_RO_VL_BOTH 0
 #endif
 #ifndef RO_VSKIN
 #define RO_VSKIN 0.3f                     // skin in units of the communication radius (<= 1: the error band is proven for pairs within 2R)
@@ -2329,10 +2332,16 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
     }
 #endif
 #undef RB_LAUNCH
-#define RO_LAUNCH_(CN_, CK_, FD_, CL_, WBF_) launch_rollout<CN_, CK_, FD_, CL_, false, WBF_, ((CN_) != 0 && !(FD_) && RO_VERLET && MGP_RO_VL_BUILD)>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags, cl)
+#define RO_LAUNCH__(CN_, CK_, FD_, CL_, WBF_, VL_) launch_rollout<CN_, CK_, FD_, CL_, false, WBF_, ((CN_) != 0 && !(FD_) && RO_VERLET && MGP_RO_VL_BUILD && (VL_))>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags, cl)
     // sized instantiations keep Verlet candidate lists behind the weight image (S1): where they would not fit the LDS, the
-    // run-time sized build (no lists) takes the shape
-    const bool vfit = !(RO_VERLET && MGP_RO_VL_BUILD) || lds + ro_voffsets(N).total + 16 <= RO_LDS_LIMIT;
+    // same instantiation without lists (64- / 128-wide builds) or the run-time sized build takes the shape
+    const bool vroom = lds + ro_voffsets(N).total + 16 <= RO_LDS_LIMIT;
+    const bool vfit = !(RO_VERLET && MGP_RO_VL_BUILD) || MGP_RO_VL_BOTH || vroom;
+#if MGP_RO_VL_BOTH
+#define RO_LAUNCH_(CN_, CK_, FD_, CL_, WBF_) (vroom ? RO_LAUNCH__(CN_, CK_, FD_, CL_, WBF_, true) : RO_LAUNCH__(CN_, CK_, FD_, CL_, WBF_, false))
+#else
+#define RO_LAUNCH_(CN_, CK_, FD_, CL_, WBF_) RO_LAUNCH__(CN_, CK_, FD_, CL_, WBF_, true)
+#endif
 #ifdef MGP_RO_WIDE
 #define RO_LAUNCH(CN_, CK_, FD_, CL_) (P.bf ? RO_LAUNCH_(CN_, CK_, FD_, CL_, RO_BF16_CHAIN) : RO_LAUNCH_(CN_, CK_, FD_, CL_, false))
 #else
@@ -2368,6 +2377,7 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
     return fade ? RO_LAUNCH(0, 0, true, false) : RO_LAUNCH(0, 0, false, false);
 #undef RO_LAUNCH
 #undef RO_LAUNCH_
+#undef RO_LAUNCH__
 }
 }  // namespace
 

@@ -418,10 +418,11 @@ void train_reduce_kernel(const float* __restrict__ part, int ntiles, int Pstride
 {
     unsigned xseq = 0;
     bool bad = false;                                    // P2P: an exchange timed out, now or earlier (sticky status word):
-    if (P2P) {                                           // the weights stay as they are -- a late peer's share counted as 0
-        xseq = (unsigned)X.ctl[0] + 1u;                  // would be a wrong, rank-divergent step -- and the host raises at its
-        bad = X.ctl[2] != 0;                             // next status check (P2PExchange.check)
-    }
+    if (P2P) {                                           // a late peer's share counted as 0 would be a wrong, rank-divergent
+        xseq = (unsigned)X.ctl[0] + 1u;                  // step, so THIS entry is not stepped -- but `bad` is per thread: in the
+        bad = X.ctl[2] != 0;                             // update where a peer is late, entries that arrived in time ARE stepped.
+    }                                                    // The weights are not to be used after that: the host raises at its next
+                                                         // status check and restores the round's starting point (DAGGER.end_updates)
     constexpr int NG = 64 * TR_GROUPS / EPW;          // groups of tiles
     __shared__ float sh[NG][EPW];
     __shared__ float shc[2];

@@ -211,7 +211,10 @@ def sample_initial_states(rng, p, B, device, max_tries=100000):
     L = _lib.lib()
     out = []
     tried = 0
-    M = int(min(4096, max(256, 64 * B)))
+    # candidates per block: bounded by a byte budget (M x (4 n + 2) fp64 uniforms <= 32 MB: at n = 1000 a block of 4096 would
+    # be 130 MB on the host plus 65 MB on the device)
+    m_cap = int(max(16, min(4096, (32 << 20) // (8 * per))))
+    M = int(min(m_cap, max(256, 64 * B)))
     while True:
         state = rng.get_state()
         U = rng.random_sample((M, per))
@@ -220,7 +223,13 @@ def sample_initial_states(rng, p, B, device, max_tries=100000):
         r2m = torch.empty((M,), device=device, dtype=torch.float64)
         _lib.check(L.mgp_flock_reset_check(pos.data_ptr(), M, n, ctypes.c_double(p.comm_radius2), deg.data_ptr(), r2m.data_ptr(),
                                            ops._stream()), 'mgp_flock_reset_check')
-        ok = np.flatnonzero((deg.cpu().numpy() >= p.min_degree) & (np.sqrt(r2m.cpu().numpy()) >= p.min_dist_thresh))
+        # (one pinned, non-blocking copy of both statistics and one wait, instead of two blocking .cpu() calls)
+        host = torch.empty((2, M), dtype=torch.float64, pin_memory=torch.cuda.is_available())
+        host[0].copy_(deg.to(torch.float64), non_blocking=True)
+        host[1].copy_(r2m, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        hn = host.numpy()
+        ok = np.flatnonzero((hn[0] >= p.min_degree) & (np.sqrt(hn[1]) >= p.min_dist_thresh))
         take = ok[:B - len(out)]
         if take.size:
             out += list(_candidates_from_uniforms(U[take], p))
@@ -232,7 +241,7 @@ def sample_initial_states(rng, p, B, device, max_tries=100000):
         tried += M
         if tried >= max_tries * B:
             raise RuntimeError("flock reset: no admissible initial configuration found")
-        M = int(min(4096, 2 * M))
+        M = int(min(m_cap, 2 * M))
 
 
 # ----------------------------------------------------------------------------------- device simulator

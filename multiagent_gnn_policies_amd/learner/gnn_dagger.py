@@ -230,11 +230,29 @@ class DAGGER(object):
         kernel polls for a peer that is still seconds away (the exchange gives up after 5 s)."""
         if self.p2p is not None:
             torch.distributed.barrier()
+            # A timed-out exchange leaves the weights in a state no rank can trust: the fused reduce (csrc/train_step.hip,
+            # train_reduce_kernel<P2P>) skips Adam for the entries whose own poll gave up and for workgroups that saw the
+            # sticky status word, but entries that had arrived in time were stepped -- differently on each rank.  The round's
+            # starting point (weights, both moments, step counter: 21 KB) is kept, and end_updates() rolls back to it before
+            # it raises.
+            o = self.actor_optim
+            self._round_start = (o.flat.clone(), o.m.clone(), o.v.clone(), o.step_dev.clone(), o.step_count)
 
     def end_updates(self):
-        """After a round of updates: raises if an exchange timed out (synchronises the stream)."""
+        """After a round of updates: raises if an exchange timed out (synchronises the stream) -- with the weights, the Adam
+        moments and the step counter rolled back to where begin_updates() found them."""
         if self.p2p is not None:
-            self.p2p.check()
+            try:
+                self.p2p.check()
+            except Exception:
+                snap = getattr(self, '_round_start', None)
+                if snap is not None:
+                    o = self.actor_optim
+                    o.flat.copy_(snap[0]); o.m.copy_(snap[1]); o.v.copy_(snap[2]); o.step_dev.copy_(snap[3])
+                    o.step_count = snap[4]
+                raise
+            finally:
+                self._round_start = None
 
     def _checked_step(self):
         """Adam after an eager all-reduce.  When that all-reduce was the one-shot exchange (stand-alone kernel,

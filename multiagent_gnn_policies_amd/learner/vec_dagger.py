@@ -147,7 +147,37 @@ def _run_sampled(obj, U, sampler, batch_sampler=None):
     return obj.loss_hist[:U].sum()
 
 
+_SAMPLE_BATCH_OK = {}          # (n, k) -> the block form reproduces random.sample on this interpreter (checked on first use)
+
+
+def _sample_batch_sequential(n, k, count):
+    return np.array([random.sample(range(n), k) for _ in range(count)], dtype=np.int64).reshape(max(count, 0), k)
+
+
 def sample_batch(n, k, count):
+    """The reference's minibatch draws (replay_buffer.py:40) for `count` updates at once.  The block form below re-implements
+    CPython internals (random.sample's set-size threshold, _randbelow's rejection loop, getrandbits' word order): on first use
+    for a shape it is compared with random.sample itself -- values AND generator state, on a saved and restored state -- and
+    an interpreter on which they differ keeps the sequential sampler."""
+    key = (n > 21, k)
+    ok = _SAMPLE_BATCH_OK.get(key)
+    if ok is None:
+        state = random.getstate()
+        try:
+            a = _sample_batch_block(n, k, 8)
+            sa = random.getstate()
+            random.setstate(state)
+            b = _sample_batch_sequential(n, k, 8)
+            ok = bool(np.array_equal(a, b)) and sa == random.getstate()
+        except Exception:
+            ok = False
+        finally:
+            random.setstate(state)
+        _SAMPLE_BATCH_OK[key] = ok
+    return _sample_batch_block(n, k, count) if ok else _sample_batch_sequential(n, k, count)
+
+
+def _sample_batch_block(n, k, count):
     """`count` consecutive draws of random.sample(range(n), k) -- the reference's minibatch sampler (replay_buffer.py:40) -- as one
     (count, k) int64 array: the SAME values from the SAME stream of Python's global generator, which is left in the state
     `count` calls of random.sample would leave it in.  A round of updates draws thousands of minibatches; at ~10 us per
@@ -160,7 +190,7 @@ def sample_batch(n, k, count):
     import math
     setsize = 21 + (4 ** math.ceil(math.log(k * 3, 4)) if k > 5 else 0)
     if count <= 0 or k <= 0 or n <= setsize or n >= (1 << 32):
-        return np.array([random.sample(range(n), k) for _ in range(count)], dtype=np.int64).reshape(max(count, 0), k)
+        return _sample_batch_sequential(n, k, count)
     bits = n.bit_length()
     need = count * k
     state = random.getstate()

@@ -85,6 +85,11 @@ def _check_bound(u, ref, noise_refs, what, plain_everywhere, factor=1.0):
         #  noise above, the others to 1e-5; the fp32-MFMA build of round 3 happened to land at 9e-6 there, the split-bf16 layers
         #  at 1.01e-5: the same distribution, another draw)
         assert np.all(err <= 1e-5)
+    if plain_everywhere:
+        # [r5] ... and a hard cap on those lattice states whatever their conditioning: the split-bf16 layers landed at 1.01e-5 on the
+        # one ill-conditioned episode -- anything beyond 1.1e-5 is drift of the kernel, not of the reference, and must not be
+        # absorbed by the noise allowance
+        assert np.all(err <= 1.1e-5), float(err.max())
 
 
 def _weights():

@@ -117,11 +117,16 @@ def run_sections_concurrently(path, names, jobs):
     import time
     results, running, order = {}, {}, list(names)
     pending = list(enumerate(order))
+    try:                                                          # workers are dealt to the VISIBLE devices, not to `jobs` slots
+        import torch
+        n_dev = max(1, torch.cuda.device_count())
+    except Exception:
+        n_dev = 1
     try:
         while pending or running:
             while pending and len(running) < jobs:
                 i, name = pending.pop(0)
-                env = dict(os.environ, LOCAL_RANK=str(i % max(1, jobs)), MGP_TRAIN_WORKER='1')
+                env = dict(os.environ, LOCAL_RANK=str(i % n_dev), MGP_TRAIN_WORKER='1')
                 fo, fe = tempfile.TemporaryFile('w+'), tempfile.TemporaryFile('w+')   # (files, not pipes: a debug run prints a lot)
                 proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), path, '--section', name], env=env,
                                         stdout=fo, stderr=fe, text=True)
@@ -138,7 +143,9 @@ def run_sections_concurrently(path, names, jobs):
                 if proc.returncode != 0:
                     raise RuntimeError("section %r failed:\n%s" % (name, err[-4000:]))
                 lines = [ln for ln in out.splitlines() if ln.startswith(name + ", ")]
-                results[name] = lines[-1] if lines else (out.strip().splitlines() or [''])[-1]
+                if not lines:                                     # never pass some other output line off as the result
+                    raise RuntimeError("section %r printed no '%s, ...' result line; its output ended with:\n%s" % (name, name, out[-2000:]))
+                results[name] = lines[-1]
                 extra = [ln for ln in out.splitlines() if ln != results[name]]
                 if extra:                                         # a section's own progress lines (debug = True), kept together
                     sys.stdout.write("\n".join(extra) + "\n")
@@ -146,6 +153,7 @@ def run_sections_concurrently(path, names, jobs):
     finally:
         for proc, fo, fe in running.values():
             proc.kill()
+            fo.close(); fe.close()
     return [results[n] for n in order]
 
 
