@@ -9,6 +9,7 @@
   dagger    python bench.py --dagger --gpus W with MGP_P2P=1 and MGP_P2P=0:  collection rate, us per update, which exchange ran
             (`exchange`: p2p | rccl | gloo), exchange_mem_kind (2 = uncached device memory mapped over hipIpc), the bring-up stage
             if the one-shot exchange was refused, weights bit-identical across ranks
+  rccl@2    python bench.py --dagger --gpus 2 with MGP_P2P=0: the update round captured with the RCCL all-reduce inside, two ranks
   exchange  tests/p2p_worker.py allreduce at W ranks, one per device: us per exchange inside a 32-exchange HIP graph
 One JSON object on stdout (and gpurun_out/first_multi_gpu.json).  `fallback` is true -- and the exit status 1 -- if MGP_P2P=1 did
 NOT run the one-shot exchange (hipIpcOpenMemHandle across devices refused, self-test failed ...): loud, never silent.
@@ -69,6 +70,20 @@ def main():
                                   "dist": d["dist"]}
         else:
             rec["dagger"][tag] = d
+    # ---- the captured-graph update round on the RCCL all-reduce at TWO ranks (MGP_P2P=0): the form that has only ever run at world 1
+    #      (tests/test_gpu_nccl.py) -- its first contact with a second device must not wait for somebody to think of it
+    if not dry:
+        d = run_json([sys.executable, 'bench.py', '--dagger', '--gpus', '2', '--steps', '200', '--warmup', '20', '--episodes', '256',
+                      '--updates', '1024'], env=dict(share, MGP_P2P='0'))
+        if "updates" in d:
+            u = d["updates"]
+            rec["dagger_rccl_2_ranks"] = {"exchange": u["exchange"], "us_per_update": 1e3 * u["ms_per_update"],
+                                          "ran_rccl_inside_the_graph": u["exchange"] == 'rccl',
+                                          "weights_bit_identical_across_ranks": d["weights_bit_identical_across_ranks"], "dist": d["dist"]}
+        else:
+            rec["dagger_rccl_2_ranks"] = d
+    else:
+        rec["dagger_rccl_2_ranks"] = {"skipped": "needs two devices (an RCCL all-reduce between two ranks on one device is not the case to test)"}
     # ---- the exchange alone, W ranks (one per device where there are W devices)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     try:

@@ -1,12 +1,12 @@
 """Copy the outputs of tools/regen_profiles.sh (gpurun_out/final/) into profiles/<round>_* (run from the repo root;
-ROUND=r04 by default)."""
+ROUND=r05 by default)."""
 import json
 import os
 import shutil
 import sys
 sys.path.insert(0, ".")
 import os
-O, R = 'gpurun_out/final', os.environ.get('ROUND', 'r04')
+O, R = 'gpurun_out/final', os.environ.get('ROUND', 'r05')
 
 
 def last_json(path):
@@ -19,7 +19,7 @@ d2 = last_json(O + '/bench_under_rocprof.json')
 for name, x in (('--steps 20 --warmup 5', d20), ('default', d), ('--steps 20 under rocprofv3', d2)):
     r = x['roofline']
     print('%-28s value %.4g ms/step %.5f | roofline %s frac %.3f traffic %s | parity %s %.2e | mean degree %.2f' % (
-        name, x['value'], x['ms_per_step'], r['bound'], r['frac'], r['traffic'], x['parity']['ok'], x['parity']['max_rel'],
+        name, x['value'], x['ms_per_step'], r['bound'], r['frac'] if r['frac'] is not None else float('nan'), r['traffic'], x['parity']['ok'], x['parity']['max_rel'],
         x['config']['mean_degree']))
     print('   dense kernels:', {k: (round(v['avg_launch_ms'] * 1e3, 2), round(v['frac'], 3), v['traffic']) for k, v in r['dense_kernels'].items()
                                 if isinstance(v, dict)})
@@ -47,8 +47,9 @@ open('profiles/%s_rollout_phase_stamps.txt' % R, 'w').write(
     "# tools/harness/ro_phase_prof.hip on MI355X (RO_CARRY=1: prebuilt weight image + factored hand-over, the repeated-launch form):\n"
     "# in-kernel s_memtime stamps of workgroup 0, lane 0 of eleven waves, step 5 of the launch (shader cycles).  First block: regular-lattice\n"
     "# harness state, 200-step launch; second block: bench.py's own state 5 steps after reset (irregular degrees), 20-step launches.\n"
-    "# Schedule of round 3: B/C (gather stage K-1 + MLP + output layer on registers + per-axis integration, waves 0-6) | S1 (full-row\n"
-    "# membership test, lists, weights; 13 waves) | S2 (fp64 features, waves 0-6 || gather stage 1 of the next step, waves 7-13); 3 barriers.\n"
+    "# Schedule: B/C (gather stage K-1 + MLP + output layer on registers + per-axis integration, waves 0-6) | S1 (membership: the cheap pass\n"
+    "# over the row's Verlet candidates on the stamped step 5 -- stamps 16-19 belong to the exact / rebuild pass and stay empty there --; 13 waves)\n"
+    "# | S2 (fp64 features, waves 0-6 || gather stage 1 of the next step, waves 7-13 || the Verlet helper on wave 14); 3 barriers.\n"
     + open(O + '/rollout_phase_stamps.txt').read())
 open('profiles/%s_rollout_launch_cost.txt' % R, 'w').write(
     "# tools/harness/ro_launch_prof.hip: anatomy of a resident launch (prebuilt weight image, factored hand-over), B=256 N=100 K=3.  Every launch\n"
@@ -87,3 +88,21 @@ if os.path.exists(O + '/factored_step_stamps.txt'):
         + open(O + '/factored_kernel_trace.txt').read())
     for n in ('n1000', 'n300'):
         shutil.copy(O + '/dagger_round_%s.json' % n, 'profiles/%s_dagger_round_%s_factored.json' % (R, n))
+
+for src, hdr in (
+        ('rollout_ab.txt',
+         "# tools/gpu/r5_ab.sh: the resident kernel on bench.py's own state 5 steps after a disc reset, B=256 N=100 K=3, three repetitions:\n"
+         "# ro_prof_base = round 4's sources, x0 = this round's sources with RO_VERLET=0 (no candidate lists), x1 = the product build (skin 0.3,\n"
+         "# two passes of eight per trip); T200 / T20 / T1 = 200-, 20- and one-step launches back to back (us per step, us per launch for T1).\n"
+         "# Then the phase stamps of x1 (step 5: a cheap step) and of the same build stamped at step 0 (a rebuild step), then the launch anatomy\n"
+         "# (tools/harness/ro_launch_prof.hip) without (ro_launch_0) and with (ro_launch_v) the lists.\n"),
+        ('flock_advance_stamps.txt',
+         "# tools/harness/flock_phase_prof.hip: mgp_flock_step (ping-pong sim step) and mgp_flock_step_advance (sim + state transition, K = 3) back to\n"
+         "# back; stamps of workgroup 0 of flock_advance_kernel (shader cycles); below each block the row-tiled kernel of rounds 1-4 on the same box.\n"),
+        ('rollout_long_launches.txt',
+         "# tools/gpu/r5_long.sh: 100 / 500 / 1000-step launches from the bench state (no resets: the flock of a 1000-step launch is 1000+ steps old),\n"
+         "# candidate lists off (x0) and on (x1), with the S1 modes the helper wave chose over all workgroups.\n"),
+        ('rollout_wg_times_lists.txt', ''), ('rollout_wg_times_no_lists.txt', '')):
+    if os.path.exists(O + '/' + src):
+        open('profiles/%s_%s' % (R, src), 'w').write(hdr + open(O + '/' + src).read())
+print('installed profiles/%s_*' % R)

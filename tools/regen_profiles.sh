@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates every round artefact under profiles/ on the GPU box (run through gpurun from the repo root):
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/regen_profiles.sh > gpurun_out/regen.log 2>&1'
-#   python tools/install_profiles.py          # copies gpurun_out/final/* into profiles/<round>_*  (ROUND=r04)
+#   python tools/install_profiles.py          # copies gpurun_out/final/* into profiles/<round>_*  (ROUND=r05)
 # The harnesses must have been built first (they travel with the snapshot under scratch/):  bash tools/build_harness.sh
 # PMC passes use --pmc with --kernel-trace only (no sys/runtime/hip trace domains).
 set -x
@@ -26,12 +26,12 @@ F=$(find $O/pmc_fetch -name "*results.db" | head -1); W=$(find $O/pmc_write -nam
 F2=$(find $O/pmc_fetch20 -name "*results.db" | head -1); W2=$(find $O/pmc_write20 -name "*results.db" | head -1)
 cd $R
 python tools/pmc_summary.py $F $W $O/pmc_traffic.json 256,100,3 $F2 $W2 20 > $O/pmc_hbm_traffic.txt 2>&1
-cp $O/pmc_traffic.json $R/profiles/${ROUND:-r04}_pmc_traffic.json
+cp $O/pmc_traffic.json $R/profiles/${ROUND:-r05}_pmc_traffic.json
 FF=$(find $O/pmc_fetch_f -name "*results.db" | head -1); WF=$(find $O/pmc_write_f -name "*results.db" | head -1)
 python tools/pmc_summary.py $FF $WF $O/pmc_traffic_factored.json 64,1000,3 > $O/pmc_hbm_traffic_factored.txt 2>&1
-cp $O/pmc_traffic_factored.json $R/profiles/${ROUND:-r04}_pmc_traffic_factored.json
+cp $O/pmc_traffic_factored.json $R/profiles/${ROUND:-r05}_pmc_traffic_factored.json
 python tools/pmc_sq_summary.py $Q $O/pmc_sq.json > $O/pmc_sq.txt 2>&1
-cp $O/pmc_sq.json $R/profiles/${ROUND:-r04}_pmc_sq.json
+cp $O/pmc_sq.json $R/profiles/${ROUND:-r05}_pmc_sq.json
 # 2. bench (traffic / sq now resolved from the files just written): the driver's command line, the default, and under rocprof
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_steps20.json 2> $O/bench_steps20.err
 python bench.py > $O/bench_final.json 2> $O/bench_final.err
@@ -45,6 +45,14 @@ RO_CARRY=1 ./scratch/ro_prof 256 100 3 200 > $O/rollout_phase_stamps.txt 2>&1
 python tools/dump_rollout_state.py /tmp/ro_state5.bin 5 > /dev/null 2>&1
 RO_STATE=/tmp/ro_state5.bin RO_CARRY=1 ./scratch/ro_prof 256 100 3 20 20 >> $O/rollout_phase_stamps.txt 2>&1
 { RO_STATE=/tmp/ro_state5.bin RO_WG_DUMP=$O/rollout_wg_times.txt ./scratch/ro_launch 256 100 3 "1 2 3 5 10 20 40 100" 30; ./scratch/ro_launch 256 100 3 "1 2 5 20" 30; } > $O/rollout_launch_cost.txt 2>&1
+# 3a. [r5] resident kernel A/B (scratch/ro_prof_base = round 4's sources, x0 = this round's with RO_VERLET=0, x1 = the product build) and the
+#     per-episode durations / S1 modes of a 20-step launch with and without the candidate lists
+RO_STAMP_BINS="scratch/ro_prof_x1 scratch/ro_st0" timeout 600 bash tools/gpu/r5_ab.sh > $O/rollout_ab.txt 2>&1
+cp gpurun_out/wg_times_ro_launch_v.txt $O/rollout_wg_times_lists.txt 2>/dev/null
+cp gpurun_out/wg_times_ro_launch_0.txt $O/rollout_wg_times_no_lists.txt 2>/dev/null
+timeout 300 bash tools/gpu/r5_long.sh > $O/rollout_long_launches.txt 2>&1
+# 3a'. [r5] mgp_flock_step_advance: the one-workgroup-per-episode kernel and the row-tiled one it replaces (tools/harness/flock_phase_prof.hip)
+{ for cfg in "256 100" "2048 100" "256 128" "16 100"; do echo "== flock_advance_kernel, B N = $cfg"; ./scratch/fl_prof $cfg | grep -v "stamp [0-7] "; echo "== row-tiled kernel (MGP_FLOCK_ADVANCE_TILED=1), B N = $cfg"; MGP_FLOCK_ADVANCE_TILED=1 ./scratch/fl_prof $cfg | head -2; done; } > $O/flock_advance_stamps.txt 2>&1
 # 3b. phase stamps of the fused Actor forward (MFMA aggregation variant), B = 256 and B = 1
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -w -o /tmp/af_prof tools/harness/af_phase_prof.hip 2>/dev/null
 { /tmp/af_prof 256 100; /tmp/af_prof 1 100; } > $O/actor_fwd_phase_stamps.txt 2>&1
@@ -75,8 +83,8 @@ print('degree sweep: comm_radius $R_', 'mean degree at reset %.2f' % d['config']
 # 5. the DAGGER round (BASELINE configs[3]): one rank, and two ranks sharing this GPU (gloo carries the IPC handles; the gradient
 #    goes through the one-shot exchange), plus the exchange's own latency for 2 / 3 / 4 ranks on the one device
 python bench.py --dagger --steps 500 --warmup 20 > $O/dagger_round_1rank.json 2> $O/dagger_round_1rank.err
-MGP_DIST_BACKEND=gloo python bench.py --dagger --gpus 2 --steps 500 --warmup 20 --episodes 128 2> $O/dagger_round_2ranks.err | grep "^{" > $O/dagger_round_2ranks_shared_gpu.json
-python - > $O/p2p_exchange_latency.txt 2>&1 <<'PY'
+MGP_DIST_BACKEND=gloo timeout 300 python bench.py --dagger --gpus 2 --steps 500 --warmup 20 --episodes 128 2> $O/dagger_round_2ranks.err | grep "^{" > $O/dagger_round_2ranks_shared_gpu.json
+timeout 900 python - > $O/p2p_exchange_latency.txt 2>&1 <<'PY'
 import sys
 sys.path.insert(0, 'tests')
 import test_gpu_p2p as t
@@ -84,7 +92,7 @@ for w in (2, 3, 4, 8):
     r = t.run_ranks('allreduce', world=w, timeout=900)
     print('ranks %d (one MI355X, IPC between processes): %.2f us per exchange of 1,731 floats inside a 32-exchange HIP graph (launch of the stand-alone kernel included), mailbox memory kind %d (2 = uncached), %d exchanges checked bit-exact' % (w, r['exchange_us_in_graph'], r['mem_kind'], r['exchanges']))
 PY
-DRY=1 python tools/first_multi_gpu.py > $O/first_multi_gpu_dry.json 2> $O/first_multi_gpu_dry.err
+DRY=1 timeout 600 python tools/first_multi_gpu.py > $O/first_multi_gpu_dry.json 2> $O/first_multi_gpu_dry.err
 # 6. instruction mix of the resident kernel (harness, bench state)
 bash tools/gpu/ro_pmc.sh > $O/rollout_inst_mix.txt 2>&1
 # 7. the factored path (N > 256; cfg-3 shape 64 x 1000, K = 3): harness stamps of its three kernels, their kernel trace, the
