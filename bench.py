@@ -1265,8 +1265,10 @@ def main():
             "agg_fwd": hbm_block('agg_fwd', "mgp_agg_fwd: agg_fwd_mfma4_kernel for N <= 128 (four waves per (episode, tap): a wave "
                                  "streams half the rows of its column block), agg_fwd_kernel otherwise (aggregation "
                                  "X.G alone): 4KN^2 + 8KFN bytes per episode", ('agg_fwd_mfma4_kernel', 'agg_fwd_mfma_kernel', 'agg_fwd_kernel')),
-            "sim_state_step": hbm_block('sim_state_step', "flock_step_kernel<advance> (sim step + delayed-GSO / delay-line "
-                                        "transition, fused)", ('flock_step_kernel',)),
+            "sim_state_step": hbm_block('sim_state_step', "mgp_flock_step_advance: flock_advance_kernel for N <= 128 (one workgroup per "
+                                        "episode: sim step + delayed-GSO / delay-line transition, source slice staged in LDS by "
+                                        "LDS-DMA), the row-tiled flock_step_kernel<advance> otherwise",
+                                        ('flock_advance_kernel',) if (N <= 128 and N % 4 == 0) else ('flock_step_kernel',)),
             "rotating_input_sets": n_sets,
         }
         if resident:

@@ -120,7 +120,7 @@ __host__ __device__ constexpr RoVOff ro_voffsets(int N)
     v.cnt = ro_take(off, N * 4);
     v.pref = ro_take(off, 2 * N * 8);
     v.gap = ro_take(off, N * 4);                              // float [N]: distance to the nearest agent at the rebuild - R, agents without candidates
-    v.flag = ro_take(off, 64);                                // int [0] next step's mode, [1] steps the lists have served, [2] steps of backoff;
+    v.flag = ro_take(off, 64);                                // int [0] next step's mode, [1] steps the lists have served, [2] steps of backoff, [3] next backoff;
                                                               // double [4] at +16: frame offset (x, y), frame velocity (x, y); bytes 48..55: target
                                                               // of masked list writes
     v.total = off;
@@ -402,7 +402,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         // the first step builds the candidate lists unless the launch is too short to use them; sxy[N] (the unused 32 bytes
         // behind the coordinates) is the SENTINEL the padding entries of a candidate list point at: far outside every radius
         vflag[0] = (T >= RO_VMINLIFE) ? RO_VM_REBUILD : RO_VM_FULL;
-        vflag[1] = 0; vflag[2] = 0;
+        vflag[1] = 0; vflag[2] = 0; vflag[3] = 8;
         sxy[N] = make_float4(3.0e18f, 3.0e18f, 0.f, 0.f);
     }
     if (CL) {
@@ -1166,6 +1166,9 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             // an agent that had NO candidate at the rebuild the wave therefore keeps gap_o = (distance to its nearest agent then)
             // - R, and every pair of o is safe while D_o + D_j <= gap_o.  Sufficient for the step: every agent has D_i <= skin / 2, or
             // D_i + max_j D_j <= gap_i (gap = 0 for agents that had candidates).
+            // (raised priority: a hundred instructions on a SIMD it shares with three busy waves -- as the youngest wave it finished
+            //  last, 3.3k cycles into the phase, and any instruction added to it lengthened the step)
+            __builtin_amdgcn_s_setprio(3);
             double* vst = reinterpret_cast<double*>(vflag) + 2;    // frame offset (x, y), frame velocity (x, y): state of this wave, kept in LDS
             const double hacc = fabs(p.max_accel * p.action_gain) * p.dt * p.dt * 0.5;
             const float skin = RO_VSKIN * Rf;
@@ -1192,20 +1195,27 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                     }
                     iso[a_] = __builtin_amdgcn_ballot_w64(lonely);
                 }
-                for (int a_ = 0, budget = 8; a_ < 2; ++a_) {  // (wave-uniform loops; a handful of agents at most)
+                // (wave-uniform loops over at most six such agents -- a flock hundreds of steps past the time limit has dozens, and
+                //  this wave must not become the phase's tail; fp32 distances on the coordinates S1 used, relative to the reference
+                //  point: each within 2^-24 of its magnitude, charged to the gap below)
+                for (int a_ = 0, budget = 6; a_ < 2; ++a_) {
                     unsigned long long mk = iso[a_];
                     while (mk != 0ull && budget > 0) {
                         const int o = 64 * a_ + __builtin_ctzll(mk);
                         mk &= mk - 1ull; --budget;
-                        const double xo = spx[o], yo = spy[o];
+                        const float2 so = *reinterpret_cast<const float2*>(&sxy[o]);
                         float nm = __builtin_huge_valf();
                         for (int j = lane; j < N; j += 64) {
-                            const double dx = xo - spx[j], dy = yo - spy[j];
-                            const float r2 = (float)(dx * dx + dy * dy) * 0.999999f;
+                            const float2 sj = *reinterpret_cast<const float2*>(&sxy[j]);
+                            const float dx = so.x - sj.x, dy = so.y - sj.y;
+                            const float r2 = fmaf(dy, dy, dx * dx);
                             if (j != o) nm = fminf(nm, r2);
                         }
                         nm = -wave_max_to_last(-nm);
-                        if (lane == 63) vgap[o] = sqrtf(nm) * 0.999999f - Rf - vmarg;
+                        if (lane == 63) {
+                            const float dn = sqrtf(nm);
+                            vgap[o] = dn * 0.999998f - 1.e-6f * (fabsf(so.x) + fabsf(so.y) + dn) - Rf - vmarg;
+                        }
                     }
                 }
                 if (lane == 0) { vst[0] = fvx; vst[1] = fvy; vst[2] = fvx; vst[3] = fvy; }
@@ -1235,16 +1245,19 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             const bool cheap_ok = vl_ok && __builtin_amdgcn_ballot_w64(bad) == 0ull;
             // Next step's mode.  A list that did not serve RO_VMINLIFE steps was not worth its rebuild (~0.4k cycles on top of the
             // exact pass): the flock moves too fast for this skin -- exact passes for a while, then another try.
-            int age = (vmode == RO_VM_CHEAP) ? vflag[1] + 1 : 0, backoff = vflag[2];
+            // (the back-off doubles, 8 .. 256 steps, while lists keep dying young, and starts over once one has served eight steps)
+            int age = (vmode == RO_VM_CHEAP) ? vflag[1] + 1 : 0, backoff = vflag[2], bnext = vflag[3];
+            if (age >= 8) bnext = 8;
             int next = RO_VM_CHEAP;
             if (!cheap_ok) {                                  // (wave-uniform)
-                if (vl_ok && age < RO_VMINLIFE) backoff = 8;
+                if (vl_ok && age < RO_VMINLIFE) { backoff = bnext; bnext = min(2 * bnext, 256); }
                 const bool rebuild = backoff == 0 && (T - (t + 1) >= RO_VMINLIFE);
                 if (backoff > 0) --backoff;
                 next = rebuild ? RO_VM_REBUILD : RO_VM_FULL;
             }
-            if (lane == 0) { vflag[1] = age; vflag[2] = backoff; }
+            if (lane == 0) { vflag[1] = age; vflag[2] = backoff; vflag[3] = bnext; }
             if (lane == 0) vflag[0] = next;
+            __builtin_amdgcn_s_setprio(0);
             RO_STAMP(24);
 #ifdef MGP_RO_PROFILE
             if (blockIdx.x < 4096 && lane == 0) atomicAdd(&mgp_ro_vstat[blockIdx.x * 4 + next], 1u);
