@@ -789,6 +789,295 @@ void actor_fwd_pol_kernel(const float* __restrict__ X, const float* __restrict__
     }
 }
 
+// ---- Two hidden layers wider than the policy shape (cfg/hidden_size.cfg sweeps hidden_size up to 128), inference: the same
+// stream and staging scheme with the hidden layers in split-bf16 form over 16 MA / 16 MB output channels (MA, MB = 4 or 8
+// m-tiles; narrower layers run zero-padded).  The generic kernel above spends 50k of its 65k cycles at [128, 128] behind the
+// stream (fp32 MFMA k-steps of 32 cycles, weights by one LDS-DMA dword per element: the barrier waits for them at 31k);
+// here a layer-1 m-tile is KB = MA / 2 blocks of six 16-cycle products (block kb multiplies the accumulator registers of
+// layer 0's m-tiles 2 kb, 2 kb + 1: no LDS round trip between the layers), 3.8k cycles per 16-column tile for both layers.
+//   Weight image: one 48-byte record [piece][8 bf16] per (plane, lane), plane = m-tile for layer 0 (element j of k-group lq
+//   <-> channel 4 j + lq of the aggregation tile), (m-tile, block) for layer 1 (element j <-> channel 32 kb + 4 lq + j for
+//   j < 4, 32 kb + 16 + 4 lq + (j - 4) beyond).  The two staging waves build the records in the shadow of the stream, plane by
+//   plane (planes of equal parity), four planes' loads in flight.  At MA = MB = 8 the image is 123 KB; with the 16 KB
+//   aggregation tile and the 24 KB the streaming waves need for their row-class sums that is 4 KB more than the CU has, so
+//   the LAST eight planes of layer 1 (m-tiles 6, 7) share their LDS with the row-class area: their records wait in the
+//   staging waves' registers (four per lane) and are stored after the barrier, and a second barrier -- which the column
+//   waves reach after layer 0 and six m-tiles of layer 1, ~3k cycles later -- stands in front of their first use.
+template <int MA, int MB> struct AwPlan {
+    static constexpr int KB = MA / 2;                                       // K blocks of layer 1
+    static constexpr int P0 = MA, P1 = MB * KB;                              // record planes of the two layers
+    static constexpr int LATE = (MA == 8 && MB == 8) ? 8 : 0;                // planes stored after the first barrier
+    static constexpr int IMG0 = 0, B0 = P0 * 64 * RO_WFS, IMG1 = B0 + 16 * MA, B1 = IMG1 + P1 * 64 * RO_WFS;   // float offsets from the image base
+    static constexpr int W2 = B1 + 16 * MB, END = W2 + 2 * 16 * MB + 16;     // output layer: pairs (W[0][c], W[1][c]), bias pair, pad
+    static constexpr int RED = LATE ? IMG1 + (P1 - LATE) * 64 * RO_WFS : END; // row-class sums of the streaming waves (floats from the image base)
+};
+
+// m-tiles mt, mt + 1 of a layer with NKB input blocks for the wave's CT column tiles (every A record read from LDS multiplies
+// CT B operands); 2 CT accumulator chains in flight, smallest products first.  Measured at [128, 128]
+// (tools/harness/af_phase_prof.hip 256 N 128, -DMGP_AW_CT=1 / 2): one tile on each of seven waves 18.45 us per launch at
+// N = 100 and 20.7 at N = 128, two tiles on each of four 18.95 and 21.7 (and two spilled registers at N > 112) -- layer 1
+// takes 11.0k / 11.6k cycles either way: per SIMD the same 384 products (6.1k cycles of the matrix pipe) and the same ~1.06k
+// VALU instructions (tanh: two quarter-rate instructions per value, 2.3k cycles by ablation; the bf16 split of the next
+// layer's operand), which the scheduler interleaves (3-4 VALU per product in the listing) but whose times ADD on a SIMD
+// rather than overlap; halving the LDS reads of the image buys nothing.  CT = 1 is the build.
+template <int NKB, int CT, int MZ>
+__device__ __forceinline__ void aw_tiles2(const ro_bf16x8 (&b1)[CT][4], const ro_bf16x8 (&b2)[CT][4], const ro_bf16x8 (&b3)[CT][4],
+                                          const float* prec /* this lane's record of plane (m-tile 0, block 0) */,
+                                          const float* pbias /* + 4 lq */, int mt, float (&z)[CT][MZ][4])
+{
+    f32x4 acc[2][CT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const float4 bv = *reinterpret_cast<const float4*>(pbias + (mt + m) * 16);
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[m][t] = f32x4{bv.x, bv.y, bv.z, bv.w};
+    }
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        ro_bf16x8 a1[2], a2[2], a3[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const float4* pa = reinterpret_cast<const float4*>(prec + ((mt + m) * NKB + kb) * 64 * RO_WFS);
+            const float4 u1 = pa[0], u2 = pa[1], u3 = pa[2];
+            a1[m] = *reinterpret_cast<const ro_bf16x8*>(&u1);
+            a2[m] = *reinterpret_cast<const ro_bf16x8*>(&u2);
+            a3[m] = *reinterpret_cast<const ro_bf16x8*>(&u3);
+        }
+#define MGP_AW_ROUND(A_, B_)                                                                                              \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                                     \
+            _Pragma("unroll") for (int t = 0; t < CT; ++t)                                                                \
+                acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[m], B_[t][kb], acc[m][t], 0, 0, 0)
+        MGP_AW_ROUND(a1, b3); MGP_AW_ROUND(a3, b1); MGP_AW_ROUND(a2, b2);
+        MGP_AW_ROUND(a1, b2); MGP_AW_ROUND(a2, b1); MGP_AW_ROUND(a1, b1);
+#undef MGP_AW_ROUND
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) z[t][mt + m][rr] = tanh_fast(acc[m][t][rr]);
+}
+
+template <int S, int FH, int MA, int MB>
+__global__ __launch_bounds__(AF_THREADS)
+void actor_fwd_wide_kernel(const float* __restrict__ X, const float* __restrict__ G, float* __restrict__ out, ActorParams P,
+                           int B, int K, int N, int nblk)
+{
+    using PL = AwPlan<MA, MB>;
+    constexpr int KB = PL::KB, NP = PL::P0 + PL::P1, LATE = PL::LATE, EARLY = NP - LATE;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int b = blockIdx.x;
+    const int F = 6, FK = F * K;
+    const int h1 = P.dims[1], h2 = P.dims[2];
+    const int ncols16 = pad16(N);
+    float* ys = smem;                                             // [ncols16][RO_CS]
+    float* wimg = smem + ncols16 * RO_CS;
+    f32x4* red = reinterpret_cast<f32x4*>(wimg + PL::RED);
+    const int nstream = K * nblk;
+    const bool staging = wave >= nstream && wave < nstream + 2;
+    ro_bf16x8 late[LATE ? 4 : 1][3];                              // the staging waves' late records, split, across the barrier
+    AF_STAMP(0);
+    if (wave < nstream) {
+        const int gtot = N >> 2, g0 = (nblk == 2) ? ((gtot + 1) >> 1) : gtot;
+        const int k = wave / nblk, blk = wave - k * nblk;
+        const int ng = blk ? gtot - g0 : g0;
+        const int g = blk * g0 + min(li, ng - 1);
+        agg_mfma_unit<S, FH>(G + ((size_t)b * K + k) * (size_t)N * N + 4 * g, X + ((size_t)b * K + k) * (size_t)F * N, N, F, N,
+                             lane, red + wave * (4 * 64),
+                             [&](int h, const f32x4& tot) {
+                                 if (li < ng) {
+#pragma unroll
+                                     for (int i = 0; i < 4; ++i) {
+                                         const int c = 4 * h + i;
+                                         if (c < F) ys[(4 * g + lq) * RO_CS + rpos(c * K + k)] = tot[i];
+                                     }
+                                 }
+                             });
+        AF_STAMP(3);
+    } else if (staging) {
+        const int sw = __builtin_amdgcn_readfirstlane(wave) - nstream;
+        // Records: staging wave sw builds the planes of its parity.  EVERY load of the wave is issued before the first record is
+        // built (a request issued while the operator streams comes back with the stream, ~5 us later: four planes per round
+        // trip measured 40k cycles for the 20 planes of a wave, the barrier at 43k instead of 14k), 64 requests per lane.
+        // The wave asks for its weights at raised priority: in front of the streaming waves' requests, not interleaved with them.
+        constexpr int H0 = MA / 2, H1 = PL::P1 / 2, H1E = (PL::P1 - LATE) / 2;
+        __builtin_amdgcn_s_setprio(3);
+        float w0[H0][8];
+        float4 w1[H1][2];
+#pragma unroll
+        for (int i = 0; i < H0; ++i) {
+            const int o = 16 * (sw + 2 * i) + li;
+            const float* row = P.W[0] + (size_t)min(o, h1 - 1) * FK;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w0[i][j] = row[min(4 * j + lq, FK - 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < H1; ++i) {
+            const int q = sw + 2 * i, mt = q / KB, kb = q - mt * KB;
+            const float* row = P.W[1] + (size_t)min(16 * mt + li, h2 - 1) * h1;
+            const int c0 = 32 * kb + 4 * lq;
+            w1[i][0] = *reinterpret_cast<const float4*>(row + min(c0, h1 - 4));          // h1 % 4 == 0: a quad is inside or outside
+            w1[i][1] = *reinterpret_cast<const float4*>(row + min(c0 + 16, h1 - 4));
+        }
+        // biases (staging wave sw: layer sw) and the output layer (wave 1): requested behind the records, stored at the end
+        constexpr int NBV = 16 * (MA > MB ? MA : MB) / 64, NW2 = 2 * 16 * MB / 64;
+        float bv[NBV], w2v[NW2], b2v = 0.f;
+        {
+            const int hl = sw ? h2 : h1;
+            const float* bl = P.b[sw];
+#pragma unroll
+            for (int i = 0; i < NBV; ++i) bv[i] = bl[min(lane + 64 * i, hl - 1)];
+#pragma unroll
+            for (int i = 0; i < NW2; ++i) {                                    // float 2 c + o = W[o][c]
+                const int e = lane + 64 * i, c = e >> 1, o = e & 1;
+                w2v[i] = sw ? P.W[2][(size_t)o * h2 + min(c, h2 - 1)] : 0.f;
+            }
+            if (sw && lane < 2) b2v = P.b[2][lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
+        {                                                                      // padding channels FK .. 31 of the aggregation tile
+            const int st = lane + 64 * sw;
+            if (st < ncols16)
+                for (int q = FK; q < 32; ++q) ys[st * RO_CS + rpos(q)] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < H0; ++i) {
+            const int p = sw + 2 * i, o = 16 * p + li;
+            float w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = (o < h1 && 4 * j + lq < FK) ? w0[i][j] : 0.f;
+            ro_bf16x8 a1, a2, a3;
+            ro_split3(w, a1, a2, a3);
+            float4* dst = reinterpret_cast<float4*>(wimg + PL::IMG0 + (p * 64 + lane) * RO_WFS);
+            dst[0] = *reinterpret_cast<const float4*>(&a1);
+            dst[1] = *reinterpret_cast<const float4*>(&a2);
+            dst[2] = *reinterpret_cast<const float4*>(&a3);
+        }
+#pragma unroll
+        for (int i = 0; i < H1; ++i) {
+            const int q = sw + 2 * i, mt = q / KB, kb = q - mt * KB;
+            const int o = 16 * mt + li, c0 = 32 * kb + 4 * lq;
+            const bool ok0 = o < h2 && c0 < h1, ok1 = o < h2 && c0 + 16 < h1;
+            const float4 u0 = w1[i][0], u1 = w1[i][1];
+            float w[8] = {ok0 ? u0.x : 0.f, ok0 ? u0.y : 0.f, ok0 ? u0.z : 0.f, ok0 ? u0.w : 0.f,
+                          ok1 ? u1.x : 0.f, ok1 ? u1.y : 0.f, ok1 ? u1.z : 0.f, ok1 ? u1.w : 0.f};
+            if (i < H1E) {
+                ro_bf16x8 a1, a2, a3;
+                ro_split3(w, a1, a2, a3);
+                float4* dst = reinterpret_cast<float4*>(wimg + PL::IMG1 + (q * 64 + lane) * RO_WFS);
+                dst[0] = *reinterpret_cast<const float4*>(&a1);
+                dst[1] = *reinterpret_cast<const float4*>(&a2);
+                dst[2] = *reinterpret_cast<const float4*>(&a3);
+            } else {
+                const int il = i >= H1E ? i - H1E : 0;
+                ro_split3(w, late[il][0], late[il][1], late[il][2]);
+            }
+        }
+        {
+            const int hl = sw ? h2 : h1;
+            float* dst = wimg + (sw ? PL::B1 : PL::B0);
+#pragma unroll
+            for (int i = 0; i < NBV; ++i)
+                if (lane + 64 * i < 16 * (sw ? MB : MA)) dst[lane + 64 * i] = (lane + 64 * i < hl) ? bv[i] : 0.f;
+            if (sw) {
+                float* w2 = wimg + PL::W2;
+#pragma unroll
+                for (int i = 0; i < NW2; ++i) w2[lane + 64 * i] = (((lane + 64 * i) >> 1) < h2) ? w2v[i] : 0.f;
+                if (lane < 2) w2[2 * 16 * MB + lane] = b2v;
+            }
+        }
+        AF_STAMP_T(19, 64 * nstream);
+    }
+    __syncthreads();
+    AF_STAMP(4);
+    if constexpr (LATE > 0) {
+        if (staging) {
+            const int sw = __builtin_amdgcn_readfirstlane(wave) - nstream;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4* dst = reinterpret_cast<float4*>(wimg + PL::IMG1 + (EARLY - MA + sw + 2 * i) * 64 * RO_WFS + lane * RO_WFS);
+                dst[0] = *reinterpret_cast<const float4*>(&late[i][0]);
+                dst[1] = *reinterpret_cast<const float4*>(&late[i][1]);
+                dst[2] = *reinterpret_cast<const float4*>(&late[i][2]);
+            }
+        }
+    }
+    // column waves: CT tiles of 16 agent columns each (MGP_AW_CT = 2 from five tiles on: the measured alternative, see aw_tiles2)
+#ifndef MGP_AW_CT
+#define MGP_AW_CT 1
+#endif
+    constexpr int CT = S > 16 ? MGP_AW_CT : 1;
+    const int NT = ncols16 / 16;
+    const bool colw = wave * CT < NT;
+    int col[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) col[t] = min(wave * CT + t, NT - 1) * 16 + li;      // (an odd last tile is computed twice, stored once)
+    float za[CT][MA][4], zb[CT][MB][4];
+    ro_bf16x8 c1[CT][4], c2[CT][4], c3[CT][4];
+    constexpr int MB_EARLY = MB - LATE / KB;                      // m-tiles of layer 1 whose planes are in place at the first barrier
+    if (colw) {
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            float fb[8];
+            const float4* pb = reinterpret_cast<const float4*>(ys + col[t] * RO_CS + lq * RO_KS);
+            const float4 t0 = pb[0], t1 = pb[1];
+            fb[0] = t0.x; fb[1] = t0.y; fb[2] = t0.z; fb[3] = t0.w; fb[4] = t1.x; fb[5] = t1.y; fb[6] = t1.z; fb[7] = t1.w;
+            ro_split3(fb, c1[t][0], c2[t][0], c3[t][0]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MA; mt += 2)
+            aw_tiles2<1, CT, MA>(c1, c2, c3, wimg + PL::IMG0 + lane * RO_WFS, wimg + PL::B0 + lq * 4, mt, za);
+        AF_STAMP(6);
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { x[j] = za[t][2 * kb][j]; x[4 + j] = za[t][2 * kb + 1][j]; }
+                ro_split3(x, c1[t][kb], c2[t][kb], c3[t][kb]);
+            }
+#pragma unroll
+        for (int mt = 0; mt < MB_EARLY; mt += 2)
+            aw_tiles2<KB, CT, MB>(c1, c2, c3, wimg + PL::IMG1 + lane * RO_WFS, wimg + PL::B1 + lq * 4, mt, zb);
+    }
+    if constexpr (LATE > 0) {
+        __syncthreads();
+        if (colw) {
+#pragma unroll
+            for (int mt = MB_EARLY; mt < MB; mt += 2)
+                aw_tiles2<KB, CT, MB>(c1, c2, c3, wimg + PL::IMG1 + lane * RO_WFS, wimg + PL::B1 + lq * 4, mt, zb);
+        }
+    }
+    if (colw) {
+        AF_STAMP(7);
+        // output layer on the accumulator registers: lane (li, lq) holds channels 16 a + 4 lq + rr of column li
+        const float* w2 = wimg + PL::W2;
+        const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * 16 * MB);
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            f32x2 u2 = {0.f, 0.f}, u2b = {0.f, 0.f};
+#pragma unroll
+            for (int a_ = 0; a_ < MB; ++a_) {
+                const float4 wa = *reinterpret_cast<const float4*>(w2 + 2 * (16 * a_ + 4 * lq));
+                const float4 wb = *reinterpret_cast<const float4*>(w2 + 2 * (16 * a_ + 4 * lq) + 4);
+                u2 = __builtin_elementwise_fma((f32x2){zb[t][a_][0], zb[t][a_][0]}, (f32x2){wa.x, wa.y}, u2);
+                u2b = __builtin_elementwise_fma((f32x2){zb[t][a_][1], zb[t][a_][1]}, (f32x2){wa.z, wa.w}, u2b);
+                u2 = __builtin_elementwise_fma((f32x2){zb[t][a_][2], zb[t][a_][2]}, (f32x2){wb.x, wb.y}, u2);
+                u2b = __builtin_elementwise_fma((f32x2){zb[t][a_][3], zb[t][a_][3]}, (f32x2){wb.z, wb.w}, u2b);
+            }
+            u2 = u2 + u2b;
+            const float ux = rows_sum4(u2.x) + bb.x, uy = rows_sum4(u2.y) + bb.y;
+            if (lq < 2 && wave * CT + t < NT && col[t] < N) out[((size_t)b * 2 + lq) * N + col[t]] = lq ? uy : ux;
+        }
+        AF_STAMP(8);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Backward (parameters only).  Workgroup per (b, 64-column tile).  LDS: delta ping-pong [maxw][65],
 // input tile [maxin][65].  Partials: part[tile][P] with P = sum_l cout*cin + cout, layer-major (W then b).
@@ -1047,6 +1336,21 @@ int launch_fwd_pol(const float* X, const float* G, float* out, const ActorParams
     return mgp_launch_status();
 }
 
+template <int S, int FH, int MA, int MB>
+int launch_fwd_wide(const float* X, const float* G, float* out, const ActorParams& P, const PlanM& pm, int B, int K, int N,
+                    hipStream_t st)
+{
+    using PL = AwPlan<MA, MB>;
+    const size_t red = (size_t)K * pm.nblk * 4 * 64 * 4;                      // floats
+    const size_t lds = ((size_t)pad16(N) * RO_CS + (PL::LATE ? (size_t)PL::END : PL::RED + red)) * sizeof(float);
+    if (PL::LATE && red > (size_t)PL::LATE * 64 * RO_WFS) return MGP_EUNSUPPORTED;
+    if (lds > 160 * 1024) return MGP_EUNSUPPORTED;
+    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(actor_fwd_wide_kernel<S, FH, MA, MB>), lds) != hipSuccess) return MGP_ELAUNCH;
+    hipLaunchKernelGGL((actor_fwd_wide_kernel<S, FH, MA, MB>), dim3((unsigned)B), dim3(AF_THREADS), lds, st, X, G, out, P, B, K, N,
+                       pm.nblk);
+    return mgp_launch_status();
+}
+
 template <int CT, int V>
 int launch_fwd(const float* X, const float* G, float* out, float* saved, const ActorParams& P, const Plan& pl,
                int B, int K, int N, hipStream_t st)
@@ -1104,6 +1408,17 @@ extern "C" int mgp_actor_fwd(const float* X, const float* G, const float* const*
             if (pm.S <= 16) return launch_fwd_pol<16, 2>(X, G, out, P, pm, B, K, N, st);
             if (pm.S <= 28) return launch_fwd_pol<28, 2>(X, G, out, P, pm, B, K, N, st);
             return launch_fwd_pol<32, 2>(X, G, out, P, pm, B, K, N, st);
+        }
+        // two hidden layers beyond the policy shape, inference: the split-bf16 form at 64 or 128 padded channels
+        static const bool wide_off = getenv("MGP_ACTOR_WIDE") != nullptr && atoi(getenv("MGP_ACTOR_WIDE")) == 0;   // (A/B switch)
+        if (saved == nullptr && !wide_off && n_layers == 3 && dims[0] == 6 && dims[3] == 2 && 6 * K <= 32 &&
+            (dims[1] > 32 || dims[2] > 32) && dims[1] <= 128 && dims[2] <= 128 && dims[1] % 4 == 0 && mgp_aligned16(W[1])) {
+#define MGP_AW_CASE(S_) return (dims[1] <= 64 && dims[2] <= 64) ? launch_fwd_wide<S_, 2, 4, 4>(X, G, out, P, pm, B, K, N, st) \
+                                                                 : launch_fwd_wide<S_, 2, 8, 8>(X, G, out, P, pm, B, K, N, st)
+            if (pm.S <= 16) MGP_AW_CASE(16);
+            if (pm.S <= 28) MGP_AW_CASE(28);
+            MGP_AW_CASE(32);
+#undef MGP_AW_CASE
         }
 #define MGP_AM_CASE(S_) return dims[0] <= 4 ? launch_fwd_mfma<S_, 1>(X, G, out, saved, P, pm, B, K, N, st) \
                                              : launch_fwd_mfma<S_, 2>(X, G, out, saved, P, pm, B, K, N, st)

@@ -92,6 +92,43 @@ def test_actor_fwd_mfma_variant_shapes(N, K):
     assert torch.equal(out, out2)
 
 
+WIDE_SHAPES = [((128, 128), 100, 3), ((128, 128), 128, 3), ((128, 128), 16, 5), ((128, 128), 64, 1), ((64, 64), 100, 3),
+               ((64, 64), 128, 2), ((48, 100), 100, 3), ((128, 36), 68, 2), ((36, 32), 100, 3), ((32, 40), 20, 4),
+               ((100, 72), 124, 3), ((64, 128), 96, 1), ((96, 64), 36, 5)]
+
+
+@pytest.mark.parametrize('hidden,N,K', WIDE_SHAPES)
+def test_actor_fwd_wide_inference_kernel(hidden, N, K):
+    """actor_fwd_wide_kernel: inference through mgp_actor_fwd (no saved activations) with TWO hidden layers of which one is
+    wider than 32 -- split-bf16 layers at 64 or 128 padded channels, the last planes of the [128, 128] weight image stored
+    behind the first barrier -- against the fp64 oracle and against the generic fp32-MFMA chain (MGP_ACTOR_WIDE=0 is read once
+    per process, so the generic form is reached through the training forward, which saves activations); widths that are not
+    multiples of 16, one and two column blocks, K 1..5, repeated launches bit-identical (padding never read)."""
+    from multiagent_gnn_policies_amd.learner import Actor
+    seed = 7 * N + K + hidden[0]
+    rs = np.random.RandomState(seed)
+    B = int(rs.choice([1, 3, 9]))
+    torch.manual_seed(seed)
+    actor = Actor(6, 2, list(hidden), K, 0).cuda()
+    actor.use_fused = True
+    with torch.no_grad():                                      # weights and biases large enough to saturate some tanh units
+        for c in actor.conv_layers:
+            c.weight.mul_(2.0); c.bias.add_(0.1 * torch.randn_like(c.bias))
+    X, G = (synth.make_dense_inputs if seed % 2 else synth.make_inputs)(seed, B, K, 6, N)
+    Ws = [c.weight.detach().cpu().numpy() for c in actor.conv_layers]
+    bs = [c.bias.detach().cpu().numpy() for c in actor.conv_layers]
+    ref = oa.forward(X, G, Ws, bs, 0, dtype=np.float64)
+    xt, gt = torch.from_numpy(X).cuda(), torch.from_numpy(G).cuda()
+    with torch.no_grad():
+        out = actor(xt, gt)
+        out2 = actor(xt, gt)
+    generic = actor(xt, gt)                                    # grad mode: the generic chain (it saves activations)
+    assert out.shape == ref.shape and torch.equal(out, out2)
+    e_wide, e_gen = relerr(out.cpu().numpy(), ref), relerr(generic.detach().cpu().numpy(), ref)
+    print('hidden %s N %d K %d B %d: wide kernel %.2e, generic chain %.2e vs fp64' % (hidden, N, K, B, e_wide, e_gen))
+    assert e_wide <= 1e-5 and e_gen <= 1e-5, (hidden, N, K, B)
+
+
 @pytest.mark.parametrize('seed', range(40))
 def test_state_and_sim_random_sizes(seed):
     from multiagent_gnn_policies_amd.envs import FlockParams, VecFlock

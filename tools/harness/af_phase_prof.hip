@@ -9,7 +9,9 @@ int main(int argc, char** argv) {
     int B = 256, K = 3, N = 100, F = 6;
     if (argc > 1) B = atoi(argv[1]);
     if (argc > 2) N = atoi(argv[2]);
-    int dims[4] = {F, 32, 32, 2};
+    int H = 32;
+    if (argc > 3) H = atoi(argv[3]);                   // hidden width of both layers (32: the compiled policy shape)
+    int dims[4] = {F, H, H, 2};
     size_t nG = (size_t)B * K * N * N, nX = (size_t)B * K * F * N;
     const int NSETS = 10;
     std::vector<float*> Gs(NSETS), Xs(NSETS);
@@ -20,11 +22,11 @@ int main(int argc, char** argv) {
         hipMemcpy(Xs[i], h.data(), nX * 4, hipMemcpyHostToDevice);
     }
     float *W0, *W1, *W2, *b0, *b1, *b2, *out;
-    hipMalloc(&W0, 32 * 18 * 4); hipMalloc(&W1, 32 * 32 * 4); hipMalloc(&W2, 2 * 32 * 4);
-    hipMalloc(&b0, 128); hipMalloc(&b1, 128); hipMalloc(&b2, 8); hipMalloc(&out, (size_t)B * 2 * N * 4);
-    hipMemcpy(W0, h.data(), 32 * 18 * 4, hipMemcpyHostToDevice); hipMemcpy(W1, h.data(), 32 * 32 * 4, hipMemcpyHostToDevice);
-    hipMemcpy(W2, h.data(), 2 * 32 * 4, hipMemcpyHostToDevice); hipMemcpy(b0, h.data(), 128, hipMemcpyHostToDevice);
-    hipMemcpy(b1, h.data(), 128, hipMemcpyHostToDevice); hipMemcpy(b2, h.data(), 8, hipMemcpyHostToDevice);
+    hipMalloc(&W0, H * 18 * 4); hipMalloc(&W1, H * H * 4); hipMalloc(&W2, 2 * H * 4);
+    hipMalloc(&b0, H * 4); hipMalloc(&b1, H * 4); hipMalloc(&b2, 8); hipMalloc(&out, (size_t)B * 2 * N * 4);
+    hipMemcpy(W0, h.data(), H * 18 * 4, hipMemcpyHostToDevice); hipMemcpy(W1, h.data(), H * H * 4, hipMemcpyHostToDevice);
+    hipMemcpy(W2, h.data(), 2 * H * 4, hipMemcpyHostToDevice); hipMemcpy(b0, h.data(), H * 4, hipMemcpyHostToDevice);
+    hipMemcpy(b1, h.data(), H * 4, hipMemcpyHostToDevice); hipMemcpy(b2, h.data(), 8, hipMemcpyHostToDevice);
     const float* W[3] = {W0, W1, W2}; const float* bb[3] = {b0, b1, b2};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 5; ++i) mgp_actor_fwd(Xs[i % NSETS], Gs[i % NSETS], W, bb, dims, 3, out, nullptr, B, K, N, nullptr);
