@@ -10,5 +10,6 @@ hipcc $F -o scratch/sp_prof tools/harness/sp_step_prof.hip &
 hipcc $F -DMGP_SP_PROFILE -o scratch/sp_prof_stamps tools/harness/sp_step_prof.hip &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -w -o scratch/ts_prof tools/harness/train_phase_prof.hip &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -Imultiagent_gnn_policies_amd/csrc -o scratch/stream_floor tools/harness/stream_floor.hip &
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -DMGP_AF_MLP_STAMPS -o scratch/af_prof tools/harness/af_phase_prof.hip &
 wait
 ls -la scratch/ro_prof scratch/ro_launch scratch/sp_prof scratch/sp_prof_stamps scratch/ts_prof

@@ -53,6 +53,9 @@ cp gpurun_out/wg_times_ro_launch_0.txt $O/rollout_wg_times_no_lists.txt 2>/dev/n
 timeout 300 bash tools/gpu/r5_long.sh > $O/rollout_long_launches.txt 2>&1
 # 3a'. [r5] mgp_flock_step_advance: the one-workgroup-per-episode kernel and the row-tiled one it replaces (tools/harness/flock_phase_prof.hip)
 { for cfg in "256 100" "2048 100" "256 128" "16 100"; do echo "== flock_advance_kernel, B N = $cfg"; ./scratch/fl_prof $cfg | grep -v "stamp [0-7] "; echo "== row-tiled kernel (MGP_FLOCK_ADVANCE_TILED=1), B N = $cfg"; MGP_FLOCK_ADVANCE_TILED=1 ./scratch/fl_prof $cfg | head -2; done; } > $O/flock_advance_stamps.txt 2>&1
+# 3b'. [r5] fused Actor forward at the wide shapes (actor_fwd_wide_kernel; scratch/af_prof = tools/harness/af_phase_prof.hip with the MLP
+#      stamps) and the generic fp32-MFMA chain on the same box
+{ for cfg in "256 100 128" "256 128 128" "256 100 64" "1 100 128"; do echo "== actor_fwd_wide_kernel, B N hidden = $cfg"; ./scratch/af_prof $cfg | grep -v "^block"; echo "== generic chain (MGP_ACTOR_WIDE=0), B N hidden = $cfg"; MGP_ACTOR_WIDE=0 ./scratch/af_prof $cfg | head -1; done; } > $O/actor_fwd_wide_stamps.txt 2>&1
 # 6. instruction mix of the resident kernel (harness, bench state)
 bash tools/gpu/ro_pmc.sh > $O/rollout_inst_mix.txt 2>&1
 bash tools/gpu/other_cfgs.sh > $O/other_configs.txt 2>&1

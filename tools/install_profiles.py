@@ -102,7 +102,14 @@ for src, hdr in (
         ('rollout_long_launches.txt',
          "# tools/gpu/r5_long.sh: 100 / 500 / 1000-step launches from the bench state (no resets: the flock of a 1000-step launch is 1000+ steps old),\n"
          "# candidate lists off (x0) and on (x1), with the S1 modes the helper wave chose over all workgroups.\n"),
+        ('actor_fwd_wide_stamps.txt',
+         "# tools/harness/af_phase_prof.hip B N hidden (-DMGP_AF_MLP_STAMPS): mgp_actor_fwd, inference, two hidden layers of `hidden` channels, back to back on\n"
+         "# rotating input sets; stamps of workgroup 0 (shader cycles): thread 0 (a streaming wave, then column tile 0): 1 = its X + G requests issued |\n"
+         "# 2 = its 4x4x1 MFMAs done | 3 = aggregation tile written | 4 = first barrier passed | 6 = layer 0 done | 7 = layer 1 done (incl. the second\n"
+         "# barrier at [128, 128]) | 8 = action written; first thread of staging wave 0: 19 = its records are in LDS.  Below each block the generic\n"
+         "# fp32-MFMA chain (MGP_ACTOR_WIDE=0) on the same box.\n"),
         ('rollout_wg_times_lists.txt', ''), ('rollout_wg_times_no_lists.txt', '')):
     if os.path.exists(O + '/' + src):
-        open('profiles/%s_%s' % (R, src), 'w').write(hdr + open(O + '/' + src).read())
+        body = ''.join(l for l in open(O + '/' + src).read().splitlines(True) if not l.startswith('+ '))     # (the regen script runs under set -x)
+        open('profiles/%s_%s' % (R, src), 'w').write(hdr + body)
 print('installed profiles/%s_*' % R)
