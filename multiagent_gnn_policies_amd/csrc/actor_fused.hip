@@ -593,6 +593,10 @@ void actor_fwd_mfma_kernel(const float* __restrict__ X, const float* __restrict_
             for (int i = zlo + lane; i < zhi; i += 64) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef MGP_AF_STAGE_PRIO
+#define MGP_AF_STAGE_PRIO 1
+#endif
+        if (MGP_AF_STAGE_PRIO) __builtin_amdgcn_s_setprio(3);
         for (int l = 0; l < P.n_layers; ++l) {
             const int cin = (l == 0) ? FK : P.dims[l], cout = P.dims[l + 1], stride = WC.lstride[l];
             const float* src = P.W[l] + lane;
@@ -607,6 +611,7 @@ void actor_fwd_mfma_kernel(const float* __restrict__ X, const float* __restrict_
                 if (lane + 64 < cout) lds_dma_dword(P.b[l] + lane + 64, dst + pad16(cout) * stride + 64);
             }
         }
+        if (MGP_AF_STAGE_PRIO) __builtin_amdgcn_s_setprio(0);
         AF_STAMP_T(16, 64 * nstream);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         AF_STAMP_T(19, 64 * nstream);
@@ -1297,16 +1302,20 @@ bool make_plan_mfma(const float* const* W, const float* const* bias, const int* 
         wc.strideP |= (unsigned long long)(wc.lstride[l] & 255) << (8 * l);
     }
     if (wtot > 0xFFFF) return false;
-    // cut the area where half of the weight rows (one LDS-DMA each) lie below
+    // cut the area where half of the LDS-DMA instructions lie below: a row costs one per 64 input channels ([r5]: the cut used to
+    // count rows -- at [18 -> 128 -> 128 -> 2] staging wave 1 issued 320 of the 388 and the barrier waited for it until 31k cycles)
     wc.split = wtot;
+    (void)rows_total;
+    int cost_total = 0;
+    for (int l = 0; l < n_layers; ++l) cost_total += dims[l + 1] * ((((l == 0) ? F * K : dims[l]) + 63) / 64);
     for (int l = 0, seen = 0; l < n_layers; ++l) {
-        const int cout = dims[l + 1];
-        int os = (rows_total + 1) / 2 - seen;
+        const int cout = dims[l + 1], per_row = (((l == 0) ? F * K : dims[l]) + 63) / 64;
+        int os = ((cost_total + 1) / 2 - seen) / per_row;
         os = os < 0 ? 0 : (os > cout ? cout : os);
         wc.osplit[l] = os;
         if (os < cout && wc.split == wtot) wc.split = wc.lw[l] + os * wc.lstride[l];
         wc.bias_owner[l] = (wc.lw[l] + pad16(cout) * wc.lstride[l] >= wc.split) ? 1 : 0;
-        seen += cout;
+        seen += cout * per_row;
     }
     const int buf = pad16(N) * AF_CS;
     pm->cv.ys = 0; pm->cv.w = buf; pm->cv.wtot = wtot;
