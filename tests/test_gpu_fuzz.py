@@ -129,6 +129,49 @@ def test_actor_fwd_wide_inference_kernel(hidden, N, K):
     assert e_wide <= 1e-5 and e_gen <= 1e-5, (hidden, N, K, B)
 
 
+DEEP_SHAPES = [((128, 128, 128), 100, 3), ((128, 128, 128, 128), 100, 3), ((128, 128, 128), 128, 3), ((128, 64, 128), 16, 5),
+               ((100, 72, 96, 48), 124, 2), ((32, 128, 32), 64, 1), ((128, 128, 128, 128, 128), 36, 4), ((68, 128, 128), 96, 3)]
+
+
+@pytest.mark.parametrize('hidden,N,K', DEEP_SHAPES)
+def test_actor_fwd_deep_inference(hidden, N, K):
+    """mgp_actor_fwd_deep (three or more hidden layers, one wider than 64: cfg/hidden_size.cfg n_layers 3, 4 at hidden_size
+    128): actor_fwd_wide_kernel writing the second hidden layer + one actor_tail_kernel launch per further layer, against the
+    fp64 oracle and against the composed path (mgp_agg_fwd + mgp_dense_fwd per layer, what these shapes ran on before);
+    ragged widths, one and two column blocks, repeated calls bit-identical."""
+    from multiagent_gnn_policies_amd.learner import Actor
+    seed = 5 * N + K + len(hidden)
+    rs = np.random.RandomState(seed)
+    B = int(rs.choice([1, 3, 9]))
+    torch.manual_seed(seed)
+    actor = Actor(6, 2, list(hidden), K, 0).cuda()
+    with torch.no_grad():
+        for c in actor.conv_layers:
+            c.weight.mul_(1.5); c.bias.add_(0.1 * torch.randn_like(c.bias))
+    X, G = (synth.make_dense_inputs if seed % 2 else synth.make_inputs)(seed, B, K, 6, N)
+    Ws = [c.weight.detach().cpu().numpy() for c in actor.conv_layers]
+    bs = [c.bias.detach().cpu().numpy() for c in actor.conv_layers]
+    ref = oa.forward(X, G, Ws, bs, 0, dtype=np.float64)
+    xt, gt = torch.from_numpy(X).cuda(), torch.from_numpy(G).cuda()
+    from multiagent_gnn_policies_amd.learner import actor_fused
+    with torch.no_grad():
+        actor.use_fused = True
+        import ctypes
+        cdims = (ctypes.c_int * (len(hidden) + 2))(6, *hidden, 2)
+        deep = actor_fused._try_forward_deep(actor, xt, gt, cdims)      # (shapes the one-launch plan also covers go there in actor())
+        assert deep is not None, 'shape not taken by mgp_actor_fwd_deep'
+        deep2 = actor_fused._try_forward_deep(actor, xt, gt, cdims)
+        out = actor(xt, gt)
+        out2 = actor(xt, gt)
+        actor.use_fused = False
+        composed = actor(xt, gt)
+    assert out.shape == ref.shape and torch.equal(out, out2) and torch.equal(deep, deep2)
+    assert relerr(out.cpu().numpy(), ref) <= 1e-5
+    e_deep, e_comp = relerr(deep.cpu().numpy(), ref), relerr(composed.cpu().numpy(), ref)
+    print('hidden %s N %d K %d B %d: deep path %.2e, composed %.2e vs fp64' % (hidden, N, K, B, e_deep, e_comp))
+    assert e_deep <= 1e-5 and e_comp <= 1e-5, (hidden, N, K, B)
+
+
 @pytest.mark.parametrize('seed', range(40))
 def test_state_and_sim_random_sizes(seed):
     from multiagent_gnn_policies_amd.envs import FlockParams, VecFlock

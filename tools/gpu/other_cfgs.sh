@@ -28,6 +28,8 @@ done <<CFGS
 256 100 3 64 2 FlockingRelative-v0
 256 100 3 128 1 FlockingRelative-v0
 256 100 3 128 2 FlockingRelative-v0
+256 100 3 128 3 FlockingRelative-v0
+256 100 3 128 4 FlockingRelative-v0
 256 100 3 32 2 FlockingStochastic-v0
 256 100 1 32 2 FlockingLeader-v0
 256 100 2 32 2 FlockingTwoFlocks-v0
