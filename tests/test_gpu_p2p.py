@@ -26,7 +26,9 @@ def run_ranks(scenario, world=2, timeout=600, **extra):
     procs = []
     for rk in range(world):
         env = dict(os.environ, PYTHONPATH=ROOT, RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE=str(world),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=port, MGP_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=port, MGP_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0',
+                   MGP_P2P_TIMEOUT_MS='60000')     # the ranks share ONE device here and take turns on it: on a loaded box an exchange
+                                                   # of eight ranks has waited out the 5 s default (the 'timeout' scenario sets its own)
         env.update(extra)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'p2p_worker.py'), scenario], cwd=ROOT,
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))

@@ -205,6 +205,7 @@ def _bench_no_launcher(extra, backend='gloo', timeout=900):
         env.pop(k_, None)
     if backend is not None:
         env['MGP_DIST_BACKEND'] = backend
+        env['MGP_P2P_TIMEOUT_MS'] = '60000'                  # gloo here = two ranks taking turns on ONE device
     return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + extra, cwd=ROOT, env=env,
                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
 

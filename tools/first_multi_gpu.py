@@ -38,7 +38,7 @@ def main():
     dry = os.environ.get('DRY') == '1' or ndev < 2
     rec = {"devices_visible": ndev, "dry_run_on_one_device": dry, "torch": torch.__version__,
            "device_name": torch.cuda.get_device_name(0) if ndev else None}
-    share = {'MGP_DIST_BACKEND': 'gloo'} if dry else {}
+    share = {'MGP_DIST_BACKEND': 'gloo', 'MGP_P2P_TIMEOUT_MS': '60000'} if dry else {}     # ranks taking turns on one device wait longer
     worlds = [1, 2] if dry else [n for n in (1, 2, 4, 8) if n <= ndev]
     # ---- rollout scaling (no data-path collective: episodes shard)
     rec["rollout"] = {}
