@@ -39,6 +39,8 @@ SHAPES = [
     ('FlockingRelative-v0', 100, 3, 64, 2),      # cfg/hidden_size.cfg
     ('FlockingRelative-v0', 100, 3, 128, 1),
     ('FlockingRelative-v0', 100, 3, 128, 2),
+    ('FlockingRelative-v0', 100, 3, 128, 3),     # cfg/hidden_size.cfg:104-106 (inference: mgp_actor_fwd_deep; updates on the composed ops)
+    ('FlockingRelative-v0', 100, 3, 128, 4),     # cfg/hidden_size.cfg:128-130
     ('FlockingRelative-v0', 100, 3, 64, 1),
     ('FlockingRelative-v0', 100, 3, 32, 1),
     ('FlockingRelative-v0', 100, 3, 32, 3),
