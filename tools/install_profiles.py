@@ -108,6 +108,10 @@ for src, hdr in (
          "# 2 = its 4x4x1 MFMAs done | 3 = aggregation tile written | 4 = first barrier passed | 6 = layer 0 done | 7 = layer 1 done (incl. the second\n"
          "# barrier at [128, 128]) | 8 = action written; first thread of staging wave 0: 19 = its records are in LDS.  Below each block the generic\n"
          "# fp32-MFMA chain (MGP_ACTOR_WIDE=0) on the same box.\n"),
+        ('hidden_grid.txt',
+         "# tools/gpu/hidden_grid.sh: every (n_layers, hidden_size) of the reference's cfg/hidden_size.cfg at N = 100, K = 3, 256 episodes, 100-step\n"
+         "# policy_rollout calls after a disc reset: agent-steps/s (value = the resident kernel where it covers the shape), the two paths, the in-run\n"
+         "# parity gate per path (max_rel against the CPU port's Actor forward and the bound it passed on), the weights (trained where a fixture exists).\n"),
         ('rollout_wg_times_lists.txt', ''), ('rollout_wg_times_no_lists.txt', '')):
     if os.path.exists(O + '/' + src):
         body = ''.join(l for l in open(O + '/' + src).read().splitlines(True) if not l.startswith('+ '))     # (the regen script runs under set -x)
