@@ -60,5 +60,6 @@ timeout 300 bash tools/gpu/r5_long.sh > $O/rollout_long_launches.txt 2>&1
 bash tools/gpu/ro_pmc.sh > $O/rollout_inst_mix.txt 2>&1
 bash tools/gpu/other_cfgs.sh > $O/other_configs.txt 2>&1
 bash tools/gpu/hidden_grid.sh > $O/hidden_grid.txt 2>&1
+bash tools/gpu/sweep_grid.sh > $O/sweep_grid.txt 2>&1
 rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_fetch20 $O/pmc_write20 $O/pmc_fetch_f $O/pmc_write_f $O/trace gpurun_out/ro_pmc
 ls $O

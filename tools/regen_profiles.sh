@@ -63,6 +63,7 @@ hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -w -o /tmp/af_prof tools/ha
 python tools/bench_update.py > $O/dagger_update.json 2> $O/dagger_update.err
 bash tools/gpu/other_cfgs.sh > $O/other_configs.txt 2>&1
 bash tools/gpu/hidden_grid.sh > $O/hidden_grid.txt 2>&1
+bash tools/gpu/sweep_grid.sh > $O/sweep_grid.txt 2>&1
 for cfg in "1 100 3 32 2" "2048 100 3 32 2"; do set -- $cfg; python bench.py --episodes $1 --agents $2 --taps $3 --hidden $4 --layers $5 --no-cpu-baseline --steps 100 --warmup 10 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
