@@ -30,7 +30,7 @@ extern "C" {
                                              leaves the weights untouched (mgp_train_step_p2p);
                                       0.3.2: + mgp_replay_aggregate, mgp_train_step_agg / _grads_agg / _agg_supported (DAGGER updates on
                                              the aggregated first-layer input, operator slices never formed), mgp_flock_reset_check;
-                                      0.3.3: + mgp_actor_fwd_deep / mgp_actor_deep_scratch_floats (inference with three or more hidden layers
+                                      0.3.3: + mgp_actor_fwd_deep / mgp_actor_deep_supported (inference with three or more hidden layers
                                              beyond the one-launch LDS plan: hidden_size 128 at n_layers 3, 4) */
 
 #define MGP_OK            0
@@ -125,15 +125,15 @@ int  mgp_actor_fwd(const float* X, const float* G,
                    int B, int K, int N, void* stream);
 
 /* The same forward for THREE OR MORE hidden layers of which one is wider than 64 (cfg/hidden_size.cfg:104-106, 128-130:
- * n_layers 3 and 4 at hidden_size 128; reference learner/actor.py:45-86, inference): aggregation + the first two hidden
- * layers in one launch, one launch per further hidden layer (the last one with the output layer), activations (B, h, N)
- * through `scratch` (mgp_actor_deep_scratch_floats() floats; 0 = shape not covered: F = 6, nA = 2, 6 K <= 32, hidden widths
- * multiples of 4 up to 128, 16 <= N <= 128, N % 4 == 0).  X, G and W[1 .. n_layers-2] 16-byte aligned. */
-long mgp_actor_deep_scratch_floats(const int* dims, int n_layers, int B, int K, int N);
+ * n_layers 3 and 4 at hidden_size 128; reference learner/actor.py:45-86, inference only): one launch -- the aggregation and
+ * the first two hidden layers as in mgp_actor_fwd, then every further hidden layer on the same workgroup with the weight image
+ * in LDS rebuilt per layer (the activations stay in the matrix accumulators).  mgp_actor_deep_supported: F = 6, nA = 2,
+ * 6 K <= 32, hidden widths multiples of 4 up to 128, 16 <= N <= 128, N % 4 == 0.  X, G and W[1 .. n_layers-2] 16-byte aligned. */
+int  mgp_actor_deep_supported(const int* dims, int n_layers, int K, int N);
 int  mgp_actor_fwd_deep(const float* X, const float* G,
                         const float* const* W, const float* const* b,
                         const int* dims, int n_layers,
-                        float* out, float* scratch,
+                        float* out,
                         int B, int K, int N, void* stream);
 
 /* Backward of the fused Actor forward (parameters only; X and G are leaves without grad

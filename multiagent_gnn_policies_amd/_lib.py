@@ -58,9 +58,9 @@ SIGNATURES = {
     'mgp_actor_supported': (_int, [ctypes.POINTER(_int), _int, _int, _int]),
     'mgp_actor_fwd': (_int, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_int), _int,
                              _vp, _vp, _int, _int, _int, _vp]),
-    'mgp_actor_deep_scratch_floats': (_long, [ctypes.POINTER(_int), _int, _int, _int, _int]),
+    'mgp_actor_deep_supported': (_int, [ctypes.POINTER(_int), _int, _int, _int]),
     'mgp_actor_fwd_deep': (_int, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_int), _int,
-                                  _vp, _vp, _int, _int, _int, _vp]),
+                                  _vp, _int, _int, _int, _vp]),
     'mgp_actor_bwd_workspace': (_long, [ctypes.POINTER(_int), _int, _int, _int, _int]),
     'mgp_actor_bwd': (_int, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_int), _int, ctypes.POINTER(_vp),
                              ctypes.POINTER(_vp), _int, _int, _int, _vp, _vp]),

@@ -864,7 +864,7 @@ __device__ __forceinline__ void aw_tiles2(const ro_bf16x8 (&b1)[CT][4], const ro
             for (int rr = 0; rr < 4; ++rr) z[t][mt + m][rr] = tanh_fast(acc[m][t][rr]);
 }
 
-template <int S, int FH, int MA, int MB, bool HID = false>   // HID: write the second hidden layer (B, h2, N) to `out` instead of the action (mgp_actor_fwd_deep)
+template <int S, int FH, int MA, int MB, bool HID = false>   // HID: further hidden layers follow the second one in the same launch (mgp_actor_fwd_deep)
 __global__ __launch_bounds__(AF_THREADS)
 void actor_fwd_wide_kernel(const float* __restrict__ X, const float* __restrict__ G, float* __restrict__ out, ActorParams P,
                            int B, int K, int N, int nblk)
@@ -1059,18 +1059,61 @@ void actor_fwd_wide_kernel(const float* __restrict__ X, const float* __restrict_
         }
     }
     if constexpr (HID) {
-        if (colw) {
+        // ---- hidden layers 2 .. n_layers - 2 in the same launch: a column wave's accumulators ARE the next layer's B operand, so only
+        // the weight image changes -- all eight waves rebuild the 32 planes of IMG1 (four each; their requests go out before the
+        // barrier that ends the previous layer's reads), the biases and, with the last hidden layer, the output layer.  Two
+        // barriers per layer; no activation leaves the CU.
+        static_assert(MA == 8 && MB == 8 && (S <= 16 || MGP_AW_CT == 1), "deep form: 128 padded channels, one column tile per wave");
+        for (int l = 2; l < P.n_layers - 1; ++l) {
+            const int cin = P.dims[l], cout = P.dims[l + 1];
+            const bool lastl = l == P.n_layers - 2;
+            const float* Wl = P.W[l];
+            float4 w1[4][2];
 #pragma unroll
-            for (int t = 0; t < CT; ++t)
-                if (wave * CT + t < NT && col[t] < N) {
-                    // scratch layout (B, N, 128): a column's channels are contiguous -- the four accumulator registers of an m-tile are
-                    // one aligned quad, and the next launch reads its B operand as eight quads (channels beyond h2 hold tanh(0) = 0)
-                    float4* zr = reinterpret_cast<float4*>(out + ((size_t)b * N + col[t]) * 128 + 4 * lq);
+            for (int i = 0; i < 4; ++i) {
+                const int q = wave + 8 * i, mt = q >> 2, kb = q & 3;
+                const float* row = Wl + (size_t)min(16 * mt + li, cout - 1) * cin;
+                const int c0 = 32 * kb + 4 * lq;
+                w1[i][0] = *reinterpret_cast<const float4*>(row + min(c0, cin - 4));           // cin % 4 == 0
+                w1[i][1] = *reinterpret_cast<const float4*>(row + min(c0 + 16, cin - 4));
+            }
+            float bvl = 0.f, w2l = 0.f;
+            if (tid < 128) bvl = P.b[l][min(tid, cout - 1)];
+            if (lastl && tid >= 128 && tid < 384) { const int e = tid - 128, c = e >> 1, o = e & 1; w2l = P.W[l + 1][(size_t)o * cout + min(c, cout - 1)]; }
+            if (lastl && tid >= 384 && tid < 386) w2l = P.b[l + 1][tid - 384];
+            __syncthreads();                                       // every column wave has finished with the previous image
 #pragma unroll
-                    for (int mt = 0; mt < MB; ++mt) zr[4 * mt] = make_float4(zb[t][mt][0], zb[t][mt][1], zb[t][mt][2], zb[t][mt][3]);
+            for (int i = 0; i < 4; ++i) {
+                const int q = wave + 8 * i, mt = q >> 2, kb = q & 3;
+                const int o = 16 * mt + li, c0 = 32 * kb + 4 * lq;
+                const bool ok0 = o < cout && c0 < cin, ok1 = o < cout && c0 + 16 < cin;
+                const float4 u0 = w1[i][0], u1 = w1[i][1];
+                float w[8] = {ok0 ? u0.x : 0.f, ok0 ? u0.y : 0.f, ok0 ? u0.z : 0.f, ok0 ? u0.w : 0.f,
+                              ok1 ? u1.x : 0.f, ok1 ? u1.y : 0.f, ok1 ? u1.z : 0.f, ok1 ? u1.w : 0.f};
+                ro_bf16x8 a1, a2, a3;
+                ro_split3(w, a1, a2, a3);
+                float4* d4 = reinterpret_cast<float4*>(wimg + PL::IMG1 + (q * 64 + lane) * RO_WFS);
+                d4[0] = *reinterpret_cast<const float4*>(&a1);
+                d4[1] = *reinterpret_cast<const float4*>(&a2);
+                d4[2] = *reinterpret_cast<const float4*>(&a3);
+            }
+            if (tid < 128) wimg[PL::B1 + tid] = (tid < cout) ? bvl : 0.f;
+            if (lastl && tid >= 128 && tid < 384) wimg[PL::W2 + tid - 128] = (((tid - 128) >> 1) < cout) ? w2l : 0.f;
+            if (lastl && tid >= 384 && tid < 386) wimg[PL::W2 + 2 * 16 * MB + tid - 384] = w2l;
+            __syncthreads();
+            if (colw) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    float x[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { x[j] = zb[0][2 * kb][j]; x[4 + j] = zb[0][2 * kb + 1][j]; }
+                    ro_split3(x, c1[0][kb], c2[0][kb], c3[0][kb]);
                 }
+#pragma unroll
+                for (int mt = 0; mt < 8; mt += 2)
+                    aw_tiles2<4, CT, MB>(c1, c2, c3, wimg + PL::IMG1 + lane * RO_WFS, wimg + PL::B1 + lq * 4, mt, zb);
+            }
         }
-        return;
     }
     if (colw) {
         AF_STAMP(7);
@@ -1094,116 +1137,6 @@ void actor_fwd_wide_kernel(const float* __restrict__ X, const float* __restrict_
             if (lq < 2 && wave * CT + t < NT && col[t] < N) out[((size_t)b * 2 + lq) * N + col[t]] = lq ? uy : ux;
         }
         AF_STAMP(8);
-    }
-}
-
-// ---- Hidden layers beyond the second (cfg/hidden_size.cfg: n_layers 3 and 4 at hidden_size 128: two 98 KB weight images do not
-// share a CU's LDS, so these shapes used to fall to mgp_agg_fwd + one mgp_dense_fwd per layer, 210-280 us per step).  One launch
-// per further hidden layer: workgroup = episode, a wave = 16 agent columns; the input activations Z (B, N, 128: channels of a
-// column contiguous) come straight from HBM into the B-operand registers as eight quads (channel 32 kb + 4 lq + j | 32 kb + 16 +
-// 4 lq + (j - 4) of the lane's column: the enumeration of aw_tiles2), the layer's bf16 piece image (32 planes) is built by all eight waves, four planes each, every
-// request of the wave issued first; one barrier; the layer as in actor_fwd_wide_kernel.  LAST: the 2-wide output layer on the
-// accumulators, else the activations go back to HBM for the next launch.
-constexpr int AT_IMG = 32 * 64 * RO_WFS, AT_B = AT_IMG, AT_W2 = AT_B + 128, AT_END = AT_W2 + 2 * 128 + 16;   // floats
-
-template <bool LAST>
-__global__ __launch_bounds__(AF_THREADS)
-void actor_tail_kernel(const float* __restrict__ Zin, const float* __restrict__ Wl, const float* __restrict__ bl,
-                       const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ dst,
-                       int cin, int cout, int N)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lq = lane >> 4;
-    const int b = blockIdx.x;
-    float* wimg = smem;
-    const int NT = pad16(N) / 16;
-    const bool colw = wave < NT;
-    const int col = min(wave * 16 + li, N - 1);
-    // the wave's input operand (32 values per lane; clamped addresses, masked below), then its four planes of the image
-    float zin[4][8];
-    {
-        const float4* zr = reinterpret_cast<const float4*>(Zin + ((size_t)b * N + col) * 128 + 4 * lq);   // (B, N, 128): see the writers
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), u1 = u0;
-            if (colw) { u0 = zr[8 * kb]; u1 = zr[8 * kb + 4]; }
-            zin[kb][0] = u0.x; zin[kb][1] = u0.y; zin[kb][2] = u0.z; zin[kb][3] = u0.w;
-            zin[kb][4] = u1.x; zin[kb][5] = u1.y; zin[kb][6] = u1.z; zin[kb][7] = u1.w;
-        }
-    }
-    float4 w1[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = wave + 8 * i, mt = q >> 2, kb = q & 3;
-        const float* row = Wl + (size_t)min(16 * mt + li, cout - 1) * cin;
-        const int c0 = 32 * kb + 4 * lq;
-        w1[i][0] = *reinterpret_cast<const float4*>(row + min(c0, cin - 4));               // cin % 4 == 0
-        w1[i][1] = *reinterpret_cast<const float4*>(row + min(c0 + 16, cin - 4));
-    }
-    float bv = 0.f, w2v = 0.f;
-    if (tid < 128) bv = bl[min(tid, cout - 1)];
-    if (LAST && tid >= 128 && tid < 384) { const int e = tid - 128, c = e >> 1, o = e & 1; w2v = W2[(size_t)o * cout + min(c, cout - 1)]; }
-    if (LAST && tid >= 384 && tid < 386) w2v = b2[tid - 384];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = wave + 8 * i, mt = q >> 2, kb = q & 3;
-        const int o = 16 * mt + li, c0 = 32 * kb + 4 * lq;
-        const bool ok0 = o < cout && c0 < cin, ok1 = o < cout && c0 + 16 < cin;
-        const float4 u0 = w1[i][0], u1 = w1[i][1];
-        float w[8] = {ok0 ? u0.x : 0.f, ok0 ? u0.y : 0.f, ok0 ? u0.z : 0.f, ok0 ? u0.w : 0.f,
-                      ok1 ? u1.x : 0.f, ok1 ? u1.y : 0.f, ok1 ? u1.z : 0.f, ok1 ? u1.w : 0.f};
-        ro_bf16x8 a1, a2, a3;
-        ro_split3(w, a1, a2, a3);
-        float4* d4 = reinterpret_cast<float4*>(wimg + (q * 64 + lane) * RO_WFS);
-        d4[0] = *reinterpret_cast<const float4*>(&a1);
-        d4[1] = *reinterpret_cast<const float4*>(&a2);
-        d4[2] = *reinterpret_cast<const float4*>(&a3);
-    }
-    if (tid < 128) wimg[AT_B + tid] = (tid < cout) ? bv : 0.f;
-    if (LAST && tid >= 128 && tid < 384) wimg[AT_W2 + tid - 128] = (((tid - 128) >> 1) < cout) ? w2v : 0.f;
-    if (LAST && tid >= 384 && tid < 386) wimg[AT_W2 + 256 + tid - 384] = w2v;
-    __syncthreads();
-    if (!colw) return;
-    ro_bf16x8 c1[1][4], c2[1][4], c3[1][4];
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-        float x[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = 32 * kb + (j < 4 ? 4 * lq + j : 16 + 4 * lq + (j - 4));
-            x[j] = (c < cin) ? zin[kb][j] : 0.f;
-        }
-        ro_split3(x, c1[0][kb], c2[0][kb], c3[0][kb]);
-    }
-    float zb[1][8][4];
-#pragma unroll
-    for (int mt = 0; mt < 8; mt += 2)
-        aw_tiles2<4, 1, 8>(c1, c2, c3, wimg + lane * RO_WFS, wimg + AT_B + lq * 4, mt, zb);
-    const int colr = wave * 16 + li;
-    if constexpr (LAST) {
-        const float* w2 = wimg + AT_W2;
-        const float2 bb = *reinterpret_cast<const float2*>(w2 + 256);
-        f32x2 u2 = {0.f, 0.f}, u2b = {0.f, 0.f};
-#pragma unroll
-        for (int a_ = 0; a_ < 8; ++a_) {
-            const float4 wa = *reinterpret_cast<const float4*>(w2 + 2 * (16 * a_ + 4 * lq));
-            const float4 wb = *reinterpret_cast<const float4*>(w2 + 2 * (16 * a_ + 4 * lq) + 4);
-            u2 = __builtin_elementwise_fma((f32x2){zb[0][a_][0], zb[0][a_][0]}, (f32x2){wa.x, wa.y}, u2);
-            u2b = __builtin_elementwise_fma((f32x2){zb[0][a_][1], zb[0][a_][1]}, (f32x2){wa.z, wa.w}, u2b);
-            u2 = __builtin_elementwise_fma((f32x2){zb[0][a_][2], zb[0][a_][2]}, (f32x2){wb.x, wb.y}, u2);
-            u2b = __builtin_elementwise_fma((f32x2){zb[0][a_][3], zb[0][a_][3]}, (f32x2){wb.z, wb.w}, u2b);
-        }
-        u2 = u2 + u2b;
-        const float ux = rows_sum4(u2.x) + bb.x, uy = rows_sum4(u2.y) + bb.y;
-        if (lq < 2 && colr < N) dst[((size_t)b * 2 + lq) * N + colr] = lq ? uy : ux;
-    } else {
-        if (colr < N) {
-            float4* zr = reinterpret_cast<float4*>(dst + ((size_t)b * N + colr) * 128 + 4 * lq);
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt) zr[4 * mt] = make_float4(zb[0][mt][0], zb[0][mt][1], zb[0][mt][2], zb[0][mt][3]);
-        }
     }
 }
 
@@ -1485,7 +1418,7 @@ int launch_fwd_wide(const float* X, const float* G, float* out, const ActorParam
 }
 
 template <int S>
-int launch_fwd_wide_hidden(const float* X, const float* G, float* zout, const ActorParams& P, const PlanM& pm, int B, int K, int N,
+int launch_fwd_wide_hidden(const float* X, const float* G, float* out, const ActorParams& P, const PlanM& pm, int B, int K, int N,
                            hipStream_t st)
 {
     using PL = AwPlan<8, 8>;
@@ -1493,7 +1426,7 @@ int launch_fwd_wide_hidden(const float* X, const float* G, float* zout, const Ac
     const size_t lds = ((size_t)pad16(N) * RO_CS + (size_t)PL::END) * sizeof(float);
     if (red > (size_t)PL::LATE * 64 * RO_WFS || lds > 160 * 1024) return MGP_EUNSUPPORTED;
     if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(actor_fwd_wide_kernel<S, 2, 8, 8, true>), lds) != hipSuccess) return MGP_ELAUNCH;
-    hipLaunchKernelGGL((actor_fwd_wide_kernel<S, 2, 8, 8, true>), dim3((unsigned)B), dim3(AF_THREADS), lds, st, X, G, zout, P, B, K, N,
+    hipLaunchKernelGGL((actor_fwd_wide_kernel<S, 2, 8, 8, true>), dim3((unsigned)B), dim3(AF_THREADS), lds, st, X, G, out, P, B, K, N,
                        pm.nblk);
     return mgp_launch_status();
 }
@@ -1542,19 +1475,18 @@ static bool deep_shape(const int* dims, int n_layers, int K, int N)
     return widest > 64;
 }
 
-extern "C" long mgp_actor_deep_scratch_floats(const int* dims, int n_layers, int B, int K, int N)
+extern "C" int mgp_actor_deep_supported(const int* dims, int n_layers, int K, int N)
 {
-    if (B <= 0 || !deep_shape(dims, n_layers, K, N)) return 0;
-    return 2L * B * 128 * N;
+    return deep_shape(dims, n_layers, K, N) ? 1 : 0;
 }
 
 extern "C" int mgp_actor_fwd_deep(const float* X, const float* G, const float* const* W, const float* const* b,
-                                  const int* dims, int n_layers, float* out, float* scratch, int B, int K, int N, void* stream)
+                                  const int* dims, int n_layers, float* out, int B, int K, int N, void* stream)
 {
     if (dims == nullptr || W == nullptr || b == nullptr || B < 0) return MGP_EINVAL;
     if (!deep_shape(dims, n_layers, K, N)) return MGP_EUNSUPPORTED;
     if (B == 0) return MGP_OK;
-    MGP_CHECK_PTR(X); MGP_CHECK_PTR(G); MGP_CHECK_PTR(out); MGP_CHECK_PTR(scratch);
+    MGP_CHECK_PTR(X); MGP_CHECK_PTR(G); MGP_CHECK_PTR(out);
     if (!mgp_aligned16(X) || !mgp_aligned16(G)) return MGP_EALIGN;
     ActorParams P;
     P.n_layers = n_layers;
@@ -1569,29 +1501,9 @@ extern "C" int mgp_actor_fwd_deep(const float* X, const float* G, const float* c
     PlanM pm;
     pm.nblk = N / 4 > 16 ? 2 : 1;
     pm.S = 4 * ((N + 15) / 16);
-    float* z[2] = {scratch, scratch + (size_t)B * 128 * N};
-    int rc = pm.S <= 16 ? launch_fwd_wide_hidden<16>(X, G, z[0], P, pm, B, K, N, st)
-           : pm.S <= 28 ? launch_fwd_wide_hidden<28>(X, G, z[0], P, pm, B, K, N, st)
-                        : launch_fwd_wide_hidden<32>(X, G, z[0], P, pm, B, K, N, st);
-    if (rc != MGP_OK) return rc;
-    const size_t lds = (size_t)AT_END * sizeof(float);
-    int cur = 0;
-    for (int l = 2; l < n_layers - 1; ++l) {                    // hidden layer l: dims[l] -> dims[l + 1]
-        const bool last = l == n_layers - 2;
-        if (last) {
-            if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(actor_tail_kernel<true>), lds) != hipSuccess) return MGP_ELAUNCH;
-            hipLaunchKernelGGL(actor_tail_kernel<true>, dim3((unsigned)B), dim3(AF_THREADS), lds, st, z[cur], W[l], b[l],
-                               W[l + 1], b[l + 1], out, dims[l], dims[l + 1], N);
-        } else {
-            if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(actor_tail_kernel<false>), lds) != hipSuccess) return MGP_ELAUNCH;
-            hipLaunchKernelGGL(actor_tail_kernel<false>, dim3((unsigned)B), dim3(AF_THREADS), lds, st, z[cur], W[l], b[l],
-                               (const float*)nullptr, (const float*)nullptr, z[cur ^ 1], dims[l], dims[l + 1], N);
-        }
-        rc = mgp_launch_status();
-        if (rc != MGP_OK) return rc;
-        cur ^= 1;
-    }
-    return MGP_OK;
+    return pm.S <= 16 ? launch_fwd_wide_hidden<16>(X, G, out, P, pm, B, K, N, st)
+         : pm.S <= 28 ? launch_fwd_wide_hidden<28>(X, G, out, P, pm, B, K, N, st)
+                      : launch_fwd_wide_hidden<32>(X, G, out, P, pm, B, K, N, st);
 }
 
 extern "C" int mgp_actor_fwd(const float* X, const float* G, const float* const* W, const float* const* b,

@@ -59,34 +59,23 @@ class _ActorFusedFn(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads)
 
 
-_deep_scratch = {}
-
-
 def _try_forward_deep(actor, delay_state, delay_gso, cdims):
-    """Inference with three or more hidden layers beyond the one-launch LDS plan (hidden_size 128 at n_layers 3, 4):
-    mgp_actor_fwd_deep, activations through a cached scratch buffer.  None when not covered (or gradients are wanted)."""
+    """Inference with three or more hidden layers beyond mgp_actor_fwd's LDS plan (hidden_size 128 at n_layers 3, 4):
+    mgp_actor_fwd_deep, one launch.  None when not covered (or gradients are wanted: the composed ops carry autograd)."""
     if torch.is_grad_enabled() and any(p.requires_grad for p in actor.parameters()):
         return None
     L = _lib.lib()
     B, K, _, N = delay_state.shape
-    n = L.mgp_actor_deep_scratch_floats(cdims, actor.n_layers, B, actor.k, N)
-    if n <= 0:
+    if not L.mgp_actor_deep_supported(cdims, actor.n_layers, actor.k, N):
         return None
     X, G = delay_state.contiguous(), delay_gso.contiguous()
     Ws = [c.weight.view(c.weight.shape[0], -1).contiguous() for c in actor.conv_layers]
     bs = [c.bias.contiguous() for c in actor.conv_layers]
     if (X.data_ptr() | G.data_ptr()) & 15 or any(w.data_ptr() & 15 for w in Ws[1:-1]):
         return None
-    if torch.cuda.is_current_stream_capturing():               # a graph's buffers belong to its own pool: never cached here
-        buf = torch.empty((n,), device=X.device, dtype=torch.float32)
-    else:
-        key = (X.device, torch.cuda.current_stream(X.device).cuda_stream)
-        buf = _deep_scratch.get(key)
-        if buf is None or buf.numel() < n:
-            buf = _deep_scratch[key] = torch.empty((n,), device=X.device, dtype=torch.float32)
     out = torch.empty((B, 1, actor.layers[-1], N), device=X.device, dtype=torch.float32)
     rc = L.mgp_actor_fwd_deep(ops._ptr(X), ops._ptr(G), _ptr_array(Ws), _ptr_array(bs), cdims, actor.n_layers,
-                              ops._ptr(out), ops._ptr(buf), B, actor.k, N, ops._stream())
+                              ops._ptr(out), B, actor.k, N, ops._stream())
     _lib.check(rc, 'mgp_actor_fwd_deep')
     return out
 

@@ -136,9 +136,10 @@ DEEP_SHAPES = [((128, 128, 128), 100, 3), ((128, 128, 128, 128), 100, 3), ((128,
 @pytest.mark.parametrize('hidden,N,K', DEEP_SHAPES)
 def test_actor_fwd_deep_inference(hidden, N, K):
     """mgp_actor_fwd_deep (three or more hidden layers, one wider than 64: cfg/hidden_size.cfg n_layers 3, 4 at hidden_size
-    128): actor_fwd_wide_kernel writing the second hidden layer + one actor_tail_kernel launch per further layer, against the
-    fp64 oracle and against the composed path (mgp_agg_fwd + mgp_dense_fwd per layer, what these shapes ran on before);
-    ragged widths, one and two column blocks, repeated calls bit-identical."""
+    128): actor_fwd_wide_kernel with every further hidden layer in the same launch (the weight image in LDS rebuilt per layer,
+    activations in the accumulators), against the fp64 oracle and against the composed path (mgp_agg_fwd + mgp_dense_fwd per
+    layer, what these shapes ran on before); ragged widths, one and two column blocks, up to five hidden layers, repeated calls
+    bit-identical."""
     from multiagent_gnn_policies_amd.learner import Actor
     seed = 5 * N + K + len(hidden)
     rs = np.random.RandomState(seed)
