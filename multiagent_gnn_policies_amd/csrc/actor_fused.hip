@@ -1011,6 +1011,29 @@ void actor_fwd_wide_kernel(const float* __restrict__ X, const float* __restrict_
             }
         }
     }
+    // deep form: this wave's four planes of the NEXT hidden layer (and its share of the biases / the output layer), requested one
+    // layer ahead -- the first time here, before layers 0 and 1 run
+    float4 w1[HID ? 4 : 1][2];
+    float bvl = 0.f, w2l = 0.f;
+    auto deep_fetch = [&](const int l) {
+        if constexpr (HID) {
+            const int cin = P.dims[l], cout = P.dims[l + 1];
+            const bool lastl = l == P.n_layers - 2;
+            const float* Wl = P.W[l];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = wave + 8 * i, mt = q >> 2, kb = q & 3;
+                const float* row = Wl + (size_t)min(16 * mt + li, cout - 1) * cin;
+                const int c0 = 32 * kb + 4 * lq;
+                w1[i][0] = *reinterpret_cast<const float4*>(row + min(c0, cin - 4));           // cin % 4 == 0
+                w1[i][1] = *reinterpret_cast<const float4*>(row + min(c0 + 16, cin - 4));
+            }
+            if (tid < 128) bvl = P.b[l][min(tid, cout - 1)];
+            if (lastl && tid >= 128 && tid < 384) { const int e = tid - 128, c = e >> 1, o = e & 1; w2l = P.W[l + 1][(size_t)o * cout + min(c, cout - 1)]; }
+            if (lastl && tid >= 384 && tid < 386) w2l = P.b[l + 1][tid - 384];
+        }
+    };
+    if constexpr (HID) deep_fetch(2);
     // column waves: CT tiles of 16 agent columns each (MGP_AW_CT = 2 from five tiles on: the measured alternative, see aw_tiles2)
 #ifndef MGP_AW_CT
 #define MGP_AW_CT 1
@@ -1060,27 +1083,14 @@ void actor_fwd_wide_kernel(const float* __restrict__ X, const float* __restrict_
     }
     if constexpr (HID) {
         // ---- hidden layers 2 .. n_layers - 2 in the same launch: a column wave's accumulators ARE the next layer's B operand, so only
-        // the weight image changes -- all eight waves rebuild the 32 planes of IMG1 (four each; their requests go out before the
-        // barrier that ends the previous layer's reads), the biases and, with the last hidden layer, the output layer.  Two
-        // barriers per layer; no activation leaves the CU.
+        // the weight image changes -- all eight waves rebuild the 32 planes of IMG1 (four each; requested one layer ahead, under
+        // the previous layer's products: deep_fetch), the biases and, with the last hidden layer, the output layer.  Two barriers
+        // per layer; no activation leaves the CU.  7.1 us per layer at N = 100 (requests at the top of the layer instead of a
+        // layer ahead: 7.2).
         static_assert(MA == 8 && MB == 8 && (S <= 16 || MGP_AW_CT == 1), "deep form: 128 padded channels, one column tile per wave");
         for (int l = 2; l < P.n_layers - 1; ++l) {
             const int cin = P.dims[l], cout = P.dims[l + 1];
             const bool lastl = l == P.n_layers - 2;
-            const float* Wl = P.W[l];
-            float4 w1[4][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int q = wave + 8 * i, mt = q >> 2, kb = q & 3;
-                const float* row = Wl + (size_t)min(16 * mt + li, cout - 1) * cin;
-                const int c0 = 32 * kb + 4 * lq;
-                w1[i][0] = *reinterpret_cast<const float4*>(row + min(c0, cin - 4));           // cin % 4 == 0
-                w1[i][1] = *reinterpret_cast<const float4*>(row + min(c0 + 16, cin - 4));
-            }
-            float bvl = 0.f, w2l = 0.f;
-            if (tid < 128) bvl = P.b[l][min(tid, cout - 1)];
-            if (lastl && tid >= 128 && tid < 384) { const int e = tid - 128, c = e >> 1, o = e & 1; w2l = P.W[l + 1][(size_t)o * cout + min(c, cout - 1)]; }
-            if (lastl && tid >= 384 && tid < 386) w2l = P.b[l + 1][tid - 384];
             __syncthreads();                                       // every column wave has finished with the previous image
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1101,6 +1111,7 @@ void actor_fwd_wide_kernel(const float* __restrict__ X, const float* __restrict_
             if (lastl && tid >= 128 && tid < 384) wimg[PL::W2 + tid - 128] = (((tid - 128) >> 1) < cout) ? w2l : 0.f;
             if (lastl && tid >= 384 && tid < 386) wimg[PL::W2 + 2 * 16 * MB + tid - 384] = w2l;
             __syncthreads();
+            if (l + 1 < P.n_layers - 1) deep_fetch(l + 1);       // the next layer's planes travel under this layer's products
             if (colw) {
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
