@@ -37,6 +37,33 @@ def test_library_loads_and_exports_every_header_symbol():
     assert 'invalid' in _lib.strerror(-1)
 
 
+def test_forward_coverage_queries_need_no_device():
+    """Which shapes the one-launch forwards take is host logic (mgp_actor_supported / mgp_actor_deep_supported: plans, no
+    launches): every (n_layers, hidden_size) of the reference's cfg/hidden_size.cfg at N = 100, K = 3 is covered by one of
+    them, and the deep form refuses what its kernel cannot do."""
+    import ctypes
+    from multiagent_gnn_policies_amd import _lib
+    L = _lib.lib()
+
+    def q(fn, hidden, K=3, N=100):
+        dims = (ctypes.c_int * (len(hidden) + 2))(6, *hidden, 2)
+        return fn(dims, len(hidden) + 1, K, N)
+
+    for n_layers in (1, 2, 3, 4):
+        for h in (4, 8, 16, 32, 64, 128):
+            hidden = [h] * n_layers
+            assert q(L.mgp_actor_supported, hidden) or q(L.mgp_actor_deep_supported, hidden), hidden
+    assert not q(L.mgp_actor_supported, [128, 128, 128]) and q(L.mgp_actor_deep_supported, [128, 128, 128])
+    assert q(L.mgp_actor_deep_supported, [128] * 5) and q(L.mgp_actor_deep_supported, [100, 72, 96, 48], K=2, N=124)
+    assert not q(L.mgp_actor_deep_supported, [128, 128])                    # two hidden layers: mgp_actor_fwd's wide kernel
+    assert not q(L.mgp_actor_deep_supported, [64, 64, 64])                  # nothing wider than 64: mgp_actor_fwd's plan fits
+    assert not q(L.mgp_actor_deep_supported, [128, 130, 128])               # a width that is no multiple of 4
+    assert not q(L.mgp_actor_deep_supported, [128, 132, 128])               # wider than 128
+    assert not q(L.mgp_actor_deep_supported, [128] * 3, N=132) and not q(L.mgp_actor_deep_supported, [128] * 3, N=98)
+    assert not q(L.mgp_actor_deep_supported, [128] * 3, K=6)                # 6 K > 32 aggregation channels
+    assert not q(L.mgp_actor_deep_supported, [128] * 3, K=4, N=128)         # two column blocks x four taps > six streaming waves
+
+
 def test_library_is_in_tree_and_built_for_gfx950():
     from multiagent_gnn_policies_amd import build
     assert os.path.dirname(build.LIB_PATH) == os.path.join(ROOT, 'multiagent_gnn_policies_amd')
