@@ -42,6 +42,13 @@ SHAPES = [
     ('FlockingRelative-v0', 100, 3, 128, 3),     # cfg/hidden_size.cfg:104-106 (inference: mgp_actor_fwd_deep; updates on the composed ops)
     ('FlockingRelative-v0', 100, 3, 128, 4),     # cfg/hidden_size.cfg:128-130
     ('FlockingRelative-v0', 100, 3, 64, 1),
+    # the remaining cells of cfg/hidden_size.cfg (n_layers 1..4 x hidden_size 4..128): every cell of the grid runs a trained policy
+    ('FlockingRelative-v0', 100, 3, 4, 1), ('FlockingRelative-v0', 100, 3, 8, 1), ('FlockingRelative-v0', 100, 3, 16, 1),
+    ('FlockingRelative-v0', 100, 3, 4, 2), ('FlockingRelative-v0', 100, 3, 8, 2), ('FlockingRelative-v0', 100, 3, 16, 2),
+    ('FlockingRelative-v0', 100, 3, 4, 3), ('FlockingRelative-v0', 100, 3, 8, 3), ('FlockingRelative-v0', 100, 3, 16, 3),
+    ('FlockingRelative-v0', 100, 3, 64, 3),
+    ('FlockingRelative-v0', 100, 3, 4, 4), ('FlockingRelative-v0', 100, 3, 8, 4), ('FlockingRelative-v0', 100, 3, 16, 4),
+    ('FlockingRelative-v0', 100, 3, 32, 4), ('FlockingRelative-v0', 100, 3, 64, 4),
     ('FlockingRelative-v0', 100, 3, 32, 1),
     ('FlockingRelative-v0', 100, 3, 32, 3),
     ('FlockingLeader-v0', 100, 1, 32, 2),        # cfg/dagger_leader.cfg (k = 1)
