@@ -917,6 +917,9 @@ def main():
                          'timed region every this many env steps; 0 = never (rounds 1-3)')
     ap.add_argument('--comm-radius', type=float, default=1.0,
                     help='communication radius R (FlockParams.comm_radius; the mean degree of a reset state goes with R^2)')
+    ap.add_argument('--v-max', type=float, default=None,
+                    help='reset velocity range (FlockParams.v_max and v_bias, as the cfg key v_max sets both: cfg/vel.cfg sweeps 0.5 .. 5.5)')
+    ap.add_argument('--dt', type=float, default=None, help='integration step (FlockParams.dt: cfg/dt.cfg sweeps 0.0075 .. 0.1)')
     ap.add_argument('--dagger', action='store_true',
                     help='BASELINE configs[3]: one DAGGER round per rank -- data collection (--episodes lanes x --steps env '
                          'steps) then --updates minibatch updates of --batch-size per rank, gradients exchanged between the '
@@ -955,7 +958,12 @@ def main():
         dagger_round_bench(args, device, rank, world)
         return
 
-    ro = Rollout(device, B, N, K, hidden, seed=1000 + rank, init_mode=args.init, comm_radius=args.comm_radius, env=args.env)
+    phys = {}
+    if args.v_max is not None:
+        phys.update(v_max=args.v_max, v_bias=args.v_max)
+    if args.dt is not None:
+        phys.update(dt=args.dt)
+    ro = Rollout(device, B, N, K, hidden, seed=1000 + rank, init_mode=args.init, comm_radius=args.comm_radius, env=args.env, **phys)
     deg_start = float((ro.sim.network != 0).sum(dim=-1).double().mean().item())
     init_name = ('jittered lattice' if use_grid(ro.params) else 'uniform disc') + " (FlockParams.init_mode='%s')" % args.init
 
@@ -1135,7 +1143,7 @@ def main():
     # the same launch on the jittered lattice (rounds 1-2 timed this state: sparser, mean degree 6.8 at reset against 8.5)
     el_grid, deg_grid = None, None
     if resident and not use_grid(ro.params):
-        ro_g = Rollout(device, B, N, K, hidden, seed=1000 + rank, init_mode='grid', comm_radius=args.comm_radius, env=args.env)
+        ro_g = Rollout(device, B, N, K, hidden, seed=1000 + rank, init_mode='grid', comm_radius=args.comm_radius, env=args.env, **phys)
         deg_grid = float((ro_g.sim.network != 0).sum(dim=-1).double().mean().item())
         ep_g = Episodes(ro_g, args.episode_steps, ro_g.presample_resets(1, 3000 + rank) if n_resets else [])
         ro_g.prepare_resident(ep_g.chunks([args.warmup, args.steps]) + [args.warmup, args.steps])
@@ -1199,7 +1207,7 @@ def main():
                        "graph_steps": gs, "weights": ro.weights, "parallelism": "episodes sharded x%d, no "
                        "data-path collective" % world, "state_finite": finite,
                        "mean_degree": deg, "mean_degree_at_reset": deg_start, "mean_degree_over_timed_region": deg_region,
-                       "episode_steps": args.episode_steps,
+                       "episode_steps": args.episode_steps, "comm_radius": ro.params.comm_radius, "v_max": ro.params.v_max, "dt": ro.params.dt,
                        "episode_ends_in_timed_region": (resets_in_region if resident else None),
                        "init": "%s; every lane is reset on the device every %d env steps (time limit) inside the timed region; "
                                "%d steps since the last reset at the end of it" % (init_name, args.episode_steps, ep.since)

@@ -115,7 +115,7 @@ for src, hdr in (
         ('sweep_grid.txt',
          "# tools/gpu/sweep_grid.sh: the reference's other sweeps at full size, 256 episodes, 100-step policy_rollout calls after a reset, reference checkpoint\n"
          "# or trained policy where one exists for (env, K): cfg/n.cfg (n_agents 25..150 x k 1..4), cfg/n_twoflocks.cfg (50..250), cfg/rad.cfg (comm_radius\n"
-         "# 0.8..4: mean degree 3..79).  One workgroup per episode: at 256 episodes small flocks leave the CUs' other workgroup slots empty.\n"),
+         "# 0.8..4: mean degree 3..79), cfg/vel.cfg (v_max 0.5..5.5), cfg/dt.cfg (dt 0.0075..0.1).  One workgroup per episode: at 256 episodes small flocks leave the CUs' other workgroup slots empty.\n"),
         ('rollout_wg_times_lists.txt', ''), ('rollout_wg_times_no_lists.txt', '')):
     if os.path.exists(O + '/' + src):
         body = ''.join(l for l in open(O + '/' + src).read().splitlines(True) if not l.startswith('+ '))     # (the regen script runs under set -x)
