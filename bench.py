@@ -419,6 +419,7 @@ def parity_gate(ro, n_check=16):
     goldens) on the identical (S, X) = (delay_gso, delay_state) the HIP kernels consume, for `n_check` sampled episodes:
       two_launch  mgp_actor_fwd on the current state
       resident    the action of a one-step mgp_rollout_steps launch from the same state (when the shape is covered)
+      factored    N > 256: the action of one step of the factored path (mgp_sparse_rollout) from the same state
     max_rel is elementwise |gpu - cpu| / max(1, |cpu|); the gate is max_rel <= 1e-5.  Runs after the timed regions."""
     from oracle import torch_port
     from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
@@ -449,10 +450,13 @@ def parity_gate(ro, n_check=16):
     noise_b = torch.maximum(rel_b(ref, exact), rel_b(moved, exact))
     well = noise_b <= 0.5 * PARITY_TOL                        # episodes where the fp32 reference is determined to < tol
     paths = {'two_launch': two}
-    if ro.resident_supported():
+    if ro.resident_supported() or ro.factored_supported():
+        # one step of the path that is `value`, from the very state whose (S, X) the reference was evaluated on: the
+        # episode-resident kernel, or -- N > 256 -- the factored path's K launches (policy_rollout continues the factored state the
+        # timed region left; without one it would fall back to the two-launch step and return False)
         action = torch.zeros((B, 1, N_ACT, ro.N), device=ro.sim.device)
         if policy_rollout(ro.actor, ro.sim, ro.state, 1, action=action):
-            paths['resident'] = action[idx].cpu().double()
+            paths['resident' if ro.resident_supported() else 'factored'] = action[idx].cpu().double()
     ok = True
     for name, u in paths.items():
         r_ref, r_ex = rel_b(u, ref), rel_b(u, exact)

@@ -27,7 +27,7 @@ extern "C" {
                                       0.2.1: + mgp_replay_gather_many; mgp_actor_fwd covers layer widths up to 128 at N <= 128;
                                       0.3.0: + mgp_p2p_* (one-shot gradient exchange), mgp_train_step_p2p, mgp_adam_step_filed;
                                       0.3.1: + mgp_rollout_f32ref_* (checker build of the resident kernels); a timed-out exchange
-                                             leaves the weights untouched (mgp_train_step_p2p);
+                                             skips Adam for the entries it missed (mgp_train_step_p2p: timeout semantics below);
                                       0.3.2: + mgp_replay_aggregate, mgp_train_step_agg / _grads_agg / _agg_supported (DAGGER updates on
                                              the aggregated first-layer input, operator slices never formed), mgp_flock_reset_check;
                                       0.3.3: + mgp_actor_fwd_deep / mgp_actor_deep_supported (inference with three or more hidden layers
@@ -431,7 +431,12 @@ int  mgp_p2p_allreduce_mean(MgpP2P* comm, float* buf, int n, void* stream);
  * the same two launches, with the exchange above between the local reduction and Adam inside the second one -- each of its
  * workgroups exchanges the 64 gradient entries it has just reduced.  flat_grad receives the averaged gradient, loss[0] /
  * loss_hist the averaged loss; every rank applies the identical step.  idx, cursor and loss_hist: all NULL (mgp_train_step
- * semantics) or all given (mgp_train_step_indexed semantics).  comm: n_floats >= parameter count + 1. */
+ * semantics) or all given (mgp_train_step_indexed semantics).  comm: n_floats >= parameter count + 1.
+ * Timeout semantics: a workgroup whose poll gives up sets the communicator's sticky status word and skips Adam for ITS 64
+ * entries; workgroups that see the word set skip too; entries whose packets had arrived in time ARE stepped -- so after a
+ * timed-out exchange the weights are partially stepped on that rank and fully stepped on a peer that merely arrived late.
+ * The caller restores the round's starting point on EVERY rank (DAGGER.end_updates: MAX all-reduce of the status, rollback of
+ * weights / moments / step counter, raise) and re-creates the communicator before the next round. */
 int  mgp_train_step_p2p(const float* X, const float* G, const float* target, const long* idx, int* cursor,
                         float* loss_hist, int hist_cap, float* flat_param, float* flat_grad, float* m, float* v,
                         const int* dims, int n_layers, float lr, float beta1, float beta2, float eps,

@@ -1549,12 +1549,13 @@ extern "C" int mgp_actor_fwd(const float* X, const float* G, const float* const*
         static const bool wide_off = getenv("MGP_ACTOR_WIDE") != nullptr && atoi(getenv("MGP_ACTOR_WIDE")) == 0;   // (A/B switch)
         if (saved == nullptr && !wide_off && n_layers == 3 && dims[0] == 6 && dims[3] == 2 && 6 * K <= 32 &&
             (dims[1] > 32 || dims[2] > 32) && dims[1] <= 128 && dims[2] <= 128 && dims[1] % 4 == 0 && mgp_aligned16(W[1])) {
-#define MGP_AW_CASE(S_) return (dims[1] <= 64 && dims[2] <= 64) ? launch_fwd_wide<S_, 2, 4, 4>(X, G, out, P, pm, B, K, N, st) \
-                                                                 : launch_fwd_wide<S_, 2, 8, 8>(X, G, out, P, pm, B, K, N, st)
-            if (pm.S <= 16) MGP_AW_CASE(16);
-            if (pm.S <= 28) MGP_AW_CASE(28);
-            MGP_AW_CASE(32);
+#define MGP_AW_CASE(S_) ((dims[1] <= 64 && dims[2] <= 64) ? launch_fwd_wide<S_, 2, 4, 4>(X, G, out, P, pm, B, K, N, st) \
+                                                          : launch_fwd_wide<S_, 2, 8, 8>(X, G, out, P, pm, B, K, N, st))
+            const int rcw = pm.S <= 16 ? MGP_AW_CASE(16) : (pm.S <= 28 ? MGP_AW_CASE(28) : MGP_AW_CASE(32));
 #undef MGP_AW_CASE
+            // (a shape the wide kernel's own LDS plan declines -- its row-class area or 160 KB -- falls through to the generic chain
+            //  below, which ran it before this kernel existed; today make_plan_mfma's K * blocks <= 6 keeps that unreachable)
+            if (rcw != MGP_EUNSUPPORTED) return rcw;
         }
 #define MGP_AM_CASE(S_) return dims[0] <= 4 ? launch_fwd_mfma<S_, 1>(X, G, out, saved, P, pm, B, K, N, st) \
                                              : launch_fwd_mfma<S_, 2>(X, G, out, saved, P, pm, B, K, N, st)

@@ -480,6 +480,7 @@ int launch_flock(double* x, double* x_out, const float* u, long su_agent, long s
 //  whole source slice, 20 MB instead of 10 through the CUs' memory pipelines in front of the agent states: 15.9 us against 13.4.)
 constexpr int FA_THREADS = 1024;
 constexpr int FA_WAVES = FA_THREADS / 64;
+constexpr int FA_DELAY_ELEMS = 3072;                        // delay-line elements the kernel copies, (K - 1) 6 N: 4 taps of 6 x 128
 
 struct FaOff { int pos, sxy, bits, wrow, rcnt, rlist, stage, total; };
 __host__ __device__ inline int fa_take(int& off, int bytes) { const int o = off; off += (bytes + 15) & ~15; return o; }
@@ -567,7 +568,16 @@ void flock_advance_kernel(const double* __restrict__ x, double* __restrict__ xo,
     };
 
     FL_STAMP(8);
-    if (prod) stage_slice(1);                               // first thing: the slice streams in behind everything below
+    // [r6] the DMA waves start a few hundred cycles late: a CU takes in ~11 bytes per cycle, so the 40 KB slice is ~3.6k cycles of
+    // its load path -- and whatever is requested at the same moment shares the queue with it.  The agent states, the action and the
+    // delay line (9 KB: what the first phase waits for) are requested by the lower waves in the first ~200 cycles; with the slice
+    // behind them they are back ~3k cycles earlier, and the slice is not needed before the product rows (tools/harness/
+    // flock_phase_prof.hip: stamp 9)
+#ifndef FA_DMA_DELAY
+#define FA_DMA_DELAY 6                                      // s_sleep units of 64 cycles
+#endif
+    if (FA_DMA_DELAY > 0 && prod && wave >= FA_DMA_W0) __builtin_amdgcn_s_sleep(FA_DMA_DELAY);
+    if (prod) stage_slice(1);                               // the slice streams in behind everything below
     // ---- agent states and the delay line's taps are requested together (the lower eight waves); thread i owns agent i (the
     //      expression tree of integrate_one: bit-exact given the action)
     double px = 0.0, py = 0.0, vx = 0.0, vy = 0.0, cx = 0.0, cy = 0.0;
@@ -581,7 +591,7 @@ void flock_advance_kernel(const double* __restrict__ x, double* __restrict__ xo,
     }
     const long tap = 6L * N, per = (long)K * tap;
     constexpr int XT_ = 64 * FA_DMA_W0;                     // threads that copy the delay line: the waves below the DMA waves
-    constexpr int XP = 3072 / XT_;                          // elements per thread: (K - 1) 6 N <= 4 * 6 * 128 = 3072
+    constexpr int XP = FA_DELAY_ELEMS / XT_;                // elements per thread: (K - 1) 6 N <= 4 * 6 * 128 (checked by the dispatch)
     float xpv[XP];
 #pragma unroll
     for (int r = 0; r < XP; ++r) {
@@ -930,7 +940,10 @@ extern "C" int mgp_flock_step_advance(double* x, double* x_out, const float* u, 
     mgp_clear_error();
     // one workgroup per episode (flock_advance_kernel) unless MGP_FLOCK_ADVANCE_TILED asks for the row-tiled kernel of rounds 1-4
     static const bool tiled = getenv("MGP_FLOCK_ADVANCE_TILED") != nullptr && getenv("MGP_FLOCK_ADVANCE_TILED")[0] == '1';
-    if (!tiled && fa_offsets(N, K).total <= 160 * 1024 && mgp_aligned16(x))      // (the agent states are read as 16-byte pairs)
+    // flock_advance_kernel copies the delay line through a fixed register array: (K - 1) 6 N <= FA_DELAY_ELEMS (K <= 5 at N = 128);
+    // longer delay lines run the row-tiled kernel, which loops over any K
+    if (!tiled && fa_offsets(N, K).total <= 160 * 1024 && (long)(K - 1) * 6 * N <= FA_DELAY_ELEMS &&
+        mgp_aligned16(x))                                                         // (the agent states are read as 16-byte pairs)
         return launch_advance_episode(x, x_out, u, su_agent, su_axis, o, p, B, N, static_cast<hipStream_t>(stream));
     return launch_step<true, FP_THREADS, FP_ROWS, FP_PIECES>(x, x_out, u, su_agent, su_axis, o, p, B, N,
                                                   static_cast<hipStream_t>(stream));

@@ -79,6 +79,13 @@ template <int CK> struct RoGatherUnroll { static constexpr int value = CK ? 4 : 
 #ifndef RO_VERLET
 #define RO_VERLET 1
 #endif
+#ifndef RO_BC_PRIO
+#define RO_BC_PRIO 2                      // policy phase: raised priority for the SIMDs' second tiles until the end of layer RO_BC_PRIO - 1 (0: off);
+                                          // measured 1 / 2 / 3 against 0: -1.0 % per step each (B/C 4.98k -> 4.74k cycles at 2), same bits
+#endif
+#ifndef RO_S2_PRIO
+#define RO_S2_PRIO 0                      // S2: wave priority of the gather group (0: as dispatched)
+#endif
 #ifndef RO_FEAT_PAIR
 #define RO_FEAT_PAIR 0                    // feature pass of S2: two list entries per trip with their LDS reads in flight together
                                           // (measured: the feature waves end 0.2k cycles earlier, the phase -- bound by the gather waves -- does not)
@@ -681,6 +688,12 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         // Layer metadata comes from bit-packed scalar kernel arguments: P.dims[l] indexed dynamically is re-fetched from
         // the kernel-argument segment every layer of every step (~700 cycles each).
         if (wave < NT) {                                      // wave w owns columns 16 w .. 16 w + 15 through every layer
+#if RO_BC_PRIO
+            // the second tile of a SIMD (waves 4 .. NT - 1 share SIMDs with waves 0 .. 2) loses every arbitration to the older wave
+            // and ends ~0.9k cycles behind it: raised priority for the first part of the phase hands part of that delay to the
+            // first tile, and the phase ends with the later of the two
+            if (RO_BC_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
             if (fused && K >= 3) {
                 // last gather stage (tap K - 1 times A_{t-K+2}) for the wave's own columns: four lanes per column walk its
                 // list two entries at a time, DPP quad sum, straight into the B-fragment slot the first layer reads below
@@ -782,7 +795,13 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 }
                 mtp = MT;
                 RO_STAMP(12 + l);
+#if RO_BC_PRIO
+                if (l + 1 == RO_BC_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(0);
+#endif
             }
+#if RO_BC_PRIO
+            if (RO_BC_PRIO > 2 && wave >= 4) __builtin_amdgcn_s_setprio(0);
+#endif
             // ---------------------------------------------------------- C: output layer + integration, same wave, no barrier
             const int lo_ = n_layers - 1;
             const float* w2 = wl + (CM ? 2 * (2 * 64 * WFS + 32) : (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull));
@@ -1347,7 +1366,15 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             }
             RO_STAMP(22);
         } else if (do_s1 && gtid >= 0 && gtid < grp) {
+#if RO_S2_PRIO
+            // the gather group is dispatched behind the feature group and, as the younger half of every SIMD, ends the phase 0.5k
+            // cycles after it: raised priority hands that delay to the feature waves
+            __builtin_amdgcn_s_setprio(RO_S2_PRIO);
+#endif
             gather_stage1(gtid, curn, rc_new, rl_new, w_new);
+#if RO_S2_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             RO_STAMP(20);
             RO_STAMP(23);
         }

@@ -139,17 +139,35 @@ __device__ __forceinline__ void ro_layer_regs(const float (&fb)[RO_KS], const fl
 // first layer (its B operand is the aggregation's LDS tile), 4 lq + j | 16 + 4 lq + (j - 4) for the second (B operand = the
 // first layer's accumulator registers).
 typedef __attribute__((ext_vector_type(8))) __bf16 ro_bf16x8;
+#ifndef RO_MFMA_LARGEST_FIRST
+#define RO_MFMA_LARGEST_FIRST 0           // order of a layer's six products: 0 = smallest first (the product build), 1 = largest first (A/B)
+#endif
+
+// Two values per v_cvt_pk_bf16_f32 (round to nearest even, the rounding of the scalar (__bf16) conversion): the packed word is
+// unpacked with one shift and one mask, so a pair costs 3 conversions + 4 unpacks + 4 subtractions = 11 instructions.  (Written
+// value by value, hipcc converted every piece alone AND again in pairs for the operand words: 15 per pair, 7 of them conversions
+// at half the plain VALU rate -- profiles/r06_valu_rate.txt.)  Same pieces, bit for bit.
+__device__ __forceinline__ unsigned int ro_cvt_pk_bf16(float lo, float hi)
+{
+    unsigned int r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
 
 __device__ __forceinline__ void ro_split3(const float* x /* [8] */, ro_bf16x8& h1, ro_bf16x8& h2, ro_bf16x8& h3)
 {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 w1, w2, w3;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 a = (__bf16)x[j];
-        const float r = x[j] - (float)a;
-        const __bf16 b = (__bf16)r;
-        const float r2 = r - (float)b;
-        h1[j] = a; h2[j] = b; h3[j] = (__bf16)r2;
+    for (int j = 0; j < 4; ++j) {
+        const float x0 = x[2 * j], x1 = x[2 * j + 1];
+        const unsigned int p = ro_cvt_pk_bf16(x0, x1);
+        const float r0 = x0 - __uint_as_float(p << 16), r1 = x1 - __uint_as_float(p & 0xFFFF0000u);
+        const unsigned int q = ro_cvt_pk_bf16(r0, r1);
+        const float s0 = r0 - __uint_as_float(q << 16), s1 = r1 - __uint_as_float(q & 0xFFFF0000u);
+        w1[j] = p; w2[j] = q; w3[j] = ro_cvt_pk_bf16(s0, s1);
     }
+    h1 = __builtin_bit_cast(ro_bf16x8, w1); h2 = __builtin_bit_cast(ro_bf16x8, w2); h3 = __builtin_bit_cast(ro_bf16x8, w3);
 }
 
 // Two K blocks (layer inputs of up to 64 channels: rollout_wide.hip).  x[8 kb + j] <-> channel 16 (2 kb) + 4 lq + j for j < 4,
@@ -225,6 +243,27 @@ __device__ __forceinline__ void ro_layer_bf16(const float* x /* [8 RO_KB] */, co
             const float4 bv = *reinterpret_cast<const float4*>(pbias + (h + mt) * 16);
             acc[mt][0] = bv.x; acc[mt][1] = bv.y; acc[mt][2] = bv.z; acc[mt][3] = bv.w;
         }
+#if RO_MFMA_LARGEST_FIRST
+        // (experiment: the product that needs only the FIRST pieces opens the chain, so that it can issue while the later pieces
+        //  are still being split off)
+#pragma unroll
+        for (int mt = 0; mt < CH; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b1, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < CH; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[mt], b1, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < CH; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[mt], b1, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < CH; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b2, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < CH; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[mt], b2, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < CH; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b3, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < CH; ++mt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) zn[h + mt][rr] = TANH ? tanh_fast(acc[mt][rr]) : acc[mt][rr];
+        continue;
+#endif
         // smallest products first; the m-tiles of a chunk alternate (independent accumulator chains)
 #pragma unroll
         for (int mt = 0; mt < CH; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b3, acc[mt], 0, 0, 0);

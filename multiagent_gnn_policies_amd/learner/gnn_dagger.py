@@ -239,20 +239,37 @@ class DAGGER(object):
             self._round_start = (o.flat.clone(), o.m.clone(), o.v.clone(), o.step_dev.clone(), o.step_count)
 
     def end_updates(self):
-        """After a round of updates: raises if an exchange timed out (synchronises the stream) -- with the weights, the Adam
-        moments and the step counter rolled back to where begin_updates() found them."""
+        """After a round of updates: if an exchange timed out ON ANY RANK (synchronises the stream; one MAX all-reduce of the
+        status flag), every rank rolls the weights, the Adam moments and the step counter back to where begin_updates() found
+        them and raises.  The agreement is collective because the failure is not: the rank whose poll gave up skipped Adam for
+        the entries it missed, while a peer that merely arrived late found every packet waiting and stepped -- a caller that
+        caught the error on one rank and went on would train on diverged ranks.  After a failure the exchange's sequence
+        numbers are out of step: call reset_exchange() (collective) before the next round."""
+        if self.p2p is None:
+            return
+        snap, self._round_start = getattr(self, '_round_start', None), None
+        st, _ = self.p2p.status()
+        if parallel.any_rank(st != 0):
+            if snap is not None:
+                o = self.actor_optim
+                o.flat.copy_(snap[0]); o.m.copy_(snap[1]); o.v.copy_(snap[2]); o.step_dev.copy_(snap[3])
+                o.step_count = snap[4]
+            from .._lib import MgpError
+            raise MgpError("one-shot gradient exchange: a peer did not publish within the timeout on %s (rank %d of %d)%s"
+                           % ("this rank" if st != 0 else "another rank", self.p2p.rank, self.p2p.world,
+                              "; weights, moments and step counter restored to the start of the round" if snap is not None else ""))
+
+    def reset_exchange(self):
+        """Collective: tears the one-shot exchange down and brings a fresh one up (new mailboxes, sequence numbers at zero).
+        The only way on after end_updates() raised.  Update graphs captured with the old exchange are dropped (rebuilt on the
+        next update); FrameUpdates objects bound to this learner must be rebuilt by their owner."""
         if self.p2p is not None:
-            try:
-                self.p2p.check()
-            except Exception:
-                snap = getattr(self, '_round_start', None)
-                if snap is not None:
-                    o = self.actor_optim
-                    o.flat.copy_(snap[0]); o.m.copy_(snap[1]); o.v.copy_(snap[2]); o.step_dev.copy_(snap[3])
-                    o.step_count = snap[4]
-                raise
-            finally:
-                self._round_start = None
+            torch.cuda.synchronize()
+            self.p2p.close()
+        self._graphed = {}
+        self.p2p = parallel.P2PExchange.create(self.actor_optim.flat.numel() + 1, self.device)
+        self.grad_sync.p2p = self.p2p
+        return self.p2p is not None
 
     def _checked_step(self):
         """Adam after an eager all-reduce.  When that all-reduce was the one-shot exchange (stand-alone kernel,
@@ -329,7 +346,10 @@ class DAGGER(object):
             if not sync:
                 return loss.clone()
             value = loss.item()
-            self.end_updates()                     # the stream is idle anyway: a timed-out exchange raises HERE, per update
+            # the stream is idle anyway: outside a begin_updates() / end_updates() round a timed-out exchange raises HERE, per
+            # update (rank-local); inside a round the status word is sticky and end_updates() settles it on every rank together
+            if self.p2p is not None and getattr(self, '_round_start', None) is None:
+                self.p2p.check()
             return value
         loss = self._train_grads(delay_state_batch, delay_gso_batch, optimal_action_batch)
         if loss is not None:                       # two launches wrote the flat gradient; (all-reduce,) Adam

@@ -147,7 +147,14 @@ def _run_sampled(obj, U, sampler, batch_sampler=None):
     return obj.loss_hist[:U].sum()
 
 
-_SAMPLE_BATCH_OK = {}          # (n, k) -> the block form reproduces random.sample on this interpreter (checked on first use)
+_SAMPLE_BATCH_OK = {}          # k -> the block form reproduces random.sample on this interpreter (checked on its first real use)
+
+
+def _sample_setsize(k):
+    """random.sample's set-size threshold (CPython: 21, plus 4 ** ceil(log4(3 k)) for k > 5): populations up to it take the
+    pool branch of random.sample, which the block form does not restate."""
+    import math
+    return 21 + (4 ** math.ceil(math.log(k * 3, 4)) if k > 5 else 0)
 
 
 def _sample_batch_sequential(n, k, count):
@@ -159,8 +166,9 @@ def sample_batch(n, k, count):
     CPython internals (random.sample's set-size threshold, _randbelow's rejection loop, getrandbits' word order): on first use
     for a shape it is compared with random.sample itself -- values AND generator state, on a saved and restored state -- and
     an interpreter on which they differ keeps the sequential sampler."""
-    key = (n > 21, k)
-    ok = _SAMPLE_BATCH_OK.get(key)
+    if count <= 0 or k <= 0 or n <= _sample_setsize(k) or n >= (1 << 32):
+        return _sample_batch_sequential(n, k, count)              # the block form does not apply: nothing to verify, nothing cached
+    ok = _SAMPLE_BATCH_OK.get(k)                                  # (the block path is taken for every n beyond the threshold)
     if ok is None:
         state = random.getstate()
         try:
@@ -173,7 +181,7 @@ def sample_batch(n, k, count):
             ok = False
         finally:
             random.setstate(state)
-        _SAMPLE_BATCH_OK[key] = ok
+        _SAMPLE_BATCH_OK[k] = ok
     return _sample_batch_block(n, k, count) if ok else _sample_batch_sequential(n, k, count)
 
 
@@ -187,9 +195,7 @@ def _sample_batch_block(n, k, count):
     once (getrandbits(32 M): M successive words, little end first) holds every value the calls would see, in order; the block
     is filtered with numpy, and the generator is rewound and advanced by exactly the number of words the calls would have
     consumed.  Minibatches with an internal repeat (rare: k^2 / 2n) are finished by the sequential rule on the same stream."""
-    import math
-    setsize = 21 + (4 ** math.ceil(math.log(k * 3, 4)) if k > 5 else 0)
-    if count <= 0 or k <= 0 or n <= setsize or n >= (1 << 32):
+    if count <= 0 or k <= 0 or n <= _sample_setsize(k) or n >= (1 << 32):
         return _sample_batch_sequential(n, k, count)
     bits = n.bit_length()
     need = count * k

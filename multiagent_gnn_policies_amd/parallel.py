@@ -104,6 +104,16 @@ def _comm_device():
     return torch.device('cpu')
 
 
+def any_rank(flag):
+    """True on every rank if `flag` is true on any (one MAX all-reduce of a single int on the collective device): how the
+    ranks of a data-parallel round agree on a failure only some of them observed."""
+    if not is_distributed():
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=_comm_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))
+
+
 def all_gather_floats(values):
     """Gather a list of floats (episode rewards for mean / std, reference gnn_dagger.py:235-237) from every rank, rank
     order preserved.  Two fixed-shape tensor collectives -- the counts, then the values padded to the longest list -- as

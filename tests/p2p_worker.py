@@ -152,6 +152,76 @@ def scenario_train(comm, dev, rk, world):
     return {"losses": losses, "max_weight_diff_vs_single_process": err}
 
 
+def scenario_dp_timeout(comm, dev, rk, world):
+    """One rank falls behind INSIDE a data-parallel round (begin_updates .. end_updates) by more than the exchange's timeout.
+    The early rank's poll gives up (Adam skipped for what it missed), the late rank finds every packet waiting and steps:
+    only one of them sees an error locally.  end_updates() must raise on EVERY rank, with weights, both Adam moments and the
+    step counter (device and host) back at the round's start and identical across ranks; after reset_exchange() the next
+    round must work."""
+    import configparser
+    from multiagent_gnn_policies_amd import _lib
+    from multiagent_gnn_policies_amd.learner.gnn_dagger import DAGGER
+    cp = configparser.ConfigParser()
+    cp['DEFAULT'] = dict(n_states='6', n_actions='2', k='3', hidden_size='32', gamma='0.99', tau='0.5', n_agents='100',
+                         actor_lr='1e-3')
+    cp['t'] = {}
+    B, N, K = 20, 100, 3
+    torch.manual_seed(5)
+    learner = DAGGER(dev, cp['t'])
+    assert learner.p2p is not None, "DAGGER must have brought the one-shot exchange up"
+    gen = torch.Generator(device='cpu').manual_seed(50 + rk)
+    X = torch.randn((B, K, 6, N), generator=gen).to(dev)
+    m = torch.rand((B, K, N, N), generator=gen) < 0.08
+    G = (m.float() / m.float().sum(-1, keepdim=True).clamp(min=1))
+    G[:, 0] = torch.eye(N)
+    G = G.to(dev)
+    Y = torch.randn((B, 1, 2, N), generator=gen).to(dev)
+    o = learner.actor_optim
+    # a good round first (also captures the update graph outside the timed part)
+    learner.begin_updates()
+    for _ in range(2):
+        learner.gradient_step_tensors(X, G, Y, sync=False)
+    learner.end_updates()
+    start = (o.flat.clone(), o.m.clone(), o.v.clone(), int(o.step_dev.item()), o.step_count)
+    assert start[3] == 2 and start[4] == 2
+    _lib.lib().mgp_p2p_set_timeout_ms(learner.p2p.handle, 150)
+    learner.begin_updates()
+    learner.gradient_step_tensors(X, G, Y, sync=False)
+    torch.cuda.synchronize()
+    if rk == world - 1:
+        time.sleep(1.0)                                          # the last rank is late: its peers' polls give up meanwhile
+    for _ in range(2):
+        learner.gradient_step_tensors(X, G, Y, sync=False)
+    torch.cuda.synchronize()
+    local_status = learner.p2p.status()[0]
+    moved = not torch.equal(o.flat, start[0])                    # (some rank stepped: the round did run)
+    raised = False
+    try:
+        learner.end_updates()
+    except _lib.MgpError as e:
+        raised = True
+        msg = str(e)
+    assert raised, "end_updates() must raise on every rank (local status %d)" % local_status
+    assert torch.equal(o.flat, start[0]) and torch.equal(o.m, start[1]) and torch.equal(o.v, start[2])
+    assert int(o.step_dev.item()) == start[3] and o.step_count == start[4]
+    parts = gather_cpu(o.flat)
+    assert all(torch.equal(parts[0], q) for q in parts[1:]), "rolled-back weights must be identical on every rank"
+    seen = gather_cpu(torch.tensor([local_status, 1 if moved else 0], dtype=torch.int32))
+    statuses = [int(q[0]) for q in seen]
+    assert any(statuses) and not all(statuses), ("the scenario needs a rank that saw the timeout and one that did not", statuses)
+    # the exchange is rebuilt, the next round runs and leaves bit-identical weights everywhere
+    assert learner.reset_exchange()
+    learner.begin_updates()
+    for _ in range(3):
+        learner.gradient_step_tensors(X, G, Y, sync=False)
+    learner.end_updates()
+    assert int(o.step_dev.item()) == start[3] + 3
+    parts = gather_cpu(o.flat)
+    assert all(torch.equal(parts[0], q) for q in parts[1:])
+    assert not torch.equal(o.flat, start[0])
+    return {"statuses_per_rank": statuses, "some_rank_stepped_before_rollback": [int(q[1]) for q in seen], "message": msg}
+
+
 def scenario_vec(comm, dev, rk, world):
     """The data-parallel round of the vectorised loop: graphs of 32 updates (gather-many + 32 x two launches with the exchange
     inside) against the same updates issued one by one (gather + GraphedUpdate) -- same ids, same weights at the start."""
@@ -220,8 +290,8 @@ def main():
     dev = torch.device('cuda', parallel.local_device_index(local))
     torch.cuda.set_device(dev)
     res = {}
-    if scenario in ('train', 'vec'):
-        res = {'train': scenario_train, 'vec': scenario_vec}[scenario](None, dev, rk, world)
+    if scenario in ('train', 'vec', 'dp_timeout'):
+        res = {'train': scenario_train, 'vec': scenario_vec, 'dp_timeout': scenario_dp_timeout}[scenario](None, dev, rk, world)
     else:
         comm = parallel.P2PExchange.create(1731, dev)
         assert comm is not None, "one-shot exchange did not come up"

@@ -521,6 +521,14 @@ def test_batched_minibatch_sampler_is_random_sample_exactly():
             got = sample_batch(n, k, count)
             assert got.shape == (count, k) and got.dtype == np.int64 and got.tolist() == ref, (n, k, count, seed)
             assert random.random() == tail, (n, k, count, seed)
+    # the self-check runs -- and is cached -- only on a call that takes the block path: a first call below random.sample's
+    # set-size threshold (85 for k = 20) must not vouch for the block form
+    from multiagent_gnn_policies_amd.learner import vec_dagger
+    vec_dagger._SAMPLE_BATCH_OK.clear()
+    sample_batch(60, 20, 4)
+    assert 20 not in vec_dagger._SAMPLE_BATCH_OK
+    sample_batch(86, 20, 4)
+    assert vec_dagger._SAMPLE_BATCH_OK.get(20) is True
     mem = FrameReplay(8, 8 * 30, 3, 16, torch.device('cpu'))
     mem.advance(47)                                              # the ring (30 + 2 guard steps) has wrapped
     random.seed(5)

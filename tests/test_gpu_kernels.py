@@ -284,9 +284,11 @@ def test_flock_pingpong_equals_inplace(n):
         assert torch.equal(a, b_)
 
 
-@pytest.mark.parametrize('cfg', [(3, 3, 100), (2, 4, 36), (2, 2, 16), (2, 3, 128)])
+@pytest.mark.parametrize('cfg', [(3, 3, 100), (2, 4, 36), (2, 2, 16), (2, 3, 128), (2, 5, 128), (2, 6, 128), (2, 7, 100)])
 def test_fused_sim_state_kernel_equals_two_kernel_protocol(cfg):
-    """mgp_flock_step_advance == mgp_flock_step (strided outputs) + mgp_gso_advance, bit for bit, incl. episode starts."""
+    """mgp_flock_step_advance == mgp_flock_step (strided outputs) + mgp_gso_advance, bit for bit, incl. episode starts.
+    (K - 1) 6 N beyond 3072 -- K = 6 at N = 128, K = 7 at N = 100 -- is past the one-workgroup kernel's delay-line registers: the
+    dispatch must hand those shapes to the row-tiled kernel (every tap of Xd_next written)."""
     from multiagent_gnn_policies_amd.envs import FlockParams, VecFlock
     from multiagent_gnn_policies_amd.learner.state_with_delay import BatchedDelayState
     B, K, N = cfg

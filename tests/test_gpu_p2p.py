@@ -75,6 +75,17 @@ def test_missing_peer_is_a_status_not_a_hang():
     assert r['status'] == 1
 
 
+@pytest.mark.parametrize('world', [2, 3])
+def test_timeout_inside_a_data_parallel_round_rolls_every_rank_back(world):
+    """DAGGER.begin_updates() .. end_updates() with one rank a second late in the middle of the round (exchange timeout 150 ms):
+    the early ranks see the timeout, the late one does not -- end_updates() raises on ALL of them with weights, Adam moments
+    and step counters restored to the round's start (identical across ranks), and after reset_exchange() the next round runs."""
+    r = run_ranks('dp_timeout', world=world)
+    assert any(r['statuses_per_rank']) and not all(r['statuses_per_rank']), r
+    assert any(r['some_rank_stepped_before_rollback']), r
+    assert 'restored to the start of the round' in r['message']
+
+
 def test_data_parallel_update_with_the_exchange_inside_equals_the_averaged_single_process_update():
     r = run_ranks('train')
     assert r['max_weight_diff_vs_single_process'] <= 1e-7

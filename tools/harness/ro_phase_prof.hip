@@ -85,6 +85,14 @@ int main(int argc, char** argv) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("%sB=%d N=%d K=%d T=%d resident rollout: %.1f us per launch, %.2f us per step -> %.3e agent-steps/s\n", use_carry ? "[carry] " : "", B, N, K, T,
            1e3 * ms / IT, 1e3 * ms / IT / T, (double)B * N * T / (1e-3 * ms / IT));
+    {   // bit-level fingerprint of the final state and the last launch's rewards (A/B builds of the same arithmetic must agree)
+        std::vector<unsigned long long> fx((size_t)B * N * 4), fr((size_t)B * T);
+        hipMemcpy(fx.data(), x, fx.size() * 8, hipMemcpyDeviceToHost); hipMemcpy(fr.data(), rew, fr.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long h1 = 1469598103934665603ull, h2 = h1;
+        for (unsigned long long v : fx) { h1 ^= v; h1 *= 1099511628211ull; }
+        for (unsigned long long v : fr) { h2 ^= v; h2 *= 1099511628211ull; }
+        printf("fingerprint: state %016llx rewards %016llx\n", h1, h2);
+    }
     std::vector<unsigned int> vs(4096 * 4);
     hipMemcpyFromSymbol(vs.data(), HIP_SYMBOL(mgp_ro_vstat), vs.size() * 4);
     {
@@ -102,12 +110,12 @@ int main(int argc, char** argv) {
                            "D2/D3 done (barrier)", "step done", "A: first gather stage of this wave done", "D1: membership bits done (barrier)",
                            "D2/D3: lists + neighbour feature terms done (waves 0-6)", "C: max published (atomic issued)", "D: lists written", "E: rows of slices >= 2 done (barrier)", "B: layer 0 tile done (before barrier)", "B: layer 1 tile done", "C: output layer + quad sums done", "C: integrated, coordinates stored", "S1: pair tests done", "S1: fallback / fading done", "S1: row word combined", "S1: list written", "S2: gather group loop done", "S2: reward wave done", "S2: features group done", "S2: gather group done", "S2: Verlet helper wave done"};
     const int order[] = {0, 6, 1, 12, 13, 14, 15, 3, 16, 17, 18, 19, 7, 8, 22, 20, 23, 21, 24, 4, 5};
-    printf("cycles since step start, lane 0 of waves 0 1 2 3 4 5 6 | 7 9 12 13 14 15\n");
-    const int wv[] = {0, 1, 2, 3, 4, 5, 6, 7, 9, 12, 13, 14, 15};
+    printf("cycles since step start, lane 0 of waves 0 .. 15\n");
+    const int wv[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
     for (int oi = 0; oi < 21; ++oi) {
         const int i = order[oi];
         printf("  stamp %2d :", i);
-        for (int w = 0; w < 13; ++w) {
+        for (int w = 0; w < 16; ++w) {
             const long long d = (long long)(st[wv[w] * 32 + i] - st[0]);
             if (d > -100000 && d < 10000000) printf(" %6lld", d); else printf("      -");
         }
