@@ -61,17 +61,16 @@ from multiagent_gnn_policies_amd.envs import FlockParams, VecFlock  # noqa: E402
 from multiagent_gnn_policies_amd.envs.flocking import use_grid  # noqa: E402
 from multiagent_gnn_policies_amd.learner import Actor  # noqa: E402
 from multiagent_gnn_policies_amd.learner.state_with_delay import BatchedDelayState  # noqa: E402
+# the legs that are not the contract line itself live in tools/bench_legs/ (same JSON as before the split)
+from tools.bench_legs.common import F_FEAT, N_ACT, PARITY_TOL, PROFILE_ROUND  # noqa: E402,F401
+from tools.bench_legs.cpu import cpu_baseline  # noqa: E402
+from tools.bench_legs.dagger import dagger_round_bench, dagger_update_bench  # noqa: E402,F401
+from tools.bench_legs.kernels import kernel_rooflines, time_kernel  # noqa: E402,F401
+from tools.bench_legs.launch import _JSON_FD, check_one_device_per_rank, dist_record, emit_json, self_launch  # noqa: E402
+from tools.bench_legs.parity import parity_gate  # noqa: E402
+from tools.bench_legs.roofline import roofline_blocks  # noqa: E402
 
 DEFAULT_STEPS = 1000      # env steps in the timed region (resident path: one launch; ~10 ms)
-HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
-MFMA_BF16_PEAK_TFLOPS = 2500.0                     # dense bf16 (MI355X_MICROARCH.md: ~2.5 PFLOP/s; no sparsity)
-N_CUS = 256               # MI355X: 256 CUs in 8 XCDs
-CLOCK_GHZ = 2.4           # peak engine clock (MI355X_MICROARCH.md); the peaks above are quoted at it
-MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32 / 32x32x2 dense peak (MI355X_MICROARCH.md: = the fp32 vector rate)
-PARITY_TOL = 1e-5
-NOISE_FACTOR = 2.0          # allowance on ill-conditioned episodes: tol + NOISE_FACTOR x the reference's own fp32 noise (round 3: 10)
-PROFILE_ROUND = 'r05'
-F_FEAT, N_ACT = 6, 2
 
 
 POLICY_DIR = os.path.join(ROOT, 'tests', 'golden', 'policies')
@@ -259,641 +258,11 @@ class Episodes(object):
                 self.since = 0
 
 
-def time_kernel(fn, n_sets, iters):
-    """Average duration (ms) of one launch of fn(i): HIP events on the launch stream around a captured HIP graph of
-    `n_sets` back-to-back launches (one per rotating input set), replayed until `iters` launches have run.  The graph
-    keeps the measurement GPU-bound (an eager Python loop is host-bound below ~25 us per launch); what remains on
-    top of the kernel is the ~1.5 us dependent-kernel boundary, so the figure is slightly conservative."""
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for i in range(min(n_sets, 3)):
-            fn(i)
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        for i in range(n_sets):
-            fn(i)
-    reps = max(2, (iters + n_sets - 1) // n_sets)
-    graph.replay()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        graph.replay()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / (reps * n_sets)
-    del graph
-    return ms
-
-
-def kernel_rooflines(device, B, N, K, actor, flock_c):
-    """Per-kernel live measurements on rotating buffers (working set > 256 MiB Infinity Cache)."""
-    g_bytes = 4 * K * N * N * B
-    n_sets = max(2, int(np.ceil(320 * 2 ** 20 / g_bytes)))
-    n_sets = min(n_sets, 24)
-    gen = torch.Generator(device=device).manual_seed(1)
-    Gs = [torch.rand((B, K, N, N), device=device, generator=gen) for _ in range(n_sets)]
-    Xs = [torch.randn((B, K, F_FEAT, N), device=device, generator=gen) for _ in range(n_sets)]
-    res = {}
-    # --- aggregation (the roofline kernel)
-    iters = max(50, 4 * n_sets)
-    ms = time_kernel(lambda i: ops.agg_fwd(Xs[i].permute(0, 2, 1, 3), Gs[i]), n_sets, iters)
-    agg_bytes = (4 * K * N * N + 8 * K * F_FEAT * N) * B
-    res['agg_fwd'] = dict(ms=ms, bytes=agg_bytes, gbs=agg_bytes / ms / 1e6)
-    # --- whole Actor forward (aggregation + filter GEMM + MLP readout), fused kernel
-    with torch.no_grad():
-        ms = time_kernel(lambda i: actor(Xs[i], Gs[i]), n_sets, iters)
-    n_params = sum(p.numel() for p in actor.parameters())
-    act_bytes = (4 * K * N * N + 4 * K * F_FEAT * N + 4 * N_ACT * N) * B + 4 * n_params
-    res['actor_fwd'] = dict(ms=ms, bytes=act_bytes, gbs=act_bytes / ms / 1e6)
-    # --- delayed-GSO update: read A, G_prev[1..K-2]; write K slices
-    As = [torch.zeros((B, N, N), device=device) for _ in range(n_sets)]
-    for a in As:
-        mask = torch.rand((B, N, N), device=device, generator=gen) < (8.0 / N)
-        a.copy_(mask.float() / mask.float().sum(-1, keepdim=True).clamp(min=1))
-    Gn = [torch.empty((B, K, N, N), device=device) for _ in range(2)]
-    Xn = torch.empty((B, K, F_FEAT, N), device=device)
-    Xt = torch.randn((B, F_FEAT, N), device=device, generator=gen)
-    ms = time_kernel(lambda i: ops.gso_update_into(As[i], Gs[i], Gn[i % 2], Xt, Xs[i], Xn, True), n_sets, iters)
-    gso_bytes = 4 * (2 * K - 1) * N * N * B
-    res['gso_update'] = dict(ms=ms, bytes=gso_bytes, gbs=gso_bytes / ms / 1e6)
-    # --- sim step: writes the dense N x N network matrix
-    xs = torch.randn((B, N, 4), device=device, dtype=torch.float64, generator=gen) * 3.0
-    u = torch.zeros((B, N, 2), device=device)
-    feat = torch.empty((B, F_FEAT, N), device=device)
-    rew = torch.empty((B,), device=device, dtype=torch.float64)
-    ms = time_kernel(lambda i: ops.flock_step(xs, u, flock_c, A=As[i], feat=feat, reward=rew), n_sets, iters)
-    sim_bytes = (4 * N * N + 8 * 4 * N * 2 + 4 * (2 + 6) * N) * B
-    res['flock_step'] = dict(ms=ms, bytes=sim_bytes, gbs=sim_bytes / ms / 1e6)
-    # --- fused sim step + delayed-GSO / delay-line transition (what the timed step actually launches):
-    #     writes A_t (N^2) and the products (K-2) N^2, gathers (K-2) N^2 of G_prev, features/labels/state are small
-    try:
-        from multiagent_gnn_policies_amd.envs import VecFlock
-        params = FlockParams(n_agents=N, init_mode='grid')
-        sim = VecFlock(B, params, device, with_expert=True)
-        sim.reset(np.random.RandomState(3))
-        states = [BatchedDelayState(device, B, K, F_FEAT, N) for _ in range(min(n_sets, 6))]
-        for st_ in states:
-            st_.push(sim.network, sim.features)
-            sim.step_advance(u.view(B, N, 2), st_)
-        ms = time_kernel(lambda i: sim.step_advance(u.view(B, N, 2), states[i % len(states)]), len(states), iters)
-        ss_bytes = (4 * N * N * (1 + 2 * max(K - 2, 0)) + 8 * 4 * N * 2 + 4 * (2 + 6 + 2) * N + 4 * 2 * (K - 1) * F_FEAT * N) * B
-        res['sim_state_step'] = dict(ms=ms, bytes=ss_bytes, gbs=ss_bytes / ms / 1e6)
-    except Exception as e:                               # shapes the fused kernel does not cover
-        res['sim_state_step'] = dict(ms=float('nan'), bytes=0, gbs=0.0, note=str(e))
-    del Gs, Xs, As
-    torch.cuda.empty_cache()
-    return res, n_sets
-
-
-def _profile_json(name):
-    path = os.path.join(ROOT, 'profiles', '%s_%s' % (PROFILE_ROUND, name))
-    try:
-        with open(path) as f:
-            return json.load(f)
-    except Exception:
-        return None
-
-
-def pmc_traffic(kernel, B, N, K, steps_per_launch=None):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/<round>_pmc_traffic.json:
-    separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction; tools/pmc_summary.py).
-    The episode-resident kernel is profiled at two launch lengths, which gives bytes(T) = fixed + per_step * T for any
-    --steps.  Returns (bytes or None, note): None when no pass on these shapes is committed; the note says whether the pass
-    was taken on this very build of the kernels (source hash) or on an earlier one."""
-    d = _profile_json('pmc_traffic.json')
-    if d is None:
-        return None, 'no committed PMC pass'
-    meta = d.get('_meta', {})
-    if meta.get('shape') != [B, N, K]:
-        return None, 'committed PMC pass is for shape %s' % (meta.get('shape'),)
-    from multiagent_gnn_policies_amd import build as mgp_build
-    note = 'profiles/%s_pmc_traffic.json (%s)' % (PROFILE_ROUND, 'this build' if meta.get('source_hash') == mgp_build.source_hash()
-                                                  else 'taken on an earlier build of the kernels')
-    try:
-        if steps_per_launch is None:
-            return d[kernel]['total_bytes'], note
-        m = d[kernel + '_model']
-        return m['fixed_bytes'] + m['bytes_per_step'] * steps_per_launch, note + '; fixed %.0f B + %.0f B/step per launch' % (
-            m['fixed_bytes'], m['bytes_per_step'])
-    except KeyError:
-        return None, 'kernel not in the committed PMC pass'
-
-
-def pmc_traffic_factored(B, N, K):
-    """HBM bytes per ENV STEP of the factored path (simulator + gather stage(s) + policy tail) from the committed PMC passes
-    (profiles/<round>_pmc_traffic_factored.json: tools/pmc_probe.py with PROBE_FACTORED=1), or (None, why)."""
-    d = _profile_json('pmc_traffic_factored.json')
-    if d is None:
-        return None, 'no committed PMC pass of the factored kernels'
-    if d.get('_meta', {}).get('shape') != [B, N, K]:
-        return None, 'committed PMC pass is for shape %s' % (d.get('_meta', {}).get('shape'),)
-    tot, parts = 0.0, []
-    for k, per_step in (('sp_sim_kernel', 1), ('spl_gather_kernel', max(K - 2, 0)), ('spl_policy_kernel', 1)):
-        if per_step and k in d:
-            tot += d[k]['total_bytes'] * per_step
-            parts.append('%s %.2f MB' % (k, d[k]['total_bytes'] / 1e6))
-    if not parts:
-        return None, 'kernels not in the committed PMC pass'
-    return tot, 'profiles/%s_pmc_traffic_factored.json (per launch: %s)' % (PROFILE_ROUND, ', '.join(parts))
-
-
-def pmc_sq(kernel):
-    """Wave-cycle breakdown and matrix-pipe occupancy of `kernel` from the committed SQ-counter pass
-    (profiles/<round>_pmc_sq.json, tools/pmc_sq_summary.py), or None."""
-    d = _profile_json('pmc_sq.json')
-    if d is None or kernel not in d:
-        return None
-    v = dict(d[kernel])
-    v['source'] = 'profiles/%s_pmc_sq.json' % PROFILE_ROUND
-    return v
-
-
-def parity_gate(ro, n_check=16):
-    """In-run parity gate, part of the cpu_baseline leg (the only place besides cpu_baseline() where bench.py touches
-    oracle/, and only as the checker): the reference op sequence of actor.py:63-82 in PyTorch-CPU fp32
-    (oracle/torch_port.actor_forward -- the very port that is timed as cpu_baseline, itself pinned to the reference by the
-    goldens) on the identical (S, X) = (delay_gso, delay_state) the HIP kernels consume, for `n_check` sampled episodes:
-      two_launch  mgp_actor_fwd on the current state
-      resident    the action of a one-step mgp_rollout_steps launch from the same state (when the shape is covered)
-      factored    N > 256: the action of one step of the factored path (mgp_sparse_rollout) from the same state
-    max_rel is elementwise |gpu - cpu| / max(1, |cpu|); the gate is max_rel <= 1e-5.  Runs after the timed regions."""
-    from oracle import torch_port
-    from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
-    B = ro.B
-    idx = sorted(set(int(i) for i in np.linspace(0, B - 1, min(n_check, B))))
-    G = ro.state.delay_gso[idx].cpu()
-    X = ro.state.delay_state[idx].cpu()
-    Ws = [c.weight.detach().cpu() for c in ro.actor.conv_layers]
-    bs = [c.bias.detach().cpu() for c in ro.actor.conv_layers]
-    with torch.no_grad():
-        ref = torch_port.actor_forward(X, G, Ws, bs, 0, ro.K).double()
-        # the same op sequence in fp64 on the same fp32 inputs: how far the fp32 REFERENCE itself is from the exact result
-        # on this state (crowded flocks make 1/r^4 features O(1e4) and the policy ill-conditioned: two fp32 evaluations
-        # of the reference -- numpy vs torch op order -- then differ by more than 1e-5 from each other)
-        exact = torch_port.actor_forward(X.double(), G.double(), [w.double() for w in Ws], [b_.double() for b_ in bs], 0, ro.K)
-        two = ro.actor(ro.state.delay_state, ro.state.delay_gso)[idx].cpu().double()
-    res = {}
-
-    def rel_b(u, r):                                          # per sampled episode: max over (action axis, agent)
-        return ((u - r).abs() / r.abs().clamp(min=1.0)).flatten(1).max(dim=1).values
-    # second witness of how well fp32 determines the result on this state: the exact evaluation of inputs moved by ONE fp32
-    # rounding (every element of S and X times (1 +- 2^-24), fixed seed) -- what a single rounding of the operands does
-    gen = torch.Generator().manual_seed(12345)
-    sgn = lambda t: (torch.randint(0, 2, t.shape, generator=gen).double() * 2.0 - 1.0) * 2.0 ** -24
-    with torch.no_grad():
-        moved = torch_port.actor_forward(X.double() * (1.0 + sgn(X)), G.double() * (1.0 + sgn(G)), [w.double() for w in Ws],
-                                         [b_.double() for b_ in bs], 0, ro.K)
-    noise_b = torch.maximum(rel_b(ref, exact), rel_b(moved, exact))
-    well = noise_b <= 0.5 * PARITY_TOL                        # episodes where the fp32 reference is determined to < tol
-    paths = {'two_launch': two}
-    if ro.resident_supported() or ro.factored_supported():
-        # one step of the path that is `value`, from the very state whose (S, X) the reference was evaluated on: the
-        # episode-resident kernel, or -- N > 256 -- the factored path's K launches (policy_rollout continues the factored state the
-        # timed region left; without one it would fall back to the two-launch step and return False)
-        action = torch.zeros((B, 1, N_ACT, ro.N), device=ro.sim.device)
-        if policy_rollout(ro.actor, ro.sim, ro.state, 1, action=action):
-            paths['resident' if ro.resident_supported() else 'factored'] = action[idx].cpu().double()
-    ok = True
-    for name, u in paths.items():
-        r_ref, r_ex = rel_b(u, ref), rel_b(u, exact)
-        res[name] = {"max_abs": float((u - ref).abs().max()), "max_rel": float(r_ref.max()),
-                     "max_rel_vs_exact": float(r_ex.max()),
-                     "max_rel_well_conditioned": float(r_ref[well].max()) if bool(well.any()) else None}
-        plain = r_ref <= PARITY_TOL
-        res[name]["episodes_within_plain_tol"] = int(plain.sum())
-        relaxed = plain | (r_ex <= PARITY_TOL + NOISE_FACTOR * noise_b)
-        res[name]["passed_on"] = "plain bound" if bool(plain.all()) else ("relaxed bound (see criterion)" if bool(relaxed.all())
-                                                                          else "FAILED")
-        # an episode passes on the plain bound, or -- where the reference's own fp32 evaluation is not determined to that
-        # accuracy -- by staying within tol + NOISE_FACTOR x that episode's reference noise of the fp64 evaluation
-        ok = ok and bool((plain | (r_ex <= PARITY_TOL + NOISE_FACTOR * noise_b)).all())
-        if 'reference checkpoint' in ro.weights and bool(well.all()):
-            ok = ok and bool(plain.all())                    # the shipped policy on well-conditioned states: plain bound only
-    worst = max((v["max_rel_well_conditioned"] for v in res.values() if v["max_rel_well_conditioned"] is not None),
-                default=None)
-    return {"ok": ok, "tol": PARITY_TOL, "max_abs": max(v['max_abs'] for v in res.values()),
-            "max_rel": max(v['max_rel'] for v in res.values()),            # over ALL checked episodes and paths
-            "max_rel_well_conditioned": worst,
-            "passed_on": {k_: v["passed_on"] for k_, v in res.items()},
-            "reference_fp32_noise": float(noise_b.max()), "max_abs_reference_output": float(ref.abs().max()),
-            "checked_episodes": len(idx), "well_conditioned_episodes": int(well.sum()), "paths": res,
-            "criterion": "per sampled episode: elementwise |gpu - cpu| / max(1, |cpu|) <= tol against the fp32 CPU reference "
-                         "(paths.*.episodes_within_plain_tol counts these), or, failing that, within tol + 2 x the "
-                         "episode's reference_fp32_noise of the fp64 evaluation of the same op sequence on the same fp32 "
-                         "inputs (reference_fp32_noise = how far fp32 evaluations of the REFERENCE are from that evaluation -- "
-                         "the larger of two witnesses: the PyTorch-CPU fp32 op sequence, and the exact evaluation of inputs "
-                         "moved by one fp32 rounding: "
-                         "colliding agents drive 1/r^4 features to 1e6, random-init wide networks amplify them, and any "
-                         "two fp32 evaluations then differ by more than tol).  max_rel is over all checked episodes, "
-                         "max_rel_well_conditioned over those where the reference is determined to tol/2; passed_on says "
-                         "per path which bound it passed on.  The shipped reference checkpoint on well-conditioned states is "
-                         "held to the plain bound only",
-            "reference": "oracle/torch_port.actor_forward: PyTorch-CPU fp32, the op sequence of reference actor.py:63-82, "
-                         "on the identical (delay_gso, delay_state) of the sampled episodes"}
-
-
 def mean_degree(state):
     """Mean number of neighbours per agent in the current networks (rows of delay_gso[:, 1]), over all episodes."""
     if state.K < 2:
         return None
     return float((state.delay_gso[:, 1] != 0).sum(dim=-1).double().mean().item())
-
-
-def cpu_baseline(N, K, hidden, budget_s=12.0, init_mode='auto', actor=None, variant=None):
-    """Reference-style single-episode CPU loop (oracle/torch_port.py + numpy sim), bounded sample.  `actor`: the policy the
-    GPU legs ran (its weights are copied to the host); `variant`: FlockParams fields of the environment variant."""
-    from oracle import flock as ofl, torch_port
-    path = os.path.join(ROOT, 'tests', 'golden', 'ckpt_dagger_k3.npz')
-    torch.manual_seed(11)
-    if actor is not None:
-        Ws = [c.weight.detach().cpu().clone() for c in actor.conv_layers]
-        bs = [c.bias.detach().cpu().clone() for c in actor.conv_layers]
-    elif os.path.exists(path) and K == 3 and hidden == [32, 32]:
-        with np.load(path) as z:
-            Ws = [torch.from_numpy(z[f'conv_layers__{i}__weight']) for i in range(3)]
-            bs = [torch.from_numpy(z[f'conv_layers__{i}__bias']) for i in range(3)]
-    else:
-        dims = [F_FEAT] + hidden + [N_ACT]
-        Ws = [torch.randn(dims[i + 1], dims[i], K if i == 0 else 1, 1) * 0.1 for i in range(len(dims) - 1)]
-        bs = [torch.zeros(dims[i + 1]) for i in range(len(dims) - 1)]
-    p = ofl.FlockParams(n_agents=N, init_mode=init_mode, **(variant or {}))
-    x0 = ofl.reset(np.random.RandomState(0), p)
-    default_threads = torch.get_num_threads()
-    runs = []
-    for threads in sorted({1, default_threads}):
-        torch.set_num_threads(threads)
-        x = x0
-        torch_port.rollout_steps(x, p, Ws, bs, K, 5)                     # warm-up
-        chunk, done = 50, 0
-        t0 = time.perf_counter()
-        while True:
-            _, x = torch_port.rollout_steps(x, p, Ws, bs, K, chunk)
-            done += chunk
-            el = time.perf_counter() - t0
-            if el >= budget_s / 2 or done >= 20000:
-                break
-        runs.append((N * done / el, threads, done, el))
-    torch.set_num_threads(default_threads)
-    best = max(runs)
-    return dict(value=best[0], unit='agent-steps/s', cores=best[1], kind='port',
-                sample='1 episode x %d steps (%.1f s) at %d torch thread(s), reference-style B=1 loop: numpy fp64 '
-                       'sim + torch-CPU state update (incl. curr_gso) + Actor forward; all thread settings tried: '
-                       '%s; host has %d logical cores'
-                       % (best[2], best[3], best[1],
-                          ', '.join('%d thr -> %.3g agent-steps/s' % (r[1], r[0]) for r in runs), os.cpu_count() or 0),
-                ms_per_env_step=1e3 * best[3] / best[2])
-
-
-def dagger_update_bench():
-    """Secondary measurement (`bench.py --dagger-update`): one DAGGER gradient_step at the reference's training
-    shape (cfg/dagger.cfg: B=20, N=100, K=3) on the HIP path -- fused forward + MSE gradient + fused backward + flat
-    Adam, replayed from one HIP graph -- next to the same op sequence of the CPU port (torch autograd + Adam; this is
-    the cpu_baseline leg of the update measurement: the only place this function touches oracle/)."""
-    import configparser
-    from multiagent_gnn_policies_amd.learner.gnn_dagger import DAGGER
-    B, N, K = 20, 100, 3
-    cp = configparser.ConfigParser()
-    cp['DEFAULT'] = dict(n_states='6', n_actions='2', k=str(K), hidden_size='32', gamma='0.99', tau='0.5',
-                         n_agents=str(N), actor_lr='5e-5')
-    cp['t'] = {}
-    torch.manual_seed(11)
-    dev = torch.device('cuda:0')
-    learner = DAGGER(dev, cp['t'])
-    gen = torch.Generator(device=dev).manual_seed(0)
-    xd = torch.randn((B, K, F_FEAT, N), device=dev, generator=gen)
-    mask = torch.rand((B, K, N, N), device=dev, generator=gen) < (8.0 / N)
-    gd = mask.float() / mask.float().sum(-1, keepdim=True).clamp(min=1)
-    gd[:, 0] = torch.eye(N, device=dev)
-    yd = torch.randn((B, 1, N_ACT, N), device=dev, generator=gen)
-    for _ in range(20):
-        learner.gradient_step_tensors(xd, gd, yd)
-    torch.cuda.synchronize()
-    n = 300
-    t0 = time.perf_counter()
-    for _ in range(n):
-        learner.gradient_step_tensors(xd, gd, yd)                 # drop-in semantics: the host reads every loss
-    torch.cuda.synchronize()
-    gpu_ms = 1e3 * (time.perf_counter() - t0) / n
-    t0 = time.perf_counter()
-    for _ in range(n):
-        learner.gradient_step_tensors(xd, gd, yd, sync=False)     # vectorised DAGGER: losses stay on the device
-    torch.cuda.synchronize()
-    gpu_ms_pipe = 1e3 * (time.perf_counter() - t0) / n
-    # vectorised DAGGER's round of updates: minibatches gathered from a device replay inside the kernel, index table
-    # uploaded once, one graph replay per update (sampling on the host included: random.sample per update)
-    from multiagent_gnn_policies_amd.learner.vec_dagger import DeviceReplay, IndexedUpdates
-    cap, U = 4096, 2000
-    rb = DeviceReplay(cap, K, F_FEAT, N, N_ACT, dev)
-    for i0 in range(0, cap, B):
-        rb.insert_batch(xd, gd, yd)
-    iu = IndexedUpdates(learner, rb, B, U)
-    iu.run_sampled(64)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    loss_round = iu.run_sampled(U).item()
-    gpu_ms_idx = 1e3 * (time.perf_counter() - t0) / U
-    assert np.isfinite(loss_round)
-    from oracle import torch_port                          # CPU leg
-    res = {}
-    xc, gc, yc = xd.cpu(), gd.cpu(), yd.cpu()
-    for thr in sorted({1, torch.get_num_threads()}):
-        torch.set_num_threads(thr)
-        Ws = [torch.nn.Parameter(c.weight.detach().cpu().clone()) for c in learner.actor.conv_layers]
-        bs = [torch.nn.Parameter(c.bias.detach().cpu().clone()) for c in learner.actor.conv_layers]
-        opt = torch.optim.Adam(Ws + bs, lr=5e-5)
-
-        def step():
-            opt.zero_grad()
-            out = torch_port.actor_forward(xc, gc, Ws, bs, 0, K)
-            loss = torch.nn.functional.mse_loss(out, yc)
-            loss.backward()
-            opt.step()
-            return loss.item()
-        for _ in range(5):
-            step()
-        t0 = time.perf_counter()
-        m = 100
-        for _ in range(m):
-            step()
-        res[thr] = 1e3 * (time.perf_counter() - t0) / m
-    # DAGGER data collection (BASELINE.json configs[3], gnn_dagger.py:154-178): rollouts with expert labels, beta coin and
-    # replay insert -- on the collecting build of the resident kernel (one launch per round) vs the host-stepped two-launch
-    # loop of round 1 (>= 5 launches + host RNG + H2D per step)
-    from multiagent_gnn_policies_amd.learner.vec_dagger import FrameReplay, collect_round, FrameUpdates
-    lanes, Tc = 256, 500
-    pcol = FlockParams(n_agents=N, init_mode='grid')
-    simc = VecFlock(lanes, pcol, dev, with_expert=True)
-    stc = BatchedDelayState(dev, lanes, K, F_FEAT, N)
-    memc = FrameReplay(lanes, lanes * Tc, K, N, dev)
-    beta_t = torch.full((lanes,), 0.75, device=dev)
-    eps = torch.arange(lanes, dtype=torch.int32, device=dev)
-    np.random.seed(3)
-    collect_round(learner, simc, stc, memc, beta_t, eps, 11, 20)                 # warm-up (also the reset sampling cache)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    collect_round(learner, simc, stc, memc, beta_t, eps, 11, Tc)
-    torch.cuda.synchronize()
-    t_round = time.perf_counter() - t0
-    e0c, e1c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    from multiagent_gnn_policies_amd.learner.rollouts import _actor_params
-    wsc, bsc = _actor_params(learner.actor)
-    img = ops.rollout_image(wsc, bsc, tuple(learner.actor.layers), K, N)
-    exp_io = simc.controller().permute(0, 2, 1).contiguous()
-    e0c.record()
-    ops.rollout_collect(simc.x, stc._G[stc._cur], stc.delay_state, tuple(learner.actor.layers), simc._c, Tc, memc, exp_io, beta_t,
-                        eps, 11, age0=Tc, ring_step0=memc.head, carry=stc.carry_buffer(),
-                        flags=ops.RO_ENTER_CARRY | ops.RO_EXIT_CARRY | ops.RO_SKIP_DENSE, image=img)
-    e1c.record()
-    torch.cuda.synchronize()
-    collect_kernel_ms = e0c.elapsed_time(e1c)
-    fu = FrameUpdates(learner, memc, B, 2000, True)
-    fu.run_sampled(64)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    fu.run_sampled(2000).item()                                # random.sample per update, overlapped with the GPU's replays
-    frame_update_ms = 1e3 * (time.perf_counter() - t0) / 2000
-
-    return {"update": "DAGGER gradient_step B=20 N=100 K=3", "hip_ms": gpu_ms, "hip_updates_per_s": 1e3 / gpu_ms,
-            "collect": {"lanes": lanes, "steps": Tc, "kernel_ms": collect_kernel_ms,
-                        "kernel_agent_steps_per_s": lanes * N * Tc / (1e-3 * collect_kernel_ms),
-                        "round_wall_s_incl_host_reset_sampling": t_round,
-                        "replay_bytes_per_transition": memc.bytes_per_transition(),
-                        "hip_ms_frame_update_round": frame_update_ms},
-            "hip_ms_pipelined": gpu_ms_pipe, "hip_updates_per_s_pipelined": 1e3 / gpu_ms_pipe,
-            "hip_ms_indexed_round": gpu_ms_idx, "hip_updates_per_s_indexed_round": 1e3 / gpu_ms_idx,
-            "cpu_port_ms_by_threads": res, "host_cores": os.cpu_count()}
-
-
-def self_launch(n):
-    """`python bench.py --gpus N` with no launcher: start N ranks of this very command (one per GPU; RANK / LOCAL_RANK /
-    WORLD_SIZE / MASTER_* as torch.distributed.run would set them), pass rank 0's JSON line through, return the worst exit
-    status.  Refuses -- loudly -- to run more RCCL ranks than there are devices."""
-    import socket
-    import subprocess
-    backend = os.environ.get('MGP_DIST_BACKEND') or 'nccl'
-    have = torch.cuda.device_count()
-    if backend == 'nccl' and n > have:
-        sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible: RCCL needs one GPU per rank "
-                         "(MGP_DIST_BACKEND=gloo lets ranks share a device, for tests)\n" % (n, have))
-        return 2
-    sock = socket.socket()
-    sock.bind(('127.0.0.1', 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    procs = []
-    for rk in range(n):
-        env = dict(os.environ, RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if rk == 0 else subprocess.DEVNULL))
-    worst = 0
-    try:
-        pending = list(procs)
-        while pending:
-            for p in list(pending):
-                rc = p.poll()
-                if rc is None:
-                    continue
-                pending.remove(p)
-                if rc != 0:
-                    worst = worst or rc
-                    for q in pending:                            # a dead rank leaves the others in a collective: stop them
-                        q.terminate()
-            time.sleep(0.05)
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-    return worst
-
-
-def check_one_device_per_rank(world):
-    if world > 1 and torch.distributed.get_backend() == 'nccl' and world > torch.cuda.device_count():
-        raise SystemExit("bench.py: %d RCCL ranks but %d device(s) visible: one GPU per rank" % (world, torch.cuda.device_count()))
-
-
-def dist_record():
-    """What the process group really was (the record shows that RCCL saw N ranks)."""
-    d = torch.distributed
-    if d.is_available() and d.is_initialized():
-        return {"backend": d.get_backend(), "world_size": d.get_world_size(), "devices_visible": torch.cuda.device_count()}
-    return {"backend": None, "world_size": 1, "devices_visible": torch.cuda.device_count()}
-
-
-def dagger_round_bench(args, device, rank, world):
-    """BASELINE.json configs[3] (reference gnn_dagger.py:126-243, one device, one env): one DAGGER round on every rank --
-      collection  --episodes lanes x --steps env steps inside ONE mgp_rollout_collect launch per rank (policy forward, expert
-                  label, beta coin, simulator step, state transition, frame filed into the replay ring); ranks never talk
-      updates     --updates minibatch updates of --batch-size samples PER RANK from the rank's own replay, captured 32 to a
-                  HIP graph; the ranks' gradients (1,730 floats + the loss) are exchanged inside every update -- the one-shot
-                  IPC exchange (csrc/p2p_device.h) or, without it, the RCCL all-reduce captured in the graph
-    Timed with the contract's barrier + synchronize bracketing, MAX over ranks; the weights must be bit-identical on every
-    rank at the end (the run fails otherwise)."""
-    import configparser
-    from multiagent_gnn_policies_amd.learner.gnn_dagger import DAGGER
-    from multiagent_gnn_policies_amd.learner.vec_dagger import (FrameReplay, FrameUpdates, collect_round, collect_supported,
-                                                                _dp_mode)
-    dist = torch.distributed
-    lanes, N, K, T, U, Bt = args.episodes, args.agents, args.taps, args.steps, args.updates, args.batch_size
-    cp = configparser.ConfigParser()
-    cp['DEFAULT'] = dict(n_states=str(F_FEAT), n_actions=str(N_ACT), k=str(K), hidden_size=str(args.hidden),
-                         n_layers=str(args.layers), gamma='0.99', tau='0.5', n_agents=str(N), actor_lr='5e-5')
-    cp['t'] = {}
-    torch.manual_seed(11)
-    learner = DAGGER(device, cp['t'])
-    if not (collect_supported(learner, K, N) and FrameUpdates.supported(learner, Bt, N)):
-        raise SystemExit("bench.py --dagger: shape outside mgp_rollout_collect / the graph-captured update path")
-    p = FlockParams(n_agents=N, init_mode=args.init)
-    sim = VecFlock(lanes, p, device, with_expert=True)
-    state = BatchedDelayState(device, lanes, K, F_FEAT, N)
-    memory = FrameReplay(lanes, lanes * max(T, args.warmup, 1), K, N, device)
-    beta = torch.full((lanes,), 0.75, device=device)
-    eps = torch.arange(rank * lanes, (rank + 1) * lanes, dtype=torch.int32, device=device)
-    np.random.seed(1000 + rank)
-    import random
-    random.seed(1000 + rank)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    def max_over_ranks(x):
-        if world > 1:
-            t = torch.tensor([x], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t.item())
-        return x
-
-    # ---- collection: reset sampling (host, once per round) is outside the timed region, the launch inside
-    from multiagent_gnn_policies_amd.learner.rollouts import _actor_params
-
-    def collect_factored(steps):
-        """N > 256: the same round on the factored state in HBM (K launches per env step enqueued by one library call;
-        frame, label and coin inside the policy launch: mgp_sparse_policy_collect)."""
-        from multiagent_gnn_policies_amd.learner.sparse_rollout import SparseFlockState, sparse_collect
-        sim.reset(np.random)
-        state.reset()
-        state.push(sim.network, sim.features)
-        sp = SparseFlockState(sim, K)
-        sp.observe_reset(sim)
-        gc.disable()                                             # (see timed(): no interpreter GC pass inside the timed region)
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        sparse_collect(learner.actor, sim, sp, memory, beta, eps, 11, 0, steps)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        gc.enable()
-        barrier()
-        return max_over_ranks(el)
-
-    def collect(steps):
-        if N > 256:
-            return collect_factored(steps)
-        sim.reset(np.random)
-        state.reset()
-        state.push(sim.network, sim.features)
-        expert_io = sim.controller().permute(0, 2, 1).contiguous()
-        ws, bs = _actor_params(learner.actor)
-        image = ops.rollout_image(ws, bs, tuple(learner.actor.layers), K, N)
-        carry = state.carry_buffer()
-        gc.disable()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ok = ops.rollout_collect(sim.x, state._G[state._cur], state.delay_state, tuple(learner.actor.layers), sim._c, steps,
-                                 memory, expert_io, beta, eps, 11, age0=0, ring_step0=memory.head, carry=carry,
-                                 flags=ops.RO_ENTER_CARRY | ops.RO_EXIT_CARRY | ops.RO_SKIP_DENSE, image=image)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        gc.enable()
-        barrier()
-        assert ok
-        memory.advance(steps)
-        state._pushes += steps
-        state._dense_stale = True
-        return max_over_ranks(el)
-    gc.freeze()
-    collect(max(args.warmup, K))
-    t_collect = collect(T)
-    # ---- updates
-    fu = FrameUpdates(learner, memory, Bt, max(U, 64), p.mean_pooling)
-    learner.begin_updates()
-    gc.freeze()
-    fu.run_sampled(64)                                           # warm-up: captures both graphs
-    learner.end_updates()
-    gc.disable()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    loss_sum = fu.run_sampled(U)
-    torch.cuda.synchronize()
-    t_upd = time.perf_counter() - t0
-    gc.enable()
-    barrier()
-    t_upd = max_over_ranks(t_upd)
-    learner.end_updates()
-    loss_mean = float(loss_sum.item()) / U
-    # ---- every rank must hold the same weights, bit for bit
-    identical = True
-    if world > 1:
-        cdev = device if dist.get_backend() == 'nccl' else torch.device('cpu')
-        mine = learner.actor_optim.flat.detach().to(cdev)
-        parts = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine)
-        identical = all(torch.equal(parts[0], q) for q in parts[1:])
-    if rank == 0:
-        out = {
-            "metric": "agent-steps/sec of DAGGER data collection, FlockingRelative-v0 N=%d K=%d" % (N, K),
-            "value": world * lanes * N * T / t_collect, "unit": "agent-steps/s", "n_gpus": world, "steps": T,
-            "warmup": args.warmup, "ms_per_step": 1e3 * t_collect / T, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "DAGGER round (BASELINE.json configs[3]): %d lanes x %d steps of data collection per rank "
-                                   "(%s: policy forward, expert label, beta coin, sim step, frame insert), "
-                                   "then %d updates of %d samples per rank with the gradient exchanged between %d rank(s)"
-                                   % (lanes, T, "mgp_rollout_collect" if N <= 256 else "factored state, mgp_sparse_policy_collect",
-                                      U, Bt, world),
-                       "episodes_per_gpu": lanes, "agents": N, "taps": K, "hidden": [args.hidden] * args.layers,
-                       "init": args.init, "beta": 0.75,
-                       "parallelism": "episodes sharded x%d; one exchange of %d floats per update"
-                                      % (world, learner.actor_optim.flat.numel() + 1)},
-            "updates": {"count": U, "batch_size_per_rank": Bt, "ms_per_update": 1e3 * t_upd / U,
-                        "updates_per_s": U / t_upd, "samples_per_s": U * Bt * world / t_upd, "mean_loss": loss_mean,
-                        "exchange": (fu.dp or "none (single process)"),
-                        "exchange_mem_kind": getattr(learner.p2p, 'mem_kind', None),
-                        "exchange_bringup": parallel.P2PExchange.last_bringup,
-                        "updates_per_graph": 32,
-                        # aggregated: mgp_replay_aggregate + mgp_train_step_agg (the K-hop products along the frames' bit rows,
-                        # operator slices never formed); dense: mgp_replay_gather_many / _rows + mgp_train_step_indexed
-                        "slots": "aggregated" if fu.aggregated else "dense"},
-            "round_s": t_collect + t_upd,
-            "weights_bit_identical_across_ranks": identical,
-            "dist": dist_record(),
-        }
-        emit_json(out)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    if not identical:
-        sys.stderr.write("bench.py --dagger: the ranks' weights differ\n")
-        sys.exit(4)
-
-
-_JSON_FD = [None]
-
-
-def emit_json(obj):
-    """The result line, on the process's ORIGINAL stdout (see main: fd 1 is pointed at stderr while the bench runs)."""
-    line = (json.dumps(obj) + "\n").encode()
-    if _JSON_FD[0] is None:
-        sys.stdout.write(line.decode()); sys.stdout.flush()
-    else:
-        sys.stdout.flush()
-        os.write(_JSON_FD[0], line)
 
 
 def main():
@@ -942,7 +311,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
-        sys.exit(self_launch(args.gpus))                         # `python bench.py --gpus N` starts its own N ranks
+        sys.exit(self_launch(args.gpus, os.path.abspath(__file__)))                        # `python bench.py --gpus N` starts its own N ranks
     # ONE line on stdout: libraries that print there from C (gloo's "[Gloo] Rank 0 is connected ..." when several ranks share
     # a GPU in tests) are sent to stderr for the rest of the process; the JSON line goes to the saved descriptor (emit_json)
     sys.stdout.flush()
@@ -1250,145 +619,12 @@ def main():
                                                  "mean_degree_at_reset": deg_grid}
     if rank == 0 and not args.no_roofline:
         trace('-')
-        res, n_sets = kernel_rooflines(device, B, N, K, ro.actor, ro.sim._c)
-        trace('kernel_rooflines')
-        fused = getattr(ro.actor, 'use_fused', False) and ro.actor.ind_agg == 0
-
-        def hbm_block(key, kname, pmc_names):
-            r = res[key]
-            tr, tr_note, sq = None, 'not profiled', None
-            for pmc_name in pmc_names:                       # the variant the library picked for this shape comes first
-                tr, tr_note = pmc_traffic(pmc_name, B, N, K)
-                sq = pmc_sq(pmc_name)
-                if tr is not None:
-                    break
-            return {"kernel": kname, "bound": "hbm", "achieved": r['gbs'], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": r['gbs'] / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_note,
-                    "algorithmic_bytes_per_launch": r['bytes'], "avg_launch_ms": r['ms'], "sq": sq}
-        # HBM-roofline figures of the kernels that stream the dense operator G (B,K,N,N) from HBM on every launch --
-        # north_star's "fraction of HBM roofline for the S^k X aggregation" -- measured live with HIP events on the
-        # launch stream over rotating input sets larger than the Infinity Cache; algorithmic bytes per SURVEY.md 8(d)
-        dense = {
-            "actor_fwd": hbm_block('actor_fwd', "mgp_actor_fwd: for N <= 128 actor_fwd_pol_kernel (the reference's policy shape [32, 32] compiled in: "
-                                   "aggregation on 4x4x1 fp32 MFMA, hidden layers on split-bf16 MFMA) or actor_fwd_mfma_kernel (any "
-                                   "widths <= 128, fp32 MFMA), actor_fwd_kernel otherwise: 4KN^2 + 4KFN + 4 nA N bytes per "
-                                   "episode", ('actor_fwd_pol_kernel', 'actor_fwd_mfma_kernel', 'actor_fwd_kernel')
-                                   if hidden == [32, 32] else ('actor_fwd_mfma_kernel', 'actor_fwd_kernel')),
-            "agg_fwd": hbm_block('agg_fwd', "mgp_agg_fwd: agg_fwd_mfma4_kernel for N <= 128 (four waves per (episode, tap): a wave "
-                                 "streams half the rows of its column block), agg_fwd_kernel otherwise (aggregation "
-                                 "X.G alone): 4KN^2 + 8KFN bytes per episode", ('agg_fwd_mfma4_kernel', 'agg_fwd_mfma_kernel', 'agg_fwd_kernel')),
-            "sim_state_step": hbm_block('sim_state_step', "mgp_flock_step_advance: flock_advance_kernel for N <= 128 (one workgroup per "
-                                        "episode: sim step + delayed-GSO / delay-line transition, source slice staged in LDS by "
-                                        "LDS-DMA), the row-tiled flock_step_kernel<advance> otherwise",
-                                        ('flock_advance_kernel',) if (N <= 128 and N % 4 == 0) else ('flock_step_kernel',)),
-            "rotating_input_sets": n_sets,
-        }
-        if resident:
-            # dominant (only) kernel of the timed region.  Its one roofline-shaped resource is the matrix pipe (filter GEMM +
-            # hidden layers on fp32 MFMA); nothing streams from HBM.  achieved = ALGORITHMIC flops of the MFMA-run layers
-            # (2 N sum_l cin_l cout_l per episode-step, hidden layers only) / launch duration.
-            n_launch = res_launches                              # launches of the timed region (split at episode ends / 2000 steps)
-            spl = args.steps / float(n_launch)
-            dims = [F_FEAT * K] + hidden
-            flops_unit = 2.0 * N * sum(a * b_ for a, b_ in zip(dims[:-1], dims[1:]))
-            flops = flops_unit * B * spl
-            ms = res_launch_ms / n_launch
-            alg = (4 * K * N * N + 8 * K * F_FEAT * N) * B * spl
-            # which instructions run those flops: layers whose inputs have <= 32 channels run on split-bf16 MFMA (three bf16
-            # pieces per fp32 operand, six 16x16x32 products per fp32 product: rollout_common.h ro_layer_bf16), the 64-wide
-            # build on fp32 MFMA 16x16x4.  `frac` above stays against the fp32 matrix peak -- the rate a plain fp32
-            # implementation of the same flops is bounded by; the bf16 figures are here for the pipe's own occupancy
-            split = N <= 128 or max(hidden) <= 32        # every build of the N <= 128 kernel; beyond, widths <= 32 only
-            matrix_note = ({"form": "split-bf16: v_mfma_f32_16x16x32_bf16, 6 bf16 products per fp32 product, K padded to 32",
-                            "bf16_flops_per_episode_step": 6.0 * 2.0 * N * sum(32 * 16 * ((b_ + 15) // 16) for b_ in dims[1:]),
-                            "bf16_peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS}
-                           if split else {"form": "fp32: v_mfma_f32_16x16x4_f32"})
-            if split:
-                matrix_note["frac_of_bf16_peak"] = (matrix_note["bf16_flops_per_episode_step"] * B * spl / ms / 1e9 /
-                                                    MFMA_BF16_PEAK_TFLOPS)
-            tr, tr_note = pmc_traffic('rollout_kernel', B, N, K, steps_per_launch=spl)
-            # The MEASURED limiter of this kernel is vector-instruction issue (its fullest SIMD's VALU pipe), not the matrix pipe
-            # (sq.mfma_busy ~ 0.07) and not HBM (traffic = state in / out): `bound` names it.  achieved = VALU wave-instructions
-            # per second = (SQ_INSTS_VALU per episode-step of the committed counter pass of THIS build, profiles/<round>_pmc_sq.json)
-            # x the episode-steps per second of the live, event-stamped launches; peak = CUs x 4 SIMDs x clock / 4 cycles (a wave64
-            # vector instruction occupies its SIMD for at least four cycles; fp64 pairs, transcendentals and MFMAs longer, so the
-            # fraction is a LOWER bound on how busy the pipes are).  sq.valu_issue is the same quantity over the SIMDs' busy
-            # cycles of the profiled launches.  The matrix-pipe figure stays beside it under `mfma`.
-            sq = pmc_sq('rollout_kernel')
-            sq_meta = (_profile_json('pmc_sq.json') or {}).get('_meta', {})
-            valu_unit = None
-            profiled_shape = (N == 100 and K == 3 and hidden == [32, 32])          # tools/pmc_probe.py profiles the headline shape
-            if not profiled_shape:
-                sq = None
-            if sq is not None and sq.get('valu_insts') and sq_meta.get('rollout_episode_steps_per_launch'):
-                valu_unit = sq['valu_insts'] / float(sq_meta['rollout_episode_steps_per_launch'])
-            valu_peak = N_CUS * 4 * CLOCK_GHZ / 4.0                                  # G wave-instructions / s
-            valu_ach = (valu_unit * B * spl / ms / 1e6) if valu_unit else None
-            out["roofline"] = {
-                "kernel": "rollout_kernel (episode-resident: power-iterated aggregation along neighbour lists + split-bf16 MFMA "
-                          "filter/MLP + sim step + Verlet-listed neighbour search, %.0f steps per launch on average)" % spl,
-                "bound": "valu", "achieved": valu_ach, "peak": valu_peak, "unit": "G wave-instructions/s",
-                "frac": (valu_ach / valu_peak) if valu_ach else (sq or {}).get('valu_issue'),
-                "valu_insts_per_episode_step": valu_unit,
-                "bound_note": "vector-ALU issue: %d CUs x 4 SIMDs x %.1f GHz / 4 cycles per wave64 instruction; instruction count "
-                              "from the committed SQ counter pass of this build, rate from this run's event-stamped launches" % (N_CUS, CLOCK_GHZ),
-                "mfma": {"achieved": flops / ms / 1e9, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": flops / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
-                         "note": "algorithmic flops of the MFMA-run layers against the fp32 matrix peak (rounds 1-4 reported this as "
-                                 "`frac`); the pipe itself is sq.mfma_busy busy"},
-                "traffic": tr, "traffic_source": tr_note,
-                "algorithmic_flops_per_launch": flops, "algorithmic_flops_per_episode_step": flops_unit,
-                "avg_launch_ms": ms, "steps_per_launch": spl, "resident": True,
-                "matrix_instructions": matrix_note,
-                "launch_timing": "HIP events stamped by the launch itself (mgp_set_launch_events) in a second pass over the same "
-                                 "steps of the same episodes (paths.resident.ms_per_step_event_pass); the pass `value` is taken "
-                                 "from carries no events",
-                "limiter": "vector-ALU instruction issue: sq.valu_issue (>= 0.6: SQ_INSTS_VALU x 4 cycles over the four SIMDs' busy "
-                           "cycles, a lower bound -- fp64, transcendental and MFMA instructions hold the pipe longer) is the "
-                           "resource nearest its ceiling; the rest of a step is LDS latency and workgroup barriers with one "
-                           "workgroup per CU.  Neither HBM (traffic = state in/out + 8 B of reward per step) nor the matrix "
-                           "pipe (sq.mfma_busy) is saturated -- the fractions in `sq` are the evidence",
-                "sq": sq,
-                "equivalent_hbm": {"GBps": alg / ms / 1e6, "frac_of_peak": alg / ms / 1e6 / HBM_PEAK_GBS,
-                                   "algorithmic_bytes_per_launch": alg,
-                                   "note": "NOT a roofline fraction: the bytes the dense-contract aggregation (4KN^2 + 8KFN "
-                                           "per episode-step, SURVEY.md 8d) WOULD stream for these steps / launch time; "
-                                           "inside the launch the operator exists only as neighbour lists in LDS"},
-                "dense_kernels": dense}
-        elif factored:
-            # N > 256: the factored state in HBM, K launches per env step (simulator, K - 2 gather stages, policy tail).  No
-            # dense operator exists; the bytes a step REQUIRES (each array once) per episode:
-            #   simulator    x in + out (2 x 32 N), bit rows (8 NW N), row weights (4 N), feature rows (32 N), lists (32 N)
-            #   gather q     lists of A_{t-q+1} (32 N) + row weights (4 N), source rows of taps >= q in (32 N each) and out
-            #   policy tail  lists + weights of the last factor, its source rows, the K finished taps (32 N each), action (8 N)
-            NW = (N + 63) // 64
-            sim_b = (64 + 8 * NW + 4 + 32 + 32) * N
-            gather_b = sum((36 + 64 * (K - q)) * N for q in range(1, K - 1))          # stages 1 .. K-2: taps q .. K-1 in and out
-            policy_b = ((36 + 32) * (1 if K >= 2 else 0) + 32 * K + 8) * N
-            req = (sim_b + gather_b + policy_b) * B
-            ms_step = 1e3 * el_fact / args.steps
-            trf, trf_note = pmc_traffic_factored(B, N, K)
-            out["roofline"] = {
-                "kernel": "factored step: sp_sim_kernel + %d x spl_gather_kernel + spl_policy_kernel (%d launches per env step)"
-                          % (max(K - 2, 0), max(K, 2)),
-                "bound": "hbm", "achieved": req / ms_step / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": req / ms_step / 1e6 / HBM_PEAK_GBS, "traffic": trf, "traffic_source": trf_note,
-                "required_bytes_per_step": req,
-                "required_bytes_per_episode_step": {"simulator": sim_b, "gather_stages": gather_b, "policy_tail": policy_b},
-                "avg_step_ms": ms_step,
-                "note": "bytes the factored state REQUIRES per env step (bit rows, lists, row weights, feature rings, agent "
-                        "states: each array once) / wall time per step of the timed region / 8 TB/s.  The path is latency-, not "
-                        "bandwidth-bound: every launch starts with the wait for the rows the previous launch wrote on other "
-                        "XCDs (profiles/%s_factored_step_stamps.txt); the dense-contract bytes of this shape would be %.0f MB "
-                        "per step" % (PROFILE_ROUND, (4 * K * N * N + 8 * K * F_FEAT * N) * B / 1e6),
-                "dense_kernels": dense}
-        else:
-            out["roofline"] = dict(dense["actor_fwd" if fused else "agg_fwd"], dense_kernels=dense)
-        out["kernels"] = {k: {"avg_launch_ms": v['ms'], "algorithmic_bytes": v['bytes'], "GBps": v['gbs']}
-                          for k, v in res.items()}
+        out["roofline"], out["kernels"] = roofline_blocks(
+            device, B, N, K, hidden, ro.actor, ro.sim._c, 'resident' if resident else ('factored' if factored else 'dense'), args.steps,
+            res_launches=res_launches if resident else None, res_launch_ms=res_launch_ms, el_fact=el_fact)
+        trace('roofline blocks')
     parity = None
     if rank == 0 and not args.no_parity:
-        trace('roofline blocks')
         parity = parity_gate(ro)
         trace('parity gate')
         out["parity"] = parity

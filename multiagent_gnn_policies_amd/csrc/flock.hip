@@ -555,31 +555,35 @@ void flock_advance_kernel(const double* __restrict__ x, double* __restrict__ xo,
     const float* Gp = o.Gp + (size_t)b * K * NN;
     float* Gn = o.Gn + (size_t)b * K * NN;
     const bool prod = K > 2 && o.has_prev;
-    // source slice `sl` of G_prev -> LDS, 1 KB per wave and request, no registers, nothing to wait for until it is read; by the
-    // UPPER eight waves: hipcc does not count these requests, loads return in order, so a wave that waited for a load of its own
-    // behind them would wait for the whole slice -- the upper waves load nothing else
-    constexpr int FA_DMA_WAVES = 8, FA_DMA_W0 = FA_WAVES - FA_DMA_WAVES;
+    // source slice `sl` of G_prev -> LDS, 1 KB per wave and request, no registers, nothing to wait for until it is read.  hipcc does
+    // not count these requests but the hardware does, and loads return in order: EVERY s_waitcnt vmcnt a DMA wave executes
+    // afterwards -- its own lanes masked off or not -- blocks it until its share of the slice has landed.  [r6] So the requests
+    // are issued by waves that have nothing to do until the slice is needed: waves 13 and 14 where the membership phase runs on
+    // thirteen row waves (8 N <= 832: N <= 104), the upper eight waves otherwise (they then join the membership phase late).
+    constexpr int FA_LOAD_WAVES = 8;                        // waves 0 .. 7 load the agent states and copy the delay line
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool spare = 8 * N <= 13 * 64;
+    const int dma_w0 = spare ? 13 : FA_WAVES - 8, dma_n = spare ? 2 : 8;
     auto stage_slice = [&](const int sl) {
         const unsigned char* src = reinterpret_cast<const unsigned char*>(Gp + (size_t)sl * NN);
         const int bytes = (int)NN * 4;
-        if (wave >= FA_DMA_W0 && wave < FA_DMA_W0 + FA_DMA_WAVES)
-            for (int c = (wave - FA_DMA_W0) * 1024; c < bytes; c += FA_DMA_WAVES * 1024)
+        if (wave_u >= dma_w0 && wave_u < dma_w0 + dma_n)
+            for (int c = (wave_u - dma_w0) * 1024; c < bytes; c += dma_n * 1024)
                 if (c + lane * 16 < bytes) fa_lds_dma16(src + c + lane * 16, stage + c);
     };
 
     FL_STAMP(8);
-    // [r6] the DMA waves start a few hundred cycles late: a CU takes in ~11 bytes per cycle, so the 40 KB slice is ~3.6k cycles of
-    // its load path -- and whatever is requested at the same moment shares the queue with it.  The agent states, the action and the
-    // delay line (9 KB: what the first phase waits for) are requested by the lower waves in the first ~200 cycles; with the slice
-    // behind them they are back ~3k cycles earlier, and the slice is not needed before the product rows (tools/harness/
-    // flock_phase_prof.hip: stamp 9)
-#ifndef FA_DMA_DELAY
-#define FA_DMA_DELAY 6                                      // s_sleep units of 64 cycles
-#endif
-    if (FA_DMA_DELAY > 0 && prod && wave >= FA_DMA_W0) __builtin_amdgcn_s_sleep(FA_DMA_DELAY);
-    if (prod) stage_slice(1);                               // the slice streams in behind everything below
+    // Issuing is not free either: the CU's load path takes a 1 KB request every ~100 cycles, so the forty requests of a slice keep
+    // their waves busy for ~4k cycles -- in front of the first barrier that held every wave back (stamp 9 at 4.3k cycles, and later
+    // the later the DMA started: profiles/r06_flock_advance_stamps.txt).  The spare waves therefore issue BEHIND that barrier; the
+    // slice lands ~4k cycles into the 9.5k-cycle membership phase.
+    if (prod && !spare) stage_slice(1);                     // (N > 104: no spare wave -- first thing, as in round 5)
     // ---- agent states and the delay line's taps are requested together (the lower eight waves); thread i owns agent i (the
     //      expression tree of integrate_one: bit-exact given the action)
+    // [r6] Behind a SCALAR branch on the wave index: the waits hipcc puts in front of the first use of these loads are then
+    // executed by the loading waves only (with the DMA on the upper eight waves and this section executed by all sixteen, the first
+    // barrier stood at 4.9k cycles -- the slice's arrival -- instead of the states' ~2k: tools/harness/flock_phase_prof.hip stamp 9).
+    if (wave_u < FA_LOAD_WAVES) {
     double px = 0.0, py = 0.0, vx = 0.0, vy = 0.0, cx = 0.0, cy = 0.0;
     if (tid < N) {
         const double2 pa = *reinterpret_cast<const double2*>(xb + tid * 4), pb = *reinterpret_cast<const double2*>(xb + tid * 4 + 2);
@@ -590,7 +594,7 @@ void flock_advance_kernel(const double* __restrict__ x, double* __restrict__ xo,
         cx = pc.x; cy = pc.y;
     }
     const long tap = 6L * N, per = (long)K * tap;
-    constexpr int XT_ = 64 * FA_DMA_W0;                     // threads that copy the delay line: the waves below the DMA waves
+    constexpr int XT_ = 64 * FA_LOAD_WAVES;                 // threads that copy the delay line
     constexpr int XP = FA_DELAY_ELEMS / XT_;                // elements per thread: (K - 1) 6 N <= 4 * 6 * 128 (checked by the dispatch)
     float xpv[XP];
 #pragma unroll
@@ -611,8 +615,10 @@ void flock_advance_kernel(const double* __restrict__ x, double* __restrict__ xo,
             if (tid < XT_ && e < per) o.Xn[(long)b * per + e] = xpv[r];
         }
     }
+    }
     __syncthreads();
     FL_STAMP(9);
+    if (prod && spare) stage_slice(1);                      // waves 13, 14: under the membership phase of waves 0 .. 12
     FL_STAMP(10);
     // ---- membership + features: eight lanes per row, lane `piece` owns candidates j0 .. j0 + jh - 1 (the row-tiled kernel's
     //      pieces).  Meanwhile the last wave forms the episode sums in the reduction tree of the row-tiled kernel (256 threads

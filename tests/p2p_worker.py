@@ -153,7 +153,7 @@ def scenario_train(comm, dev, rk, world):
 
 
 def scenario_dp_timeout(comm, dev, rk, world):
-    """One rank falls behind INSIDE a data-parallel round (begin_updates .. end_updates) by more than the exchange's timeout.
+    """One rank falls behind INSIDE a data-parallel round (begin_updates .. end_updates) by more than the exchange's timeout (400 ms here).
     The early rank's poll gives up (Adam skipped for what it missed), the late rank finds every packet waiting and steps:
     only one of them sees an error locally.  end_updates() must raise on EVERY rank, with weights, both Adam moments and the
     step counter (device and host) back at the round's start and identical across ranks; after reset_exchange() the next
@@ -177,19 +177,20 @@ def scenario_dp_timeout(comm, dev, rk, world):
     G = G.to(dev)
     Y = torch.randn((B, 1, 2, N), generator=gen).to(dev)
     o = learner.actor_optim
-    # a good round first (also captures the update graph outside the timed part)
+    # the exchange's timeout is a kernel argument: it must be set BEFORE the update graph is captured (first update below)
+    _lib.lib().mgp_p2p_set_timeout_ms(learner.p2p.handle, 400)
+    # a good round first (captures the update graph)
     learner.begin_updates()
     for _ in range(2):
         learner.gradient_step_tensors(X, G, Y, sync=False)
     learner.end_updates()
     start = (o.flat.clone(), o.m.clone(), o.v.clone(), int(o.step_dev.item()), o.step_count)
     assert start[3] == 2 and start[4] == 2
-    _lib.lib().mgp_p2p_set_timeout_ms(learner.p2p.handle, 150)
     learner.begin_updates()
     learner.gradient_step_tensors(X, G, Y, sync=False)
     torch.cuda.synchronize()
     if rk == world - 1:
-        time.sleep(1.0)                                          # the last rank is late: its peers' polls give up meanwhile
+        time.sleep(2.0)                                          # the last rank is late: its peers' polls give up meanwhile
     for _ in range(2):
         learner.gradient_step_tensors(X, G, Y, sync=False)
     torch.cuda.synchronize()

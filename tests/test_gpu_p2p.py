@@ -77,7 +77,7 @@ def test_missing_peer_is_a_status_not_a_hang():
 
 @pytest.mark.parametrize('world', [2, 3])
 def test_timeout_inside_a_data_parallel_round_rolls_every_rank_back(world):
-    """DAGGER.begin_updates() .. end_updates() with one rank a second late in the middle of the round (exchange timeout 150 ms):
+    """DAGGER.begin_updates() .. end_updates() with one rank two seconds late in the middle of the round (exchange timeout 400 ms):
     the early ranks see the timeout, the late one does not -- end_updates() raises on ALL of them with weights, Adam moments
     and step counters restored to the round's start (identical across ranks), and after reset_exchange() the next round runs."""
     r = run_ranks('dp_timeout', world=world)

@@ -12,6 +12,17 @@ import sqlite3
 import sys
 
 
+def _source_hash():
+    """Hash of the kernel sources the profiled library was built from (bench.py says whether the numbers are this build's)."""
+    try:
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from multiagent_gnn_policies_amd import build
+        return build.source_hash()
+    except Exception:
+        return None
+
+
 def main(path):
     import sys
     db = sqlite3.connect(path)
@@ -74,6 +85,7 @@ def main(path):
         out['_meta'] = {"units": "fractions of SQ_WAVE_CYCLES (wave residency); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / "
                                  "(4 SIMDs x SQ_BUSY_CU_CYCLES); valu_issue = SQ_INSTS_VALU x 4 cycles / (4 SIMDs x SQ_BUSY_CU_CYCLES), a lower bound on "
                                  "the vector pipes' busy share", "probe_T": __import__('os').environ.get('PROBE_T', '1000'),
+                        "source_hash": _source_hash(),
                         # tools/pmc_probe.py: one 3-step launch, then five of PROBE_T steps, B = PROBE_B episodes: the average launch
                         # of the pass covers this many episode-steps (bench.py: VALU instructions per episode-step)
                         "rollout_episode_steps_per_launch": int(__import__('os').environ.get('PROBE_B', '256')) *
