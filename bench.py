@@ -553,6 +553,13 @@ def main():
     out = None
     if rank == 0:
         total_eps = B * world
+        # which build of the resident kernel the library's dispatch picked for this episode count (csrc/rollout.hip: ro_use_t512)
+        cus = torch.cuda.get_device_properties(device).multi_processor_count
+        forced = os.environ.get('MGP_RO_T512', '')
+        t512 = (forced != '0') if forced else (B > cus)
+        t512 = t512 and N == 100 and K == 3 and hidden == [32, 32]
+        resident_build = ("512 threads, two episodes per CU (rollout_t512.hip: %d episodes > %d CUs)" % (B, cus) if t512 else
+                          "1024 threads, one episode per CU")
         value = total_eps * N * args.steps / el
         out = {
             "metric": "agent-steps/sec, %s N=%d K=%d" % (args.env, N, K),
@@ -571,7 +578,8 @@ def main():
                                      "from and left as the factored hand-over: membership bits + row weights of the last K - 1 networks).  "
                                      "The dense delay_gso slices of the contract are DEFERRED (MGP_RO_SKIP_DENSE): rebuilt on first read "
                                      "(mgp_rollout_carry_to_dense, ~37 us per 256 episodes), i.e. outside the timed region; "
-                                     "paths.resident_dense_exit times the same steps with the slices rebuilt inside every launch" % args.steps)
+                                     "paths.resident_dense_exit times the same steps with the slices rebuilt inside every launch.  "
+                                     "Workgroups: %s" % (args.steps, resident_build))
                                     if resident else
                                     "two_launch: mgp_actor_fwd + mgp_flock_step_advance per step (HIP graph)",
                        "step_path_rule": "by shape: resident if mgp_rollout_supported (N <= 256, widths <= 64; one hidden layer up to 128 wide at N <= 128), factored if "

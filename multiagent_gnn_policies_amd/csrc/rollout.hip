@@ -40,13 +40,24 @@
 // This translation unit is built with -ffp-contract=off (fp64 spec arithmetic); fp32 fused multiply-adds are explicit.
 #include <hip/hip_ext.h>
 #include "rollout_common.h"
-#if !defined(MGP_RO_WIDE) && !defined(MGP_RO_X128)
+#if !defined(MGP_RO_WIDE) && !defined(MGP_RO_X128) && !defined(MGP_RO_T512)
 #define MGP_RO_BASE 1                      // the build that owns the public entry points (layer widths <= 32)
 #endif
 
 namespace {
 
+// [r6] MGP_RO_T512 (rollout_t512.hip): the headline instantiation once more as a 512-thread workgroup of <= 80 KB, so that a CU
+// holds TWO episodes when a launch has more episodes than the device has CUs.  A step is a chain of dependent phases of one
+// episode (vector pipes about half busy, waves parked 57 % of their cycles); a second, independent chain on the
+// CU fills those gaps.  Eight waves: the policy phase as before (7 tile waves), S1 in two row passes of 64 rows, S2's two
+// groups one after the other on the same seven waves, reward + Verlet helper on wave 7.  Every sum keeps its order: the bits
+// are the 1024-thread build's.
+#ifdef MGP_RO_T512
+constexpr int RO_THREADS = 512;
+#else
 constexpr int RO_THREADS = 1024;
+#endif
+constexpr bool RO_T512 = RO_THREADS == 512;
 constexpr int RO_WAVES = RO_THREADS / 64;
 #ifndef RO_S1L
 #define RO_S1L 8                          // (4 lanes per row -- 7 waves instead of 13, 25 candidates each -- measured 1 % slower)
@@ -242,7 +253,9 @@ __host__ __device__ constexpr RoOff ro_offsets(int N, int K)
     c.wrow = ro_take(off, H * N * 4);
     c.uact = ro_take(off, 2 * N * 4);
     c.xt = ro_take(off, K * Np * 8 * 4);
-    c.vb = ro_take(off, 2 * (K > 2 ? K - 2 : 0) * Np * 8 * 4);
+    // (K = 3 uses parity 1 of the ping-pong only -- stage 1 writes it, the last stage reads it --: the T512 build, which must stay
+    //  under 80 KB, allocates that half alone and biases the pointer)
+    c.vb = ro_take(off, ((RO_T512 && K == 3) ? 1 : 2) * (K > 2 ? K - 2 : 0) * Np * 8 * 4);
     c.act = ro_take(off, ((N + 15) & ~15) * RO_CS * 4);
     c.rlist = ro_take(off, H * N * ro_list_stride(N));
     c.rcnt = ro_take(off, H * N * 4);
@@ -267,7 +280,7 @@ __host__ __device__ constexpr RoOff ro_offsets(int N, int K)
 // (four 64-wide layers at N = 100: cfg/hidden_size.cfg [4, 64]).
 // VL: Verlet candidate lists in S1 (above; the launcher selects it when the lists fit the LDS next to the weight image).
 template <int CN, int CK, bool FD, bool CL, bool CM = false, bool WBF = RO_BF16_CHAIN, bool VL = false>
-__global__ __launch_bounds__(RO_THREADS)
+__global__ __launch_bounds__(RO_THREADS, RO_T512 ? 4 : 1)
 void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __restrict__ Xd, float* __restrict__ action,
                     double* __restrict__ rewards, RoParams P, MgpFlockParams p, int K_arg, int N_arg, int T,
                     unsigned long long dimsA, unsigned int dims8, unsigned long long woffA, unsigned long long woffB,
@@ -288,7 +301,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     float* wrow = reinterpret_cast<float*>(smraw + cv.wrow);
     float* uact = reinterpret_cast<float*>(smraw + cv.uact);
     float* XT = reinterpret_cast<float*>(smraw + cv.xt);
-    float* VB = reinterpret_cast<float*>(smraw + cv.vb);
+    float* VB = reinterpret_cast<float*>(smraw + cv.vb) - ((RO_T512 && K == 3) ? (K - 2) * ((N + 3) & ~3) * 8 : 0);
     float* wl = reinterpret_cast<float*>(smraw + cv.wl);
     float* act = reinterpret_cast<float*>(smraw + cv.act);
     unsigned char* rlist = smraw + cv.rlist;
@@ -324,6 +337,9 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     // first barrier: 3.3 us from kernel begin to the first step, tools/harness/ro_launch_prof.hip.)
     constexpr int XTP = 4;                                    // delay-line elements per thread (K 6 N <= 5 * 6 * 128 = 3840)
     constexpr int CYP = 2;                                    // (network, row, quarter) items per thread (H N 4 <= 2048)
+    static_assert(!RO_T512 || (CN == 100 && CK == 3), "the 512-thread build is instantiated for the headline (N, K) only");
+    static_assert(!RO_T512 || (CK * 6 * CN <= XTP * RO_THREADS && 2 * CN * 4 <= CYP * RO_THREADS && 4 * ((CN + 15) & ~15) <= RO_THREADS),
+                  "thread maps of the 512-thread build");
     const int nXT = K * 6 * N;
     float xtv[XTP];
 #pragma unroll
@@ -936,8 +952,12 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         {   // ---- phase S1
         const int tid = ro_fresh_tid_ph(2);
         const int lane = tid & 63, wave = tid >> 6;
-        const int pi = tid / RO_PIECES, piece = tid % RO_PIECES;  // membership: agent row pi, piece of the row's candidates
-        if (wave == RO_WAVES - 1 && (rewards != nullptr || CL)) {
+        const int piece = tid % RO_PIECES;                    // membership: piece of the row's candidates
+        // (T512: 64 rows per pass, two passes at N = 100; the reward wave sums the velocities in the pass it has no rows in)
+        constexpr int S1_ROWS = RO_THREADS / RO_PIECES;
+        for (int rb = 0; rb < (RO_T512 ? N : 1); rb += S1_ROWS) {
+        const int pi = rb + tid / RO_PIECES;                  // agent row
+        if (wave == RO_WAVES - 1 && (rewards != nullptr || CL) && (!RO_T512 || rb + S1_ROWS >= N)) {
             double sx = 0.0, sy = 0.0;
             for (int i = lane; i < N; i += 64) { sx += svx[i]; sy += svy[i]; }
             sx = wave_sum_d(sx); sy = wave_sum_d(sy);
@@ -1147,6 +1167,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             }
         }
         }
+        }
         __syncthreads();
         RO_STAMP(7);
         // -------------------------------------------------------------- S2: fp64 feature terms  ||  gather stage 1 of step t + 1
@@ -1163,7 +1184,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         const int fr = tid >> 2, fq = tid & 3;                //   features: agent row fr, lane fq of 4
         if (tid == RO_THREADS - 2) { cref[0] = spx[0]; cref[1] = spy[0]; }   // next step's reference point (any point is valid)
         const int grp = 4 * ((N + 15) & ~15);                 // threads per group
-        const int vl_wave = (N <= 112) ? RO_WAVES - 2 : RO_WAVES - 1;   // the wave that keeps the Verlet books (VL builds)
+        const int vl_wave = (N <= 112 && !RO_T512) ? RO_WAVES - 2 : RO_WAVES - 1;   // the wave that keeps the Verlet books (VL builds)
         if (wave == RO_WAVES - 1 && rewards != nullptr) {     // second half of the reward (velocities change in phase C only)
             double dv = 0.0;
             for (int i = lane; i < N; i += 64) {
@@ -1282,7 +1303,8 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             if (blockIdx.x < 4096 && lane == 0) atomicAdd(&mgp_ro_vstat[blockIdx.x * 4 + next], 1u);
 #endif
         }
-        const int gtid = tid - grp;                           // (the groups swapped -- gather on the older waves -- measured the same)
+        // (T512: one group of threads runs the feature pass, then the gather stage -- they are independent of each other)
+        const int gtid = RO_T512 ? tid : tid - grp;           // (the groups swapped -- gather on the older waves -- measured the same)
         if (tid < grp) {
             double f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0;
             int cnt = 0;
@@ -1365,7 +1387,8 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 y0[rpos(3 * K)] = (float)f3; y0[rpos(4 * K)] = (float)f4; y0[rpos(5 * K)] = (float)f5;
             }
             RO_STAMP(22);
-        } else if (do_s1 && gtid >= 0 && gtid < grp) {
+        }
+        if (do_s1 && gtid >= 0 && gtid < grp && (RO_T512 || tid >= grp)) {
 #if RO_S2_PRIO
             // the gather group is dispatched behind the feature group and, as the younger half of every SIMD, ends the phase 0.5k
             // cycles after it: raised priority hands that delay to the feature waves
@@ -2200,7 +2223,15 @@ int launch_rollout_big(double* x, float* G, float* Xd, float* action, double* re
 // public entry points and forwards the shapes only the wide build covers.
 // Build levels: 0 = this file as is (public entry points), 1 = rollout_wide.hip, 2 = rollout_w128.hip (ONE hidden layer up to
 // 128 wide: cfg/hidden_size.cfg:58).  A level forwards the shapes it does not cover to the next one.
-#if defined(MGP_RO_F32REF)
+#if defined(MGP_RO_T512)
+// rollout_t512.hip: the headline instantiation as 512-thread workgroups (two episodes per CU); reached from the base build's
+// dispatch when a launch has more episodes than the device has CUs; library-internal entry points, nothing forwarded
+#define MGP_RO_SUPPORTED mgp_rollout_t512_supported_
+#define MGP_RO_STEPS_EX mgp_rollout_t512_steps_ex_
+#define MGP_RO_COLLECT mgp_rollout_t512_collect_
+#define MGP_RO_IMAGE_FLOATS mgp_rollout_t512_image_floats_
+#define MGP_RO_IMAGE mgp_rollout_t512_image_
+#elif defined(MGP_RO_F32REF)
 // rollout_f32ref.hip: this build once more with the hidden layers on fp32 MFMA 16x16x4 (MGP_RO_BF16 = 0) -- the arithmetic the
 // split-bf16 layers stand in for; entry points of their own (include/mgp.h), nothing forwarded
 #define MGP_RO_SUPPORTED mgp_rollout_f32ref_supported
@@ -2289,6 +2320,35 @@ extern "C" int MGP_RO_IMAGE(const float* const* W, const float* const* b, const 
     return mgp_launch_status();
 }
 
+#if defined(MGP_RO_BASE) && !defined(MGP_RO_F32REF)
+extern "C" int mgp_rollout_t512_steps_ex_(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
+                                          const int* dims, int n_layers, float* action, double* rewards,
+                                          const MgpFlockParams* p, int B, int K, int N, int T, const float* image, void* carry,
+                                          int flags, void* stream);
+extern "C" int mgp_rollout_t512_collect_(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
+                                         const int* dims, int n_layers, double* rewards, const MgpFlockParams* p, int B, int K, int N,
+                                         int T, const float* image, void* carry, int flags, const MgpCollect* cl, void* stream);
+namespace {
+// Two episodes per CU (rollout_t512.hip) pay when a launch has more episodes than the device has CUs: one 1024-thread workgroup
+// fills a CU, so beyond that the launch time is linear in the episode count, while two 512-thread workgroups overlap one
+// episode's dependent phases with the other's.  MGP_RO_T512 = 0 / 1 forces the choice (tests, A/B).
+bool ro_use_t512(int B)
+{
+    const char* env = getenv("MGP_RO_T512");                 // (read on every launch: tests switch builds inside one process)
+    if (env != nullptr && env[0] != 0) return atoi(env) != 0;
+    static thread_local int cus_dev = -1, cus = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (dev != cus_dev) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+        cus = v; cus_dev = dev;
+    }
+    return cus > 0 && B > cus;
+}
+}  // namespace
+#endif
+
 namespace {
 int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* const* b,
            const int* dims, int n_layers, float* action, double* rewards,
@@ -2355,6 +2415,17 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int wt = P.wtot;
     const bool fade = p->link_drop != 0u;   // FlockingStochastic-v0: the generic builds carry the fade hash, the others do not
+#ifdef MGP_RO_T512
+    // this build is one instantiation: the reference's policy shape at the headline (N, K), plain and collecting
+    if (!(N == 100 && K == 3 && !fade && n_layers == 3 && dims[1] == 32 && dims[2] == 32 && P.woff[1] == 2 * 64 * RO_WFS + 32 &&
+          P.woff[2] == 2 * (2 * 64 * RO_WFS + 32)) || !(RO_VERLET != 0))
+        return MGP_EUNSUPPORTED;
+    if (cl != nullptr)
+        return launch_rollout<100, 3, false, true, true, RO_BF16_CHAIN, true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB,
+                                                                              n_layers, lds, st, image, wt, carry, flags, cl);
+    return launch_rollout<100, 3, false, false, true, RO_BF16_CHAIN, true>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB,
+                                                                           n_layers, lds, st, image, wt, carry, flags, cl);
+#else
 #define RB_LAUNCH(FD_, CL_) launch_rollout_big<FD_, CL_>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers, lds, st, image, wt, carry, flags, cl)
 #ifndef MGP_RO_X128
     if (N > RO_MAXN) {
@@ -2390,9 +2461,16 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
     if (cl != nullptr) {               // the data-collection builds (DAGGER rollouts)
 #ifdef MGP_RO_BASE
         if (N == 100 && K == 3 && !fade && n_layers == 3 && dims[1] == 32 && dims[2] == 32 && P.woff[1] == 2 * 64 * RO_WFS + 32 &&
-            P.woff[2] == 2 * (2 * 64 * RO_WFS + 32))                                  // cfg/dagger.cfg, policy shape compiled in
+            P.woff[2] == 2 * (2 * 64 * RO_WFS + 32)) {                                // cfg/dagger.cfg, policy shape compiled in
+#ifndef MGP_RO_F32REF
+            if (RO_VERLET != 0 && ro_use_t512(B)) {
+                const int rc = mgp_rollout_t512_collect_(x, G, Xd, W, b, dims, n_layers, rewards, p, B, K, N, T, image, carry_v, flags, cl, stream);
+                if (rc != MGP_EUNSUPPORTED) return rc;
+            }
+#endif
             return launch_rollout<100, 3, false, true, true, RO_BF16_CHAIN, RO_VERLET != 0>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB,
                                                              n_layers, lds, st, image, wt, carry, flags, cl);
+        }
 #endif
         if (N == 100 && K == 3 && !fade && vfit) return RO_LAUNCH(100, 3, false, true);
         return fade ? RO_LAUNCH(0, 0, true, true) : RO_LAUNCH(0, 0, false, true);
@@ -2400,9 +2478,16 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
 #ifdef MGP_RO_BASE
     // the reference's own policy shape at the headline (N, K): everything compile-time (cfg/dagger.cfg; BASELINE.json configs[0..1])
     if (N == 100 && K == 3 && !fade && n_layers == 3 && dims[1] == 32 && dims[2] == 32 && P.woff[1] == 2 * 64 * RO_WFS + 32 &&
-        P.woff[2] == 2 * (2 * 64 * RO_WFS + 32))
+        P.woff[2] == 2 * (2 * 64 * RO_WFS + 32)) {
+#ifndef MGP_RO_F32REF
+        if (RO_VERLET != 0 && ro_use_t512(B)) {
+            const int rc = mgp_rollout_t512_steps_ex_(x, G, Xd, W, b, dims, n_layers, action, rewards, p, B, K, N, T, image, carry_v, flags, stream);
+            if (rc != MGP_EUNSUPPORTED) return rc;
+        }
+#endif
         return launch_rollout<100, 3, false, false, true, RO_BF16_CHAIN, RO_VERLET != 0>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB, n_layers,
                                                           lds, st, image, wt, carry, flags, cl);
+    }
 #endif
     if (N == 100 && K == 3 && !fade && vfit)   // the headline (N, K) with any covered policy, every build: compile-time addresses
         return RO_LAUNCH(100, 3, false, false);
@@ -2418,6 +2503,7 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
 #undef RO_LAUNCH
 #undef RO_LAUNCH_
 #undef RO_LAUNCH__
+#endif
 }
 }  // namespace
 

@@ -215,6 +215,29 @@ def test_collect_chunking_is_bit_identical_and_gather_rebuilds_the_states(N, K, 
     assert torch.equal(Y.view(Bt, 2, N), mem.label.view(-1, 2, N)[idx])
 
 
+def test_collecting_build_two_episodes_per_cu_is_bit_identical(monkeypatch):
+    """[r6] mgp_rollout_collect on 512-thread workgroups (csrc/rollout_t512.hip: selected when a launch has more lanes than the
+    device has CUs, forced here with MGP_RO_T512): state, expert hand-over and every filed frame -- features, membership bits,
+    labels, ages -- equal the 1024-thread build's bit for bit, one launch and chunked."""
+    B, T, seed = 3, 23, 99
+    beta = torch.tensor([0.5, 0.7, 0.2], device='cuda')
+    episode = torch.tensor([3, 4, 5], dtype=torch.int32, device='cuda')
+    runs = []
+    for build, chunks in (('0', [T]), ('1', [T]), ('1', [1, 9, 13])):
+        monkeypatch.setenv('MGP_RO_T512', build)
+        op, actor, sim, st, mem = _setup(100, 3, (32, 32), B, {}, ring_capacity=B * 16)     # ring shorter than the run: wraps
+        expert_io = sim.controller().permute(0, 2, 1).contiguous()
+        t0 = 0
+        for c in chunks:
+            _collect(actor, sim, st, mem, expert_io, beta, episode, seed, age0=t0, T=c)
+            t0 += c
+        runs.append((sim.x.clone(), st.delay_state.clone(), st.delay_gso.clone(), expert_io.clone(), mem.feat.clone(),
+                     mem.bits.clone(), mem.label.clone(), mem.age.clone()))
+    for other in runs[1:]:
+        for a, b_ in zip(runs[0], other):
+            assert torch.equal(a, b_)
+
+
 @pytest.mark.parametrize('aggregated', [True, False], ids=['aggregated', 'dense'])
 def test_frame_updates_many_per_graph_equal_one_per_graph(aggregated):
     """A round of updates replayed 32-per-graph (device cursor, device step counter) is bit-identical to the same round replayed

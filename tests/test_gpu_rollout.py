@@ -258,6 +258,51 @@ def test_rollout_candidate_lists_keep_the_exact_network(K):
         assert K == 1 or np.array_equal(outs[0][5][b], h["network"].astype(np.float32)), b   # (K = 1 keeps no operator slice)
 
 
+def test_two_episodes_per_cu_build_is_bit_identical(monkeypatch):
+    """[r6] Launches with more episodes than the device has CUs run the headline shape as 512-thread workgroups, two episodes per
+    CU (csrc/rollout_t512.hip; MGP_RO_T512 = 0 / 1 forces the choice): S1 in two row passes, S2's groups one after the other,
+    eight waves.  Every sum keeps its order, so the build must reproduce the 1024-thread build BIT FOR BIT -- on the stress
+    states of the candidate-list test (escaper, clump beyond the list capacity, ten times the reset speed), dense entry and carry
+    entry, one launch and chunked, lazy and in-launch dense slices."""
+    from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout
+    N, K, B, T = 100, 3, 5, 41
+    outs = {}
+    for build in ('0', '1'):
+        monkeypatch.setenv('MGP_RO_T512', build)
+        for chunks, lazy in (([T], True), ([1, 7, 33], True), ([20, 21], False)):
+            rs, op, actor, sim, st = _make(N, K, (32, 32), B, seed=21)
+            rs = np.random.RandomState(5)
+            xs = np.stack([ofl.reset(rs, ofl.FlockParams(n_agents=N, init_mode='disc')) for _ in range(B)])
+            xs[1, 7, 0:2] = (9.0, 0.5); xs[1, 7, 2:4] = (-25.0, 0.3)
+            ang = rs.uniform(0, 2 * np.pi, 80); rad = 0.45 * np.sqrt(rs.uniform(0, 1, 80))
+            xs[2, :80, 0] = rad * np.cos(ang); xs[2, :80, 1] = rad * np.sin(ang)
+            xs[3, :, 2:4] *= 10.0
+            sim.set_state(xs)
+            st = type(st)('cuda', B, K, 6, N)
+            st.push(sim.network, sim.features)
+            if not lazy:
+                st._carry_valid = False                           # dense entry: the first K - 1 steps read the caller's slices
+            rewards = torch.zeros((B, T), device='cuda', dtype=torch.float64)
+            action = torch.zeros((B, 1, 2, N), device='cuda')
+            t0 = 0
+            for c in chunks:
+                rw = torch.zeros((B, c), device='cuda', dtype=torch.float64)
+                assert policy_rollout(actor, sim, st, c, rewards=rw, action=action, lazy_dense=lazy)
+                rewards[:, t0:t0 + c] = rw
+                t0 += c
+            outs[(build, tuple(chunks))] = _snapshot(sim, st) + (action.cpu().numpy().copy(), rewards.cpu().numpy().copy(),
+                                                               sim.network.cpu().numpy())
+    ref = outs[('0', (T,))]
+    assert np.isfinite(ref[0]).all()
+    for key, other in outs.items():
+        if key[1] == (20, 21):
+            continue                                              # (dense entry re-associates the first steps' products: compared below)
+        for name, a, b in zip(('x', 'delay_gso', 'delay_state', 'last action', 'rewards', 'network'), ref, other):
+            assert np.array_equal(a, b), (key, name)
+    for name, a, b in zip(('x', 'delay_gso', 'delay_state', 'last action', 'rewards', 'network'), outs[('0', (20, 21))], outs[('1', (20, 21))]):
+        assert np.array_equal(a, b), ('dense entry', name)
+
+
 def test_resident_plan_equals_policy_rollout():
     """ResidentPlan (the host side of a repeated launch bound once) launches the same kernel with the same arguments."""
     from multiagent_gnn_policies_amd.learner.rollouts import policy_rollout, ResidentPlan

@@ -1,12 +1,12 @@
 """Copy the outputs of tools/regen_profiles.sh (gpurun_out/final/) into profiles/<round>_* (run from the repo root;
-ROUND=r05 by default)."""
+ROUND=r06 by default)."""
 import json
 import os
 import shutil
 import sys
 sys.path.insert(0, ".")
 import os
-O, R = 'gpurun_out/final', os.environ.get('ROUND', 'r05')
+O, R = 'gpurun_out/final', os.environ.get('ROUND', 'r06')
 
 
 def last_json(path):
@@ -71,7 +71,7 @@ from multiagent_gnn_policies_amd import build
 print('hash ok', build.source_hash() == json.load(open('profiles/%s_pmc_traffic.json' % R))['_meta']['source_hash'])
 
 for name in ('dagger_round_1rank.json', 'dagger_round_2ranks_shared_gpu.json', 'p2p_exchange_latency.txt', 'rollout_inst_mix.txt',
-             'agg_forms.txt', 'dagger_update_slots.txt', 'train_phase_stamps.txt', 'stream_floor.txt', 'train_wall.json', 'train_wall_n200_k4.json', 'first_multi_gpu_dry.json', 'pmc_traffic_factored.json', 'pmc_hbm_traffic_factored.txt'):
+             'agg_forms.txt', 'valu_rate.txt', 'valu_rate_pmc.txt', 'two_episodes_per_cu.txt', 'pmc_sq_b2048.txt', 'dagger_update_slots.txt', 'train_phase_stamps.txt', 'stream_floor.txt', 'train_wall.json', 'train_wall_n200_k4.json', 'first_multi_gpu_dry.json', 'pmc_traffic_factored.json', 'pmc_hbm_traffic_factored.txt'):
     if os.path.exists(O + '/' + name):
         shutil.copy(O + '/' + name, 'profiles/%s_%s' % (R, name))
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates every round artefact under profiles/ on the GPU box (run through gpurun from the repo root):
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/regen_profiles.sh > gpurun_out/regen.log 2>&1'
-#   python tools/install_profiles.py          # copies gpurun_out/final/* into profiles/<round>_*  (ROUND=r05)
+#   python tools/install_profiles.py          # copies gpurun_out/final/* into profiles/<round>_*  (ROUND=r06)
 # The harnesses must have been built first (they travel with the snapshot under scratch/):  bash tools/build_harness.sh
 # PMC passes use --pmc with --kernel-trace only (no sys/runtime/hip trace domains).
 set -x
@@ -26,12 +26,12 @@ F=$(find $O/pmc_fetch -name "*results.db" | head -1); W=$(find $O/pmc_write -nam
 F2=$(find $O/pmc_fetch20 -name "*results.db" | head -1); W2=$(find $O/pmc_write20 -name "*results.db" | head -1)
 cd $R
 python tools/pmc_summary.py $F $W $O/pmc_traffic.json 256,100,3 $F2 $W2 20 > $O/pmc_hbm_traffic.txt 2>&1
-cp $O/pmc_traffic.json $R/profiles/${ROUND:-r05}_pmc_traffic.json
+cp $O/pmc_traffic.json $R/profiles/${ROUND:-r06}_pmc_traffic.json
 FF=$(find $O/pmc_fetch_f -name "*results.db" | head -1); WF=$(find $O/pmc_write_f -name "*results.db" | head -1)
 python tools/pmc_summary.py $FF $WF $O/pmc_traffic_factored.json 64,1000,3 > $O/pmc_hbm_traffic_factored.txt 2>&1
-cp $O/pmc_traffic_factored.json $R/profiles/${ROUND:-r05}_pmc_traffic_factored.json
+cp $O/pmc_traffic_factored.json $R/profiles/${ROUND:-r06}_pmc_traffic_factored.json
 python tools/pmc_sq_summary.py $Q $O/pmc_sq.json > $O/pmc_sq.txt 2>&1
-cp $O/pmc_sq.json $R/profiles/${ROUND:-r05}_pmc_sq.json
+cp $O/pmc_sq.json $R/profiles/${ROUND:-r06}_pmc_sq.json
 # 2. bench (traffic / sq now resolved from the files just written): the driver's command line, the default, and under rocprof
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_steps20.json 2> $O/bench_steps20.err
 python bench.py > $O/bench_final.json 2> $O/bench_final.err
@@ -45,12 +45,18 @@ RO_CARRY=1 ./scratch/ro_prof 256 100 3 200 > $O/rollout_phase_stamps.txt 2>&1
 python tools/dump_rollout_state.py /tmp/ro_state5.bin 5 > /dev/null 2>&1
 RO_STATE=/tmp/ro_state5.bin RO_CARRY=1 ./scratch/ro_prof 256 100 3 20 20 >> $O/rollout_phase_stamps.txt 2>&1
 { RO_STATE=/tmp/ro_state5.bin RO_WG_DUMP=$O/rollout_wg_times.txt ./scratch/ro_launch 256 100 3 "1 2 3 5 10 20 40 100" 30; ./scratch/ro_launch 256 100 3 "1 2 5 20" 30; } > $O/rollout_launch_cost.txt 2>&1
-# 3a. [r5] resident kernel A/B (scratch/ro_prof_base = round 4's sources, x0 = this round's with RO_VERLET=0, x1 = the product build) and the
-#     per-episode durations / S1 modes of a 20-step launch with and without the candidate lists
-RO_STAMP_BINS="scratch/ro_prof_x1 scratch/ro_st0" timeout 600 bash tools/gpu/r5_ab.sh > $O/rollout_ab.txt 2>&1
-cp gpurun_out/wg_times_ro_launch_v.txt $O/rollout_wg_times_lists.txt 2>/dev/null
-cp gpurun_out/wg_times_ro_launch_0.txt $O/rollout_wg_times_no_lists.txt 2>/dev/null
-timeout 300 bash tools/gpu/r5_long.sh > $O/rollout_long_launches.txt 2>&1
+# 3a. [r6] what a wave64 vector instruction costs its SIMD, per class (tools/harness/valu_rate.hip) + what SQ_ACTIVE_INST_VALU counts per
+#     instruction (counter pass over the same kernels); the step of the launch's FIRST step (a rebuild step) beside the cheap step above
+(cd $R && ./scratch/valu_rate > $O/valu_rate.txt 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CU_CYCLES --kernel-trace -d $O/pmc_valu -o v -- $R/scratch/valu_rate pmc > $O/valu_rate_pmc.log 2>&1)
+(cd $R && python tools/pmc_sq_summary.py $(find $O/pmc_valu -name "*results.db" | head -1) > $O/valu_rate_pmc.txt 2>&1; rm -rf $O/pmc_valu)
+cd $R
+{ echo "== step 0 of the launch (rebuild step), bench state"; RO_STATE=/tmp/ro_state5.bin RO_CARRY=1 ./scratch/ro_st0 256 100 3 20 20; } >> $O/rollout_phase_stamps.txt 2>&1
+# 3a''. [r6] two episodes per CU (rollout_t512.hip) against one, B = 256 .. 2048, harness + bench.py + DAGGER collection; and the SQ shares
+#       of the resident kernel at 2048 episodes (512-thread workgroups)
+bash tools/gpu/r6_t512.sh > $O/two_episodes_per_cu.txt 2>&1
+(cd /tmp && PROBE_B=2048 PROBE_T=200 PROBE_ROLLOUT_ONLY=1 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU --kernel-trace -d $O/pmc_sq_b2048 -o sq -- python $R/tools/pmc_probe.py > $O/pmc_sq_b2048.log 2>&1)
+python tools/pmc_sq_summary.py $(find $O/pmc_sq_b2048 -name "*results.db" | head -1) > $O/pmc_sq_b2048.txt 2>&1; rm -rf $O/pmc_sq_b2048
 # 3a'. [r5] mgp_flock_step_advance: the one-workgroup-per-episode kernel and the row-tiled one it replaces (tools/harness/flock_phase_prof.hip)
 { for cfg in "256 100" "2048 100" "256 128" "16 100"; do echo "== flock_advance_kernel, B N = $cfg"; ./scratch/fl_prof $cfg | grep -v "stamp [0-7] "; echo "== row-tiled kernel (MGP_FLOCK_ADVANCE_TILED=1), B N = $cfg"; MGP_FLOCK_ADVANCE_TILED=1 ./scratch/fl_prof $cfg | head -2; done; } > $O/flock_advance_stamps.txt 2>&1
 # 3b'. [r5] fused Actor forward at the wide shapes (actor_fwd_wide_kernel; scratch/af_prof = tools/harness/af_phase_prof.hip with the MLP
