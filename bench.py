@@ -10,7 +10,7 @@ all state resident on the GPU, no host round trip.  Up to three implementations 
   resident    mgp_rollout_steps: ALL timed steps in one launch of the episode-resident kernel (one workgroup per
               episode; delay line / agent states / neighbour lists of the last K-1 networks / weights in LDS, the
               aggregation power-iterated along those lists; HBM sees the state on entry and exit).  This is `value`
-              when the shape is covered (N <= 256, widths <= 64; one hidden layer up to 128 wide at N <= 128).
+              when the shape is covered (N <= 256, widths <= 64; one hidden layer up to 128 wide at N <= 128; two at N = 100, K = 3).
   factored    N > 256 only: the same factored state kept in HBM as bit rows / feature rings, K launches per step
               (mgp_sparse_rollout); the dense delay_gso of the contract is rebuilt on first read, outside the timed region.
   two_launch  mgp_actor_fwd + mgp_flock_step_advance per step (dense operator streamed from HBM every step),
@@ -39,7 +39,7 @@ Also reported on the same JSON line:
                 identical (S, X) the kernels consumed, for 16 sampled episodes: {ok, tol, max_abs, max_rel, ...}.
                 A failed gate prints the line with "ok": false and exits with status 3.
 Which implementation is `value` is a function of the SHAPE only (never of --steps): resident where mgp_rollout_supported
-says so (N <= 256, widths <= 64; one hidden layer up to 128 wide at N <= 128), factored for N > 256 where mgp_sparse_policy_supported, else two_launch; config.step_path
+says so (N <= 256, widths <= 64; one hidden layer up to 128 wide at N <= 128; two at N = 100, K = 3), factored for N > 256 where mgp_sparse_policy_supported, else two_launch; config.step_path
 names it and paths.* carries every implementation that was timed.
 """
 import argparse
@@ -582,7 +582,7 @@ def main():
                                      "Workgroups: %s" % (args.steps, resident_build))
                                     if resident else
                                     "two_launch: mgp_actor_fwd + mgp_flock_step_advance per step (HIP graph)",
-                       "step_path_rule": "by shape: resident if mgp_rollout_supported (N <= 256, widths <= 64; one hidden layer up to 128 wide at N <= 128), factored if "
+                       "step_path_rule": "by shape: resident if mgp_rollout_supported (N <= 256, widths <= 64; one hidden layer up to 128 wide at N <= 128; two at N = 100, K = 3), factored if "
                                          "N > 256 and mgp_sparse_policy_supported, else two_launch",
                        "episodes_per_gpu": B, "episodes_total": total_eps, "agents": N, "taps": K,
                        "graph_steps": gs, "weights": ro.weights, "parallelism": "episodes sharded x%d, no "

@@ -40,7 +40,7 @@
 // This translation unit is built with -ffp-contract=off (fp64 spec arithmetic); fp32 fused multiply-adds are explicit.
 #include <hip/hip_ext.h>
 #include "rollout_common.h"
-#if !defined(MGP_RO_WIDE) && !defined(MGP_RO_X128) && !defined(MGP_RO_T512)
+#if !defined(MGP_RO_WIDE) && !defined(MGP_RO_X128) && !defined(MGP_RO_T512) && !defined(MGP_RO_X2)
 #define MGP_RO_BASE 1                      // the build that owns the public entry points (layer widths <= 32)
 #endif
 
@@ -58,6 +58,13 @@ constexpr int RO_THREADS = 512;
 constexpr int RO_THREADS = 1024;
 #endif
 constexpr bool RO_T512 = RO_THREADS == 512;
+// [r6] MGP_RO_X2 (rollout_w128x2.hip): two hidden layers of up to 128 channels (cfg/hidden_size.cfg:81-82) at the headline (N, K):
+// the second layer's K blocks 2 and 3 streamed through one LDS buffer by LDS-DMA (rollout_common.h, RO_X2_*)
+#ifdef MGP_RO_X2
+constexpr bool RO_X2 = true;
+#else
+constexpr bool RO_X2 = false;
+#endif
 constexpr int RO_WAVES = RO_THREADS / 64;
 #ifndef RO_S1L
 #define RO_S1L 8                          // (4 lanes per row -- 7 waves instead of 13, 25 candidates each -- measured 1 % slower)
@@ -255,7 +262,7 @@ __host__ __device__ constexpr RoOff ro_offsets(int N, int K)
     c.xt = ro_take(off, K * Np * 8 * 4);
     // (K = 3 uses parity 1 of the ping-pong only -- stage 1 writes it, the last stage reads it --: the T512 build, which must stay
     //  under 80 KB, allocates that half alone and biases the pointer)
-    c.vb = ro_take(off, ((RO_T512 && K == 3) ? 1 : 2) * (K > 2 ? K - 2 : 0) * Np * 8 * 4);
+    c.vb = ro_take(off, (((RO_T512 || RO_X2) && K == 3) ? 1 : 2) * (K > 2 ? K - 2 : 0) * Np * 8 * 4);
     c.act = ro_take(off, ((N + 15) & ~15) * RO_CS * 4);
     c.rlist = ro_take(off, H * N * ro_list_stride(N));
     c.rcnt = ro_take(off, H * N * 4);
@@ -301,7 +308,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     float* wrow = reinterpret_cast<float*>(smraw + cv.wrow);
     float* uact = reinterpret_cast<float*>(smraw + cv.uact);
     float* XT = reinterpret_cast<float*>(smraw + cv.xt);
-    float* VB = reinterpret_cast<float*>(smraw + cv.vb) - ((RO_T512 && K == 3) ? (K - 2) * ((N + 3) & ~3) * 8 : 0);
+    float* VB = reinterpret_cast<float*>(smraw + cv.vb) - (((RO_T512 || RO_X2) && K == 3) ? (K - 2) * ((N + 3) & ~3) * 8 : 0);
     float* wl = reinterpret_cast<float*>(smraw + cv.wl);
     float* act = reinterpret_cast<float*>(smraw + cv.act);
     unsigned char* rlist = smraw + cv.rlist;
@@ -374,7 +381,20 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     // weights in MFMA A-fragment order (see actor_fused.hip): wfrag[mt][lane][RO_WFS], lane = (c & 3) * 16 + (o & 15),
     // slot s = c >> 2, zero padded; then the bias of the layer's MT*16 rows.  A caller that launches repeatedly with the
     // same weights passes the image prebuilt (mgp_rollout_image: the same elements, computed once): a flat 16-byte copy.
-    if (image != nullptr) {
+    // X2: LDS = [layer 0][layer-1 blocks 0, 1][stream buffer <- block 2][layer-1 bias][output layer]; the image in HBM holds
+    // [layer 0][blocks 0 .. 3][bias][output layer]: one flat copy up to and including block 2, one of what lies behind block 3
+    float* x2_b0 = wl + RO_X2_L0;                             // (X2 builds only)
+    float* x2_buf = x2_b0 + 2 * RO_X2_BLK;
+    float* x2_bias1 = x2_buf + RO_X2_BLK;
+    float* x2_out = x2_bias1 + 128;
+    const float* x2_img_b2 = image + RO_X2_L0 + 2 * RO_X2_BLK;
+    if (RO_X2) {
+        const float4* src4 = reinterpret_cast<const float4*>(image);
+        float4* dst4 = reinterpret_cast<float4*>(wl);
+        constexpr int HEAD4 = (RO_X2_L0 + 3 * RO_X2_BLK) / 4, TAIL4 = (128 + RO_X2_OUT) / 4;
+        for (int e = tid; e < HEAD4; e += RO_THREADS) dst4[e] = src4[e];
+        for (int e = tid; e < TAIL4; e += RO_THREADS) dst4[HEAD4 + e] = src4[HEAD4 + RO_X2_BLK / 4 + e];
+    } else if (image != nullptr) {
         const float4* src4 = reinterpret_cast<const float4*>(image);
         float4* dst4 = reinterpret_cast<float4*>(wl);
         for (int e = tid; e < image_floats / 4; e += RO_THREADS) dst4[e] = src4[e];
@@ -776,8 +796,46 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) zc[a_][rr] = 0.f;
             int mtp = 0;
+            if constexpr (RO_X2) {
+                // layer 0 (18 -> 128: eight m-tiles on the aggregation tile), then layer 1 (128 -> 128) K block by K block on the
+                // accumulator registers: block kb multiplies the first layer's m-tiles 2 kb, 2 kb + 1 (this lane's eight values of
+                // its k-group), split into three bf16 pieces on the fly.  Order 2, 0, 1, 3: block 2 sits in the stream buffer when
+                // the phase starts; behind barrier X1 (every tile wave is through with it) waves 14 / 15 stream block 3 into the
+                // buffer while blocks 0 and 1 are multiplied from their resident copies; barrier X2 stands before its first use.
+                float fb[RO_KS];
+                const float4* pb = reinterpret_cast<const float4*>(act + col * RO_CS + lq * RO_KS);
 #pragma unroll
-            for (int l = 0; l < (CM ? 2 : n_layers - 1); ++l) {
+                for (int i = 0; i < RO_KS / 4; ++i) { const float4 tq = pb[i]; fb[4 * i] = tq.x; fb[4 * i + 1] = tq.y; fb[4 * i + 2] = tq.z; fb[4 * i + 3] = tq.w; }
+                ro_layer_bf16<8, true>(fb, wl + lane * RO_WFS, wl + 8 * 64 * RO_WFS + lq * 4, zc, 1);
+                RO_STAMP(12);
+                f32x4 acc[8];
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    const float4 bv = *reinterpret_cast<const float4*>(x2_bias1 + mt * 16 + lq * 4);
+                    acc[mt] = f32x4{bv.x, bv.y, bv.z, bv.w};
+                }
+#define RO_X2_BLOCK(KB_, BASE_) do { \
+                    const float xk[8] = {zc[2 * (KB_)][0], zc[2 * (KB_)][1], zc[2 * (KB_)][2], zc[2 * (KB_)][3], \
+                                         zc[2 * (KB_) + 1][0], zc[2 * (KB_) + 1][1], zc[2 * (KB_) + 1][2], zc[2 * (KB_) + 1][3]}; \
+                    ro_bf16x8 b1_, b2_, b3_; \
+                    ro_split3(xk, b1_, b2_, b3_); \
+                    ro_x2_block((BASE_) + lane * 12, b1_, b2_, b3_, acc); } while (0)
+                RO_X2_BLOCK(2, x2_buf);
+                __syncthreads();                              // X1
+                RO_X2_BLOCK(0, x2_b0);
+                RO_X2_BLOCK(1, x2_b0 + RO_X2_BLK);
+                __syncthreads();                              // X2
+                RO_X2_BLOCK(3, x2_buf);
+#undef RO_X2_BLOCK
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) zc[mt][rr] = tanh_fast(acc[mt][rr]);
+                mtp = 8;
+                RO_STAMP(13);
+            }
+#pragma unroll
+            for (int l = 0; l < (RO_X2 ? 0 : (CM ? 2 : n_layers - 1)); ++l) {
                 const int cout = CM ? 32 : ro_dim(dimsA, dims8, l + 1);
                 const int MT = CM ? 2 : ro_mt(cout);
                 // (CM: a 32-wide hidden layer's block is 2 m-tiles of fragments + 32 bias values)
@@ -820,7 +878,8 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
 #endif
             // ---------------------------------------------------------- C: output layer + integration, same wave, no barrier
             const int lo_ = n_layers - 1;
-            const float* w2 = wl + (CM ? 2 * (2 * 64 * WFS + 32) : (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull));
+            const float* w2 = RO_X2 ? x2_out
+                                    : wl + (CM ? 2 * (2 * 64 * WFS + 32) : (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull));
             if (CM || n_layers > 1) {
                 // The 2-wide output layer on the accumulator registers of the last hidden layer: lane (li, lq) holds channels
                 // c = 16 a + 4 lq + rr of column li, whose weight pairs (W[0][c], W[1][c]) are two 16-byte reads per m-tile;
@@ -906,6 +965,17 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 }
             }
         } else {
+            if (RO_X2) {
+                __syncthreads();                              // X1: every tile wave is through with block 2
+                const int wu = __builtin_amdgcn_readfirstlane(wave);
+                if (wu >= RO_WAVES - 2) {                     // waves 14, 15: 12 requests of 1 KB each
+                    const unsigned char* src = reinterpret_cast<const unsigned char*>(x2_img_b2 + RO_X2_BLK);
+                    unsigned char* dst = reinterpret_cast<unsigned char*>(x2_buf);
+                    for (int c = (wu - (RO_WAVES - 2)) * 1024; c < RO_X2_BLK * 4; c += 2048) ro_lds_dma16(src + c + lane * 16, dst + c);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();                              // X2: block 3 is in the buffer
+            }
             if (VL && __builtin_amdgcn_readfirstlane(vflag[0]) == RO_VM_REBUILD) {
                 // S1 of this step rebuilds the candidate lists: the waves without columns pad every row with the sentinel index
                 const int it0 = tid - NT * 64, nth = RO_THREADS - NT * 64;
@@ -944,6 +1014,17 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         const int vmode_raw = VL ? vflag[0] : (int)RO_VM_FULL;
         __syncthreads();
         RO_STAMP(3);
+        if (RO_X2 && t + 1 < T) {
+            // the next step's block 2 -> stream buffer (every tile wave is through with block 3), by the two waves that have least to
+            // do in the simulator phases; waited for in front of the step's last barrier
+            const int wu = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            if (wu >= RO_WAVES - 2) {
+                const unsigned char* src = reinterpret_cast<const unsigned char*>(x2_img_b2);
+                unsigned char* dst = reinterpret_cast<unsigned char*>(x2_buf);
+                const int ln = (int)(threadIdx.x & 63);
+                for (int c = (wu - (RO_WAVES - 2)) * 1024; c < RO_X2_BLK * 4; c += 2048) ro_lds_dma16(src + c + ln * 16, dst + c);
+            }
+        }
         // -------------------------------------------------------------- S1: membership bits + neighbour lists of the new state
         // reward (spec section 4: two-pass population variance of the velocities), one wave, split around the S1 barrier so
         // that its serial fp64 chain is not what the barrier waits for: the sums here, the variance pass in S2
@@ -1402,6 +1483,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             RO_STAMP(23);
         }
         }
+        if (RO_X2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the streamed block of the next step has landed)
         __syncthreads();
         RO_STAMP(4);
         cur = curn;
@@ -2076,6 +2158,22 @@ bool make_carve(const int* dims, int n_layers, int K, int N, RoParams* P, int* l
     if (dims == nullptr || n_layers < 1 || n_layers > MGP_MAX_LAYERS) return false;
     if (K < 1 || K > 5 || N < 4 || N > RB_MAXN) return false;                   // N <= 128: 2 N (K - 1) gather threads <= 1024
     if (dims[0] != 6 || dims[n_layers] != 2) return false;                      // simulator: 6 features in, 2-D action out
+#ifdef MGP_RO_X2
+    {   // this build: two hidden layers, at least one of them wider than 64 (the 64-wide build takes the rest), N = 100, K = 3; fixed
+        // image layout (rollout_common.h RO_X2_*), its LDS copy is one K block shorter than the image
+        if (n_layers != 3 || N != 100 || K != 3 || dims[1] < 1 || dims[2] < 1 || dims[1] > 128 || dims[2] > 128 ||
+            (dims[1] <= 64 && dims[2] <= 64)) return false;
+        const int total = ro_offsets(N, K).wl + RO_X2_LDS * 4;
+        if (total > RO_LDS_LIMIT) return false;
+        if (P) {
+            P->woff[0] = 0; P->woff[1] = RO_X2_L0; P->woff[2] = RO_X2_L0 + RO_X2_L1;
+            for (int l = 0; l <= n_layers; ++l) P->dims[l] = dims[l];
+            P->n_layers = n_layers; P->wtot = RO_X2_IMAGE; P->bf = 1;
+        }
+        if (lds_bytes) *lds_bytes = total;
+        return true;
+    }
+#endif
 #ifdef MGP_RO_X128
     if (n_layers != 2 || N > RO_MAXN) return false;                             // this build: ONE hidden layer (up to 128 wide), N <= 128
 #endif
@@ -2159,7 +2257,9 @@ __global__ void rollout_image_kernel(RoParams P, int K, float* __restrict__ imag
         const int tot = last ? ro_weight_image_size(cout, true) : ro_chain_image_size(cout, false, bf);
         const int span = (l + 1 < P.n_layers ? P.woff[l + 1] : P.wtot) - P.woff[l];
         for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < span; e += gridDim.x * blockDim.x)
-            image[P.woff[l] + e] = (e >= tot) ? 0.f : (last ? ro_weight_image_elem(P.W[l], P.b[l], cin, cout, true, e)
+            image[P.woff[l] + e] = (RO_X2 && l == 0) ? ro_x2_l0_elem(P.W[l], P.b[l], cin, cout, e)
+                                   : (RO_X2 && l == 1) ? ro_x2_l1_elem(P.W[l], P.b[l], cin, cout, e)
+                                   : (e >= tot) ? 0.f : (last ? ro_weight_image_elem(P.W[l], P.b[l], cin, cout, true, e)
                                                              : ro_chain_image_elem(P.W[l], P.b[l], cin, cout, l, false, e, bf));
     }
 }
@@ -2239,12 +2339,19 @@ int launch_rollout_big(double* x, float* G, float* Xd, float* action, double* re
 #define MGP_RO_COLLECT mgp_rollout_f32ref_collect_
 #define MGP_RO_IMAGE_FLOATS mgp_rollout_f32ref_image_floats
 #define MGP_RO_IMAGE mgp_rollout_f32ref_image
+#elif defined(MGP_RO_X2)
+#define MGP_RO_SUPPORTED mgp_rollout_x2_supported_
+#define MGP_RO_STEPS_EX mgp_rollout_x2_steps_ex_
+#define MGP_RO_COLLECT mgp_rollout_x2_collect_
+#define MGP_RO_IMAGE_FLOATS mgp_rollout_x2_image_floats_
+#define MGP_RO_IMAGE mgp_rollout_x2_image_
 #elif defined(MGP_RO_X128)
 #define MGP_RO_SUPPORTED mgp_rollout_x128_supported_
 #define MGP_RO_STEPS_EX mgp_rollout_x128_steps_ex_
 #define MGP_RO_COLLECT mgp_rollout_x128_collect_
 #define MGP_RO_IMAGE_FLOATS mgp_rollout_x128_image_floats_
 #define MGP_RO_IMAGE mgp_rollout_x128_image_
+#define MGP_RO_NEXT(name) mgp_rollout_x2_##name##_
 #elif defined(MGP_RO_WIDE)
 #define MGP_RO_SUPPORTED mgp_rollout_wide_supported_
 #define MGP_RO_STEPS_EX mgp_rollout_wide_steps_ex_
@@ -2415,7 +2522,14 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int wt = P.wtot;
     const bool fade = p->link_drop != 0u;   // FlockingStochastic-v0: the generic builds carry the fade hash, the others do not
-#ifdef MGP_RO_T512
+#ifdef MGP_RO_X2
+    // one instantiation: (N, K) = (100, 3), no link fading, no data collection, the weight image prebuilt (blocks 2 and 3 of the
+    // second layer are streamed from it every step: it cannot be built inside the launch).  Anything else: the caller's
+    // two-launch path (ops.rollout_steps builds the image and retries when only that was missing).
+    if (cl != nullptr || fade || image == nullptr || !mgp_aligned16(image)) return MGP_EUNSUPPORTED;
+    return launch_rollout<100, 3, false, false, false, RO_BF16_CHAIN, false>(x, G, Xd, action, rewards, P, p, B, K, N, T, dimsA, dims8, woffA, woffB,
+                                                                             n_layers, lds, st, image, wt, carry, flags, cl);
+#elif defined(MGP_RO_T512)
     // this build is one instantiation: the reference's policy shape at the headline (N, K), plain and collecting
     if (!(N == 100 && K == 3 && !fade && n_layers == 3 && dims[1] == 32 && dims[2] == 32 && P.woff[1] == 2 * 64 * RO_WFS + 32 &&
           P.woff[2] == 2 * (2 * 64 * RO_WFS + 32)) || !(RO_VERLET != 0))

@@ -320,6 +320,114 @@ __device__ __forceinline__ float ro_chain_image_elem_bf(const float* __restrict_
     return __uint_as_float(word);
 }
 
+// ---- [r6] two hidden layers of up to 128 channels on the resident kernel (rollout_w128x2.hip, MGP_RO_X2).  The second layer's
+// piece image is 4 K blocks (32 input channels each) x 8 m-tiles x 64 lanes x 48 bytes = 96 KB -- with the first layer's 24 KB
+// and 59 KB of episode state more than a CU's 160 KB.  Blocks 0 and 1 stay in LDS; blocks 2 and 3 share ONE 24 KB buffer and
+// are streamed into it from the caller's image (L2) by LDS-DMA, each once per step, under compute: block 3 while the tile
+// waves multiply blocks 0 and 1, block 2 (for the next step) under the simulator phases.  Image layout of that layer:
+// [kb][mt][lane][piece][8 bf16] (a K block is one contiguous 24,576-byte span), then the bias [128]; element j of k-group lq of
+// block kb <-> input channel 32 kb + (j < 4 ? 4 lq + j : 16 + 4 lq + (j - 4)): the accumulator registers of m-tiles 2 kb,
+// 2 kb + 1 of the first layer.
+constexpr int RO_X2_KB = 4;                                   // K blocks of the second layer
+constexpr int RO_X2_BLK = 8 * 64 * 12;                        // floats per K block: 8 m-tiles x 64 lanes x 12
+constexpr int RO_X2_L0 = 8 * 64 * 12 + 128;                   // first layer: 8 m-tiles of records + 128 bias values
+constexpr int RO_X2_L1 = RO_X2_KB * RO_X2_BLK + 128;          // second layer: 4 K blocks + bias
+constexpr int RO_X2_OUT = (2 * 128 + 2 + 15) & ~15;           // output layer: channel-ordered pairs + bias pair, padded
+constexpr int RO_X2_IMAGE = RO_X2_L0 + RO_X2_L1 + RO_X2_OUT;  // floats of the image in HBM
+constexpr int RO_X2_LDS = RO_X2_L0 + 2 * RO_X2_BLK + 128 + RO_X2_OUT + RO_X2_BLK;   // floats in LDS: blocks 0, 1 + the stream buffer
+
+__device__ __forceinline__ float ro_x2_l1_elem(const float* __restrict__ src, const float* __restrict__ bias, int cin, int cout, int e)
+{
+    if (e >= RO_X2_KB * RO_X2_BLK) { const int o = e - RO_X2_KB * RO_X2_BLK; return (o < cout) ? bias[o] : 0.f; }
+    const int kb = e / RO_X2_BLK, r0 = e - kb * RO_X2_BLK;
+    const int mt = r0 / (64 * 12), r1 = r0 - mt * (64 * 12);
+    const int ln = r1 / 12, sl = r1 - ln * 12;
+    const int piece = sl >> 2, pr = sl & 3;
+    const int lqq = ln >> 4, o = mt * 16 + (ln & 15);
+    unsigned int word = 0u;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int j = 2 * pr + t;
+        const int c = 32 * kb + (j < 4 ? 4 * lqq + j : 16 + 4 * lqq + (j - 4));
+        const float w = (o < cout && c < cin) ? src[(size_t)o * cin + c] : 0.f;
+        const __bf16 a = (__bf16)w;
+        const float r = w - (float)a;
+        const __bf16 b = (__bf16)r;
+        const float r2 = r - (float)b;
+        const __bf16 h = piece == 0 ? a : (piece == 1 ? b : (__bf16)r2);
+        unsigned short bits;
+        __builtin_memcpy(&bits, &h, 2);
+        word |= (unsigned int)bits << (16 * t);
+    }
+    return __uint_as_float(word);
+}
+
+// first layer of that build: always eight m-tiles of records + 128 bias values (rows beyond cout are zero), the first-layer
+// channel enumeration of ro_chain_image_elem_bf (element j of k-group lq <-> aggregation channel 4 j + lq)
+__device__ __forceinline__ float ro_x2_l0_elem(const float* __restrict__ src, const float* __restrict__ bias, int cin, int cout, int e)
+{
+    if (e >= 8 * 64 * 12) { const int o = e - 8 * 64 * 12; return (o < cout) ? bias[o] : 0.f; }
+    const int mt = e / (64 * 12), r1 = e - mt * (64 * 12);
+    const int ln = r1 / 12, sl = r1 - ln * 12;
+    const int piece = sl >> 2, pr = sl & 3;
+    const int lqq = ln >> 4, o = mt * 16 + (ln & 15);
+    unsigned int word = 0u;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int c = 4 * (2 * pr + t) + lqq;
+        const float w = (o < cout && c < cin) ? src[(size_t)o * cin + c] : 0.f;
+        const __bf16 a = (__bf16)w;
+        const float r = w - (float)a;
+        const __bf16 b = (__bf16)r;
+        const float r2 = r - (float)b;
+        const __bf16 h = piece == 0 ? a : (piece == 1 ? b : (__bf16)r2);
+        unsigned short bits;
+        __builtin_memcpy(&bits, &h, 2);
+        word |= (unsigned int)bits << (16 * t);
+    }
+    return __uint_as_float(word);
+}
+
+// 16 bytes per active lane straight into LDS: LDS[dst_uniform + 16 * lane] = *src (global_load_lds_dwordx4; M0 carries the LDS
+// base).  hipcc does not count the request; the hardware does: the issuing wave waits with s_waitcnt vmcnt(0) before the barrier
+// in front of the first read, and every vmcnt wait it executes in between blocks on it.
+__device__ __forceinline__ void ro_lds_dma16(const void* src, const void* dst_uniform)
+{
+    const unsigned int base = __builtin_amdgcn_readfirstlane((unsigned int)reinterpret_cast<uintptr_t>(dst_uniform));
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(base), "v"(src) : "memory", "m0");
+}
+
+// one K block of the second layer: acc[mt] += W[mt][kb] . x for the eight m-tiles, two at a time (independent accumulator
+// chains), the six products of ro_layer_bf16 smallest first
+__device__ __forceinline__ void ro_x2_block(const float* blk /* this lane's record of m-tile 0 */, const ro_bf16x8& b1,
+                                            const ro_bf16x8& b2, const ro_bf16x8& b3, f32x4 (&acc)[8])
+{
+#pragma unroll
+    for (int h = 0; h < 8; h += 2) {
+        ro_bf16x8 a1[2], a2[2], a3[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const float4* pa = reinterpret_cast<const float4*>(blk + (h + mt) * 64 * 12);
+            const float4 u1 = pa[0], u2 = pa[1], u3 = pa[2];
+            a1[mt] = *reinterpret_cast<const ro_bf16x8*>(&u1);
+            a2[mt] = *reinterpret_cast<const ro_bf16x8*>(&u2);
+            a3[mt] = *reinterpret_cast<const ro_bf16x8*>(&u3);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[h + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b3, acc[h + mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[h + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[mt], b1, acc[h + mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[h + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[mt], b2, acc[h + mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[h + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b2, acc[h + mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[h + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[mt], b1, acc[h + mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[h + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b1, acc[h + mt], 0, 0, 0);
+    }
+}
+
 // the LDS-tile form of a hidden layer (ro_mlp_cols: every layer reads its B operand from the wave's activation columns, slot
 // j of k-lane lq <-> channel 4 j + lq, and writes its output there) on the same instructions; its weight blocks are the
 // first-layer enumeration of ro_chain_image_elem_bf for every layer (ro_weight_image_elem)

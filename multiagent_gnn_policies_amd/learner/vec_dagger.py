@@ -621,6 +621,9 @@ def collect_supported(learner, K, N, params=None):
     if N > 256:                                                 # factored state in HBM: mgp_sparse_policy_collect, K launches per step
         from .sparse_rollout import sparse_supported
         return sparse_supported(learner.actor, K, N)
+    hidden = [int(v) for v in learner.actor.layers[1:-1]]
+    if len(hidden) >= 2 and max(hidden) > 64:                   # two 128-wide layers: the resident build that streams its second layer
+        return False                                            # (rollout_w128x2.hip) has no collecting form
     return ops.rollout_supported(tuple(learner.actor.layers), K, N)
 
 

@@ -288,6 +288,13 @@ def rollout_steps(x, G, Xd, weights, biases, dims, params, T, action=None, rewar
     entry = _lib.lib().mgp_rollout_f32ref_steps_ex if f32ref else _lib.lib().mgp_rollout_steps_ex
     rc = entry(_ptr(x), _ptr(G), _ptr(Xd), wa, ba, cd, len(dims) - 1, _ptr(action), _ptr(rewards),
                ctypes.byref(params), B, K, N, int(T), _ptr(image), _ptr(carry), int(flags), _stream())
+    if rc == -5 and image is None and not f32ref and rollout_supported(tuple(dims), K, N):
+        # a build that streams part of its weight image from HBM every step (two 128-wide hidden layers: rollout_w128x2.hip) cannot
+        # build the image inside the launch: build it here, once per call, and launch again
+        image = rollout_image(weights, biases, tuple(dims), K, N)
+        if image is not None:
+            rc = entry(_ptr(x), _ptr(G), _ptr(Xd), None, None, cd, len(dims) - 1, _ptr(action), _ptr(rewards),
+                       ctypes.byref(params), B, K, N, int(T), _ptr(image), _ptr(carry), int(flags), _stream())
     if rc == -5:
         return False
     _lib.check(rc, 'mgp_rollout_steps_ex')

@@ -359,8 +359,10 @@ def test_coverage_predicates_are_host_side():
     assert not ops.rollout_supported((6, 64, 64, 64, 64, 64, 2), 3, 100)   # five 64-wide layers: weight image + state > 160 KB
     assert not ops.rollout_supported((6, 64, 64, 64, 64, 2), 3, 128)       # four of them at N = 128 neither
     assert ops.rollout_supported((6, 128, 2), 3, 100)              # ONE hidden layer up to 128 wide: the third build ...
-    assert not ops.rollout_supported((6, 128, 128, 2), 3, 100)     # ... two of them, or a second hidden layer behind it:
-    assert not ops.rollout_supported((6, 128, 32, 2), 3, 100)      #     two-launch path
+    assert ops.rollout_supported((6, 128, 128, 2), 3, 100)         # ... [r6] two of them, or a second hidden layer behind it, at the
+    assert ops.rollout_supported((6, 128, 32, 2), 3, 100)          #     headline (N, K): the build that streams the second layer
+    assert not ops.rollout_supported((6, 128, 128, 2), 4, 100) and not ops.rollout_supported((6, 128, 128, 2), 3, 125)   # elsewhere: two-launch path
+    assert not ops.rollout_supported((6, 128, 128, 128, 2), 3, 100)
     assert not ops.rollout_supported((6, 32, 2), 3, 1000)          # BASELINE configs[2]: two-launch path
     assert not ops.rollout_supported((6, 32, 2), 6, 100) and not ops.rollout_supported((6, 32, 2), 3, 3)
     assert not ops.rollout_supported((5, 32, 2), 3, 100) and not ops.rollout_supported((6, 32, 3), 3, 100)

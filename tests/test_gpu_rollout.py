@@ -107,6 +107,11 @@ CASES = [
     (64, 2, (96,), {'mean_pooling': False}),
     (100, 4, (80,), {'n_leaders': 1}),
     (128, 3, (128,), {'link_drop': 0.25, 'link_seed': 3}),
+    # [r6] two hidden layers of up to 128 channels (cfg/hidden_size.cfg:81-82): the fourth build (rollout_w128x2.hip), the second
+    # layer's K blocks 2 and 3 streamed through one LDS buffer every step
+    (100, 3, (128, 128), {}),
+    (100, 3, (96, 72), {'mean_pooling': False, 'n_leaders': 2}),
+    (100, 3, (128, 40), {}),
 ]
 
 
@@ -413,7 +418,9 @@ def test_rollout_unsupported_shapes_fall_back():
     from multiagent_gnn_policies_amd import ops
     assert ops.rollout_supported((6, 64, 64, 2), 3, 100)          # 64-wide layers: the wide build
     assert ops.rollout_supported((6, 128, 2), 3, 100)             # ONE hidden layer up to 128 wide: the third build
-    assert not ops.rollout_supported((6, 128, 128, 2), 3, 100)    # two of them: two-launch path
+    assert ops.rollout_supported((6, 128, 128, 2), 3, 100)        # [r6] two of them at the headline (N, K): the streaming build
+    assert not ops.rollout_supported((6, 128, 128, 2), 3, 128) and not ops.rollout_supported((6, 128, 128, 2), 2, 100)   # only there
+    assert not ops.rollout_supported((6, 128, 128, 128, 2), 3, 100)   # three: two-launch path (mgp_actor_fwd_deep)
     assert not ops.rollout_supported((6, 128, 2), 3, 200)         # (the wide single layer is built for N <= 128)
     assert ops.rollout_supported((6, 32, 32, 2), 4, 100)          # no dense operator slice lives in LDS: K is bounded by
     assert ops.rollout_supported((6, 32, 32, 2), 5, 128)          # the 2 N (K - 1) gather threads only

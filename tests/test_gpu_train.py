@@ -282,7 +282,12 @@ def test_bench_single_gpu_contract_and_paths(n, k, paths):
         # timed with them rebuilt inside the launch, vector-issue as the bound with the matrix figure beside it, a median of repeats
         assert 'MGP_RO_SKIP_DENSE' in d['config']['step_path'] and 'resident_dense_exit' in d['config']['step_path']
         assert d['paths']['resident_dense_exit']['ms_per_step'] > 0.9 * r_['ms_per_step']
-        assert d['roofline']['bound'] == 'valu' and {'achieved', 'peak', 'frac'} <= set(d['roofline']['mfma'])
+        # [r6] the vector-issue figure rests on a counter pass + ISA mix of the headline shape: other shapes carry the algorithmic matrix-pipe
+        # figure as `frac` and say that their limiter was not measured
+        assert d['roofline']['bound'] == ('valu' if (n, k) == (100, 3) else 'mfma') and {'achieved', 'peak', 'frac'} <= set(d['roofline']['mfma'])
+        assert d['roofline']['frac'] is not None and d['roofline']['frac'] > 0
+        if (n, k) == (100, 3):
+            assert 2.0 < d['roofline']['mean_cycles_per_valu_instruction'] < 5.0
         vm = d['value_median_of']
         assert vm['n'] >= 3 and len(vm['samples_ms_per_step']) == vm['n'] and vm['samples_ms_per_step'][0] == d['ms_per_step']
         assert min(vm['samples_ms_per_step']) <= vm['ms_per_step'] <= max(vm['samples_ms_per_step'])
