@@ -27,7 +27,7 @@ COMMON_FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall',
 _RO = ['-ffp-contract=off', '-fno-slp-vectorize']
 PER_FILE_FLAGS = {'flock.hip': ['-ffp-contract=off'], 'rollout.hip': _RO,
                   'sparse_sim.hip': ['-ffp-contract=off'], 'rollout_wide.hip': _RO,
-                  'rollout_w128.hip': _RO, 'rollout_f32ref.hip': _RO, 'rollout_t512.hip': _RO, 'rollout_w128x2.hip': _RO}
+                  'rollout_w128.hip': _RO, 'rollout_f32ref.hip': _RO, 'rollout_t512.hip': _RO, 'rollout_w128x2.hip': _RO, 'rollout_w128xd.hip': _RO}
 
 
 def sources():

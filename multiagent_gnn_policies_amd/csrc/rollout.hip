@@ -40,7 +40,7 @@
 // This translation unit is built with -ffp-contract=off (fp64 spec arithmetic); fp32 fused multiply-adds are explicit.
 #include <hip/hip_ext.h>
 #include "rollout_common.h"
-#if !defined(MGP_RO_WIDE) && !defined(MGP_RO_X128) && !defined(MGP_RO_T512) && !defined(MGP_RO_X2)
+#if !defined(MGP_RO_WIDE) && !defined(MGP_RO_X128) && !defined(MGP_RO_T512) && !defined(MGP_RO_X2) && !defined(MGP_RO_XD)
 #define MGP_RO_BASE 1                      // the build that owns the public entry points (layer widths <= 32)
 #endif
 
@@ -65,6 +65,15 @@ constexpr bool RO_X2 = true;
 #else
 constexpr bool RO_X2 = false;
 #endif
+// MGP_RO_XD (rollout_w128xd.hip): three and more hidden layers of up to 128 channels (cfg/hidden_size.cfg:104-106, 128-130) at the
+// headline (N, K): EVERY K block of the layers behind the first is streamed, through a ring of three 24 KB buffers, two blocks in
+// flight while one is multiplied (one workgroup barrier per block)
+#ifdef MGP_RO_XD
+constexpr bool RO_XD = true;
+#else
+constexpr bool RO_XD = false;
+#endif
+constexpr bool RO_XS = RO_X2 || RO_XD;                        // a build that streams weight blocks
 constexpr int RO_WAVES = RO_THREADS / 64;
 #ifndef RO_S1L
 #define RO_S1L 8                          // (4 lanes per row -- 7 waves instead of 13, 25 candidates each -- measured 1 % slower)
@@ -262,7 +271,7 @@ __host__ __device__ constexpr RoOff ro_offsets(int N, int K)
     c.xt = ro_take(off, K * Np * 8 * 4);
     // (K = 3 uses parity 1 of the ping-pong only -- stage 1 writes it, the last stage reads it --: the T512 build, which must stay
     //  under 80 KB, allocates that half alone and biases the pointer)
-    c.vb = ro_take(off, (((RO_T512 || RO_X2) && K == 3) ? 1 : 2) * (K > 2 ? K - 2 : 0) * Np * 8 * 4);
+    c.vb = ro_take(off, (((RO_T512 || RO_XS) && K == 3) ? 1 : 2) * (K > 2 ? K - 2 : 0) * Np * 8 * 4);
     c.act = ro_take(off, ((N + 15) & ~15) * RO_CS * 4);
     c.rlist = ro_take(off, H * N * ro_list_stride(N));
     c.rcnt = ro_take(off, H * N * 4);
@@ -308,7 +317,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     float* wrow = reinterpret_cast<float*>(smraw + cv.wrow);
     float* uact = reinterpret_cast<float*>(smraw + cv.uact);
     float* XT = reinterpret_cast<float*>(smraw + cv.xt);
-    float* VB = reinterpret_cast<float*>(smraw + cv.vb) - (((RO_T512 || RO_X2) && K == 3) ? (K - 2) * ((N + 3) & ~3) * 8 : 0);
+    float* VB = reinterpret_cast<float*>(smraw + cv.vb) - (((RO_T512 || RO_XS) && K == 3) ? (K - 2) * ((N + 3) & ~3) * 8 : 0);
     float* wl = reinterpret_cast<float*>(smraw + cv.wl);
     float* act = reinterpret_cast<float*>(smraw + cv.act);
     unsigned char* rlist = smraw + cv.rlist;
@@ -388,7 +397,34 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
     float* x2_bias1 = x2_buf + RO_X2_BLK;
     float* x2_out = x2_bias1 + 128;
     const float* x2_img_b2 = image + RO_X2_L0 + 2 * RO_X2_BLK;
-    if (RO_X2) {
+    // XD: LDS = [layer 0][biases of layers 1 .. L - 1][output layer][ring of three K-block buffers]; image = [layer 0][per layer: 4 blocks +
+    // bias][output layer].  Blocks 0 and 1 of layer 1 are requested into ring slots 0, 1 here (waves 14 / 15) and waited for behind
+    // the entry's last barrier... in front of it (below).
+    const int xd_nb = 4 * (n_layers - 2);                     // streamed K blocks per step (XD builds)
+    float* xd_bias = wl + RO_X2_L0;                           // [n_layers - 2][128]
+    float* xd_out = xd_bias + 128 * (n_layers - 2);
+    float* xd_ring = xd_out + RO_X2_OUT;                      // [3][RO_X2_BLK]
+    auto xd_block_src = [&](const int g) -> const unsigned char* {      // global block g = 4 (layer - 1) + kb
+        return reinterpret_cast<const unsigned char*>(image + RO_X2_L0 + (g >> 2) * RO_X2_L1 + (g & 3) * RO_X2_BLK);
+    };
+    auto xd_dma = [&](const int g, const int wu_, const int ln_) {   // by waves 14, 15: 12 requests of 1 KB each
+        const unsigned char* src = xd_block_src(g);
+        unsigned char* dst = reinterpret_cast<unsigned char*>(xd_ring + (g % 3) * RO_X2_BLK);
+        for (int c = (wu_ - (RO_WAVES - 2)) * 1024; c < RO_X2_BLK * 4; c += 2048) ro_lds_dma16(src + c + ln_ * 16, dst + c);
+    };
+    if (RO_XD) {
+        const float4* src4 = reinterpret_cast<const float4*>(image);
+        float4* dst4 = reinterpret_cast<float4*>(wl);
+        for (int e = tid; e < RO_X2_L0 / 4; e += RO_THREADS) dst4[e] = src4[e];
+        for (int e = tid; e < 32 * (n_layers - 2); e += RO_THREADS) {           // biases: 32 float4 per layer, behind its four blocks
+            const int l1 = e >> 5, q = e & 31;
+            reinterpret_cast<float4*>(xd_bias)[e] = src4[(RO_X2_L0 + l1 * RO_X2_L1 + 4 * RO_X2_BLK) / 4 + q];
+        }
+        for (int e = tid; e < RO_X2_OUT / 4; e += RO_THREADS)
+            reinterpret_cast<float4*>(xd_out)[e] = src4[(RO_X2_L0 + (n_layers - 2) * RO_X2_L1) / 4 + e];
+        const int wu_ = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        if (wu_ >= RO_WAVES - 2) { xd_dma(0, wu_, (int)(threadIdx.x & 63)); xd_dma(1, wu_, (int)(threadIdx.x & 63)); }
+    } else if (RO_X2) {
         const float4* src4 = reinterpret_cast<const float4*>(image);
         float4* dst4 = reinterpret_cast<float4*>(wl);
         constexpr int HEAD4 = (RO_X2_L0 + 3 * RO_X2_BLK) / 4, TAIL4 = (128 + RO_X2_OUT) / 4;
@@ -453,6 +489,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         const double bq = floor((double)betav * 4294967296.0);            // P(expert drives) in units of 2^-32
         coin_thr = bq <= 0.0 ? 0ull : (bq >= 4294967296.0 ? 4294967296ull : (unsigned long long)bq);
     }
+    if (RO_XD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (ring slots 0, 1 hold blocks 0, 1)
     __syncthreads();
     RO_WALL(7);
     // history networks handed over in factored form (MGP_RO_ENTER_CARRY): bits -> ascending neighbour lists, four lanes per
@@ -834,8 +871,44 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 mtp = 8;
                 RO_STAMP(13);
             }
+            if constexpr (RO_XD) {
+                // layer 0 on the aggregation tile, then every further hidden layer K block by K block from the ring: block g = 4 (l - 1)
+                // + kb sits in slot g % 3; barrier B_g (g >= 1) says that it has landed AND that every tile wave is through with block
+                // g - 1, whose slot the DMA waves then refill with block g + 2
+                float fb[RO_KS];
+                const float4* pb = reinterpret_cast<const float4*>(act + col * RO_CS + lq * RO_KS);
 #pragma unroll
-            for (int l = 0; l < (RO_X2 ? 0 : (CM ? 2 : n_layers - 1)); ++l) {
+                for (int i = 0; i < RO_KS / 4; ++i) { const float4 tq = pb[i]; fb[4 * i] = tq.x; fb[4 * i + 1] = tq.y; fb[4 * i + 2] = tq.z; fb[4 * i + 3] = tq.w; }
+                ro_layer_bf16<8, true>(fb, wl + lane * RO_WFS, wl + 8 * 64 * RO_WFS + lq * 4, zc, 1);
+                RO_STAMP(12);
+#pragma unroll 1
+                for (int l = 1; l < n_layers - 1; ++l) {
+                    f32x4 acc[8];
+#pragma unroll
+                    for (int mt = 0; mt < 8; ++mt) {
+                        const float4 bv = *reinterpret_cast<const float4*>(xd_bias + (l - 1) * 128 + mt * 16 + lq * 4);
+                        acc[mt] = f32x4{bv.x, bv.y, bv.z, bv.w};
+                    }
+#define RO_XD_BLOCK(KB_) do { \
+                        const int g_ = 4 * (l - 1) + (KB_); \
+                        if (g_ >= 1) __syncthreads(); \
+                        const float xk[8] = {zc[2 * (KB_)][0], zc[2 * (KB_)][1], zc[2 * (KB_)][2], zc[2 * (KB_)][3], \
+                                             zc[2 * (KB_) + 1][0], zc[2 * (KB_) + 1][1], zc[2 * (KB_) + 1][2], zc[2 * (KB_) + 1][3]}; \
+                        ro_bf16x8 b1_, b2_, b3_; \
+                        ro_split3(xk, b1_, b2_, b3_); \
+                        ro_x2_block<1>(xd_ring + (g_ % 3) * RO_X2_BLK + lane * 12, b1_, b2_, b3_, acc); } while (0)
+                    RO_XD_BLOCK(0); RO_XD_BLOCK(1); RO_XD_BLOCK(2); RO_XD_BLOCK(3);
+#undef RO_XD_BLOCK
+#pragma unroll
+                    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) zc[mt][rr] = tanh_fast(acc[mt][rr]);
+                }
+                mtp = 8;
+                RO_STAMP(13);
+            }
+#pragma unroll
+            for (int l = 0; l < (RO_XS ? 0 : (CM ? 2 : n_layers - 1)); ++l) {
                 const int cout = CM ? 32 : ro_dim(dimsA, dims8, l + 1);
                 const int MT = CM ? 2 : ro_mt(cout);
                 // (CM: a 32-wide hidden layer's block is 2 m-tiles of fragments + 32 bias values)
@@ -878,7 +951,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
 #endif
             // ---------------------------------------------------------- C: output layer + integration, same wave, no barrier
             const int lo_ = n_layers - 1;
-            const float* w2 = RO_X2 ? x2_out
+            const float* w2 = RO_XD ? xd_out : RO_X2 ? x2_out
                                     : wl + (CM ? 2 * (2 * 64 * WFS + 32) : (int)((((lo_ < 4) ? woffA : woffB) >> (16 * (lo_ & 3))) & 0xFFFFull));
             if (CM || n_layers > 1) {
                 // The 2-wide output layer on the accumulator registers of the last hidden layer: lane (li, lq) holds channels
@@ -965,6 +1038,21 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
                 }
             }
         } else {
+            if (RO_XD) {
+                // the other waves keep the ring turning: block 2 first (slot 2 is free), then at every barrier B_g the DMA waves first wait
+                // for block g (block g + 1 may still be in flight: 12 requests per wave) and behind it refill block g - 1's slot
+                const int wu = __builtin_amdgcn_readfirstlane(wave);
+                const bool dmaw = wu >= RO_WAVES - 2;
+                if (dmaw && xd_nb > 2) xd_dma(2, wu, lane);
+                for (int g = 1; g < xd_nb; ++g) {
+                    if (dmaw && g >= 2) {
+                        if (g + 1 < xd_nb) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    __syncthreads();
+                    if (dmaw && g + 2 < xd_nb) xd_dma(g + 2, wu, lane);
+                }
+            }
             if (RO_X2) {
                 __syncthreads();                              // X1: every tile wave is through with block 2
                 const int wu = __builtin_amdgcn_readfirstlane(wave);
@@ -1014,6 +1102,10 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
         const int vmode_raw = VL ? vflag[0] : (int)RO_VM_FULL;
         __syncthreads();
         RO_STAMP(3);
+        if (RO_XD && t + 1 < T) {                             // the next step's blocks 0, 1 -> ring slots 0, 1 (all tile waves are through)
+            const int wu = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            if (wu >= RO_WAVES - 2) { xd_dma(0, wu, (int)(threadIdx.x & 63)); xd_dma(1, wu, (int)(threadIdx.x & 63)); }
+        }
         if (RO_X2 && t + 1 < T) {
             // the next step's block 2 -> stream buffer (every tile wave is through with block 3), by the two waves that have least to
             // do in the simulator phases; waited for in front of the step's last barrier
@@ -1483,7 +1575,7 @@ void rollout_kernel(double* __restrict__ x, float* __restrict__ G, float* __rest
             RO_STAMP(23);
         }
         }
-        if (RO_X2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the streamed block of the next step has landed)
+        if (RO_XS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the streamed block(s) of the next step have landed)
         __syncthreads();
         RO_STAMP(4);
         cur = curn;
@@ -2158,6 +2250,23 @@ bool make_carve(const int* dims, int n_layers, int K, int N, RoParams* P, int* l
     if (dims == nullptr || n_layers < 1 || n_layers > MGP_MAX_LAYERS) return false;
     if (K < 1 || K > 5 || N < 4 || N > RB_MAXN) return false;                   // N <= 128: 2 N (K - 1) gather threads <= 1024
     if (dims[0] != 6 || dims[n_layers] != 2) return false;                      // simulator: 6 features in, 2-D action out
+#ifdef MGP_RO_XD
+    {   // this build: three or more hidden layers of up to 128 channels, at least one of them wider than 64, N = 100, K = 3
+        if (n_layers < 4 || N != 100 || K != 3) return false;
+        int widest = 0;
+        for (int l = 1; l < n_layers; ++l) { if (dims[l] < 1 || dims[l] > 128) return false; widest = dims[l] > widest ? dims[l] : widest; }
+        if (widest <= 64) return false;
+        const int total = ro_offsets(N, K).wl + (RO_X2_L0 + 128 * (n_layers - 2) + RO_X2_OUT + 3 * RO_X2_BLK) * 4;
+        if (total > RO_LDS_LIMIT) return false;
+        if (P) {
+            for (int l = 0; l < n_layers; ++l) P->woff[l] = (l == 0) ? 0 : RO_X2_L0 + (l - 1) * RO_X2_L1;
+            for (int l = 0; l <= n_layers; ++l) P->dims[l] = dims[l];
+            P->n_layers = n_layers; P->wtot = RO_X2_L0 + (n_layers - 2) * RO_X2_L1 + RO_X2_OUT; P->bf = 1;
+        }
+        if (lds_bytes) *lds_bytes = total;
+        return true;
+    }
+#endif
 #ifdef MGP_RO_X2
     {   // this build: two hidden layers, at least one of them wider than 64 (the 64-wide build takes the rest), N = 100, K = 3; fixed
         // image layout (rollout_common.h RO_X2_*), its LDS copy is one K block shorter than the image
@@ -2257,8 +2366,8 @@ __global__ void rollout_image_kernel(RoParams P, int K, float* __restrict__ imag
         const int tot = last ? ro_weight_image_size(cout, true) : ro_chain_image_size(cout, false, bf);
         const int span = (l + 1 < P.n_layers ? P.woff[l + 1] : P.wtot) - P.woff[l];
         for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < span; e += gridDim.x * blockDim.x)
-            image[P.woff[l] + e] = (RO_X2 && l == 0) ? ro_x2_l0_elem(P.W[l], P.b[l], cin, cout, e)
-                                   : (RO_X2 && l == 1) ? ro_x2_l1_elem(P.W[l], P.b[l], cin, cout, e)
+            image[P.woff[l] + e] = (RO_XS && l == 0) ? ro_x2_l0_elem(P.W[l], P.b[l], cin, cout, e)
+                                   : (RO_XS && l >= 1 && !last) ? ro_x2_l1_elem(P.W[l], P.b[l], cin, cout, e)
                                    : (e >= tot) ? 0.f : (last ? ro_weight_image_elem(P.W[l], P.b[l], cin, cout, true, e)
                                                              : ro_chain_image_elem(P.W[l], P.b[l], cin, cout, l, false, e, bf));
     }
@@ -2339,12 +2448,19 @@ int launch_rollout_big(double* x, float* G, float* Xd, float* action, double* re
 #define MGP_RO_COLLECT mgp_rollout_f32ref_collect_
 #define MGP_RO_IMAGE_FLOATS mgp_rollout_f32ref_image_floats
 #define MGP_RO_IMAGE mgp_rollout_f32ref_image
+#elif defined(MGP_RO_XD)
+#define MGP_RO_SUPPORTED mgp_rollout_xd_supported_
+#define MGP_RO_STEPS_EX mgp_rollout_xd_steps_ex_
+#define MGP_RO_COLLECT mgp_rollout_xd_collect_
+#define MGP_RO_IMAGE_FLOATS mgp_rollout_xd_image_floats_
+#define MGP_RO_IMAGE mgp_rollout_xd_image_
 #elif defined(MGP_RO_X2)
 #define MGP_RO_SUPPORTED mgp_rollout_x2_supported_
 #define MGP_RO_STEPS_EX mgp_rollout_x2_steps_ex_
 #define MGP_RO_COLLECT mgp_rollout_x2_collect_
 #define MGP_RO_IMAGE_FLOATS mgp_rollout_x2_image_floats_
 #define MGP_RO_IMAGE mgp_rollout_x2_image_
+#define MGP_RO_NEXT(name) mgp_rollout_xd_##name##_
 #elif defined(MGP_RO_X128)
 #define MGP_RO_SUPPORTED mgp_rollout_x128_supported_
 #define MGP_RO_STEPS_EX mgp_rollout_x128_steps_ex_
@@ -2514,6 +2630,7 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
         else dims8 = (unsigned int)dims[l];
     }
     for (int l = 0; l < n_layers; ++l) {
+        if (RO_XS) continue;                                 // (the streaming builds have a fixed image layout: offsets are not passed)
         if (P.woff[l] > 0xFFFF) return MGP_EUNSUPPORTED;
         if (l < 4) woffA |= (unsigned long long)P.woff[l] << (16 * l);
         else woffB |= (unsigned long long)P.woff[l] << (16 * (l - 4));
@@ -2522,7 +2639,7 @@ int ro_run(double* x, float* G, float* Xd, const float* const* W, const float* c
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int wt = P.wtot;
     const bool fade = p->link_drop != 0u;   // FlockingStochastic-v0: the generic builds carry the fade hash, the others do not
-#ifdef MGP_RO_X2
+#if defined(MGP_RO_X2) || defined(MGP_RO_XD)
     // one instantiation: (N, K) = (100, 3), no link fading, no data collection, the weight image prebuilt (blocks 2 and 3 of the
     // second layer are streamed from it every step: it cannot be built inside the launch).  Anything else: the caller's
     // two-launch path (ops.rollout_steps builds the image and retries when only that was missing).

@@ -399,14 +399,15 @@ __device__ __forceinline__ void ro_lds_dma16(const void* src, const void* dst_un
 
 // one K block of the second layer: acc[mt] += W[mt][kb] . x for the eight m-tiles, two at a time (independent accumulator
 // chains), the six products of ro_layer_bf16 smallest first
-__device__ __forceinline__ void ro_x2_block(const float* blk /* this lane's record of m-tile 0 */, const ro_bf16x8& b1,
+template <int CH = 2>                                         // m-tiles in flight (a dependent chain of 16x16x32 MFMAs issues at the independent rate:
+__device__ __forceinline__ void ro_x2_block(const float* blk /* this lane's record of m-tile 0 */, const ro_bf16x8& b1,   // profiles/r06_valu_rate.txt)
                                             const ro_bf16x8& b2, const ro_bf16x8& b3, f32x4 (&acc)[8])
 {
 #pragma unroll
-    for (int h = 0; h < 8; h += 2) {
-        ro_bf16x8 a1[2], a2[2], a3[2];
+    for (int h = 0; h < 8; h += CH) {
+        ro_bf16x8 a1[CH], a2[CH], a3[CH];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < CH; ++mt) {
             const float4* pa = reinterpret_cast<const float4*>(blk + (h + mt) * 64 * 12);
             const float4 u1 = pa[0], u2 = pa[1], u3 = pa[2];
             a1[mt] = *reinterpret_cast<const ro_bf16x8*>(&u1);
@@ -414,17 +415,17 @@ __device__ __forceinline__ void ro_x2_block(const float* blk /* this lane's reco
             a3[mt] = *reinterpret_cast<const ro_bf16x8*>(&u3);
         }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[h + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b3, acc[h + mt], 0, 0, 0);
+        for (int mt = 0; mt < CH; ++mt) acc[h + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b3, acc[h + mt], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[h + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[mt], b1, acc[h + mt], 0, 0, 0);
+        for (int mt = 0; mt < CH; ++mt) acc[h + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[mt], b1, acc[h + mt], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[h + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[mt], b2, acc[h + mt], 0, 0, 0);
+        for (int mt = 0; mt < CH; ++mt) acc[h + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[mt], b2, acc[h + mt], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[h + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b2, acc[h + mt], 0, 0, 0);
+        for (int mt = 0; mt < CH; ++mt) acc[h + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b2, acc[h + mt], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[h + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[mt], b1, acc[h + mt], 0, 0, 0);
+        for (int mt = 0; mt < CH; ++mt) acc[h + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[mt], b1, acc[h + mt], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[h + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b1, acc[h + mt], 0, 0, 0);
+        for (int mt = 0; mt < CH; ++mt) acc[h + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b1, acc[h + mt], 0, 0, 0);
     }
 }
 

@@ -362,7 +362,7 @@ def test_coverage_predicates_are_host_side():
     assert ops.rollout_supported((6, 128, 128, 2), 3, 100)         # ... [r6] two of them, or a second hidden layer behind it, at the
     assert ops.rollout_supported((6, 128, 32, 2), 3, 100)          #     headline (N, K): the build that streams the second layer
     assert not ops.rollout_supported((6, 128, 128, 2), 4, 100) and not ops.rollout_supported((6, 128, 128, 2), 3, 125)   # elsewhere: two-launch path
-    assert not ops.rollout_supported((6, 128, 128, 128, 2), 3, 100)
+    assert ops.rollout_supported((6, 128, 128, 128, 2), 3, 100) and not ops.rollout_supported((6, 128, 128, 128, 2), 2, 100)
     assert not ops.rollout_supported((6, 32, 2), 3, 1000)          # BASELINE configs[2]: two-launch path
     assert not ops.rollout_supported((6, 32, 2), 6, 100) and not ops.rollout_supported((6, 32, 2), 3, 3)
     assert not ops.rollout_supported((5, 32, 2), 3, 100) and not ops.rollout_supported((6, 32, 3), 3, 100)

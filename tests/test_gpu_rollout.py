@@ -112,6 +112,11 @@ CASES = [
     (100, 3, (128, 128), {}),
     (100, 3, (96, 72), {'mean_pooling': False, 'n_leaders': 2}),
     (100, 3, (128, 40), {}),
+    # [r6] three and more of them (cfg/hidden_size.cfg:104-106, 128-130): the fifth build (rollout_w128xd.hip), every K block of the layers
+    # behind the first streamed through a ring of three LDS buffers
+    (100, 3, (128, 128, 128), {}),
+    (100, 3, (128, 128, 128, 128), {}),
+    (100, 3, (72, 128, 40), {'mean_pooling': False}),
 ]
 
 
@@ -420,7 +425,8 @@ def test_rollout_unsupported_shapes_fall_back():
     assert ops.rollout_supported((6, 128, 2), 3, 100)             # ONE hidden layer up to 128 wide: the third build
     assert ops.rollout_supported((6, 128, 128, 2), 3, 100)        # [r6] two of them at the headline (N, K): the streaming build
     assert not ops.rollout_supported((6, 128, 128, 2), 3, 128) and not ops.rollout_supported((6, 128, 128, 2), 2, 100)   # only there
-    assert not ops.rollout_supported((6, 128, 128, 128, 2), 3, 100)   # three: two-launch path (mgp_actor_fwd_deep)
+    assert ops.rollout_supported((6, 128, 128, 128, 2), 3, 100) and ops.rollout_supported((6, 128, 128, 128, 128, 2), 3, 100)   # [r6] the ring build
+    assert not ops.rollout_supported((6, 128, 128, 128, 2), 3, 64)    # ... at the headline (N, K) only
     assert not ops.rollout_supported((6, 128, 2), 3, 200)         # (the wide single layer is built for N <= 128)
     assert ops.rollout_supported((6, 32, 32, 2), 4, 100)          # no dense operator slice lives in LDS: K is bounded by
     assert ops.rollout_supported((6, 32, 32, 2), 5, 128)          # the 2 N (K - 1) gather threads only

@@ -12,6 +12,17 @@ import sqlite3
 import sys
 
 
+def _mix_cycles():
+    """Mean cycles per wave64 VALU instruction of the resident kernel's step loop (tools/isa_mix.py), 4.0 if none is committed.
+    (It is the rollout kernel's mix; the other kernels' lines use it as the best available figure.)"""
+    try:
+        import json, os
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        return float(json.load(open(os.path.join(root, 'profiles', 'r06_isa_mix.json')))['mean_cycles_per_valu_instruction'])
+    except Exception:
+        return 4.0
+
+
 def _source_hash():
     """Hash of the kernel sources the profiled library was built from (bench.py says whether the numbers are this build's)."""
     try:
@@ -61,8 +72,10 @@ def main(path):
             print("    %-28s %15.1f%%  of (busy CU cycles x 4 SIMDs)" % ('matrix pipe busy', 100.0 * v['SQ_VALU_MFMA_BUSY_CYCLES'] /
                                                                         (4.0 * v['SQ_BUSY_CU_CYCLES'])))
         if v.get('SQ_INSTS_VALU') and v.get('SQ_BUSY_CU_CYCLES'):
-            print("    %-28s %15.1f%%  of (busy CU cycles x 4 SIMDs), at 4 cycles per wave instruction: a lower bound" %
-                  ('vector pipes issuing', 100.0 * v['SQ_INSTS_VALU'] / v['SQ_BUSY_CU_CYCLES']))
+            c = _mix_cycles()
+            print("    %-28s %15.1f%%  of (busy CU cycles x 4 SIMDs), at %.2f cycles per wave instruction (%s)" %
+                  ('vector pipes issuing', 100.0 * v['SQ_INSTS_VALU'] * c / (4.0 * v['SQ_BUSY_CU_CYCLES']), c,
+                   'mix-weighted cost of the resident kernel\'s step loop: profiles/r06_isa_mix.json' if c != 4.0 else 'no ISA mix committed: flat 4'))
 
 
     if len(sys.argv) > 2:                                       # machine-readable fractions for bench.py's roofline.sq
@@ -77,14 +90,13 @@ def main(path):
                  "avg_launch_us": v.get('_us'), "valu_insts": v.get('SQ_INSTS_VALU'), "mfma_f32_insts": v.get('SQ_INSTS_VALU_MFMA_F32')}
             if v.get('SQ_BUSY_CU_CYCLES'):
                 o["mfma_busy"] = v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (4.0 * v['SQ_BUSY_CU_CYCLES'])
-                # a wave64 VALU instruction occupies its SIMD's vector pipe for >= 4 cycles (fp64 / transcendental / MFMA longer):
-                # SQ_INSTS_VALU x 4 / (4 SIMDs x busy CU cycles) is a LOWER bound on how busy the vector pipes are
-                o["valu_issue"] = v.get('SQ_INSTS_VALU', 0.0) / v['SQ_BUSY_CU_CYCLES']
+                # SQ_INSTS_VALU x (mix-weighted cycles per instruction, tools/isa_mix.py) / (4 SIMDs x busy CU cycles)
+                o["valu_issue"] = v.get('SQ_INSTS_VALU', 0.0) * _mix_cycles() / (4.0 * v['SQ_BUSY_CU_CYCLES'])
                 o["busy_cu_cycles"] = v['SQ_BUSY_CU_CYCLES']
             out[k] = o
         out['_meta'] = {"units": "fractions of SQ_WAVE_CYCLES (wave residency); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / "
-                                 "(4 SIMDs x SQ_BUSY_CU_CYCLES); valu_issue = SQ_INSTS_VALU x 4 cycles / (4 SIMDs x SQ_BUSY_CU_CYCLES), a lower bound on "
-                                 "the vector pipes' busy share", "probe_T": __import__('os').environ.get('PROBE_T', '1000'),
+                                 "(4 SIMDs x SQ_BUSY_CU_CYCLES); valu_issue = SQ_INSTS_VALU x the mix-weighted cycles per instruction "
+                                 "(tools/isa_mix.py) / (4 SIMDs x SQ_BUSY_CU_CYCLES)", "probe_T": __import__('os').environ.get('PROBE_T', '1000'),
                         "source_hash": _source_hash(),
                         # tools/pmc_probe.py: one 3-step launch, then five of PROBE_T steps, B = PROBE_B episodes: the average launch
                         # of the pass covers this many episode-steps (bench.py: VALU instructions per episode-step)
