@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MGP_VERSION 330            /* 0.2.0: + mgp_rollout_steps_ex / _image / _carry_*, mgp_rollout_collect, mgp_replay_gather;
+#define MGP_VERSION 334            /* 0.2.0: + mgp_rollout_steps_ex / _image / _carry_*, mgp_rollout_collect, mgp_replay_gather;
                                       0.2.1: + mgp_replay_gather_many; mgp_actor_fwd covers layer widths up to 128 at N <= 128;
                                       0.3.0: + mgp_p2p_* (one-shot gradient exchange), mgp_train_step_p2p, mgp_adam_step_filed;
                                       0.3.1: + mgp_rollout_f32ref_* (checker build of the resident kernels); a timed-out exchange
@@ -31,7 +31,13 @@ extern "C" {
                                       0.3.2: + mgp_replay_aggregate, mgp_train_step_agg / _grads_agg / _agg_supported (DAGGER updates on
                                              the aggregated first-layer input, operator slices never formed), mgp_flock_reset_check;
                                       0.3.3: + mgp_actor_fwd_deep / mgp_actor_deep_supported (inference with three or more hidden layers
-                                             beyond the one-launch LDS plan: hidden_size 128 at n_layers 3, 4) */
+                                             beyond the one-launch LDS plan: hidden_size 128 at n_layers 3, 4);
+                                      0.3.4: no new entry point.  mgp_rollout_steps_ex / _collect at the headline shape run 512-thread
+                                             workgroups, two episodes per CU, when B exceeds the device's CU count (same bits; MGP_RO_T512
+                                             = 0 / 1 forces the choice); mgp_rollout_supported / _steps_ex / _image cover two and more
+                                             hidden layers of up to 128 channels at (N, K) = (100, 3) -- those builds stream weight blocks
+                                             from the image every step and return MGP_EUNSUPPORTED without a prebuilt one;
+                                             mgp_train_step_p2p: timeout semantics spelled out (partial step; collective rollback is the caller's) */
 
 #define MGP_OK            0
 #define MGP_EINVAL       -1        /* bad size / null pointer / unsupported combination */
@@ -266,7 +272,11 @@ int mgp_rollout_steps(double* x, float* G, float* Xd, const float* const* W, con
  * With ENTER|EXIT the chain x_{t-j} A_t .. A_{t-j+1} never passes through rounded dense products, so ANY chunking of an
  * episode into launches is bit-identical to one launch.  A launch that enters from dense slices can only hand over a
  * complete history if it runs T >= K - 1 steps (else MGP_EINVAL with EXIT_CARRY / SKIP_DENSE).
- * x and Xd (B,K,6,N) are always read on entry and written on exit (they are exact: integration and features are fp64). */
+ * x and Xd (B,K,6,N) are always read on entry and written on exit (they are exact: integration and features are fp64).
+ * [0.3.4] Two and more hidden layers of more than 64 (up to 128) channels at (N, K) = (100, 3) stream weight blocks from `image`
+ * every step: image == NULL returns MGP_EUNSUPPORTED there (build it once with mgp_rollout_image; mgp_rollout_collect does not
+ * cover these shapes).  At the reference's policy shape a launch of more episodes than the device has CUs runs two episodes per
+ * CU on 512-thread workgroups -- same results bit for bit. */
 #define MGP_RO_ENTER_CARRY 1
 #define MGP_RO_EXIT_CARRY 2
 #define MGP_RO_SKIP_DENSE 4
