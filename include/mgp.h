@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MGP_VERSION 334            /* 0.2.0: + mgp_rollout_steps_ex / _image / _carry_*, mgp_rollout_collect, mgp_replay_gather;
+#define MGP_VERSION 340            /* 0.2.0: + mgp_rollout_steps_ex / _image / _carry_*, mgp_rollout_collect, mgp_replay_gather;
                                       0.2.1: + mgp_replay_gather_many; mgp_actor_fwd covers layer widths up to 128 at N <= 128;
                                       0.3.0: + mgp_p2p_* (one-shot gradient exchange), mgp_train_step_p2p, mgp_adam_step_filed;
                                       0.3.1: + mgp_rollout_f32ref_* (checker build of the resident kernels); a timed-out exchange
@@ -37,7 +37,9 @@ extern "C" {
                                              = 0 / 1 forces the choice); mgp_rollout_supported / _steps_ex / _image cover two and more
                                              hidden layers of up to 128 channels at (N, K) = (100, 3) -- those builds stream weight blocks
                                              from the image every step and return MGP_EUNSUPPORTED without a prebuilt one;
-                                             mgp_train_step_p2p: timeout semantics spelled out (partial step; collective rollback is the caller's) */
+                                             mgp_train_step_p2p: timeout semantics spelled out (partial step; collective rollback is the caller's)
+                                      0.4.0: + mgp_sparse_rollout_persistent / _status: mgp_sparse_rollout at K = 3, N <= 1024 runs its T
+                                             steps as ONE launch of persistent workgroups (bit-identical outputs; see there) */
 
 #define MGP_OK            0
 #define MGP_EINVAL       -1        /* bad size / null pointer / unsupported combination */
@@ -529,6 +531,18 @@ int  mgp_sparse_rollout(unsigned long long* bits, float* wrow, float* feat, cons
                         int n_layers, float* scratch, float* action, double* x_a, double* x_b, double* rewards,
                         float* expert, const MgpFlockParams* p, int B, int K, int N, int T, int* cur, int* hs,
                         const MgpSparseCollect* collect, unsigned short* nbr, void* stream);
+/* Persistent form (csrc/sparse_persist.hip; replaces the per-step launches of gnn_dagger.py:154-165 / test_model.py:38-44 for
+ * N > 256): where mgp_sparse_rollout_persistent(...) = 1 -- K = 3, N <= 1024, no link fading, <= 4 layers -- and the call has
+ * neighbour lists and no collection, the T steps run as ONE launch of workgroups that stay resident, keep the episode's feature
+ * rows / row weights / own list rows in LDS and hand each other only what a sibling lacks (write-through stores, one arrival
+ * counter per exchange) through the same state buffers: every output is bit-identical to the K-launch form; bit rows, list
+ * rows and x are written for the networks / the state that outlive the call.  A launch holds (CUs / ceil(N/256)) episodes
+ * (more: further launches); a workgroup whose siblings do not arrive within 3 s (CUs held by another process) gives up: the
+ * episode's action / state / rewards are NaN and mgp_sparse_rollout_status -- which synchronises `stream` -- returns
+ * MGP_ELAUNCH (MGP_OK otherwise; meaningful after a call that ran the persistent form).  MGP_SP_PERSIST=0 keeps the K-launch
+ * form.  The persistent form uses scratch[0 .. B N 8) and B * 16 words behind it. */
+int  mgp_sparse_rollout_persistent(const int* dims, int n_layers, int K, int N, const MgpFlockParams* p);
+int  mgp_sparse_rollout_status(const float* scratch, int B, int K, int N, void* stream);
 /* nbr (B,H,N,16) u16 or NULL: the networks of the bit-row ring once more as compact neighbour LISTS, kept in step with it by
  * the cell-list simulator (mgp_flock_step_cells_nbr; N <= 2048) and read by the gather / policy launches instead of the bit rows
  * (32 instead of 128 bytes per row to request at N = 1000, entries dealt evenly over a column's four lanes).  Row layout: up

@@ -121,6 +121,8 @@ SIGNATURES = {
     'mgp_sparse_policy_step': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     'mgp_sparse_to_dense': (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     'mgp_sparse_force_direct': (_int, [_int]),
+    'mgp_sparse_rollout_persistent': (_int, [_vp, _int, _int, _int, _vp]),
+    'mgp_sparse_rollout_status': (_int, [_vp, _int, _int, _int, _vp]),
     'mgp_sparse_rollout': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int,
                                   ctypes.POINTER(_int), ctypes.POINTER(_int), _vp, _vp, _vp]),
     'mgp_flock_step_cells_nbr': (_int, [_vp, _vp, _vp, _long, _long, _vp, _long, _vp, _long, _vp, _long, _vp, _long, _vp, _vp,

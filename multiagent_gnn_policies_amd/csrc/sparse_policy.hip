@@ -16,6 +16,7 @@
 #include "mgp_common.h"
 #include "mgp_device.h"
 #include "rollout_common.h"
+#include "sparse_common.h"
 
 namespace {
 
@@ -28,7 +29,6 @@ __device__ unsigned long long mgp_sp_stamps[2 * 16 * 16];  // [kernel][wave][sta
 
 constexpr int SP_THREADS = 256;
 constexpr int SP_COLS = 64;               // agent columns per workgroup: 4 lanes per column / one 16-column MFMA tile per wave
-constexpr int SP_MAXTAPS = 4;             // K <= 5
 
 // sum over the set bits m of `w` (base index `base`) of wq[m] * src[m][0..5]   (src rows are 8 floats)
 __device__ __forceinline__ void sp_gather_word(unsigned long long w, int base, const float* __restrict__ wq,
@@ -631,23 +631,6 @@ void sp_to_dense_kernel(const unsigned long long* __restrict__ bits, const float
 
 int sp_mode = 0;                          // mgp_sparse_force_direct: 0 default, 1 direct kernels, 2 staged kernels on bit rows only
 
-int sp_plan(const int* dims, int n_layers, int K, int* woff, int* wtot)
-{
-    if (dims == nullptr || n_layers < 1 || n_layers > MGP_MAX_LAYERS) return MGP_EINVAL;
-    if (K < 1 || K > SP_MAXTAPS + 1) return MGP_EUNSUPPORTED;
-    if (dims[0] != 6 || dims[n_layers] != 2) return MGP_EUNSUPPORTED;
-    int tot = 0;
-    for (int l = 0; l < n_layers; ++l) {
-        const int cin = (l == 0) ? 6 * K : dims[l], cout = dims[l + 1];
-        if (cin < 1 || cout < 1 || cin > 4 * RO_KS || cout > 4 * RO_KS) return MGP_EUNSUPPORTED;
-        woff[l] = tot;
-        tot += ro_weight_image_size(cout, l == n_layers - 1);
-        tot = (tot + 3) & ~3;
-    }
-    *wtot = tot;
-    return MGP_OK;
-}
-
 }  // namespace
 
 extern "C" int mgp_sparse_policy_supported(const int* dims, int n_layers, int K, int N)
@@ -853,6 +836,12 @@ extern "C" int mgp_sparse_rollout(unsigned long long* bits, float* wrow, float* 
     const int H = K > 2 ? K - 1 : 1;
     const int NW = mgp_sparse_words(N);
     int c = *cur, h = *hs;
+    if (collect == nullptr && T > 0) {                          // one launch of persistent workgroups where the shape is covered
+        const int rc = spp_rollout(bits, wrow, feat, image, dims, n_layers, scratch, action, x_a, x_b, rewards, expert, p, B, K, N,
+                                   T, c, h, sp_mode != 0 ? nullptr : nbr, static_cast<hipStream_t>(stream));
+        if (rc == MGP_OK) { *cur = (c + T) % K; *hs = (h + T) % H; return MGP_OK; }
+        if (rc != MGP_EUNSUPPORTED) return rc;
+    }
     MgpSparseCollect col = {};
     if (collect != nullptr) col = *collect;
     double* xs[2] = {x_a, x_b};

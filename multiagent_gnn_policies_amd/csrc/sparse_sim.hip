@@ -22,6 +22,7 @@
 #include "mgp_common.h"
 #include "mgp_device.h"
 #include "rollout_common.h"
+#include "sparse_common.h"
 
 namespace {
 
@@ -31,32 +32,6 @@ __device__ unsigned long long mgp_ss_stamps[16 * 16];     // [wave][stamp]
 #else
 #define SS_STAMP(i) do { } while (0)
 #endif
-
-constexpr int SS_THREADS = 1024;
-constexpr int SS_WAVES = SS_THREADS / 64;
-constexpr int SS_ROWS = SS_THREADS / 4;    // rows per workgroup: four lanes per row
-constexpr int SS_G = 32;                   // cells per axis, at most
-constexpr int SS_MAXN = 2048;              // two agents per thread in the load phase; LDS plan 154 KB at N = 2048
-
-__device__ __forceinline__ double ss_first_lane(double v)
-{
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)b);
-    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(b >> 32));
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-
-// inclusive prefix sum over the wave on the DPP path (row_shr 1, 2, 4, 8 inside rows of 16, then row_bcast15 / row_bcast31)
-__device__ __forceinline__ int ss_wave_scan(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);     // row_shr:1 (zeros shift in)
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);     // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);     // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);     // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast15 -> rows 1, 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast31 -> rows 2, 3
-    return v;
-}
 
 struct SsOut {
     unsigned long long* bits; float* wq; float* featT; long sBb, sWb, sTb;

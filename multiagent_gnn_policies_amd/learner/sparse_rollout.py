@@ -69,6 +69,12 @@ class SparseFlockState(object):
             ops._ptr(reward), ops._ptr(expert), ctypes.byref(sim._c), self.B, self.N, ops._stream())
         _lib.check(rc, 'mgp_flock_step_sparse')
 
+    def check_status(self):
+        """Synchronises; raises if an episode's persistent workgroups gave up waiting for each other in an earlier
+        mgp_sparse_rollout call on this state (csrc/sparse_persist.hip: CUs held by another process; its outputs are NaN)."""
+        rc = _lib.lib().mgp_sparse_rollout_status(ops._ptr(self.scratch), self.B, self.K, self.N, ops._stream())
+        _lib.check(rc, 'mgp_sparse_rollout_status')
+
     def observe_reset(self, sim):
         """Start at the simulator's current x as a freshly reset episode (no history)."""
         self.bits.zero_(); self.wrow.zero_(); self.feat.zero_()
@@ -93,6 +99,7 @@ class SparseFlockState(object):
         """Materialise the reference's dense state into `state` (BatchedDelayState): delay_state from the feature ring now,
         delay_gso slices 1..K-1 from the bit rows now or -- lazy -- when somebody reads them (state.delay_gso /
         sim.network: 12 MB per episode at N = 1000, 180 us for 64 episodes), and point the simulator's observation views at them."""
+        self.check_status()
         X = state._X[state._cur]
         for k in range(self.K):                                 # (K small strided copies; no index tensor: that would be an H2D)
             X[:, k].copy_(self.feat[:, (self.cur - k) % self.K, :, :6].transpose(1, 2))

@@ -32,7 +32,7 @@ def test_library_loads_and_exports_every_header_symbol():
     for name in declared:
         assert hasattr(handle, name), "libmgp.so does not export %s declared in include/mgp.h" % name
     assert set(declared) == set(_lib.SIGNATURES), "ctypes signature table out of sync with include/mgp.h"
-    assert handle.mgp_version() == 334
+    assert handle.mgp_version() == 340
     assert _lib.strerror(0) == 'ok'
     assert 'invalid' in _lib.strerror(-1)
 

@@ -203,3 +203,55 @@ def test_neighbour_lists_mirror_the_bit_rows():
                     assert cnt == len(want) and set(got) == want and len(set(got)) == cnt
                     n_list += 1
         assert (n_over == 0 and n_list == B * N) if scale == 1.0 else n_over > 0
+
+
+@pytest.mark.parametrize('N,hidden,B,scale,variant', [
+    (300, (32, 32), 3, 1.0, {}),
+    (1000, (32, 32), 2, 1.0, {}),
+    (700, (32,), 2, 1.0, {'mean_pooling': False, 'n_leaders': 2}),
+    (1000, (32, 32), 2, 0.45, {}),                 # contracted flock: degrees beyond the 15-entry lists (bit-row fallback)
+    (520, (16, 32, 8), 2, 1.0, {'comm_radius': 1.4}),
+    (300, (32, 32), 131, 1.0, {}),                 # more episodes than one launch of resident workgroups holds (256 CUs / 2 tiles)
+])
+def test_persistent_factored_rollout_is_bit_identical(N, hidden, B, scale, variant, monkeypatch):
+    """mgp_sparse_rollout at K = 3, N <= 1024 runs its T steps as ONE launch of persistent workgroups (csrc/sparse_persist.hip:
+    the episode's rows stay in LDS, siblings exchange through the state buffers behind arrival counters).  Same arithmetic in
+    the same order: actions, rewards, the fp64 state and every ring -- features, row weights, bit rows, list rows -- equal the
+    K-launch form's bit for bit, in one call and chunked (odd first chunk: the second call starts from the other x buffer)."""
+    import ctypes
+    from multiagent_gnn_policies_amd import _lib
+    from multiagent_gnn_policies_amd.learner.sparse_rollout import SparseFlockState, sparse_policy_rollout
+    K, T = 3, 7
+    outs = []
+    for mode in ('launches', 'persistent', 'persistent_chunked'):
+        monkeypatch.setenv('MGP_SP_PERSIST', '0' if mode == 'launches' else '1')
+        rs, op, actor, sim, st = _make(N, K, hidden, B, seed=N + 1, **variant)
+        dims = tuple(actor.layers)
+        cd = (ctypes.c_int * len(dims))(*dims)
+        assert _lib.lib().mgp_sparse_rollout_persistent(cd, len(dims) - 1, K, N, ctypes.byref(sim._c)) == (0 if mode == 'launches' else 1)
+        if scale != 1.0:
+            x = sim.x.clone(); x[:, :, :2] *= scale; sim.x.copy_(x)
+        sp = SparseFlockState(sim, K)
+        sp.observe_reset(sim)
+        action = torch.zeros((B, 1, 2, N), device='cuda')
+        rewards = torch.zeros((B, T), device='cuda', dtype=torch.float64)
+        if mode == 'persistent_chunked':
+            r1 = torch.zeros((B, 3), device='cuda', dtype=torch.float64); r2 = torch.zeros((B, 4), device='cuda', dtype=torch.float64)
+            sparse_policy_rollout(actor, sim, sp, 3, rewards=r1, action=action)
+            sparse_policy_rollout(actor, sim, sp, 4, rewards=r2, action=action)
+            rewards[:, :3] = r1; rewards[:, 3:] = r2
+        else:
+            sparse_policy_rollout(actor, sim, sp, T, rewards=rewards, action=action)
+        sp.check_status()
+        assert torch.isfinite(action).all() and torch.isfinite(rewards).all() and float(action.abs().max()) > 0
+        outs.append(dict(x=sim.x.clone(), action=action.clone(), rewards=rewards.clone(), bits=sp.bits.clone(), wrow=sp.wrow.clone(),
+                         feat=sp.feat.clone(), nbr=sp.nbr.clone(), expert=sim.expert.clone() if sim.with_expert else None,
+                         slots=(sp.cur, sp.hs)))
+    if scale != 1.0:
+        assert (outs[0]['nbr'][:, :, :, 15].to(torch.int32) & 0xFFFF).eq(0xFFFF).any(), "the contracted flock must overflow some lists"
+    for other in outs[1:]:
+        for k, v in outs[0].items():
+            if k == 'slots':
+                assert v == other[k]
+            elif v is not None:
+                assert torch.equal(v, other[k]), "%s differs between the K-launch and the persistent form" % k
