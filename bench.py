@@ -157,9 +157,18 @@ class Rollout(object):
         return ops.rollout_supported(tuple(self.actor.layers), self.K, self.N)
 
     def factored_supported(self):
-        """N > 256: the factored state in HBM (learner/sparse_rollout.py), K launches per step."""
+        """N > 256: the factored state in HBM (learner/sparse_rollout.py); one persistent launch per call where
+        factored_persistent(), else K launches per step."""
         from multiagent_gnn_policies_amd.learner.sparse_rollout import sparse_supported
         return self.N > 256 and sparse_supported(self.actor, self.K, self.N)
+
+    def factored_persistent(self):
+        """Does mgp_sparse_rollout run this shape as ONE launch of persistent workgroups (csrc/sparse_persist.hip)?"""
+        import ctypes
+        from multiagent_gnn_policies_amd import _lib
+        dims = tuple(self.actor.layers)
+        cd = (ctypes.c_int * len(dims))(*dims)
+        return bool(_lib.lib().mgp_sparse_rollout_persistent(cd, len(dims) - 1, self.K, self.N, ctypes.byref(self.sim._c)))
 
     def restart(self, seed):
         """Back to a reset observation (the factored path starts where the history is known)."""
@@ -569,8 +578,13 @@ def main():
             "config": {"workload": "%s N=%d K=%d, %d parallel episodes per MI355X "
                                    "(BASELINE.json configs[1]); per step: Actor forward (hidden %s) -> action -> "
                                    "sim step -> delayed-GSO / delay-line update" % (args.env, N, K, B, hidden),
-                       "step_path": ("factored: state as bit rows / feature ring in HBM, K launches per step "
-                                     "(mgp_sparse_rollout: simulator + gather + policy launches); the dense delay_gso of the contract is "
+                       "step_path": (("factored, persistent form: state as bit rows / list rows / feature ring in HBM, every "
+                                      "mgp_sparse_rollout call ONE launch of workgroups that stay resident for its steps (an episode's "
+                                      "feature rows, row weights and own list rows in LDS; siblings exchange through the state buffers "
+                                      "behind arrival counters; bit-identical to the K-launch form); the dense delay_gso of the contract is "
+                                      if ro.factored_persistent() else
+                                      "factored: state as bit rows / feature ring in HBM, K launches per step "
+                                      "(mgp_sparse_rollout: simulator + gather + policy launches); the dense delay_gso of the contract is ") +
                                      "rebuilt on first read (mgp_sparse_to_dense, ~180 us per 64 x 1000 state), i.e. AFTER and outside "
                                      "the timed region -- as the resident path defers its dense slices (RO_SKIP_DENSE)")
                                     if factored else

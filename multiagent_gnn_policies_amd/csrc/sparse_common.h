@@ -12,6 +12,7 @@ constexpr int SS_ROWS = SS_THREADS / 4;    // rows per workgroup: four lanes per
 constexpr int SS_G = 32;                   // cells per axis, at most
 constexpr int SS_MAXN = 2048;              // two agents per thread in the load phase; LDS plan 154 KB at N = 2048
 constexpr int SP_MAXTAPS = 4;              // K <= 5
+constexpr int SS_SUBCAP = 8;               // hits a lane of the row search can note (sp_sim_kernel and the persistent form alike)
 
 __device__ __forceinline__ double ss_first_lane(double v)
 {

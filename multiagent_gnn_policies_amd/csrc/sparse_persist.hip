@@ -47,7 +47,7 @@ __device__ unsigned long long mgp_pp_stamps[16 * 32];     // [wave][stamp], work
 
 constexpr int PP_THREADS = 1024;
 constexpr int PP_ROWS = 256;               // rows / columns per workgroup: four lanes each
-constexpr int PP_SUBCAP = 8;               // hits a lane of the row search can note (a row's list holds 15)
+constexpr int PP_SUBCAP = SS_SUBCAP;       // hits a lane of the row search can note (a row's list holds 15)
 constexpr int PP_K = 3;
 constexpr long long PP_TIMEOUT = 300000000ll;   // wall_clock64 ticks (100 MHz): 3 s
 
@@ -248,23 +248,20 @@ void spp_rollout_kernel(PpArgs A)
             *reinterpret_cast<uint4*>(lists + ((size_t)t * PP_ROWS + r) * 16 + 8 * hf) = v;
         }
     }
+    for (int i = tid; i < PP_ROWS * RO_CS / 4; i += PP_THREADS) reinterpret_cast<float4*>(act)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     int rs1 = 0;                                               // ring slot of tap 1 (x_{t-1}); tap 2 in the other
     int ws = 0;                                                // lw / lists slot of A_t; A_{t-1} in the other
     bool alive = true;
 
     for (int s = 0; s < A.T; ++s) {
 #ifdef MGP_SP_PROFILE
-        stamp_on = (s == A.T - 1) && tile == 1 && ep == 3;
+        stamp_on = (s == (A.T > 4 ? A.T - 4 : 0)) && tile == 1 && ep == 3;
 #endif
         const int nc = (cur + 1) % K, nh = (hs + 1) % H;
         const unsigned int target = (unsigned int)(tiles * (s + 1));
         const bool last_h = s >= A.T - H;                      // this step's network outlives the call
         PP_STAMP(0);
         // ================= gather stage 1: taps 1, 2 times A_t =================
-        {
-            float4* za = reinterpret_cast<float4*>(act);
-            for (int i = tid; i < PP_ROWS * RO_CS / 4; i += PP_THREADS) za[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
         __syncthreads();                                        // act is zero; lw / lists / ring of this step are complete
         {
             const uint2 lst = *reinterpret_cast<const uint2*>(lists + ((size_t)ws * PP_ROWS + gc) * 16 + 4 * part);
@@ -284,7 +281,9 @@ void spp_rollout_kernel(PpArgs A)
         }
         PP_STAMP(1);
         pp_arrive(ctr + 0);
-        {   // ring: x_t (published one exchange round ago, or by the previous launch) replaces x_{t-2}
+        {   // ring: x_t (published one exchange round ago, or by the previous launch) replaces x_{t-2}.  (Requested in front of
+            // the arrival -- one round trip for the store drain and these loads -- or behind exchange (c) and held in registers
+            // through the gather: both measured SLOWER, 26.5 -> 30.4 us per step; the kernel sits at its 128-VGPR limit.)
             const float* src = feat_b + (size_t)cur * N * 8;
             float* dst = ring + (size_t)(rs1 ^ 1) * N * 6;
             for (int i = tid; i < 3 * N; i += PP_THREADS) {
@@ -368,6 +367,7 @@ void spp_rollout_kernel(PpArgs A)
 #pragma clang fp contract(off)
             float aux = 0.f, auy = 0.f;
             if (in && tid >= p.n_leaders) { aux = pp_ld1(act_b + tid); auy = pp_ld1(act_b + N + tid); }
+            PP_STAMP(14);
             for (int c = tid; c < SS_G * SS_G + 2; c += PP_THREADS) start[c] = 0;
             double sum_vx = 0.0, sum_vy = 0.0;
             float bnx = -3e38f, bxx = -3e38f, bny = -3e38f, bxy = -3e38f;
@@ -387,6 +387,7 @@ void spp_rollout_kernel(PpArgs A)
                 const float m0 = wave_max_to_last(bnx), m1 = wave_max_to_last(bxx), m2 = wave_max_to_last(bny), m3 = wave_max_to_last(bxy);
                 if (lane == 63) { red[wave][0] = s0; red[wave][1] = s1; redf[wave] = make_float4(m0, m1, m2, m3); }
             }
+            PP_STAMP(15);
             __syncthreads();
             double tot_vx, tot_vy, mnx, mxx, mny, mxy;
             {
@@ -407,6 +408,7 @@ void spp_rollout_kernel(PpArgs A)
                 mnx = -((double)nx + 2.4e-7 * fabs((double)nx) + 1e-30); mxx = (double)xx + 2.4e-7 * fabs((double)xx) + 1e-30;
                 mny = -((double)ny + 2.4e-7 * fabs((double)ny) + 1e-30); mxy = (double)xy + 2.4e-7 * fabs((double)xy) + 1e-30;
             }
+            PP_STAMP(16);
             const bool does_reward = A.rewards != nullptr && tile == 0;
             if (does_reward) {                                  // spec section 4: population variance, two passes
                 const double mvx = tot_vx / (double)N, mvy = tot_vy / (double)N;
@@ -424,6 +426,7 @@ void spp_rollout_kernel(PpArgs A)
             const int gx = max(1, (int)fmin((double)SS_G, floor(ex_ / R)));
             const int gy = max(1, (int)fmin((double)SS_G, floor(ey_ / R)));
             const double iwx = (ex_ > 0.0) ? (double)gx / ex_ : 0.0, iwy = (ey_ > 0.0) ? (double)gy / ey_ : 0.0;
+            const float cwf = (float)fmax(ex_ / (double)gx, ey_ / (double)gy);
             int myc = 0;
             if (in) {
                 int cx = (int)((px - mnx) * iwx), cy = (int)((py - mny) * iwy);
@@ -432,6 +435,7 @@ void spp_rollout_kernel(PpArgs A)
                 cid[tid] = (unsigned short)myc;
                 atomicAdd(&start[myc + 1], 1);
             }
+            PP_STAMP(17);
             __syncthreads();
             if (does_reward && tid == 0) {
                 double var = 0.0;
@@ -451,9 +455,11 @@ void spp_rollout_kernel(PpArgs A)
                 start[tid + 1] = base + inc;
                 cursor[tid] = base + inc - cnt;
             }
+            PP_STAMP(18);
             __syncthreads();
             if (in) tmp[atomicAdd(&cursor[myc], 1)] = (unsigned short)tid;
             __syncthreads();
+            PP_STAMP(19);
             if (in) {
                 const int s0 = start[myc], s1 = start[myc + 1];
                 int rank = 0;
@@ -486,7 +492,6 @@ void spp_rollout_kernel(PpArgs A)
                 unsigned short* mine = sub + (size_t)tid * PP_SUBCAP;
                 int cnt = 0;
                 const float xif = (float)xi, yif = (float)yi, R2f = (float)R2;
-                const float cwf = (float)fmax(ex_ / (double)gx, ey_ / (double)gy);
                 const float Rf = (float)R;
                 const float band = 2.384185791015625e-07f * 4.f * Rf * (2.f * fmaxf(fabsf(xif), fabsf(yif)) + 3.f * cwf + Rf) + 1e-30f;
                 for (int dy = -1; dy <= 1; ++dy) {
@@ -527,38 +532,21 @@ void spp_rollout_kernel(PpArgs A)
                     if (last_h)
                         *reinterpret_cast<uint2*>(nbr_b + ((size_t)nh * N + i) * 16 + 4 * part) = *reinterpret_cast<const uint2*>(lrow + 4 * part);
                 }
-                if (last_h || !fits) {                          // the bit row: this lane's quarter of its words
+                unsigned long long* gb = bits_b + ((size_t)nh * N + i) * NW;
+                if ((last_h || !fits) && cmax <= PP_SUBCAP) {   // the bit row from the lanes' lists: this lane's quarter of its words
                     unsigned long long bw[4] = {0ull, 0ull, 0ull, 0ull};
                     const int w0 = part * wpl;
-                    if (cmax <= PP_SUBCAP) {
-                        for (int e = 0; e < tot; ++e) {
-                            int k = e, sl = 0;
-                            if (k >= c0) { k -= c0; sl = 1; if (k >= c1) { k -= c1; sl = 2; if (k >= c2) { k -= c2; sl = 3; } } }
-                            const int j = rowsub[sl * PP_SUBCAP + k];
-                            const int wd = (j >> 6) - w0;
-                            const unsigned long long bit = 1ull << (j & 63);
+                    for (int e = 0; e < tot; ++e) {
+                        int k = e, sl = 0;
+                        if (k >= c0) { k -= c0; sl = 1; if (k >= c1) { k -= c1; sl = 2; if (k >= c2) { k -= c2; sl = 3; } } }
+                        const int j = rowsub[sl * PP_SUBCAP + k];
+                        const int wd = (j >> 6) - w0;
+                        const unsigned long long bit = 1ull << (j & 63);
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) bw[q] |= (wd == q) ? bit : 0ull;
-                        }
-                    } else {                                    // a lane's list overflowed: every lane tests every candidate
-                        for (int dy = -1; dy <= 1; ++dy) {
-                            const int yy = cy + dy;
-                            if (yy < 0 || yy >= gy) continue;
-                            const int s0 = start[yy * gx + xa], s1 = start[yy * gx + xz + 1];
-                            for (int a = s0; a < s1; ++a) {
-                                const int j = sorted[a];
-                                const double dx = xi - spx[j], dyy = yi - spy[j];
-                                if (j == i || !(dx * dx + dyy * dyy < R2)) continue;
-                                const int wd = (j >> 6) - w0;
-                                const unsigned long long bit = 1ull << (j & 63);
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) bw[q] |= (wd == q) ? bit : 0ull;
-                            }
-                        }
+                        for (int q = 0; q < 4; ++q) bw[q] |= (wd == q) ? bit : 0ull;
                     }
-                    unsigned long long* gb = bits_b + ((size_t)nh * N + i) * NW + w0;
-                    *reinterpret_cast<ulonglong2*>(gb) = make_ulonglong2(bw[0], bw[1]);
-                    if (wpl > 2) *reinterpret_cast<ulonglong2*>(gb + 2) = make_ulonglong2(bw[2], bw[3]);
+                    *reinterpret_cast<ulonglong2*>(gb + w0) = make_ulonglong2(bw[0], bw[1]);
+                    if (wpl > 2) *reinterpret_cast<ulonglong2*>(gb + w0 + 2) = make_ulonglong2(bw[2], bw[3]);
                 }
                 // Pass 2: the row's hits -- the four lists one after the other -- dealt round-robin to the four lanes
                 if (cmax <= PP_SUBCAP) {
@@ -570,6 +558,11 @@ void spp_rollout_kernel(PpArgs A)
                         terms(j, dx, dyy, dx * dx + dyy * dyy);
                     }
                 } else {
+                    // a lane's list overflowed (a dense flock): every lane walks its candidates again -- for the feature terms
+                    // and for the bit row (such a row always needs one: its gathers read it), OR-ed into the zeroed row in HBM
+                    *reinterpret_cast<ulonglong2*>(gb + part * wpl) = make_ulonglong2(0ull, 0ull);
+                    if (wpl > 2) *reinterpret_cast<ulonglong2*>(gb + part * wpl + 2) = make_ulonglong2(0ull, 0ull);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the quad's zeros have landed before anybody's bit
                     for (int dy = -1; dy <= 1; ++dy) {
                         const int yy = cy + dy;
                         if (yy < 0 || yy >= gy) continue;
@@ -580,6 +573,7 @@ void spp_rollout_kernel(PpArgs A)
                             const double r2 = dx * dx + dyy * dyy;
                             if (j == i || !(r2 < R2)) continue;
                             terms(j, dx, dyy, r2);
+                            __hip_atomic_fetch_or(gb + (j >> 6), 1ull << (j & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }
                 }
@@ -609,11 +603,13 @@ void spp_rollout_kernel(PpArgs A)
         PP_STAMP(10);
         pp_arrive(ctr + 2);
         PP_STAMP(11);
+        // (in the shadow of the exchange: the next step's activation tile; the simulator's scratch is dead behind the arrival's barrier)
+        for (int i = tid; i < PP_ROWS * RO_CS / 4; i += PP_THREADS) reinterpret_cast<float4*>(act)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         alive = pp_wait(ctr + 2, target, err, &s_dead);
         if (!alive) break;
         PP_STAMP(12);
-        for (int i = tid; i < N; i += PP_THREADS)               // the siblings' row weights of A_{t+1}
-            if (i < i0 || i >= i0 + PP_ROWS) lwr[(ws ^ 1) * Np + i] = pp_ld1(wrow_b + (size_t)nh * N + i);
+        if (in && (tid < i0 || tid >= i0 + PP_ROWS))             // the siblings' row weights of A_{t+1}
+            lwr[(ws ^ 1) * Np + tid] = pp_ld1(wrow_b + (size_t)nh * N + tid);
         cur = nc; hs = nh; ws ^= 1; rs1 ^= 1;
         PP_STAMP(13);
     }

@@ -401,10 +401,13 @@ extern "C" int mgp_flock_step_cells_nbr(const double* x, double* x_out, const fl
     const int N4 = (N + 3) & ~3;
     const size_t lds0 = (size_t)4 * N * 8 + (size_t)(SS_G * SS_G + 2 + SS_G * SS_G) * 4 + (size_t)3 * N4 * 2 + 8
                         + (size_t)SS_ROWS * (NW + 1) * 8;
-    // per-lane hit lists of the row search: 16 entries where the LDS has room, else 8, else none (single-pass fallback);
-    // fp32 positions for the pre-filter of the membership tests where they fit besides
+    // per-lane hit lists of the row search: SS_SUBCAP = 8 entries where the LDS has room (a row's list holds 15), else none
+    // (single-pass fallback); fp32 positions for the pre-filter of the membership tests where they fit besides.
+    // [r6] 8, not 16, wherever the lists exist: which rows fall back -- to the second walk for their feature sums, to the bit
+    // row in the gathers -- depends on this number, and the persistent form (sparse_persist.hip: 8, its LDS is full) must
+    // make the same choice row for row to stay bit-identical.
     const size_t cap_lds = 160 * 1024;
-    const int subcap = (lds0 + (size_t)SS_THREADS * 16 * 2 <= cap_lds) ? 16 : ((lds0 + (size_t)SS_THREADS * 8 * 2 <= cap_lds) ? 8 : 0);
+    const int subcap = (lds0 + (size_t)SS_THREADS * SS_SUBCAP * 2 <= cap_lds) ? SS_SUBCAP : 0;
     const size_t lds1a = lds0 + (size_t)SS_THREADS * subcap * 2 + 8;
     const bool nbl_on = nbr != nullptr && subcap > 0 && lds1a + (size_t)SS_ROWS * 16 * 2 <= cap_lds;
     const size_t lds1 = lds1a + (nbl_on ? (size_t)SS_ROWS * 16 * 2 : 0);

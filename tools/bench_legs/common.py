@@ -57,6 +57,12 @@ def pmc_traffic_factored(B, N, K):
         return None, 'no committed PMC pass of the factored kernels'
     if d.get('_meta', {}).get('shape') != [B, N, K]:
         return None, 'committed PMC pass is for shape %s' % (d.get('_meta', {}).get('shape'),)
+    if 'spp_rollout_kernel' in d:                               # the persistent form: one launch per call of FT steps
+        ft = float(d['_meta'].get('factored_steps_per_launch', 200))
+        k = d['spp_rollout_kernel']
+        return k['total_bytes'] / ft, ('profiles/%s_pmc_traffic_factored.json (spp_rollout_kernel: %.1f MB read + %.1f MB written per '
+                                       'launch of %d steps, entry and exit included)' % (PROFILE_ROUND, k['read_bytes'] / 1e6,
+                                                                                         k['write_bytes'] / 1e6, ft))
     tot, parts = 0.0, []
     for k, per_step in (('sp_sim_kernel', 1), ('spl_gather_kernel', max(K - 2, 0)), ('spl_policy_kernel', 1)):
         if per_step and k in d:

@@ -155,19 +155,22 @@ def roofline_blocks(device, B, N, K, hidden, actor, flock_c, mode, steps, res_la
         req = (sim_b + gather_b + policy_b) * B
         ms_step = 1e3 * el_fact / steps
         trf, trf_note = pmc_traffic_factored(B, N, K)
+        persistent = 'spp_rollout_kernel' in (trf_note or '')
         roof = {
-            "kernel": "factored step: sp_sim_kernel + %d x spl_gather_kernel + spl_policy_kernel (%d launches per env step)"
-                      % (max(K - 2, 0), max(K, 2)),
+            "kernel": ("factored step inside spp_rollout_kernel (one launch of persistent workgroups per call; gather stage, policy "
+                       "tail and cell-list simulator as phases behind three sibling exchanges per step)" if persistent else
+                       "factored step: sp_sim_kernel + %d x spl_gather_kernel + spl_policy_kernel (%d launches per env step)"
+                       % (max(K - 2, 0), max(K, 2))),
             "bound": "hbm", "achieved": req / ms_step / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": req / ms_step / 1e6 / HBM_PEAK_GBS, "traffic": trf, "traffic_source": trf_note,
             "required_bytes_per_step": req,
             "required_bytes_per_episode_step": {"simulator": sim_b, "gather_stages": gather_b, "policy_tail": policy_b},
             "avg_step_ms": ms_step,
             "note": "bytes the factored state REQUIRES per env step (bit rows, lists, row weights, feature rings, agent "
-                    "states: each array once) / wall time per step of the timed region / 8 TB/s.  The path is latency-, not "
-                    "bandwidth-bound: every launch starts with the wait for the rows the previous launch wrote on other "
-                    "XCDs (profiles/%s_factored_step_stamps.txt); the dense-contract bytes of this shape would be %.0f MB "
-                    "per step" % (PROFILE_ROUND, (4 * K * N * N + 8 * K * F_FEAT * N) * B / 1e6),
+                    "states: each array once, as the K-launch form defines them) / wall time per step of the timed region / 8 TB/s.  "
+                    "The path is latency-, not bandwidth-bound: three sibling exchanges and a dependent chain of phases per "
+                    "step (profiles/%s_factored_step_stamps.txt); `traffic` = PMC bytes per env step; the dense-contract "
+                    "bytes of this shape would be %.0f MB per step" % (PROFILE_ROUND, (4 * K * N * N + 8 * K * F_FEAT * N) * B / 1e6),
             "dense_kernels": dense}
         return roof, _kernels(res)
     return dict(dense["actor_fwd" if fused else "agg_fwd"], dense_kernels=dense), _kernels(res)

@@ -8,6 +8,8 @@ hipcc $F -o scratch/ro_prof tools/harness/ro_phase_prof.hip multiagent_gnn_polic
 hipcc $F -o scratch/ro_launch tools/harness/ro_launch_prof.hip multiagent_gnn_policies_amd/csrc/rollout_t512.hip &
 hipcc $F -o scratch/sp_prof tools/harness/sp_step_prof.hip &
 hipcc $F -DMGP_SP_PROFILE -o scratch/sp_prof_stamps tools/harness/sp_step_prof.hip &
+hipcc $F -o scratch/sp_persist tools/harness/sp_persist_check.hip &
+hipcc $F -DMGP_SP_PROFILE -o scratch/sp_persist_stamps tools/harness/sp_persist_check.hip &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -w -o scratch/ts_prof tools/harness/train_phase_prof.hip &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -Imultiagent_gnn_policies_amd/csrc -o scratch/stream_floor tools/harness/stream_floor.hip &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -DMGP_AF_MLP_STAMPS -o scratch/af_prof tools/harness/af_phase_prof.hip &

@@ -143,10 +143,11 @@ int main(int argc, char** argv)
         hipMemcpyFromSymbol(st, HIP_SYMBOL(mgp_pp_stamps), sizeof(st));
         const char* names[] = {"step start", "gather stage 1 done, stores issued", "arrived (a), ring refill done", "exchange (a) complete", "siblings' rows in LDS",
                                "tail gather done (barrier)", "MLP done, action stored", "arrived (b)", "exchange (b) complete", "cell list built", "row search done, outputs stored",
-                               "arrived (c)", "exchange (c) complete", "siblings' weights in LDS"};
+                               "arrived (c)", "exchange (c) complete", "siblings' weights in LDS", "sim: action requested", "sim: integrated, wave reductions", "sim: block reductions (barrier)",
+                               "sim: grid + histogram issued", "sim: scan done", "sim: scattered (barrier)"};
         const int wv[] = {0, 5, 10, 15};
-        printf("spp_rollout_kernel, workgroup (tile 1, episode 3), last step: cycles since the step's start, lane 0 of waves 0 5 10 15\n");
-        for (int i = 0; i < 14; ++i) { printf("  stamp %2d :", i); for (int w = 0; w < 4; ++w) printf(" %7lld", (long long)(st[wv[w] * 32 + i] - st[0])); printf("  %s\n", names[i]); }
+        printf("spp_rollout_kernel, workgroup (tile 1, episode 3), a steady-state step (T - 4): cycles since the step's start, lane 0 of waves 0 5 10 15\n");
+        for (int i = 0; i < 20; ++i) { printf("  stamp %2d :", i); for (int w = 0; w < 4; ++w) printf(" %7lld", (long long)(st[wv[w] * 32 + i] - st[0])); printf("  %s\n", names[i]); }
     }
 #endif
     return fails ? 2 : 0;

@@ -3,6 +3,7 @@
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o scratch/sp_prof tools/harness/sp_step_prof.hip && ./scratch/sp_prof 64 1000 3 100
 #include "../../multiagent_gnn_policies_amd/csrc/sparse_sim.hip"
 #include "../../multiagent_gnn_policies_amd/csrc/sparse_policy.hip"
+#include "../../multiagent_gnn_policies_amd/csrc/sparse_persist.hip"   // (mgp_sparse_rollout links against it; this harness keeps the K-launch form)
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -13,6 +14,7 @@ extern "C" int mgp_flock_step_sparse(const double*, double*, const float*, long,
                                      double*, float*, const MgpFlockParams*, int, int, void*) { return MGP_EUNSUPPORTED; }   // (flock.hip is not linked here)
 extern "C" int mgp_sparse_words(int N) { return N <= 0 ? 0 : 8 * (((((N + 7) / 8) + 63) & ~63) / 64); }
 int main(int argc, char** argv) {
+    setenv("MGP_SP_PERSIST", "0", 1);                        // one call per step here: the K launches are what is timed
     int B = argc > 1 ? atoi(argv[1]) : 64, N = argc > 2 ? atoi(argv[2]) : 1000, K = argc > 3 ? atoi(argv[3]) : 3;
     int T = argc > 4 ? atoi(argv[4]) : 100;
     const int side = (int)ceil(sqrt((double)N));

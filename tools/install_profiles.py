@@ -77,13 +77,17 @@ for name in ('dagger_round_1rank.json', 'dagger_round_2ranks_shared_gpu.json', '
 
 if os.path.exists(O + '/factored_step_stamps.txt'):
     open('profiles/%s_factored_step_stamps.txt' % R, 'w').write(
-        "# tools/harness/sp_step_prof.hip on MI355X: the factored-state step (N > 256) -- gather stage(s), policy tail, cell-list simulator --\n"
+        "# tools/harness/sp_persist_check.hip on MI355X: the factored-state rollout (N > 256) as ONE launch of persistent workgroups\n"
+        "# (csrc/sparse_persist.hip) against the K-launch form on the same state -- every output buffer compared bit for bit, both timed,\n"
+        "# in-kernel stamps of a steady-state step; args: episodes agents steps-per-call [lattice pitch / radius: 0.3 = a contracted flock].\n"
+        "# Below the separator, tools/harness/sp_step_prof.hip: the K-launch form one call per step -- gather stage(s), policy tail, cell-list simulator --\n"
         "# on a hash-permuted jittered lattice (neighbours not adjacent in index).  First block: in-kernel s_memtime stamps (shader cycles) of\n"
         "# workgroup (tile 1, episode 3), lane 0 of waves 0 / 5 / 10 / 15, last step; then the unstamped build at 64 x 1000 (K = 3), 256 x 300, 64 x 1000 (K = 4).\n"
         "# Round 2's kernels on the same harness state: 49.6 us per step (simulator 25.2, policy tail 13.7, gather 10.5).\n"
         + open(O + '/factored_step_stamps.txt').read())
     open('profiles/%s_factored_kernel_trace.txt' % R, 'w').write(
-        "# rocprofv3 --kernel-trace --stats of `scratch/sp_prof 64 1000 3 200` (the harness above), then bench.py at the cfg-3 shape\n"
+        "# rocprofv3 --kernel-trace --stats of `scratch/sp_persist 64 1000 100` (both forms; spp_rollout_kernel = 100 steps per launch) and of\n"
+        "# `scratch/sp_prof 64 1000 3 200` (the K-launch form, one call per step), then bench.py at the cfg-3 shape\n"
         "# (jittered-lattice resets ordered by radius: FlockParams.init_mode 'auto' at N > 100) at 100 and 500 steps per policy_rollout call\n"
         + open(O + '/factored_kernel_trace.txt').read())
     for n in ('n1000', 'n300'):

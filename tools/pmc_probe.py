@@ -25,10 +25,13 @@ def main():
         # the factored path (N > 256): simulator + gather + policy launches of 200 env steps at BASELINE configs[2]'s shape
         ro = bench.Rollout(dev, B, N, K, [32, 32], seed=1000)
         assert ro.factored_supported()
-        ro.run_resident(20)
-        ro.run_resident(200)
+        # [r6] six calls of PROBE_FT steps each (the first enters from the reset observation): where the persistent form covers
+        # the shape every call is ONE launch of spp_rollout_kernel, whose bytes per launch / PROBE_FT are the bytes per env step
+        FT = int(os.environ.get('PROBE_FT', '200'))
+        for _ in range(6):
+            ro.run_resident(FT)
         torch.cuda.synchronize()
-        print('factored path: 200 env steps at', B, 'x', N)
+        print('factored path: 6 calls of', FT, 'env steps at', B, 'x', N)
         return
     actor = Actor(6, 2, [32, 32], K, 0).to(dev)
     bench.load_weights(actor)

@@ -57,6 +57,7 @@ def main():
         from multiagent_gnn_policies_amd import build as mgp_build
         shape = [int(v) for v in sys.argv[4].split(',')] if len(sys.argv) > 4 else [256, 100, 3]
         res['_meta'] = {'shape': shape, 'source_hash': mgp_build.source_hash(), 'rollout_steps_per_launch': int(os.environ.get('PROBE_T', '1000')),
+                        'factored_steps_per_launch': int(os.environ.get('PROBE_FT', '200')),
                         'note': 'bytes per launch; read = 2 x FETCH_SIZE KiB, write = WRITE_SIZE KiB'}
         with open(sys.argv[3], 'w') as f:
             json.dump(res, f, indent=1)

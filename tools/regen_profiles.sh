@@ -19,7 +19,7 @@ export PROBE_T=20
 PROBE_ROLLOUT_ONLY=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch20 -o fetch -- python $R/tools/pmc_probe.py > $O/pmc_fetch20.log 2>&1
 PROBE_ROLLOUT_ONLY=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write20 -o write -- python $R/tools/pmc_probe.py > $O/pmc_write20.log 2>&1
 export PROBE_T=1000
-# the factored path (BASELINE configs[2]: 64 x 1000): bytes per launch of its three kernels
+# the factored path (BASELINE configs[2]: 64 x 1000): bytes per launch of spp_rollout_kernel (six calls of PROBE_FT = 200 steps)
 PROBE_FACTORED=1 PROBE_B=64 PROBE_N=1000 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_f -o fetch -- python $R/tools/pmc_probe.py > $O/pmc_fetch_f.log 2>&1
 PROBE_FACTORED=1 PROBE_B=64 PROBE_N=1000 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write_f -o write -- python $R/tools/pmc_probe.py > $O/pmc_write_f.log 2>&1
 F=$(find $O/pmc_fetch -name "*results.db" | head -1); W=$(find $O/pmc_write -name "*results.db" | head -1); Q=$(find $O/pmc_sq -name "*results.db" | head -1)
@@ -109,10 +109,16 @@ bash tools/gpu/ro_pmc.sh > $O/rollout_inst_mix.txt 2>&1
 # 7. the factored path (N > 256; cfg-3 shape 64 x 1000, K = 3): harness stamps of its three kernels, their kernel trace, the
 #    bench at 100 / 500 steps per call, and DAGGER rounds collecting on the factored state (N = 1000, N = 300)
 #    (harness: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DMGP_SP_PROFILE] -o scratch/sp_prof[_stamps] tools/harness/sp_step_prof.hip)
-{ ./scratch/sp_prof_stamps 64 1000 3 200; ./scratch/sp_prof 64 1000 3 200; ./scratch/sp_prof 256 300 3 200; ./scratch/sp_prof 64 1000 4 200; } > $O/factored_step_stamps.txt 2>&1
+#    [r6] + the persistent form (tools/harness/sp_persist_check.hip: every output against the K-launch form bit for bit, both timed,
+#    stamps of a steady-state step; 64 x 1000, 256 x 300 in two launches of 128 episodes, a contracted flock on the bit-row fallback)
+{ ./scratch/sp_persist_stamps 64 1000 100; ./scratch/sp_persist 64 1000 100; ./scratch/sp_persist 64 1000 500; ./scratch/sp_persist 256 300 100; ./scratch/sp_persist 64 1000 50 0.3;
+  echo "== the K-launch form, one call per step (tools/harness/sp_step_prof.hip)"
+  ./scratch/sp_prof_stamps 64 1000 3 200; ./scratch/sp_prof 64 1000 3 200; ./scratch/sp_prof 256 300 3 200; ./scratch/sp_prof 64 1000 4 200; } > $O/factored_step_stamps.txt 2>&1
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $O/trace_spp -o spp -- $R/scratch/sp_persist 64 1000 100 > /dev/null 2>&1)
+python tools/rocpd_stats.py $(find $O/trace_spp -name "*results.db" | head -1) | head -9 > $O/factored_kernel_trace.txt 2>&1
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $O/trace_sp -o sp -- $R/scratch/sp_prof 64 1000 3 200 > /dev/null 2>&1)
 TS=$(find $O/trace_sp -name "*results.db" | head -1)
-python tools/rocpd_stats.py $TS | head -8 > $O/factored_kernel_trace.txt 2>&1
+python tools/rocpd_stats.py $TS | head -8 >> $O/factored_kernel_trace.txt 2>&1
 for st in 100 500; do python bench.py --episodes 64 --agents 1000 --taps 3 --no-cpu-baseline --no-roofline --steps $st --warmup 10 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
@@ -120,5 +126,5 @@ print('64 1000 3 hidden 32 x 2, $st steps per call:', 'value %.3e' % d['value'],
 " >> $O/factored_kernel_trace.txt; done
 python bench.py --dagger --episodes 64 --agents 1000 --steps 200 --warmup 10 --updates 64 2> $O/dagger_round_n1000.err | grep "^{" > $O/dagger_round_n1000.json
 python bench.py --dagger --episodes 256 --agents 300 --steps 200 --warmup 10 --updates 256 2> $O/dagger_round_n300.err | grep "^{" > $O/dagger_round_n300.json
-rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_fetch20 $O/pmc_write20 $O/pmc_fetch_f $O/pmc_write_f $O/trace $O/trace_sp gpurun_out/ro_pmc
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_fetch20 $O/pmc_write20 $O/pmc_fetch_f $O/pmc_write_f $O/trace $O/trace_sp $O/trace_spp gpurun_out/ro_pmc
 ls -la $O
