@@ -58,4 +58,5 @@ inline int sp_plan(const int* dims, int n_layers, int K, int* woff, int* wtot)
 // (MGP_OK: enqueued; MGP_EUNSUPPORTED: not covered, the caller enqueues the K launches per step; other codes: errors).
 int spp_rollout(unsigned long long* bits, float* wrow, float* feat, const float* image, const int* dims, int n_layers,
                 float* scratch, float* action, double* x_a, double* x_b, double* rewards, float* expert,
-                const MgpFlockParams* p, int B, int K, int N, int T, int cur, int hs, unsigned short* nbr, hipStream_t st);
+                const MgpFlockParams* p, int B, int K, int N, int T, int cur, int hs, unsigned short* nbr,
+                const MgpSparseCollect* collect, hipStream_t st);

@@ -25,10 +25,10 @@
 // to HBM where somebody can read them: in the last H = 2 steps of the call (the networks that outlive it) and for rows
 // whose list overflows (their own gathers fall back to the bit row).
 //
-// Covered: K = 3, N <= 1024, no link fading, no DAGGER collection, <= 4 layers; everything else stays on the K-launch path.
+// Covered: K = 3, N <= 1024, no link fading, <= 4 layers (policy rollouts and DAGGER collection); everything else stays on the K-launch path.
 // Residency: a workgroup needs a CU to itself (156 KB of LDS), an episode's workgroups spin on each other, so a launch
 // holds at most (CUs / tiles) episodes -- more episodes run as further launches -- and every poll gives up after
-// PP_TIMEOUT (another process holding CUs): the episode's outputs are poisoned with NaN and the error word is set
+// MGP_SP_PERSIST_TIMEOUT_MS, default 3 s (another process holding CUs): the episode's outputs are poisoned with NaN and the error word is set
 // (mgp_sparse_rollout_status).
 #include <math.h>
 #include "mgp_common.h"
@@ -49,7 +49,7 @@ constexpr int PP_THREADS = 1024;
 constexpr int PP_ROWS = 256;               // rows / columns per workgroup: four lanes each
 constexpr int PP_SUBCAP = SS_SUBCAP;       // hits a lane of the row search can note (a row's list holds 15)
 constexpr int PP_K = 3;
-constexpr long long PP_TIMEOUT = 300000000ll;   // wall_clock64 ticks (100 MHz): 3 s
+constexpr long long PP_TICKS_PER_MS = 100000ll;  // wall_clock64 runs at 100 MHz
 
 struct PpArgs {
     unsigned long long* bits; float* wrow; float* feat; unsigned short* nbr;      // the rings; batch strides in elements:
@@ -62,6 +62,9 @@ struct PpArgs {
     float* expert;                 // (B,N,2) or NULL
     unsigned int* ctrl;            // [B][16]: arrival counters 0..2, error word 3
     int B, N, NW, T, cur, hs, b0, Bc, n_layers;
+    MgpSparseCollect col;          // DAGGER collection (col.feat != NULL): frames of the FIRST step's ring_step / age_now onwards
+    int timeout_ms;                // a poll gives up after this long (MGP_SP_PERSIST_TIMEOUT_MS, default 3000)
+    int fault_episode;             // test hook (MGP_SP_PERSIST_FAULT): this episode's tile-1 workgroup stops arriving after step 0; -1: none
     unsigned long long dimsA, woffA;
     MgpFlockParams p;
 };
@@ -91,15 +94,15 @@ __device__ __forceinline__ unsigned long long pp_ldw(const unsigned long long* p
 }
 
 // every payload store of the workgroup has been acknowledged, then ONE arrival
-__device__ __forceinline__ void pp_arrive(unsigned int* ctr)
+__device__ __forceinline__ void pp_arrive(unsigned int* ctr, bool mute)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && !mute) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // thread 0 polls until all `target` arrivals are in (or somebody gave up); returns false when the episode is dead
-__device__ __forceinline__ bool pp_wait(const unsigned int* ctr, unsigned int target, unsigned int* err, int* s_dead)
+__device__ __forceinline__ bool pp_wait(const unsigned int* ctr, unsigned int target, unsigned int* err, int* s_dead, long long timeout)
 {
     if (threadIdx.x == 0) {
         const long long t0 = wall_clock64();
@@ -107,7 +110,7 @@ __device__ __forceinline__ bool pp_wait(const unsigned int* ctr, unsigned int ta
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 63) == 0 &&
-                (wall_clock64() - t0 > PP_TIMEOUT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                (wall_clock64() - t0 > timeout || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                 __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *s_dead = 1;
                 break;
@@ -249,6 +252,7 @@ void spp_rollout_kernel(PpArgs A)
         }
     }
     for (int i = tid; i < PP_ROWS * RO_CS / 4; i += PP_THREADS) reinterpret_cast<float4*>(act)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long timeout = (long long)A.timeout_ms * PP_TICKS_PER_MS;
     int rs1 = 0;                                               // ring slot of tap 1 (x_{t-1}); tap 2 in the other
     int ws = 0;                                                // lw / lists slot of A_t; A_{t-1} in the other
     bool alive = true;
@@ -259,7 +263,9 @@ void spp_rollout_kernel(PpArgs A)
 #endif
         const int nc = (cur + 1) % K, nh = (hs + 1) % H;
         const unsigned int target = (unsigned int)(tiles * (s + 1));
-        const bool last_h = s >= A.T - H;                      // this step's network outlives the call
+        const bool collecting = A.col.feat != nullptr;
+        const bool last_h = s >= A.T - H || collecting;        // this step's network outlives the call (or is filed as a frame)
+        const bool mute = b == A.fault_episode && tile == 1 && s >= 1;      // (test hook: a workgroup that never arrives)
         PP_STAMP(0);
         // ================= gather stage 1: taps 1, 2 times A_t =================
         __syncthreads();                                        // act is zero; lw / lists / ring of this step are complete
@@ -280,7 +286,7 @@ void spp_rollout_kernel(PpArgs A)
             }
         }
         PP_STAMP(1);
-        pp_arrive(ctr + 0);
+        pp_arrive(ctr + 0, mute);
         {   // ring: x_t (published one exchange round ago, or by the previous launch) replaces x_{t-2}.  (Requested in front of
             // the arrival -- one round trip for the store drain and these loads -- or behind exchange (c) and held in registers
             // through the gather: both measured SLOWER, 26.5 -> 30.4 us per step; the kernel sits at its 128-VGPR limit.)
@@ -292,7 +298,7 @@ void spp_rollout_kernel(PpArgs A)
             }
         }
         PP_STAMP(2);
-        alive = pp_wait(ctr + 0, target, err, &s_dead);
+        alive = pp_wait(ctr + 0, target, err, &s_dead, timeout);
         if (!alive) break;
         PP_STAMP(3);
         for (int i = tid; i < 3 * N; i += PP_THREADS) {         // the siblings' rows of tap 2's running product
@@ -302,11 +308,38 @@ void spp_rollout_kernel(PpArgs A)
         __syncthreads();
         PP_STAMP(4);
         // ================= policy tail: tap 0, last factor of tap 2, MLP =================
+        bool expert_drives = false;
         {
             const float* xt = ring + (size_t)(rs1 ^ 1) * N * 6;
             for (int i = tid; i < PP_ROWS * 6; i += PP_THREADS) {
                 const int c = i / 6, f = i - 6 * c;
                 if (i0 + c < N) act[c * RO_CS + rpos(f * K + 0)] = xt[(size_t)(i0 + c) * 6 + f];
+            }
+            if (collecting) {
+                // DAGGER collection (gnn_dagger.py:154-178; spl_policy_kernel<CL>): the frame of the state the step starts from
+                // -- features x_t, bit rows and row weights of A_t, the expert's action for x_t, the age -- own columns / rows
+                const size_t fr = (size_t)((A.col.ring_step + s) % A.col.ring_steps) * A.B + b;
+                const int age_now = A.col.age_now + s;
+                const double bq = floor((double)A.col.beta[b] * 4294967296.0);            // P(expert drives) in units of 2^-32
+                const unsigned long long thr = bq <= 0.0 ? 0ull : (bq >= 4294967296.0 ? 4294967296ull : (unsigned long long)bq);
+                expert_drives = (unsigned long long)dagger_coin(A.col.seed, A.col.episode[b], (unsigned int)age_now) < thr;
+                const int cols = min(PP_ROWS, N - i0);
+                float* ff = A.col.feat + fr * 6 * N;
+                for (int i = tid; i < 6 * PP_ROWS; i += PP_THREADS) {
+                    const int f = i >> 8, c = i & 255;
+                    if (c < cols) ff[(size_t)f * N + i0 + c] = xt[(size_t)(i0 + c) * 6 + f];
+                }
+                const float* ex = A.expert + (size_t)b * N * 2;
+                float* lb = A.col.label + fr * 2 * N;
+                for (int i = tid; i < 2 * PP_ROWS; i += PP_THREADS) {
+                    const int a = i >> 8, c = i & 255;
+                    if (c < cols) lb[(size_t)a * N + i0 + c] = pp_ld1(ex + (size_t)(i0 + c) * 2 + a);
+                }
+                const unsigned long long* nr = bits_b + ((size_t)hs * N + i0) * NW;
+                unsigned long long* fb = A.col.bits + (fr * N + i0) * NW;
+                for (int i = tid; i < cols * NW; i += PP_THREADS) fb[i] = pp_ldw(nr + i);
+                if (tid < cols) A.col.wrow[fr * N + i0 + tid] = lwr[ws * Np + i0 + tid];
+                if (tile == 0 && tid == 0) A.col.age[fr] = age_now;
             }
             const int hq = ro_slot(hs, 1, H);
             const uint2 lst = *reinterpret_cast<const uint2*>(lists + ((size_t)(ws ^ 1) * PP_ROWS + gc) * 16 + 4 * part);
@@ -352,14 +385,19 @@ void spp_rollout_kernel(PpArgs A)
             ux += dpp_f<0x4E>(ux); uy += dpp_f<0x4E>(uy);
             if (cg == 0 && i0 + ccol < N) {
                 const float2 bb = *reinterpret_cast<const float2*>(w2 + 2 * 4 * RO_KS);
-                pp_st1(act_b + i0 + ccol, ux + bb.x);
-                pp_st1(act_b + N + i0 + ccol, uy + bb.y);
+                float ax = ux + bb.x, ay = uy + bb.y;
+                if (expert_drives) {                            // gnn_dagger.py:157-161: the stored label drives the step
+                    const float2 e2 = pp_ld2(A.expert + ((size_t)b * N + i0 + ccol) * 2);
+                    ax = e2.x; ay = e2.y;
+                }
+                pp_st1(act_b + i0 + ccol, ax);
+                pp_st1(act_b + N + i0 + ccol, ay);
             }
         }
         PP_STAMP(6);
-        pp_arrive(ctr + 1);
+        pp_arrive(ctr + 1, mute);
         PP_STAMP(7);
-        alive = pp_wait(ctr + 1, target, err, &s_dead);
+        alive = pp_wait(ctr + 1, target, err, &s_dead, timeout);
         if (!alive) break;
         PP_STAMP(8);
         // ================= simulator (sp_sim_kernel, the whole episode from registers) =================
@@ -601,11 +639,11 @@ void spp_rollout_kernel(PpArgs A)
             }
         }
         PP_STAMP(10);
-        pp_arrive(ctr + 2);
+        pp_arrive(ctr + 2, mute);
         PP_STAMP(11);
         // (in the shadow of the exchange: the next step's activation tile; the simulator's scratch is dead behind the arrival's barrier)
         for (int i = tid; i < PP_ROWS * RO_CS / 4; i += PP_THREADS) reinterpret_cast<float4*>(act)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        alive = pp_wait(ctr + 2, target, err, &s_dead);
+        alive = pp_wait(ctr + 2, target, err, &s_dead, timeout);
         if (!alive) break;
         PP_STAMP(12);
         if (in && (tid < i0 || tid >= i0 + PP_ROWS))             // the siblings' row weights of A_{t+1}
@@ -653,7 +691,7 @@ int spp_covered(const int* dims, int n_layers, int K, int N, const MgpFlockParam
 }
 }  // namespace
 
-/* 1 when mgp_sparse_rollout runs this shape as one launch of persistent workgroups (given neighbour lists and no collection). */
+/* 1 when mgp_sparse_rollout runs this shape as one launch of persistent workgroups (given neighbour lists). */
 extern "C" int mgp_sparse_rollout_persistent(const int* dims, int n_layers, int K, int N, const MgpFlockParams* p)
 {
     int woff[MGP_MAX_LAYERS], wtot = 0;
@@ -663,11 +701,13 @@ extern "C" int mgp_sparse_rollout_persistent(const int* dims, int n_layers, int 
 
 int spp_rollout(unsigned long long* bits, float* wrow, float* feat, const float* image, const int* dims, int n_layers,
                 float* scratch, float* action, double* x_a, double* x_b, double* rewards, float* expert,
-                const MgpFlockParams* p, int B, int K, int N, int T, int cur, int hs, unsigned short* nbr, hipStream_t st)
+                const MgpFlockParams* p, int B, int K, int N, int T, int cur, int hs, unsigned short* nbr,
+                const MgpSparseCollect* collect, hipStream_t st)
 {
     int woff[MGP_MAX_LAYERS], wtot = 0;
     size_t lds = 0;
     if (T < 1 || B < 1 || nbr == nullptr) return MGP_EUNSUPPORTED;
+    if (collect != nullptr && expert == nullptr) return MGP_EINVAL;
     if (spp_covered(dims, n_layers, K, N, p, woff, &wtot, &lds) != MGP_OK) return MGP_EUNSUPPORTED;
     static thread_local int cus_dev = -1, cus = 0;
     int dev = 0;
@@ -700,6 +740,11 @@ int spp_rollout(unsigned long long* bits, float* wrow, float* feat, const float*
     for (int l = 0; l <= n_layers; ++l) A.dimsA |= (unsigned long long)(dims[l] & 255) << (8 * l);
     for (int l = 0; l < n_layers; ++l) A.woffA |= (unsigned long long)woff[l] << (16 * l);
     A.p = *p;
+    if (collect != nullptr) A.col = *collect;
+    const char* tmo = getenv("MGP_SP_PERSIST_TIMEOUT_MS");
+    A.timeout_ms = (tmo != nullptr && atoi(tmo) > 0) ? atoi(tmo) : 3000;
+    const char* flt = getenv("MGP_SP_PERSIST_FAULT");
+    A.fault_episode = (flt != nullptr && flt[0] != 0) ? atoi(flt) : -1;
     mgp_clear_error();
     if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(spp_rollout_kernel), lds) != hipSuccess) return MGP_ELAUNCH;
     if (hipMemsetAsync(A.ctrl, 0, (size_t)B * 16 * sizeof(unsigned int), st) != hipSuccess) return MGP_ELAUNCH;

@@ -836,9 +836,15 @@ extern "C" int mgp_sparse_rollout(unsigned long long* bits, float* wrow, float* 
     const int H = K > 2 ? K - 1 : 1;
     const int NW = mgp_sparse_words(N);
     int c = *cur, h = *hs;
-    if (collect == nullptr && T > 0) {                          // one launch of persistent workgroups where the shape is covered
+    if (T > 0) {                                                // one launch of persistent workgroups where the shape is covered
+        if (collect != nullptr) {
+            MGP_CHECK_PTR(collect->feat); MGP_CHECK_PTR8(collect->bits); MGP_CHECK_PTR(collect->wrow); MGP_CHECK_PTR(collect->label);
+            MGP_CHECK_PTR(collect->age); MGP_CHECK_PTR(collect->expert); MGP_CHECK_PTR(collect->beta); MGP_CHECK_PTR(collect->episode);
+            if (collect->ring_steps < 1 || collect->ring_step < 0 || collect->ring_step >= collect->ring_steps || collect->age_now < 0)
+                return MGP_EINVAL;
+        }
         const int rc = spp_rollout(bits, wrow, feat, image, dims, n_layers, scratch, action, x_a, x_b, rewards, expert, p, B, K, N,
-                                   T, c, h, sp_mode != 0 ? nullptr : nbr, static_cast<hipStream_t>(stream));
+                                   T, c, h, sp_mode != 0 ? nullptr : nbr, collect, static_cast<hipStream_t>(stream));
         if (rc == MGP_OK) { *cur = (c + T) % K; *hs = (h + T) % H; return MGP_OK; }
         if (rc != MGP_EUNSUPPORTED) return rc;
     }

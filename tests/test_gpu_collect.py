@@ -446,3 +446,27 @@ def test_vectorised_dagger_collects_on_the_factored_state():
     assert res['collect'] == 'device' and res['updates'] == 2 * 3 * 4
     assert res['replay_bytes_per_transition'] == 32 * 300 + 8 * 8 * 300 + 4 * 300 + 4
     assert np.isfinite(res['mean']) and res['mean'] < 0
+
+
+@pytest.mark.parametrize('N,hidden,variant', [(300, (32, 32), {}), (1000, (32, 32), {}), (600, (32,), {'mean_pooling': False, 'centralized': False})])
+def test_sparse_collect_persistent_form_equals_the_k_launch_form(N, hidden, variant, monkeypatch):
+    """DAGGER collection on the factored state at K = 3 runs inside the persistent launch (csrc/sparse_persist.hip: frames
+    filed and the expert's action substituted in its policy phase): frames, labels, ages, the state and every ring equal the
+    K-launch form's (mgp_sparse_policy_collect per step) bit for bit."""
+    from multiagent_gnn_policies_amd.learner.sparse_rollout import sparse_collect
+    K, B, T, seed = 3, 3, 8, 77
+    beta = torch.tensor([0.5, 0.9, 0.1], device='cuda')
+    episode = torch.tensor([11, 12, 99], dtype=torch.int32, device='cuda')
+    runs = []
+    for persist in ('0', '1'):
+        monkeypatch.setenv('MGP_SP_PERSIST', persist)
+        op, actor, sim, st, mem, sp = _setup_sparse(N, K, hidden, B, variant, ring_capacity=B * 5)
+        rewards = torch.zeros((B, T), device='cuda', dtype=torch.float64)
+        sparse_collect(actor, sim, sp, mem, beta, episode, seed, 0, 3, rewards=rewards[:, :3].clone())
+        sparse_collect(actor, sim, sp, mem, beta, episode, seed, 3, T - 3)
+        sp.check_status()
+        runs.append((sim.x.clone(), sp.bits.clone(), sp.wrow.clone(), sp.feat.clone(), sp.nbr.clone(), sim.expert.clone(), mem.feat.clone(),
+                     mem.bits.clone(), mem.wrow.clone(), mem.label.clone(), mem.age.clone()))
+    for a, b_ in zip(*runs):
+        assert torch.equal(a, b_)
+    assert runs[0][6].abs().sum() > 0 and runs[0][7].any()

@@ -255,3 +255,45 @@ def test_persistent_factored_rollout_is_bit_identical(N, hidden, B, scale, varia
                 assert v == other[k]
             elif v is not None:
                 assert torch.equal(v, other[k]), "%s differs between the K-launch and the persistent form" % k
+
+
+def test_persistent_rollout_gives_up_loudly_when_a_sibling_never_arrives(monkeypatch):
+    """An episode's persistent workgroups spin on each other's arrival counters; CUs held by another process could keep a
+    sibling from ever starting.  Every poll is bounded: with the test hook muting one workgroup of episode 1 (from step 1 on)
+    its siblings give up after the timeout, the episode's action / state / rewards are NaN, the status call reports it --
+    and the other episodes of the same launch finish with exactly the results of an undisturbed run."""
+    from multiagent_gnn_policies_amd import _lib
+    from multiagent_gnn_policies_amd.learner.sparse_rollout import SparseFlockState, sparse_policy_rollout
+    N, K, B, T = 300, 3, 3, 5
+    monkeypatch.setenv('MGP_SP_PERSIST', '1')
+    monkeypatch.setenv('MGP_SP_PERSIST_TIMEOUT_MS', '200')
+    outs = []
+    for fault in (None, '1'):
+        if fault is None:
+            monkeypatch.delenv('MGP_SP_PERSIST_FAULT', raising=False)
+        else:
+            monkeypatch.setenv('MGP_SP_PERSIST_FAULT', fault)
+        rs, op, actor, sim, st = _make(N, K, (32, 32), B, seed=9)
+        sp = SparseFlockState(sim, K)
+        sp.observe_reset(sim)
+        action = torch.zeros((B, 1, 2, N), device='cuda')
+        rewards = torch.zeros((B, T), device='cuda', dtype=torch.float64)
+        sparse_policy_rollout(actor, sim, sp, T, rewards=rewards, action=action)
+        if fault is None:
+            sp.check_status()
+        else:
+            with pytest.raises(_lib.MgpError):
+                sp.check_status()
+        outs.append((sim.x.clone(), action.clone(), rewards.clone()))
+    (x0, a0, r0), (x1, a1, r1) = outs
+    assert torch.isnan(a1[1]).all() and torch.isnan(x1[1]).all() and torch.isnan(r1[1]).all()
+    for b in (0, 2):
+        assert torch.equal(x0[b], x1[b]) and torch.equal(a0[b], a1[b]) and torch.equal(r0[b], r1[b])
+    # the state object is usable again after a reset observation
+    monkeypatch.delenv('MGP_SP_PERSIST_FAULT', raising=False)
+    rs, op, actor, sim, st = _make(N, K, (32, 32), B, seed=9)
+    sp = SparseFlockState(sim, K)
+    sp.observe_reset(sim)
+    sparse_policy_rollout(actor, sim, sp, T)
+    sp.check_status()
+    assert torch.equal(sim.x, x0)
