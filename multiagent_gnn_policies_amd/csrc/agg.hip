@@ -326,6 +326,85 @@ int launch_agg_fwd_mfma4(const float* X, const float* G, float* Y, int B, int K,
     return mgp_launch_status();
 }
 
+// ---- [r6] ONE workgroup per episode, eight waves = (column block, row part of S steps), the K = 3 taps one after the other in
+// every wave: the requests of all three taps are issued up front (3 S float4 per lane), so a tap's products, row-class sums,
+// part combine (one barrier) and stores run while the later taps' rows are still in flight -- round 5's review: "inside a wave,
+// issue the row stream as two half-batches; run the row sums and stores of the first under the second's flight".  One
+// workgroup fills a CU (3 S + 18 + 32 float4 registers per lane, 80 KB of LDS): the same bytes in flight per CU as three
+// four-wave workgroups.  Selected with MGP_AGG_FORM=43 (A/B; profiles/r06_agg_forms.txt).
+template <int S, int FH, int PART, bool NT>
+__device__ __forceinline__ void agg3_wave(const float* __restrict__ X, const float* __restrict__ G, float* __restrict__ Y, int C, int N,
+                                          long sxk, long sxc, long syk, long syc, int b_unused, int lane, int wave, int blk, int g, int ng,
+                                          f32x4* red, f32x4* comb)
+{
+    constexpr int S0 = PART * S;
+    const int li = lane & 15, lq = lane >> 4;
+    AggRowsRegs<S, S0, FH> r0, r1, r2;
+    const size_t gstride = (size_t)N * N;
+    agg_mfma_rows_request<S, S0, FH, NT>(r0, G + 4 * g, X, sxc, C, N, lane);
+    agg_mfma_rows_request<S, S0, FH, NT>(r1, G + gstride + 4 * g, X + sxk, sxc, C, N, lane);
+    agg_mfma_rows_request<S, S0, FH, NT>(r2, G + 2 * gstride + 4 * g, X + 2 * sxk, sxc, C, N, lane);
+    auto tail = [&](int k, const f32x4 (&mine)[FH]) {
+        f32x4* cb = comb + (size_t)k * 8 * FH * 64;               // [tap][wave][FH][64]
+        if (PART != 0) {
+#pragma unroll
+            for (int h = 0; h < FH; ++h) cb[(wave * FH + h) * 64 + lane] = mine[h];
+        }
+        __syncthreads();
+        if (PART == 0 && li < ng) {
+            float* Yk = Y + (size_t)k * syk + 4 * g + lq;
+#pragma unroll
+            for (int h = 0; h < FH; ++h) {
+                f32x4 tot = mine[h];
+#pragma unroll
+                for (int q = 1; q < 4; ++q) tot += cb[((wave + q) * FH + h) * 64 + lane];     // fixed order: part 1, 2, 3
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (4 * h + i < C) Yk[(size_t)(4 * h + i) * syc] = tot[i];
+            }
+        }
+    };
+    f32x4 mine[FH];
+    auto keep = [&](int h, const f32x4& tot) { mine[h] = tot; };
+    agg_mfma_rows_products<S, S0, FH>(r0, C, N, lane, red, keep); tail(0, mine);
+    agg_mfma_rows_products<S, S0, FH>(r1, C, N, lane, red, keep); tail(1, mine);
+    agg_mfma_rows_products<S, S0, FH>(r2, C, N, lane, red, keep); tail(2, mine);
+}
+
+template <int S, int FH, bool NT>
+__global__ __launch_bounds__(512)
+void agg_fwd_mfma3_kernel(const float* __restrict__ X, const float* __restrict__ G, float* __restrict__ Y,
+                          int C, int N, long sxb, long sxk, long sxc, long syb, long syk, long syc)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15;
+    const int b = blockIdx.x;
+    const int blk = wave >> 2, part = wave & 3;
+    const int gtot = N >> 2, g0 = (gtot + 1) >> 1;
+    const int ng = blk ? gtot - g0 : g0;
+    const int g = blk * g0 + min(li, ng - 1);
+    f32x4* red = reinterpret_cast<f32x4*>(smem) + wave * (4 * 64);
+    f32x4* comb = reinterpret_cast<f32x4*>(smem) + 8 * (4 * 64);
+    const float* Gb = G + (size_t)b * 3 * (size_t)N * N;
+    const float* Xb = X + (size_t)b * sxb;
+    float* Yb = Y + (size_t)b * syb;
+    if (part == 0) agg3_wave<S, FH, 0, NT>(Xb, Gb, Yb, C, N, sxk, sxc, syk, syc, b, lane, wave, blk, g, ng, red, comb);
+    else if (part == 1) agg3_wave<S, FH, 1, NT>(Xb, Gb, Yb, C, N, sxk, sxc, syk, syc, b, lane, wave, blk, g, ng, red, comb);
+    else if (part == 2) agg3_wave<S, FH, 2, NT>(Xb, Gb, Yb, C, N, sxk, sxc, syk, syc, b, lane, wave, blk, g, ng, red, comb);
+    else agg3_wave<S, FH, 3, NT>(Xb, Gb, Yb, C, N, sxk, sxc, syk, syc, b, lane, wave, blk, g, ng, red, comb);
+}
+
+template <int S, int FH>
+int launch_agg_fwd_mfma3(const float* X, const float* G, float* Y, int B, int C, int N,
+                         long sxb, long sxk, long sxc, long syb, long syk, long syc, hipStream_t st)
+{
+    const size_t lds = (size_t)(8 * 4 * 64 + 3 * 8 * FH * 64) * 16;
+    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(agg_fwd_mfma3_kernel<S, FH, true>), lds) != hipSuccess) return MGP_ELAUNCH;
+    hipLaunchKernelGGL((agg_fwd_mfma3_kernel<S, FH, true>), dim3((unsigned)B), dim3(512), lds, st, X, G, Y, C, N, sxb, sxk, sxc, syb, syk, syc);
+    return mgp_launch_status();
+}
+
 template <int V>
 int dispatch_agg_fwd(const float* X, const float* G, float* Y, int B, int K, int C, int N,
                      long sxb, long sxk, long sxc, long syb, long syk, long syc, hipStream_t st)
@@ -374,6 +453,9 @@ extern "C" int mgp_agg_fwd(const float* X, const float* G, float* Y, int B, int 
                                                       : launch_agg_fwd_mfma4<S_, 2, NH_, NB_, NT_>(X, G, Y, B, K, C, N, sxb, sxk, sxc, syb, syk, syc, st)
         if (N <= 64) MGP_AG4_CASE(4, 4, 1, true);              // one column block, four row parts of 4 steps (16 rows each)
         if (N <= 112) {
+            if (agg_form == 43 && K == 3 && N > 64)            // (A/B: one workgroup per episode, the taps in sequence; the barriers need whole waves: N > 64 has two column blocks)
+                return C <= 4 ? launch_agg_fwd_mfma3<7, 1>(X, G, Y, B, C, N, sxb, sxk, sxc, syb, syk, syc, st)
+                              : launch_agg_fwd_mfma3<7, 2>(X, G, Y, B, C, N, sxb, sxk, sxc, syb, syk, syc, st);
             if (agg_form == 41) MGP_AG4_CASE(14, 2, 2, false); // (A/B: default cache policy)
             if (agg_form == 42) MGP_AG4_CASE(7, 4, 2, true);   // (A/B: eight waves of 7 steps)
             MGP_AG4_CASE(14, 2, 2, true);                      // two column blocks, two row parts of 14 steps

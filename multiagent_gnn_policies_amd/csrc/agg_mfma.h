@@ -131,4 +131,70 @@ __device__ __forceinline__ void agg_mfma_rows(const float* __restrict__ Gk, cons
     }
 }
 
+// agg_mfma_rows in two halves -- the requests of a unit's row part, and its products / row-class sums -- for the kernel that
+// puts SEVERAL units' requests in flight before the first product (agg.hip: agg_fwd_mfma3_kernel: a wave streams its row part of
+// tap 0, 1, 2 of one episode; a tap's sums, part combine and stores run under the later taps' flight).
+template <int S, int S0, int FH>
+struct AggRowsRegs {
+    static constexpr int T0 = S0 >> 2, TQ = ((S0 + S + 3) >> 2) - T0;
+    f32x4 xa[FH][TQ];
+    f32x4 gv[S];
+};
+
+template <int S, int S0, int FH, bool NT>
+__device__ __forceinline__ void agg_mfma_rows_request(AggRowsRegs<S, S0, FH>& r, const float* __restrict__ Gk,
+                                                      const float* __restrict__ Xk, long sxc, int F, int N, int lane)
+{
+    const int li = lane & 15, lq = lane >> 4;
+    constexpr int T0 = AggRowsRegs<S, S0, FH>::T0, TQ = AggRowsRegs<S, S0, FH>::TQ;
+#pragma unroll
+    for (int h = 0; h < FH; ++h) {
+        const float* xr = Xk + (size_t)min(4 * h + (li & 3), F - 1) * sxc;
+#pragma unroll
+        for (int t4 = 0; t4 < TQ; ++t4)
+            r.xa[h][t4] = *reinterpret_cast<const f32x4*>(xr + min(16 * (T0 + t4) + 4 * lq, N - 4));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const f32x4* gp = reinterpret_cast<const f32x4*>(Gk + (size_t)min(16 * ((S0 + s) >> 2) + 4 * lq + ((S0 + s) & 3), N - 1) * N);
+        r.gv[s] = NT ? __builtin_nontemporal_load(gp) : *gp;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int S, int S0, int FH, class Part>
+__device__ __forceinline__ void agg_mfma_rows_products(const AggRowsRegs<S, S0, FH>& r, int F, int N, int lane, f32x4* red, Part part)
+{
+    const int li = lane & 15, lq = lane >> 4;
+    constexpr int T0 = AggRowsRegs<S, S0, FH>::T0;
+    f32x4 acc[4][FH];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int h = 0; h < FH; ++h) acc[t][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const bool rok = 16 * ((S0 + s) >> 2) + 4 * lq + ((S0 + s) & 3) < N;
+#pragma unroll
+        for (int h = 0; h < FH; ++h) {
+            const float a = (rok && 4 * h + (li & 3) < F) ? r.xa[h][((S0 + s) >> 2) - T0][(S0 + s) & 3] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[t][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, r.gv[s][t], acc[t][h], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int h = 0; h < FH; ++h) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) red[t * 64 + lane] = acc[t][h];
+        const f32x4* p = red + lq * 64 + li;
+        f32x4 tot = p[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) tot += p[16 * q];
+        part(h, tot);
+    }
+}
+
 }  // namespace

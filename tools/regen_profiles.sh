@@ -77,6 +77,8 @@ k = {a: (round(v['avg_launch_ms']*1e3,1), round(v['GBps'])) for a, v in d.get('k
 print('$1 x N=$2 K=$3 hidden $4 x $5', 'value %.3e' % d['value'], 'ms/step %.4f' % d['ms_per_step'], 'paths', {a: '%.3e' % b['value'] for a, b in d['paths'].items()}, 'parity', d['parity']['ok'], d['parity']['passed_on'], 'kernels (us, GB/s)', k)
 " >> $O/other_configs.txt; done
 for f in 8 4; do MGP_AGG_FORM=$f python tools/gpu/agg_ab.py 2>/dev/null; done > $O/agg_forms.txt
+# [r6] form 43: one workgroup per episode, the three taps in sequence in every wave (a tap's sums and stores under the later taps' flight)
+AGG_SHAPES="256,100,3 512,100,3 1024,100,3 2048,100,3" MGP_AGG_FORM=43 python tools/gpu/agg_ab.py 2>/dev/null | grep agg_fwd >> $O/agg_forms.txt
 bash tools/gpu/update_slots_ab.sh > $O/dagger_update_slots.txt 2>&1
 ./scratch/stream_floor > $O/stream_floor.txt 2>&1
 python tools/gpu/train_wall.py 2>/dev/null | tail -1 > $O/train_wall.json
