@@ -532,7 +532,7 @@ int  mgp_sparse_rollout(unsigned long long* bits, float* wrow, float* feat, cons
                         float* expert, const MgpFlockParams* p, int B, int K, int N, int T, int* cur, int* hs,
                         const MgpSparseCollect* collect, unsigned short* nbr, void* stream);
 /* Persistent form (csrc/sparse_persist.hip; replaces the per-step launches of gnn_dagger.py:154-165 / test_model.py:38-44 for
- * N > 256): where mgp_sparse_rollout_persistent(...) = 1 -- K = 3, N <= 1024, no link fading, <= 4 layers -- and the call has
+ * N > 256): where mgp_sparse_rollout_persistent(...) = 1 -- K = 3, N <= 1024, <= 4 layers -- and the call has
  * neighbour lists (policy rollouts and DAGGER collection alike), the T steps run as ONE launch of workgroups that stay resident, keep the episode's feature
  * rows / row weights / own list rows in LDS and hand each other only what a sibling lacks (write-through stores, one arrival
  * counter per exchange) through the same state buffers: every output is bit-identical to the K-launch form; bit rows, list

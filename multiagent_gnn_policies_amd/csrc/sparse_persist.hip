@@ -25,7 +25,7 @@
 // to HBM where somebody can read them: in the last H = 2 steps of the call (the networks that outlive it) and for rows
 // whose list overflows (their own gathers fall back to the bit row).
 //
-// Covered: K = 3, N <= 1024, no link fading, <= 4 layers (policy rollouts and DAGGER collection); everything else stays on the K-launch path.
+// Covered: K = 3, N <= 1024, <= 4 layers (policy rollouts and DAGGER collection, every environment variant); everything else stays on the K-launch path.
 // Residency: a workgroup needs a CU to itself (156 KB of LDS), an episode's workgroups spin on each other, so a launch
 // holds at most (CUs / tiles) episodes -- more episodes run as further launches -- and every poll gives up after
 // MGP_SP_PERSIST_TIMEOUT_MS, default 3 s (another process holding CUs): the episode's outputs are poisoned with NaN and the error word is set
@@ -63,6 +63,7 @@ struct PpArgs {
     unsigned int* ctrl;            // [B][16]: arrival counters 0..2, error word 3
     int B, N, NW, T, cur, hs, b0, Bc, n_layers;
     MgpSparseCollect col;          // DAGGER collection (col.feat != NULL): frames of the FIRST step's ring_step / age_now onwards
+    int allow_near;                // 0: always the write-through exchange (MGP_SP_PERSIST_NEAR=0)
     int timeout_ms;                // a poll gives up after this long (MGP_SP_PERSIST_TIMEOUT_MS, default 3000)
     int fault_episode;             // test hook (MGP_SP_PERSIST_FAULT): this episode's tile-1 workgroup stops arriving after step 0; -1: none
     unsigned long long dimsA, woffA;
@@ -70,13 +71,18 @@ struct PpArgs {
 };
 
 // agent-scope relaxed accesses: global_load / global_store ... sc1 (bypass this CU's L1, write through the XCD's L2)
-__device__ __forceinline__ void pp_st2(float* p, float a, float b)
+// `near`: every workgroup of the episode runs on ONE XCD (checked at the launch's start, see the kernel): a plain store -- written
+// through this CU's L1 into the XCD's L2, where the line STAYS -- is what a sibling's L1-bypassing load finds there, and the
+// arrival's s_waitcnt returns when the L2 has it.  Otherwise the write-through form (`sc1`: the line leaves the L2 for memory).
+__device__ __forceinline__ void pp_st2(float* p, float a, float b, bool near)
 {
+    if (near) { *reinterpret_cast<float2*>(p) = make_float2(a, b); return; }
     const unsigned long long v = ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a);
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void pp_st1(float* p, float a)
+__device__ __forceinline__ void pp_st1(float* p, float a, bool near)
 {
+    if (near) { *p = a; return; }
     __hip_atomic_store(reinterpret_cast<unsigned int*>(p), __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float2 pp_ld2(const float* p)
@@ -185,6 +191,7 @@ void spp_rollout_kernel(PpArgs A)
     __shared__ double red2[SS_WAVES];
     __shared__ int shi[SS_WAVES];
     __shared__ int s_dead;
+    __shared__ int s_near;
     const int N = A.N, NW = A.NW, Np = (N + 3) & ~3, N4 = Np, wt4 = (A.wtot + 3) & ~3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = (N + PP_ROWS - 1) / PP_ROWS;
@@ -253,11 +260,29 @@ void spp_rollout_kernel(PpArgs A)
     }
     for (int i = tid; i < PP_ROWS * RO_CS / 4; i += PP_THREADS) reinterpret_cast<float4*>(act)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const long long timeout = (long long)A.timeout_ms * PP_TICKS_PER_MS;
+    // ---- where do the siblings run?  Observed: block b runs on XCD b % 8, and the grid puts an episode's tiles Bc blocks apart;
+    // nothing promises it, so every workgroup files its XCC id (HW_REG_XCC_ID) and the episode agrees on `near` behind one
+    // exchange of its own (counter 4, mask word 5).  near = 0 costs speed, never correctness (MGP_SP_PERSIST_NEAR=0 forces it).
+    bool near = false, alive_entry = true;
+    {
+        if (tid == 0) {
+            const unsigned int xcc = (unsigned int)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;     // hwreg(HW_REG_XCC_ID, 0, 4)
+            __hip_atomic_fetch_or(ctr + 5, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_near = 0;
+        }
+        pp_arrive(ctr + 4, false);
+        if (!pp_wait(ctr + 4, (unsigned int)tiles, err, &s_dead, timeout)) alive_entry = false;
+        if (tid == 0) {
+            const unsigned int mask = __hip_atomic_load(ctr + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_near = (A.allow_near && (mask & (mask - 1u)) == 0u) ? 1 : 0;
+        }
+        __syncthreads();
+        near = s_near != 0;
+    }
     int rs1 = 0;                                               // ring slot of tap 1 (x_{t-1}); tap 2 in the other
     int ws = 0;                                                // lw / lists slot of A_t; A_{t-1} in the other
-    bool alive = true;
-
-    for (int s = 0; s < A.T; ++s) {
+    bool alive = alive_entry;
+    for (int s = 0; s < A.T && alive; ++s) {
 #ifdef MGP_SP_PROFILE
         stamp_on = (s == (A.T > 4 ? A.T - 4 : 0)) && tile == 1 && ep == 3;
 #endif
@@ -281,7 +306,7 @@ void spp_rollout_kernel(PpArgs A)
                 } else {
                     const int f = 2 * (part - 1);
                     *reinterpret_cast<float2*>(vst + (size_t)gn * 6 + f) = make_float2(sa[1][f], sa[1][f + 1]);
-                    pp_st2(vbuf_b + (size_t)gn * 8 + f, sa[1][f], sa[1][f + 1]);
+                    pp_st2(vbuf_b + (size_t)gn * 8 + f, sa[1][f], sa[1][f + 1], near);
                 }
             }
         }
@@ -390,8 +415,8 @@ void spp_rollout_kernel(PpArgs A)
                     const float2 e2 = pp_ld2(A.expert + ((size_t)b * N + i0 + ccol) * 2);
                     ax = e2.x; ay = e2.y;
                 }
-                pp_st1(act_b + i0 + ccol, ax);
-                pp_st1(act_b + N + i0 + ccol, ay);
+                pp_st1(act_b + i0 + ccol, ax, near);
+                pp_st1(act_b + N + i0 + ccol, ay, near);
             }
         }
         PP_STAMP(6);
@@ -529,6 +554,8 @@ void spp_rollout_kernel(PpArgs A)
                 };
                 unsigned short* mine = sub + (size_t)tid * PP_SUBCAP;
                 int cnt = 0;
+                const bool fading = p.link_drop != 0u;          // FLOCK-SPEC item 8: a radius pair is connected iff its hash says so
+                const unsigned int wi = fading ? fade_word(xi, yi) : 0u;
                 const float xif = (float)xi, yif = (float)yi, R2f = (float)R2;
                 const float Rf = (float)R;
                 const float band = 2.384185791015625e-07f * 4.f * Rf * (2.f * fmaxf(fabsf(xif), fabsf(yif)) + 3.f * cwf + Rf) + 1e-30f;
@@ -546,6 +573,7 @@ void spp_rollout_kernel(PpArgs A)
                             const double dx = xi - spx[j], dyy = yi - spy[j];
                             if (!(dx * dx + dyy * dyy < R2)) continue;
                         }
+                        if (fading && !link_up(p, i, j, N, wi, fade_word(spx[j], spy[j]))) continue;
                         if (cnt < PP_SUBCAP) mine[cnt] = (unsigned short)j;
                         ++cnt;
                     }
@@ -610,6 +638,7 @@ void spp_rollout_kernel(PpArgs A)
                             const double dx = xi - spx[j], dyy = yi - spy[j];
                             const double r2 = dx * dx + dyy * dyy;
                             if (j == i || !(r2 < R2)) continue;
+                            if (fading && !link_up(p, i, j, N, wi, fade_word(spx[j], spy[j]))) continue;
                             terms(j, dx, dyy, r2);
                             __hip_atomic_fetch_or(gb + (j >> 6), 1ull << (j & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
@@ -625,7 +654,7 @@ void spp_rollout_kernel(PpArgs A)
                     const double dg = (double)deg;
                     const double w = p.mean_pooling ? 1.0 / (dg == 0.0 ? 1.0 : dg) : 1.0;
                     lwr[(ws ^ 1) * Np + i] = (float)w;
-                    pp_st1(wrow_b + (size_t)nh * N + i, (float)w);
+                    pp_st1(wrow_b + (size_t)nh * N + i, (float)w, near);
                     if (A.expert != nullptr) {                  // spec section 5
                         double tvx = f0, tvy = f3;
                         if (p.centralized) { tvx = (double)N * vxi - tot_vx; tvy = (double)N * vyi - tot_vy; }
@@ -633,9 +662,9 @@ void spp_rollout_kernel(PpArgs A)
                         const double uy = clipd(-tvy - (2.0 * f5 - 2.0 * f4), -p.ctrl_clip, p.ctrl_clip) * p.ctrl_gain;
                         *reinterpret_cast<float2*>(A.expert + ((size_t)b * N + i) * 2) = make_float2((float)ux, (float)uy);
                     }
-                } else if (part == 1) pp_st2(ft, (float)f0, (float)f1);
-                else if (part == 2) pp_st2(ft + 2, (float)f2, (float)f3);
-                else pp_st2(ft + 4, (float)f4, (float)f5);
+                } else if (part == 1) pp_st2(ft, (float)f0, (float)f1, near);
+                else if (part == 2) pp_st2(ft + 2, (float)f2, (float)f3, near);
+                else pp_st2(ft + 4, (float)f4, (float)f5, near);
             }
         }
         PP_STAMP(10);
@@ -681,7 +710,7 @@ int spp_covered(const int* dims, int n_layers, int K, int N, const MgpFlockParam
 {
     const char* env = getenv("MGP_SP_PERSIST");                // (read on every call: tests switch forms inside one process)
     if (env != nullptr && env[0] != 0 && atoi(env) == 0) return MGP_EUNSUPPORTED;
-    if (K != PP_K || N < 1 || N > PP_THREADS || p == nullptr || p->link_drop != 0u) return MGP_EUNSUPPORTED;
+    if (K != PP_K || N < 1 || N > PP_THREADS || p == nullptr) return MGP_EUNSUPPORTED;
     if (n_layers < 1 || n_layers > 4) return MGP_EUNSUPPORTED;
     if (sp_plan(dims, n_layers, K, woff, wtot) != MGP_OK) return MGP_EUNSUPPORTED;
     for (int l = 0; l < n_layers; ++l) if (woff[l] > 0xFFFF) return MGP_EUNSUPPORTED;
@@ -743,6 +772,8 @@ int spp_rollout(unsigned long long* bits, float* wrow, float* feat, const float*
     if (collect != nullptr) A.col = *collect;
     const char* tmo = getenv("MGP_SP_PERSIST_TIMEOUT_MS");
     A.timeout_ms = (tmo != nullptr && atoi(tmo) > 0) ? atoi(tmo) : 3000;
+    const char* nr = getenv("MGP_SP_PERSIST_NEAR");
+    A.allow_near = (nr != nullptr && nr[0] != 0 && atoi(nr) == 0) ? 0 : 1;
     const char* flt = getenv("MGP_SP_PERSIST_FAULT");
     A.fault_episode = (flt != nullptr && flt[0] != 0) ? atoi(flt) : -1;
     mgp_clear_error();

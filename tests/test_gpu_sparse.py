@@ -211,6 +211,8 @@ def test_neighbour_lists_mirror_the_bit_rows():
     (700, (32,), 2, 1.0, {'mean_pooling': False, 'n_leaders': 2}),
     (1000, (32, 32), 2, 0.45, {}),                 # contracted flock: degrees beyond the 15-entry lists (bit-row fallback)
     (520, (16, 32, 8), 2, 1.0, {'comm_radius': 1.4}),
+    (513, (32,), 2, 1.0, {'link_drop': 0.3, 'link_seed': 4}),   # FlockingStochastic's link fading
+    (513, (32,), 2, 0.4, {'link_drop': 0.2, 'link_seed': 9}),   # ... on the bit-row fallback
     (300, (32, 32), 131, 1.0, {}),                 # more episodes than one launch of resident workgroups holds (256 CUs / 2 tiles)
 ])
 def test_persistent_factored_rollout_is_bit_identical(N, hidden, B, scale, variant, monkeypatch):
