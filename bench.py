@@ -378,7 +378,7 @@ def main():
         # (an odd number of eager steps, or an episode end, re-aligns them: Rollout.device_reset(align=))
         ep.align = (ro.sim.x.data_ptr(), ro.state._cur)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with ops.graph_capture(graph):
             for _ in range(gs):
                 ro.step()
 

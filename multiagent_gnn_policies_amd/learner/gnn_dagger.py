@@ -175,7 +175,7 @@ class GraphedUpdate(object):
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(graph):
+                with ops.graph_capture(graph):
                     self._enqueue()
                 self.graph = graph
             except RuntimeError as e:                 # a collective the runtime refuses to capture: stay eager, loudly

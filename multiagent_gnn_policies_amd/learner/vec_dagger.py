@@ -16,7 +16,7 @@ import random
 import numpy as np
 import torch
 
-from .. import parallel
+from .. import ops, parallel
 from ..envs import FlockParams, VecFlock
 from ..envs.flocking import _REGISTRY, sample_initial_states, use_grid
 from .rollouts import policy_rollout
@@ -91,10 +91,10 @@ def _replay_updates(obj, U):
     if obj.graph is None:
         torch.cuda.synchronize()
         obj.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(obj.graph):
+        with ops.graph_capture(obj.graph):
             obj._enqueue()
         obj.graph_many = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(obj.graph_many):
+        with ops.graph_capture(obj.graph_many):
             if hasattr(obj, '_enqueue_many'):
                 obj._enqueue_many(UPDATES_PER_GRAPH)
             else:

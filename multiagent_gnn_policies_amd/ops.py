@@ -2,6 +2,7 @@
 HIP stream, and the autograd glue.  Every function here runs a hand-written HIP kernel from libmgp.so;
 nothing falls back to ATen math or to the CPU.
 """
+import contextlib
 import ctypes
 
 import torch
@@ -37,6 +38,24 @@ def _dev(t, name, dtype=torch.float32):
 
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+@contextlib.contextmanager
+def graph_capture(graph):
+    """`torch.cuda.graph(graph)` with Python's cyclic collector held off.  A collection DURING capture can run the destructor
+    of an unrelated device object (an older CUDAGraph, an event of an earlier test or training round); its HIP call is illegal
+    on a capturing thread and the runtime aborts the process -- seen once in three full GPU test runs ("Fatal Python error:
+    Aborted ... Garbage-collecting" under an update's _enqueue).  Collect first, then keep the collector off until the capture ends."""
+    import gc
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 
 # ------------------------------------------------------------------------------------ aggregation

@@ -22,7 +22,7 @@ def time_kernel(fn, n_sets, iters):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with ops.graph_capture(graph):
         for i in range(n_sets):
             fn(i)
     reps = max(2, (iters + n_sets - 1) // n_sets)
