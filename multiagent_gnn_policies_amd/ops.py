@@ -45,11 +45,10 @@ def graph_capture(graph):
     """`torch.cuda.graph(graph)` with Python's cyclic collector held off.  A collection DURING capture can run the destructor
     of an unrelated device object (an older CUDAGraph, an event of an earlier test or training round); its HIP call is illegal
     on a capturing thread and the runtime aborts the process -- seen once in three full GPU test runs ("Fatal Python error:
-    Aborted ... Garbage-collecting" under an update's _enqueue).  Collect first, then keep the collector off until the capture ends."""
+    Aborted ... Garbage-collecting" under an update's _enqueue).  The collector stays off until the capture ends."""
     import gc
     was = gc.isenabled()
-    gc.collect()
-    gc.disable()
+    gc.disable()                          # (torch.cuda.graph collects once on entry by itself)
     try:
         with torch.cuda.graph(graph):
             yield
