@@ -182,6 +182,10 @@ __device__ __forceinline__ void pp_gather_list(uint2 lst, int part, const unsign
 // grid: x = tile * Bc + episode-of-the-chunk (an episode's tiles land on one XCD when Bc is a multiple of 8).
 // LDS: ring | lw | lists | image | scratch = max( simulator: px py vx vy [N] f64, start, cursor, cid tmp sorted, sub, posf ;
 //                                                 policy: act [256][RO_CS], vst [N][6] )
+// CL: DAGGER collection compiled in; FD: link fading compiled in (the plain rollout pays for neither: the kernel sits at its
+// 128-VGPR limit and every path compiled in costs the others spills -- 26.2 -> 28.4 us per step measured for 40 lines of
+// frame filing)
+template <bool CL, bool FD>
 __global__ __launch_bounds__(PP_THREADS)
 void spp_rollout_kernel(PpArgs A)
 {
@@ -288,7 +292,7 @@ void spp_rollout_kernel(PpArgs A)
 #endif
         const int nc = (cur + 1) % K, nh = (hs + 1) % H;
         const unsigned int target = (unsigned int)(tiles * (s + 1));
-        const bool collecting = A.col.feat != nullptr;
+        const bool collecting = CL && A.col.feat != nullptr;
         const bool last_h = s >= A.T - H || collecting;        // this step's network outlives the call (or is filed as a frame)
         const bool mute = b == A.fault_episode && tile == 1 && s >= 1;      // (test hook: a workgroup that never arrives)
         PP_STAMP(0);
@@ -554,7 +558,7 @@ void spp_rollout_kernel(PpArgs A)
                 };
                 unsigned short* mine = sub + (size_t)tid * PP_SUBCAP;
                 int cnt = 0;
-                const bool fading = p.link_drop != 0u;          // FLOCK-SPEC item 8: a radius pair is connected iff its hash says so
+                const bool fading = FD && p.link_drop != 0u;    // FLOCK-SPEC item 8: a radius pair is connected iff its hash says so
                 const unsigned int wi = fading ? fade_word(xi, yi) : 0u;
                 const float xif = (float)xi, yif = (float)yi, R2f = (float)R2;
                 const float Rf = (float)R;
@@ -777,13 +781,18 @@ int spp_rollout(unsigned long long* bits, float* wrow, float* feat, const float*
     const char* flt = getenv("MGP_SP_PERSIST_FAULT");
     A.fault_episode = (flt != nullptr && flt[0] != 0) ? atoi(flt) : -1;
     mgp_clear_error();
-    if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(spp_rollout_kernel), lds) != hipSuccess) return MGP_ELAUNCH;
-    if (hipMemsetAsync(A.ctrl, 0, (size_t)B * 16 * sizeof(unsigned int), st) != hipSuccess) return MGP_ELAUNCH;
-    for (int b0 = 0; b0 < B; b0 += bc_max) {
-        A.b0 = b0; A.Bc = (B - b0 < bc_max) ? B - b0 : bc_max;
-        hipLaunchKernelGGL(spp_rollout_kernel, dim3((unsigned int)(tiles * A.Bc)), dim3(PP_THREADS), lds, st, A);
-    }
-    return mgp_launch_status();
+    auto go = [&](auto kern) -> int {
+        if (mgp_allow_dyn_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return MGP_ELAUNCH;
+        if (hipMemsetAsync(A.ctrl, 0, (size_t)B * 16 * sizeof(unsigned int), st) != hipSuccess) return MGP_ELAUNCH;
+        for (int b0 = 0; b0 < B; b0 += bc_max) {
+            A.b0 = b0; A.Bc = (B - b0 < bc_max) ? B - b0 : bc_max;
+            hipLaunchKernelGGL(kern, dim3((unsigned int)(tiles * A.Bc)), dim3(PP_THREADS), lds, st, A);
+        }
+        return mgp_launch_status();
+    };
+    const bool fd = p->link_drop != 0u;
+    if (collect != nullptr) return fd ? go(spp_rollout_kernel<true, true>) : go(spp_rollout_kernel<true, false>);
+    return fd ? go(spp_rollout_kernel<false, true>) : go(spp_rollout_kernel<false, false>);
 }
 
 /* Error word of the persistent form of mgp_sparse_rollout: synchronises `stream`, then MGP_OK, or MGP_ELAUNCH when an episode's
