@@ -563,3 +563,28 @@ def test_reset_candidate_positions_are_the_position_half_of_the_candidates():
         p = FlockParams(**kw)
         U = np.random.RandomState(1).random_sample((64, 4 * p.n_agents + 2))
         assert np.array_equal(fl._candidate_positions(U, p), fl._candidates_from_uniforms(U, p)[:, :, 0:2])
+
+
+def test_persistent_factored_form_coverage_query_needs_no_device(monkeypatch):
+    """Which shapes mgp_sparse_rollout runs as one launch of persistent workgroups is host logic (plan + LDS budget):
+    K = 3, N <= 1024 where the LDS plan fits, <= 4 layers of <= 32 channels; MGP_SP_PERSIST=0 switches the form off."""
+    import ctypes
+    from multiagent_gnn_policies_amd import _lib
+    L = _lib.lib()
+    p = _lib.MgpFlockParams()
+    p.comm_radius2, p.dt = 1.0, 0.01
+
+    def q(hidden, K, N):
+        dims = (ctypes.c_int * (len(hidden) + 2))(6, *hidden, 2)
+        return L.mgp_sparse_rollout_persistent(dims, len(hidden) + 1, K, N, ctypes.byref(p))
+
+    monkeypatch.delenv('MGP_SP_PERSIST', raising=False)
+    assert q((32, 32), 3, 1000) == 1 and q((32, 32), 3, 300) == 1 and q((32,), 3, 1024) == 1 and q((16, 32, 8), 3, 520) == 1
+    assert q((32, 32), 2, 1000) == 0 and q((32, 32), 4, 400) == 0            # other tap counts: K launches per step
+    assert q((32, 32), 3, 1025) == 0 and q((32, 32), 3, 2048) == 0           # one agent per thread, 156 KB of LDS at N = 1000
+    assert q((32, 32, 32, 32), 3, 1000) == 0                                 # five layers
+    assert q((64, 64), 3, 1000) == 0                                         # wider than the factored policy kernels cover
+    p.link_drop = 1 << 30
+    assert q((32, 32), 3, 1000) == 1                                         # link fading is compiled in as its own instantiation
+    monkeypatch.setenv('MGP_SP_PERSIST', '0')
+    assert q((32, 32), 3, 1000) == 0
