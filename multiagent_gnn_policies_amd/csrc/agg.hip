@@ -262,7 +262,7 @@ int launch_agg_fwd_mfma(const float* X, const float* G, float* Y, int B, int K, 
 // workgroups share a CU and, beyond one workgroup per CU (B K > 256), one workgroup's row sums, part combine and stores
 // overlap the next one's stream -- the eight-wave kernel holds 240 VGPRs per wave: ONE workgroup per CU, every launch phase
 // exposed once per episode (4.15 TB/s at B = 2048 against 3.4 at B = 256).  Parts are added in fixed order through LDS.
-template <int S, int FH, int NH, int NBLK, bool NT, bool NTS = false>   // S row steps per wave, NH row parts, NBLK column blocks: 64 NH NBLK threads; NTS: non-temporal stores
+template <int S, int FH, int NH, int NBLK, bool NT, bool NTS = false, int D = S>   // S row steps per wave, NH row parts, NBLK column blocks: 64 NH NBLK threads; NTS: non-temporal stores; D: requests in flight per lane (agg_mfma.h)
 __global__ __launch_bounds__(64 * NH * NBLK)         // (forcing <= 128 VGPRs for a fourth wave per SIMD spills and measured 7 % slower)
 void agg_fwd_mfma4_kernel(const float* __restrict__ X, const float* __restrict__ G, float* __restrict__ Y,
                           int K, int C, int N, long sxb, long sxk, long sxc, long syb, long syk, long syc)
@@ -282,10 +282,10 @@ void agg_fwd_mfma4_kernel(const float* __restrict__ X, const float* __restrict__
     const float* Xk = X + (size_t)b * sxb + (size_t)k * sxk;
     f32x4 mine[FH];
     auto keep = [&](int h, const f32x4& tot) { mine[h] = tot; };
-    if (part == 0) agg_mfma_rows<S, 0, FH, NT>(Gk, Xk, sxc, C, N, lane, red, keep);
-    else if (part == 1) agg_mfma_rows<S, S, FH, NT>(Gk, Xk, sxc, C, N, lane, red, keep);
-    else if (NH == 4 && part == 2) agg_mfma_rows<S, (NH == 4 ? 2 * S : 0), FH, NT>(Gk, Xk, sxc, C, N, lane, red, keep);
-    else agg_mfma_rows<S, (NH == 4 ? 3 * S : 0), FH, NT>(Gk, Xk, sxc, C, N, lane, red, keep);
+    if (part == 0) agg_mfma_rows<S, 0, FH, NT, D>(Gk, Xk, sxc, C, N, lane, red, keep);
+    else if (part == 1) agg_mfma_rows<S, S, FH, NT, D>(Gk, Xk, sxc, C, N, lane, red, keep);
+    else if (NH == 4 && part == 2) agg_mfma_rows<S, (NH == 4 ? 2 * S : 0), FH, NT, D>(Gk, Xk, sxc, C, N, lane, red, keep);
+    else agg_mfma_rows<S, (NH == 4 ? 3 * S : 0), FH, NT, D>(Gk, Xk, sxc, C, N, lane, red, keep);
     if (part != 0) {
 #pragma unroll
         for (int h = 0; h < FH; ++h) comb[(wave * FH + h) * 64 + lane] = mine[h];
@@ -308,7 +308,7 @@ void agg_fwd_mfma4_kernel(const float* __restrict__ X, const float* __restrict__
     }
 }
 
-template <int S, int FH, int NH, int NBLK, bool NT = true>
+template <int S, int FH, int NH, int NBLK, bool NT = true, int D = S>
 int launch_agg_fwd_mfma4(const float* X, const float* G, float* Y, int B, int K, int C, int N,
                          long sxb, long sxk, long sxc, long syb, long syk, long syc, hipStream_t st)
 {
@@ -317,11 +317,16 @@ int launch_agg_fwd_mfma4(const float* X, const float* G, float* Y, int B, int K,
     // results with the non-temporal hint once the launch is several workgroups per CU deep (B K >= 3072: 15 MB of results in a
     // 246 MB read stream at B = 2048 -- 50.8 -> 48.4 us in the harness; at B = 256 the plain stores are the faster ones: 8.5 vs 8.9)
     static const int nts_from = getenv("MGP_AGG_NTS") ? atoi(getenv("MGP_AGG_NTS")) : 3072;
+    // [r6] ... and with half of a wave's requests (7 of 14) issued behind its products instead of up front: the memory system serves
+    // requests roughly in issue order, so with everything up front the waves that issued last hold ALL their products at the end of
+    // the stream; spread over the launch, B = 2048: 53.5 -> 51.2 us (0.643 -> 0.672 of 8 TB/s), 1024: 30.3 -> 29.5, 4096: 108.5 ->
+    // 105; no change at B <= 512, where a launch is one wave of workgroups (profiles/r06_agg_forms.txt, forms 44-46).
+    constexpr int DD = (D == S && S == 14) ? 7 : D;
     if ((long)B * K >= nts_from)
-        hipLaunchKernelGGL((agg_fwd_mfma4_kernel<S, FH, NH, NBLK, NT, true>), dim3((unsigned)(B * K)), dim3(64 * NW), lds, st,
+        hipLaunchKernelGGL((agg_fwd_mfma4_kernel<S, FH, NH, NBLK, NT, true, DD>), dim3((unsigned)(B * K)), dim3(64 * NW), lds, st,
                            X, G, Y, K, C, N, sxb, sxk, sxc, syb, syk, syc);
     else
-        hipLaunchKernelGGL((agg_fwd_mfma4_kernel<S, FH, NH, NBLK, NT>), dim3((unsigned)(B * K)), dim3(64 * NW), lds, st,
+        hipLaunchKernelGGL((agg_fwd_mfma4_kernel<S, FH, NH, NBLK, NT, false, D>), dim3((unsigned)(B * K)), dim3(64 * NW), lds, st,
                            X, G, Y, K, C, N, sxb, sxk, sxc, syb, syk, syc);
     return mgp_launch_status();
 }
@@ -456,6 +461,13 @@ extern "C" int mgp_agg_fwd(const float* X, const float* G, float* Y, int B, int 
             if (agg_form == 43 && K == 3 && N > 64)            // (A/B: one workgroup per episode, the taps in sequence; the barriers need whole waves: N > 64 has two column blocks)
                 return C <= 4 ? launch_agg_fwd_mfma3<7, 1>(X, G, Y, B, C, N, sxb, sxk, sxc, syb, syk, syc, st)
                               : launch_agg_fwd_mfma3<7, 2>(X, G, Y, B, C, N, sxb, sxk, sxc, syb, syk, syc, st);
+            if (agg_form == 44 || agg_form == 45 || agg_form == 46) { // (A/B: 7 / 10 / 4 of the 14 requests up front at EVERY batch size)
+                const int d = agg_form == 44 ? 7 : (agg_form == 45 ? 10 : 4);
+#define MGP_AG4_D(D_) return C <= 4 ? launch_agg_fwd_mfma4<14, 1, 2, 2, true, D_>(X, G, Y, B, K, C, N, sxb, sxk, sxc, syb, syk, syc, st) \
+                                    : launch_agg_fwd_mfma4<14, 2, 2, 2, true, D_>(X, G, Y, B, K, C, N, sxb, sxk, sxc, syb, syk, syc, st)
+                if (d == 7) MGP_AG4_D(7); if (d == 10) MGP_AG4_D(10); MGP_AG4_D(4);
+#undef MGP_AG4_D
+            }
             if (agg_form == 41) MGP_AG4_CASE(14, 2, 2, false); // (A/B: default cache policy)
             if (agg_form == 42) MGP_AG4_CASE(7, 4, 2, true);   // (A/B: eight waves of 7 steps)
             MGP_AG4_CASE(14, 2, 2, true);                      // two column blocks, two row parts of 14 steps

@@ -80,7 +80,11 @@ __device__ __forceinline__ void agg_mfma_unit(const float* __restrict__ Gk, cons
 #ifndef AGG_NT
 #define AGG_NT 1                          // operator loads with the non-temporal hint (read once, never again)
 #endif
-template <int S, int S0, int FH, bool NT = (AGG_NT != 0), class Part>
+// D: requests in flight per lane.  D = S: the whole row part is requested up front.  D < S ([r6], A/B form 44): D requests up front, the
+// request of step s + D behind the products of step s -- a wave's requests are then spread over the launch instead of landing
+// together (the memory system serves them roughly in issue order: the waves that issued last otherwise hold ALL their products at
+// the end of the stream; tools/harness/stream_floor.hip prices that tail at ~1.3 us of 8.8).
+template <int S, int S0, int FH, bool NT = (AGG_NT != 0), int D = S, class Part>
 __device__ __forceinline__ void agg_mfma_rows(const float* __restrict__ Gk, const float* __restrict__ Xk, long sxc, int F,
                                               int N, int lane, f32x4* red, Part part)
 {
@@ -96,12 +100,13 @@ __device__ __forceinline__ void agg_mfma_rows(const float* __restrict__ Gk, cons
             xa[h][t4] = *reinterpret_cast<const f32x4*>(xr + min(16 * (T0 + t4) + 4 * lq, N - 4));
     }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
+    auto request = [&](int s) {
         const f32x4* gp = reinterpret_cast<const f32x4*>(Gk + (size_t)min(16 * ((S0 + s) >> 2) + 4 * lq + ((S0 + s) & 3), N - 1) * N);
         gv[s] = NT ? __builtin_nontemporal_load(gp) : *gp;
         __builtin_amdgcn_sched_barrier(0);
-    }
+    };
+#pragma unroll
+    for (int s = 0; s < (D < S ? D : S); ++s) request(s);
     f32x4 acc[4][FH];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -118,6 +123,7 @@ __device__ __forceinline__ void agg_mfma_rows(const float* __restrict__ Gk, cons
                 acc[t][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, gv[s][t], acc[t][h], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (D < S && s + D < S) request(s + D);
     }
 #pragma unroll
     for (int h = 0; h < FH; ++h) {

@@ -79,6 +79,8 @@ print('$1 x N=$2 K=$3 hidden $4 x $5', 'value %.3e' % d['value'], 'ms/step %.4f'
 for f in 8 4; do MGP_AGG_FORM=$f python tools/gpu/agg_ab.py 2>/dev/null; done > $O/agg_forms.txt
 # [r6] form 43: one workgroup per episode, the three taps in sequence in every wave (a tap's sums and stores under the later taps' flight)
 AGG_SHAPES="256,100,3 512,100,3 1024,100,3 2048,100,3" MGP_AGG_FORM=43 python tools/gpu/agg_ab.py 2>/dev/null | grep agg_fwd >> $O/agg_forms.txt
+# [r6] forms 44 / 45: 7 / 10 of a wave's 14 requests up front at every batch size (the default does that from B K >= 3072 on)
+for f in 44 45; do AGG_SHAPES="256,100,3 512,100,3 1024,100,3 2048,100,3" MGP_AGG_FORM=$f python tools/gpu/agg_ab.py 2>/dev/null | grep agg_fwd >> $O/agg_forms.txt; done
 bash tools/gpu/update_slots_ab.sh > $O/dagger_update_slots.txt 2>&1
 ./scratch/stream_floor > $O/stream_floor.txt 2>&1
 python tools/gpu/train_wall.py 2>/dev/null | tail -1 > $O/train_wall.json
