@@ -643,7 +643,8 @@ def main():
         trace('-')
         out["roofline"], out["kernels"] = roofline_blocks(
             device, B, N, K, hidden, ro.actor, ro.sim._c, 'resident' if resident else ('factored' if factored else 'dense'), args.steps,
-            res_launches=res_launches if resident else None, res_launch_ms=res_launch_ms, el_fact=el_fact)
+            res_launches=res_launches if resident else None, res_launch_ms=res_launch_ms, el_fact=el_fact,
+            factored_persistent=ro.factored_persistent() if factored else None)
         trace('roofline blocks')
     parity = None
     if rank == 0 and not args.no_parity:

@@ -44,7 +44,8 @@ def hbm_block(res, key, kname, pmc_names, B, N, K):
             "algorithmic_bytes_per_launch": r['bytes'], "avg_launch_ms": r['ms'], "sq": sq}
 
 
-def roofline_blocks(device, B, N, K, hidden, actor, flock_c, mode, steps, res_launches=None, res_launch_ms=None, el_fact=None):
+def roofline_blocks(device, B, N, K, hidden, actor, flock_c, mode, steps, res_launches=None, res_launch_ms=None, el_fact=None,
+                    factored_persistent=None):
     """-> (roofline, kernels) for the JSON line.  mode: 'resident' | 'factored' | 'dense' (which path is `value`)."""
     res, n_sets = _k.kernel_rooflines(device, B, N, K, actor, flock_c)
     fused = getattr(actor, 'use_fused', False) and actor.ind_agg == 0
@@ -155,7 +156,8 @@ def roofline_blocks(device, B, N, K, hidden, actor, flock_c, mode, steps, res_la
         req = (sim_b + gather_b + policy_b) * B
         ms_step = 1e3 * el_fact / steps
         trf, trf_note = pmc_traffic_factored(B, N, K)
-        persistent = 'spp_rollout_kernel' in (trf_note or '')
+        # which form ran: the caller's query of the library (mgp_sparse_rollout_persistent); without it, what the PMC file profiled
+        persistent = factored_persistent if factored_persistent is not None else 'spp_rollout_kernel' in (trf_note or '')
         roof = {
             "kernel": ("factored step inside spp_rollout_kernel (one launch of persistent workgroups per call; gather stage, policy "
                        "tail and cell-list simulator as phases behind three sibling exchanges per step)" if persistent else
