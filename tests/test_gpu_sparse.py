@@ -299,3 +299,37 @@ def test_persistent_rollout_gives_up_loudly_when_a_sibling_never_arrives(monkeyp
     sparse_policy_rollout(actor, sim, sp, T)
     sp.check_status()
     assert torch.equal(sim.x, x0)
+
+
+def test_persistent_rollout_under_uneven_load(monkeypatch):
+    """The sibling exchanges of the persistent form (arrival counters, L1-bypassing loads; plain stores where an episode's
+    workgroups share an XCD: B a multiple of 8) with the chip busy on something else: a second stream streams copies through
+    HBM while the rollout runs, so workgroups start late, siblings wait for each other and the caches are anything but cold.
+    Every repetition must reproduce the K-launch form's result of the idle chip bit for bit."""
+    from multiagent_gnn_policies_amd.learner.sparse_rollout import SparseFlockState, sparse_policy_rollout
+    N, K, B, T = 1000, 3, 8, 40
+
+    def run(persist, load):
+        monkeypatch.setenv('MGP_SP_PERSIST', persist)
+        rs, op, actor, sim, st = _make(N, K, (32, 32), B, seed=21)
+        sp = SparseFlockState(sim, K)
+        sp.observe_reset(sim)
+        action = torch.zeros((B, 1, 2, N), device='cuda')
+        rewards = torch.zeros((B, T), device='cuda', dtype=torch.float64)
+        torch.cuda.synchronize()
+        if load:
+            side = torch.cuda.Stream()
+            a = torch.empty((64 << 20,), device='cuda', dtype=torch.float32); b_ = torch.ones_like(a)
+            with torch.cuda.stream(side):
+                for _ in range(60):
+                    a.copy_(b_); b_.add_(a, alpha=0.5)
+        sparse_policy_rollout(actor, sim, sp, T, rewards=rewards, action=action)
+        sp.check_status()
+        torch.cuda.synchronize()
+        return sim.x.clone(), action.clone(), rewards.clone(), sp.feat.clone(), sp.wrow.clone(), sp.bits.clone(), sp.nbr.clone()
+
+    ref = run('0', False)
+    for rep in range(3):
+        got = run('1', True)
+        for a, b_ in zip(ref, got):
+            assert torch.equal(a, b_), "repetition %d differs from the K-launch form" % rep
