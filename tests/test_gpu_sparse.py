@@ -333,3 +333,35 @@ def test_persistent_rollout_under_uneven_load(monkeypatch):
         got = run('1', True)
         for a, b_ in zip(ref, got):
             assert torch.equal(a, b_), "repetition %d differs from the K-launch form" % rep
+
+
+def test_persistent_rollout_is_graph_capturable(monkeypatch):
+    """mgp_sparse_rollout's persistent form inside a HIP graph (the counters' memset is a node of its own): captured once,
+    replayed twice = two eager calls, bit for bit (T a multiple of 6: the ring slots and the x ping-pong are back in place,
+    so the captured pointers describe every replay)."""
+    from multiagent_gnn_policies_amd import ops
+    from multiagent_gnn_policies_amd.learner.sparse_rollout import SparseFlockState, sparse_policy_rollout
+    monkeypatch.setenv('MGP_SP_PERSIST', '1')
+    N, K, B, T = 1000, 3, 8, 6
+    outs = []
+    for mode in ('eager', 'graph'):
+        rs, op, actor, sim, st = _make(N, K, (32, 32), B, seed=3)
+        sp = SparseFlockState(sim, K)
+        sp.observe_reset(sim)
+        action = torch.zeros((B, 1, 2, N), device='cuda')
+        if mode == 'eager':
+            sparse_policy_rollout(actor, sim, sp, T, action=action)
+            sparse_policy_rollout(actor, sim, sp, T, action=action)
+        else:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            slots = (sp.cur, sp.hs)
+            with ops.graph_capture(g):
+                sparse_policy_rollout(actor, sim, sp, T, action=action)
+            assert (sp.cur, sp.hs) == slots
+            g.replay()
+            g.replay()
+        sp.check_status()
+        outs.append((sim.x.clone(), action.clone(), sp.feat.clone(), sp.wrow.clone(), sp.bits.clone()))
+    for a, b_ in zip(*outs):
+        assert torch.equal(a, b_)
