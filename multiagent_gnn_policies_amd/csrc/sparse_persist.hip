@@ -199,8 +199,11 @@ void spp_rollout_kernel(PpArgs A)
     const int N = A.N, NW = A.NW, Np = (N + 3) & ~3, N4 = Np, wt4 = (A.wtot + 3) & ~3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = (N + PP_ROWS - 1) / PP_ROWS;
+    // rows / columns of a tile: the episode's N dealt evenly over its workgroups in whole 16-column MFMA tiles (N = 300: 2 x 160
+    // instead of 256 + 44; N = 520: 3 x 176 instead of 256 + 256 + 8): a step lasts as long as its slowest tile
+    const int rpt = min(PP_ROWS, (((N + tiles - 1) / tiles) + 15) & ~15);
     const int ep = (int)(blockIdx.x % (unsigned int)A.Bc), tile = (int)(blockIdx.x / (unsigned int)A.Bc), b = A.b0 + ep;
-    const int i0 = tile * PP_ROWS;
+    const int i0 = tile * rpt;
     const int K = PP_K, H = 2;
     // ---- LDS plan
     float* ring = ppm;                                                           // [2][N][6]
@@ -230,7 +233,7 @@ void spp_rollout_kernel(PpArgs A)
     const MgpFlockParams& p = A.p;
     const int wpl = NW >> 2;                                   // words of a bit row per lane of its quad (NW is a multiple of 8)
     const int gc = tid >> 2, part = tid & 3, gn = i0 + gc;     // column / row of this quad
-    const bool live = gn < N;
+    const bool live = gc < rpt && gn < N;
     const bool in = tid < N;                                   // this thread's agent (the same in every workgroup of the episode)
 #ifdef MGP_SP_PROFILE
     bool stamp_on = false;
@@ -258,7 +261,7 @@ void spp_rollout_kernel(PpArgs A)
         if (tid < 2 * PP_ROWS) {                               // 256 rows x 32 bytes
             const int r = tid >> 1, hf = tid & 1;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (i0 + r < N) v = *reinterpret_cast<const uint4*>(nbr_b + ((size_t)hq * N + i0 + r) * 16 + 8 * hf);
+            if (r < rpt && i0 + r < N) v = *reinterpret_cast<const uint4*>(nbr_b + ((size_t)hq * N + i0 + r) * 16 + 8 * hf);
             *reinterpret_cast<uint4*>(lists + ((size_t)t * PP_ROWS + r) * 16 + 8 * hf) = v;
         }
     }
@@ -332,7 +335,7 @@ void spp_rollout_kernel(PpArgs A)
         PP_STAMP(3);
         for (int i = tid; i < 3 * N; i += PP_THREADS) {         // the siblings' rows of tap 2's running product
             const int m = i / 3, h2 = 2 * (i - 3 * m);
-            if (m < i0 || m >= i0 + PP_ROWS) *reinterpret_cast<float2*>(vst + m * 6 + h2) = pp_ld2(vbuf_b + (size_t)m * 8 + h2);
+            if (m < i0 || m >= i0 + rpt) *reinterpret_cast<float2*>(vst + m * 6 + h2) = pp_ld2(vbuf_b + (size_t)m * 8 + h2);
         }
         __syncthreads();
         PP_STAMP(4);
@@ -342,7 +345,7 @@ void spp_rollout_kernel(PpArgs A)
             const float* xt = ring + (size_t)(rs1 ^ 1) * N * 6;
             for (int i = tid; i < PP_ROWS * 6; i += PP_THREADS) {
                 const int c = i / 6, f = i - 6 * c;
-                if (i0 + c < N) act[c * RO_CS + rpos(f * K + 0)] = xt[(size_t)(i0 + c) * 6 + f];
+                if (c < rpt && i0 + c < N) act[c * RO_CS + rpos(f * K + 0)] = xt[(size_t)(i0 + c) * 6 + f];
             }
             if (collecting) {
                 // DAGGER collection (gnn_dagger.py:154-178; spl_policy_kernel<CL>): the frame of the state the step starts from
@@ -352,7 +355,7 @@ void spp_rollout_kernel(PpArgs A)
                 const double bq = floor((double)A.col.beta[b] * 4294967296.0);            // P(expert drives) in units of 2^-32
                 const unsigned long long thr = bq <= 0.0 ? 0ull : (bq >= 4294967296.0 ? 4294967296ull : (unsigned long long)bq);
                 expert_drives = (unsigned long long)dagger_coin(A.col.seed, A.col.episode[b], (unsigned int)age_now) < thr;
-                const int cols = min(PP_ROWS, N - i0);
+                const int cols = max(0, min(rpt, N - i0));
                 float* ff = A.col.feat + fr * 6 * N;
                 for (int i = tid; i < 6 * PP_ROWS; i += PP_THREADS) {
                     const int f = i >> 8, c = i & 255;
@@ -382,7 +385,7 @@ void spp_rollout_kernel(PpArgs A)
         }
         __syncthreads();
         PP_STAMP(5);
-        if (i0 + wave * 16 < N) {                               // whole waves: wave w owns columns 16 w .. 16 w + 15
+        if (wave * 16 < rpt && i0 + wave * 16 < N) {            // whole waves: wave w owns columns 16 w .. 16 w + 15
             const int li = lane & 15, lq = lane >> 4;
             float* pcol = act + (wave * 16 + li) * RO_CS;
             for (int l = 0; l < A.n_layers - 1; ++l) {
@@ -679,13 +682,13 @@ void spp_rollout_kernel(PpArgs A)
         alive = pp_wait(ctr + 2, target, err, &s_dead, timeout);
         if (!alive) break;
         PP_STAMP(12);
-        if (in && (tid < i0 || tid >= i0 + PP_ROWS))             // the siblings' row weights of A_{t+1}
+        if (in && (tid < i0 || tid >= i0 + rpt))                 // the siblings' row weights of A_{t+1}
             lwr[(ws ^ 1) * Np + tid] = pp_ld1(wrow_b + (size_t)nh * N + tid);
         cur = nc; hs = nh; ws ^= 1; rs1 ^= 1;
         PP_STAMP(13);
     }
     // ---- exit: the state of the own rows; a dead episode poisons what its caller will read
-    if (in && tid >= i0 && tid < i0 + PP_ROWS) {
+    if (in && tid >= i0 && tid < i0 + rpt) {
         double* xr = A.x_out + ((size_t)b * N + tid) * 4;
         if (!alive) px = py = vx = vy = __builtin_nan("");
         *reinterpret_cast<double2*>(xr) = make_double2(px, py);
