@@ -536,14 +536,16 @@ int  mgp_sparse_rollout(unsigned long long* bits, float* wrow, float* feat, cons
  * neighbour lists (policy rollouts and DAGGER collection alike), the T steps run as ONE launch of workgroups that stay resident, keep the episode's feature
  * rows / row weights / own list rows in LDS and hand each other only what a sibling lacks (write-through stores, one arrival
  * counter per exchange) through the same state buffers: every output is bit-identical to the K-launch form; bit rows, list
- * rows and x are written for the networks / the state that outlive the call.  A launch holds (CUs / ceil(N/256)) episodes
+ * rows and x are written for the networks / the state that outlive the call.  A launch holds (CUs / workgroups per episode) episodes
  * (more: further launches); a workgroup whose siblings do not arrive within 3 s (CUs held by another process) gives up: the
  * episode's action / state / rewards are NaN and mgp_sparse_rollout_status -- which synchronises `stream` -- returns
  * MGP_ELAUNCH (MGP_OK otherwise; meaningful after a call that ran the persistent form).  The persistent form uses
  * scratch[0 .. B N 8) and B * 16 words behind it.  Environment: MGP_SP_PERSIST=0 keeps the K-launch form;
  * MGP_SP_PERSIST_TIMEOUT_MS (default 3000) bounds every wait; MGP_SP_PERSIST_NEAR=0 keeps write-through stores in the sibling
  * exchanges even where an episode's workgroups found themselves on one XCD (default: plain stores there, served by that XCD's
- * L2 -- same bits, ~4 % faster); MGP_SP_PERSIST_FAULT=<episode> is a test hook (that episode's second workgroup stops arriving). */
+ * L2 -- same bits, ~4 % faster); MGP_SP_PERSIST_TILES=<n> forces the workgroups per episode (default: ceil(N / 256), more when
+ * the call has fewer episodes than the device CUs); MGP_SP_PERSIST_FAULT=<episode> is a test hook (that episode's second
+ * workgroup stops arriving). */
 int  mgp_sparse_rollout_persistent(const int* dims, int n_layers, int K, int N, const MgpFlockParams* p);
 int  mgp_sparse_rollout_status(const float* scratch, int B, int K, int N, void* stream);
 /* nbr (B,H,N,16) u16 or NULL: the networks of the bit-row ring once more as compact neighbour LISTS, kept in step with it by

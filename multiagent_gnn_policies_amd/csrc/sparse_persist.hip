@@ -62,6 +62,7 @@ struct PpArgs {
     float* expert;                 // (B,N,2) or NULL
     unsigned int* ctrl;            // [B][16]: arrival counters 0..2, error word 3
     int B, N, NW, T, cur, hs, b0, Bc, n_layers;
+    int tiles;                     // workgroups per episode: ceil(N / 256) at least; more when the call has fewer episodes than the device CUs
     MgpSparseCollect col;          // DAGGER collection (col.feat != NULL): frames of the FIRST step's ring_step / age_now onwards
     int allow_near;                // 0: always the write-through exchange (MGP_SP_PERSIST_NEAR=0)
     int timeout_ms;                // a poll gives up after this long (MGP_SP_PERSIST_TIMEOUT_MS, default 3000)
@@ -198,7 +199,7 @@ void spp_rollout_kernel(PpArgs A)
     __shared__ int s_near;
     const int N = A.N, NW = A.NW, Np = (N + 3) & ~3, N4 = Np, wt4 = (A.wtot + 3) & ~3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles = (N + PP_ROWS - 1) / PP_ROWS;
+    const int tiles = A.tiles;
     // rows / columns of a tile: the episode's N dealt evenly over its workgroups in whole 16-column MFMA tiles (N = 300: 2 x 160
     // instead of 256 + 44; N = 520: 3 x 176 instead of 256 + 256 + 8): a step lasts as long as its slowest tile
     const int rpt = min(PP_ROWS, (((N + tiles - 1) / tiles) + 15) & ~15);
@@ -753,10 +754,25 @@ int spp_rollout(unsigned long long* bits, float* wrow, float* feat, const float*
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return MGP_ENODEV;
         cus = v; cus_dev = dev;
     }
-    const int tiles = mgp_ceil_div(N, PP_ROWS);
+    // workgroups per episode: ceil(N / 256) at least -- and as many more as the device has CUs for when the call is short of
+    // episodes (8 x 1000: 32 tiles of 32 rows instead of 4 of 250 on 32 of 256 CUs): the row search, the gathers and the MLP
+    // shrink with the rows of a tile, the per-workgroup set-up (integration, cell list) does not
+    int tiles = mgp_ceil_div(N, PP_ROWS);
+    if (tiles > cus) return MGP_EUNSUPPORTED;
+    {
+        const int most = mgp_ceil_div(N, 16);                   // one 16-column MFMA tile per workgroup at the very least
+        int want = cus / (B < 1 ? 1 : B);
+        const char* tl = getenv("MGP_SP_PERSIST_TILES");        // (A/B and tests: forces the tile count where valid)
+        if (tl != nullptr && atoi(tl) > 0) want = atoi(tl);
+        if (want > most) want = most;
+        if (want > cus) want = cus;
+        if (want > tiles) tiles = want;
+        const int rpt = ((mgp_ceil_div(N, tiles) + 15) & ~15) < PP_ROWS ? ((mgp_ceil_div(N, tiles) + 15) & ~15) : PP_ROWS;
+        tiles = mgp_ceil_div(N, rpt);                           // (no tile without rows: the kernel derives the same rpt from this count)
+    }
     int bc_max = cus / tiles;                                   // one workgroup per CU: the episodes that can be resident together
     if (bc_max < 1) return MGP_EUNSUPPORTED;
-    if (bc_max >= 8) bc_max &= ~7;                              // whole XCD rounds: an episode's tiles share an L2
+    if (bc_max >= 8 && B > bc_max) bc_max &= ~7;                // several launches: whole XCD rounds, an episode's tiles share an L2
     MGP_CHECK_PTR8(bits); MGP_CHECK_PTR(wrow); MGP_CHECK_PTR(feat); MGP_CHECK_PTR(image); MGP_CHECK_PTR(action);
     MGP_CHECK_PTR(scratch); MGP_CHECK_PTR8(x_a); MGP_CHECK_PTR8(x_b);
     if (!mgp_aligned16(feat) || !mgp_aligned16(image) || !mgp_aligned16(scratch) || !mgp_aligned16(x_a) || !mgp_aligned16(x_b)
@@ -772,7 +788,7 @@ int spp_rollout(unsigned long long* bits, float* wrow, float* feat, const float*
     A.action = action;
     A.x_in = x_a; A.x_out = (T & 1) ? x_b : x_a;
     A.rewards = rewards; A.expert = expert;
-    A.B = B; A.N = N; A.NW = NW; A.T = T; A.cur = cur; A.hs = hs; A.n_layers = n_layers;
+    A.B = B; A.N = N; A.NW = NW; A.T = T; A.cur = cur; A.hs = hs; A.n_layers = n_layers; A.tiles = tiles;
     for (int l = 0; l <= n_layers; ++l) A.dimsA |= (unsigned long long)(dims[l] & 255) << (8 * l);
     for (int l = 0; l < n_layers; ++l) A.woffA |= (unsigned long long)woff[l] << (16 * l);
     A.p = *p;

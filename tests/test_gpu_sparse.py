@@ -365,3 +365,27 @@ def test_persistent_rollout_is_graph_capturable(monkeypatch):
         outs.append((sim.x.clone(), action.clone(), sp.feat.clone(), sp.wrow.clone(), sp.bits.clone()))
     for a, b_ in zip(*outs):
         assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize('N,B,tiles', [(1000, 2, 4), (1000, 3, 9), (300, 3, 2), (700, 2, 44)])
+def test_persistent_rollout_tile_counts(N, B, tiles, monkeypatch):
+    """How many workgroups share an episode is a launch decision (ceil(N / 256) at least, more when the call has fewer episodes
+    than the device CUs; rows dealt evenly in whole 16-column tiles): every count gives the K-launch form's bits.  The
+    small-batch cases of the other tests run on many small tiles; here the count is forced, 4 x 250 rows at N = 1000 (the
+    layout of BASELINE configs[2]: 64 episodes on 256 CUs) included."""
+    from multiagent_gnn_policies_amd.learner.sparse_rollout import SparseFlockState, sparse_policy_rollout
+    K, T = 3, 5
+    outs = []
+    for persist in ('0', '1'):
+        monkeypatch.setenv('MGP_SP_PERSIST', persist)
+        monkeypatch.setenv('MGP_SP_PERSIST_TILES', str(tiles))
+        rs, op, actor, sim, st = _make(N, K, (32, 32), B, seed=N + tiles)
+        sp = SparseFlockState(sim, K)
+        sp.observe_reset(sim)
+        action = torch.zeros((B, 1, 2, N), device='cuda')
+        rewards = torch.zeros((B, T), device='cuda', dtype=torch.float64)
+        sparse_policy_rollout(actor, sim, sp, T, rewards=rewards, action=action)
+        sp.check_status()
+        outs.append((sim.x.clone(), action.clone(), rewards.clone(), sp.feat.clone(), sp.wrow.clone(), sp.bits.clone(), sp.nbr.clone()))
+    for a, b_ in zip(*outs):
+        assert torch.equal(a, b_)
